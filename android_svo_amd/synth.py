@@ -1,0 +1,230 @@
+"""Deterministic synthetic inputs for the SVO hot path.
+
+A textured plane is rendered analytically for a reference pose and a current
+pose; pyramids use the truncating 2x2 mean (the arm64 / scalar form of
+vk::halfSample, reference vision.cpp:89-110) and are treated as *inputs* by
+every consumer (oracle, HIP path, reference harness), so the SSE2/NEON rounding
+split of the reference never enters a comparison.
+
+Everything here is numpy on the host; nothing is timed.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import List, Tuple
+
+import numpy as np
+
+N_LEVELS = 5
+
+
+@dataclasses.dataclass
+class Camera:
+    width: int
+    height: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+
+    @staticmethod
+    def default(width: int = 640, height: int = 480) -> "Camera":
+        f = 500.0 if width <= 640 else 1000.0
+        return Camera(width, height, f, f, width / 2 - 0.5, height / 2 - 0.5)
+
+
+# ---- SE3 helpers in the reference's storage order [t(3), q(xyzw)] ---------------
+
+def quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by + ay * bw + az * bx - ax * bz,
+        aw * bz + az * bw + ax * by - ay * bx,
+        aw * bw - ax * bx - ay * by - az * bz])
+
+
+def quat_rot(q, p):
+    qv = np.asarray(q[:3])
+    uv = 2.0 * np.cross(qv, p)
+    return p + q[3] * uv + np.cross(qv, uv)
+
+
+def se3_from_twist(t, w):
+    """Pose with translation t and rotation exp(w) (plain axis-angle; generator only)."""
+    w = np.asarray(w, dtype=np.float64)
+    th = float(np.linalg.norm(w))
+    if th < 1e-12:
+        q = np.array([0.0, 0.0, 0.0, 1.0])
+    else:
+        q = np.concatenate([math.sin(th / 2) * w / th, [math.cos(th / 2)]])
+    return np.concatenate([np.asarray(t, dtype=np.float64), q])
+
+
+def se3_inv(T):
+    qi = np.array([-T[3], -T[4], -T[5], T[6]])
+    return np.concatenate([-quat_rot(qi, T[:3]), qi])
+
+
+def se3_mul(A, B):
+    return np.concatenate([A[:3] + quat_rot(A[3:], B[:3]), quat_mul(A[3:], B[3:])])
+
+
+def se3_act(T, p):
+    return T[:3] + quat_rot(T[3:], p)
+
+
+def rot_matrix(q):
+    x, y, z, w = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def pose_error(Ta, Tb) -> Tuple[float, float]:
+    """(rotation error rad, translation error m) of E = Ta * Tb^-1."""
+    E = se3_mul(np.asarray(Ta, dtype=np.float64), se3_inv(np.asarray(Tb, dtype=np.float64)))
+    n = float(np.linalg.norm(E[3:6]))
+    w = float(E[6])
+    ang = 2.0 * math.atan2(n, abs(w))
+    return ang, float(np.linalg.norm(E[:3]))
+
+
+# ---- scene ------------------------------------------------------------------------
+
+class PlaneScene:
+    """Plane n.X = d in the world frame with a band-limited texture."""
+
+    def __init__(self, seed: int = 12345, depth: float = 2.0, tilt=(0.08, -0.05)):
+        rng = np.random.default_rng(seed)
+        n = np.array([tilt[0], tilt[1], 1.0])
+        self.n = n / np.linalg.norm(n)
+        self.d = depth * self.n[2]
+        # in-plane basis
+        e1 = np.cross([0.0, 1.0, 0.0], self.n)
+        self.e1 = e1 / np.linalg.norm(e1)
+        self.e2 = np.cross(self.n, self.e1)
+        k = 6
+        self.freq = rng.uniform(4.0, 28.0, size=(k, 2)) * rng.choice([-1.0, 1.0], size=(k, 2))
+        self.phase = rng.uniform(0, 2 * math.pi, size=k)
+        self.amp = rng.uniform(0.5, 1.0, size=k)
+        self.grid = rng.uniform(-1.0, 1.0, size=(96, 96))
+        self.grid_scale = 18.0  # cells per metre
+
+    def texture(self, s, t):
+        val = np.zeros_like(s)
+        for (fa, fb), ph, am in zip(self.freq, self.phase, self.amp):
+            val += am * np.sin(fa * s + fb * t + ph)
+        gs = (s * self.grid_scale) % 95.0
+        gt = (t * self.grid_scale) % 95.0
+        i0 = np.floor(gs).astype(np.int64)
+        j0 = np.floor(gt).astype(np.int64)
+        a = gs - i0
+        b = gt - j0
+        g = self.grid
+        noise = ((1 - a) * (1 - b) * g[j0, i0] + a * (1 - b) * g[j0, i0 + 1]
+                 + (1 - a) * b * g[j0 + 1, i0] + a * b * g[j0 + 1, i0 + 1])
+        val = val / np.sum(self.amp) * 0.55 + noise * 0.45
+        return val
+
+    def intersect(self, cam: Camera, T_f_w, u, v):
+        """World points hit by pixel rays (u, v) of a camera at pose T_f_w."""
+        T_w_f = se3_inv(np.asarray(T_f_w, dtype=np.float64))
+        R = rot_matrix(T_w_f[3:])
+        o = T_w_f[:3]
+        x = (u - cam.cx) / cam.fx
+        y = (v - cam.cy) / cam.fy
+        dirs = np.stack([x, y, np.ones_like(x)], axis=-1) @ R.T
+        lam = (self.d - o @ self.n) / (dirs @ self.n)
+        return o + dirs * lam[..., None]
+
+    def render(self, cam: Camera, T_f_w) -> np.ndarray:
+        v, u = np.mgrid[0:cam.height, 0:cam.width].astype(np.float64)
+        X = self.intersect(cam, T_f_w, u, v)
+        s = X @ self.e1
+        t = X @ self.e2
+        val = self.texture(s, t)
+        img = np.clip(np.rint(127.5 + 110.0 * val), 0, 255).astype(np.uint8)
+        return np.ascontiguousarray(img)
+
+
+def half_sample(img: np.ndarray) -> np.ndarray:
+    h, w = img.shape
+    a = img[0:h - h % 2:2, 0:w - w % 2:2].astype(np.uint16)
+    b = img[0:h - h % 2:2, 1:w:2].astype(np.uint16)
+    c = img[1:h:2, 0:w - w % 2:2].astype(np.uint16)
+    d = img[1:h:2, 1:w:2].astype(np.uint16)
+    return np.ascontiguousarray(((a + b + c + d) // 4).astype(np.uint8))
+
+
+def build_pyramid(img: np.ndarray, n_levels: int = N_LEVELS) -> List[np.ndarray]:
+    pyr = [np.ascontiguousarray(img)]
+    for _ in range(1, n_levels):
+        pyr.append(half_sample(pyr[-1]))
+    return pyr
+
+
+def cam2world(cam: Camera, px: np.ndarray) -> np.ndarray:
+    x = (px[:, 0] - cam.cx) / cam.fx
+    y = (px[:, 1] - cam.cy) / cam.fy
+    z = np.ones_like(x)
+    n = np.sqrt(x * x + y * y + z * z)
+    return np.stack([x / n, y / n, z / n], axis=1)
+
+
+@dataclasses.dataclass
+class FramePair:
+    cam: Camera
+    ref_pyr: List[np.ndarray]
+    cur_pyr: List[np.ndarray]
+    px: np.ndarray          # [n,2] f64 level-0 pixel
+    f: np.ndarray           # [n,3] f64 unit bearing
+    pos: np.ndarray         # [n,3] f64 world point
+    has_point: np.ndarray   # [n] u8
+    T_ref_w: np.ndarray     # [7]
+    T_cur_w_true: np.ndarray
+    T_cur_w_init: np.ndarray
+
+
+def grid_features(cam: Camera, n_target: int, rng, border: int = 48) -> np.ndarray:
+    w = cam.width - 2 * border
+    h = cam.height - 2 * border
+    step = math.sqrt(w * h / float(n_target))
+    nx = max(1, int(math.ceil(w / step)))
+    ny = max(1, int(math.ceil(n_target / nx)))
+    while nx * ny < n_target:
+        ny += 1
+    xs = border + (np.arange(nx) + 0.0) * (w - 1.0) / max(nx, 1)
+    ys = border + (np.arange(ny) + 0.0) * (h - 1.0) / max(ny, 1)
+    gx, gy = np.meshgrid(xs, ys)
+    px = np.stack([gx.ravel(), gy.ravel()], axis=1)[:n_target]
+    px = np.floor(px) + rng.uniform(0.0, 1.0, size=px.shape)
+    return np.ascontiguousarray(px)
+
+
+def make_frame_pair(seed: int = 12345, width: int = 640, height: int = 480, n_features: int = 200,
+                    depth: float = 2.0, null_point_every: int = 0,
+                    t_mag: float = 0.03, r_mag: float = 0.01) -> FramePair:
+    rng = np.random.default_rng(seed)
+    cam = Camera.default(width, height)
+    scene = PlaneScene(seed=seed, depth=depth,
+                       tilt=(rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1)))
+    T_ref_w = se3_from_twist(rng.uniform(-0.05, 0.05, 3), rng.uniform(-0.02, 0.02, 3))
+    xi_t = rng.uniform(-t_mag, t_mag, 3)
+    xi_r = rng.uniform(-r_mag, r_mag, 3)
+    xi_r[np.abs(xi_r) < 1e-4] = 1e-3          # non-zero rotation
+    T_cur_ref = se3_from_twist(xi_t, xi_r)
+    T_cur_w = se3_mul(T_cur_ref, T_ref_w)
+    ref_img = scene.render(cam, T_ref_w)
+    cur_img = scene.render(cam, T_cur_w)
+    px = grid_features(cam, n_features, rng)
+    f = cam2world(cam, px)
+    pos = scene.intersect(cam, T_ref_w, px[:, 0], px[:, 1])
+    has_point = np.ones(len(px), dtype=np.uint8)
+    if null_point_every:
+        has_point[::null_point_every] = 0
+    return FramePair(cam, build_pyramid(ref_img), build_pyramid(cur_img), px, np.ascontiguousarray(f),
+                     np.ascontiguousarray(pos), has_point, T_ref_w, T_cur_w, T_ref_w.copy())

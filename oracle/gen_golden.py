@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own code (oracle/_ref/libsvo_ref.so).
+
+Run only where /root/reference is mounted:   make -C oracle ref && python oracle/gen_golden.py
+The fixtures hold inputs and the reference's outputs (data only, no reference text).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from android_svo_amd import synth  # noqa: E402
+from oracle.ref import refpy  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def crc(a: np.ndarray) -> int:
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def rand_pose(rng, t=0.5, r=0.5):
+    return synth.se3_from_twist(rng.uniform(-t, t, 3), rng.uniform(-r, r, 3))
+
+
+def gen_se3(rng):
+    n = 64
+    A = np.stack([rand_pose(rng) for _ in range(n)])
+    B = np.stack([rand_pose(rng, 2.0, 3.0) for _ in range(n)])
+    p = rng.uniform(-3, 3, (n, 3))
+    tw = rng.uniform(-0.3, 0.3, (n, 6))
+    tw[0, 3:] = [1e-12, -2e-12, 1e-12]      # small-angle branch of the rotation part
+    tw[1, 3:] = 0.0                          # theta == 0: NaN translation quirk
+    tw[2] *= 1e-7
+    q = B[:, 3:].copy()
+    q[3] = [0, 0, 0, 1.0]                    # n < NEAR_ZERO branch of SO3::log
+    q[4] = [0.6, 0.0, 0.8, 1e-12]            # |w| < NEAR_ZERO branch
+    np.savez_compressed(
+        os.path.join(OUT, "se3.npz"), A=A, B=B, p=p, tw=tw, q=q,
+        mul=np.stack([refpy.se3_mul(a, b) for a, b in zip(A, B)]),
+        inv=np.stack([refpy.se3_inverse(a) for a in A]),
+        act=np.stack([refpy.se3_act(a, x) for a, x in zip(A, p)]),
+        exp=np.stack([refpy.se3_exp(x) for x in tw]),
+        log=np.stack([refpy.so3_log(x) for x in q]),
+        rot=np.stack([refpy.rotation_matrix(a) for a in A]))
+
+
+def gen_algebra(rng):
+    n = 64
+    xyz = rng.uniform(-1, 1, (n, 3)) + [0, 0, 2.5]
+    J = np.stack([refpy.jacobian_xyz2uv(x) for x in xyz])
+    Hs, bs = [], []
+    for i in range(48):
+        M = rng.normal(size=(40, 6)) * rng.uniform(0.1, 100, 6)
+        H = M.T @ M
+        if i % 8 == 7:
+            H[:, 5] = 0; H[5, :] = 0          # rank deficient (pseudo-inverse branch)
+        if i == 40:
+            H[:] = 0                          # all-zero matrix
+        Hs.append(H.reshape(36)); bs.append(rng.normal(size=6) * 100)
+    Hs, bs = np.stack(Hs), np.stack(bs)
+    x = np.stack([refpy.ldlt6_solve(h, b) for h, b in zip(Hs, bs)])
+    np.savez_compressed(os.path.join(OUT, "algebra.npz"), xyz=xyz, J=J, H=Hs, b=bs, x=x)
+
+
+def gen_gn(rng):
+    """Reference NLLSSolver/Eigen/SE3 driving the restated residual body."""
+    fp = synth.make_frame_pair(seed=777, width=320, height=240, n_features=120, null_point_every=7,
+                               t_mag=0.015, r_mag=0.006)
+    d = refpy.driven_sparse_align(fp)
+    d2 = refpy.driven_sparse_align(fp, max_level=4, min_level=2)
+    save = dict(width=320, height=240, px=fp.px, f=fp.f, pos=fp.pos, has_point=fp.has_point,
+                T_ref_w=fp.T_ref_w, T_cur_w_init=fp.T_cur_w_init, T_cur_w_true=fp.T_cur_w_true,
+                cam=np.array([fp.cam.fx, fp.cam.fy, fp.cam.cx, fp.cam.cy]),
+                T_out=d["T_cur_w"], n_tracked=d["n_tracked"], chi2=d["chi2"], iters=d["iters"], H=d["H"],
+                T_out_l2=d2["T_cur_w"], n_tracked_l2=d2["n_tracked"], chi2_l2=d2["chi2"], iters_l2=d2["iters"])
+    for l in range(5):
+        save["ref%d" % l] = fp.ref_pyr[l]
+        save["cur%d" % l] = fp.cur_pyr[l]
+    np.savez_compressed(os.path.join(OUT, "gn_small.npz"), **save)
+    # full-size cases by generator seed; image checksums guard against generator drift
+    cases = []
+    for seed, n in ((12345, 200), (12346, 2000), (12347, 1200)):
+        fp = synth.make_frame_pair(seed=seed, n_features=n)
+        d = refpy.driven_sparse_align(fp)
+        d2 = refpy.driven_sparse_align(fp, max_level=4, min_level=2)
+        cases.append(dict(seed=seed, n=n, crc_ref=crc(fp.ref_pyr[0]), crc_cur=crc(fp.cur_pyr[0]),
+                          crc_px=crc(fp.px), T_out=d["T_cur_w"], n_tracked=d["n_tracked"], chi2=d["chi2"],
+                          iters=d["iters"], T_out_l2=d2["T_cur_w"], iters_l2=d2["iters"],
+                          T_true=fp.T_cur_w_true))
+    np.savez_compressed(os.path.join(OUT, "gn_full.npz"),
+                        **{k: np.array([c[k] for c in cases]) for k in cases[0]})
+
+
+def small_scene(seed=4242, w=160, h=120):
+    cam = synth.Camera(w, h, 125.0, 125.0, w / 2 - 0.5, h / 2 - 0.5)
+    scene = synth.PlaneScene(seed=seed, depth=2.0)
+    T0 = synth.se3_from_twist([0, 0, 0], [0, 0, 0])
+    T1 = synth.se3_from_twist([0.06, -0.02, 0.01], [0.004, -0.006, 0.01])
+    return cam, scene, T0, T1, scene.render(cam, T0), scene.render(cam, T1)
+
+
+def gen_align(rng):
+    cam, scene, T0, T1, ref, cur = small_scene()
+    n = 256
+    pwb = np.zeros((n, 100), dtype=np.uint8)
+    patch = np.zeros((n, 64), dtype=np.uint8)
+    px_in = np.zeros((n, 2))
+    n_iter = np.full(n, 10, dtype=np.int32)
+    for i in range(n):
+        cx, cy = rng.integers(8, cam.width - 8), rng.integers(8, cam.height - 8)
+        pwb[i] = ref[cy - 5:cy + 5, cx - 5:cx + 5].reshape(100)
+        patch[i] = refpy.patch_from_border(pwb[i])
+        # the same world point seen in `cur`, perturbed
+        X = scene.intersect(cam, T0, np.array([float(cx)]), np.array([float(cy)]))[0]
+        Xc = synth.se3_act(T1, X)
+        px_in[i] = [cam.fx * Xc[0] / Xc[2] + cam.cx, cam.fy * Xc[1] / Xc[2] + cam.cy]
+        px_in[i] += rng.uniform(-2, 2, 2)
+    px_in[0] = [3.2, 40.0]                       # left border -> break before first iteration
+    px_in[1] = [cam.width - 4.5, 60.0]           # right border
+    px_in[2] = [80.3, cam.height - 3.9]          # bottom border
+    pwb[3] = 128                                  # flat template: singular H -> inf/NaN path
+    patch[3] = 128
+    n_iter[4] = 1; n_iter[5] = 0; n_iter[6] = 3
+    pwb[7] = rng.integers(0, 256, 100)            # noise template (diverges / leaves image)
+    patch[7] = refpy.patch_from_border(pwb[7])
+    ok = np.zeros(n, dtype=np.uint8)
+    px_out = np.zeros((n, 2))
+    for i in range(n):
+        o, p = refpy.align2d(cur, pwb[i], patch[i], int(n_iter[i]), px_in[i])
+        ok[i] = o; px_out[i] = p
+    # align1D
+    dirs = rng.normal(size=(n, 2)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    ok1 = np.zeros(n, dtype=np.uint8)
+    px_out1 = np.zeros((n, 2))
+    hinv = np.zeros(n)
+    for i in range(n):
+        o, p, h = refpy.align1d(cur, dirs[i], pwb[i], patch[i], int(n_iter[i]), px_in[i])
+        ok1[i] = o; px_out1[i] = p; hinv[i] = h
+    np.savez_compressed(os.path.join(OUT, "align.npz"), cur=cur, pwb=pwb, patch=patch, px_in=px_in,
+                        n_iter=n_iter, ok=ok, px_out=px_out, dirs=dirs, ok1=ok1, px_out1=px_out1, hinv=hinv)
+
+
+def gen_matcher(rng):
+    cam, scene, T0, T1, ref, cur = small_scene()
+    n = 256
+    # ZMSSD
+    zp = rng.integers(0, 256, (n, 64)).astype(np.uint8)
+    zp[:64] = np.stack([cur[y:y + 8, x:x + 8].reshape(64) for x, y in
+                        zip(rng.integers(0, 150, 64), rng.integers(0, 110, 64))])
+    zxy = np.stack([rng.integers(0, cam.width - 8, n), rng.integers(0, cam.height - 8, n)], axis=1)
+    zxy[0] = [0, 0]
+    zp[1] = 255; zp[2] = 0
+    zs = np.array([refpy.zmssd(zp[i], cur, int(zxy[i, 0]), int(zxy[i, 1])) for i in range(n)], dtype=np.int64)
+    # warp matrix / search level / warpAffine / triangulation / cam2world
+    px_ref = np.stack([rng.uniform(12, cam.width - 12, n), rng.uniform(12, cam.height - 12, n)], axis=1)
+    level_ref = rng.integers(0, 3, n).astype(np.int32)
+    f_ref = np.stack([refpy.cam2world(cam, u, v) for u, v in px_ref])
+    depth = rng.uniform(0.8, 4.0, n)
+    T_cur_ref = np.stack([synth.se3_from_twist(rng.uniform(-0.3, 0.3, 3), rng.uniform(-0.15, 0.15, 3))
+                          for _ in range(n)])
+    T_cur_ref[:16, 2] += rng.uniform(0.5, 1.5, 16)   # forward motion: det(A) > 3 -> search level > 0
+    T_cur_ref[16] = synth.se3_from_twist([0, 0, 0], [0, 0, 0])
+    A = np.stack([refpy.get_warp_matrix_affine(cam, px_ref[i], f_ref[i], depth[i], T_cur_ref[i], int(level_ref[i]))
+                  for i in range(n)])
+    A[17] = 0.0                                      # zero matrix -> NaN inverse -> patch untouched (sentinel 7)
+    # (a singular non-zero A gives an inf inverse, NaN sample coordinates and an out-of-bounds
+    #  read in the reference: undefined behaviour, not a fixture)
+    best = np.array([refpy.get_best_search_level(A[i], 2) for i in range(n)], dtype=np.int32)
+    ref_pyr = synth.build_pyramid(ref, 3)
+    patches = np.stack([refpy.warp_affine(A[i], ref_pyr[level_ref[i]], px_ref[i], int(level_ref[i]), int(best[i]), 5)
+                        for i in range(n)])
+    f_cur = np.stack([refpy.cam2world(cam, u, v) for u, v in
+                      zip(rng.uniform(0, cam.width, n), rng.uniform(0, cam.height, n))])
+    f_cur[20] = synth.quat_rot(T_cur_ref[20, 3:], f_ref[20])   # parallel rays: det < 1e-6 -> false
+    tri = [refpy.depth_from_triangulation(T_cur_ref[i], f_ref[i], f_cur[i]) for i in range(n)]
+    np.savez_compressed(
+        os.path.join(OUT, "matcher.npz"), cur=cur, ref=ref, zp=zp, zxy=zxy, zs=zs,
+        cam=np.array([cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy]), px_ref=px_ref,
+        level_ref=level_ref, f_ref=f_ref, depth=depth, T_cur_ref=T_cur_ref, A=A, best=best,
+        patches=patches, f_cur=f_cur, tri_ok=np.array([t[0] for t in tri], dtype=np.uint8),
+        tri_depth=np.array([t[1] for t in tri]))
+
+
+def gen_vision(rng):
+    cam, scene, T0, T1, ref, cur = small_scene()
+    n = 512
+    uv = np.stack([rng.uniform(0, cam.width - 1.001, n), rng.uniform(0, cam.height - 1.001, n)], axis=1).astype(np.float32)
+    uv[0] = [0, 0]; uv[1] = [10, 20]; uv[2] = [10.5, 20.5]
+    val = np.array([refpy.interpolate_8u(cur, float(u), float(v)) for u, v in uv], dtype=np.float32)
+    img = rng.integers(0, 256, (48, 64)).astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, "vision.npz"), cur=cur, uv=uv, val=val, img=img,
+                        half_sse2=refpy.half_sample(img), half_scalar=refpy.half_sample(img, force_scalar=True),
+                        half_odd=refpy.half_sample(img[:, :50].copy()))
+
+
+def main():
+    assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(20240607)
+    gen_se3(rng); gen_algebra(rng); gen_gn(rng); gen_align(rng); gen_matcher(rng); gen_vision(rng)
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
+
+
+if __name__ == "__main__":
+    main()

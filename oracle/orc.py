@@ -1,0 +1,217 @@
+"""ctypes binding of the CPU oracle (oracle/libsvo_oracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsvo_oracle.so")
+MAX_LEVELS = 8
+
+
+class Camera(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("fx", C.c_double), ("fy", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("d", C.c_double * 5), ("distortion", C.c_int)]
+
+
+class SiaParams(C.Structure):
+    _fields_ = [("max_level", C.c_int), ("min_level", C.c_int), ("n_iter", C.c_int),
+                ("eps", C.c_double), ("early_stop", C.c_int)]
+
+
+class SiaResult(C.Structure):
+    _fields_ = [("T_cur_w", C.c_double * 7), ("n_tracked", C.c_size_t), ("H", C.c_double * 36),
+                ("Jres", C.c_double * 6), ("chi2", C.c_double), ("stop", C.c_int),
+                ("iters", C.c_int * MAX_LEVELS), ("n_precompute_patches", C.c_long),
+                ("n_residual_patches", C.c_long)]
+
+
+class Seed(C.Structure):
+    _fields_ = [("a", C.c_float), ("b", C.c_float), ("mu", C.c_float), ("z_range", C.c_float),
+                ("sigma2", C.c_float)]
+
+
+class EpiResult(C.Structure):
+    _fields_ = [("ok", C.c_int), ("depth", C.c_double), ("px_cur", C.c_double * 2),
+                ("search_level", C.c_int), ("epi_length", C.c_double), ("n_zmssd", C.c_int),
+                ("n_align_iters", C.c_int), ("path", C.c_int), ("patch_with_border", C.c_uint8 * 100)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "svo_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libsvo_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.svo_orc_interpolate_8u.restype = C.c_float
+        _lib.svo_orc_compute_tau.restype = C.c_double
+        _lib.svo_orc_sia_eval.restype = C.c_double
+        _lib.svo_orc_sia_open.restype = C.c_void_p
+    return _lib
+
+
+def camera(cam, dist: Sequence[float] | None = None) -> Camera:
+    c = Camera()
+    c.width, c.height = int(cam.width), int(cam.height)
+    c.fx, c.fy, c.cx, c.cy = cam.fx, cam.fy, cam.cx, cam.cy
+    d = list(dist) if dist is not None else [0.0] * 5
+    for i in range(5):
+        c.d[i] = d[i]
+    c.distortion = 1 if abs(d[0]) > 1e-7 else 0   # pinhole_camera.cpp:27
+    return c
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def pyr_ptrs(pyr):
+    arr = (C.POINTER(C.c_uint8) * MAX_LEVELS)()
+    for i, im in enumerate(pyr):
+        assert im.flags["C_CONTIGUOUS"] and im.dtype == np.uint8
+        arr[i] = _p(im, C.c_uint8)
+    return arr
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def sparse_img_align(fp, max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=True,
+                     T_cur_w_init=None) -> SiaResult:
+    L = lib()
+    cam = camera(fp.cam)
+    prm = SiaParams(max_level, min_level, n_iter, eps, 1 if early_stop else 0)
+    out = SiaResult()
+    rp, cp = pyr_ptrs(fp.ref_pyr), pyr_ptrs(fp.cur_pyr)
+    px, f, pos = f64(fp.px), f64(fp.f), f64(fp.pos)
+    hp = np.ascontiguousarray(fp.has_point, dtype=np.uint8)
+    T_ref = f64(fp.T_ref_w)
+    T_init = f64(fp.T_cur_w_init if T_cur_w_init is None else T_cur_w_init)
+    L.svo_orc_sparse_img_align(C.byref(cam), rp, cp, C.c_int(len(px)), _p(px, C.c_double),
+                               _p(f, C.c_double), _p(pos, C.c_double), _p(hp, C.c_uint8),
+                               _p(T_ref, C.c_double), _p(T_init, C.c_double), C.byref(prm), C.byref(out))
+    return out
+
+
+def sia_single_eval(fp, level, T_cur_from_ref, want_caches=False):
+    L = lib()
+    cam = camera(fp.cam)
+    n = len(fp.px)
+    px, f, pos = f64(fp.px), f64(fp.f), f64(fp.pos)
+    hp = np.ascontiguousarray(fp.has_point, dtype=np.uint8)
+    out28 = np.zeros(28)
+    nm = C.c_long(0)
+    cache = np.zeros((n, 16), dtype=np.float32)
+    jac = np.zeros((n, 16, 6), dtype=np.float64)
+    vis = np.zeros(n, dtype=np.uint8)
+    T_ref = f64(fp.T_ref_w)
+    T = f64(T_cur_from_ref)
+    L.svo_orc_sia_single_eval(C.byref(cam), _p(fp.ref_pyr[level], C.c_uint8), _p(fp.cur_pyr[level], C.c_uint8),
+                              C.c_int(level), C.c_int(n), _p(px, C.c_double), _p(f, C.c_double),
+                              _p(pos, C.c_double), _p(hp, C.c_uint8), _p(T_ref, C.c_double),
+                              _p(T, C.c_double), _p(out28, C.c_double), C.byref(nm),
+                              _p(cache, C.c_float), _p(jac, C.c_double), _p(vis, C.c_uint8))
+    if want_caches:
+        return out28, nm.value, cache, jac, vis
+    return out28, nm.value
+
+
+def align2d(img, pwb, patch, n_iter, px):
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    pwb = np.ascontiguousarray(pwb, dtype=np.uint8)
+    patch = np.ascontiguousarray(patch, dtype=np.uint8)
+    p = f64(px).copy()
+    it = C.c_int(0)
+    ok = L.svo_orc_align2d(_p(img, C.c_uint8), img.shape[1], img.shape[0], img.shape[1],
+                           _p(pwb, C.c_uint8), _p(patch, C.c_uint8), n_iter, _p(p, C.c_double), C.byref(it))
+    return bool(ok), p, it.value
+
+
+def align1d(img, direction, pwb, patch, n_iter, px):
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    pwb = np.ascontiguousarray(pwb, dtype=np.uint8)
+    patch = np.ascontiguousarray(patch, dtype=np.uint8)
+    d = np.ascontiguousarray(direction, dtype=np.float32)
+    p = f64(px).copy()
+    it = C.c_int(0)
+    hinv = C.c_double(0)
+    ok = L.svo_orc_align1d(_p(img, C.c_uint8), img.shape[1], img.shape[0], img.shape[1], _p(d, C.c_float),
+                           _p(pwb, C.c_uint8), _p(patch, C.c_uint8), n_iter, _p(p, C.c_double),
+                           C.byref(hinv), C.byref(it))
+    return bool(ok), p, hinv.value, it.value
+
+
+def update_seed(x, tau2, seed5):
+    s = Seed(*[float(v) for v in seed5])
+    lib().svo_orc_update_seed(C.c_float(x), C.c_float(tau2), C.byref(s))
+    return np.array([s.a, s.b, s.mu, s.z_range, s.sigma2], dtype=np.float32)
+
+
+def seed_init(depth_mean, depth_min):
+    s = Seed()
+    lib().svo_orc_seed_init(C.byref(s), C.c_float(depth_mean), C.c_float(depth_min))
+    return np.array([s.a, s.b, s.mu, s.z_range, s.sigma2], dtype=np.float32)
+
+
+def compute_tau(T_ref_cur, f, z, px_error_angle):
+    T = f64(T_ref_cur)
+    ff = f64(f)
+    return lib().svo_orc_compute_tau(_p(T, C.c_double), _p(ff, C.c_double), C.c_double(z),
+                                     C.c_double(px_error_angle))
+
+
+def find_epipolar_match(cam, ref_pyr, cur_pyr, T_cur_ref, px_ref, f_ref, level_ref, d_est, d_min, d_max,
+                        n_pyr_levels=3, align_max_iter=10, max_steps=1000) -> EpiResult:
+    c = camera(cam)
+    out = EpiResult()
+    T = f64(T_cur_ref)
+    p = f64(px_ref)
+    ff = f64(f_ref)
+    lib().svo_orc_find_epipolar_match_direct(
+        C.byref(c), pyr_ptrs(ref_pyr), pyr_ptrs(cur_pyr), _p(T, C.c_double), _p(p, C.c_double),
+        _p(ff, C.c_double), C.c_int(level_ref), C.c_double(d_est), C.c_double(d_min), C.c_double(d_max),
+        C.c_int(n_pyr_levels), C.c_int(align_max_iter), C.c_int(max_steps), C.byref(out))
+    return out
+
+
+def update_seeds(cam, ref_pyr, cur_pyr, T_ref_w, T_cur_w, px, f, level, a, b, mu, z_range, sigma2,
+                 n_pyr_levels=3, align_max_iter=10, max_steps=1000, conv_thresh=100.0):
+    """In-place update of (a, b, mu, sigma2); returns dict of per-seed outputs."""
+    c = camera(cam)
+    n = len(px)
+    px, f = f64(px), f64(f)
+    level = np.ascontiguousarray(level, dtype=np.int32)
+    for arr in (a, b, mu, z_range, sigma2):
+        assert arr.dtype == np.float32 and arr.flags["C_CONTIGUOUS"]
+    status = np.zeros(n, dtype=np.int32)
+    z = np.zeros(n)
+    xyz = np.zeros((n, 3))
+    nz = np.zeros(n, dtype=np.int32)
+    na = np.zeros(n, dtype=np.int32)
+    Tr, Tc = f64(T_ref_w), f64(T_cur_w)
+    lib().svo_orc_update_seeds(
+        C.byref(c), pyr_ptrs(ref_pyr), pyr_ptrs(cur_pyr), _p(Tr, C.c_double), _p(Tc, C.c_double),
+        C.c_int(n), _p(px, C.c_double), _p(f, C.c_double), _p(level, C.c_int), _p(a, C.c_float),
+        _p(b, C.c_float), _p(mu, C.c_float), _p(z_range, C.c_float), _p(sigma2, C.c_float),
+        C.c_int(n_pyr_levels), C.c_int(align_max_iter), C.c_int(max_steps), C.c_double(conv_thresh),
+        _p(status, C.c_int), _p(z, C.c_double), _p(xyz, C.c_double), _p(nz, C.c_int), _p(na, C.c_int))
+    return {"status": status, "z": z, "xyz_world": xyz, "n_zmssd": nz, "n_align_iters": na}

@@ -1,0 +1,169 @@
+"""ctypes binding of oracle/_ref/libsvo_ref.so (the reference's own code, built by
+`make -C oracle ref` where /root/reference is mounted) -- TEST INFRASTRUCTURE ONLY.
+Used to generate tests/golden/* and, when present, for live cross-checks of the
+C restatement.  `available()` is False on the GPU box unless the prebuilt .so travelled.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .. import orc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "_ref", "libsvo_ref.so")
+_lib = None
+
+
+def available() -> bool:
+    return os.path.exists(_LIB_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.ref_interpolate_8u.restype = C.c_float
+    return _lib
+
+
+_p = orc._p
+f64 = orc.f64
+D = C.c_double
+
+
+def _call_vec(name, n_out, *ins):
+    out = np.zeros(n_out)
+    args = [_p(f64(a), D) for a in ins]
+    keep = [f64(a) for a in ins]
+    args = [_p(a, D) for a in keep]
+    getattr(lib(), name)(*args, _p(out, D))
+    return out
+
+
+def se3_mul(A, B): return _call_vec("ref_se3_mul", 7, A, B)
+def se3_inverse(A): return _call_vec("ref_se3_inverse", 7, A)
+def se3_act(A, p): return _call_vec("ref_se3_act", 3, A, p)
+def se3_exp(l): return _call_vec("ref_se3_exp", 7, l)
+def so3_log(q): return _call_vec("ref_so3_log", 3, q)
+def rotation_matrix(A): return _call_vec("ref_se3_rotation_matrix", 9, A)
+def jacobian_xyz2uv(p): return _call_vec("ref_jacobian_xyz2uv", 12, p)
+def ldlt6_solve(H, b): return _call_vec("ref_ldlt6_solve", 6, np.asarray(H).reshape(36), b)
+
+
+def driven_sparse_align(fp, max_level=4, min_level=0, n_iter=30, eps=1e-6, T_cur_w_init=None):
+    cam = orc.camera(fp.cam)
+    rp, cp = orc.pyr_ptrs(fp.ref_pyr), orc.pyr_ptrs(fp.cur_pyr)
+    px, f, pos = f64(fp.px), f64(fp.f), f64(fp.pos)
+    hp = np.ascontiguousarray(fp.has_point, dtype=np.uint8)
+    T_ref = f64(fp.T_ref_w)
+    T_init = f64(fp.T_cur_w_init if T_cur_w_init is None else T_cur_w_init)
+    T_out = np.zeros(7)
+    nt = C.c_size_t(0)
+    chi2 = D(0)
+    iters = np.zeros(8, dtype=np.int32)
+    H = np.zeros(36)
+    lib().ref_driven_sparse_align(C.byref(cam), rp, cp, C.c_int(len(px)), _p(px, D), _p(f, D), _p(pos, D),
+                                  _p(hp, C.c_uint8), _p(T_ref, D), _p(T_init, D), C.c_int(max_level),
+                                  C.c_int(min_level), C.c_int(n_iter), D(eps), _p(T_out, D), C.byref(nt),
+                                  C.byref(chi2), _p(iters, C.c_int), _p(H, D))
+    return {"T_cur_w": T_out, "n_tracked": nt.value, "chi2": chi2.value, "iters": iters, "H": H}
+
+
+def align2d(img, pwb, patch, n_iter, px):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    pwb = np.ascontiguousarray(pwb, dtype=np.uint8)
+    patch = np.ascontiguousarray(patch, dtype=np.uint8)
+    p = f64(px).copy()
+    ok = lib().ref_align2d(_p(img, C.c_uint8), img.shape[1], img.shape[0], img.shape[1], _p(pwb, C.c_uint8),
+                           _p(patch, C.c_uint8), n_iter, _p(p, D))
+    return bool(ok), p
+
+
+def align1d(img, direction, pwb, patch, n_iter, px):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    pwb = np.ascontiguousarray(pwb, dtype=np.uint8)
+    patch = np.ascontiguousarray(patch, dtype=np.uint8)
+    d = np.ascontiguousarray(direction, dtype=np.float32)
+    p = f64(px).copy()
+    hinv = D(0)
+    ok = lib().ref_align1d(_p(img, C.c_uint8), img.shape[1], img.shape[0], img.shape[1], _p(d, C.c_float),
+                           _p(pwb, C.c_uint8), _p(patch, C.c_uint8), n_iter, _p(p, D), C.byref(hinv))
+    return bool(ok), p, hinv.value
+
+
+def zmssd(ref_patch, img, x0, y0):
+    ref_patch = np.ascontiguousarray(ref_patch, dtype=np.uint8)
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    ptr = C.cast(img.ctypes.data + y0 * img.shape[1] + x0, C.POINTER(C.c_uint8))
+    return lib().ref_zmssd(_p(ref_patch, C.c_uint8), ptr, img.shape[1])
+
+
+def get_warp_matrix_affine(cam, px_ref, f_ref, depth_ref, T_cur_ref, level_ref):
+    A = np.zeros(4)
+    p, ff, T = f64(px_ref), f64(f_ref), f64(T_cur_ref)
+    lib().ref_get_warp_matrix_affine(C.c_int(cam.width), C.c_int(cam.height), D(cam.fx), D(cam.fy), D(cam.cx),
+                                     D(cam.cy), _p(p, D), _p(ff, D), D(depth_ref), _p(T, D),
+                                     C.c_int(level_ref), _p(A, D))
+    return A
+
+
+def get_best_search_level(A, max_level):
+    a = f64(A)
+    return lib().ref_get_best_search_level(_p(a, D), C.c_int(max_level))
+
+
+def warp_affine(A, img, px_ref, level_ref, search_level, halfpatch_size):
+    a, p = f64(A), f64(px_ref)
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    n = 2 * halfpatch_size
+    patch = np.full(n * n, 7, dtype=np.uint8)
+    lib().ref_warp_affine(_p(a, D), _p(img, C.c_uint8), img.shape[1], img.shape[0], _p(p, D),
+                          C.c_int(level_ref), C.c_int(search_level), C.c_int(halfpatch_size),
+                          _p(patch, C.c_uint8))
+    return patch
+
+
+def patch_from_border(pwb):
+    pwb = np.ascontiguousarray(pwb, dtype=np.uint8)
+    out = np.zeros(64, dtype=np.uint8)
+    lib().ref_patch_from_border(_p(pwb, C.c_uint8), _p(out, C.c_uint8))
+    return out
+
+
+def depth_from_triangulation(T_search_ref, f_ref, f_cur):
+    T, a, b = f64(T_search_ref), f64(f_ref), f64(f_cur)
+    d = D(0)
+    ok = lib().ref_depth_from_triangulation(_p(T, D), _p(a, D), _p(b, D), C.byref(d))
+    return bool(ok), d.value
+
+
+def cam2world(cam, u, v):
+    out = np.zeros(3)
+    lib().ref_cam2world(C.c_int(cam.width), C.c_int(cam.height), D(cam.fx), D(cam.fy), D(cam.cx), D(cam.cy),
+                        D(u), D(v), _p(out, D))
+    return out
+
+
+def interpolate_8u(img, u, v):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    return float(lib().ref_interpolate_8u(_p(img, C.c_uint8), img.shape[1], img.shape[0], C.c_float(u),
+                                          C.c_float(v)))
+
+
+def half_sample(img, force_scalar=False):
+    """SSE2 path when the buffer is 16-byte aligned and cols%16==0, else the scalar path."""
+    h, w = img.shape
+    raw = np.zeros(h * w + 64, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 16
+    if force_scalar:
+        off += 1
+    a = raw[off:off + h * w].reshape(h, w)
+    a[:] = img
+    rawo = np.zeros((h // 2) * (w // 2) + 64, dtype=np.uint8)
+    offo = (-rawo.ctypes.data) % 16
+    o = rawo[offo:offo + (h // 2) * (w // 2)].reshape(h // 2, w // 2)
+    lib().ref_half_sample(_p(a, C.c_uint8), w, h, _p(o, C.c_uint8))
+    return o.copy()

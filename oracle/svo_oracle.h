@@ -1,0 +1,211 @@
+/*
+ * svo_oracle.h -- CPU restatement of the SVO hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity oracle for android_svo_amd: a plain-C, single-threaded
+ * restatement of the reference algorithms on flat SoA buffers.  It is NOT part
+ * of the product: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  Every function cites the reference file:line
+ * it follows (paths relative to /root/reference/app/src/main/cpp/svo/, headers
+ * under include/svo/).
+ *
+ * Pinning status (see oracle/README.md and DESIGN.md):
+ *   pinned against the reference's own code compiled here (oracle/_ref):
+ *     SE3/SO3 algebra, Frame::jacobian_xyz2uv, Eigen LDLT 6x6 solve,
+ *     NLLSSolver Gauss-Newton control flow, feature_alignment::align2D/align1D,
+ *     ZMSSD, warp::getWarpMatrixAffine/getBestSearchLevel/warpAffine,
+ *     depthFromTriangulation, vk::interpolateMat_8u, vk::halfSample.
+ *   pinned by the known-answer vector recorded in SURVEY.md 8(a-9):
+ *     Seed ctor + DepthFilter::updateSeed.
+ *   PARITY UNPINNED (restated from source text only; the reference translation
+ *   units need the OpenCV core library and the Android NDK log header, both
+ *   absent here, so they are unbuildable under the no-stand-ins rule):
+ *     SparseImgAlign::precomputeReferencePatches / computeResiduals bodies,
+ *     Matcher::findEpipolarMatchDirect glue loop, DepthFilter::updateSeeds glue,
+ *     DepthFilter::computeTau.
+ *
+ * Conventions: SE3 = double[7] {tx,ty,tz,qx,qy,qz,qw} (reference SE3.h/SO3.h
+ * member order); images are u8, row-major, stride == cols; pyramids are arrays
+ * of level pointers, level l has (width>>l) x (height>>l) pixels.
+ */
+#ifndef SVO_ORACLE_H_
+#define SVO_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVO_ORACLE_MAX_LEVELS 8
+
+/* Pinhole camera with the reference's radtan forward model
+ * (pinhole_camera.cpp:73-106).  distortion != 0 enables d[0..4]. */
+typedef struct {
+  int width, height;
+  double fx, fy, cx, cy;
+  double d[5];
+  int distortion;
+} svo_orc_camera;
+
+/* ---- SE3 / SO3 (SE3.h:35-61,153-182; SO3.h:468-488,523-526) ------------- */
+void svo_orc_se3_identity(double T[7]);
+void svo_orc_se3_mul(const double A[7], const double B[7], double out[7]);
+void svo_orc_se3_inverse(const double T[7], double out[7]);
+void svo_orc_se3_act(const double T[7], const double p[3], double out[3]);
+void svo_orc_se3_exp(const double twist[6], double out[7]);
+void svo_orc_so3_log(const double q[4], double out[3]);
+void svo_orc_se3_rotation_matrix(const double T[7], double R[9]);
+
+/* ---- camera (abstract_camera.h:41-72, pinhole_camera.cpp:44-106) -------- */
+void svo_orc_world2cam_uv(const svo_orc_camera* cam, const double uv[2], double px[2]);
+void svo_orc_world2cam(const svo_orc_camera* cam, const double xyz[3], double px[2]);
+/* distortion-free branch only (pinhole_camera.cpp:47-52,64) */
+void svo_orc_cam2world(const svo_orc_camera* cam, double u, double v, double f[3]);
+
+/* ---- small algebra ------------------------------------------------------ */
+/* Frame::jacobian_xyz2uv, frame.h:110-132. J is 2x6 row-major. */
+void svo_orc_jacobian_xyz2uv(const double xyz[3], double J[12]);
+/* x = H.ldlt().solve(b) with Eigen 3.4.0's pivoted LDLT (Cholesky/LDLT.h:297-403,
+ * 574-613).  H is 6x6 (symmetric; lower part is read).  Returns 1. */
+int svo_orc_ldlt6_solve(const double H[36], const double b[6], double x[6]);
+
+/* ---- image helpers ------------------------------------------------------ */
+/* vk::halfSample scalar form (vision.cpp:89-110): (a+b+c+d)/4 truncating. */
+void svo_orc_half_sample(const uint8_t* in, int w, int h, uint8_t* out);
+/* vk::halfSample SSE2 form (vision.cpp:20-45): avg-of-avg, rounding up. */
+void svo_orc_half_sample_sse2form(const uint8_t* in, int w, int h, uint8_t* out);
+/* vk::interpolateMat_8u, vision.h:19-36 */
+float svo_orc_interpolate_8u(const uint8_t* img, int stride, float u, float v);
+
+/* ---- SparseImgAlign (sparse_img_align.cpp:51-308, nlls_solver_impl.hpp:25-100) */
+typedef struct {
+  int max_level, min_level;   /* coarse-to-fine: level = max..min           */
+  int n_iter;                 /* max GN iterations per level                */
+  double eps;                 /* 1e-6 in the reference ctor (:40)           */
+  int early_stop;             /* 1 = reference semantics; 0 = fixed work    */
+} svo_orc_sia_params;
+
+typedef struct {
+  double T_cur_w[7];          /* result pose                                */
+  size_t n_tracked;           /* n_meas_/16 of the last residual evaluation */
+  double H[36];               /* H_ of the last evaluation                  */
+  double Jres[6];
+  double chi2;                /* chi2_ member after the run                 */
+  int stop;                   /* stop_ member after the run                 */
+  int iters[SVO_ORACLE_MAX_LEVELS];   /* residual evaluations per level     */
+  /* algorithmic work counters */
+  long n_precompute_patches;  /* sum over levels of patches precomputed      */
+  long n_residual_patches;    /* sum over evaluations of patches accumulated */
+} svo_orc_sia_result;
+
+int svo_orc_sparse_img_align(
+    const svo_orc_camera* cam,
+    const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr,
+    int n_feat, const double* px /*[n][2]*/, const double* f /*[n][3]*/,
+    const double* pos /*[n][3]*/, const uint8_t* has_point /*[n]*/,
+    const double T_ref_w[7], const double T_cur_w_init[7],
+    const svo_orc_sia_params* prm, svo_orc_sia_result* out);
+
+/* Single residual/linearisation evaluation, for kernel-level parity tests:
+ * runs precompute at `level` (fresh visibility) then one computeResiduals at
+ * T_cur_from_ref.  out28 = {H upper-tri (21, row-major i<=j), Jres (6), chi2sum}
+ * and n_meas. */
+int svo_orc_sia_single_eval(
+    const svo_orc_camera* cam, const uint8_t* ref_img, const uint8_t* cur_img,
+    int level, int n_feat, const double* px, const double* f, const double* pos,
+    const uint8_t* has_point, const double T_ref_w[7], const double T_cur_from_ref[7],
+    double out28[28], long* n_meas,
+    float* ref_patch_cache /*[n][16] or NULL*/, double* jac_cache /*[n][16][6] or NULL*/,
+    uint8_t* visible /*[n] or NULL*/);
+
+/* Step-wise access to the restated residual body (used by oracle/ref to run the
+ * reference's own NLLSSolver driver on top of it). */
+void* svo_orc_sia_open(const svo_orc_camera* cam, const uint8_t* const* ref_pyr,
+                       const uint8_t* const* cur_pyr, int n_feat, const double* px,
+                       const double* f, const double* pos, const uint8_t* has_point,
+                       const double T_ref_w[7]);
+void svo_orc_sia_set_level(void* h, int level);
+double svo_orc_sia_eval(void* h, const double T_cur_from_ref[7], int linearize, double H[36],
+                        double Jres[6], size_t* n_meas);
+void svo_orc_sia_close(void* h);
+
+/* ---- feature_alignment (feature_alignment.cpp:35-152, 154-282) ---------- */
+int svo_orc_align2d(const uint8_t* cur_img, int cols, int rows, int stride,
+                    const uint8_t* ref_patch_with_border /*10x10*/,
+                    const uint8_t* ref_patch /*8x8*/, int n_iter,
+                    double px_inout[2], int* iters_done);
+int svo_orc_align1d(const uint8_t* cur_img, int cols, int rows, int stride,
+                    const float dir[2], const uint8_t* ref_patch_with_border,
+                    const uint8_t* ref_patch, int n_iter, double px_inout[2],
+                    double* h_inv, int* iters_done);
+
+/* ---- matcher pieces (matcher.cpp:36-147, patch_score.h:40-220) ---------- */
+void svo_orc_get_warp_matrix_affine(
+    const svo_orc_camera* cam_ref, const svo_orc_camera* cam_cur,
+    const double px_ref[2], const double f_ref[3], double depth_ref,
+    const double T_cur_ref[7], int level_ref, double A_cur_ref[4] /*row-major*/);
+int svo_orc_get_best_search_level(const double A_cur_ref[4], int max_level);
+/* returns 0 when the inverse warp is NaN (patch left untouched, matcher.cpp:94-98) */
+int svo_orc_warp_affine(const double A_cur_ref[4], const uint8_t* img_ref, int cols,
+                        int rows, const double px_ref[2], int level_ref,
+                        int search_level, int halfpatch_size, uint8_t* patch);
+void svo_orc_patch_from_border(const uint8_t* patch_with_border, uint8_t* patch);
+int svo_orc_zmssd(const uint8_t* ref_patch /*64*/, const uint8_t* cur, int stride);
+int svo_orc_depth_from_triangulation(const double T_search_ref[7], const double f_ref[3],
+                                     const double f_cur[3], double* depth);
+
+typedef struct {
+  int ok;                /* return value of findEpipolarMatchDirect          */
+  double depth;
+  double px_cur[2];
+  int search_level;
+  double epi_length;
+  int n_zmssd;           /* ZMSSD evaluations actually executed (after dedupe) */
+  int n_align_iters;     /* align2D iterations executed                        */
+  int path;              /* 0 = short epipolar (direct align), 1 = search, 2 = skipped (too long) */
+  uint8_t patch_with_border[100];
+} svo_orc_epi_result;
+
+/* Matcher::findEpipolarMatchDirect, matcher.cpp:207-355 (CORNER features,
+ * align_1d=false, subpix_refinement=true: Matcher::Options defaults matcher.h:83-91);
+ * n_pyr_levels = Config::nPyrLevels() (config.cpp:59 -> 3). */
+int svo_orc_find_epipolar_match_direct(
+    const svo_orc_camera* cam, const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr,
+    const double T_cur_ref[7], const double px_ref[2], const double f_ref[3], int level_ref,
+    double d_estimate, double d_min, double d_max, int n_pyr_levels, int align_max_iter,
+    int max_epi_search_steps, svo_orc_epi_result* out);
+
+/* ---- depth filter (depth_filter.cpp:36-45, 237-341, 359-416) ------------ */
+typedef struct { float a, b, mu, z_range, sigma2; } svo_orc_seed;
+void svo_orc_seed_init(svo_orc_seed* s, float depth_mean, float depth_min);
+void svo_orc_update_seed(float x, float tau2, svo_orc_seed* s);
+double svo_orc_compute_tau(const double T_ref_cur[7], const double f[3], double z,
+                           double px_error_angle);
+
+/* per-seed outcome codes of one updateSeeds pass */
+enum {
+  SVO_SEED_BEHIND = 0,        /* xyz_f.z < 0                     (:268-271) */
+  SVO_SEED_NOT_IN_FRAME = 1,  /* !isInFrame                      (:272-275) */
+  SVO_SEED_NO_MATCH = 2,      /* match failed -> b++             (:283-290) */
+  SVO_SEED_UPDATED = 3,       /* Bayes update done               (:299)     */
+  SVO_SEED_CONVERGED = 4,     /* updated and converged -> erase  (:310-331) */
+  SVO_SEED_NAN = 5            /* updated, z_inv_min NaN -> erase (:333-337) */
+};
+
+/* DepthFilter::updateSeeds body for seeds of ONE reference keyframe against one
+ * current frame (no ageing/halt: host bookkeeping).  Arrays are SoA per seed. */
+int svo_orc_update_seeds(
+    const svo_orc_camera* cam, const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr,
+    const double T_ref_w[7], const double T_cur_w[7],
+    int n_seeds, const double* px /*[n][2]*/, const double* f /*[n][3]*/, const int* level,
+    float* a, float* b, float* mu, const float* z_range, float* sigma2,
+    int n_pyr_levels, int align_max_iter, int max_epi_search_steps,
+    double convergence_sigma2_thresh,
+    int* status, double* z_out, double* xyz_world /*[n][3], valid when converged*/,
+    int* n_zmssd, int* n_align_iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
