@@ -1,0 +1,218 @@
+// svo_ctx.hip -- contexts, device memory helpers and HBM-resident image pyramids.
+//
+// Pyramid layout in HBM: one allocation per batch; slot s occupies
+// [s*pyr_bytes, (s+1)*pyr_bytes), its levels are packed back to back (each level
+// start rounded up to 16 bytes so dword/dwordx4 loads of the half-sample kernel are
+// aligned).  640x480x5 levels = 409 200 B per pyramid.
+#include "svo_internal.h"
+
+namespace {
+
+// 2x2 truncating mean, one thread per 4 output pixels (reads 2 x 8 B, writes 4 B):
+// vk::halfSample scalar / NEON form, vision.cpp:49-67,89-110.  HBM-bound: 1.25 B moved
+// per input byte.
+__global__ void half_sample_kernel(const uint8_t* __restrict__ in, int w, int h, uint8_t* __restrict__ out) {
+  const int ow = w >> 1, oh = h >> 1;
+  const int quads = (ow + 3) >> 2;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (q >= quads || y >= oh) return;
+  const uint8_t* top = in + (size_t)(2 * y) * w + 8 * q;
+  const uint8_t* bot = top + w;
+  uint8_t* o = out + (size_t)y * ow + 4 * q;
+  const int x0 = 4 * q;
+  if (x0 + 4 <= ow && (w & 7) == 0 && (ow & 3) == 0) {
+    const uint2 t = *reinterpret_cast<const uint2*>(top);
+    const uint2 b = *reinterpret_cast<const uint2*>(bot);
+    auto px = [](unsigned tw, unsigned bw, int s) -> unsigned {
+      return (((tw >> s) & 0xff) + ((tw >> (s + 8)) & 0xff) + ((bw >> s) & 0xff) + ((bw >> (s + 8)) & 0xff)) >> 2;
+    };
+    const unsigned r = px(t.x, b.x, 0) | (px(t.x, b.x, 16) << 8) | (px(t.y, b.y, 0) << 16) | (px(t.y, b.y, 16) << 24);
+    *reinterpret_cast<unsigned*>(o) = r;
+  } else {
+    for (int i = 0; i < 4 && x0 + i < ow; ++i)
+      o[i] = (uint8_t)(((unsigned)top[2 * i] + top[2 * i + 1] + bot[2 * i] + bot[2 * i + 1]) >> 2);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* svo_hip_version(void) { return "svo_hip 0.1 (gfx950)"; }
+
+int svo_hip_device_count(int* count) {
+  if (!count) return SVO_HIP_ERR_INVALID;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return SVO_HIP_ERR_DEVICE; }
+  *count = n;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_ctx_create(svo_hip_ctx** out, int device, void* stream) {
+  if (!out) return SVO_HIP_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SVO_HIP_ERR_DEVICE;
+  if (device < 0 || device >= n) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* c = new (std::nothrow) svo_hip_ctx();
+  if (!c) return SVO_HIP_ERR_NOMEM;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete c; return SVO_HIP_ERR_DEVICE; }
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+    c->own_stream = false;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SVO_HIP_ERR_DEVICE; }
+    c->own_stream = true;
+  }
+  *out = c;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_ctx_destroy(svo_hip_ctx* ctx) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  if (ctx->own_stream && ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  delete ctx;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_ctx_sync(svo_hip_ctx* ctx) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_HIP_OK;
+}
+
+void* svo_hip_ctx_stream(svo_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+const char* svo_hip_last_error(svo_hip_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int svo_hip_malloc(svo_hip_ctx* ctx, void** dev_ptr, size_t bytes) {
+  if (!ctx || !dev_ptr) return SVO_HIP_ERR_INVALID;
+  *dev_ptr = nullptr;
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(dev_ptr, bytes ? bytes : 1);
+  if (e == hipErrorOutOfMemory) return svo_fail(ctx, SVO_HIP_ERR_NOMEM, "hipMalloc", "out of memory");
+  SVO_CHECK_HIP(ctx, e);
+  return SVO_HIP_OK;
+}
+
+int svo_hip_free(svo_hip_ctx* ctx, void* dev_ptr) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  if (!dev_ptr) return SVO_HIP_OK;
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SVO_CHECK_HIP(ctx, hipFree(dev_ptr));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_memcpy_h2d(svo_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+  if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return SVO_HIP_ERR_INVALID;
+  if (!bytes) return SVO_HIP_OK;
+  // pageable host memory: hipMemcpyAsync stages it before returning, so the caller's
+  // buffer is not retained (SURVEY 8b "Ownership")
+  SVO_CHECK_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_memcpy_d2h(svo_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+  if (!ctx || (!dst_host && bytes) || (!src_dev && bytes)) return SVO_HIP_ERR_INVALID;
+  if (!bytes) return SVO_HIP_OK;
+  SVO_CHECK_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_memset(svo_hip_ctx* ctx, void* dst_dev, int value, size_t bytes) {
+  if (!ctx || (!dst_dev && bytes)) return SVO_HIP_ERR_INVALID;
+  if (!bytes) return SVO_HIP_OK;
+  SVO_CHECK_HIP(ctx, hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_pyramid_create(svo_hip_ctx* ctx, int width, int height, int n_levels, int batch,
+                           svo_hip_pyramid** out) {
+  if (!ctx || !out) return SVO_HIP_ERR_INVALID;
+  *out = nullptr;
+  SVO_REQUIRE(ctx, width > 0 && height > 0 && batch > 0);
+  SVO_REQUIRE(ctx, n_levels >= 1 && n_levels <= SVO_HIP_MAX_LEVELS);
+  SVO_REQUIRE(ctx, (width >> (n_levels - 1)) > 0 && (height >> (n_levels - 1)) > 0);
+  svo_hip_pyramid* p = new (std::nothrow) svo_hip_pyramid();
+  if (!p) return SVO_HIP_ERR_NOMEM;
+  p->ctx = ctx; p->width = width; p->height = height; p->n_levels = n_levels; p->batch = batch;
+  size_t off = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    p->level_offset[l] = off;
+    off += (size_t)(width >> l) * (size_t)(height >> l);
+    off = (off + 15) & ~(size_t)15;
+  }
+  p->level_offset[n_levels] = off;
+  p->pyr_bytes = off;
+  void* d = nullptr;
+  int rc = svo_hip_malloc(ctx, &d, p->pyr_bytes * (size_t)batch + 64);   // +64: tail slack for 8-byte row reads
+  if (rc != SVO_HIP_OK) { delete p; return rc; }
+  p->base = (uint8_t*)d;
+  *out = p;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_pyramid_destroy(svo_hip_pyramid* pyr) {
+  if (!pyr) return SVO_HIP_ERR_INVALID;
+  int rc = svo_hip_free(pyr->ctx, pyr->base);
+  delete pyr;
+  return rc;
+}
+
+int svo_hip_pyramid_upload(svo_hip_pyramid* pyr, int slot, const uint8_t* const* levels) {
+  if (!pyr || !levels) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = pyr->ctx;
+  SVO_REQUIRE(ctx, slot >= 0 && slot < pyr->batch);
+  for (int l = 0; l < pyr->n_levels; ++l) {
+    SVO_REQUIRE(ctx, levels[l] != nullptr);
+    size_t bytes = (size_t)(pyr->width >> l) * (size_t)(pyr->height >> l);
+    SVO_CHECK_HIP(ctx, hipMemcpyAsync(pyr->base + (size_t)slot * pyr->pyr_bytes + pyr->level_offset[l], levels[l],
+                                      bytes, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_pyramid_upload_level0_and_build(svo_hip_pyramid* pyr, int slot, const uint8_t* level0) {
+  if (!pyr || !level0) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = pyr->ctx;
+  SVO_REQUIRE(ctx, slot >= 0 && slot < pyr->batch);
+  uint8_t* base = pyr->base + (size_t)slot * pyr->pyr_bytes;
+  SVO_CHECK_HIP(ctx, hipMemcpyAsync(base, level0, (size_t)pyr->width * pyr->height, hipMemcpyHostToDevice, ctx->stream));
+  for (int l = 1; l < pyr->n_levels; ++l) {
+    const int w = pyr->width >> (l - 1), h = pyr->height >> (l - 1);
+    const int ow = w >> 1, oh = h >> 1;
+    dim3 block(64), grid(((ow + 3) / 4 + 63) / 64, oh);
+    hipLaunchKernelGGL(half_sample_kernel, grid, block, 0, ctx->stream, base + pyr->level_offset[l - 1], w, h,
+                       base + pyr->level_offset[l]);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_pyramid_download_level(svo_hip_pyramid* pyr, int slot, int level, uint8_t* out_host) {
+  if (!pyr || !out_host) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = pyr->ctx;
+  SVO_REQUIRE(ctx, slot >= 0 && slot < pyr->batch && level >= 0 && level < pyr->n_levels);
+  size_t bytes = (size_t)(pyr->width >> level) * (size_t)(pyr->height >> level);
+  return svo_hip_memcpy_d2h(ctx, out_host, pyr->base + (size_t)slot * pyr->pyr_bytes + pyr->level_offset[level], bytes);
+}
+
+int svo_hip_pyramid_info(const svo_hip_pyramid* pyr, int* width, int* height, int* n_levels, int* batch,
+                         size_t* pyr_bytes, void** base_dev) {
+  if (!pyr) return SVO_HIP_ERR_INVALID;
+  if (width) *width = pyr->width;
+  if (height) *height = pyr->height;
+  if (n_levels) *n_levels = pyr->n_levels;
+  if (batch) *batch = pyr->batch;
+  if (pyr_bytes) *pyr_bytes = pyr->pyr_bytes;
+  if (base_dev) *base_dev = pyr->base;
+  return SVO_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,571 @@
+// svo_depth.hip -- align2D batch, DepthFilter::updateSeed / computeTau batches and the
+// full per-seed DepthFilter::updateSeeds body (visibility, epipolar ZMSSD search, align2D,
+// triangulation, tau, Bayes update, convergence test) on gfx950.
+//
+// Reference: S/depth_filter.cpp:237-416, S/matcher.cpp:36-147,207-355,
+// I/patch_score.h:40-220, S/feature_alignment.cpp:154-282.
+//
+// Mapping: one wave64 per seed.  The fp64 geometry of a seed is wave-uniform (every lane
+// evaluates it; it is a few hundred flops against thousands of lane-ops of search work);
+// the 10x10 warped reference patch is built by lanes 0..99 (two passes) into LDS; the
+// epipolar search assigns one candidate position per lane (64 candidates per pass), each
+// lane computing a whole 8x8 ZMSSD with packed u8 dot products against the LDS patch;
+// the best candidate is an order-preserving wave arg-min (first minimum wins, exactly the
+// serial `zmssd < zmssd_best` scan); the sub-pixel refinement is the wave-per-patch
+// align2D of svo_align_device.h.
+//
+// Exactness: all integer/index work (candidate pixel, search level, warped patch bytes,
+// ZMSSD, arg-min) is bit-exact against the CPU path: the fp64 chains that feed integer
+// conversions use the same operation order (built with -ffp-contract=off), and the
+// epipolar abscissa uv_i is produced by the same repeated addition uv += step as
+// S/matcher.cpp:299 (each lane replays its prefix).
+#include "svo_align_device.h"
+#include "svo_internal.h"
+
+using namespace svo_dev;
+
+namespace {
+
+constexpr int ZMSSD_THRESHOLD = 2000 * 64;     // I/patch_score.h:46
+
+// ---- align2D over n patches: one wave per patch, 4 waves per block --------------------------
+__global__ __launch_bounds__(256) void align2d_kernel(const uint8_t* __restrict__ img, int cols, int rows, int n,
+                                                      const uint8_t* __restrict__ pwb, int n_iter,
+                                                      double* __restrict__ px, uint8_t* __restrict__ converged,
+                                                      int32_t* __restrict__ iters) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n) return;
+  double u = px[2 * (size_t)w], v = px[2 * (size_t)w + 1];
+  int it = 0;
+  const bool ok = align2d_wave(img, cols, rows, cols, pwb + (size_t)w * 100, n_iter, &u, &v, &it);
+  if ((threadIdx.x & 63) == 0) {
+    px[2 * (size_t)w] = u;
+    px[2 * (size_t)w + 1] = v;
+    converged[w] = ok ? 1 : 0;
+    if (iters) iters[w] = it;
+  }
+}
+
+// ---- DepthFilter::updateSeed (S/depth_filter.cpp:359-391) -------------------------------------
+struct SeedState { float a, b, mu, z_range, sigma2; };
+
+SVO_DEV double normal_pdf_quirk(double x, double mean, double std_dev) {
+  const double SQRT_2_PI = 1.41421356237309505;       // sqrt(2), as in the reference (:360)
+  const double q = (x - mean) / std_dev;
+  const double exponent = -0.5 * (q * q);              // pow(q, 2)
+  return (1 / (std_dev * SQRT_2_PI)) * exp(exponent);
+}
+
+SVO_DEV void update_seed(const float x, const float tau2, SeedState* seed) {
+  const float norm_scale = sqrtf(seed->sigma2 + tau2);
+  if (norm_scale != norm_scale) return;
+  const float s2 = (float)(1. / (1. / seed->sigma2 + 1. / tau2));
+  const float m = s2 * (seed->mu / seed->sigma2 + x / tau2);
+  float C1 = (float)(seed->a / (seed->a + seed->b) * normal_pdf_quirk(x, seed->mu, norm_scale));
+  float C2 = (float)(seed->b / (seed->a + seed->b) * 1. / seed->z_range);
+  const float normalization_constant = C1 + C2;
+  C1 /= normalization_constant;
+  C2 /= normalization_constant;
+  const float f = (float)(C1 * (seed->a + 1.) / (seed->a + seed->b + 1.) + C2 * seed->a / (seed->a + seed->b + 1.));
+  const float e = (float)(C1 * (seed->a + 1.) * (seed->a + 2.) / ((seed->a + seed->b + 1.) * (seed->a + seed->b + 2.)) +
+                          C2 * seed->a * (seed->a + 1.0f) / ((seed->a + seed->b + 1.0f) * (seed->a + seed->b + 2.0f)));
+  const float mu_new = C1 * m + C2 * seed->mu;
+  seed->sigma2 = C1 * (s2 + m * m) + C2 * (seed->sigma2 + seed->mu * seed->mu) - mu_new * mu_new;
+  seed->mu = mu_new;
+  seed->a = (e - f) / (f - e / f);
+  seed->b = seed->a * (1.0f - f) / f;
+}
+
+// 44 B/seed of HBM traffic (20 B state + 8 B measurement read, 16 B written): purely HBM-bound
+__global__ void update_seed_kernel(int n, const float* __restrict__ x, const float* __restrict__ tau2,
+                                   float* __restrict__ a, float* __restrict__ b, float* __restrict__ mu,
+                                   const float* __restrict__ z_range, float* __restrict__ sigma2) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    SeedState s = {a[i], b[i], mu[i], z_range[i], sigma2[i]};
+    update_seed(x[i], tau2[i], &s);
+    a[i] = s.a; b[i] = s.b; mu[i] = s.mu; sigma2[i] = s.sigma2;
+  }
+}
+
+// S/depth_filter.cpp:396-416; PI = 3.14159265 (I/global.h:92)
+SVO_DEV double compute_tau(const double* t, const double* f, double z, double px_error_angle) {
+  const double PI_SVO = 3.14159265;
+  const double a[3] = {f[0] * z - t[0], f[1] * z - t[1], f[2] * z - t[2]};
+  const double t_norm = sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+  const double a_norm = sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+  const double alpha = acos(((f[0] * t[0] + f[1] * t[1]) + f[2] * t[2]) / t_norm);
+  const double beta = acos(((a[0] * -t[0] + a[1] * -t[1]) + a[2] * -t[2]) / (t_norm * a_norm));
+  const double beta_plus = beta + px_error_angle;
+  const double gamma_plus = PI_SVO - alpha - beta_plus;
+  const double z_plus = t_norm * sin(beta_plus) / sin(gamma_plus);
+  return z_plus - z;
+}
+
+struct Vec3 { double v[3]; };
+
+__global__ void compute_tau_kernel(int n, Vec3 t, const double* __restrict__ f, const double* __restrict__ z,
+                                   double px_error_angle, double* __restrict__ tau) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double fi[3] = {f[3 * (size_t)i], f[3 * (size_t)i + 1], f[3 * (size_t)i + 2]};
+    tau[i] = compute_tau(t.v, fi, z[i], px_error_angle);
+  }
+}
+
+// ---- matcher pieces ---------------------------------------------------------------------------
+// S/matcher.cpp:36-60 (A row-major)
+SVO_DEV void get_warp_matrix_affine(const Cam& cam, const double* px_ref, const double* f_ref, double depth_ref,
+                                    const double* T_cur_ref, int level_ref, double* A) {
+  const int halfpatch_size = 5;
+  const double xyz_ref[3] = {f_ref[0] * depth_ref, f_ref[1] * depth_ref, f_ref[2] * depth_ref};
+  double du[3], dv[3];
+  const double off = (double)halfpatch_size * (1 << level_ref);
+  cam2world(cam, px_ref[0] + off, px_ref[1] + 0.0 * (1 << level_ref), du);
+  cam2world(cam, px_ref[0] + 0.0 * (1 << level_ref), px_ref[1] + off, dv);
+  const double su = xyz_ref[2] / du[2];
+  du[0] *= su; du[1] *= su; du[2] *= su;
+  const double sv = xyz_ref[2] / dv[2];
+  dv[0] *= sv; dv[1] *= sv; dv[2] *= sv;
+  double p[3], px_cur[2], px_du[2], px_dv[2];
+  se3_act(T_cur_ref, xyz_ref, p); world2cam(cam, p, px_cur);
+  se3_act(T_cur_ref, du, p);      world2cam(cam, p, px_du);
+  se3_act(T_cur_ref, dv, p);      world2cam(cam, p, px_dv);
+  A[0] = (px_du[0] - px_cur[0]) / halfpatch_size;
+  A[2] = (px_du[1] - px_cur[1]) / halfpatch_size;
+  A[1] = (px_dv[0] - px_cur[0]) / halfpatch_size;
+  A[3] = (px_dv[1] - px_cur[1]) / halfpatch_size;
+}
+
+// S/matcher.cpp:123-136
+SVO_DEV bool depth_from_triangulation(const double* T_search_ref, const double* f_ref, const double* f_cur,
+                                      double* depth) {
+  double R[9];
+  const double t[3] = {T_search_ref[0], T_search_ref[1], T_search_ref[2]};
+  se3_rotation_matrix(T_search_ref, R);
+  double a0[3];
+  const double a1[3] = {f_cur[0], f_cur[1], f_cur[2]};
+  for (int i = 0; i < 3; ++i) a0[i] = (R[3 * i] * f_ref[0] + R[3 * i + 1] * f_ref[1]) + R[3 * i + 2] * f_ref[2];
+  const double m00 = (a0[0] * a0[0] + a0[1] * a0[1]) + a0[2] * a0[2];
+  const double m01 = (a0[0] * a1[0] + a0[1] * a1[1]) + a0[2] * a1[2];
+  const double m11 = (a1[0] * a1[0] + a1[1] * a1[1]) + a1[2] * a1[2];
+  const double det = m00 * m11 - m01 * m01;
+  if (det < 0.000001) return false;
+  const double invdet = 1.0 / det;
+  const double n00 = -(m11 * invdet), n01 = -(-m01 * invdet);
+  double r0[3];
+  for (int k = 0; k < 3; ++k) r0[k] = n00 * a0[k] + n01 * a1[k];
+  *depth = fabs((r0[0] * t[0] + r0[1] * t[1]) + r0[2] * t[2]);
+  return true;
+}
+
+struct DfFrame {
+  Cam cam;
+  double T_ref_cur[7];       // it->ftr->frame->T_f_w_ * frame->T_f_w_.inverse()   (depth_filter.cpp:264)
+  double T_cur_ref_vis[7];   // T_ref_cur.inverse()                                (:265)
+  double T_cur_ref[7];       // cur.T_f_w_ * ref.T_f_w_.inverse()                  (matcher.cpp:216)
+  double T_ref_inv[7];       // ref.T_f_w_.inverse()                                (:314)
+  double px_error_angle;
+  size_t ref_level_off[SVO_HIP_MAX_LEVELS];
+  size_t cur_level_off[SVO_HIP_MAX_LEVELS];
+  int n_pyr_levels, align_max_iter, max_epi_search_steps;
+  double conv_thresh;
+};
+
+// 8x8 ZMSSD of the LDS reference patch against the image patch whose top-left is `p`
+// (I/patch_score.h:186-219: integer exact).
+SVO_DEV int zmssd_8x8(const uint8_t* __restrict__ p, int stride, const uint32_t* patch_words, int sumA, int sumAA) {
+  uint32_t sumB = 0, sumBB = 0, sumAB = 0;
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    const uint8_t* row = p + y * stride;
+    uint32_t w0, w1;
+    __builtin_memcpy(&w0, row, 4);
+    __builtin_memcpy(&w1, row + 4, 4);
+    const uint32_t a0 = patch_words[2 * y], a1 = patch_words[2 * y + 1];
+    sumB = __builtin_amdgcn_udot4(w0, 0x01010101u, sumB, false);
+    sumB = __builtin_amdgcn_udot4(w1, 0x01010101u, sumB, false);
+    sumBB = __builtin_amdgcn_udot4(w0, w0, sumBB, false);
+    sumBB = __builtin_amdgcn_udot4(w1, w1, sumBB, false);
+    sumAB = __builtin_amdgcn_udot4(w0, a0, sumAB, false);
+    sumAB = __builtin_amdgcn_udot4(w1, a1, sumAB, false);
+  }
+  const int sB = (int)sumB, sBB = (int)sumBB, sAB = (int)sumAB;
+  return sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
+}
+
+// One wave per seed; 4 seeds per 256-thread block.
+__global__ __launch_bounds__(256) void depth_filter_update_kernel(
+    DfFrame fr, const uint8_t* __restrict__ ref_pyr, const uint8_t* __restrict__ cur_pyr, int n,
+    const double* __restrict__ px, const double* __restrict__ f, const int32_t* __restrict__ level,
+    float* __restrict__ sa, float* __restrict__ sb, float* __restrict__ smu, const float* __restrict__ sz_range,
+    float* __restrict__ ssigma2, int32_t* __restrict__ status, double* __restrict__ z_out,
+    double* __restrict__ xyz_world, int32_t* __restrict__ n_zmssd_out, int32_t* __restrict__ n_align_out) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_pwb[4][112];
+  __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][16];
+  const int wib = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wib;
+  if (i >= n) return;                      // wave-uniform; no block-level barrier is used below
+  const Cam cam = fr.cam;
+  uint8_t* pwb = s_pwb[wib];
+  uint32_t* patch_words = s_patch[wib];
+
+  int n_zmssd = 0, n_align = 0;
+  int st = SVO_HIP_SEED_NO_MATCH;
+  double z = 0.0;
+  const double fi[3] = {f[3 * (size_t)i], f[3 * (size_t)i + 1], f[3 * (size_t)i + 2]};
+  const double px_ref[2] = {px[2 * (size_t)i], px[2 * (size_t)i + 1]};
+  const int level_ref = level[i];
+  SeedState seed = {sa[i], sb[i], smu[i], sz_range[i], ssigma2[i]};
+
+  // ---- visibility in the current frame (depth_filter.cpp:264-275)
+  const double inv_mu = 1.0 / seed.mu;
+  const double pf[3] = {inv_mu * fi[0], inv_mu * fi[1], inv_mu * fi[2]};
+  double xyz_f[3];
+  se3_act(fr.T_cur_ref_vis, pf, xyz_f);
+  bool live = true;
+  if (xyz_f[2] < 0.0) { st = SVO_HIP_SEED_BEHIND; live = false; }
+  if (live) {
+    double pc[2];
+    world2cam(cam, xyz_f, pc);
+    const int ox = (int)pc[0], oy = (int)pc[1];
+    if (!(ox >= 0 && ox < cam.width && oy >= 0 && oy < cam.height)) { st = SVO_HIP_SEED_NOT_IN_FRAME; live = false; }
+  }
+  const float z_inv_min = seed.mu + sqrtf(seed.sigma2);
+  bool matched = false;
+  if (live) {
+    const float z_inv_lo = seed.mu - sqrtf(seed.sigma2);
+    const float z_inv_max = (z_inv_lo < 0.00000001f) ? 0.00000001f : z_inv_lo;
+    const double d_estimate = 1.0 / seed.mu, d_min = 1.0 / z_inv_min, d_max = 1.0 / z_inv_max;
+
+    // ---- Matcher::findEpipolarMatchDirect (matcher.cpp:207-355)
+    const double* T_cur_ref = fr.T_cur_ref;
+    double pa[3], pb[3], tmp[3];
+    tmp[0] = fi[0] * d_min; tmp[1] = fi[1] * d_min; tmp[2] = fi[2] * d_min;
+    se3_act(T_cur_ref, tmp, pa);
+    tmp[0] = fi[0] * d_max; tmp[1] = fi[1] * d_max; tmp[2] = fi[2] * d_max;
+    se3_act(T_cur_ref, tmp, pb);
+    const double Aep[2] = {pa[0] / pa[2], pa[1] / pa[2]};
+    const double Bep[2] = {pb[0] / pb[2], pb[1] / pb[2]};
+    const double epi_dir[2] = {Aep[0] - Bep[0], Aep[1] - Bep[1]};
+    double Acr[4];
+    get_warp_matrix_affine(cam, px_ref, fi, d_estimate, T_cur_ref, level_ref, Acr);
+    int search_level = 0;
+    {
+      double D = Acr[0] * Acr[3] - Acr[2] * Acr[1];
+      while (D > 3.0 && search_level < fr.n_pyr_levels - 1) { search_level += 1; D *= 0.25; }
+    }
+    double px_A[2], px_B[2];
+    world2cam_uv(cam, Aep[0], Aep[1], px_A);
+    world2cam_uv(cam, Bep[0], Bep[1], px_B);
+    double epi_length;
+    {
+      const double ex = px_A[0] - px_B[0], ey = px_A[1] - px_B[1];
+      epi_length = sqrt(ex * ex + ey * ey) / (1 << search_level);
+    }
+
+    // ---- warp::warpAffine of the 10x10 reference patch (matcher.cpp:83-116), lanes 0..99
+    {
+      const int rcols = cam.width >> level_ref, rrows = cam.height >> level_ref;
+      const uint8_t* img_ref = ref_pyr + fr.ref_level_off[level_ref];
+      const double det = Acr[0] * Acr[3] - Acr[2] * Acr[1];
+      const double invdet = 1.0 / det;
+      const float a00 = (float)(Acr[3] * invdet), a01 = (float)(-Acr[1] * invdet);
+      const float a10 = (float)(-Acr[2] * invdet), a11 = (float)(Acr[0] * invdet);
+      const bool warp_nan = a00 != a00;     // reference leaves the previous patch in place; we zero it
+      const float prx = (float)px_ref[0] / (1 << level_ref);
+      const float pry = (float)px_ref[1] / (1 << level_ref);
+      for (int k = lane; k < 100; k += 64) {
+        const int yy = k / 10, xx = k - yy * 10;
+        float ppx = (float)(xx - 5), ppy = (float)(yy - 5);
+        ppx *= (1 << search_level);
+        ppy *= (1 << search_level);
+        const float qx = (a00 * ppx + a01 * ppy) + prx;
+        const float qy = (a10 * ppx + a11 * ppy) + pry;
+        uint8_t val = 0;
+        // the reference reads out of bounds when qx/qy are NaN (inf inverse of a singular A);
+        // here such samples are 0
+        if (!warp_nan && qx >= 0 && qy >= 0 && qx < rcols - 1 && qy < rrows - 1)
+          val = (uint8_t)interpolate_8u(img_ref, rcols, qx, qy);
+        pwb[k] = val;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // createPatchFromPatchWithBorder (matcher.cpp:138-147): lane = pixel of the 8x8 patch
+      reinterpret_cast<uint8_t*>(patch_words)[lane] = pwb[((lane >> 3) + 1) * 10 + (lane & 7) + 1];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+
+    const int ccols = cam.width >> search_level, crows = cam.height >> search_level;
+    const uint8_t* cur_img = cur_pyr + fr.cur_level_off[search_level];
+    double px_cur[2] = {0, 0};
+    bool do_align = false;
+
+    if (epi_length < 2.0) {
+      px_cur[0] = (px_A[0] + px_B[0]) / 2.0;
+      px_cur[1] = (px_A[1] + px_B[1]) / 2.0;
+      do_align = true;
+    } else {
+      size_t n_steps = (size_t)(epi_length / 0.7);
+      const double step[2] = {epi_dir[0] / n_steps, epi_dir[1] / n_steps};
+      if (n_steps <= (size_t)fr.max_epi_search_steps) {
+        // reference patch statistics (ZMSSD ctor, patch_score.h:49-61)
+        int sumA, sumAA;
+        {
+          const uint32_t a = reinterpret_cast<uint8_t*>(patch_words)[lane];
+          sumA = group_sum<64>((int)a);
+          sumAA = group_sum<64>((int)(a * a));
+        }
+        ++n_steps;
+        double uv_base[2] = {Bep[0] - step[0], Bep[1] - step[1]};      // uv of step index `chunk0`
+        unsigned long long best_key = ~0ull;
+        double best_uv[2] = {0, 0};
+        int prev_tail_x = 0, prev_tail_y = 0;                            // last_checked_pxi entering the chunk
+        for (size_t chunk0 = 0; chunk0 < n_steps; chunk0 += 64) {
+          // uv_i by the same repeated addition as the serial loop: lane l adds `step` l times
+          double uv[2] = {uv_base[0], uv_base[1]};
+          for (int k = 0; k < 63; ++k) {
+            if (k < lane) { uv[0] += step[0]; uv[1] += step[1]; }
+          }
+          const size_t idx = chunk0 + lane;
+          const bool in_range = idx < n_steps;
+          double pxs[2];
+          world2cam_uv(cam, uv[0], uv[1], pxs);
+          const int pxi_x = (int)(pxs[0] / (1 << search_level) + 0.5);
+          const int pxi_y = (int)(pxs[1] / (1 << search_level) + 0.5);
+          // dedupe against the previous step (matcher.cpp:306-308): it never changes the arg-min,
+          // only the count of evaluations, which we keep for the work counters
+          int prev_x = __shfl_up(pxi_x, 1, 64), prev_y = __shfl_up(pxi_y, 1, 64);
+          if (lane == 0) { prev_x = prev_tail_x; prev_y = prev_tail_y; }
+          const bool dup = (pxi_x == prev_x && pxi_y == prev_y);
+          const bool inframe = is_in_frame_level(cam, pxi_x, pxi_y, 8, search_level);
+          // last_checked_pxi only advances on non-duplicates, so a duplicate run compares against the
+          // run's first element, which equals the previous element: the neighbour test is equivalent
+          int score = 0x7fffffff;
+          const bool eval = in_range && !dup && inframe;
+          if (eval) {
+            const uint8_t* cp = cur_img + (pxi_y - 4) * ccols + (pxi_x - 4);
+            score = zmssd_8x8(cp, ccols, patch_words, sumA, sumAA);
+          }
+          n_zmssd += __popcll(__ballot(eval));
+          if (eval && score < ZMSSD_THRESHOLD) {
+            const unsigned long long key = ((unsigned long long)(unsigned)score << 32) | (unsigned long long)idx;
+            if (key < best_key) { best_key = key; best_uv[0] = uv[0]; best_uv[1] = uv[1]; }
+          }
+          // next chunk: base = uv of lane 63 plus one more step; tail pixel = lane 63's pixel
+          const double n0 = __shfl(uv[0], 63, 64) + step[0], n1 = __shfl(uv[1], 63, 64) + step[1];
+          uv_base[0] = n0; uv_base[1] = n1;
+          prev_tail_x = __shfl(pxi_x, 63, 64); prev_tail_y = __shfl(pxi_y, 63, 64);
+        }
+        // wave arg-min on (score, index): the smallest score, earliest index on ties
+        unsigned long long k = best_key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned long long other = __shfl_xor(k, o, 64);
+          k = other < k ? other : k;
+        }
+        if (k != ~0ull) {
+          const int src = __ffsll((long long)__ballot(best_key == k)) - 1;
+          const double bu = __shfl(best_uv[0], src, 64), bv = __shfl(best_uv[1], src, 64);
+          world2cam_uv(cam, bu, bv, px_cur);
+          do_align = true;
+        }
+      }
+    }
+
+    if (do_align) {
+      double us = px_cur[0] / (1 << search_level), vs = px_cur[1] / (1 << search_level);
+      const bool res = align2d_wave(cur_img, ccols, crows, ccols, pwb, fr.align_max_iter, &us, &vs, &n_align);
+      if (res) {
+        px_cur[0] = us * (1 << search_level);
+        px_cur[1] = vs * (1 << search_level);
+        double fc[3];
+        cam2world(cam, px_cur[0], px_cur[1], fc);
+        matched = depth_from_triangulation(T_cur_ref, fi, fc, &z);
+      }
+    }
+
+    if (!matched) {
+      seed.b += 1.0f;                                   // depth_filter.cpp:286
+      st = SVO_HIP_SEED_NO_MATCH;
+      z = 0.0;
+    } else {
+      // ---- computeTau + updateSeed + convergence (depth_filter.cpp:294-337)
+      const double tau = compute_tau(fr.T_ref_cur, fi, z, fr.px_error_angle);
+      const double zmt = z - tau;
+      const double tau_inverse = 0.5 * (1.0 / (0.0000001 < zmt ? zmt : 0.0000001) - 1.0 / (z + tau));
+      update_seed((float)(1. / z), (float)(tau_inverse * tau_inverse), &seed);
+      if ((double)sqrtf(seed.sigma2) < seed.z_range / fr.conv_thresh) {
+        st = SVO_HIP_SEED_CONVERGED;
+        if (xyz_world && lane == 0) {
+          const double im = 1.0 / seed.mu;
+          const double pfw[3] = {fi[0] * im, fi[1] * im, fi[2] * im};
+          double xw[3];
+          se3_act(fr.T_ref_inv, pfw, xw);
+          xyz_world[3 * (size_t)i] = xw[0]; xyz_world[3 * (size_t)i + 1] = xw[1]; xyz_world[3 * (size_t)i + 2] = xw[2];
+        }
+      } else if (z_inv_min != z_inv_min) {
+        st = SVO_HIP_SEED_NAN;
+      } else {
+        st = SVO_HIP_SEED_UPDATED;
+      }
+    }
+  }
+
+  if (lane == 0) {
+    sa[i] = seed.a; sb[i] = seed.b; smu[i] = seed.mu; ssigma2[i] = seed.sigma2;
+    status[i] = st;
+    if (z_out) z_out[i] = z;
+    if (n_zmssd_out) n_zmssd_out[i] = n_zmssd;
+    if (n_align_out) n_align_out[i] = n_align;
+  }
+}
+
+int grid_for(int n, int block) {
+  long long g = ((long long)n + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int svo_hip_align2d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int slot, int level, int n,
+                              const uint8_t* pwb_dev, const uint8_t* ref_patch_dev, int n_iter, double* px_dev,
+                              uint8_t* converged_dev, int32_t* iters_dev) {
+  if (!ctx || !cur) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, slot >= 0 && slot < cur->batch && level >= 0 && level < cur->n_levels);
+  SVO_REQUIRE(ctx, n >= 0 && n_iter >= 0);
+  if (n == 0) return SVO_HIP_OK;
+  SVO_REQUIRE(ctx, pwb_dev && px_dev && converged_dev);
+  (void)ref_patch_dev;   // the 8x8 patch is the interior of the bordered one (matcher.cpp:138-147)
+  const uint8_t* img = cur->base + (size_t)slot * cur->pyr_bytes + cur->level_offset[level];
+  hipLaunchKernelGGL(align2d_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, img, cur->width >> level,
+                     cur->height >> level, n, pwb_dev, n_iter, px_dev, converged_dev, iters_dev);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+int svo_hip_align2d_batch(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int slot, int level, int n,
+                          const uint8_t* pwb, const uint8_t* ref_patch, int n_iter, double* px, uint8_t* converged,
+                          int32_t* iters) {
+  if (!ctx || !cur) return SVO_HIP_ERR_INVALID;
+  if (n == 0) return SVO_HIP_OK;
+  SVO_REQUIRE(ctx, n > 0 && pwb && px && converged);
+  (void)ref_patch;
+  void *d_pwb = nullptr, *d_px = nullptr, *d_conv = nullptr, *d_it = nullptr;
+  int rc = svo_hip_malloc(ctx, &d_pwb, (size_t)n * 100);
+  if (rc == SVO_HIP_OK) rc = svo_hip_malloc(ctx, &d_px, (size_t)n * 16);
+  if (rc == SVO_HIP_OK) rc = svo_hip_malloc(ctx, &d_conv, (size_t)n);
+  if (rc == SVO_HIP_OK) rc = svo_hip_malloc(ctx, &d_it, (size_t)n * 4);
+  if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d_pwb, pwb, (size_t)n * 100);
+  if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d_px, px, (size_t)n * 16);
+  if (rc == SVO_HIP_OK)
+    rc = svo_hip_align2d_batch_dev(ctx, cur, slot, level, n, (const uint8_t*)d_pwb, nullptr, n_iter, (double*)d_px,
+                                   (uint8_t*)d_conv, (int32_t*)d_it);
+  if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, px, d_px, (size_t)n * 16);
+  if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, converged, d_conv, (size_t)n);
+  if (rc == SVO_HIP_OK && iters) rc = svo_hip_memcpy_d2h(ctx, iters, d_it, (size_t)n * 4);
+  (void)svo_hip_free(ctx, d_pwb); (void)svo_hip_free(ctx, d_px); (void)svo_hip_free(ctx, d_conv); (void)svo_hip_free(ctx, d_it);
+  return rc;
+}
+
+int svo_hip_update_seed_batch_dev(svo_hip_ctx* ctx, int n, const float* x, const float* tau2, float* a, float* b,
+                                  float* mu, const float* z_range, float* sigma2) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n >= 0);
+  if (n == 0) return SVO_HIP_OK;
+  SVO_REQUIRE(ctx, x && tau2 && a && b && mu && z_range && sigma2);
+  hipLaunchKernelGGL(update_seed_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, x, tau2, a, b, mu,
+                     z_range, sigma2);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+int svo_hip_compute_tau_batch_dev(svo_hip_ctx* ctx, int n, const double T_ref_cur[7], const double* f,
+                                  const double* z, double px_error_angle, double* tau) {
+  if (!ctx || !T_ref_cur) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n >= 0);
+  if (n == 0) return SVO_HIP_OK;
+  SVO_REQUIRE(ctx, f && z && tau);
+  Vec3 t = {{T_ref_cur[0], T_ref_cur[1], T_ref_cur[2]}};
+  hipLaunchKernelGGL(compute_tau_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, t, f, z,
+                     px_error_angle, tau);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+// host-side SE3 helpers (same arithmetic as the device ones; this TU is built with -ffp-contract=off)
+static void h_cross(const double* a, const double* b, double* o) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static void h_rot(const double* q, const double* p, double* o) {
+  double uv[3], quv[3];
+  h_cross(q, p, uv);
+  uv[0] = uv[0] + uv[0]; uv[1] = uv[1] + uv[1]; uv[2] = uv[2] + uv[2];
+  h_cross(q, uv, quv);
+  double x = (p[0] + q[3] * uv[0]) + quv[0], y = (p[1] + q[3] * uv[1]) + quv[1], z = (p[2] + q[3] * uv[2]) + quv[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static void h_inv(const double* T, double* o) {
+  double qi[4] = {-T[3], -T[4], -T[5], T[6]}, rt[3];
+  h_rot(qi, T, rt);
+  o[0] = -rt[0]; o[1] = -rt[1]; o[2] = -rt[2]; o[3] = qi[0]; o[4] = qi[1]; o[5] = qi[2]; o[6] = qi[3];
+}
+static void h_mul(const double* A, const double* B, double* o) {
+  const double* a = A + 3; const double* b = B + 3;
+  double q[4] = {a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1], a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2],
+                 a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0], a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]};
+  double rt[3];
+  h_rot(a, B, rt);
+  double t0 = A[0] + rt[0], t1 = A[1] + rt[1], t2 = A[2] + rt[2];
+  o[0] = t0; o[1] = t1; o[2] = t2; o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3];
+}
+
+int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,
+                                    const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                                    const double T_ref_w[7], const double T_cur_w[7], int n, const double* px,
+                                    const double* f, const int32_t* level, float* a, float* b, float* mu,
+                                    const float* z_range, float* sigma2, const svo_hip_df_params* prm,
+                                    int32_t* status, double* z, double* xyz_world, int32_t* n_zmssd,
+                                    int32_t* n_align_iters) {
+  if (!ctx || !ref || !cur || !cam || !T_ref_w || !T_cur_w || !prm) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, ref_slot >= 0 && ref_slot < ref->batch && cur_slot >= 0 && cur_slot < cur->batch);
+  SVO_REQUIRE(ctx, ref->width == cam->width && ref->height == cam->height);
+  SVO_REQUIRE(ctx, cur->width == cam->width && cur->height == cam->height);
+  SVO_REQUIRE(ctx, prm->n_pyr_levels >= 1 && prm->n_pyr_levels <= ref->n_levels && prm->n_pyr_levels <= cur->n_levels);
+  SVO_REQUIRE(ctx, prm->align_max_iter >= 0 && prm->max_epi_search_steps >= 0);
+  SVO_REQUIRE(ctx, cam->distortion == 0);      // cam2world needs the iterative undistort otherwise
+  SVO_REQUIRE(ctx, n >= 0);
+  if (n == 0) return SVO_HIP_OK;
+  SVO_REQUIRE(ctx, px && f && level && a && b && mu && z_range && sigma2 && status);
+  DfFrame fr;
+  memset(&fr, 0, sizeof(fr));
+  fr.cam = svo_make_cam(*cam);
+  double T_cur_inv[7];
+  h_inv(T_cur_w, T_cur_inv);
+  h_mul(T_ref_w, T_cur_inv, fr.T_ref_cur);
+  h_inv(fr.T_ref_cur, fr.T_cur_ref_vis);
+  h_inv(T_ref_w, fr.T_ref_inv);
+  h_mul(T_cur_w, fr.T_ref_inv, fr.T_cur_ref);
+  const double focal_length = fabs(cam->fx);
+  fr.px_error_angle = atan(1.0 / (2.0 * focal_length)) * 2.0;       // depth_filter.cpp:245-247
+  for (int l = 0; l < ref->n_levels; ++l) fr.ref_level_off[l] = ref->level_offset[l];
+  for (int l = 0; l < cur->n_levels; ++l) fr.cur_level_off[l] = cur->level_offset[l];
+  fr.n_pyr_levels = prm->n_pyr_levels;
+  fr.align_max_iter = prm->align_max_iter;
+  fr.max_epi_search_steps = prm->max_epi_search_steps;
+  fr.conv_thresh = prm->seed_convergence_sigma2_thresh;
+  hipLaunchKernelGGL(depth_filter_update_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, fr,
+                     ref->base + (size_t)ref_slot * ref->pyr_bytes, cur->base + (size_t)cur_slot * cur->pyr_bytes, n, px,
+                     f, level, a, b, mu, z_range, sigma2, status, z, xyz_world, n_zmssd, n_align_iters);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+// svo_device_math.h -- SE3/SO3, pinhole camera and 6x6 LDLT for gfx950 device code.
+//
+// Semantics follow the reference statement by statement (quirks included) so that
+// fp64 index-critical chains (projection -> floor/round -> pixel index) round the
+// same way as the CPU path; the library is built with -ffp-contract=off.
+//   SE3/SO3:  I/SE3.h:35-61,153-182, I/SO3.h:468-488,523-526
+//   camera:   S/pinhole_camera.cpp:44-106, I/abstract_camera.h:52-70
+//   LDLT:     Eigen 3.4.0 Cholesky/LDLT.h:297-403,574-613 (as used by
+//             SparseImgAlign::solve, S/sparse_img_align.cpp:291-297)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/svo_hip.h"
+
+#define SVO_DEV __device__ __forceinline__
+
+namespace svo_dev {
+
+struct Cam {
+  double fx, fy, cx, cy;
+  double d[5];
+  int distortion;
+  int width, height;
+};
+
+SVO_DEV void cross3(const double* a, const double* b, double* o) {
+  double x = a[1] * b[2] - a[2] * b[1];
+  double y = a[2] * b[0] - a[0] * b[2];
+  double z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+
+// q = {x,y,z,w}.  p + w*uv + q x uv with uv = 2 (q x p)   (I/SO3.h:478-483)
+SVO_DEV void so3_rotate(const double* q, const double* p, double* o) {
+  double uv[3], quv[3];
+  cross3(q, p, uv);
+  uv[0] = uv[0] + uv[0]; uv[1] = uv[1] + uv[1]; uv[2] = uv[2] + uv[2];
+  cross3(q, uv, quv);
+  double x = (p[0] + q[3] * uv[0]) + quv[0];
+  double y = (p[1] + q[3] * uv[1]) + quv[1];
+  double z = (p[2] + q[3] * uv[2]) + quv[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+
+SVO_DEV void so3_mul(const double* a, const double* b, double* o) {
+  double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+
+// T = {tx,ty,tz,qx,qy,qz,qw}
+SVO_DEV void se3_mul(const double* A, const double* B, double* out) {
+  double q[4], rt[3];
+  so3_mul(A + 3, B + 3, q);
+  so3_rotate(A + 3, B, rt);
+  double t0 = A[0] + rt[0], t1 = A[1] + rt[1], t2 = A[2] + rt[2];
+  out[0] = t0; out[1] = t1; out[2] = t2;
+  out[3] = q[0]; out[4] = q[1]; out[5] = q[2]; out[6] = q[3];
+}
+
+SVO_DEV void se3_inverse(const double* T, double* out) {
+  double qi[4] = {-T[3], -T[4], -T[5], T[6]};
+  double rt[3];
+  so3_rotate(qi, T, rt);
+  out[0] = -rt[0]; out[1] = -rt[1]; out[2] = -rt[2];
+  out[3] = qi[0]; out[4] = qi[1]; out[5] = qi[2]; out[6] = qi[3];
+}
+
+SVO_DEV void se3_act(const double* T, const double* p, double* out) {
+  double r[3];
+  so3_rotate(T + 3, p, r);
+  out[0] = T[0] + r[0]; out[1] = T[1] + r[1]; out[2] = T[2] + r[2];
+}
+
+// I/SE3.h:153-182.  theta == 0 gives a NaN translation, as in the reference.
+SVO_DEV void se3_exp(const double* l, double* out) {
+  const double p[3] = {l[0], l[1], l[2]};
+  const double r[3] = {l[3], l[4], l[5]};
+  double theta_sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  double theta = sqrt(theta_sq);
+  double half_theta = 0.5 * theta;
+  double imag_factor, real_factor;
+  if (theta < 1e-10) {
+    double theta_po4 = theta_sq * theta_sq;
+    imag_factor = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
+    real_factor = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * theta_po4;
+  } else {
+    double sin_half_theta = sin(half_theta);
+    imag_factor = sin_half_theta / theta;
+    real_factor = cos(half_theta);
+  }
+  double rxp[3], rxrxp[3];
+  cross3(r, p, rxp);
+  cross3(r, rxp, rxrxp);
+  double c1 = (1 - cos(theta)) / theta_sq;
+  double c2 = (theta - sin(theta)) / (theta_sq * theta);
+  out[0] = (p[0] + c1 * rxp[0]) + c2 * rxrxp[0];
+  out[1] = (p[1] + c1 * rxp[1]) + c2 * rxrxp[1];
+  out[2] = (p[2] + c1 * rxp[2]) + c2 * rxrxp[2];
+  out[3] = imag_factor * r[0];
+  out[4] = imag_factor * r[1];
+  out[5] = imag_factor * r[2];
+  out[6] = real_factor;
+}
+
+// row-major 3x3 (I/SO3.h:391-406)
+SVO_DEV void se3_rotation_matrix(const double* T, double* m) {
+  double x = T[3], y = T[4], z = T[5], w = T[6];
+  double x2 = x * x, y2 = y * y, z2 = z * z;
+  double xy = x * y, xz = x * z, yz = y * z;
+  double wx = w * x, wy = w * y, wz = w * z;
+  m[0] = 1.0 - 2.0 * (y2 + z2); m[1] = 2.0 * (xy - wz);       m[2] = 2.0 * (xz + wy);
+  m[3] = 2.0 * (xy + wz);       m[4] = 1.0 - 2.0 * (x2 + z2); m[5] = 2.0 * (yz - wx);
+  m[6] = 2.0 * (xz - wy);       m[7] = 2.0 * (yz + wx);       m[8] = 1.0 - 2.0 * (x2 + y2);
+}
+
+// unit-plane (u,v) -> pixel, with the radtan model when enabled (S/pinhole_camera.cpp:79-106)
+SVO_DEV void world2cam_uv(const Cam& c, double u, double v, double* px) {
+  if (!c.distortion) {
+    px[0] = c.fx * u + c.cx;
+    px[1] = c.fy * v + c.cy;
+  } else {
+    double x = u, y = v;
+    double r2 = x * x + y * y;
+    double r4 = r2 * r2;
+    double r6 = r4 * r2;
+    double a1 = 2 * x * y;
+    double a2 = r2 + 2 * x * x;
+    double a3 = r2 + 2 * y * y;
+    double cdist = 1 + c.d[0] * r2 + c.d[1] * r4 + c.d[4] * r6;
+    double xd = x * cdist + c.d[2] * a1 + c.d[3] * a2;
+    double yd = y * cdist + c.d[2] * a3 + c.d[3] * a1;
+    px[0] = xd * c.fx + c.cx;
+    px[1] = yd * c.fy + c.cy;
+  }
+}
+
+SVO_DEV void world2cam(const Cam& c, const double* xyz, double* px) {
+  world2cam_uv(c, xyz[0] / xyz[2], xyz[1] / xyz[2], px);
+}
+
+// distortion-free branch (S/pinhole_camera.cpp:47-52,64)
+SVO_DEV void cam2world(const Cam& c, double u, double v, double* f) {
+  double x = (u - c.cx) / c.fx;
+  double y = (v - c.cy) / c.fy;
+  double z = 1.0;
+  double n2 = x * x + y * y + z * z;
+  if (n2 > 0.0) {
+    double n = sqrt(n2);
+    f[0] = x / n; f[1] = y / n; f[2] = z / n;
+  } else {
+    f[0] = x; f[1] = y; f[2] = z;
+  }
+}
+
+SVO_DEV bool is_in_frame_level(const Cam& c, int ox, int oy, int boundary, int level) {
+  return ox >= boundary && ox < c.width / (1 << level) - boundary && oy >= boundary &&
+         oy < c.height / (1 << level) - boundary;
+}
+
+// I/frame.h:110-132, 2x6 row-major
+SVO_DEV void jacobian_xyz2uv(const double* p, double* J) {
+  const double x = p[0], y = p[1];
+  const double z_inv = 1. / p[2];
+  const double z_inv_2 = z_inv * z_inv;
+  J[0] = -z_inv;
+  J[1] = 0.0;
+  J[2] = x * z_inv_2;
+  J[3] = y * J[2];
+  J[4] = -(1.0 + x * J[2]);
+  J[5] = y * z_inv;
+  J[6] = 0.0;
+  J[7] = -z_inv;
+  J[8] = y * z_inv_2;
+  J[9] = 1.0 + y * J[8];
+  J[10] = -J[3];
+  J[11] = -x * z_inv;
+}
+
+// Pivoted LDL^T of a symmetric 6x6 (lower part read) and solve, one thread.
+SVO_DEV void ldlt6_solve(const double* Hin, const double* b, double* x) {
+  constexpr int N = 6;
+  double m[N][N];
+  int tr[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) m[i][j] = Hin[i * N + j];
+  bool all_zero = false;
+  for (int k = 0; k < N && !all_zero; ++k) {
+    int big = k;
+    double best = fabs(m[k][k]);
+    for (int i = k + 1; i < N; ++i)
+      if (fabs(m[i][i]) > best) { best = fabs(m[i][i]); big = i; }
+    tr[k] = big;
+    if (k != big) {
+      for (int j = 0; j < k; ++j) { double t = m[k][j]; m[k][j] = m[big][j]; m[big][j] = t; }
+      for (int i = big + 1; i < N; ++i) { double t = m[i][k]; m[i][k] = m[i][big]; m[i][big] = t; }
+      { double t = m[k][k]; m[k][k] = m[big][big]; m[big][big] = t; }
+      for (int i = k + 1; i < big; ++i) { double t = m[i][k]; m[i][k] = m[big][i]; m[big][i] = t; }
+    }
+    if (k > 0) {
+      double temp[N];
+      for (int i = 0; i < k; ++i) temp[i] = m[i][i] * m[k][i];
+      double s = 0.0;
+      for (int i = 0; i < k; ++i) s += m[k][i] * temp[i];
+      m[k][k] -= s;
+      for (int r = k + 1; r < N; ++r) {
+        double a = 0.0;
+        for (int i = 0; i < k; ++i) a += m[r][i] * temp[i];
+        m[r][k] -= a;
+      }
+    }
+    double akk = m[k][k];
+    bool valid = fabs(akk) > 0.0;
+    if (k == 0 && !valid) {
+      for (int j = 0; j < N; ++j) tr[j] = j;
+      all_zero = true;
+    } else if (valid) {
+      for (int r = k + 1; r < N; ++r) m[r][k] /= akk;
+    }
+  }
+  double d[N];
+  for (int i = 0; i < N; ++i) d[i] = b[i];
+  for (int k = 0; k < N; ++k)
+    if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+  for (int i = 0; i < N; ++i) {
+    double s = d[i];
+    for (int j = 0; j < i; ++j) s -= m[i][j] * d[j];
+    d[i] = s;
+  }
+  const double tol = 2.2250738585072014e-308;   // DBL_MIN: pseudo-inverse of D
+  for (int i = 0; i < N; ++i) {
+    if (fabs(m[i][i]) > tol) d[i] /= m[i][i]; else d[i] = 0.0;
+  }
+  for (int i = N - 1; i >= 0; --i) {
+    double s = d[i];
+    for (int j = i + 1; j < N; ++j) s -= m[j][i] * d[j];
+    d[i] = s;
+  }
+  for (int k = N - 1; k >= 0; --k)
+    if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+  for (int i = 0; i < N; ++i) x[i] = d[i];
+}
+
+// vk::interpolateMat_8u (I/vision.h:19-36)
+SVO_DEV float interpolate_8u(const uint8_t* img, int stride, float u, float v) {
+  int x = (int)floorf(u);
+  int y = (int)floorf(v);
+  float subpix_x = u - x;
+  float subpix_y = v - y;
+  float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
+  float w01 = (1.0f - subpix_x) * subpix_y;
+  float w10 = subpix_x * (1.0f - subpix_y);
+  float w11 = 1.0f - w00 - w01 - w10;
+  const uint8_t* ptr = img + y * stride + x;
+  return w00 * ptr[0] + w01 * ptr[stride] + w10 * ptr[1] + w11 * ptr[stride + 1];
+}
+
+// butterfly sum over `width` consecutive lanes (width = 16 or 64), all lanes get the sum
+template <int WIDTH>
+SVO_DEV double group_sum(double v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int WIDTH>
+SVO_DEV float group_sum(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int WIDTH>
+SVO_DEV int group_sum(int v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace svo_dev

@@ -1,0 +1,50 @@
+// svo_internal.h -- host-side objects behind the opaque C-ABI handles.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/svo_hip.h"
+#include "svo_device_math.h"
+
+struct svo_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  char err[512] = {0};
+};
+
+struct svo_hip_pyramid {
+  svo_hip_ctx* ctx = nullptr;
+  int width = 0, height = 0, n_levels = 0, batch = 0;
+  size_t level_offset[SVO_HIP_MAX_LEVELS + 1] = {0};   // byte offset of each level inside one pyramid
+  size_t pyr_bytes = 0;                                // bytes of one pyramid (16-byte aligned levels)
+  uint8_t* base = nullptr;                             // device
+};
+
+inline int svo_fail(svo_hip_ctx* ctx, int code, const char* what, const char* detail) {
+  if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, detail ? detail : "");
+  return code;
+}
+
+#define SVO_CHECK_HIP(ctx, expr)                                                        \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) return svo_fail((ctx), SVO_HIP_ERR_DEVICE, #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+#define SVO_REQUIRE(ctx, cond)                                                          \
+  do {                                                                                  \
+    if (!(cond)) return svo_fail((ctx), SVO_HIP_ERR_INVALID, "invalid argument", #cond); \
+  } while (0)
+
+inline svo_dev::Cam svo_make_cam(const svo_hip_camera& c) {
+  svo_dev::Cam d;
+  d.fx = c.fx; d.fy = c.fy; d.cx = c.cx; d.cy = c.cy;
+  for (int i = 0; i < 5; ++i) d.d[i] = c.d[i];
+  d.distortion = c.distortion;
+  d.width = c.width; d.height = c.height;
+  return d;
+}

@@ -1,0 +1,357 @@
+"""ctypes binding of csrc/libsvo_hip.so (the C-ABI of include/svo_hip.h).
+
+This is the host-side mirror used by tests and bench.py; it adds nothing to the
+computation.  There is NO CPU fallback: if the library is missing or no GPU is
+present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsvo_hip.so")
+MAX_LEVELS = 8
+REDUCE_DOUBLES = 32
+
+SEED_BEHIND, SEED_NOT_IN_FRAME, SEED_NO_MATCH, SEED_UPDATED, SEED_CONVERGED, SEED_NAN = range(6)
+
+
+class SvoHipError(RuntimeError):
+    pass
+
+
+class CCamera(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("fx", C.c_double), ("fy", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("d", C.c_double * 5), ("distortion", C.c_int)]
+
+
+class CSiaParams(C.Structure):
+    _fields_ = [("max_level", C.c_int), ("min_level", C.c_int), ("n_iter", C.c_int), ("eps", C.c_double),
+                ("early_stop", C.c_int)]
+
+
+class CSiaResult(C.Structure):
+    _fields_ = [("T_cur_w", C.c_double * 7), ("n_tracked", C.c_uint64), ("H", C.c_double * 36),
+                ("chi2", C.c_double), ("stop", C.c_int), ("iters", C.c_int * MAX_LEVELS),
+                ("n_precompute_patches", C.c_uint64), ("n_residual_patches", C.c_uint64)]
+
+
+class CDfParams(C.Structure):
+    _fields_ = [("n_pyr_levels", C.c_int), ("align_max_iter", C.c_int), ("max_epi_search_steps", C.c_int),
+                ("seed_convergence_sigma2_thresh", C.c_double)]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libsvo_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SvoHipError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C android_svo_amd/csrc)" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.svo_hip_last_error.restype = C.c_char_p
+        _lib.svo_hip_version.restype = C.c_char_p
+        _lib.svo_hip_ctx_stream.restype = C.c_void_p
+    return _lib
+
+
+def make_camera(cam, dist: Optional[Sequence[float]] = None) -> CCamera:
+    c = CCamera()
+    c.width, c.height = int(cam.width), int(cam.height)
+    c.fx, c.fy, c.cx, c.cy = cam.fx, cam.fy, cam.cx, cam.cy
+    d = list(dist) if dist is not None else [0.0] * 5
+    for i in range(5):
+        c.d[i] = d[i]
+    c.distortion = 1 if abs(d[0]) > 1e-7 else 0     # pinhole_camera.cpp:27
+    return c
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Context:
+    """svo_hip_ctx: one device + one stream."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.svo_hip_ctx_create(C.byref(self.h), C.c_int(device), C.c_void_p(stream))
+        if rc != 0:
+            raise SvoHipError("svo_hip_ctx_create failed (%d): no usable MI355X / HIP device %d" % (rc, device))
+
+    def check(self, rc: int, what: str = ""):
+        if rc != 0:
+            msg = self.lib.svo_hip_last_error(self.h)
+            raise SvoHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    def sync(self):
+        self.check(self.lib.svo_hip_ctx_sync(self.h), "sync")
+
+    @property
+    def stream(self) -> int:
+        return self.lib.svo_hip_ctx_stream(self.h) or 0
+
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self.check(self.lib.svo_hip_malloc(self.h, C.byref(p), C.c_size_t(nbytes)), "malloc")
+        return p.value
+
+    def free(self, ptr: int):
+        self.check(self.lib.svo_hip_free(self.h, C.c_void_p(ptr)), "free")
+
+    def to_device(self, arr: np.ndarray) -> "DeviceArray":
+        return DeviceArray(self, arr=np.ascontiguousarray(arr))
+
+    def empty(self, shape, dtype) -> "DeviceArray":
+        return DeviceArray(self, shape=shape, dtype=dtype)
+
+    def close(self):
+        if self.h:
+            self.lib.svo_hip_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class DeviceArray:
+    """A typed device allocation owned through the C-ABI (svo_hip_malloc)."""
+
+    def __init__(self, ctx: Context, arr: Optional[np.ndarray] = None, shape=None, dtype=None):
+        self.ctx = ctx
+        if arr is not None:
+            shape, dtype = arr.shape, arr.dtype
+        self.shape = tuple(np.atleast_1d(shape)) if not isinstance(shape, tuple) else shape
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = ctx.malloc(max(self.nbytes, 1))
+        if arr is not None:
+            self.upload(arr)
+
+    def upload(self, arr: np.ndarray):
+        a = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert a.nbytes == self.nbytes
+        self.ctx.check(self.ctx.lib.svo_hip_memcpy_h2d(self.ctx.h, C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p),
+                                                       C.c_size_t(self.nbytes)), "h2d")
+        self.ctx.sync()        # the source numpy buffer may be a temporary
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.ctx.check(self.ctx.lib.svo_hip_memcpy_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+                                                       C.c_size_t(self.nbytes)), "d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.free(self.ptr)
+            self.ptr = 0
+
+
+class Pyramid:
+    """svo_hip_pyramid: a batch of image pyramids resident in HBM."""
+
+    def __init__(self, ctx: Context, width: int, height: int, n_levels: int = 5, batch: int = 1):
+        self.ctx, self.width, self.height, self.n_levels, self.batch = ctx, width, height, n_levels, batch
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.svo_hip_pyramid_create(ctx.h, width, height, n_levels, batch, C.byref(self.h)), "pyramid_create")
+
+    def upload(self, slot: int, levels: List[np.ndarray]):
+        assert len(levels) >= self.n_levels
+        arr = (C.POINTER(C.c_uint8) * MAX_LEVELS)()
+        keep = []
+        for l in range(self.n_levels):
+            im = np.ascontiguousarray(levels[l], dtype=np.uint8)
+            assert im.shape == (self.height >> l, self.width >> l), (im.shape, l)
+            keep.append(im)
+            arr[l] = _ptr(im, C.c_uint8)
+        self.ctx.check(self.ctx.lib.svo_hip_pyramid_upload(self.h, slot, arr), "pyramid_upload")
+        self.ctx.sync()
+
+    def upload_level0_and_build(self, slot: int, img: np.ndarray):
+        im = np.ascontiguousarray(img, dtype=np.uint8)
+        assert im.shape == (self.height, self.width)
+        self.ctx.check(self.ctx.lib.svo_hip_pyramid_upload_level0_and_build(self.h, slot, _ptr(im, C.c_uint8)), "pyramid_build")
+        self.ctx.sync()
+
+    def download_level(self, slot: int, level: int) -> np.ndarray:
+        out = np.empty((self.height >> level, self.width >> level), dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.svo_hip_pyramid_download_level(self.h, slot, level, _ptr(out, C.c_uint8)), "pyramid_download")
+        return out
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.svo_hip_pyramid_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class SparseImgAlign:
+    """Batched svo::SparseImgAlign (I/sparse_img_align.h:33-79) over `batch` frame pairs."""
+
+    def __init__(self, ctx: Context, batch: int, max_features: int):
+        self.ctx, self.batch, self.max_features = ctx, batch, max_features
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.svo_hip_sia_create(ctx.h, batch, max_features, C.byref(self.h)), "sia_create")
+
+    def set_frames(self, ref: Pyramid, cur: Pyramid):
+        self.ref, self.cur = ref, cur
+        self.ctx.check(self.ctx.lib.svo_hip_sia_set_frames(self.h, ref.h, cur.h), "sia_set_frames")
+
+    def upload_pair(self, slot: int, fp, T_cur_w_init=None):
+        px, f, pos = _f64(fp.px), _f64(fp.f), _f64(fp.pos)
+        hp = np.ascontiguousarray(fp.has_point, dtype=np.uint8)
+        L = self.ctx.lib
+        self.ctx.check(L.svo_hip_sia_upload_features(self.h, slot, len(px), _ptr(px, C.c_double), _ptr(f, C.c_double),
+                                                     _ptr(pos, C.c_double), _ptr(hp, C.c_uint8)), "sia_upload_features")
+        cam = make_camera(fp.cam, getattr(fp, "dist", None))
+        Tr = _f64(fp.T_ref_w)
+        Ti = _f64(fp.T_cur_w_init if T_cur_w_init is None else T_cur_w_init)
+        self.ctx.check(L.svo_hip_sia_upload_poses(self.h, slot, C.byref(cam), _ptr(Tr, C.c_double), _ptr(Ti, C.c_double)),
+                       "sia_upload_poses")
+        self.ctx.sync()
+
+    def set_shard(self, rank: int, world: int):
+        self.ctx.check(self.ctx.lib.svo_hip_sia_set_shard(self.h, rank, world), "sia_set_shard")
+
+    @staticmethod
+    def params(max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=True) -> CSiaParams:
+        return CSiaParams(max_level, min_level, n_iter, eps, 1 if early_stop else 0)
+
+    def run(self, n_slots: int, prm: CSiaParams):
+        self.ctx.check(self.ctx.lib.svo_hip_sia_run(self.h, n_slots, C.byref(prm)), "sia_run")
+
+    # stepwise form
+    def begin(self, n_slots, prm): self.ctx.check(self.ctx.lib.svo_hip_sia_begin(self.h, n_slots, C.byref(prm)), "sia_begin")
+    def level_begin(self, level): self.ctx.check(self.ctx.lib.svo_hip_sia_level_begin(self.h, level), "sia_level_begin")
+    def accumulate(self): self.ctx.check(self.ctx.lib.svo_hip_sia_accumulate(self.h), "sia_accumulate")
+    def solve_update(self): self.ctx.check(self.ctx.lib.svo_hip_sia_solve_update(self.h), "sia_solve_update")
+    def finish(self): self.ctx.check(self.ctx.lib.svo_hip_sia_finish(self.h), "sia_finish")
+
+    def reduce_buffer(self):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        self.ctx.check(self.ctx.lib.svo_hip_sia_reduce_buffer(self.h, C.byref(p), C.byref(n)), "sia_reduce_buffer")
+        return p.value, n.value
+
+    def set_reduce_buffer(self, dev_ptr: int):
+        self.ctx.check(self.ctx.lib.svo_hip_sia_set_reduce_buffer(self.h, C.c_void_p(dev_ptr)), "sia_set_reduce_buffer")
+
+    def download(self, slot: int) -> CSiaResult:
+        out = CSiaResult()
+        self.ctx.check(self.ctx.lib.svo_hip_sia_download(self.h, slot, C.byref(out)), "sia_download")
+        return out
+
+    def download_all(self, n_slots: int):
+        arr = (CSiaResult * n_slots)()
+        self.ctx.check(self.ctx.lib.svo_hip_sia_download_all(self.h, n_slots, arr), "sia_download_all")
+        return list(arr)
+
+    def download_caches(self, slot: int, n: int):
+        ref = np.zeros((n, 16), dtype=np.float32)
+        dx = np.zeros((n, 16), dtype=np.float32)
+        dy = np.zeros((n, 16), dtype=np.float32)
+        vis = np.zeros(n, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.svo_hip_sia_download_caches(self.h, slot, _ptr(ref, C.c_float), _ptr(dx, C.c_float),
+                                                                _ptr(dy, C.c_float), _ptr(vis, C.c_uint8)), "sia_download_caches")
+        return ref, dx, dy, vis
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.svo_hip_sia_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def align2d_batch(ctx: Context, cur: Pyramid, slot: int, level: int, pwb: np.ndarray, patch: np.ndarray, n_iter: int,
+                  px: np.ndarray):
+    """feature_alignment::align2D over n patches (host buffers in, host buffers out)."""
+    n = len(px)
+    pwb = np.ascontiguousarray(pwb, dtype=np.uint8).reshape(n, 100)
+    patch = np.ascontiguousarray(patch, dtype=np.uint8).reshape(n, 64)
+    p = _f64(px).copy()
+    conv = np.zeros(n, dtype=np.uint8)
+    iters = np.zeros(n, dtype=np.int32)
+    ctx.check(ctx.lib.svo_hip_align2d_batch(ctx.h, cur.h, slot, level, n, _ptr(pwb, C.c_uint8), _ptr(patch, C.c_uint8),
+                                            n_iter, _ptr(p, C.c_double), _ptr(conv, C.c_uint8), _ptr(iters, C.c_int32)),
+              "align2d_batch")
+    return conv.astype(bool), p, iters
+
+
+def update_seed_batch(ctx: Context, x, tau2, a, b, mu, z_range, sigma2):
+    """static DepthFilter::updateSeed over SoA float32 arrays; returns the new (a, b, mu, sigma2)."""
+    n = len(x)
+    d = {k: ctx.to_device(np.ascontiguousarray(v, dtype=np.float32)) for k, v in
+         dict(x=x, tau2=tau2, a=a, b=b, mu=mu, z_range=z_range, sigma2=sigma2).items()}
+    ctx.check(ctx.lib.svo_hip_update_seed_batch_dev(ctx.h, n, *[C.c_void_p(d[k].ptr) for k in
+                                                                ("x", "tau2", "a", "b", "mu", "z_range", "sigma2")]),
+              "update_seed_batch")
+    out = tuple(d[k].download() for k in ("a", "b", "mu", "sigma2"))
+    for v in d.values():
+        v.free()
+    return out
+
+
+def compute_tau_batch(ctx: Context, T_ref_cur, f, z, px_error_angle):
+    n = len(z)
+    df, dz, dt = ctx.to_device(_f64(f)), ctx.to_device(_f64(z)), ctx.empty((n,), np.float64)
+    T = _f64(T_ref_cur)
+    ctx.check(ctx.lib.svo_hip_compute_tau_batch_dev(ctx.h, n, _ptr(T, C.c_double), C.c_void_p(df.ptr), C.c_void_p(dz.ptr),
+                                                    C.c_double(px_error_angle), C.c_void_p(dt.ptr)), "compute_tau_batch")
+    out = dt.download()
+    for v in (df, dz, dt):
+        v.free()
+    return out
+
+
+class SeedBatch:
+    """SoA seed state resident on the device (svo::Seed a,b,mu,z_range,sigma2 + Feature px,f,level)."""
+
+    def __init__(self, ctx: Context, px, f, level, a, b, mu, z_range, sigma2):
+        self.ctx, self.n = ctx, len(px)
+        self.px = ctx.to_device(_f64(px))
+        self.f = ctx.to_device(_f64(f))
+        self.level = ctx.to_device(np.ascontiguousarray(level, dtype=np.int32))
+        self.a, self.b, self.mu, self.z_range, self.sigma2 = (
+            ctx.to_device(np.ascontiguousarray(v, dtype=np.float32)) for v in (a, b, mu, z_range, sigma2))
+        self.status = ctx.empty((self.n,), np.int32)
+        self.z = ctx.empty((self.n,), np.float64)
+        self.xyz = ctx.empty((self.n, 3), np.float64)
+        self.n_zmssd = ctx.empty((self.n,), np.int32)
+        self.n_align = ctx.empty((self.n,), np.int32)
+
+    def reset_state(self, a, b, mu, sigma2):
+        for d, v in ((self.a, a), (self.b, b), (self.mu, mu), (self.sigma2, sigma2)):
+            d.upload(np.ascontiguousarray(v, dtype=np.float32))
+
+    def free(self):
+        for d in (self.px, self.f, self.level, self.a, self.b, self.mu, self.z_range, self.sigma2, self.status, self.z,
+                  self.xyz, self.n_zmssd, self.n_align):
+            d.free()
+
+
+def depth_filter_params(n_pyr_levels=3, align_max_iter=10, max_epi_search_steps=1000, conv_thresh=100.0) -> CDfParams:
+    return CDfParams(n_pyr_levels, align_max_iter, max_epi_search_steps, conv_thresh)
+
+
+def depth_filter_update(ctx: Context, ref: Pyramid, ref_slot: int, cur: Pyramid, cur_slot: int, cam, T_ref_w, T_cur_w,
+                        seeds: SeedBatch, prm: Optional[CDfParams] = None, lo: int = 0, hi: Optional[int] = None):
+    """DepthFilter::updateSeeds for seeds [lo, hi) of a device-resident batch (asynchronous)."""
+    prm = prm or depth_filter_params()
+    hi = seeds.n if hi is None else hi
+    c = make_camera(cam)
+    Tr, Tc = _f64(T_ref_w), _f64(T_cur_w)
+
+    def off(d, per):
+        return C.c_void_p(d.ptr + lo * per)
+    ctx.check(ctx.lib.svo_hip_depth_filter_update_dev(
+        ctx.h, ref.h, ref_slot, cur.h, cur_slot, C.byref(c), _ptr(Tr, C.c_double), _ptr(Tc, C.c_double), hi - lo,
+        off(seeds.px, 16), off(seeds.f, 24), off(seeds.level, 4), off(seeds.a, 4), off(seeds.b, 4), off(seeds.mu, 4),
+        off(seeds.z_range, 4), off(seeds.sigma2, 4), C.byref(prm), off(seeds.status, 4), off(seeds.z, 8),
+        off(seeds.xyz, 24), off(seeds.n_zmssd, 4), off(seeds.n_align, 4)), "depth_filter_update")

@@ -1,0 +1,207 @@
+/*
+ * svo_hip.h -- C-ABI of libsvo_hip.so: the MI355X (gfx950) implementation of SVO's
+ * data-parallel hot path (sparse image alignment, align2D, depth-filter update).
+ *
+ * This is the drop-in boundary: plain C types, pointers and sizes only.
+ * The reference has no FFI layer -- its "operator API" is the public C++ surface of
+ * svo::SparseImgAlign / svo::feature_alignment / svo::DepthFilter; the host-side C++
+ * classes that keep those signatures and forward here live in include/svo_dropin/ and are
+ * described in INTEGRATION.md.  Each entry point cites the reference interface it replaces
+ * (paths relative to /root/reference/app/src/main/cpp/svo/, "I/" = include/svo/).
+ *
+ * Conventions
+ *   - every function returns an int status (SVO_HIP_OK == 0, negative on error); nothing
+ *     throws across the boundary, device errors never abort the calling thread;
+ *   - SE3 poses are double[7] = {tx,ty,tz,qx,qy,qz,qw} (I/SE3.h, I/SO3.h member order);
+ *   - images are 8-bit, row-major, stride == cols; level l of a pyramid is (w>>l) x (h>>l);
+ *   - a context owns one HIP stream; every call on a context is enqueued on that stream and
+ *     is asynchronous unless stated otherwise.  Contexts share no mutable state, so the
+ *     tracking thread and the depth-filter thread of the reference (SURVEY 8b "Threading")
+ *     each use their own context concurrently;
+ *   - pointers named *_dev are DEVICE pointers (from svo_hip_malloc or any HIP allocator,
+ *     e.g. a torch tensor's data_ptr); all others are host pointers that are copied in
+ *     before the call returns and never retained.
+ */
+#ifndef SVO_HIP_H_
+#define SVO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVO_HIP_OK 0
+#define SVO_HIP_ERR_INVALID (-1)    /* bad argument (null, out of range, shape mismatch) */
+#define SVO_HIP_ERR_DEVICE (-2)     /* a HIP runtime call failed: see svo_hip_last_error */
+#define SVO_HIP_ERR_NOMEM (-3)
+#define SVO_HIP_ERR_STATE (-4)      /* call sequence violated */
+
+#define SVO_HIP_MAX_LEVELS 8
+#define SVO_HIP_REDUCE_DOUBLES 32   /* per frame: 21 H (upper, row-major) + 6 Jres + chi2 sum + n_meas + pad */
+
+typedef struct svo_hip_ctx svo_hip_ctx;
+typedef struct svo_hip_pyramid svo_hip_pyramid;
+typedef struct svo_hip_sia svo_hip_sia;
+
+/* vk::PinholeCamera forward model (pinhole_camera.cpp:73-106): distortion != 0 enables the
+ * 5-coefficient radtan model d = {k1,k2,p1,p2,k3} in world2cam.  cam2world (needed by the
+ * epipolar matcher) is implemented for distortion == 0 only. */
+typedef struct {
+  int width, height;
+  double fx, fy, cx, cy;
+  double d[5];
+  int distortion;
+} svo_hip_camera;
+
+/* ---- context / memory ------------------------------------------------------------------ */
+/* stream: an existing hipStream_t to enqueue on (e.g. torch's current stream), or NULL to
+ * create a private non-blocking stream. */
+int svo_hip_ctx_create(svo_hip_ctx** out, int device, void* stream);
+int svo_hip_ctx_destroy(svo_hip_ctx* ctx);
+int svo_hip_ctx_sync(svo_hip_ctx* ctx);            /* hipStreamSynchronize on the context stream */
+void* svo_hip_ctx_stream(svo_hip_ctx* ctx);
+const char* svo_hip_last_error(svo_hip_ctx* ctx);  /* text of the last failure on this context */
+const char* svo_hip_version(void);
+int svo_hip_device_count(int* count);
+
+int svo_hip_malloc(svo_hip_ctx* ctx, void** dev_ptr, size_t bytes);
+int svo_hip_free(svo_hip_ctx* ctx, void* dev_ptr);
+int svo_hip_memcpy_h2d(svo_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);   /* async */
+int svo_hip_memcpy_d2h(svo_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);   /* synchronises */
+int svo_hip_memset(svo_hip_ctx* ctx, void* dst_dev, int value, size_t bytes);
+
+/* ---- image pyramids resident in HBM (Frame::img_pyr_, frame.cpp:63,186-195) ------------ */
+/* A batch of `batch` pyramids of identical geometry, one contiguous allocation:
+ * slot s, level l starts at s*pyr_bytes + level_offset[l]. */
+int svo_hip_pyramid_create(svo_hip_ctx* ctx, int width, int height, int n_levels, int batch,
+                           svo_hip_pyramid** out);
+int svo_hip_pyramid_destroy(svo_hip_pyramid* pyr);
+/* copy all levels from host (levels[l] has (w>>l)*(h>>l) bytes) */
+int svo_hip_pyramid_upload(svo_hip_pyramid* pyr, int slot, const uint8_t* const* levels);
+/* copy level 0 only and build levels 1.. on the device with the truncating 2x2 mean
+ * (vk::halfSample scalar/NEON form, vision.cpp:49-67,89-110; frame_utils::createImgPyramid,
+ * frame.cpp:186-195).  The x86 SSE2 form of the reference rounds differently (vision.cpp:33-37). */
+int svo_hip_pyramid_upload_level0_and_build(svo_hip_pyramid* pyr, int slot, const uint8_t* level0);
+int svo_hip_pyramid_download_level(svo_hip_pyramid* pyr, int slot, int level, uint8_t* out_host);
+int svo_hip_pyramid_info(const svo_hip_pyramid* pyr, int* width, int* height, int* n_levels, int* batch,
+                         size_t* pyr_bytes, void** base_dev);
+
+/* ---- SparseImgAlign (I/sparse_img_align.h:33-79, sparse_img_align.cpp:51-308,
+ *      I/nlls_solver_impl.hpp:25-100) ------------------------------------------------------ */
+typedef struct {
+  int max_level, min_level;   /* SparseImgAlign ctor args n_levels / min_level (:29-41)        */
+  int n_iter;                 /* n_iter_ (:35)                                                 */
+  double eps;                 /* eps_ = 1e-6 (:40)                                             */
+  int early_stop;             /* 1: reference Gauss-Newton exits (error increase, |x|<=eps);
+                                 0: fixed work, exactly n_iter evaluations per level           */
+} svo_hip_sia_params;
+
+typedef struct {
+  double T_cur_w[7];          /* cur_frame_->T_f_w_ after run() (:89)                          */
+  uint64_t n_tracked;         /* return value of run(): n_meas_/patch_area_ (:91)              */
+  double H[36];               /* H_ of the last evaluation: getInformationMatrix()             */
+  double chi2;                /* getChi2()                                                      */
+  int stop;                   /* stop_                                                          */
+  int iters[SVO_HIP_MAX_LEVELS];   /* residual evaluations per pyramid level                    */
+  uint64_t n_precompute_patches;   /* algorithmic work counters: sum over levels    */
+  uint64_t n_residual_patches;     /* and over evaluations of patches actually accumulated      */
+} svo_hip_sia_result;
+
+/* A solver for `batch` independent frame pairs with up to max_features features each. */
+int svo_hip_sia_create(svo_hip_ctx* ctx, int batch, int max_features, svo_hip_sia** out);
+int svo_hip_sia_destroy(svo_hip_sia* sia);
+/* slot s of the solver aligns ref->slot s against cur->slot s (pyramids must outlive the solver use) */
+int svo_hip_sia_set_frames(svo_hip_sia* sia, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur);
+/* Flattened ref_frame->fts_ in list order (sparse_img_align.cpp:116-118): level-0 pixel px[n][2],
+ * unit bearing f[n][3], world position of the feature's point pos[n][3], has_point[n] (point != NULL). */
+int svo_hip_sia_upload_features(svo_hip_sia* sia, int slot, int n, const double* px, const double* f,
+                                const double* pos, const uint8_t* has_point);
+/* ref_frame->T_f_w_, the initial cur_frame->T_f_w_ and the camera of the pair */
+int svo_hip_sia_upload_poses(svo_hip_sia* sia, int slot, const svo_hip_camera* cam,
+                             const double T_ref_w[7], const double T_cur_w_init[7]);
+/* Only patches [n*rank/world, n*(rank+1)/world) of every frame are evaluated by this process;
+ * the per-frame sums must then be all-reduced across ranks between accumulate and solve_update. */
+int svo_hip_sia_set_shard(svo_hip_sia* sia, int rank, int world);
+
+/* run(): the whole coarse-to-fine solve for slots [0, n_slots), enqueued on the stream with no
+ * host round trip.  Poses restart from the uploaded initial poses on every call. */
+int svo_hip_sia_run(svo_hip_sia* sia, int n_slots, const svo_hip_sia_params* prm);
+/* blocks until the stream is idle, then copies the result of one slot */
+int svo_hip_sia_download(svo_hip_sia* sia, int slot, svo_hip_sia_result* out);
+/* all slots at once (out[n_slots]) */
+int svo_hip_sia_download_all(svo_hip_sia* sia, int n_slots, svo_hip_sia_result* out);
+
+/* The same solve in steps, for callers that exchange the normal equations between devices:
+ *   begin; for level = max..min { level_begin(level); n_iter x { accumulate; [all-reduce]; solve_update } } finish
+ * accumulate leaves SVO_HIP_REDUCE_DOUBLES doubles per slot in the reduce buffer. */
+int svo_hip_sia_begin(svo_hip_sia* sia, int n_slots, const svo_hip_sia_params* prm);
+int svo_hip_sia_level_begin(svo_hip_sia* sia, int level);
+int svo_hip_sia_accumulate(svo_hip_sia* sia);
+int svo_hip_sia_solve_update(svo_hip_sia* sia);
+int svo_hip_sia_finish(svo_hip_sia* sia);
+/* device address of the reduce buffer ([batch][SVO_HIP_REDUCE_DOUBLES] doubles) */
+int svo_hip_sia_reduce_buffer(svo_hip_sia* sia, void** dev_ptr, size_t* n_doubles);
+/* use a caller-owned device buffer instead (e.g. a torch tensor that RCCL all-reduces in place) */
+int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
+/* cached reference patches / per-patch Jacobian records of one slot, for kernel-level tests:
+ * ref_patch[n][16] f32, dx[n][16] f32, dy[n][16] f32, visible[n] u8 (any may be NULL) */
+int svo_hip_sia_download_caches(svo_hip_sia* sia, int slot, float* ref_patch, float* dx, float* dy,
+                                uint8_t* visible);
+
+/* ---- feature_alignment::align2D (I/feature_alignment.h:40-47, feature_alignment.cpp:154-282) */
+/* n independent 8x8 patches refined on level `level` of cur->slot: ref_patch_with_border
+ * [n][100] u8, ref_patch [n][64] u8, px [n][2] f64 in/out (level coordinates), converged [n] u8,
+ * iters [n] i32 (iterations executed; may be NULL).  All pointers are device pointers. */
+int svo_hip_align2d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int slot, int level, int n,
+                              const uint8_t* ref_patch_with_border_dev, const uint8_t* ref_patch_dev,
+                              int n_iter, double* px_dev, uint8_t* converged_dev, int32_t* iters_dev);
+/* host-buffer convenience form (copies in, runs, copies out, synchronises) */
+int svo_hip_align2d_batch(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int slot, int level, int n,
+                          const uint8_t* ref_patch_with_border, const uint8_t* ref_patch, int n_iter,
+                          double* px, uint8_t* converged, int32_t* iters);
+
+/* ---- DepthFilter (I/depth_filter.h:36-166, depth_filter.cpp:237-416; matcher.cpp:207-355) -- */
+/* static DepthFilter::updateSeed over n seeds (depth_filter.cpp:368-391): SoA device arrays */
+int svo_hip_update_seed_batch_dev(svo_hip_ctx* ctx, int n, const float* x_dev, const float* tau2_dev,
+                                  float* a_dev, float* b_dev, float* mu_dev, const float* z_range_dev,
+                                  float* sigma2_dev);
+/* static DepthFilter::computeTau over n (f, z) pairs sharing one T_ref_cur (depth_filter.cpp:396-416) */
+int svo_hip_compute_tau_batch_dev(svo_hip_ctx* ctx, int n, const double T_ref_cur[7], const double* f_dev,
+                                  const double* z_dev, double px_error_angle, double* tau_dev);
+
+typedef struct {
+  int n_pyr_levels;                  /* Config::nPyrLevels() (config.cpp:59: 3)                   */
+  int align_max_iter;                /* Matcher::Options::align_max_iter (I/matcher.h:86: 10)      */
+  int max_epi_search_steps;          /* Matcher::Options::max_epi_search_steps (I/matcher.h:88: 1000) */
+  double seed_convergence_sigma2_thresh;   /* DepthFilter::Options (I/depth_filter.h:85: 100.0)    */
+} svo_hip_df_params;
+
+/* per-seed outcome of one updateSeeds pass (depth_filter.cpp:250-340) */
+#define SVO_HIP_SEED_BEHIND 0
+#define SVO_HIP_SEED_NOT_IN_FRAME 1
+#define SVO_HIP_SEED_NO_MATCH 2
+#define SVO_HIP_SEED_UPDATED 3
+#define SVO_HIP_SEED_CONVERGED 4
+#define SVO_HIP_SEED_NAN 5
+
+/* DepthFilter::updateSeeds for n seeds created in keyframe ref->ref_slot, measured in frame
+ * cur->cur_slot: visibility test, Matcher::findEpipolarMatchDirect (epipolar ZMSSD search +
+ * align2D + triangulation), computeTau, updateSeed, convergence test.  SoA device arrays:
+ * px[n][2] f64, f[n][3] f64, level[n] i32 (Feature px/f/level), a,b,mu,sigma2 in/out f32, z_range f32;
+ * outputs status[n] i32, z[n] f64, xyz_world[n][3] f64 (valid when converged), and the work
+ * counters n_zmssd[n], n_align_iters[n] i32 (any output except status may be NULL). */
+int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,
+                                    const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                                    const double T_ref_w[7], const double T_cur_w[7], int n,
+                                    const double* px_dev, const double* f_dev, const int32_t* level_dev,
+                                    float* a_dev, float* b_dev, float* mu_dev, const float* z_range_dev,
+                                    float* sigma2_dev, const svo_hip_df_params* prm, int32_t* status_dev,
+                                    double* z_dev, double* xyz_world_dev, int32_t* n_zmssd_dev,
+                                    int32_t* n_align_iters_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVO_HIP_H_ */

