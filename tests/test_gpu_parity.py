@@ -4,6 +4,8 @@ C-ABI, against the CPU oracle on the same seeded inputs and against the golden f
 Bars: bit-exact for bytes / integers / indices; floating point within the tolerance written
 at each assert (north_star: pose error < 1e-4 rad and < 1e-3 m vs the reference path).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -164,7 +166,7 @@ def test_stepwise_equals_run_and_sharded_sum(ctx):
         sia.accumulate()
         ctx.sync()
         buf = np.zeros(32)
-        ctx.check(ctx.lib.svo_hip_memcpy_d2h(ctx.h, buf.ctypes.data, ptr, 32 * 8), "d2h")
+        ctx.check(ctx.lib.svo_hip_memcpy_d2h(ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(32 * 8)), "d2h")
         rows.append(buf)
     sia.set_shard(0, 1)
     sia.begin(1, prm)
@@ -172,7 +174,7 @@ def test_stepwise_equals_run_and_sharded_sum(ctx):
     sia.accumulate()
     ctx.sync()
     full = np.zeros(32)
-    ctx.check(ctx.lib.svo_hip_memcpy_d2h(ctx.h, full.ctypes.data, ptr, 32 * 8), "d2h")
+    ctx.check(ctx.lib.svo_hip_memcpy_d2h(ctx.h, full.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(32 * 8)), "d2h")
     np.testing.assert_allclose(rows[0] + rows[1], full, rtol=1e-12, atol=1e-9)
     assert rows[0][28] + rows[1][28] == full[28] and full[28] > 0
     _free(sia, ref, cur)
