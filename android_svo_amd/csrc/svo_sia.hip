@@ -22,6 +22,8 @@
 //   * Reductions: 16-lane xor-shuffles inside the patch, then per-lane fp64 accumulators
 //     over the block's patches, one cross-wave LDS step, one partial row per block; the
 //     per-frame sum over blocks is done in fixed order (bitwise reproducible, no atomics).
+#include <vector>
+
 #include "svo_internal.h"
 
 using namespace svo_dev;
@@ -383,6 +385,10 @@ struct svo_hip_sia {
   svo_hip_sia_params prm{};
   int n_slots = 0, level = -1, chunks = 1;
   bool begun = false;
+  // optional HIP-event timing of the two heavy kernels, on the context stream
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_res, ev_pre;     // start/stop pairs
+  size_t ev_res_used = 0, ev_pre_used = 0;
 };
 
 namespace {
@@ -402,6 +408,20 @@ int pick_chunks(int n_slots, int max_n) {
   if (c > MAX_CHUNKS) c = MAX_CHUNKS;
   if (c < 1) c = 1;
   return c;
+}
+
+// next start/stop event pair of a pool (grown on demand); nullptr when profiling is off
+hipEvent_t* next_events(svo_hip_sia* s, std::vector<hipEvent_t>& pool, size_t& used) {
+  if (!s->profiling) return nullptr;
+  if (used + 2 > pool.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return nullptr;
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return nullptr; }
+    pool.push_back(a); pool.push_back(b);
+  }
+  hipEvent_t* e = &pool[used];
+  used += 2;
+  return e;
 }
 
 int flush_fc(svo_hip_sia* s) {
@@ -451,6 +471,8 @@ int svo_hip_sia_destroy(svo_hip_sia* s) {
   void* ptrs[] = {s->fc, s->st, s->px, s->f, s->pos, s->has_point, s->visible, s->ref_cache, s->dxc, s->dyc,
                   s->rec, s->xyz, s->partial, s->reduce_own, s->n_pre_count};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (hipEvent_t e : s->ev_res) (void)hipEventDestroy(e);
+  for (hipEvent_t e : s->ev_pre) (void)hipEventDestroy(e);
   delete[] s->h_fc;
   delete s;
   return SVO_HIP_OK;
@@ -543,9 +565,12 @@ int svo_hip_sia_level_begin(svo_hip_sia* s, int level) {
   g.cols = s->ref->width >> level; g.rows = s->ref->height >> level;
   g.ref_off = s->ref->level_offset[level]; g.cur_off = s->cur->level_offset[level];
   dim3 grid((s->max_n + 15) / 16, s->n_slots), block(256);
+  hipEvent_t* ev = next_events(s, s->ev_pre, s->ev_pre_used);
+  if (ev) (void)hipEventRecord(ev[0], ctx->stream);
   hipLaunchKernelGGL(sia_precompute_kernel, grid, block, 0, ctx->stream, s->fc, s->st, s->ref->base,
                      s->ref->pyr_bytes, g, level, s->max_n, s->shard_rank, s->shard_world, s->px, s->f, s->pos,
                      s->has_point, s->ref_cache, s->dxc, s->dyc, s->rec, s->xyz, s->visible, s->n_pre_count);
+  if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
 }
@@ -559,9 +584,12 @@ int svo_hip_sia_accumulate(svo_hip_sia* s) {
   g.cols = s->ref->width >> level; g.rows = s->ref->height >> level;
   g.ref_off = s->ref->level_offset[level]; g.cur_off = s->cur->level_offset[level];
   dim3 grid(s->chunks, s->n_slots), block(256);
+  hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
+  if (ev) (void)hipEventRecord(ev[0], ctx->stream);
   hipLaunchKernelGGL(sia_residual_kernel, grid, block, 0, ctx->stream, s->fc, s->st, s->cur->base, s->cur->pyr_bytes,
                      g, level, s->max_n, s->chunks, s->shard_rank, s->shard_world, s->ref_cache, s->dxc, s->dyc,
                      s->rec, s->xyz, s->visible, s->partial);
+  if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(sia_sum_partials_kernel, dim3(s->n_slots), dim3(RED), 0, ctx->stream, s->st, s->partial,
                      s->chunks, s->reduce, s->n_slots);
@@ -601,6 +629,33 @@ int svo_hip_sia_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) 
     }
   }
   return svo_hip_sia_finish(s);
+}
+
+int svo_hip_sia_set_profiling(svo_hip_sia* s, int enable) {
+  if (!s) return SVO_HIP_ERR_INVALID;
+  s->profiling = enable != 0;
+  s->ev_res_used = 0; s->ev_pre_used = 0;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_sia_get_profile(svo_hip_sia* s, double* residual_ms, uint64_t* residual_launches, double* precompute_ms,
+                            uint64_t* precompute_launches) {
+  if (!s) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = s->ctx;
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  auto total = [&](std::vector<hipEvent_t>& pool, size_t used, double* ms, uint64_t* cnt) {
+    double t = 0.0;
+    for (size_t i = 0; i + 1 < used; i += 2) {
+      float e = 0.f;
+      if (hipEventElapsedTime(&e, pool[i], pool[i + 1]) == hipSuccess) t += e;
+    }
+    if (ms) *ms = t;
+    if (cnt) *cnt = used / 2;
+  };
+  total(s->ev_res, s->ev_res_used, residual_ms, residual_launches);
+  total(s->ev_pre, s->ev_pre_used, precompute_ms, precompute_launches);
+  s->ev_res_used = 0; s->ev_pre_used = 0;
+  return SVO_HIP_OK;
 }
 
 int svo_hip_sia_reduce_buffer(svo_hip_sia* s, void** dev_ptr, size_t* n_doubles) {

@@ -244,6 +244,17 @@ class SparseImgAlign:
     def set_reduce_buffer(self, dev_ptr: int):
         self.ctx.check(self.ctx.lib.svo_hip_sia_set_reduce_buffer(self.h, C.c_void_p(dev_ptr)), "sia_set_reduce_buffer")
 
+    def set_profiling(self, enable: bool):
+        self.ctx.check(self.ctx.lib.svo_hip_sia_set_profiling(self.h, 1 if enable else 0), "sia_set_profiling")
+
+    def get_profile(self):
+        rms, pms = C.c_double(), C.c_double()
+        rn, pn = C.c_uint64(), C.c_uint64()
+        self.ctx.check(self.ctx.lib.svo_hip_sia_get_profile(self.h, C.byref(rms), C.byref(rn), C.byref(pms), C.byref(pn)),
+                       "sia_get_profile")
+        return {"residual_ms": rms.value, "residual_launches": rn.value, "precompute_ms": pms.value,
+                "precompute_launches": pn.value}
+
     def download(self, slot: int) -> CSiaResult:
         out = CSiaResult()
         self.ctx.check(self.ctx.lib.svo_hip_sia_download(self.h, slot, C.byref(out)), "sia_download")

@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- SparseImgAlign frames/s at 640x480, L4-L0 (BASELINE.json metric) on MI355X.
+
+One "step" = one pass of the hot path over one batch of frame pairs: the whole coarse-to-fine
+solve (5 pyramid levels x 30 Gauss-Newton evaluations, fixed work = config C1) of `batch`
+independent 640x480 pairs with 2000 patches each, inputs already resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  N > 1: launched by torch.distributed.run, one rank per GPU.  Default sharding is by frame
+  pair (independent objects, no data-path collective, weak scaling).  --mode allreduce runs
+  BASELINE config C3's variant instead: every frame's patches are split over the ranks and the
+  per-frame 6x6 H / 6x1 b sums are all-reduced (RCCL over xGMI) at every Gauss-Newton step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
+dominant kernel (sia_residual_kernel) and `cpu_baseline` (the C oracle on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from android_svo_amd import hip, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+BYTES_PRECOMPUTE = 945           # per patch per level
+BYTES_RESIDUAL = 881             # per patch per Gauss-Newton evaluation
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
+    ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic scenes tiled over the batch")
+    ap.add_argument("--mode", choices=["frames", "allreduce"], default="frames")
+    ap.add_argument("--early-stop", action="store_true", help="reference GN exits instead of fixed work")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames-per-thread", type=int, default=6)
+    ap.add_argument("--profile-events", type=int, default=1, help="record HIP events around the heavy kernels in the timed region")
+    return ap.parse_args()
+
+
+def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=6):
+    """The CPU oracle (port of the reference algorithm) on the host cores, bounded sample."""
+    from oracle import orc
+    orc.lib()
+    n_threads = max(1, min(os.cpu_count() or 1, 16))
+    done = [0] * n_threads
+
+    def work(t):
+        for k in range(frames_per_thread):
+            orc.sparse_img_align(fps[(t + k) % len(fps)], n_iter=n_iter, early_stop=early_stop)
+            done[t] += 1
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dt = time.perf_counter() - t0
+    frames = sum(done)
+    # single-thread figure too (the reference's run() is serial)
+    t1 = time.perf_counter()
+    orc.sparse_img_align(fps[0], n_iter=n_iter, early_stop=early_stop)
+    single = time.perf_counter() - t1
+    return {"value": frames / dt, "unit": "frames/s", "cores": n_threads, "kind": "port",
+            "sample": "%d frame pairs (640x480, %d patches, L4-L0, %s) on %d threads in %.1f s; 1 thread: %.2f frames/s" %
+                      (frames, len(fps[0].px), "early stop" if early_stop else "30 GN evaluations/level fixed work",
+                       n_threads, dt, 1.0 / single)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    import torch
+    import torch.distributed as dist
+    multi = world > 1
+    torch.cuda.set_device(local_rank)
+    if multi:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    B = args.batch
+    n_feat = args.features
+    allreduce = args.mode == "allreduce" and multi
+    # ---- synthetic inputs (host), then resident in HBM before anything is timed
+    fps = [synth.make_frame_pair(seed=12345 + 17 * rank + i, n_features=n_feat) for i in range(args.distinct)]
+    cam = fps[0].cam
+    stream = torch.cuda.Stream(device=local_rank)
+    ctx = hip.Context(local_rank, stream=stream.cuda_stream)
+    n_slots = B * world if allreduce else B
+    ref = hip.Pyramid(ctx, cam.width, cam.height, 5, n_slots)
+    cur = hip.Pyramid(ctx, cam.width, cam.height, 5, n_slots)
+    sia = hip.SparseImgAlign(ctx, n_slots, n_feat)
+    sia.set_frames(ref, cur)
+    if allreduce:
+        # every rank holds every frame of the global batch (same seeds on all ranks), evaluates its patch shard
+        fps = [synth.make_frame_pair(seed=12345 + i, n_features=n_feat) for i in range(args.distinct)]
+        sia.set_shard(rank, world)
+    for s in range(n_slots):
+        fp = fps[s % len(fps)]
+        ref.upload(s, fp.ref_pyr)
+        cur.upload(s, fp.cur_pyr)
+        sia.upload_pair(s, fp)
+    prm = sia.params(max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=args.early_stop)
+    red = None
+    if allreduce:
+        red = torch.zeros(n_slots * hip.REDUCE_DOUBLES, dtype=torch.float64, device="cuda")
+        sia.set_reduce_buffer(red.data_ptr())
+
+    def step():
+        if not allreduce:
+            sia.run(n_slots, prm)
+            return
+        with torch.cuda.stream(stream):
+            sia.begin(n_slots, prm)
+            for level in range(prm.max_level, prm.min_level - 1, -1):
+                sia.level_begin(level)
+                for _ in range(prm.n_iter):
+                    sia.accumulate()
+                    dist.all_reduce(red)
+                    sia.solve_update()
+            sia.finish()
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    sia.set_profiling(bool(args.profile_events))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = sia.get_profile() if args.profile_events else None
+    sia.set_profiling(False)
+    if multi:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- parity spot check (outside the timed region): slot 0 against the CPU oracle
+    res = sia.download(0)
+    results = sia.download_all(min(n_slots, 8))
+    frames_global = B * world
+    value = frames_global * args.steps / dt
+
+    out = None
+    if rank == 0:
+        from oracle import orc          # checker + cpu_baseline leg only
+        o = orc.sparse_img_align(fps[0], n_iter=30, early_stop=args.early_stop)
+        rot, trans = synth.pose_error(np.array(res.T_cur_w), np.array(o.T_cur_w))
+        n_res_per_frame = res.n_residual_patches       # patches accumulated over all evaluations of one frame
+        n_pre_per_frame = res.n_precompute_patches
+        if allreduce:
+            # counters are per rank shard; scale to the whole frame for the algorithmic-bytes figure
+            n_res_per_frame = o.n_residual_patches
+            n_pre_per_frame = o.n_precompute_patches
+        evals = sum(res.iters[:5])
+        bytes_frame = n_pre_per_frame * BYTES_PRECOMPUTE + n_res_per_frame * BYTES_RESIDUAL
+        roofline = None
+        if prof and prof["residual_launches"]:
+            launches = prof["residual_launches"]
+            avg_ms = prof["residual_ms"] / launches
+            # one launch evaluates every live patch of every frame of this rank once
+            units = (n_res_per_frame / max(evals, 1)) * n_slots / (world if allreduce else 1)
+            ach = units * BYTES_RESIDUAL / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "sia_residual_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_us": avg_ms * 1e3, "launches": int(launches),
+                        "algorithmic_bytes_per_launch": units * BYTES_RESIDUAL,
+                        "precompute_avg_launch_us": (prof["precompute_ms"] / max(prof["precompute_launches"], 1)) * 1e3}
+            tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tr):
+                try:
+                    roofline["traffic"] = json.load(open(tr)).get("sia_residual_kernel_bytes_per_launch")
+                    roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc pass of this command)"
+                except Exception:
+                    pass
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(fps, n_iter=30, early_stop=args.early_stop, frames_per_thread=args.cpu_frames_per_thread)
+        out = {
+            "metric": "SparseImgAlign frames/s at 640x480 L4-L0; pose err vs CPU ref",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 normal equations / f32 image math (as the reference)", "data": "synthetic",
+            "config": {"workload": "C1: SparseImgAlign 640x480, %d patches, 5 pyramid levels (L4-L0), %s" %
+                                   (n_feat, "reference early-stop GN" if args.early_stop else "30 GN evaluations per level (fixed work)"),
+                       "frame_pairs_per_gpu_per_step": B, "global_frame_pairs_per_step": frames_global,
+                       "parallelism": ("patch-sharded + per-GN-step all-reduce of H/b (C3 variant)" if allreduce
+                                       else "frame-parallel (no collective)") + ", %d GPU(s)" % world,
+                       "distinct_scenes": args.distinct},
+            "pose_err_vs_cpu_ref": {"rot_rad": rot, "trans_m": trans, "tolerance": "1e-4 rad / 1e-3 m"},
+            "gn_evaluations_per_frame": int(evals),
+            "algorithmic_bytes_per_frame": int(bytes_frame),
+            "whole_solve_algorithmic_GBps": bytes_frame * value / 1e9,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        assert rot < 1e-4 and trans < 1e-3, "pose parity violated: %g rad %g m" % (rot, trans)
+        # all replicated slots of one scene must agree bit for bit (deterministic reductions)
+        for i, r in enumerate(results):
+            if i >= len(fps) and i % len(fps) == 0:
+                assert list(r.T_cur_w) == list(results[0].T_cur_w)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

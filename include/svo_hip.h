@@ -145,6 +145,13 @@ int svo_hip_sia_finish(svo_hip_sia* sia);
 int svo_hip_sia_reduce_buffer(svo_hip_sia* sia, void** dev_ptr, size_t* n_doubles);
 /* use a caller-owned device buffer instead (e.g. a torch tensor that RCCL all-reduces in place) */
 int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
+/* Optional timing of the two heavy kernels with HIP events recorded on the context stream around
+ * each launch (precompute: one per level; residual: one per Gauss-Newton evaluation).
+ * get_profile synchronises, returns the summed device time and launch counts since the last call
+ * and resets the counters. */
+int svo_hip_sia_set_profiling(svo_hip_sia* sia, int enable);
+int svo_hip_sia_get_profile(svo_hip_sia* sia, double* residual_ms, uint64_t* residual_launches,
+                            double* precompute_ms, uint64_t* precompute_launches);
 /* cached reference patches / per-patch Jacobian records of one slot, for kernel-level tests:
  * ref_patch[n][16] f32, dx[n][16] f32, dy[n][16] f32, visible[n] u8 (any may be NULL) */
 int svo_hip_sia_download_caches(svo_hip_sia* sia, int slot, float* ref_patch, float* dx, float* dy,
