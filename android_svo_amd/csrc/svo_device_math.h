@@ -279,4 +279,119 @@ SVO_DEV int group_sum(int v) {
   return v;
 }
 
+// ---- quad (4-lane) communication through DPP quad_perm: no LDS, no bpermute ------------------
+template <int CTRL>
+SVO_DEV int dpp_quad(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+SVO_DEV float dpp_quad(float v) { return __int_as_float(dpp_quad<CTRL>(__float_as_int(v))); }
+template <int CTRL>
+SVO_DEV double dpp_quad(double v) {
+  const int lo = dpp_quad<CTRL>(__double2loint(v)), hi = dpp_quad<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// value of lane S (0..3) of the caller's quad
+template <int S, typename T>
+SVO_DEV T quad_bcast(T v) { return dpp_quad<S * 0x55>(v); }
+// sum over the 4 lanes of a quad, all lanes get it:  (v0+v1)+(v2+v3) up to commutation
+SVO_DEV double quad_sum(double v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); return v; }
+SVO_DEV float quad_sum(float v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); return v; }
+
+// Pivoted LDL^T solve of a symmetric 6x6 with every index static (registers only, no scratch):
+// same algorithm and operation order as ldlt6_solve above.
+SVO_DEV void ldlt6_solve_reg(const double* Hin, const double* b, double* x) {
+  constexpr int N = 6;
+  double m[N][N];
+  int tr[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) m[i][j] = Hin[i * N + j];
+  bool all_zero = false;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (!all_zero) {
+      int big = k;
+      double best = fabs(m[k][k]);
+#pragma unroll
+      for (int i = k + 1; i < N; ++i)
+        if (fabs(m[i][i]) > best) { best = fabs(m[i][i]); big = i; }
+      tr[k] = big;
+#pragma unroll
+      for (int c = k + 1; c < N; ++c) {
+        if (big == c) {
+#pragma unroll
+          for (int j = 0; j < k; ++j) { double t = m[k][j]; m[k][j] = m[c][j]; m[c][j] = t; }
+#pragma unroll
+          for (int i = c + 1; i < N; ++i) { double t = m[i][k]; m[i][k] = m[i][c]; m[i][c] = t; }
+          { double t = m[k][k]; m[k][k] = m[c][c]; m[c][c] = t; }
+#pragma unroll
+          for (int i = k + 1; i < c; ++i) { double t = m[i][k]; m[i][k] = m[c][i]; m[c][i] = t; }
+        }
+      }
+      if (k > 0) {
+        double temp[N];
+#pragma unroll
+        for (int i = 0; i < k; ++i) temp[i] = m[i][i] * m[k][i];
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < k; ++i) s += m[k][i] * temp[i];
+        m[k][k] -= s;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r) {
+          double a = 0.0;
+#pragma unroll
+          for (int i = 0; i < k; ++i) a += m[r][i] * temp[i];
+          m[r][k] -= a;
+        }
+      }
+      const double akk = m[k][k];
+      const bool valid = fabs(akk) > 0.0;
+      if (k == 0 && !valid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) tr[j] = j;
+        all_zero = true;
+      } else if (valid) {
+#pragma unroll
+        for (int r = k + 1; r < N; ++r) m[r][k] /= akk;
+      }
+    }
+  }
+  double d[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) d[i] = b[i];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int c = k + 1; c < N; ++c)
+      if (tr[k] == c) { double t = d[k]; d[k] = d[c]; d[c] = t; }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double s = d[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) s -= m[i][j] * d[j];
+    d[i] = s;
+  }
+  const double tol = 2.2250738585072014e-308;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (fabs(m[i][i]) > tol) d[i] /= m[i][i]; else d[i] = 0.0;
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    double s = d[i];
+#pragma unroll
+    for (int j = i + 1; j < N; ++j) s -= m[j][i] * d[j];
+    d[i] = s;
+  }
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+#pragma unroll
+    for (int c = k + 1; c < N; ++c)
+      if (tr[k] == c) { double t = d[k]; d[k] = d[c]; d[c] = t; }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = d[i];
+}
+
 }  // namespace svo_dev

@@ -7,21 +7,29 @@
 // Design (MI355X-first, not the reference's loop structure):
 //   * B independent frame pairs are solved at once; the whole coarse-to-fine loop is a
 //     fixed sequence of kernels on one stream with the Gauss-Newton control state
-//     (model, rollback copy, chi2, stop, iteration) resident in HBM -- no host round trip,
+//     (model, rollback copy, chi2, stop, iteration) resident in HBM -- no host round trip;
 //     data-dependent early exits become per-frame "done" flags that later kernels test.
-//   * 16 lanes own one 4x4 patch (lane = pixel): a wave64 handles 4 patches, cache rows
-//     are 64 B per patch so every cache access of a wave is one contiguous 256 B segment.
-//   * Inverse-compositional structure is exploited: the per-pixel Jacobian is
-//     J = dx*A + dy*B with A,B = rows of the 2x6 projection Jacobian (per patch) times
-//     fx/2^L, so  sum_px J J^T = sxx AA^T + sxy (AB^T+BA^T) + syy BB^T  with per-patch
-//     constants and  sum_px J r = A sum(dx r) + B sum(dy r).  Instead of streaming the
-//     reference's 768 B/patch fp64 Jacobian cache every iteration we keep 3 f32 per pixel
-//     (ref, dx, dy) + a 128 B per-patch record, and only two 16-lane reductions per patch
-//     are needed per iteration.  H/Jres accumulate in fp64; chi2 like the reference in f32
-//     per patch then fp64 across patches.
-//   * Reductions: 16-lane xor-shuffles inside the patch, then per-lane fp64 accumulators
-//     over the block's patches, one cross-wave LDS step, one partial row per block; the
-//     per-frame sum over blocks is done in fixed order (bitwise reproducible, no atomics).
+//   * Work unit = a TILE of 64 patches per wavefront.  A lane plays two roles:
+//       lane-per-patch  (lane 4g+r owns patch 16r+g of the tile): fp64 projection of the
+//                       patch, bilinear weights, and the per-patch part of the normal
+//                       equations -- 64 distinct patches per instruction, nothing redundant;
+//       lane-per-pixel-row (4 sub-passes s=0..3; the quad 4g..4g+3 works on patch 16s+g,
+//                       lane r on pixel row r): two unaligned 8-byte image row reads, three
+//                       16-byte cache reads (1 KiB contiguous per wave instruction), 4 pixels
+//                       of f32 image math per lane.
+//     The owner of patch 16s+g is lane s of the same quad, so every exchange between the two
+//     roles is a DPP quad_perm (no LDS, no ds_bpermute).
+//   * Inverse-compositional structure: the per-pixel Jacobian is J = dx*A + dy*B with A,B the
+//     rows of the 2x6 projection Jacobian of the patch times fx/2^L, hence
+//       sum_px J J^T = sxx AA^T + sxy (AB^T+BA^T) + syy BB^T,   sum_px J r = A sum(dx r) + B sum(dy r).
+//     We keep 3 f32 per pixel (ref, dx, dy), {x,y,z,1/z} and {sxx,sxy,syy} per patch instead of the
+//     reference's 768 B/patch fp64 Jacobian cache.  The 21 distinct entries of each tile's
+//     sum_patches H_patch are stored once per level; an evaluation whose tile has every
+//     linearised patch inside the current image adds that row (lane e adds entry e), any
+//     other tile recomputes its H from the patches that are visible now -- H is therefore
+//     rebuilt from the visible set at every evaluation, as computeResiduals does.
+//   * fp64 for H/Jres and their partial sums; residual/chi2 in f32 per pixel row, widened per
+//     patch.  Reductions are in fixed order (bitwise reproducible run to run, no atomics).
 #include <vector>
 
 #include "svo_internal.h"
@@ -32,7 +40,11 @@ namespace {
 
 constexpr int PATCH_AREA = 16;
 constexpr int RED = SVO_HIP_REDUCE_DOUBLES;     // 32
-constexpr int MAX_CHUNKS = 128;
+constexpr int MAX_CHUNKS = 64;
+constexpr int TILE = 64;                        // patches per wavefront pass
+constexpr int TILE_ROW = 24;                    // doubles per tile-H row (21 used)
+constexpr uint8_t F_VISIBLE = 1;                // visible_fts_ (sticky across levels)
+constexpr uint8_t F_JVALID = 2;                 // jacobian_cache_ column block non-zero at this level
 
 // per-frame constants
 struct FrameConst {
@@ -67,9 +79,56 @@ struct LevelGeom {
   size_t ref_off, cur_off;   // byte offset of the level inside a pyramid
 };
 
-// upper-triangle (row-major) index -> (i, j)
-__device__ __constant__ int8_t kTriI[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
-__device__ __constant__ int8_t kTriJ[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+struct Shard { int rank, world; };
+
+SVO_DEV void shard_range(int n, Shard sh, int* lo, int* hi) {
+  *lo = (int)(((long long)n * sh.rank) / sh.world);
+  *hi = (int)(((long long)n * (sh.rank + 1)) / sh.world);
+}
+
+// byte k (0..7) of an 8-byte little-endian row segment, as float
+SVO_DEV float byte_f(uint2 w, int k) {
+  const unsigned v = k < 4 ? w.x : w.y;
+  return (float)((v >> (8 * (k & 3))) & 0xffu);
+}
+
+SVO_DEV uint2 load_row8(const uint8_t* p) {
+  uint2 w;
+  __builtin_memcpy(&w, p, 8);      // unaligned global_load_dwordx2
+  return w;
+}
+
+// The 21 upper-triangle entries (row-major) of  sxx AA^T + sxy (AB^T + BA^T) + syy BB^T.
+SVO_DEV void patch_hessian(const double* A, const double* B, double sxx, double sxy, double syy, double* hp) {
+  int e = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) {
+      hp[e] = sxx * (A[i] * A[j]) + sxy * (A[i] * B[j] + B[i] * A[j]) + syy * (B[i] * B[j]);
+      ++e;
+    }
+}
+
+// A = row 0, B = row 1 of Frame::jacobian_xyz2uv (I/frame.h:110-132) times fx/2^L, from {x,y,z,1/z}
+SVO_DEV void patch_jacobian_rows(double x, double y, double z_inv, double jscale, double* A, double* B) {
+  const double z_inv_2 = z_inv * z_inv;
+  const double j02 = x * z_inv_2;
+  const double j03 = y * j02;
+  const double j12 = y * z_inv_2;
+  A[0] = -z_inv * jscale;
+  A[1] = 0.0 * jscale;
+  A[2] = j02 * jscale;
+  A[3] = j03 * jscale;
+  A[4] = -(1.0 + x * j02) * jscale;
+  A[5] = (y * z_inv) * jscale;
+  B[0] = 0.0 * jscale;
+  B[1] = -z_inv * jscale;
+  B[2] = j12 * jscale;
+  B[3] = (1.0 + y * j12) * jscale;
+  B[4] = -j03 * jscale;
+  B[5] = (-x * z_inv) * jscale;
+}
 
 __global__ void sia_begin_kernel(const FrameConst* __restrict__ fc, FrameState* __restrict__ st, int n_slots) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,19 +147,38 @@ __global__ void sia_begin_kernel(const FrameConst* __restrict__ fc, FrameState* 
   for (int i = 0; i < SVO_HIP_MAX_LEVELS; ++i) s.iters[i] = 0;
 }
 
-// One level's precomputeReferencePatches.  grid = (ceil(max_n/16), n_slots), block = 256.
-// Algorithmic bytes per patch: 49 B footprint + 16+24+24 B feature -> 64 B + 768 B caches;
-// physical: 7x7 u8 gather + 65 B feature -> 192 B pixel caches + 128 B record + 32 B xyz.
+// xyz_ref = f * |pos - ref_pos| and 1/z for every feature: level independent
+// (sparse_img_align.cpp:131-135,220-221).  One thread per patch.
+__global__ __launch_bounds__(256) void sia_geometry_kernel(
+    const FrameConst* __restrict__ fc, int max_n, const double* __restrict__ f, const double* __restrict__ pos,
+    double4* __restrict__ xyz4) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const FrameConst& c = fc[b];
+  if (i >= c.n_feat) return;
+  const size_t fi = (size_t)b * max_n + i;
+  const double dxp = pos[3 * fi] - c.ref_pos[0];
+  const double dyp = pos[3 * fi + 1] - c.ref_pos[1];
+  const double dzp = pos[3 * fi + 2] - c.ref_pos[2];
+  const double depth = sqrt(dxp * dxp + dyp * dyp + dzp * dzp);
+  double4 o;
+  o.x = f[3 * fi] * depth; o.y = f[3 * fi + 1] * depth; o.z = f[3 * fi + 2] * depth;
+  o.w = 1. / o.z;
+  xyz4[fi] = o;
+}
+
+// One level's precomputeReferencePatches.  grid = (ceil(max_n/256), n_slots), block = 256:
+// wave w of block x owns tile 4x+w of the frame's shard.
+// Algorithmic bytes per patch: 49 B footprint + 64 B feature in, 64 B + 768 B caches out;
+// physical: 16 x 8 B row reads + 17 B feature/flag in, 192 B pixel caches + 32 B sums (+ 3 B tile row) out.
 __global__ __launch_bounds__(256) void sia_precompute_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
-    size_t pyr_bytes, LevelGeom g, int level, int max_n, int shard_rank, int shard_world,
-    const double* __restrict__ px, const double* __restrict__ f, const double* __restrict__ pos,
-    const uint8_t* __restrict__ has_point, float* __restrict__ ref_cache, float* __restrict__ dxc,
-    float* __restrict__ dyc, double* __restrict__ rec, double* __restrict__ xyz, uint8_t* __restrict__ visible,
+    size_t pyr_bytes, LevelGeom g, int level, int max_n, int max_tiles, Shard sh,
+    const double* __restrict__ px, const uint8_t* __restrict__ has_point, const double4* __restrict__ xyz4,
+    float4* __restrict__ ref_cache, float4* __restrict__ dxc, float4* __restrict__ dyc,
+    double4* __restrict__ sxyz, double* __restrict__ tile_h, uint8_t* __restrict__ flags,
     unsigned int* __restrict__ n_pre_count) {
   const int b = blockIdx.y;
-  const int lane16 = threadIdx.x & 15;
-  const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
   const FrameConst& c = fc[b];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // per-level solver reset: optimizeGaussNewton saves the model for rollback (:33) and
@@ -110,87 +188,113 @@ __global__ __launch_bounds__(256) void sia_precompute_kernel(
     s.iter = 0;
     s.level_done = s.empty;
   }
-  const int n = c.n_feat;
-  if (i >= n) return;
-  const int lo = (int)(((long long)n * shard_rank) / shard_world);
-  const int hi = (int)(((long long)n * (shard_rank + 1)) / shard_world);
-  if (i < lo || i >= hi) return;
-
-  const size_t fi = (size_t)b * max_n + i;
-  const int border = 3;
-  const float scale = 1.0f / (1 << level);
-  const float u_ref = (float)(px[2 * fi] * scale);
-  const float v_ref = (float)(px[2 * fi + 1] * scale);
-  const int u_ref_i = (int)floorf(u_ref);
-  const int v_ref_i = (int)floorf(v_ref);
-  double* r = rec + fi * 16;
-  if (!has_point[fi] || u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= g.cols ||
-      v_ref_i + border >= g.rows) {
-    r[lane16] = 0.0;              // jacobian_cache_.setZero() (:76); ref patch cache and visibility stay as they were
-    return;
-  }
-  if (lane16 == 0) {
-    visible[fi] = 1;              // sticky across levels (:67,128)
-    atomicAdd(&n_pre_count[b], 1u);
-  }
-
-  const double dxp = pos[3 * fi] - c.ref_pos[0];
-  const double dyp = pos[3 * fi + 1] - c.ref_pos[1];
-  const double dzp = pos[3 * fi + 2] - c.ref_pos[2];
-  const double depth = sqrt(dxp * dxp + dyp * dyp + dzp * dzp);
-  const double xyz_ref[3] = {f[3 * fi] * depth, f[3 * fi + 1] * depth, f[3 * fi + 2] * depth};
-  double fj[12];
-  jacobian_xyz2uv(xyz_ref, fj);
-
-  const float subpix_u = u_ref - u_ref_i;
-  const float subpix_v = v_ref - v_ref_i;
-  const float w_tl = (float)((1.0 - subpix_u) * (1.0 - subpix_v));
-  const float w_tr = (float)(subpix_u * (1.0 - subpix_v));
-  const float w_bl = (float)((1.0 - subpix_u) * subpix_v);
-  const float w_br = subpix_u * subpix_v;
-
+  int lo, hi;
+  shard_range(c.n_feat, sh, &lo, &hi);
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tile_base = lo + tile * TILE;
+  if (tile_base >= hi) return;                       // wave-uniform
+  const int q = lane >> 2, r = lane & 3;
   const int stride = g.cols;
   const uint8_t* img = ref_base + (size_t)b * pyr_bytes + g.ref_off;
-  const int y = lane16 >> 2, x = lane16 & 3;
-  const uint8_t* p = img + (v_ref_i + y - 2) * stride + (u_ref_i - 2) + x;
-  // 3x3 neighbourhood + one more row/column: 12 distinct taps
-  const float p_m10 = p[-stride], p_m11 = p[1 - stride];
-  const float p_0m1 = p[-1], p_00 = p[0], p_01 = p[1], p_02 = p[2];
-  const float p_1m1 = p[stride - 1], p_10 = p[stride], p_11 = p[stride + 1], p_12 = p[stride + 2];
-  const float p_20 = p[2 * stride], p_21 = p[2 * stride + 1];
-  const float val = w_tl * p_00 + w_tr * p_01 + w_bl * p_10 + w_br * p_11;
-  const float dx = 0.5f * ((w_tl * p_01 + w_tr * p_02 + w_bl * p_11 + w_br * p_12) -
-                           (w_tl * p_0m1 + w_tr * p_00 + w_bl * p_1m1 + w_br * p_10));
-  const float dy = 0.5f * ((w_tl * p_10 + w_tr * p_11 + w_bl * p_20 + w_br * p_21) -
-                           (w_tl * p_m10 + w_tr * p_m11 + w_bl * p_00 + w_br * p_01));
-  ref_cache[fi * 16 + lane16] = val;
-  dxc[fi * 16 + lane16] = dx;
-  dyc[fi * 16 + lane16] = dy;
 
-  const double ddx = (double)dx, ddy = (double)dy;
-  const double sxx = group_sum<16>(ddx * ddx);
-  const double sxy = group_sum<16>(ddx * ddy);
-  const double syy = group_sum<16>(ddy * ddy);
-  const double jscale = fabs(c.cam.fx) / (1 << level);   // errorMultiplier2() / 2^L (:113,172-173)
-  double out;
-  if (lane16 < 12) out = fj[lane16] * jscale;            // A = row 0, B = row 1 of the 2x6 Jacobian
-  else if (lane16 == 12) out = sxx;
-  else if (lane16 == 13) out = sxy;
-  else if (lane16 == 14) out = syy;
-  else out = 0.0;
-  r[lane16] = out;
-  if (lane16 < 3) xyz[fi * 4 + lane16] = xyz_ref[lane16];
+  // ---- lane-per-patch: visibility in the reference image and bilinear weights (:121-142)
+  const int i_own = tile_base + 16 * r + q;
+  const size_t fo = (size_t)b * max_n + i_own;
+  bool valid = false;
+  float w_tl = 0, w_tr = 0, w_bl = 0, w_br = 0;
+  int off = 0;
+  if (i_own < hi) {
+    const int border = 3;
+    const float scale = 1.0f / (1 << level);
+    const float u_ref = (float)(px[2 * fo] * scale);
+    const float v_ref = (float)(px[2 * fo + 1] * scale);
+    const int u_ref_i = (int)floorf(u_ref);
+    const int v_ref_i = (int)floorf(v_ref);
+    valid = has_point[fo] && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= g.cols ||
+                               v_ref_i + border >= g.rows);
+    const float subpix_u = u_ref - u_ref_i;
+    const float subpix_v = v_ref - v_ref_i;
+    w_tl = (float)((1.0 - subpix_u) * (1.0 - subpix_v));
+    w_tr = (float)(subpix_u * (1.0 - subpix_v));
+    w_bl = (float)((1.0 - subpix_u) * subpix_v);
+    w_br = subpix_u * subpix_v;
+    off = (v_ref_i - 3) * stride + (u_ref_i - 3);    // top-left of the 8-byte-wide, 7-row footprint
+    const uint8_t fl = flags[fo];
+    // visible_fts_ is only ever set (:128); the Jacobian block is zero unless recomputed now (:76)
+    flags[fo] = valid ? (uint8_t)(F_VISIBLE | F_JVALID) : (uint8_t)(fl & F_VISIBLE);
+  }
+  {
+    const unsigned long long m = __ballot(valid);
+    if (lane == 0 && m) atomicAdd(&n_pre_count[b], (unsigned)__popcll(m));
+  }
+
+  // ---- lane-per-pixel-row: quad q works on patch 16s+q in sub-pass s, lane r on row r
+  double sxx = 0.0, sxy = 0.0, syy = 0.0;
+#define SVO_PRE_SUBPASS(S)                                                                              \
+  {                                                                                                     \
+    const bool v_s = quad_bcast<S>((int)valid) != 0;                                                    \
+    if (v_s) {                                                                                          \
+      const float a_tl = quad_bcast<S>(w_tl), a_tr = quad_bcast<S>(w_tr);                               \
+      const float a_bl = quad_bcast<S>(w_bl), a_br = quad_bcast<S>(w_br);                               \
+      const uint8_t* p = img + quad_bcast<S>(off) + r * stride;                                         \
+      const uint2 Rm = load_row8(p), R0 = load_row8(p + stride), R1 = load_row8(p + 2 * stride),        \
+                  R2 = load_row8(p + 3 * stride);                                                       \
+      float val[4], dx[4], dy[4];                                                                       \
+      double pxx = 0.0, pxy = 0.0, pyy = 0.0;                                                           \
+      _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                   \
+        const float m_1 = byte_f(Rm, x + 1), m_2 = byte_f(Rm, x + 2);                                   \
+        const float c_0 = byte_f(R0, x), c_1 = byte_f(R0, x + 1), c_2 = byte_f(R0, x + 2), c_3 = byte_f(R0, x + 3); \
+        const float d_0 = byte_f(R1, x), d_1 = byte_f(R1, x + 1), d_2 = byte_f(R1, x + 2), d_3 = byte_f(R1, x + 3); \
+        const float e_1 = byte_f(R2, x + 1), e_2 = byte_f(R2, x + 2);                                   \
+        val[x] = a_tl * c_1 + a_tr * c_2 + a_bl * d_1 + a_br * d_2;                                     \
+        dx[x] = 0.5f * ((a_tl * c_2 + a_tr * c_3 + a_bl * d_2 + a_br * d_3) -                          \
+                        (a_tl * c_0 + a_tr * c_1 + a_bl * d_0 + a_br * d_1));                          \
+        dy[x] = 0.5f * ((a_tl * d_1 + a_tr * d_2 + a_bl * e_1 + a_br * e_2) -                          \
+                        (a_tl * m_1 + a_tr * m_2 + a_bl * c_1 + a_br * c_2));                          \
+        const double ddx = (double)dx[x], ddy = (double)dy[x];                                          \
+        pxx += ddx * ddx; pxy += ddx * ddy; pyy += ddy * ddy;                                           \
+      }                                                                                                 \
+      const size_t o4 = ((size_t)b * max_n + tile_base + 16 * S + q) * 4 + r;                          \
+      ref_cache[o4] = make_float4(val[0], val[1], val[2], val[3]);                                      \
+      dxc[o4] = make_float4(dx[0], dx[1], dx[2], dx[3]);                                                \
+      dyc[o4] = make_float4(dy[0], dy[1], dy[2], dy[3]);                                                \
+      pxx = quad_sum(pxx); pxy = quad_sum(pxy); pyy = quad_sum(pyy);                                    \
+      if (r == S) { sxx = pxx; sxy = pxy; syy = pyy; }                                                  \
+    }                                                                                                   \
+  }
+  SVO_PRE_SUBPASS(0) SVO_PRE_SUBPASS(1) SVO_PRE_SUBPASS(2) SVO_PRE_SUBPASS(3)
+#undef SVO_PRE_SUBPASS
+
+  // ---- lane-per-patch: per-patch sums and the tile's Hessian row
+  double hp[21];
+#pragma unroll
+  for (int e = 0; e < 21; ++e) hp[e] = 0.0;
+  if (valid) {
+    sxyz[fo] = make_double4(sxx, sxy, syy, 0.0);
+    const double4 X = xyz4[fo];
+    double A[6], B[6];
+    patch_jacobian_rows(X.x, X.y, X.w, fabs(c.cam.fx) / (1 << level), A, B);   // errorMultiplier2()/2^L (:113,172)
+    patch_hessian(A, B, sxx, sxy, syy, hp);
+  }
+  double mine = 0.0;
+#pragma unroll
+  for (int e = 0; e < 21; ++e) {
+    const double t = group_sum<64>(hp[e]);
+    if (lane == e) mine = t;
+  }
+  if (lane < TILE_ROW) tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane] = lane < 21 ? mine : 0.0;
 }
 
 // One computeResiduals(linearize=true) evaluation for every live frame.
-// grid = (chunks, n_slots), block = 256 (16 patches per pass).  Output: one partial row of RED
-// doubles per block.
+// grid = (chunks, n_slots), block = 256; wave w of chunk c walks tiles c*tpc + w, +4, ...
+// Output: one partial row of RED doubles per block.
 __global__ __launch_bounds__(256) void sia_residual_kernel(
     const FrameConst* __restrict__ fc, const FrameState* __restrict__ st, const uint8_t* __restrict__ cur_base,
-    size_t pyr_bytes, LevelGeom g, int level, int max_n, int chunks, int shard_rank, int shard_world,
-    const float* __restrict__ ref_cache, const float* __restrict__ dxc, const float* __restrict__ dyc,
-    const double* __restrict__ rec, const double* __restrict__ xyz, const uint8_t* __restrict__ visible,
-    double* __restrict__ partial) {
+    size_t pyr_bytes, LevelGeom g, int level, int max_n, int max_tiles, int chunks, Shard sh,
+    const float4* __restrict__ ref_cache, const float4* __restrict__ dxc, const float4* __restrict__ dyc,
+    const double4* __restrict__ sxyz, const double4* __restrict__ xyz4, const double* __restrict__ tile_h,
+    const uint8_t* __restrict__ flags, double* __restrict__ partial) {
   const int b = blockIdx.y;
   const int chunk = blockIdx.x;
   const FrameState& s = st[b];
@@ -202,94 +306,162 @@ __global__ __launch_bounds__(256) void sia_residual_kernel(
 #pragma unroll
   for (int k = 0; k < 7; ++k) T[k] = s.model[k];
 
-  const int n = c.n_feat;
-  const int lo = (int)(((long long)n * shard_rank) / shard_world);
-  const int hi = (int)(((long long)n * (shard_rank + 1)) / shard_world);
-  const int per = (((hi - lo) + chunks - 1) / chunks + 15) & ~15;
-  const int c_lo = lo + chunk * per;
-  const int c_hi = min(hi, c_lo + per);
+  int lo, hi;
+  shard_range(c.n_feat, sh, &lo, &hi);
+  const int n_tiles = (hi - lo + TILE - 1) / TILE;
+  const int tpc = (n_tiles + chunks - 1) / chunks;
+  const int t_end = min(n_tiles, (chunk + 1) * tpc);
 
-  const int lane16 = threadIdx.x & 15;
-  const int grp = threadIdx.x >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 2, r = lane & 3;
   const int border = 3;
   const float scale = 1.0f / (1 << level);
   const int stride = g.cols;
   const uint8_t* img = cur_base + (size_t)b * pyr_bytes + g.cur_off;
-  const int py = lane16 >> 2, pxx = lane16 & 3;
+  const double jscale = fabs(cam.fx) / (1 << level);
 
-  // this lane's two reduction items: e0 = lane16 (H entries 0..15), e1 = 16 + lane16:
-  //   16..20 -> H entries, 21..26 -> Jres[0..5], 27 -> chi2 sum, 28 -> n_meas
-  const int e1 = 16 + lane16;
-  const int i0 = kTriI[lane16], j0 = kTriJ[lane16];
-  const int i1 = e1 < 21 ? kTriI[e1] : 0, j1 = e1 < 21 ? kTriJ[e1] : 0;
-  const int jr = e1 - 21;            // Jres index when 0 <= jr < 6
-  double acc0 = 0.0, acc1 = 0.0;
+  double accH = 0.0;                       // lane e < 21 accumulates H entry e
+  double accJ[6] = {0, 0, 0, 0, 0, 0};     // lane-per-patch partial sums of Jres
+  double acc_chi = 0.0;
+  unsigned acc_n = 0;
 
-  for (int base = c_lo; base < c_hi; base += 16) {
-    const int i = base + grp;
-    if (i >= c_hi) continue;
-    const size_t fi = (size_t)b * max_n + i;
-    if (!visible[fi]) continue;
-    const double xyz_ref[3] = {xyz[fi * 4], xyz[fi * 4 + 1], xyz[fi * 4 + 2]};
-    double xyz_cur[3], pxd[2];
-    se3_act(T, xyz_ref, xyz_cur);
-    world2cam(cam, xyz_cur, pxd);
-    const float u_cur = (float)pxd[0] * scale;
-    const float v_cur = (float)pxd[1] * scale;
-    const int u_cur_i = (int)floorf(u_cur);
-    const int v_cur_i = (int)floorf(v_cur);
-    // NaN projections compare false everywhere in the reference and would read out of bounds
-    // there; here they are treated as outside the image.
-    if (!(u_cur_i >= 0 && v_cur_i >= 0 && u_cur_i - border >= 0 && v_cur_i - border >= 0 &&
-          u_cur_i + border < g.cols && v_cur_i + border < g.rows) || u_cur != u_cur || v_cur != v_cur)
-      continue;
-    const float subpix_u = u_cur - u_cur_i;
-    const float subpix_v = v_cur - v_cur_i;
-    const float w_tl = (float)((1.0 - subpix_u) * (1.0 - subpix_v));
-    const float w_tr = (float)(subpix_u * (1.0 - subpix_v));
-    const float w_bl = (float)((1.0 - subpix_u) * subpix_v);
-    const float w_br = subpix_u * subpix_v;
-    const uint8_t* p = img + (v_cur_i + py - 2) * stride + (u_cur_i - 2) + pxx;
-    const float intensity = w_tl * p[0] + w_tr * p[1] + w_bl * p[stride] + w_br * p[stride + 1];
-    const float res = intensity - ref_cache[fi * 16 + lane16];
-    const double dres = (double)res;
-    const float chi2p = group_sum<16>(res * res);
-    const double sdx = group_sum<16>((double)dxc[fi * 16 + lane16] * dres);
-    const double sdy = group_sum<16>((double)dyc[fi * 16 + lane16] * dres);
+  for (int tile = chunk * tpc + wave; tile < t_end; tile += 4) {
+    const int tile_base = lo + tile * TILE;
+    // ---- lane-per-patch: project the patch into the current image (:220-236)
+    const int i_own = tile_base + 16 * r + q;
+    const size_t fo = (size_t)b * max_n + i_own;
+    bool ok = false, jvalid = false;
+    float w_tl = 0, w_tr = 0, w_bl = 0, w_br = 0;
+    int off = 0;
+    double4 X = make_double4(0, 0, 1, 1);
+    if (i_own < hi) {
+      const uint8_t fl = flags[fo];
+      jvalid = (fl & F_JVALID) != 0;
+      if (fl & F_VISIBLE) {
+        X = xyz4[fo];
+        const double xyz_ref[3] = {X.x, X.y, X.z};
+        double xyz_cur[3], pxd[2];
+        se3_act(T, xyz_ref, xyz_cur);
+        world2cam(cam, xyz_cur, pxd);
+        const float u_cur = (float)pxd[0] * scale;
+        const float v_cur = (float)pxd[1] * scale;
+        const int u_cur_i = (int)floorf(u_cur);
+        const int v_cur_i = (int)floorf(v_cur);
+        // NaN projections compare false everywhere in the reference and would read out of bounds
+        // there; here they are outside the image.
+        ok = (u_cur_i >= 0 && v_cur_i >= 0 && u_cur_i - border >= 0 && v_cur_i - border >= 0 &&
+              u_cur_i + border < g.cols && v_cur_i + border < g.rows) && u_cur == u_cur && v_cur == v_cur;
+        const float subpix_u = u_cur - u_cur_i;
+        const float subpix_v = v_cur - v_cur_i;
+        w_tl = (float)((1.0 - subpix_u) * (1.0 - subpix_v));
+        w_tr = (float)(subpix_u * (1.0 - subpix_v));
+        w_bl = (float)((1.0 - subpix_u) * subpix_v);
+        w_br = subpix_u * subpix_v;
+        off = ok ? (v_cur_i - 2) * stride + (u_cur_i - 2) : 0;
+      }
+    }
 
-    const double* r = rec + fi * 16;
-    const double sxx = r[12], sxy = r[13], syy = r[14];
+    // ---- lane-per-pixel-row: residuals of patch 16s+q, row r (:238-279).
+    // All loads of the four sub-passes are issued up front and unconditionally (a patch that is
+    // not ok reads row r of the image / a cache row of its own slot: valid memory, result unused)
+    // so their latencies overlap instead of queueing behind one another.
+    double sdx = 0.0, sdy = 0.0;
+    float chi = 0.0f;
     {
-      const double Ai = r[i0], Aj = r[j0], Bi = r[6 + i0], Bj = r[6 + j0];
-      acc0 += sxx * (Ai * Aj) + sxy * (Ai * Bj + Bi * Aj) + syy * (Bi * Bj);
+      const size_t o4 = ((size_t)b * max_n + tile_base + q) * 4 + r;
+      float4 rc[4], gx[4], gy[4];
+      uint2 R0[4], R1[4];
+      float a_tl[4], a_tr[4], a_bl[4], a_br[4];
+#pragma unroll
+      for (int S = 0; S < 4; ++S) {
+        rc[S] = ref_cache[o4 + 64 * S];
+        gx[S] = dxc[o4 + 64 * S];
+        gy[S] = dyc[o4 + 64 * S];
+      }
+#define SVO_BCAST(S)                                                                  \
+      {                                                                               \
+        const uint8_t* p = img + quad_bcast<S>(off) + r * stride;                     \
+        R0[S] = load_row8(p); R1[S] = load_row8(p + stride);                          \
+        a_tl[S] = quad_bcast<S>(w_tl); a_tr[S] = quad_bcast<S>(w_tr);                 \
+        a_bl[S] = quad_bcast<S>(w_bl); a_br[S] = quad_bcast<S>(w_br);                 \
+      }
+      SVO_BCAST(0) SVO_BCAST(1) SVO_BCAST(2) SVO_BCAST(3)
+#undef SVO_BCAST
+#pragma unroll
+      for (int S = 0; S < 4; ++S) {
+        const float rcv[4] = {rc[S].x, rc[S].y, rc[S].z, rc[S].w};
+        const float gxv[4] = {gx[S].x, gx[S].y, gx[S].z, gx[S].w};
+        const float gyv[4] = {gy[S].x, gy[S].y, gy[S].z, gy[S].w};
+        double px_ = 0.0, py_ = 0.0;
+        float pc = 0.0f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float inten = a_tl[S] * byte_f(R0[S], x) + a_tr[S] * byte_f(R0[S], x + 1) +
+                              a_bl[S] * byte_f(R1[S], x) + a_br[S] * byte_f(R1[S], x + 1);
+          const float res = inten - rcv[x];
+          pc += res * res;
+          const double dres = (double)res;
+          px_ += (double)gxv[x] * dres;
+          py_ += (double)gyv[x] * dres;
+        }
+        px_ = quad_sum(px_); py_ = quad_sum(py_); pc = quad_sum(pc);
+        if (r == S) { sdx = px_; sdy = py_; chi = pc; }
+      }
     }
-    if (e1 < 21) {
-      const double Ai = r[i1], Aj = r[j1], Bi = r[6 + i1], Bj = r[6 + j1];
-      acc1 += sxx * (Ai * Aj) + sxy * (Ai * Bj + Bi * Aj) + syy * (Bi * Bj);
-    } else if (jr < 6) {
-      acc1 -= r[jr] * sdx + r[6 + jr] * sdy;           // Jres_ -= J*res (:273)
-    } else if (e1 == 27) {
-      acc1 += (double)chi2p;
-    } else if (e1 == 28) {
-      acc1 += 16.0;
+
+    // ---- lane-per-patch: normal equations
+    const bool lin = ok && jvalid;          // the patch carries a non-zero Jacobian block
+    if (ok) { acc_chi += (double)chi; acc_n += 16; }
+    double A[6], B[6];
+    if (lin) {
+      patch_jacobian_rows(X.x, X.y, X.w, jscale, A, B);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) accJ[k] -= A[k] * sdx + B[k] * sdy;          // Jres_ -= J*res (:273)
+    }
+    // H: the tile row is exact when no linearised patch of the tile left the image
+    const bool tile_whole = __ballot(jvalid && !ok) == 0ull;
+    if (tile_whole) {
+      if (lane < 21) accH += tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane];
+    } else {
+      // rare: rebuild the tile's H from the patches that are inside the image now
+      double4 S4 = make_double4(0, 0, 0, 0);
+      if (lin) S4 = sxyz[fo];
+      int e = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+          double h = 0.0;
+          if (lin) h = S4.x * (A[i] * A[j]) + S4.y * (A[i] * B[j] + B[i] * A[j]) + S4.z * (B[i] * B[j]);
+          const double t = group_sum<64>(h);
+          if (lane == e) accH += t;
+          ++e;
+        }
     }
   }
 
-  // reduce the 16 patch groups of the block: 4 groups per wave by shuffles, then 4 waves via LDS
-  acc0 += __shfl_xor(acc0, 16, 64); acc0 += __shfl_xor(acc0, 32, 64);
-  acc1 += __shfl_xor(acc1, 16, 64); acc1 += __shfl_xor(acc1, 32, 64);
-  __shared__ double red[4][32];
-  const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
-  if (wl < 16) { red[wave][wl] = acc0; red[wave][16 + wl] = acc1; }
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    double v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (threadIdx.x >= 29) v = 0.0;
-    out_row[threadIdx.x] = v;
+  // ---- wave reduction of the lane-per-patch sums, then the 4 waves through LDS
+  double mine = accH;                       // lanes 0..20
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double t = group_sum<64>(accJ[k]);
+    if (lane == 21 + k) mine = t;
   }
+  {
+    const double t = group_sum<64>(acc_chi);
+    if (lane == 27) mine = t;
+    const int tn = group_sum<64>((int)acc_n);
+    if (lane == 28) mine = (double)tn;
+  }
+  __shared__ double red[4][32];
+  if (lane < 32) red[wave][lane] = lane < 29 ? mine : 0.0;
+  __syncthreads();
+  if (threadIdx.x < 32)
+    out_row[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// Sum the block partials of each frame in fixed order -> reduce buffer [n_slots][RED].
+// Sum the block partials of each frame in fixed order -> reduce buffer [n_slots][RED]
+// (only needed when the sums leave the device loop, i.e. for the all-reduce path).
 __global__ void sia_sum_partials_kernel(const FrameState* __restrict__ st, const double* __restrict__ partial,
                                         int chunks, double* __restrict__ reduce, int n_slots) {
   const int b = blockIdx.x;
@@ -302,31 +474,55 @@ __global__ void sia_sum_partials_kernel(const FrameState* __restrict__ st, const
   reduce[(size_t)b * RED + t] = v;
 }
 
-// One Gauss-Newton control step per frame (one thread per frame):
+// One Gauss-Newton control step per frame, one wave per frame: lanes 0..28 gather the
+// frame's sums (from the block partials, or from the all-reduced buffer), lane 0 runs
 // I/nlls_solver_impl.hpp:35-99 with solve()/update() of S/sparse_img_align.cpp:291-308.
-__global__ void sia_solve_kernel(FrameState* __restrict__ st, const double* __restrict__ reduce, int n_slots,
-                                 int level, int n_iter, double eps, int early_stop) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+template <bool FROM_PARTIALS>
+__global__ __launch_bounds__(64) void sia_solve_kernel(FrameState* __restrict__ st, const double* __restrict__ src,
+                                                       int chunks, int n_slots, int level, int n_iter, double eps,
+                                                       int early_stop) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
   if (b >= n_slots) return;
   FrameState& s = st[b];
   if (s.level_done) return;
-  const double* r = reduce + (size_t)b * RED;
+  __shared__ double r[RED];
+  if (lane < RED) {
+    double v = 0.0;
+    if (FROM_PARTIALS) {
+      const double* p = src + (size_t)b * chunks * RED + lane;
+      for (int c = 0; c < chunks; ++c) v += p[(size_t)c * RED];
+    } else {
+      v = src[(size_t)b * RED + lane];
+    }
+    r[lane] = v;
+  }
+  __syncthreads();
+  if (lane != 0) return;
   double H[36], Jres[6], x[6];
-  int k = 0;
-  for (int i = 0; i < 6; ++i)
-    for (int j = i; j < 6; ++j) { H[i * 6 + j] = r[k]; H[j * 6 + i] = r[k]; ++k; }
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) { H[i * 6 + j] = r[k]; H[j * 6 + i] = r[k]; ++k; }
+  }
+#pragma unroll
   for (int i = 0; i < 6; ++i) Jres[i] = r[21 + i];
   const double chi2_sum = r[27];
   const unsigned long long n_meas = (unsigned long long)(r[28] + 0.5);
   // computeResiduals returns float chi2 / size_t n_meas evaluated in float (:285)
   const double new_chi2 = (double)((float)chi2_sum / (float)n_meas);
+#pragma unroll
   for (int i = 0; i < 36; ++i) s.H[i] = H[i];
+#pragma unroll
   for (int i = 0; i < 6; ++i) s.Jres[i] = Jres[i];
   s.n_meas = n_meas;
   s.n_res += n_meas / 16;
   s.iters[level] += 1;
 
-  ldlt6_solve(H, Jres, x);
+  ldlt6_solve_reg(H, Jres, x);
+#pragma unroll
   for (int i = 0; i < 6; ++i) s.x[i] = x[i];
   if (x[0] != x[0]) s.stop = 1;                               // NaN -> stop_ (:52-59)
   const int iter = s.iter;
@@ -335,17 +531,24 @@ __global__ void sia_solve_kernel(FrameState* __restrict__ st, const double* __re
     s.level_done = 1;
     return;
   }
-  double mx[6], dT[7], nm[7];
+  double mx[6], dT[7], nm[7], cur[7];
+#pragma unroll
   for (int i = 0; i < 6; ++i) mx[i] = -x[i];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) cur[i] = s.model[i];
   se3_exp(mx, dT);
-  se3_mul(s.model, dT, nm);                                   // T_new = T_old * exp(-x) (:307)
-  for (int i = 0; i < 7; ++i) { s.old_model[i] = s.model[i]; s.model[i] = nm[i]; }
+  se3_mul(cur, dT, nm);                                       // T_new = T_old * exp(-x) (:307)
+#pragma unroll
+  for (int i = 0; i < 7; ++i) { s.old_model[i] = cur[i]; s.model[i] = nm[i]; }
   s.chi2 = new_chi2;
   double mxn = -1;
+#pragma unroll
   for (int i = 0; i < 6; ++i) { double a = fabs(x[i]); if (a > mxn) mxn = a; }
-  if (early_stop && mxn <= eps) s.level_done = 1;             // :97-98
+  int done = 0;
+  if (early_stop && mxn <= eps) done = 1;                     // :97-98
   s.iter = iter + 1;
-  if (s.iter >= n_iter) s.level_done = 1;
+  if (iter + 1 >= n_iter) done = 1;
+  if (done) s.level_done = 1;
 }
 
 __global__ void sia_finish_kernel(const FrameConst* __restrict__ fc, FrameState* __restrict__ st,
@@ -371,8 +574,10 @@ struct svo_hip_sia {
   FrameState* st = nullptr;
   double *px = nullptr, *f = nullptr, *pos = nullptr;
   uint8_t *has_point = nullptr, *visible = nullptr;
-  float *ref_cache = nullptr, *dxc = nullptr, *dyc = nullptr;
-  double *rec = nullptr, *xyz = nullptr;
+  float4 *ref_cache = nullptr, *dxc = nullptr, *dyc = nullptr;   // [batch][max_n][4 rows] x float4
+  double4 *sxyz = nullptr, *xyz4 = nullptr;                      // {sxx,sxy,syy,-}, {x,y,z,1/z} per patch
+  double* tile_h = nullptr;                                      // [batch][max_tiles][TILE_ROW]
+  int max_tiles = 0;
   double* partial = nullptr;
   double* reduce_own = nullptr;
   double* reduce = nullptr;
@@ -401,9 +606,13 @@ int dev_alloc(svo_hip_ctx* ctx, T** p, size_t count) {
   return rc;
 }
 
+// blocks per frame for the residual kernel: aim at >= ~1024 blocks (4096 waves) on the chip while
+// giving every wave as many tiles as possible (the per-wave reduction is amortised over them)
 int pick_chunks(int n_slots, int max_n) {
-  int c = (2048 + n_slots - 1) / n_slots;
-  int cap = (max_n + 15) / 16;
+  const char* env = getenv("SVO_HIP_SIA_CHUNKS");
+  int tiles = (max_n + TILE - 1) / TILE;
+  int cap = (tiles + 3) / 4;                 // at least one tile per wave
+  int c = env ? atoi(env) : (1024 + n_slots - 1) / n_slots;
   if (c > cap) c = cap;
   if (c > MAX_CHUNKS) c = MAX_CHUNKS;
   if (c < 1) c = 1;
@@ -448,8 +657,10 @@ int svo_hip_sia_create(svo_hip_ctx* ctx, int batch, int max_features, svo_hip_si
   A(dev_alloc(ctx, &s->fc, batch)); A(dev_alloc(ctx, &s->st, batch));
   A(dev_alloc(ctx, &s->px, bn * 2)); A(dev_alloc(ctx, &s->f, bn * 3)); A(dev_alloc(ctx, &s->pos, bn * 3));
   A(dev_alloc(ctx, &s->has_point, bn)); A(dev_alloc(ctx, &s->visible, bn));
-  A(dev_alloc(ctx, &s->ref_cache, bn * 16)); A(dev_alloc(ctx, &s->dxc, bn * 16)); A(dev_alloc(ctx, &s->dyc, bn * 16));
-  A(dev_alloc(ctx, &s->rec, bn * 16)); A(dev_alloc(ctx, &s->xyz, bn * 4));
+  s->max_tiles = (max_features + TILE - 1) / TILE + 1;
+  A(dev_alloc(ctx, &s->ref_cache, bn * 4 + 256)); A(dev_alloc(ctx, &s->dxc, bn * 4 + 256)); A(dev_alloc(ctx, &s->dyc, bn * 4 + 256));
+  A(dev_alloc(ctx, &s->sxyz, bn + 64)); A(dev_alloc(ctx, &s->xyz4, bn + 64));
+  A(dev_alloc(ctx, &s->tile_h, (size_t)batch * s->max_tiles * TILE_ROW));
   A(dev_alloc(ctx, &s->partial, (size_t)batch * MAX_CHUNKS * RED));
   A(dev_alloc(ctx, &s->reduce_own, (size_t)batch * RED));
   A(dev_alloc(ctx, &s->n_pre_count, batch));
@@ -459,6 +670,10 @@ int svo_hip_sia_create(svo_hip_ctx* ctx, int batch, int max_features, svo_hip_si
   s->reduce = s->reduce_own;
   (void)hipMemsetAsync(s->has_point, 0, bn, ctx->stream);
   (void)hipMemsetAsync(s->ref_cache, 0, bn * 16 * sizeof(float), ctx->stream);
+  (void)hipMemsetAsync(s->dxc, 0, bn * 16 * sizeof(float), ctx->stream);
+  (void)hipMemsetAsync(s->dyc, 0, bn * 16 * sizeof(float), ctx->stream);
+  (void)hipMemsetAsync(s->sxyz, 0, bn * sizeof(double4), ctx->stream);
+  (void)hipMemsetAsync(s->xyz4, 0, bn * sizeof(double4), ctx->stream);
   (void)hipMemsetAsync(s->st, 0, sizeof(FrameState) * batch, ctx->stream);
   *out = s;
   return SVO_HIP_OK;
@@ -469,7 +684,7 @@ int svo_hip_sia_destroy(svo_hip_sia* s) {
   svo_hip_ctx* ctx = s->ctx;
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {s->fc, s->st, s->px, s->f, s->pos, s->has_point, s->visible, s->ref_cache, s->dxc, s->dyc,
-                  s->rec, s->xyz, s->partial, s->reduce_own, s->n_pre_count};
+                  s->sxyz, s->xyz4, s->tile_h, s->partial, s->reduce_own, s->n_pre_count};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev_res) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_pre) (void)hipEventDestroy(e);
@@ -552,6 +767,9 @@ int svo_hip_sia_begin(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm
   SVO_CHECK_HIP(ctx, hipMemsetAsync(s->n_pre_count, 0, sizeof(unsigned) * n_slots, ctx->stream));
   hipLaunchKernelGGL(sia_begin_kernel, dim3((n_slots + 63) / 64), dim3(64), 0, ctx->stream, s->fc, s->st, n_slots);
   SVO_CHECK_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(sia_geometry_kernel, dim3((s->max_n + 255) / 256, n_slots), dim3(256), 0, ctx->stream, s->fc,
+                     s->max_n, s->f, s->pos, s->xyz4);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
 }
 
@@ -564,13 +782,44 @@ int svo_hip_sia_level_begin(svo_hip_sia* s, int level) {
   LevelGeom g;
   g.cols = s->ref->width >> level; g.rows = s->ref->height >> level;
   g.ref_off = s->ref->level_offset[level]; g.cur_off = s->cur->level_offset[level];
-  dim3 grid((s->max_n + 15) / 16, s->n_slots), block(256);
+  dim3 grid((s->max_n + 255) / 256, s->n_slots), block(256);
+  const Shard sh = {s->shard_rank, s->shard_world};
   hipEvent_t* ev = next_events(s, s->ev_pre, s->ev_pre_used);
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
   hipLaunchKernelGGL(sia_precompute_kernel, grid, block, 0, ctx->stream, s->fc, s->st, s->ref->base,
-                     s->ref->pyr_bytes, g, level, s->max_n, s->shard_rank, s->shard_world, s->px, s->f, s->pos,
-                     s->has_point, s->ref_cache, s->dxc, s->dyc, s->rec, s->xyz, s->visible, s->n_pre_count);
+                     s->ref->pyr_bytes, g, level, s->max_n, s->max_tiles, sh, s->px, s->has_point, s->xyz4,
+                     s->ref_cache, s->dxc, s->dyc, s->sxyz, s->tile_h, s->visible, s->n_pre_count);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+static int launch_residual(svo_hip_sia* s) {
+  svo_hip_ctx* ctx = s->ctx;
+  const int level = s->level;
+  LevelGeom g;
+  g.cols = s->ref->width >> level; g.rows = s->ref->height >> level;
+  g.ref_off = s->ref->level_offset[level]; g.cur_off = s->cur->level_offset[level];
+  dim3 grid(s->chunks, s->n_slots), block(256);
+  hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
+  if (ev) (void)hipEventRecord(ev[0], ctx->stream);
+  const Shard sh = {s->shard_rank, s->shard_world};
+  hipLaunchKernelGGL(sia_residual_kernel, grid, block, 0, ctx->stream, s->fc, s->st, s->cur->base, s->cur->pyr_bytes,
+                     g, level, s->max_n, s->max_tiles, s->chunks, sh, s->ref_cache, s->dxc, s->dyc, s->sxyz, s->xyz4,
+                     s->tile_h, s->visible, s->partial);
+  if (ev) (void)hipEventRecord(ev[1], ctx->stream);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+static int launch_solve(svo_hip_sia* s, bool from_partials) {
+  svo_hip_ctx* ctx = s->ctx;
+  if (from_partials)
+    hipLaunchKernelGGL(sia_solve_kernel<true>, dim3(s->n_slots), dim3(64), 0, ctx->stream, s->st, s->partial, s->chunks,
+                       s->n_slots, s->level, s->prm.n_iter, s->prm.eps, s->prm.early_stop);
+  else
+    hipLaunchKernelGGL(sia_solve_kernel<false>, dim3(s->n_slots), dim3(64), 0, ctx->stream, s->st, s->reduce, s->chunks,
+                       s->n_slots, s->level, s->prm.n_iter, s->prm.eps, s->prm.early_stop);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
 }
@@ -579,18 +828,8 @@ int svo_hip_sia_accumulate(svo_hip_sia* s) {
   if (!s) return SVO_HIP_ERR_INVALID;
   svo_hip_ctx* ctx = s->ctx;
   if (!s->begun || s->level < 0) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_accumulate", "level_begin not called");
-  const int level = s->level;
-  LevelGeom g;
-  g.cols = s->ref->width >> level; g.rows = s->ref->height >> level;
-  g.ref_off = s->ref->level_offset[level]; g.cur_off = s->cur->level_offset[level];
-  dim3 grid(s->chunks, s->n_slots), block(256);
-  hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
-  if (ev) (void)hipEventRecord(ev[0], ctx->stream);
-  hipLaunchKernelGGL(sia_residual_kernel, grid, block, 0, ctx->stream, s->fc, s->st, s->cur->base, s->cur->pyr_bytes,
-                     g, level, s->max_n, s->chunks, s->shard_rank, s->shard_world, s->ref_cache, s->dxc, s->dyc,
-                     s->rec, s->xyz, s->visible, s->partial);
-  if (ev) (void)hipEventRecord(ev[1], ctx->stream);
-  SVO_CHECK_HIP(ctx, hipGetLastError());
+  int rc = launch_residual(s);
+  if (rc != SVO_HIP_OK) return rc;
   hipLaunchKernelGGL(sia_sum_partials_kernel, dim3(s->n_slots), dim3(RED), 0, ctx->stream, s->st, s->partial,
                      s->chunks, s->reduce, s->n_slots);
   SVO_CHECK_HIP(ctx, hipGetLastError());
@@ -601,10 +840,7 @@ int svo_hip_sia_solve_update(svo_hip_sia* s) {
   if (!s) return SVO_HIP_ERR_INVALID;
   svo_hip_ctx* ctx = s->ctx;
   if (!s->begun || s->level < 0) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_solve_update", "level_begin not called");
-  hipLaunchKernelGGL(sia_solve_kernel, dim3((s->n_slots + 63) / 64), dim3(64), 0, ctx->stream, s->st, s->reduce,
-                     s->n_slots, s->level, s->prm.n_iter, s->prm.eps, s->prm.early_stop);
-  SVO_CHECK_HIP(ctx, hipGetLastError());
-  return SVO_HIP_OK;
+  return launch_solve(s, false);
 }
 
 int svo_hip_sia_finish(svo_hip_sia* s) {
@@ -624,8 +860,9 @@ int svo_hip_sia_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) 
   for (int level = prm->max_level; level >= prm->min_level; --level) {
     if ((rc = svo_hip_sia_level_begin(s, level)) != SVO_HIP_OK) return rc;
     for (int it = 0; it < prm->n_iter; ++it) {
-      if ((rc = svo_hip_sia_accumulate(s)) != SVO_HIP_OK) return rc;
-      if ((rc = svo_hip_sia_solve_update(s)) != SVO_HIP_OK) return rc;
+      // single device: the solve gathers the block partials itself (no separate sum kernel)
+      if ((rc = launch_residual(s)) != SVO_HIP_OK) return rc;
+      if ((rc = launch_solve(s, true)) != SVO_HIP_OK) return rc;
     }
   }
   return svo_hip_sia_finish(s);
@@ -713,10 +950,13 @@ int svo_hip_sia_download_caches(svo_hip_sia* s, int slot, float* ref_patch, floa
   const size_t o = (size_t)slot * s->max_n;
   const int n = s->h_fc[slot].n_feat;
   int rc = SVO_HIP_OK;
-  if (ref_patch && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, ref_patch, s->ref_cache + o * 16, sizeof(float) * 16 * n);
-  if (dx && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, dx, s->dxc + o * 16, sizeof(float) * 16 * n);
-  if (dy && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, dy, s->dyc + o * 16, sizeof(float) * 16 * n);
-  if (visible && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, visible, s->visible + o, (size_t)n);
+  if (ref_patch && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, ref_patch, s->ref_cache + o * 4, sizeof(float) * 16 * n);
+  if (dx && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, dx, s->dxc + o * 4, sizeof(float) * 16 * n);
+  if (dy && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, dy, s->dyc + o * 4, sizeof(float) * 16 * n);
+  if (visible && rc == SVO_HIP_OK) {
+    rc = svo_hip_memcpy_d2h(ctx, visible, s->visible + o, (size_t)n);
+    for (int i = 0; i < n; ++i) visible[i] &= 1;     // bit 0 = visible_fts_, bit 1 is internal
+  }
   return rc;
 }
 
