@@ -568,4 +568,40 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
   return SVO_HIP_OK;
 }
 
+// host-buffer convenience form: copies the SoA arrays in, runs, copies the results out, synchronises
+int svo_hip_depth_filter_update(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot, const svo_hip_pyramid* cur,
+                                int cur_slot, const svo_hip_camera* cam, const double T_ref_w[7], const double T_cur_w[7],
+                                int n, const double* px, const double* f, const int32_t* level, float* a, float* b,
+                                float* mu, const float* z_range, float* sigma2, const svo_hip_df_params* prm,
+                                int32_t* status, double* z, double* xyz_world, int32_t* n_zmssd, int32_t* n_align_iters) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n >= 0);
+  if (n == 0) return SVO_HIP_OK;
+  SVO_REQUIRE(ctx, px && f && level && a && b && mu && z_range && sigma2 && status);
+  const size_t N = (size_t)n;
+  // one device block: px(16) f(24) z(8) xyz(24) level(4) a b mu zr s2 (5x4) status nz na (3x4) = 108 B / seed
+  const size_t o_px = 0, o_f = o_px + 16 * N, o_z = o_f + 24 * N, o_xyz = o_z + 8 * N, o_lvl = o_xyz + 24 * N,
+               o_a = o_lvl + 4 * N, o_b = o_a + 4 * N, o_mu = o_b + 4 * N, o_zr = o_mu + 4 * N, o_s2 = o_zr + 4 * N,
+               o_st = o_s2 + 4 * N, o_nz = o_st + 4 * N, o_na = o_nz + 4 * N, total = o_na + 4 * N;
+  void* blk = nullptr;
+  int rc = svo_hip_malloc(ctx, &blk, total);
+  if (rc != SVO_HIP_OK) return rc;
+  uint8_t* d = (uint8_t*)blk;
+  auto up = [&](size_t off, const void* src, size_t bytes) { if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d + off, src, bytes); };
+  up(o_px, px, 16 * N); up(o_f, f, 24 * N); up(o_lvl, level, 4 * N); up(o_a, a, 4 * N); up(o_b, b, 4 * N);
+  up(o_mu, mu, 4 * N); up(o_zr, z_range, 4 * N); up(o_s2, sigma2, 4 * N);
+  if (rc == SVO_HIP_OK)
+    rc = svo_hip_depth_filter_update_dev(ctx, ref, ref_slot, cur, cur_slot, cam, T_ref_w, T_cur_w, n, (double*)(d + o_px),
+                                         (double*)(d + o_f), (int32_t*)(d + o_lvl), (float*)(d + o_a), (float*)(d + o_b),
+                                         (float*)(d + o_mu), (float*)(d + o_zr), (float*)(d + o_s2), prm,
+                                         (int32_t*)(d + o_st), (double*)(d + o_z), (double*)(d + o_xyz),
+                                         (int32_t*)(d + o_nz), (int32_t*)(d + o_na));
+  auto down = [&](void* dst, size_t off, size_t bytes) { if (rc == SVO_HIP_OK && dst) rc = svo_hip_memcpy_d2h(ctx, dst, d + off, bytes); };
+  down(a, o_a, 4 * N); down(b, o_b, 4 * N); down(mu, o_mu, 4 * N); down(sigma2, o_s2, 4 * N);
+  down(status, o_st, 4 * N); down(z, o_z, 8 * N); down(xyz_world, o_xyz, 24 * N); down(n_zmssd, o_nz, 4 * N);
+  down(n_align_iters, o_na, 4 * N);
+  (void)svo_hip_free(ctx, blk);
+  return rc;
+}
+
 }  // extern "C"

@@ -81,6 +81,10 @@ struct LevelGeom {
 
 struct Shard { int rank, world; };
 
+// upper-triangle (row-major) index -> (i, j)
+__device__ __constant__ int8_t kTriI[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+__device__ __constant__ int8_t kTriJ[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+
 SVO_DEV void shard_range(int n, Shard sh, int* lo, int* hi) {
   *lo = (int)(((long long)n * sh.rank) / sh.world);
   *hi = (int)(((long long)n * (sh.rank + 1)) / sh.world);
@@ -320,6 +324,7 @@ __global__ __launch_bounds__(256) void sia_residual_kernel(
   const uint8_t* img = cur_base + (size_t)b * pyr_bytes + g.cur_off;
   const double jscale = fabs(cam.fx) / (1 << level);
 
+  const int tri_i = kTriI[lane < 21 ? lane : 0], tri_j = kTriJ[lane < 21 ? lane : 0];
   double accH = 0.0;                       // lane e < 21 accumulates H entry e
   double accJ[6] = {0, 0, 0, 0, 0, 0};     // lane-per-patch partial sums of Jres
   double acc_chi = 0.0;
@@ -327,18 +332,27 @@ __global__ __launch_bounds__(256) void sia_residual_kernel(
 
   for (int tile = chunk * tpc + wave; tile < t_end; tile += 4) {
     const int tile_base = lo + tile * TILE;
+    // every load that does not depend on the projection is issued first, unconditionally, so that
+    // the HBM/MALL latencies of a tile overlap (slots past n_feat are allocated, their values unused)
+    const size_t o4 = ((size_t)b * max_n + tile_base + q) * 4 + r;
+    float4 rc[4], gx[4], gy[4];
+#pragma unroll
+    for (int S = 0; S < 4; ++S) {
+      rc[S] = ref_cache[o4 + 64 * S];
+      gx[S] = dxc[o4 + 64 * S];
+      gy[S] = dyc[o4 + 64 * S];
+    }
     // ---- lane-per-patch: project the patch into the current image (:220-236)
     const int i_own = tile_base + 16 * r + q;
     const size_t fo = (size_t)b * max_n + i_own;
     bool ok = false, jvalid = false;
     float w_tl = 0, w_tr = 0, w_bl = 0, w_br = 0;
     int off = 0;
-    double4 X = make_double4(0, 0, 1, 1);
+    const double4 X = xyz4[fo];
     if (i_own < hi) {
       const uint8_t fl = flags[fo];
       jvalid = (fl & F_JVALID) != 0;
       if (fl & F_VISIBLE) {
-        X = xyz4[fo];
         const double xyz_ref[3] = {X.x, X.y, X.z};
         double xyz_cur[3], pxd[2];
         se3_act(T, xyz_ref, xyz_cur);
@@ -368,75 +382,68 @@ __global__ __launch_bounds__(256) void sia_residual_kernel(
     double sdx = 0.0, sdy = 0.0;
     float chi = 0.0f;
     {
-      const size_t o4 = ((size_t)b * max_n + tile_base + q) * 4 + r;
-      float4 rc[4], gx[4], gy[4];
       uint2 R0[4], R1[4];
-      float a_tl[4], a_tr[4], a_bl[4], a_br[4];
-#pragma unroll
-      for (int S = 0; S < 4; ++S) {
-        rc[S] = ref_cache[o4 + 64 * S];
-        gx[S] = dxc[o4 + 64 * S];
-        gy[S] = dyc[o4 + 64 * S];
-      }
-#define SVO_BCAST(S)                                                                  \
+#define SVO_ROWS(S)                                                                   \
       {                                                                               \
         const uint8_t* p = img + quad_bcast<S>(off) + r * stride;                     \
         R0[S] = load_row8(p); R1[S] = load_row8(p + stride);                          \
-        a_tl[S] = quad_bcast<S>(w_tl); a_tr[S] = quad_bcast<S>(w_tr);                 \
-        a_bl[S] = quad_bcast<S>(w_bl); a_br[S] = quad_bcast<S>(w_br);                 \
       }
-      SVO_BCAST(0) SVO_BCAST(1) SVO_BCAST(2) SVO_BCAST(3)
-#undef SVO_BCAST
-#pragma unroll
-      for (int S = 0; S < 4; ++S) {
-        const float rcv[4] = {rc[S].x, rc[S].y, rc[S].z, rc[S].w};
-        const float gxv[4] = {gx[S].x, gx[S].y, gx[S].z, gx[S].w};
-        const float gyv[4] = {gy[S].x, gy[S].y, gy[S].z, gy[S].w};
-        double px_ = 0.0, py_ = 0.0;
-        float pc = 0.0f;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const float inten = a_tl[S] * byte_f(R0[S], x) + a_tr[S] * byte_f(R0[S], x + 1) +
-                              a_bl[S] * byte_f(R1[S], x) + a_br[S] * byte_f(R1[S], x + 1);
-          const float res = inten - rcv[x];
-          pc += res * res;
-          const double dres = (double)res;
-          px_ += (double)gxv[x] * dres;
-          py_ += (double)gyv[x] * dres;
-        }
-        px_ = quad_sum(px_); py_ = quad_sum(py_); pc = quad_sum(pc);
-        if (r == S) { sdx = px_; sdy = py_; chi = pc; }
+      SVO_ROWS(0) SVO_ROWS(1) SVO_ROWS(2) SVO_ROWS(3)
+#undef SVO_ROWS
+#define SVO_RES_SUBPASS(S)                                                                              \
+      {                                                                                                 \
+        const float a_tl = quad_bcast<S>(w_tl), a_tr = quad_bcast<S>(w_tr);                             \
+        const float a_bl = quad_bcast<S>(w_bl), a_br = quad_bcast<S>(w_br);                             \
+        const float rcv[4] = {rc[S].x, rc[S].y, rc[S].z, rc[S].w};                                      \
+        const float gxv[4] = {gx[S].x, gx[S].y, gx[S].z, gx[S].w};                                      \
+        const float gyv[4] = {gy[S].x, gy[S].y, gy[S].z, gy[S].w};                                      \
+        double px_ = 0.0, py_ = 0.0;                                                                    \
+        float pc = 0.0f;                                                                                \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                 \
+          const float inten = a_tl * byte_f(R0[S], x) + a_tr * byte_f(R0[S], x + 1) +                   \
+                              a_bl * byte_f(R1[S], x) + a_br * byte_f(R1[S], x + 1);                    \
+          const float res = inten - rcv[x];                                                             \
+          pc += res * res;                                                                              \
+          const double dres = (double)res;                                                              \
+          px_ += (double)gxv[x] * dres;                                                                 \
+          py_ += (double)gyv[x] * dres;                                                                 \
+        }                                                                                               \
+        px_ = quad_sum(px_); py_ = quad_sum(py_); pc = quad_sum(pc);                                    \
+        if (r == S) { sdx = px_; sdy = py_; chi = pc; }                                                 \
       }
+      SVO_RES_SUBPASS(0) SVO_RES_SUBPASS(1) SVO_RES_SUBPASS(2) SVO_RES_SUBPASS(3)
+#undef SVO_RES_SUBPASS
     }
 
     // ---- lane-per-patch: normal equations
     const bool lin = ok && jvalid;          // the patch carries a non-zero Jacobian block
     if (ok) { acc_chi += (double)chi; acc_n += 16; }
-    double A[6], B[6];
     if (lin) {
+      double A[6], B[6];
       patch_jacobian_rows(X.x, X.y, X.w, jscale, A, B);
 #pragma unroll
       for (int k = 0; k < 6; ++k) accJ[k] -= A[k] * sdx + B[k] * sdy;          // Jres_ -= J*res (:273)
     }
-    // H: the tile row is exact when no linearised patch of the tile left the image
-    const bool tile_whole = __ballot(jvalid && !ok) == 0ull;
-    if (tile_whole) {
-      if (lane < 21) accH += tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane];
-    } else {
-      // rare: rebuild the tile's H from the patches that are inside the image now
-      double4 S4 = make_double4(0, 0, 0, 0);
-      if (lin) S4 = sxyz[fo];
-      int e = 0;
+    // H: add the tile's precomputed row (lane e adds entry e), then take out the few linearised
+    // patches that are outside the current image at this evaluation, one at a time (wave-uniform
+    // loop, normally zero trips): H is the sum over the patches visible now, as in the reference.
+    if (lane < 21) accH += tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane];
+    unsigned long long gone = __ballot(jvalid && !ok);
+    while (gone) {
+      const int src = __ffsll((long long)gone) - 1;
+      gone &= gone - 1;
+      const double gx_ = __shfl(X.x, src, 64), gy_ = __shfl(X.y, src, 64), gzi = __shfl(X.w, src, 64);
+      const double4 S4 = sxyz[(size_t)b * max_n + tile_base + 16 * (src & 3) + (src >> 2)];
+      double A[6], B[6];
+      patch_jacobian_rows(gx_, gy_, gzi, jscale, A, B);
+      double Ai = A[0], Aj = A[0], Bi = B[0], Bj = B[0];
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) {
-          double h = 0.0;
-          if (lin) h = S4.x * (A[i] * A[j]) + S4.y * (A[i] * B[j] + B[i] * A[j]) + S4.z * (B[i] * B[j]);
-          const double t = group_sum<64>(h);
-          if (lane == e) accH += t;
-          ++e;
-        }
+      for (int k = 1; k < 6; ++k) {
+        if (tri_i == k) { Ai = A[k]; Bi = B[k]; }
+        if (tri_j == k) { Aj = A[k]; Bj = B[k]; }
+      }
+      const double h = S4.x * (Ai * Aj) + S4.y * (Ai * Bj + Bi * Aj) + S4.z * (Bi * Bj);
+      if (lane < 21) accH -= h;
     }
   }
 

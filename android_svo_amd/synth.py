@@ -207,7 +207,7 @@ def grid_features(cam: Camera, n_target: int, rng, border: int = 48) -> np.ndarr
 
 def make_frame_pair(seed: int = 12345, width: int = 640, height: int = 480, n_features: int = 200,
                     depth: float = 2.0, null_point_every: int = 0,
-                    t_mag: float = 0.03, r_mag: float = 0.01) -> FramePair:
+                    t_mag: float = 0.03, r_mag: float = 0.01, border: int = 48) -> FramePair:
     rng = np.random.default_rng(seed)
     cam = Camera.default(width, height)
     scene = PlaneScene(seed=seed, depth=depth,
@@ -220,7 +220,7 @@ def make_frame_pair(seed: int = 12345, width: int = 640, height: int = 480, n_fe
     T_cur_w = se3_mul(T_cur_ref, T_ref_w)
     ref_img = scene.render(cam, T_ref_w)
     cur_img = scene.render(cam, T_cur_w)
-    px = grid_features(cam, n_features, rng)
+    px = grid_features(cam, n_features, rng, border=border)
     f = cam2world(cam, px)
     pos = scene.intersect(cam, T_ref_w, px[:, 0], px[:, 1])
     has_point = np.ones(len(px), dtype=np.uint8)

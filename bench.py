@@ -117,24 +117,17 @@ def main():
         cur.upload(s, fp.cur_pyr)
         sia.upload_pair(s, fp)
     prm = sia.params(max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=args.early_stop)
-    red = None
+    aligner = None
     if allreduce:
-        red = torch.zeros(n_slots * hip.REDUCE_DOUBLES, dtype=torch.float64, device="cuda")
-        sia.set_reduce_buffer(red.data_ptr())
+        from android_svo_amd import dist as svodist
+        aligner = svodist.HipShardedAligner(sia, n_slots, prm, rank, world, stream)
 
     def step():
         if not allreduce:
             sia.run(n_slots, prm)
             return
-        with torch.cuda.stream(stream):
-            sia.begin(n_slots, prm)
-            for level in range(prm.max_level, prm.min_level - 1, -1):
-                sia.level_begin(level)
-                for _ in range(prm.n_iter):
-                    sia.accumulate()
-                    dist.all_reduce(red)
-                    sia.solve_update()
-            sia.finish()
+        with torch.cuda.stream(stream):      # kernels and the RCCL all-reduce share this stream
+            svodist.run_allreduce(aligner, prm.max_level, prm.min_level, prm.n_iter)
 
     def fence():
         ctx.sync()

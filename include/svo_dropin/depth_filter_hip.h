@@ -1,0 +1,37 @@
+// depth_filter_hip.h -- svo::DepthFilterHip: the reference's DepthFilter with the per-seed work
+// of updateSeeds() (I/depth_filter.h:155, S/depth_filter.cpp:237-341) done on the GPU.
+//
+// DepthFilter::updateSeeds is `protected virtual` in the reference precisely as an override
+// point; everything else (thread, frame queue, keyframe hand-off, seed list, callback) is inherited
+// unchanged.  FrameHandlerMono::initialize (frame_handler_mono.cpp:46-50) constructs this class
+// instead of DepthFilter -- a one-line change described in INTEGRATION.md.
+#ifndef SVO_DEPTH_FILTER_HIP_H_
+#define SVO_DEPTH_FILTER_HIP_H_
+
+#include <condition_variable>
+
+#include <svo/depth_filter.h>
+
+#include "svo_hip_bridge.h"
+
+namespace svo {
+
+class DepthFilterHip : public DepthFilter {
+ public:
+  EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+  DepthFilterHip(feature_detection::DetectorPtr feature_detector, callback_t seed_converged_cb);
+  virtual ~DepthFilterHip();
+
+ protected:
+  /// One pass over all seeds against `frame`, batched per reference keyframe.
+  virtual void updateSeeds(FramePtr frame);
+
+ private:
+  hip_bridge::Context ctx_;            // the depth-filter thread's own stream
+  hip_bridge::PyramidCache kf_pyr_;    // keyframes that still own seeds (max_n_kfs + 1 batches alive)
+  hip_bridge::PyramidCache cur_pyr_;
+};
+
+}  // namespace svo
+
+#endif  // SVO_DEPTH_FILTER_HIP_H_

@@ -1,0 +1,117 @@
+// svo_hip_bridge.h -- glue between the reference's C++ data model (svo::Frame / Feature /
+// Point / Seed, Eigen, cv::Mat) and the C-ABI of libsvo_hip.so (include/svo_hip.h).
+//
+// These files are meant to be dropped into the reference tree (app/src/main/cpp/svo/) and
+// compiled with the reference's own headers; they contain no device code.  See INTEGRATION.md.
+#ifndef SVO_HIP_BRIDGE_H_
+#define SVO_HIP_BRIDGE_H_
+
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include <svo/abstract_camera.h>
+#include <svo/feature.h>
+#include <svo/frame.h>
+#include <svo/global.h>
+#include <svo/pinhole_camera.h>
+#include <svo/point.h>
+
+#include "svo_hip.h"
+
+namespace svo {
+namespace hip_bridge {
+
+inline void toPose7(const SE3& T, double out[7]) {
+  out[0] = T.get_translation().x; out[1] = T.get_translation().y; out[2] = T.get_translation().z;
+  out[3] = T.get_rotation().x; out[4] = T.get_rotation().y; out[5] = T.get_rotation().z;
+  out[6] = T.get_rotation().w;
+}
+
+inline SE3 fromPose7(const double p[7]) { return SE3(p[0], p[1], p[2], p[3], p[4], p[5], p[6]); }
+
+/// Camera parameters of a vk::AbstractCamera: the pinhole model exposes fx..d4; any other
+/// model is approximated by its error multiplier (distortion-free), as the harness camera does.
+inline svo_hip_camera toCamera(const vk::AbstractCamera* cam) {
+  svo_hip_camera c;
+  c.width = cam->width(); c.height = cam->height();
+  c.distortion = 0;
+  for (int i = 0; i < 5; ++i) c.d[i] = 0.0;
+  const vk::PinholeCamera* ph = dynamic_cast<const vk::PinholeCamera*>(cam);
+  if (ph) {
+    c.fx = ph->fx(); c.fy = ph->fy(); c.cx = ph->cx(); c.cy = ph->cy();
+    c.d[0] = ph->d0(); c.d[1] = ph->d1(); c.d[2] = ph->d2(); c.d[3] = ph->d3(); c.d[4] = ph->d4();
+    c.distortion = std::fabs(ph->d0()) > 0.0000001;       // pinhole_camera.cpp:27
+  } else {
+    c.fx = c.fy = cam->errorMultiplier2();
+    c.cx = cam->width() / 2.0; c.cy = cam->height() / 2.0;
+  }
+  return c;
+}
+
+/// One context (stream) per host thread that enters the library (tracking thread,
+/// depth-filter thread): SURVEY 8b "Threading".
+class Context {
+ public:
+  explicit Context(int device = 0) : ctx_(NULL) {
+    if (svo_hip_ctx_create(&ctx_, device, NULL) != SVO_HIP_OK) ctx_ = NULL;
+  }
+  ~Context() { if (ctx_) svo_hip_ctx_destroy(ctx_); }
+  svo_hip_ctx* get() const { return ctx_; }
+  bool ok() const { return ctx_ != NULL; }
+ private:
+  Context(const Context&);
+  Context& operator=(const Context&);
+  svo_hip_ctx* ctx_;
+};
+
+/// Device copy of a Frame's image pyramid, cached by frame id so a keyframe is uploaded once.
+class PyramidCache {
+ public:
+  PyramidCache(svo_hip_ctx* ctx, int capacity) : ctx_(ctx), pyr_(NULL), capacity_(capacity), next_(0) {}
+  ~PyramidCache() { if (pyr_) svo_hip_pyramid_destroy(pyr_); }
+
+  /// slot holding `frame`'s pyramid, uploading it (all levels, stride == cols) if needed; -1 on error
+  int slotOf(const Frame& frame) {
+    const int n_levels = (int)frame.img_pyr_.size();
+    const cv::Mat& l0 = frame.img_pyr_[0];
+    if (!pyr_) {
+      if (svo_hip_pyramid_create(ctx_, l0.cols, l0.rows, n_levels, capacity_, &pyr_) != SVO_HIP_OK) return -1;
+      slot_frame_.assign(capacity_, -1);
+    }
+    for (int s = 0; s < capacity_; ++s)
+      if (slot_frame_[s] == frame.id_) return s;
+    const int s = next_;
+    next_ = (next_ + 1) % capacity_;
+    std::vector<const uint8_t*> levels(SVO_HIP_MAX_LEVELS, (const uint8_t*)NULL);
+    std::vector<std::vector<uint8_t> > packed(n_levels);
+    for (int l = 0; l < n_levels; ++l) {
+      const cv::Mat& m = frame.img_pyr_[l];
+      if ((int)m.step.p[0] == m.cols) {
+        levels[l] = m.data;
+      } else {                       // compact a padded Mat: the kernels assume stride == cols
+        packed[l].resize((size_t)m.rows * m.cols);
+        for (int y = 0; y < m.rows; ++y) memcpy(&packed[l][(size_t)y * m.cols], m.data + (size_t)y * m.step.p[0], m.cols);
+        levels[l] = packed[l].data();
+      }
+    }
+    if (svo_hip_pyramid_upload(pyr_, s, levels.data()) != SVO_HIP_OK) return -1;
+    if (svo_hip_ctx_sync(ctx_) != SVO_HIP_OK) return -1;
+    slot_frame_[s] = frame.id_;
+    return s;
+  }
+  svo_hip_pyramid* pyramid() const { return pyr_; }
+
+ private:
+  svo_hip_ctx* ctx_;
+  svo_hip_pyramid* pyr_;
+  int capacity_, next_;
+  std::vector<int> slot_frame_;
+};
+
+}  // namespace hip_bridge
+}  // namespace svo
+
+#endif  // SVO_HIP_BRIDGE_H_

@@ -208,6 +208,15 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
                                     double* z_dev, double* xyz_world_dev, int32_t* n_zmssd_dev,
                                     int32_t* n_align_iters_dev);
 
+/* host-buffer convenience form of the above (copies in, runs, copies out, synchronises) */
+int svo_hip_depth_filter_update(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,
+                                const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                                const double T_ref_w[7], const double T_cur_w[7], int n, const double* px,
+                                const double* f, const int32_t* level, float* a, float* b, float* mu,
+                                const float* z_range, float* sigma2, const svo_hip_df_params* prm,
+                                int32_t* status, double* z, double* xyz_world, int32_t* n_zmssd,
+                                int32_t* n_align_iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,28 @@ def test_fixed_work_mode_matches_oracle_closely(ctx):
     _free(sia, ref, cur)
 
 
+def test_patches_leaving_the_image(ctx):
+    """Features close to the border: some patches are invisible at coarse levels (reference image
+    test), some leave the current image during the iterations.  Exercises the sticky visibility
+    flags and the per-evaluation rebuild of H from the patches visible now."""
+    fp = synth.make_frame_pair(seed=61, n_features=900, border=5, t_mag=0.05, r_mag=0.02)
+    ref, cur, sia = _upload_pair(ctx, [fp])
+    for early in (True, False):
+        sia.run(1, sia.params(early_stop=early, n_iter=30 if early else 6))
+        r = sia.download(0)
+        o = orc.sparse_img_align(fp, early_stop=early, n_iter=30 if early else 6)
+        assert o.n_tracked < 900                      # the case really loses patches
+        assert r.n_tracked == o.n_tracked
+        assert r.n_precompute_patches == o.n_precompute_patches
+        rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
+        assert rot < 1e-4 and trans < 1e-3, (rot, trans)
+        if not early:
+            assert r.n_residual_patches == o.n_residual_patches
+            H, Ho = np.array(r.H), np.array(o.H)
+            assert np.abs(H - Ho).max() <= 1e-9 * np.abs(Ho).max()
+    _free(sia, ref, cur)
+
+
 def test_batch_ragged_and_empty(ctx):
     """A batch with different feature counts, an empty frame and point-less features: every
     slot must equal its own single-frame oracle run; an empty slot keeps its pose (run() -> 0)."""

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-kernel mean of rocprofv3 --pmc counters from *_counter_collection.csv.
+Usage: tools/pmc_summary.py counter_collection.csv [kernel-substring]"""
+import collections
+import csv
+import sys
+
+
+def main():
+    path = sys.argv[1]
+    sub = sys.argv[2] if len(sys.argv) > 2 else ""
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            k = row["Kernel_Name"]
+            if sub and sub not in k:
+                continue
+            k = k.split("(")[0][-40:]
+            acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            cnt[k][row["Counter_Name"]] += 1
+    for k in acc:
+        print(k)
+        for c in sorted(acc[k]):
+            print("   %-28s mean/dispatch %.4g   (n=%d)" % (c, acc[k][c] / cnt[k][c], cnt[k][c]))
+
+
+if __name__ == "__main__":
+    main()
