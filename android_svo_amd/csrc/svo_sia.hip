@@ -30,6 +30,8 @@
 //     rebuilt from the visible set at every evaluation, as computeResiduals does.
 //   * fp64 for H/Jres and their partial sums; residual/chi2 in f32 per pixel row, widened per
 //     patch.  Reductions are in fixed order (bitwise reproducible run to run, no atomics).
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "svo_internal.h"
@@ -569,6 +571,402 @@ __global__ void sia_finish_kernel(const FrameConst* __restrict__ fc, FrameState*
   s.n_pre = n_pre_count[b];
 }
 
+// =================================================================================================
+// Fused path: the whole coarse-to-fine solve of one frame pair in ONE workgroup (1024 threads, one CU),
+// one launch per run.  Nothing is streamed from HBM between Gauss-Newton evaluations:
+//   * the 7x8-byte reference footprint of every patch lives in LDS (56 B/patch, <= 2816 patches in
+//     160 KiB); ref value / dx / dy are recomputed from it (bit-identical to the cached form);
+//   * {x,y,z,1/z}, {sxx,sxy,syy}, the reference sub-pixel offsets, the flags and the wave's tile-H
+//     entries stay in VGPRs (lane-per-patch; a wave owns tiles wave, wave+16, wave+32);
+//   * the Gauss-Newton state lives in LDS; the solve runs on one lane between two barriers;
+//   * only the current image is read from memory (two 8-byte rows per lane and sub-pass, L2/MALL).
+// Data-dependent exits are real `break`s here, so a converged frame costs nothing further.
+// Semantics are those of the streaming kernels above (same tile/quad mapping, same reductions per wave,
+// then a fixed-order sum over the 16 waves).
+// =================================================================================================
+constexpr int FUSED_THREADS = 1024;
+constexpr int FUSED_WAVES = FUSED_THREADS / 64;
+constexpr int FUSED_MAX_TILES = 44;               // 44 * 64 * 56 B = 157 696 B of footprints
+
+struct FusedLevels {
+  int cols[SVO_HIP_MAX_LEVELS], rows[SVO_HIP_MAX_LEVELS];
+  unsigned long long ref_off[SVO_HIP_MAX_LEVELS], cur_off[SVO_HIP_MAX_LEVELS];
+};
+
+struct FusedParams { int max_level, min_level, n_iter, early_stop; double eps; };
+
+// interpolated value at footprint row pair (R, Rn) and byte column k, with the reference's operation order
+SVO_DEV float interp_at(uint2 R, uint2 Rn, int k, float a_tl, float a_tr, float a_bl, float a_br) {
+  return a_tl * byte_f(R, k) + a_tr * byte_f(R, k + 1) + a_bl * byte_f(Rn, k) + a_br * byte_f(Rn, k + 1);
+}
+
+template <int TPW>
+__global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
+    const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
+    const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
+    const double* __restrict__ f, const double* __restrict__ pos, const uint8_t* __restrict__ has_point, FusedParams prm) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint2* fp = reinterpret_cast<uint2*>(smem);               // [n_tiles*64][7] footprint rows
+  __shared__ double red[FUSED_WAVES][32];
+  __shared__ double s_r[32];
+  __shared__ double s_model[8], s_old[8];
+  __shared__ double s_chi2;
+  __shared__ int s_done, s_stop, s_iter;
+  __shared__ unsigned s_npre;
+  __shared__ unsigned long long s_nres, s_nmeas;
+  __shared__ int s_iters[SVO_HIP_MAX_LEVELS];
+
+  const int b = blockIdx.x;
+  const FrameConst& c = fc[b];
+  const Cam cam = c.cam;
+  const int n = c.n_feat;
+  const int n_tiles = (n + TILE - 1) / TILE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 2, r = lane & 3;
+  const bool empty = n <= 0;
+  const int tri_i = kTriI[lane < 21 ? lane : 0], tri_j = kTriJ[lane < 21 ? lane : 0];
+
+  if (threadIdx.x == 0) {
+    double Tinv[7], T[7];
+    se3_inverse(c.T_ref_w, Tinv);
+    se3_mul(c.T_cur_w_init, Tinv, T);                        // sparse_img_align.cpp:69
+    for (int i = 0; i < 7; ++i) { s_model[i] = T[i]; s_old[i] = T[i]; }
+    s_chi2 = 1e10;                                           // reset(), nlls_solver_impl.hpp:299-309
+    s_stop = 0; s_done = 0; s_iter = 0; s_npre = 0; s_nres = 0; s_nmeas = 0;
+    for (int i = 0; i < SVO_HIP_MAX_LEVELS; ++i) s_iters[i] = 0;
+    FrameState& s = st[b];
+    for (int i = 0; i < 36; ++i) s.H[i] = 0.0;
+    for (int i = 0; i < 6; ++i) { s.Jres[i] = 0.0; s.x[i] = 0.0; }
+  }
+
+  // ---- lane-per-patch persistent state of the wave's tiles
+  double4 X[TPW];
+  double Sxx[TPW], Sxy[TPW], Syy[TPW], th[TPW];
+  float su[TPW], sv[TPW];
+  int off_ref[TPW];
+  uint8_t fl[TPW];
+#pragma unroll
+  for (int k = 0; k < TPW; ++k) {
+    const int tile = wave + FUSED_WAVES * k;
+    const int i_own = tile * TILE + 16 * r + q;
+    X[k] = make_double4(0, 0, 1, 1);
+    Sxx[k] = Sxy[k] = Syy[k] = th[k] = 0.0;
+    su[k] = sv[k] = 0.0f; off_ref[k] = 0; fl[k] = 0;
+    if (tile < n_tiles && i_own < n) {
+      const size_t fi = (size_t)b * max_n + i_own;
+      const double dxp = pos[3 * fi] - c.ref_pos[0];
+      const double dyp = pos[3 * fi + 1] - c.ref_pos[1];
+      const double dzp = pos[3 * fi + 2] - c.ref_pos[2];
+      const double depth = sqrt(dxp * dxp + dyp * dyp + dzp * dzp);
+      X[k].x = f[3 * fi] * depth; X[k].y = f[3 * fi + 1] * depth; X[k].z = f[3 * fi + 2] * depth;
+      X[k].w = 1. / X[k].z;
+    }
+  }
+  __syncthreads();
+
+  for (int level = prm.max_level; level >= prm.min_level; --level) {
+    const int cols = lv.cols[level], rows = lv.rows[level], stride = cols;
+    const uint8_t* ref_img = ref_base + (size_t)b * pyr_bytes + lv.ref_off[level];
+    const uint8_t* cur_img = cur_base + (size_t)b * pyr_bytes + lv.cur_off[level];
+    const float scale = 1.0f / (1 << level);
+    const double jscale = fabs(cam.fx) / (1 << level);
+    const int border = 3;
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < 7; ++i) s_old[i] = s_model[i];     // rollback copy (:33)
+      s_iter = 0;
+      s_done = empty ? 1 : 0;
+    }
+
+    // ================= precomputeReferencePatches for the wave's tiles =================
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+      const int tile = wave + FUSED_WAVES * k;
+      if (tile >= n_tiles) continue;                         // wave-uniform
+      const int tile_base = tile * TILE;
+      const int i_own = tile_base + 16 * r + q;
+      bool valid = false;
+      float w_tl = 0, w_tr = 0, w_bl = 0, w_br = 0;
+      int off = 0;
+      if (i_own < n) {
+        const size_t fo = (size_t)b * max_n + i_own;
+        const float u_ref = (float)(px[2 * fo] * scale);
+        const float v_ref = (float)(px[2 * fo + 1] * scale);
+        const int u_ref_i = (int)floorf(u_ref);
+        const int v_ref_i = (int)floorf(v_ref);
+        valid = has_point[fo] && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= cols ||
+                                   v_ref_i + border >= rows);
+        if (valid) {
+          su[k] = u_ref - u_ref_i;                            // kept: the cached patch is defined by them
+          sv[k] = v_ref - v_ref_i;
+          off = (v_ref_i - 3) * stride + (u_ref_i - 3);
+        }
+        // visible_fts_ is only ever set (:128); the Jacobian block is zero unless recomputed now (:76)
+        fl[k] = valid ? (uint8_t)(F_VISIBLE | F_JVALID) : (uint8_t)(fl[k] & F_VISIBLE);
+      }
+      w_tl = (float)((1.0 - su[k]) * (1.0 - sv[k]));
+      w_tr = (float)(su[k] * (1.0 - sv[k]));
+      w_bl = (float)((1.0 - su[k]) * sv[k]);
+      w_br = su[k] * sv[k];
+      {
+        const unsigned long long m = __ballot(valid);
+        if (lane == 0 && m) atomicAdd(&s_npre, (unsigned)__popcll(m));
+      }
+      double sxx = 0.0, sxy = 0.0, syy = 0.0;
+#define SVO_FPRE(S)                                                                                     \
+      {                                                                                                 \
+        const bool v_s = quad_bcast<S>((int)valid) != 0;                                                \
+        if (v_s) {                                                                                      \
+          const float a_tl = quad_bcast<S>(w_tl), a_tr = quad_bcast<S>(w_tr);                           \
+          const float a_bl = quad_bcast<S>(w_bl), a_br = quad_bcast<S>(w_br);                           \
+          const uint8_t* p = ref_img + quad_bcast<S>(off) + r * stride;                                 \
+          const uint2 Rm = load_row8(p), R0 = load_row8(p + stride), R1 = load_row8(p + 2 * stride),    \
+                      R2 = load_row8(p + 3 * stride);                                                   \
+          uint2* dst = fp + (size_t)(tile_base + 16 * S + q) * 7;                                       \
+          dst[r] = Rm;                                                                                  \
+          if (r == 3) { dst[4] = R0; dst[5] = R1; dst[6] = R2; }                                        \
+          double pxx = 0.0, pxy = 0.0, pyy = 0.0;                                                       \
+          _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                               \
+            const float dxv = 0.5f * (interp_at(R0, R1, x + 2, a_tl, a_tr, a_bl, a_br) -                \
+                                      interp_at(R0, R1, x, a_tl, a_tr, a_bl, a_br));                    \
+            const float dyv = 0.5f * (interp_at(R1, R2, x + 1, a_tl, a_tr, a_bl, a_br) -                \
+                                      interp_at(Rm, R0, x + 1, a_tl, a_tr, a_bl, a_br));                \
+            const double ddx = (double)dxv, ddy = (double)dyv;                                          \
+            pxx += ddx * ddx; pxy += ddx * ddy; pyy += ddy * ddy;                                       \
+          }                                                                                             \
+          pxx = quad_sum(pxx); pxy = quad_sum(pxy); pyy = quad_sum(pyy);                                \
+          if (r == S) { sxx = pxx; sxy = pxy; syy = pyy; }                                              \
+        }                                                                                               \
+      }
+      SVO_FPRE(0) SVO_FPRE(1) SVO_FPRE(2) SVO_FPRE(3)
+#undef SVO_FPRE
+      if (valid) { Sxx[k] = sxx; Sxy[k] = sxy; Syy[k] = syy; }
+      // the tile's Hessian row: lane e keeps entry e
+      {
+        double A[6], B[6];
+        patch_jacobian_rows(X[k].x, X[k].y, X[k].w, jscale, A, B);
+        double mine = 0.0;
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = i; j < 6; ++j) {
+            double h = 0.0;
+            if (valid) h = sxx * (A[i] * A[j]) + sxy * (A[i] * B[j] + B[i] * A[j]) + syy * (B[i] * B[j]);
+            const double t = group_sum<64>(h);
+            if (lane == e) mine = t;
+            ++e;
+          }
+        th[k] = mine;
+      }
+    }
+    __syncthreads();      // s_done / s_old of this level, footprints (own wave) in place
+
+    // ================= Gauss-Newton loop of this level =================
+    for (int iter = 0; iter < prm.n_iter; ++iter) {
+      if (s_done) break;                                     // block-uniform (read after a barrier)
+      double T[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) T[i] = s_model[i];
+      double accH = 0.0;
+      double accJ[6] = {0, 0, 0, 0, 0, 0};
+      double acc_chi = 0.0;
+      unsigned acc_n = 0;
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {
+        const int tile = wave + FUSED_WAVES * k;
+        if (tile >= n_tiles) continue;
+        const int tile_base = tile * TILE;
+        // ---- lane-per-patch: projection into the current image (:220-236)
+        bool ok = false;
+        const bool jvalid = (fl[k] & F_JVALID) != 0;
+        float w_tl = 0, w_tr = 0, w_bl = 0, w_br = 0;
+        int off = 0;
+        if (fl[k] & F_VISIBLE) {
+          const double xyz_ref[3] = {X[k].x, X[k].y, X[k].z};
+          double xyz_cur[3], pxd[2];
+          se3_act(T, xyz_ref, xyz_cur);
+          world2cam(cam, xyz_cur, pxd);
+          const float u_cur = (float)pxd[0] * scale;
+          const float v_cur = (float)pxd[1] * scale;
+          const int u_cur_i = (int)floorf(u_cur);
+          const int v_cur_i = (int)floorf(v_cur);
+          ok = (u_cur_i >= 0 && v_cur_i >= 0 && u_cur_i - border >= 0 && v_cur_i - border >= 0 &&
+                u_cur_i + border < cols && v_cur_i + border < rows) && u_cur == u_cur && v_cur == v_cur;
+          const float subpix_u = u_cur - u_cur_i;
+          const float subpix_v = v_cur - v_cur_i;
+          w_tl = (float)((1.0 - subpix_u) * (1.0 - subpix_v));
+          w_tr = (float)(subpix_u * (1.0 - subpix_v));
+          w_bl = (float)((1.0 - subpix_u) * subpix_v);
+          w_br = subpix_u * subpix_v;
+          off = ok ? (v_cur_i - 2) * stride + (u_cur_i - 2) : 0;
+        }
+        // weights of the cached reference patch (recomputed from the kept sub-pixel offsets)
+        const float rw_tl = (float)((1.0 - su[k]) * (1.0 - sv[k]));
+        const float rw_tr = (float)(su[k] * (1.0 - sv[k]));
+        const float rw_bl = (float)((1.0 - su[k]) * sv[k]);
+        const float rw_br = su[k] * sv[k];
+
+        // ---- lane-per-pixel-row: residuals of patch 16s+q, row r (:238-279)
+        double sdx = 0.0, sdy = 0.0;
+        float chi = 0.0f;
+        uint2 C0[4], C1[4];
+#define SVO_FROWS(S)                                                                  \
+        {                                                                             \
+          const uint8_t* p = cur_img + quad_bcast<S>(off) + r * stride;               \
+          C0[S] = load_row8(p); C1[S] = load_row8(p + stride);                        \
+        }
+        SVO_FROWS(0) SVO_FROWS(1) SVO_FROWS(2) SVO_FROWS(3)
+#undef SVO_FROWS
+#define SVO_FRES(S)                                                                                     \
+        {                                                                                               \
+          const float a_tl = quad_bcast<S>(w_tl), a_tr = quad_bcast<S>(w_tr);                           \
+          const float a_bl = quad_bcast<S>(w_bl), a_br = quad_bcast<S>(w_br);                           \
+          const float b_tl = quad_bcast<S>(rw_tl), b_tr = quad_bcast<S>(rw_tr);                         \
+          const float b_bl = quad_bcast<S>(rw_bl), b_br = quad_bcast<S>(rw_br);                         \
+          const uint2* src = fp + (size_t)(tile_base + 16 * S + q) * 7 + r;                             \
+          const uint2 Rm = src[0], R0 = src[1], R1 = src[2], R2 = src[3];                               \
+          double px_ = 0.0, py_ = 0.0;                                                                  \
+          float pc = 0.0f;                                                                              \
+          _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                               \
+            const float refv = interp_at(R0, R1, x + 1, b_tl, b_tr, b_bl, b_br);                        \
+            const float dxv = 0.5f * (interp_at(R0, R1, x + 2, b_tl, b_tr, b_bl, b_br) -                \
+                                      interp_at(R0, R1, x, b_tl, b_tr, b_bl, b_br));                    \
+            const float dyv = 0.5f * (interp_at(R1, R2, x + 1, b_tl, b_tr, b_bl, b_br) -                \
+                                      interp_at(Rm, R0, x + 1, b_tl, b_tr, b_bl, b_br));                \
+            const float inten = interp_at(C0[S], C1[S], x, a_tl, a_tr, a_bl, a_br);                     \
+            const float res = inten - refv;                                                             \
+            pc += res * res;                                                                            \
+            const double dres = (double)res;                                                            \
+            px_ += (double)dxv * dres;                                                                  \
+            py_ += (double)dyv * dres;                                                                  \
+          }                                                                                             \
+          px_ = quad_sum(px_); py_ = quad_sum(py_); pc = quad_sum(pc);                                  \
+          if (r == S) { sdx = px_; sdy = py_; chi = pc; }                                               \
+        }
+        SVO_FRES(0) SVO_FRES(1) SVO_FRES(2) SVO_FRES(3)
+#undef SVO_FRES
+
+        // ---- lane-per-patch: normal equations
+        const bool lin = ok && jvalid;
+        if (ok) { acc_chi += (double)chi; acc_n += 16; }
+        if (lin) {
+          double A[6], B[6];
+          patch_jacobian_rows(X[k].x, X[k].y, X[k].w, jscale, A, B);
+#pragma unroll
+          for (int kk = 0; kk < 6; ++kk) accJ[kk] -= A[kk] * sdx + B[kk] * sdy;
+        }
+        if (lane < 21) accH += th[k];
+        unsigned long long gone = __ballot(jvalid && !ok);
+        while (gone) {
+          const int src = __ffsll((long long)gone) - 1;
+          gone &= gone - 1;
+          const double gx_ = __shfl(X[k].x, src, 64), gy_ = __shfl(X[k].y, src, 64), gzi = __shfl(X[k].w, src, 64);
+          const double g_xx = __shfl(Sxx[k], src, 64), g_xy = __shfl(Sxy[k], src, 64), g_yy = __shfl(Syy[k], src, 64);
+          double A[6], B[6];
+          patch_jacobian_rows(gx_, gy_, gzi, jscale, A, B);
+          double Ai = A[0], Aj = A[0], Bi = B[0], Bj = B[0];
+#pragma unroll
+          for (int kk = 1; kk < 6; ++kk) {
+            if (tri_i == kk) { Ai = A[kk]; Bi = B[kk]; }
+            if (tri_j == kk) { Aj = A[kk]; Bj = B[kk]; }
+          }
+          const double h = g_xx * (Ai * Aj) + g_xy * (Ai * Bj + Bi * Aj) + g_yy * (Bi * Bj);
+          if (lane < 21) accH -= h;
+        }
+      }
+
+      // ---- wave reduction, then the 16 waves in fixed order, then the solve on one lane
+      double mine = accH;
+#pragma unroll
+      for (int kk = 0; kk < 6; ++kk) {
+        const double t = group_sum<64>(accJ[kk]);
+        if (lane == 21 + kk) mine = t;
+      }
+      {
+        const double t = group_sum<64>(acc_chi);
+        if (lane == 27) mine = t;
+        const int tn = group_sum<64>((int)acc_n);
+        if (lane == 28) mine = (double)tn;
+      }
+      if (lane < 32) red[wave][lane] = lane < 29 ? mine : 0.0;
+      __syncthreads();
+      if (wave == 0) {
+        if (lane < 32) {
+          double v = 0.0;
+#pragma unroll
+          for (int w = 0; w < FUSED_WAVES; ++w) v += red[w][lane];
+          s_r[lane] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane == 0) {
+          // I/nlls_solver_impl.hpp:35-99 with solve()/update() of S/sparse_img_align.cpp:291-308
+          double H[36], Jres[6], x[6];
+          {
+            int kk = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+              for (int j = i; j < 6; ++j) { H[i * 6 + j] = s_r[kk]; H[j * 6 + i] = s_r[kk]; ++kk; }
+          }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) Jres[i] = s_r[21 + i];
+          const double chi2_sum = s_r[27];
+          const unsigned long long n_meas = (unsigned long long)(s_r[28] + 0.5);
+          const double new_chi2 = (double)((float)chi2_sum / (float)n_meas);     // (:285)
+          FrameState& s = st[b];
+#pragma unroll
+          for (int i = 0; i < 36; ++i) s.H[i] = H[i];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) s.Jres[i] = Jres[i];
+          s_nmeas = n_meas;
+          s_nres += n_meas / 16;
+          s_iters[level] += 1;
+          ldlt6_solve_reg(H, Jres, x);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) s.x[i] = x[i];
+          if (x[0] != x[0]) s_stop = 1;                                          // NaN -> stop_ (:52-59)
+          const int it = s_iter;
+          if ((prm.early_stop && it > 0 && new_chi2 > s_chi2) || s_stop) {
+            for (int i = 0; i < 7; ++i) s_model[i] = s_old[i];                   // rollback (:72)
+            s_done = 1;
+          } else {
+            double mx[6], dT[7], nm[7], cur[7];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) mx[i] = -x[i];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) cur[i] = s_model[i];
+            se3_exp(mx, dT);
+            se3_mul(cur, dT, nm);                                                // T_new = T_old * exp(-x) (:307)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { s_old[i] = cur[i]; s_model[i] = nm[i]; }
+            s_chi2 = new_chi2;
+            double mxn = -1;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { double a = fabs(x[i]); if (a > mxn) mxn = a; }
+            if (prm.early_stop && mxn <= prm.eps) s_done = 1;                    // :97-98
+            s_iter = it + 1;
+            if (it + 1 >= prm.n_iter) s_done = 1;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+
+  if (threadIdx.x == 0) {
+    FrameState& s = st[b];
+    double T[7], m[7];
+    for (int i = 0; i < 7; ++i) { m[i] = s_model[i]; s.model[i] = m[i]; s.old_model[i] = s_old[i]; }
+    se3_mul(m, c.T_ref_w, T);                                                    // :89
+    for (int i = 0; i < 7; ++i) s.T_cur_w[i] = empty ? c.T_cur_w_init[i] : T[i];
+    s.chi2 = s_chi2; s.stop = s_stop; s.iter = s_iter; s.level_done = 1; s.empty = empty;
+    s.n_meas = s_nmeas; s.n_res = s_nres; s.n_pre = s_npre;
+    for (int i = 0; i < SVO_HIP_MAX_LEVELS; ++i) s.iters[i] = s_iters[i];
+  }
+}
+
 }  // namespace
 
 struct svo_hip_sia {
@@ -598,6 +996,7 @@ struct svo_hip_sia {
   int n_slots = 0, level = -1, chunks = 1;
   bool begun = false;
   // optional HIP-event timing of the two heavy kernels, on the context stream
+  int last_mode = 0;          // 0 = streaming kernels, 1 = fused one-workgroup-per-frame kernel
   bool profiling = false;
   std::vector<hipEvent_t> ev_res, ev_pre;     // start/stop pairs
   size_t ev_res_used = 0, ev_pre_used = 0;
@@ -645,6 +1044,68 @@ int flush_fc(svo_hip_sia* s) {
   SVO_CHECK_HIP(s->ctx, hipMemcpyAsync(s->fc, s->h_fc, sizeof(FrameConst) * s->batch, hipMemcpyHostToDevice, s->ctx->stream));
   s->fc_dirty = false;
   return SVO_HIP_OK;
+}
+
+// The fused kernel handles frames whose footprints fit in one CU's LDS and that are not patch-sharded.
+int fused_tiles_per_wave(const svo_hip_sia* s, int n_slots) {
+  const char* env = getenv("SVO_HIP_SIA_MODE");
+  if (env && strcmp(env, "stream") == 0) return 0;
+  if (s->shard_world != 1) return 0;
+  int max_n = 0;
+  for (int i = 0; i < n_slots; ++i) max_n = s->h_fc[i].n_feat > max_n ? s->h_fc[i].n_feat : max_n;
+  const int tiles = (max_n + TILE - 1) / TILE;
+  if (tiles > FUSED_MAX_TILES) return 0;
+  const int tpw = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
+  return tpw < 1 ? 1 : tpw;
+}
+
+template <int TPW>
+int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes) {
+  svo_hip_ctx* ctx = s->ctx;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<TPW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_TILES * TILE * 56));
+    attr_set = true;
+  }
+  FusedLevels lv;
+  memset(&lv, 0, sizeof(lv));
+  for (int l = 0; l < s->ref->n_levels; ++l) {
+    lv.cols[l] = s->ref->width >> l; lv.rows[l] = s->ref->height >> l;
+    lv.ref_off[l] = s->ref->level_offset[l]; lv.cur_off[l] = s->cur->level_offset[l];
+  }
+  FusedParams fp;
+  fp.max_level = prm->max_level; fp.min_level = prm->min_level; fp.n_iter = prm->n_iter;
+  fp.early_stop = prm->early_stop; fp.eps = prm->eps;
+  hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
+  if (ev) (void)hipEventRecord(ev[0], ctx->stream);
+  hipLaunchKernelGGL(sia_fused_kernel<TPW>, dim3(n_slots), dim3(FUSED_THREADS), lds_bytes, ctx->stream, s->fc, s->st,
+                     s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, fp);
+  if (ev) (void)hipEventRecord(ev[1], ctx->stream);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tpw) {
+  svo_hip_ctx* ctx = s->ctx;
+  SVO_REQUIRE(ctx, s->ref && s->cur);
+  SVO_REQUIRE(ctx, n_slots > 0 && n_slots <= s->batch);
+  SVO_REQUIRE(ctx, prm->min_level >= 0 && prm->max_level >= prm->min_level && prm->max_level < s->ref->n_levels);
+  SVO_REQUIRE(ctx, prm->n_iter >= 0);
+  SVO_REQUIRE(ctx, s->ref->pyr_bytes == s->cur->pyr_bytes);
+  int rc = flush_fc(s);
+  if (rc != SVO_HIP_OK) return rc;
+  int max_n = 0;
+  for (int i = 0; i < n_slots; ++i) max_n = s->h_fc[i].n_feat > max_n ? s->h_fc[i].n_feat : max_n;
+  const int tiles = max_n > 0 ? (max_n + TILE - 1) / TILE : 1;
+  const size_t lds = (size_t)tiles * TILE * 56;
+  s->begun = false;
+  s->last_mode = 1;
+  switch (tpw) {
+    case 1: return launch_fused_t<1>(s, n_slots, prm, lds);
+    case 2: return launch_fused_t<2>(s, n_slots, prm, lds);
+    default: return launch_fused_t<3>(s, n_slots, prm, lds);
+  }
 }
 
 }  // namespace
@@ -862,6 +1323,12 @@ int svo_hip_sia_finish(svo_hip_sia* s) {
 }
 
 int svo_hip_sia_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) {
+  if (!s || !prm) return SVO_HIP_ERR_INVALID;
+  if (n_slots > 0 && n_slots <= s->batch) {
+    const int tpw = fused_tiles_per_wave(s, n_slots);
+    if (tpw > 0) return run_fused(s, n_slots, prm, tpw);
+  }
+  s->last_mode = 0;
   int rc = svo_hip_sia_begin(s, n_slots, prm);
   if (rc != SVO_HIP_OK) return rc;
   for (int level = prm->max_level; level >= prm->min_level; --level) {
@@ -873,6 +1340,12 @@ int svo_hip_sia_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) 
     }
   }
   return svo_hip_sia_finish(s);
+}
+
+int svo_hip_sia_last_run_mode(svo_hip_sia* s, int* mode) {
+  if (!s || !mode) return SVO_HIP_ERR_INVALID;
+  *mode = s->last_mode;
+  return SVO_HIP_OK;
 }
 
 int svo_hip_sia_set_profiling(svo_hip_sia* s, int enable) {

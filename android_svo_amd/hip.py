@@ -244,6 +244,11 @@ class SparseImgAlign:
     def set_reduce_buffer(self, dev_ptr: int):
         self.ctx.check(self.ctx.lib.svo_hip_sia_set_reduce_buffer(self.h, C.c_void_p(dev_ptr)), "sia_set_reduce_buffer")
 
+    def last_run_mode(self) -> int:
+        m = C.c_int(-1)
+        self.ctx.check(self.ctx.lib.svo_hip_sia_last_run_mode(self.h, C.byref(m)), "sia_last_run_mode")
+        return m.value
+
     def set_profiling(self, enable: bool):
         self.ctx.check(self.ctx.lib.svo_hip_sia_set_profiling(self.h, 1 if enable else 0), "sia_set_profiling")
 

@@ -145,8 +145,14 @@ int svo_hip_sia_finish(svo_hip_sia* sia);
 int svo_hip_sia_reduce_buffer(svo_hip_sia* sia, void** dev_ptr, size_t* n_doubles);
 /* use a caller-owned device buffer instead (e.g. a torch tensor that RCCL all-reduces in place) */
 int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
+/* Which implementation the last svo_hip_sia_run used: 1 = the fused kernel (one workgroup per frame pair,
+ * reference footprints in LDS, whole coarse-to-fine loop in one launch; chosen when every frame has at most
+ * 2816 features and no patch shard is set), 0 = the streaming kernels (one launch per Gauss-Newton
+ * evaluation; always used by the step-wise entry points).  SVO_HIP_SIA_MODE=stream forces 0. */
+int svo_hip_sia_last_run_mode(svo_hip_sia* sia, int* mode);
 /* Optional timing of the two heavy kernels with HIP events recorded on the context stream around
- * each launch (precompute: one per level; residual: one per Gauss-Newton evaluation).
+ * each launch (precompute: one per level; residual: one per Gauss-Newton evaluation; in fused mode the single
+ * launch of a run is reported in the `residual` slot).
  * get_profile synchronises, returns the summed device time and launch counts since the last call
  * and resets the counters. */
 int svo_hip_sia_set_profiling(svo_hip_sia* sia, int enable);

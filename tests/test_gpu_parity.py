@@ -5,6 +5,7 @@ Bars: bit-exact for bytes / integers / indices; floating point within the tolera
 at each assert (north_star: pose error < 1e-4 rad and < 1e-3 m vs the reference path).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -20,6 +21,19 @@ def ctx():
     c = hip.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(params=["fused", "stream"])
+def sia_mode(request):
+    """svo_hip_sia_run has two implementations (one fused launch per run / one launch per Gauss-Newton
+    evaluation); every run()-level parity test is executed against both."""
+    old = os.environ.get("SVO_HIP_SIA_MODE")
+    os.environ["SVO_HIP_SIA_MODE"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("SVO_HIP_SIA_MODE", None)
+    else:
+        os.environ["SVO_HIP_SIA_MODE"] = old
 
 
 def _upload_pair(ctx, fps, max_feat=None):
@@ -46,7 +60,11 @@ def test_precompute_caches_bit_exact(ctx):
     fp = synth.make_frame_pair(seed=21, n_features=300, null_point_every=11)
     ref, cur, sia = _upload_pair(ctx, [fp])
     prm = sia.params(max_level=2, min_level=2, n_iter=1)
-    sia.run(1, prm)
+    sia.begin(1, prm)            # step-wise entry points: always the streaming kernels, which keep the caches in HBM
+    sia.level_begin(2)
+    sia.accumulate()
+    sia.solve_update()
+    sia.finish()
     rc, dx, dy, vis = sia.download_caches(0, len(fp.px))
     T_cfr = synth.se3_mul(fp.T_cur_w_init, synth.se3_inv(fp.T_ref_w))
     out28, nm, cache, jac, ovis = orc.sia_single_eval(fp, 2, T_cfr, want_caches=True)
@@ -67,7 +85,7 @@ def test_precompute_caches_bit_exact(ctx):
 
 
 @pytest.mark.parametrize("n,seed", [(200, 12345), (2000, 12346), (1200, 12347)])
-def test_sparse_img_align_pose_parity(ctx, n, seed):
+def test_sparse_img_align_pose_parity(ctx, sia_mode, n, seed):
     """Configs C0 / C1-shape, reference semantics (early stop), L4-L0 and the shipping L4-L2."""
     fp = synth.make_frame_pair(seed=seed, n_features=n)
     ref, cur, sia = _upload_pair(ctx, [fp])
@@ -80,10 +98,11 @@ def test_sparse_img_align_pose_parity(ctx, n, seed):
         assert rot < 2e-5 and trans < 5e-5, (rot, trans)          # what we actually hold
         assert r.n_tracked == o.n_tracked
         assert r.stop == o.stop == 0
+        assert sia.last_run_mode() == (1 if sia_mode == "fused" else 0)
     _free(sia, ref, cur)
 
 
-def test_sparse_img_align_golden_full(ctx, golden):
+def test_sparse_img_align_golden_full(ctx, sia_mode, golden):
     """Against poses produced by the reference's own NLLSSolver/Eigen/SE3 (tests/golden/gn_full.npz)."""
     g = golden("gn_full.npz")
     for i in range(len(g["seed"])):
@@ -96,7 +115,7 @@ def test_sparse_img_align_golden_full(ctx, golden):
         _free(sia, ref, cur)
 
 
-def test_fixed_work_mode_matches_oracle_closely(ctx):
+def test_fixed_work_mode_matches_oracle_closely(ctx, sia_mode):
     """With early stop off both sides run exactly 30 iterations per level: no data-dependent
     control flow, so poses agree to fp64 summation-order noise."""
     fp = synth.make_frame_pair(seed=31, n_features=500)
@@ -112,7 +131,7 @@ def test_fixed_work_mode_matches_oracle_closely(ctx):
     _free(sia, ref, cur)
 
 
-def test_patches_leaving_the_image(ctx):
+def test_patches_leaving_the_image(ctx, sia_mode):
     """Features close to the border: some patches are invisible at coarse levels (reference image
     test), some leave the current image during the iterations.  Exercises the sticky visibility
     flags and the per-evaluation rebuild of H from the patches visible now."""
@@ -134,7 +153,7 @@ def test_patches_leaving_the_image(ctx):
     _free(sia, ref, cur)
 
 
-def test_batch_ragged_and_empty(ctx):
+def test_batch_ragged_and_empty(ctx, sia_mode):
     """A batch with different feature counts, an empty frame and point-less features: every
     slot must equal its own single-frame oracle run; an empty slot keeps its pose (run() -> 0)."""
     fps = [synth.make_frame_pair(seed=40 + i, n_features=n, null_point_every=k)
@@ -162,13 +181,21 @@ def test_batch_ragged_and_empty(ctx):
 
 
 def test_stepwise_equals_run_and_sharded_sum(ctx):
-    """The step-wise entry points reproduce run() bit for bit, and two patch shards whose reduce
-    rows are added (what the all-reduce does across GPUs) give the same normal equations."""
+    """The step-wise entry points reproduce the streaming run() bit for bit and the fused run() to
+    summation-order noise, and two patch shards whose reduce rows are added (what the all-reduce does
+    across GPUs) give the same normal equations."""
     fp = synth.make_frame_pair(seed=51, n_features=700)
     ref, cur, sia = _upload_pair(ctx, [fp])
     prm = sia.params()
+    os.environ["SVO_HIP_SIA_MODE"] = "fused"
+    sia.run(1, prm)
+    fused = sia.download(0)
+    os.environ["SVO_HIP_SIA_MODE"] = "stream"
     sia.run(1, prm)
     whole = sia.download(0)
+    os.environ.pop("SVO_HIP_SIA_MODE")
+    rot, trans = synth.pose_error(np.array(fused.T_cur_w), np.array(whole.T_cur_w))
+    assert rot < 1e-6 and trans < 1e-6
     sia.begin(1, prm)
     for level in range(4, -1, -1):
         sia.level_begin(level)
