@@ -604,11 +604,12 @@ template <int TPW>
 __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
     const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
-    const double* __restrict__ f, const double* __restrict__ pos, const uint8_t* __restrict__ has_point, FusedParams prm) {
+    const double* __restrict__ f, const double* __restrict__ pos, const uint8_t* __restrict__ has_point,
+    double4* __restrict__ sxyz, FusedParams prm) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint2* fp = reinterpret_cast<uint2*>(smem);               // [n_tiles*64][7] footprint rows
   __shared__ double red[FUSED_WAVES][32];
-  __shared__ double s_r[32];
+  __shared__ double s_r[32], s_last[32], s_x[8];
   __shared__ double s_model[8], s_old[8];
   __shared__ double s_chi2;
   __shared__ int s_done, s_stop, s_iter;
@@ -634,24 +635,22 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     s_chi2 = 1e10;                                           // reset(), nlls_solver_impl.hpp:299-309
     s_stop = 0; s_done = 0; s_iter = 0; s_npre = 0; s_nres = 0; s_nmeas = 0;
     for (int i = 0; i < SVO_HIP_MAX_LEVELS; ++i) s_iters[i] = 0;
-    FrameState& s = st[b];
-    for (int i = 0; i < 36; ++i) s.H[i] = 0.0;
-    for (int i = 0; i < 6; ++i) { s.Jres[i] = 0.0; s.x[i] = 0.0; }
+    for (int i = 0; i < 32; ++i) s_last[i] = 0.0;
+    for (int i = 0; i < 8; ++i) s_x[i] = 0.0;
   }
 
   // ---- lane-per-patch persistent state of the wave's tiles
   double4 X[TPW];
-  double Sxx[TPW], Sxy[TPW], Syy[TPW], th[TPW];
+  double th[TPW];
   float su[TPW], sv[TPW];
-  int off_ref[TPW];
   uint8_t fl[TPW];
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
     const int tile = wave + FUSED_WAVES * k;
     const int i_own = tile * TILE + 16 * r + q;
     X[k] = make_double4(0, 0, 1, 1);
-    Sxx[k] = Sxy[k] = Syy[k] = th[k] = 0.0;
-    su[k] = sv[k] = 0.0f; off_ref[k] = 0; fl[k] = 0;
+    th[k] = 0.0;
+    su[k] = sv[k] = 0.0f; fl[k] = 0;
     if (tile < n_tiles && i_own < n) {
       const size_t fi = (size_t)b * max_n + i_own;
       const double dxp = pos[3 * fi] - c.ref_pos[0];
@@ -739,7 +738,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       }
       SVO_FPRE(0) SVO_FPRE(1) SVO_FPRE(2) SVO_FPRE(3)
 #undef SVO_FPRE
-      if (valid) { Sxx[k] = sxx; Sxy[k] = sxy; Syy[k] = syy; }
+      if (valid) sxyz[(size_t)b * max_n + i_own] = make_double4(sxx, sxy, syy, 0.0);   // only re-read when a patch leaves the image
       // the tile's Hessian row: lane e keeps entry e
       {
         double A[6], B[6];
@@ -766,7 +765,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       if (s_done) break;                                     // block-uniform (read after a barrier)
       double T[7];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) T[i] = s_model[i];
+      for (int i = 0; i < 7; ++i) {          // block-uniform: keep the model in scalar registers
+        const double v = s_model[i];
+        T[i] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                                __builtin_amdgcn_readfirstlane(__double2loint(v)));
+      }
       double accH = 0.0;
       double accJ[6] = {0, 0, 0, 0, 0, 0};
       double acc_chi = 0.0;
@@ -861,7 +864,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
           const int src = __ffsll((long long)gone) - 1;
           gone &= gone - 1;
           const double gx_ = __shfl(X[k].x, src, 64), gy_ = __shfl(X[k].y, src, 64), gzi = __shfl(X[k].w, src, 64);
-          const double g_xx = __shfl(Sxx[k], src, 64), g_xy = __shfl(Sxy[k], src, 64), g_yy = __shfl(Syy[k], src, 64);
+          const double4 G4 = sxyz[(size_t)b * max_n + tile_base + 16 * (src & 3) + (src >> 2)];
+          const double g_xx = G4.x, g_xy = G4.y, g_yy = G4.z;
           double A[6], B[6];
           patch_jacobian_rows(gx_, gy_, gzi, jscale, A, B);
           double Ai = A[0], Aj = A[0], Bi = B[0], Bj = B[0];
@@ -896,6 +900,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
 #pragma unroll
           for (int w = 0; w < FUSED_WAVES; ++w) v += red[w][lane];
           s_r[lane] = v;
+          s_last[lane] = v;                  // H_ / Jres_ of the last evaluation, reported at the end
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -914,17 +919,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
           const double chi2_sum = s_r[27];
           const unsigned long long n_meas = (unsigned long long)(s_r[28] + 0.5);
           const double new_chi2 = (double)((float)chi2_sum / (float)n_meas);     // (:285)
-          FrameState& s = st[b];
-#pragma unroll
-          for (int i = 0; i < 36; ++i) s.H[i] = H[i];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) s.Jres[i] = Jres[i];
           s_nmeas = n_meas;
           s_nres += n_meas / 16;
           s_iters[level] += 1;
           ldlt6_solve_reg(H, Jres, x);
 #pragma unroll
-          for (int i = 0; i < 6; ++i) s.x[i] = x[i];
+          for (int i = 0; i < 6; ++i) s_x[i] = x[i];
           if (x[0] != x[0]) s_stop = 1;                                          // NaN -> stop_ (:52-59)
           const int it = s_iter;
           if ((prm.early_stop && it > 0 && new_chi2 > s_chi2) || s_stop) {
@@ -963,6 +963,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     for (int i = 0; i < 7; ++i) s.T_cur_w[i] = empty ? c.T_cur_w_init[i] : T[i];
     s.chi2 = s_chi2; s.stop = s_stop; s.iter = s_iter; s.level_done = 1; s.empty = empty;
     s.n_meas = s_nmeas; s.n_res = s_nres; s.n_pre = s_npre;
+    {
+      int kk = 0;
+      for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) { s.H[i * 6 + j] = s_last[kk]; s.H[j * 6 + i] = s_last[kk]; ++kk; }
+      for (int i = 0; i < 6; ++i) { s.Jres[i] = s_last[21 + i]; s.x[i] = s_x[i]; }
+    }
     for (int i = 0; i < SVO_HIP_MAX_LEVELS; ++i) s.iters[i] = s_iters[i];
   }
 }
@@ -1080,7 +1086,7 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
   hipLaunchKernelGGL(sia_fused_kernel<TPW>, dim3(n_slots), dim3(FUSED_THREADS), lds_bytes, ctx->stream, s->fc, s->st,
-                     s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, fp);
+                     s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, fp);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;

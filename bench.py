@@ -81,6 +81,11 @@ def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=6):
 
 def main():
     args = parse_args()
+    # RCCL prints a version banner on stdout when a communicator is created; the contract is ONE JSON
+    # line on stdout, so everything else this process (or a library) prints is sent to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,7 +93,7 @@ def main():
         args.gpus = world
     import torch
     import torch.distributed as dist
-    multi = world > 1
+    multi = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # launched by torch.distributed.run
     torch.cuda.set_device(local_rank)
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -171,22 +176,36 @@ def main():
         evals = sum(res.iters[:5])
         bytes_frame = n_pre_per_frame * BYTES_PRECOMPUTE + n_res_per_frame * BYTES_RESIDUAL
         roofline = None
+        mode = sia.last_run_mode() if not allreduce else 0
         if prof and prof["residual_launches"]:
             launches = prof["residual_launches"]
             avg_ms = prof["residual_ms"] / launches
-            # one launch evaluates every live patch of every frame of this rank once
-            units = (n_res_per_frame / max(evals, 1)) * n_slots / (world if allreduce else 1)
-            ach = units * BYTES_RESIDUAL / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "sia_residual_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
+            if mode == 1:
+                # fused: ONE launch runs the whole coarse-to-fine solve of every frame pair of this rank
+                kernel = "sia_fused_kernel"
+                alg_bytes = float(bytes_frame) * n_slots
+                note = ("one launch = whole solve of %d frame pairs; reference footprints stay in LDS, so the HBM "
+                        "stream the algorithmic bytes describe does not exist: the kernel is VALU-issue bound" % n_slots)
+            else:
+                # streaming: one launch evaluates every live patch of every frame of this rank once
+                kernel = "sia_residual_kernel"
+                units = (n_res_per_frame / max(evals, 1)) * n_slots / (world if allreduce else 1)
+                alg_bytes = units * BYTES_RESIDUAL
+                note = "one launch = one Gauss-Newton evaluation of %d frame pairs" % n_slots
+            ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_us": avg_ms * 1e3, "launches": int(launches),
-                        "algorithmic_bytes_per_launch": units * BYTES_RESIDUAL,
-                        "precompute_avg_launch_us": (prof["precompute_ms"] / max(prof["precompute_launches"], 1)) * 1e3}
+                        "algorithmic_bytes_per_launch": alg_bytes, "note": note}
+            if prof["precompute_launches"]:
+                roofline["precompute_avg_launch_us"] = prof["precompute_ms"] / prof["precompute_launches"] * 1e3
             tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tr):
                 try:
-                    roofline["traffic"] = json.load(open(tr)).get("sia_residual_kernel_bytes_per_launch")
-                    roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc pass of this command)"
+                    k = json.load(open(tr))["kernels"].get(kernel)
+                    if k and k.get("batch") == n_slots:
+                        roofline["traffic"] = k["bytes_per_launch"]
+                        roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, 2xFETCH_SIZE+WRITE_SIZE)"
                 except Exception:
                     pass
         cpu = None
@@ -202,7 +221,8 @@ def main():
                        "frame_pairs_per_gpu_per_step": B, "global_frame_pairs_per_step": frames_global,
                        "parallelism": ("patch-sharded + per-GN-step all-reduce of H/b (C3 variant)" if allreduce
                                        else "frame-parallel (no collective)") + ", %d GPU(s)" % world,
-                       "distinct_scenes": args.distinct},
+                       "distinct_scenes": args.distinct,
+                       "implementation": "fused (one workgroup per frame pair, one launch per solve)" if (not allreduce and sia.last_run_mode() == 1) else "streaming (one launch per Gauss-Newton evaluation)"},
             "pose_err_vs_cpu_ref": {"rot_rad": rot, "trans_m": trans, "tolerance": "1e-4 rad / 1e-3 m"},
             "gn_evaluations_per_frame": int(evals),
             "algorithmic_bytes_per_frame": int(bytes_frame),
@@ -215,8 +235,8 @@ def main():
         for i, r in enumerate(results):
             if i >= len(fps) and i % len(fps) == 0:
                 assert list(r.T_cur_w) == list(results[0].T_cur_w)
-        print(json.dumps(out))
         sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
         dist.destroy_process_group()
