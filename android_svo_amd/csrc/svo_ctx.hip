@@ -125,6 +125,13 @@ int svo_hip_memcpy_d2h(svo_hip_ctx* ctx, void* dst_host, const void* src_dev, si
   return SVO_HIP_OK;
 }
 
+int svo_hip_copy_d2d(svo_hip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes) {
+  if (!ctx || (!dst_dev && bytes) || (!src_dev && bytes)) return SVO_HIP_ERR_INVALID;
+  if (!bytes) return SVO_HIP_OK;
+  SVO_CHECK_HIP(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return SVO_HIP_OK;
+}
+
 int svo_hip_memset(svo_hip_ctx* ctx, void* dst_dev, int value, size_t bytes) {
   if (!ctx || (!dst_dev && bytes)) return SVO_HIP_ERR_INVALID;
   if (!bytes) return SVO_HIP_OK;

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""bench_c2.py -- secondary metrics of SURVEY.md 8(d), BASELINE config C2 (and C4 shape with --seeds 1000000):
+feature_alignment::align2D over 5000 8x8 patches and one DepthFilter::updateSeeds pass over 100k seeds
+per frame on one MI355X, inputs resident in HBM, next to the CPU oracle on the host cores.
+Prints one JSON line.  (bench.py is the headline metric; this file is not run by the driver.)"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from android_svo_amd import hip, seedsynth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+
+def timed(ctx, fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    ctx.sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--patches", type=int, default=5000)
+    ap.add_argument("--seeds", type=int, default=100000)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    from oracle import orc
+
+    ctx = hip.Context(0)
+    out = {"config": {"workload": "C2: align2D x %d patches + DepthFilter update x %d seeds, 640x480" % (args.patches, args.seeds)}}
+
+    # ---------------- align2D ----------------
+    ac = seedsynth.make_align_case(n=args.patches)
+    pyr = hip.Pyramid(ctx, ac.cam.width, ac.cam.height, 5, 1)
+    pyr.upload(0, ac.cur_pyr)
+    d_pwb = ctx.to_device(ac.pwb)
+    d_px0 = ctx.to_device(ac.px_init)
+    d_px = ctx.empty(ac.px_init.shape, np.float64)
+    d_conv = ctx.empty((args.patches,), np.uint8)
+    d_it = ctx.empty((args.patches,), np.int32)
+
+    def run_align():
+        # restore the initial estimates (device to device) then refine
+        ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(d_px.ptr), C.c_void_p(d_px0.ptr), C.c_size_t(d_px.nbytes)), "d2d")
+        ctx.check(ctx.lib.svo_hip_align2d_batch_dev(ctx.h, pyr.h, 0, 0, args.patches, C.c_void_p(d_pwb.ptr), None, 10,
+                                                    C.c_void_p(d_px.ptr), C.c_void_p(d_conv.ptr), C.c_void_p(d_it.ptr)), "align2d")
+    t_align = timed(ctx, run_align, args.steps, args.warmup)
+    iters = d_it.download()
+    alg_align = float(np.sum(197 + 81 * iters))
+    out["align2d"] = {"patches_per_s": args.patches / t_align, "us_per_batch": t_align * 1e6,
+                      "converged": int(d_conv.download().sum()), "mean_iters": float(iters.mean()),
+                      "algorithmic_bytes": alg_align, "algorithmic_GBps": alg_align / t_align / 1e9,
+                      "frac_hbm": alg_align / t_align / 1e9 / HBM_PEAK_GBS}
+
+    # ---------------- depth filter ----------------
+    sc = seedsynth.make_seed_case(n_seeds=args.seeds, seed=9)
+    kf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
+    cf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
+    kf.upload(0, sc.ref_pyr)
+    cf.upload(0, sc.cur_pyr)
+    sb = hip.SeedBatch(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, sc.sigma2)
+    st0 = [ctx.to_device(v) for v in (sc.a, sc.b, sc.mu, sc.sigma2)]
+
+    def run_df():
+        for dst, src in zip((sb.a, sb.b, sb.mu, sb.sigma2), st0):        # same seed state every step
+            ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(dst.ptr), C.c_void_p(src.ptr), C.c_size_t(dst.nbytes)), "d2d")
+        hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb)
+    t_df = timed(ctx, run_df, args.steps, args.warmup)
+    nz, na, st = sb.n_zmssd.download(), sb.n_align.download(), sb.status.download()
+    alg_df = float(np.sum(44 + 56 + 100 + 64 * nz.astype(np.int64) + 81 * na.astype(np.int64)))
+    out["depth_filter"] = {"seeds_per_s": args.seeds / t_df, "us_per_frame": t_df * 1e6,
+                           "status_counts": np.bincount(st, minlength=6).tolist(), "mean_zmssd": float(nz.mean()),
+                           "mean_align_iters": float(na.mean()), "algorithmic_bytes": alg_df,
+                           "algorithmic_GBps": alg_df / t_df / 1e9, "frac_hbm": alg_df / t_df / 1e9 / HBM_PEAK_GBS}
+
+    # pure Bayes update (44 B/seed)
+    n = args.seeds
+    x = ctx.to_device((sc.mu + 0.01).astype(np.float32))
+    tau2 = ctx.to_device(np.full(n, 1e-2, dtype=np.float32))
+
+    def run_us():
+        ctx.check(ctx.lib.svo_hip_update_seed_batch_dev(ctx.h, n, C.c_void_p(x.ptr), C.c_void_p(tau2.ptr), C.c_void_p(sb.a.ptr),
+                                                        C.c_void_p(sb.b.ptr), C.c_void_p(sb.mu.ptr), C.c_void_p(sb.z_range.ptr),
+                                                        C.c_void_p(sb.sigma2.ptr)), "update_seed")
+    t_us = timed(ctx, run_us, args.steps, args.warmup)
+    out["update_seed"] = {"seeds_per_s": n / t_us, "us": t_us * 1e6, "algorithmic_GBps": 44.0 * n / t_us / 1e9,
+                          "frac_hbm": 44.0 * n / t_us / 1e9 / HBM_PEAK_GBS}
+
+    # ---------------- CPU oracle (bounded sample) ----------------
+    if not args.no_cpu_baseline:
+        n_thr = max(1, min(os.cpu_count() or 1, 16))
+        m = min(args.patches, 5000)
+        t0 = time.perf_counter()
+        for i in range(m):
+            orc.align2d(ac.cur_pyr[0], ac.pwb[i], ac.patch[i], 10, ac.px_init[i])
+        t_cpu_a = (time.perf_counter() - t0) / m
+        ns = min(args.seeds, 20000)
+        sl = [slice(t * ns // n_thr, (t + 1) * ns // n_thr) for t in range(n_thr)]
+
+        def work(s):
+            a, b, mu, s2 = (v[s].copy() for v in (sc.a, sc.b, sc.mu, sc.sigma2))
+            orc.update_seeds(sc.cam, sc.ref_pyr, sc.cur_pyr, sc.T_ref_w, sc.T_cur_w, sc.px[s], sc.f[s], sc.level[s], a, b, mu,
+                             sc.z_range[s].copy(), s2)
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(s,)) for s in sl]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        t_cpu_s = time.perf_counter() - t0
+        out["cpu_baseline"] = {"kind": "port", "align2d_patches_per_s_1thread_incl_ctypes": 1.0 / t_cpu_a,
+                               "depth_filter_seeds_per_s": ns / t_cpu_s, "cores": n_thr,
+                               "sample": "%d patches on 1 thread (python loop around the C call), %d seeds on %d threads" % (m, ns, n_thr)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

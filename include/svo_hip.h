@@ -70,6 +70,7 @@ int svo_hip_malloc(svo_hip_ctx* ctx, void** dev_ptr, size_t bytes);
 int svo_hip_free(svo_hip_ctx* ctx, void* dev_ptr);
 int svo_hip_memcpy_h2d(svo_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);   /* async */
 int svo_hip_memcpy_d2h(svo_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);   /* synchronises */
+int svo_hip_copy_d2d(svo_hip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);        /* async */
 int svo_hip_memset(svo_hip_ctx* ctx, void* dst_dev, int value, size_t bytes);
 
 /* ---- image pyramids resident in HBM (Frame::img_pyr_, frame.cpp:63,186-195) ------------ */
