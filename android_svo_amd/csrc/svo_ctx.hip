@@ -72,10 +72,9 @@ int svo_hip_ctx_create(svo_hip_ctx** out, int device, void* stream) {
 
 int svo_hip_ctx_destroy(svo_hip_ctx* ctx) {
   if (!ctx) return SVO_HIP_ERR_INVALID;
-  if (ctx->own_stream && ctx->stream) {
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamDestroy(ctx->stream);
-  }
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return SVO_HIP_OK;
 }

@@ -5,8 +5,8 @@
 // Reference: S/depth_filter.cpp:237-416, S/matcher.cpp:36-147,207-355,
 // I/patch_score.h:40-220, S/feature_alignment.cpp:154-282.
 //
-// Mapping: one wave64 per seed.  The fp64 geometry of a seed is wave-uniform (every lane
-// evaluates it; it is a few hundred flops against thousands of lane-ops of search work);
+// Mapping: three stages (thread-per-seed geometry, wave-per-seed pixel work, thread-per-seed update);
+// the fp64 geometry of a seed is evaluated once, 64 seeds per wave instruction;
 // the 10x10 warped reference patch is built by lanes 0..99 (two passes) into LDS; the
 // epipolar search assigns one candidate position per lane (64 candidates per pass), each
 // lane computing a whole 8x8 ZMSSD with packed u8 dot products against the LDS patch;
@@ -194,52 +194,63 @@ SVO_DEV int zmssd_8x8(const uint8_t* __restrict__ p, int stride, const uint32_t*
   return sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
 }
 
-// One wave per seed; 4 seeds per 256-thread block.
-__global__ __launch_bounds__(256) void depth_filter_update_kernel(
-    DfFrame fr, const uint8_t* __restrict__ ref_pyr, const uint8_t* __restrict__ cur_pyr, int n,
-    const double* __restrict__ px, const double* __restrict__ f, const int32_t* __restrict__ level,
-    float* __restrict__ sa, float* __restrict__ sb, float* __restrict__ smu, const float* __restrict__ sz_range,
-    float* __restrict__ ssigma2, int32_t* __restrict__ status, double* __restrict__ z_out,
-    double* __restrict__ xyz_world, int32_t* __restrict__ n_zmssd_out, int32_t* __restrict__ n_align_out) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_pwb[4][112];
-  __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][16];
-  const int wib = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + wib;
-  if (i >= n) return;                      // wave-uniform; no block-level barrier is used below
-  const Cam cam = fr.cam;
-  uint8_t* pwb = s_pwb[wib];
-  uint32_t* patch_words = s_patch[wib];
+// ---- DepthFilter::updateSeeds as three stages -------------------------------------------------
+// G  thread per seed : visibility, epipolar segment, affine warp, search level, search plan  -> SeedRec
+// S  wave per seed   : warp the 10x10 patch (LDS), ZMSSD search along the epipolar line, align2D -> SeedRec
+// F  thread per seed : triangulation, computeTau, updateSeed, convergence                     -> seed arrays
+// The fp64 geometry of a seed runs once (64 seeds per wave instruction) instead of on every lane of
+// the seed's wave; only the pixel work is wave-per-seed.
+struct SeedRec {                 // 96 B, one per seed of the batch (device scratch owned by the context)
+  double uv0[2];                 // path 1: B - step (epipolar abscissa of step 0); path 0: px midpoint (level 0)
+  double step[2];                // path 1: epi_dir / n_steps; after stage S: px_cur (level 0) of the match
+  float a00, a01, a10, a11;      // inverse affine warp (A_cur_ref^-1 cast to f32)
+  float prx, pry;                // ref px on its pyramid level
+  float z_inv_min;               // for the NaN test of depth_filter.cpp:333
+  int n_steps;                   // epi_length / 0.7 (before the ++ of matcher.cpp:297)
+  int search_level;
+  int path;                      // 0 direct align, 1 epipolar search, 2 no search (too long), -1 seed not live
+  int status;                    // pre-status for non-live seeds
+  int warp_nan;
+  int matched;                   // stage S: align2D converged
+  int n_zmssd, n_align;
+  int pad;
+};
 
-  int n_zmssd = 0, n_align = 0;
-  int st = SVO_HIP_SEED_NO_MATCH;
-  double z = 0.0;
+__global__ __launch_bounds__(256) void df_geometry_kernel(
+    DfFrame fr, int n, const double* __restrict__ px, const double* __restrict__ f, const int32_t* __restrict__ level,
+    const float* __restrict__ smu, const float* __restrict__ ssigma2, SeedRec* __restrict__ recs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Cam cam = fr.cam;
+  SeedRec rc;
+  rc.uv0[0] = rc.uv0[1] = rc.step[0] = rc.step[1] = 0.0;
+  rc.a00 = rc.a01 = rc.a10 = rc.a11 = rc.prx = rc.pry = 0.0f;
+  rc.n_steps = 0; rc.search_level = 0; rc.path = -1; rc.status = SVO_HIP_SEED_NO_MATCH; rc.warp_nan = 0;
+  rc.matched = 0; rc.n_zmssd = 0; rc.n_align = 0; rc.pad = 0;
   const double fi[3] = {f[3 * (size_t)i], f[3 * (size_t)i + 1], f[3 * (size_t)i + 2]};
   const double px_ref[2] = {px[2 * (size_t)i], px[2 * (size_t)i + 1]};
   const int level_ref = level[i];
-  SeedState seed = {sa[i], sb[i], smu[i], sz_range[i], ssigma2[i]};
-
+  const float mu = smu[i], sigma2 = ssigma2[i];
   // ---- visibility in the current frame (depth_filter.cpp:264-275)
-  const double inv_mu = 1.0 / seed.mu;
+  const double inv_mu = 1.0 / mu;
   const double pf[3] = {inv_mu * fi[0], inv_mu * fi[1], inv_mu * fi[2]};
   double xyz_f[3];
   se3_act(fr.T_cur_ref_vis, pf, xyz_f);
   bool live = true;
-  if (xyz_f[2] < 0.0) { st = SVO_HIP_SEED_BEHIND; live = false; }
+  if (xyz_f[2] < 0.0) { rc.status = SVO_HIP_SEED_BEHIND; live = false; }
   if (live) {
     double pc[2];
     world2cam(cam, xyz_f, pc);
     const int ox = (int)pc[0], oy = (int)pc[1];
-    if (!(ox >= 0 && ox < cam.width && oy >= 0 && oy < cam.height)) { st = SVO_HIP_SEED_NOT_IN_FRAME; live = false; }
+    if (!(ox >= 0 && ox < cam.width && oy >= 0 && oy < cam.height)) { rc.status = SVO_HIP_SEED_NOT_IN_FRAME; live = false; }
   }
-  const float z_inv_min = seed.mu + sqrtf(seed.sigma2);
-  bool matched = false;
+  const float z_inv_min = mu + sqrtf(sigma2);
+  rc.z_inv_min = z_inv_min;
   if (live) {
-    const float z_inv_lo = seed.mu - sqrtf(seed.sigma2);
+    const float z_inv_lo = mu - sqrtf(sigma2);
     const float z_inv_max = (z_inv_lo < 0.00000001f) ? 0.00000001f : z_inv_lo;
-    const double d_estimate = 1.0 / seed.mu, d_min = 1.0 / z_inv_min, d_max = 1.0 / z_inv_max;
-
-    // ---- Matcher::findEpipolarMatchDirect (matcher.cpp:207-355)
+    const double d_estimate = 1.0 / mu, d_min = 1.0 / z_inv_min, d_max = 1.0 / z_inv_max;
+    // ---- Matcher::findEpipolarMatchDirect up to the search plan (matcher.cpp:216-296)
     const double* T_cur_ref = fr.T_cur_ref;
     double pa[3], pb[3], tmp[3];
     tmp[0] = fi[0] * d_min; tmp[1] = fi[1] * d_min; tmp[2] = fi[2] * d_min;
@@ -256,6 +267,7 @@ __global__ __launch_bounds__(256) void depth_filter_update_kernel(
       double D = Acr[0] * Acr[3] - Acr[2] * Acr[1];
       while (D > 3.0 && search_level < fr.n_pyr_levels - 1) { search_level += 1; D *= 0.25; }
     }
+    rc.search_level = search_level;
     double px_A[2], px_B[2];
     world2cam_uv(cam, Aep[0], Aep[1], px_A);
     world2cam_uv(cam, Bep[0], Bep[1], px_B);
@@ -264,129 +276,204 @@ __global__ __launch_bounds__(256) void depth_filter_update_kernel(
       const double ex = px_A[0] - px_B[0], ey = px_A[1] - px_B[1];
       epi_length = sqrt(ex * ex + ey * ey) / (1 << search_level);
     }
-
-    // ---- warp::warpAffine of the 10x10 reference patch (matcher.cpp:83-116), lanes 0..99
     {
-      const int rcols = cam.width >> level_ref, rrows = cam.height >> level_ref;
-      const uint8_t* img_ref = ref_pyr + fr.ref_level_off[level_ref];
+      // warp::warpAffine prologue (matcher.cpp:92-102)
       const double det = Acr[0] * Acr[3] - Acr[2] * Acr[1];
       const double invdet = 1.0 / det;
-      const float a00 = (float)(Acr[3] * invdet), a01 = (float)(-Acr[1] * invdet);
-      const float a10 = (float)(-Acr[2] * invdet), a11 = (float)(Acr[0] * invdet);
-      const bool warp_nan = a00 != a00;     // reference leaves the previous patch in place; we zero it
-      const float prx = (float)px_ref[0] / (1 << level_ref);
-      const float pry = (float)px_ref[1] / (1 << level_ref);
-      for (int k = lane; k < 100; k += 64) {
-        const int yy = k / 10, xx = k - yy * 10;
-        float ppx = (float)(xx - 5), ppy = (float)(yy - 5);
-        ppx *= (1 << search_level);
-        ppy *= (1 << search_level);
-        const float qx = (a00 * ppx + a01 * ppy) + prx;
-        const float qy = (a10 * ppx + a11 * ppy) + pry;
-        uint8_t val = 0;
-        // the reference reads out of bounds when qx/qy are NaN (inf inverse of a singular A);
-        // here such samples are 0
-        if (!warp_nan && qx >= 0 && qy >= 0 && qx < rcols - 1 && qy < rrows - 1)
-          val = (uint8_t)interpolate_8u(img_ref, rcols, qx, qy);
-        pwb[k] = val;
-      }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      // createPatchFromPatchWithBorder (matcher.cpp:138-147): lane = pixel of the 8x8 patch
-      reinterpret_cast<uint8_t*>(patch_words)[lane] = pwb[((lane >> 3) + 1) * 10 + (lane & 7) + 1];
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      rc.a00 = (float)(Acr[3] * invdet); rc.a01 = (float)(-Acr[1] * invdet);
+      rc.a10 = (float)(-Acr[2] * invdet); rc.a11 = (float)(Acr[0] * invdet);
+      rc.warp_nan = rc.a00 != rc.a00;
+      rc.prx = (float)px_ref[0] / (1 << level_ref);
+      rc.pry = (float)px_ref[1] / (1 << level_ref);
     }
-
-    const int ccols = cam.width >> search_level, crows = cam.height >> search_level;
-    const uint8_t* cur_img = cur_pyr + fr.cur_level_off[search_level];
-    double px_cur[2] = {0, 0};
-    bool do_align = false;
-
     if (epi_length < 2.0) {
-      px_cur[0] = (px_A[0] + px_B[0]) / 2.0;
-      px_cur[1] = (px_A[1] + px_B[1]) / 2.0;
-      do_align = true;
+      rc.path = 0;
+      rc.uv0[0] = (px_A[0] + px_B[0]) / 2.0;
+      rc.uv0[1] = (px_A[1] + px_B[1]) / 2.0;
     } else {
-      size_t n_steps = (size_t)(epi_length / 0.7);
-      const double step[2] = {epi_dir[0] / n_steps, epi_dir[1] / n_steps};
-      if (n_steps <= (size_t)fr.max_epi_search_steps) {
-        // reference patch statistics (ZMSSD ctor, patch_score.h:49-61)
-        int sumA, sumAA;
-        {
-          const uint32_t a = reinterpret_cast<uint8_t*>(patch_words)[lane];
-          sumA = group_sum<64>((int)a);
-          sumAA = group_sum<64>((int)(a * a));
+      const size_t n_steps = (size_t)(epi_length / 0.7);
+      if (n_steps > (size_t)fr.max_epi_search_steps) {
+        rc.path = 2;
+      } else {
+        rc.path = 1;
+        rc.n_steps = (int)n_steps;
+        rc.step[0] = epi_dir[0] / n_steps; rc.step[1] = epi_dir[1] / n_steps;
+        rc.uv0[0] = Bep[0] - rc.step[0]; rc.uv0[1] = Bep[1] - rc.step[1];
+      }
+    }
+  }
+  recs[i] = rc;
+}
+
+// One wave per seed; 4 seeds per 256-thread block.
+__global__ __launch_bounds__(256) void df_search_kernel(
+    DfFrame fr, const uint8_t* __restrict__ ref_pyr, const uint8_t* __restrict__ cur_pyr, int n,
+    const int32_t* __restrict__ level, SeedRec* __restrict__ recs) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_pwb[4][112];
+  __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][16];
+  const int wib = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wib;
+  if (i >= n) return;                      // wave-uniform; no block-level barrier is used below
+  SeedRec* rp = recs + i;
+  const int path = rp->path;
+  if (path != 0 && path != 1) return;      // not live, or the search is skipped
+  const Cam cam = fr.cam;
+  uint8_t* pwb = s_pwb[wib];
+  uint32_t* patch_words = s_patch[wib];
+  const int level_ref = level[i];
+  const int search_level = rp->search_level;
+  int n_zmssd = 0, n_align = 0;
+
+  // ---- warp::warpAffine of the 10x10 reference patch (matcher.cpp:83-116), lanes 0..99
+  {
+    const int rcols = cam.width >> level_ref, rrows = cam.height >> level_ref;
+    const uint8_t* img_ref = ref_pyr + fr.ref_level_off[level_ref];
+    const float a00 = rp->a00, a01 = rp->a01, a10 = rp->a10, a11 = rp->a11;
+    const bool warp_nan = rp->warp_nan != 0;   // the reference keeps the previous seed's patch; we use zeros
+    const float prx = rp->prx, pry = rp->pry;
+    for (int k = lane; k < 100; k += 64) {
+      const int yy = k / 10, xx = k - yy * 10;
+      float ppx = (float)(xx - 5), ppy = (float)(yy - 5);
+      ppx *= (1 << search_level);
+      ppy *= (1 << search_level);
+      const float qx = (a00 * ppx + a01 * ppy) + prx;
+      const float qy = (a10 * ppx + a11 * ppy) + pry;
+      uint8_t val = 0;
+      // the reference reads out of bounds when qx/qy are NaN (inf inverse of a singular A); such samples are 0
+      if (!warp_nan && qx >= 0 && qy >= 0 && qx < rcols - 1 && qy < rrows - 1)
+        val = (uint8_t)interpolate_8u(img_ref, rcols, qx, qy);
+      pwb[k] = val;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // createPatchFromPatchWithBorder (matcher.cpp:138-147): lane = pixel of the 8x8 patch
+    reinterpret_cast<uint8_t*>(patch_words)[lane] = pwb[((lane >> 3) + 1) * 10 + (lane & 7) + 1];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+
+  const int ccols = cam.width >> search_level, crows = cam.height >> search_level;
+  const uint8_t* cur_img = cur_pyr + fr.cur_level_off[search_level];
+  double px_cur[2] = {rp->uv0[0], rp->uv0[1]};     // path 0: midpoint of the projected segment
+  bool do_align = path == 0;
+
+  if (path == 1) {
+    const double step[2] = {rp->step[0], rp->step[1]};
+    const double uv0[2] = {rp->uv0[0], rp->uv0[1]};
+    const int n_steps = rp->n_steps + 1;            // ++n_steps (matcher.cpp:297)
+    // reference patch statistics (ZMSSD ctor, patch_score.h:49-61)
+    int sumA, sumAA;
+    {
+      const uint32_t a = reinterpret_cast<uint8_t*>(patch_words)[lane];
+      sumA = group_sum<64>((int)a);
+      sumAA = group_sum<64>((int)(a * a));
+    }
+    unsigned long long best_key = ~0ull;
+    int prev_tail_x = 0, prev_tail_y = 0;            // last_checked_pxi entering the chunk
+    double uv_tail[2] = {uv0[0], uv0[1]};            // exact uv of step index chunk0 (slow path only)
+    bool chain_exact = true;                         // uv_tail is current (no fast chunk has been taken yet)
+    for (int chunk0 = 0; chunk0 < n_steps; chunk0 += 64) {
+      const int idx = chunk0 + lane;
+      const bool in_range = idx < n_steps;
+      // The serial loop produces uv_i by repeated addition (matcher.cpp:299).  uv0 + i*step differs from it by
+      // < 1e-13 relative, i.e. < 1e-10 px: if every candidate of the chunk is farther than 1e-7 px from a
+      // rounding boundary of (int)(px/2^L + 0.5) the integer pixel is the same and the chain is not needed.
+      double uv[2] = {uv0[0] + (double)idx * step[0], uv0[1] + (double)idx * step[1]};
+      double pxs[2];
+      world2cam_uv(cam, uv[0], uv[1], pxs);
+      double tx = pxs[0] / (1 << search_level) + 0.5, ty = pxs[1] / (1 << search_level) + 0.5;
+      const bool risky = in_range && !(fabs(tx - rint(tx)) > 1e-7 && fabs(ty - rint(ty)) > 1e-7);
+      if (__ballot(risky) != 0ull) {
+        // exact replay of the chain for this chunk: bring the tail to chunk0, then lane l adds `step` l times
+        if (!chain_exact) {
+          uv_tail[0] = uv0[0]; uv_tail[1] = uv0[1];
+          for (int k = 0; k < chunk0; ++k) { uv_tail[0] += step[0]; uv_tail[1] += step[1]; }
         }
-        ++n_steps;
-        double uv_base[2] = {Bep[0] - step[0], Bep[1] - step[1]};      // uv of step index `chunk0`
-        unsigned long long best_key = ~0ull;
-        double best_uv[2] = {0, 0};
-        int prev_tail_x = 0, prev_tail_y = 0;                            // last_checked_pxi entering the chunk
-        for (size_t chunk0 = 0; chunk0 < n_steps; chunk0 += 64) {
-          // uv_i by the same repeated addition as the serial loop: lane l adds `step` l times
-          double uv[2] = {uv_base[0], uv_base[1]};
-          for (int k = 0; k < 63; ++k) {
-            if (k < lane) { uv[0] += step[0]; uv[1] += step[1]; }
-          }
-          const size_t idx = chunk0 + lane;
-          const bool in_range = idx < n_steps;
-          double pxs[2];
-          world2cam_uv(cam, uv[0], uv[1], pxs);
-          const int pxi_x = (int)(pxs[0] / (1 << search_level) + 0.5);
-          const int pxi_y = (int)(pxs[1] / (1 << search_level) + 0.5);
-          // dedupe against the previous step (matcher.cpp:306-308): it never changes the arg-min,
-          // only the count of evaluations, which we keep for the work counters
-          int prev_x = __shfl_up(pxi_x, 1, 64), prev_y = __shfl_up(pxi_y, 1, 64);
-          if (lane == 0) { prev_x = prev_tail_x; prev_y = prev_tail_y; }
-          const bool dup = (pxi_x == prev_x && pxi_y == prev_y);
-          const bool inframe = is_in_frame_level(cam, pxi_x, pxi_y, 8, search_level);
-          // last_checked_pxi only advances on non-duplicates, so a duplicate run compares against the
-          // run's first element, which equals the previous element: the neighbour test is equivalent
-          int score = 0x7fffffff;
-          const bool eval = in_range && !dup && inframe;
-          if (eval) {
-            const uint8_t* cp = cur_img + (pxi_y - 4) * ccols + (pxi_x - 4);
-            score = zmssd_8x8(cp, ccols, patch_words, sumA, sumAA);
-          }
-          n_zmssd += __popcll(__ballot(eval));
-          if (eval && score < ZMSSD_THRESHOLD) {
-            const unsigned long long key = ((unsigned long long)(unsigned)score << 32) | (unsigned long long)idx;
-            if (key < best_key) { best_key = key; best_uv[0] = uv[0]; best_uv[1] = uv[1]; }
-          }
-          // next chunk: base = uv of lane 63 plus one more step; tail pixel = lane 63's pixel
-          const double n0 = __shfl(uv[0], 63, 64) + step[0], n1 = __shfl(uv[1], 63, 64) + step[1];
-          uv_base[0] = n0; uv_base[1] = n1;
-          prev_tail_x = __shfl(pxi_x, 63, 64); prev_tail_y = __shfl(pxi_y, 63, 64);
+        uv[0] = uv_tail[0]; uv[1] = uv_tail[1];
+        for (int k = 0; k < 63; ++k) {
+          if (k < lane) { uv[0] += step[0]; uv[1] += step[1]; }
         }
-        // wave arg-min on (score, index): the smallest score, earliest index on ties
-        unsigned long long k = best_key;
+        uv_tail[0] = __shfl(uv[0], 63, 64) + step[0];
+        uv_tail[1] = __shfl(uv[1], 63, 64) + step[1];
+        chain_exact = true;
+        world2cam_uv(cam, uv[0], uv[1], pxs);
+        tx = pxs[0] / (1 << search_level) + 0.5; ty = pxs[1] / (1 << search_level) + 0.5;
+      } else {
+        chain_exact = false;
+      }
+      const int pxi_x = (int)tx, pxi_y = (int)ty;
+      // dedupe against the previous step (matcher.cpp:306-308): it never changes the arg-min, only the
+      // count of evaluations, which we keep for the work counters
+      int prev_x = __shfl_up(pxi_x, 1, 64), prev_y = __shfl_up(pxi_y, 1, 64);
+      if (lane == 0) { prev_x = prev_tail_x; prev_y = prev_tail_y; }
+      const bool dup = (pxi_x == prev_x && pxi_y == prev_y);
+      const bool inframe = is_in_frame_level(cam, pxi_x, pxi_y, 8, search_level);
+      int score = 0x7fffffff;
+      const bool eval = in_range && !dup && inframe;
+      if (eval) {
+        const uint8_t* cp = cur_img + (pxi_y - 4) * ccols + (pxi_x - 4);
+        score = zmssd_8x8(cp, ccols, patch_words, sumA, sumAA);
+      }
+      n_zmssd += __popcll(__ballot(eval));
+      if (eval && score < ZMSSD_THRESHOLD) {
+        const unsigned long long key = ((unsigned long long)(unsigned)score << 32) | (unsigned long long)(unsigned)idx;
+        if (key < best_key) best_key = key;
+      }
+      prev_tail_x = __shfl(pxi_x, 63, 64); prev_tail_y = __shfl(pxi_y, 63, 64);
+    }
+    // wave arg-min on (score, index): the smallest score, earliest index on ties
+    unsigned long long k = best_key;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const unsigned long long other = __shfl_xor(k, o, 64);
-          k = other < k ? other : k;
-        }
-        if (k != ~0ull) {
-          const int src = __ffsll((long long)__ballot(best_key == k)) - 1;
-          const double bu = __shfl(best_uv[0], src, 64), bv = __shfl(best_uv[1], src, 64);
-          world2cam_uv(cam, bu, bv, px_cur);
-          do_align = true;
-        }
-      }
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(k, o, 64);
+      k = other < k ? other : k;
     }
-
-    if (do_align) {
-      double us = px_cur[0] / (1 << search_level), vs = px_cur[1] / (1 << search_level);
-      const bool res = align2d_wave(cur_img, ccols, crows, ccols, pwb, fr.align_max_iter, &us, &vs, &n_align);
-      if (res) {
-        px_cur[0] = us * (1 << search_level);
-        px_cur[1] = vs * (1 << search_level);
-        double fc[3];
-        cam2world(cam, px_cur[0], px_cur[1], fc);
-        matched = depth_from_triangulation(T_cur_ref, fi, fc, &z);
-      }
+    if (k != ~0ull) {
+      // uv_best: replay the serial chain up to the winning index (wave-uniform loop)
+      const int best_idx = (int)(k & 0xffffffffull);
+      double bu = uv0[0], bv = uv0[1];
+      for (int t = 0; t < best_idx; ++t) { bu += step[0]; bv += step[1]; }
+      world2cam_uv(cam, bu, bv, px_cur);
+      do_align = true;
     }
+  }
 
+  bool res = false;
+  if (do_align) {
+    double us = px_cur[0] / (1 << search_level), vs = px_cur[1] / (1 << search_level);
+    res = align2d_wave(cur_img, ccols, crows, ccols, pwb, fr.align_max_iter, &us, &vs, &n_align);
+    if (res) {
+      px_cur[0] = us * (1 << search_level);
+      px_cur[1] = vs * (1 << search_level);
+    }
+  }
+  if (lane == 0) {
+    rp->matched = res ? 1 : 0;
+    rp->step[0] = px_cur[0]; rp->step[1] = px_cur[1];
+    rp->n_zmssd = n_zmssd; rp->n_align = n_align;
+  }
+}
+
+__global__ __launch_bounds__(256) void df_finalize_kernel(
+    DfFrame fr, int n, const double* __restrict__ f, const SeedRec* __restrict__ recs, float* __restrict__ sa,
+    float* __restrict__ sb, float* __restrict__ smu, const float* __restrict__ sz_range, float* __restrict__ ssigma2,
+    int32_t* __restrict__ status, double* __restrict__ z_out, double* __restrict__ xyz_world,
+    int32_t* __restrict__ n_zmssd_out, int32_t* __restrict__ n_align_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const SeedRec rc = recs[i];
+  int st = rc.status;
+  double z = 0.0;
+  if (rc.path >= 0) {
+    const double fi[3] = {f[3 * (size_t)i], f[3 * (size_t)i + 1], f[3 * (size_t)i + 2]};
+    SeedState seed = {sa[i], sb[i], smu[i], sz_range[i], ssigma2[i]};
+    bool matched = false;
+    if (rc.matched) {
+      double fc[3];
+      cam2world(fr.cam, rc.step[0], rc.step[1], fc);
+      matched = depth_from_triangulation(fr.T_cur_ref, fi, fc, &z);
+    }
     if (!matched) {
       seed.b += 1.0f;                                   // depth_filter.cpp:286
       st = SVO_HIP_SEED_NO_MATCH;
@@ -399,28 +486,25 @@ __global__ __launch_bounds__(256) void depth_filter_update_kernel(
       update_seed((float)(1. / z), (float)(tau_inverse * tau_inverse), &seed);
       if ((double)sqrtf(seed.sigma2) < seed.z_range / fr.conv_thresh) {
         st = SVO_HIP_SEED_CONVERGED;
-        if (xyz_world && lane == 0) {
+        if (xyz_world) {
           const double im = 1.0 / seed.mu;
           const double pfw[3] = {fi[0] * im, fi[1] * im, fi[2] * im};
           double xw[3];
           se3_act(fr.T_ref_inv, pfw, xw);
           xyz_world[3 * (size_t)i] = xw[0]; xyz_world[3 * (size_t)i + 1] = xw[1]; xyz_world[3 * (size_t)i + 2] = xw[2];
         }
-      } else if (z_inv_min != z_inv_min) {
+      } else if (rc.z_inv_min != rc.z_inv_min) {
         st = SVO_HIP_SEED_NAN;
       } else {
         st = SVO_HIP_SEED_UPDATED;
       }
     }
-  }
-
-  if (lane == 0) {
     sa[i] = seed.a; sb[i] = seed.b; smu[i] = seed.mu; ssigma2[i] = seed.sigma2;
-    status[i] = st;
-    if (z_out) z_out[i] = z;
-    if (n_zmssd_out) n_zmssd_out[i] = n_zmssd;
-    if (n_align_out) n_align_out[i] = n_align;
   }
+  status[i] = st;
+  if (z_out) z_out[i] = z;
+  if (n_zmssd_out) n_zmssd_out[i] = rc.n_zmssd;
+  if (n_align_out) n_align_out[i] = rc.n_align;
 }
 
 int grid_for(int n, int block) {
@@ -561,9 +645,24 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
   fr.align_max_iter = prm->align_max_iter;
   fr.max_epi_search_steps = prm->max_epi_search_steps;
   fr.conv_thresh = prm->seed_convergence_sigma2_thresh;
-  hipLaunchKernelGGL(depth_filter_update_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, fr,
-                     ref->base + (size_t)ref_slot * ref->pyr_bytes, cur->base + (size_t)cur_slot * cur->pyr_bytes, n, px,
-                     f, level, a, b, mu, z_range, sigma2, status, z, xyz_world, n_zmssd, n_align_iters);
+  // per-seed records between the stages: grow-only scratch owned by the context
+  const size_t need = (size_t)n * sizeof(SeedRec);
+  if (ctx->scratch_bytes < need) {
+    if (ctx->scratch) { SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    void* p = nullptr;
+    int rc = svo_hip_malloc(ctx, &p, need + need / 4);
+    if (rc != SVO_HIP_OK) return rc;
+    ctx->scratch = p; ctx->scratch_bytes = need + need / 4;
+  }
+  SeedRec* recs = (SeedRec*)ctx->scratch;
+  const uint8_t* ref_img = ref->base + (size_t)ref_slot * ref->pyr_bytes;
+  const uint8_t* cur_img = cur->base + (size_t)cur_slot * cur->pyr_bytes;
+  hipLaunchKernelGGL(df_geometry_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, px, f, level, mu, sigma2, recs);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(df_search_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, fr, ref_img, cur_img, n, level, recs);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(df_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, f, recs, a, b, mu, z_range,
+                     sigma2, status, z, xyz_world, n_zmssd, n_align_iters);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
 }

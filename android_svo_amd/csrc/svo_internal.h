@@ -13,6 +13,8 @@ struct svo_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  void* scratch = nullptr;          // grow-only device workspace (depth-filter stage records)
+  size_t scratch_bytes = 0;
   char err[512] = {0};
 };
 
