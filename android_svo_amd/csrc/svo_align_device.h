@@ -94,4 +94,69 @@ SVO_DEV bool align2d_wave(const uint8_t* __restrict__ cur_img, int cols, int row
   return converged;
 }
 
+// feature_alignment::align1D (S/feature_alignment.cpp:35-152) as a wave64 routine: the patch may
+// only move along `dir`; 2 parameters (step along dir, mean offset), min_update^2 = 0.03^2,
+// chi2-increase rollback (:117-125, which subtracts update[0] from u and update[1] from v as the
+// reference does), h_inv = 1/H(0,0) * 64 (:63).
+template <typename PatchPtr>
+SVO_DEV bool align1d_wave(const uint8_t* __restrict__ cur_img, int cols, int rows, int cur_step, float dir0,
+                          float dir1, PatchPtr pwb, int n_iter, double* px_u, double* px_v, double* h_inv,
+                          int* iters) {
+  const int lane = threadIdx.x & 63;
+  const int py = lane >> 3, pxx = lane & 7;
+  const int c = (py + 1) * 10 + (pxx + 1);
+  const float ref_px = (float)pwb[c];
+  const float j0 = (float)(0.5 * (dir0 * ((int)pwb[c + 1] - (int)pwb[c - 1]) + dir1 * ((int)pwb[c + 10] - (int)pwb[c - 10])));
+  const float H00 = group_sum<64>(j0 * j0);
+  const float H01 = group_sum<64>(j0);
+  const float H11 = 64.0f;
+  *h_inv = 1.0 / H00 * 8 * 8;
+  const float det = H00 * H11 - H01 * H01;
+  const float invdet = 1.0f / det;
+  const float Hi00 = H11 * invdet, Hi01 = -H01 * invdet, Hi10 = -H01 * invdet, Hi11 = H00 * invdet;
+  float mean_diff = 0;
+  float u = (float)*px_u;
+  float v = (float)*px_v;
+  const float min_update_squared = (float)(0.03 * 0.03);
+  float chi2 = 0;
+  float up0 = 0, up1 = 0;
+  bool converged = false;
+  int it_count = 0;
+  for (int iter = 0; iter < n_iter; ++iter) {
+    const int u_r = (int)floorf(u);
+    const int v_r = (int)floorf(v);
+    if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) break;
+    if (u != u || v != v) break;
+    ++it_count;
+    const float subpix_x = u - u_r;
+    const float subpix_y = v - v_r;
+    const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
+    const float wTR = (float)(subpix_x * (1.0 - subpix_y));
+    const float wBL = (float)((1.0 - subpix_x) * subpix_y);
+    const float wBR = subpix_x * subpix_y;
+    const uint8_t* it = cur_img + (v_r + py - 4) * cur_step + (u_r - 4) + pxx;
+    const float search_pixel = wTL * it[0] + wTR * it[1] + wBL * it[cur_step] + wBR * it[cur_step + 1];
+    const float res = search_pixel - ref_px + mean_diff;
+    const float J0 = -group_sum<64>(res * j0);
+    const float J1 = -group_sum<64>(res);
+    const float new_chi2 = group_sum<64>(res * res);
+    if (iter > 0 && new_chi2 > chi2) {
+      u -= up0;
+      v -= up1;
+      break;
+    }
+    chi2 = new_chi2;
+    up0 = Hi00 * J0 + Hi01 * J1;
+    up1 = Hi10 * J0 + Hi11 * J1;
+    u += up0 * dir0;
+    v += up0 * dir1;
+    mean_diff += up1;
+    if (up0 * up0 + up1 * up1 < min_update_squared) { converged = true; break; }
+  }
+  *px_u = (double)u;
+  *px_v = (double)v;
+  *iters = it_count;
+  return converged;
+}
+
 }  // namespace svo_dev

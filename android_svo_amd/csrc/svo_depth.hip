@@ -46,6 +46,26 @@ __global__ __launch_bounds__(256) void align2d_kernel(const uint8_t* __restrict_
   }
 }
 
+// ---- align1D over n patches (edgelets / Matcher::Options::align_1d; ★-secondary) ------
+__global__ __launch_bounds__(256) void align1d_kernel(const uint8_t* __restrict__ img, int cols, int rows, int n,
+                                                      const uint8_t* __restrict__ pwb, const float* __restrict__ dir,
+                                                      int n_iter, double* __restrict__ px, uint8_t* __restrict__ converged,
+                                                      double* __restrict__ h_inv, int32_t* __restrict__ iters) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n) return;
+  double u = px[2 * (size_t)w], v = px[2 * (size_t)w + 1], hi = 0.0;
+  int it = 0;
+  const bool ok = align1d_wave(img, cols, rows, cols, dir[2 * (size_t)w], dir[2 * (size_t)w + 1], pwb + (size_t)w * 100,
+                               n_iter, &u, &v, &hi, &it);
+  if ((threadIdx.x & 63) == 0) {
+    px[2 * (size_t)w] = u;
+    px[2 * (size_t)w + 1] = v;
+    converged[w] = ok ? 1 : 0;
+    if (h_inv) h_inv[w] = hi;
+    if (iters) iters[w] = it;
+  }
+}
+
 // ---- DepthFilter::updateSeed (S/depth_filter.cpp:359-391) -------------------------------------
 struct SeedState { float a, b, mu, z_range, sigma2; };
 
@@ -530,6 +550,21 @@ int svo_hip_align2d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int 
   const uint8_t* img = cur->base + (size_t)slot * cur->pyr_bytes + cur->level_offset[level];
   hipLaunchKernelGGL(align2d_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, img, cur->width >> level,
                      cur->height >> level, n, pwb_dev, n_iter, px_dev, converged_dev, iters_dev);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+int svo_hip_align1d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int slot, int level, int n,
+                              const uint8_t* pwb_dev, const float* dir_dev, int n_iter, double* px_dev,
+                              uint8_t* converged_dev, double* h_inv_dev, int32_t* iters_dev) {
+  if (!ctx || !cur) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, slot >= 0 && slot < cur->batch && level >= 0 && level < cur->n_levels);
+  SVO_REQUIRE(ctx, n >= 0 && n_iter >= 0);
+  if (n == 0) return SVO_HIP_OK;
+  SVO_REQUIRE(ctx, pwb_dev && dir_dev && px_dev && converged_dev);
+  const uint8_t* img = cur->base + (size_t)slot * cur->pyr_bytes + cur->level_offset[level];
+  hipLaunchKernelGGL(align1d_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, img, cur->width >> level,
+                     cur->height >> level, n, pwb_dev, dir_dev, n_iter, px_dev, converged_dev, h_inv_dev, iters_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
 }

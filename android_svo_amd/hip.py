@@ -300,6 +300,23 @@ def align2d_batch(ctx: Context, cur: Pyramid, slot: int, level: int, pwb: np.nda
     return conv.astype(bool), p, iters
 
 
+def align1d_batch(ctx: Context, cur: Pyramid, slot: int, level: int, pwb: np.ndarray, dirs: np.ndarray, n_iter: int,
+                  px: np.ndarray):
+    """feature_alignment::align1D over n patches; returns (converged, px, h_inv, iters)."""
+    n = len(px)
+    d_pwb = ctx.to_device(np.ascontiguousarray(pwb, dtype=np.uint8).reshape(n, 100))
+    d_dir = ctx.to_device(np.ascontiguousarray(dirs, dtype=np.float32).reshape(n, 2))
+    d_px = ctx.to_device(_f64(px))
+    d_conv, d_h, d_it = ctx.empty((n,), np.uint8), ctx.empty((n,), np.float64), ctx.empty((n,), np.int32)
+    ctx.check(ctx.lib.svo_hip_align1d_batch_dev(ctx.h, cur.h, slot, level, n, C.c_void_p(d_pwb.ptr), C.c_void_p(d_dir.ptr),
+                                                n_iter, C.c_void_p(d_px.ptr), C.c_void_p(d_conv.ptr), C.c_void_p(d_h.ptr),
+                                                C.c_void_p(d_it.ptr)), "align1d_batch")
+    out = d_conv.download().astype(bool), d_px.download(), d_h.download(), d_it.download()
+    for d in (d_pwb, d_dir, d_px, d_conv, d_h, d_it):
+        d.free()
+    return out
+
+
 def update_seed_batch(ctx: Context, x, tau2, a, b, mu, z_range, sigma2):
     """static DepthFilter::updateSeed over SoA float32 arrays; returns the new (a, b, mu, sigma2)."""
     n = len(x)

@@ -187,6 +187,7 @@ class FramePair:
     T_ref_w: np.ndarray     # [7]
     T_cur_w_true: np.ndarray
     T_cur_w_init: np.ndarray
+    dist: object = None     # optional radtan coefficients (k1,k2,p1,p2,k3) of the forward model
 
 
 def grid_features(cam: Camera, n_target: int, rng, border: int = 48) -> np.ndarray:

@@ -176,6 +176,12 @@ int svo_hip_align2d_batch(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int slot
                           const uint8_t* ref_patch_with_border, const uint8_t* ref_patch, int n_iter,
                           double* px, uint8_t* converged, int32_t* iters);
 
+/* feature_alignment::align1D (I/feature_alignment.h:30-38, feature_alignment.cpp:35-152): n patches that may only
+ * move along dir[n][2] (f32, e.g. the epipolar direction); h_inv[n] f64 out (may be NULL).  Device pointers. */
+int svo_hip_align1d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int slot, int level, int n,
+                              const uint8_t* ref_patch_with_border_dev, const float* dir_dev, int n_iter,
+                              double* px_dev, uint8_t* converged_dev, double* h_inv_dev, int32_t* iters_dev);
+
 /* ---- DepthFilter (I/depth_filter.h:36-166, depth_filter.cpp:237-416; matcher.cpp:207-355) -- */
 /* static DepthFilter::updateSeed over n seeds (depth_filter.cpp:368-391): SoA device arrays */
 int svo_hip_update_seed_batch_dev(svo_hip_ctx* ctx, int n, const float* x_dev, const float* tau2_dev,

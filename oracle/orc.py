@@ -96,7 +96,7 @@ def f64(a):
 def sparse_img_align(fp, max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=True,
                      T_cur_w_init=None) -> SiaResult:
     L = lib()
-    cam = camera(fp.cam)
+    cam = camera(fp.cam, getattr(fp, "dist", None))
     prm = SiaParams(max_level, min_level, n_iter, eps, 1 if early_stop else 0)
     out = SiaResult()
     rp, cp = pyr_ptrs(fp.ref_pyr), pyr_ptrs(fp.cur_pyr)
