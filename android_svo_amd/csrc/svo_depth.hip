@@ -189,6 +189,7 @@ struct DfFrame {
   size_t ref_level_off[SVO_HIP_MAX_LEVELS];
   size_t cur_level_off[SVO_HIP_MAX_LEVELS];
   int n_pyr_levels, align_max_iter, max_epi_search_steps;
+  int keep_px_on_failure;    // findMatchDirect writes px_scaled back even when align fails (matcher.cpp:200)
   double conv_thresh;
 };
 
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
 
 // One wave per seed; 4 seeds per 256-thread block.
 __global__ __launch_bounds__(256) void df_search_kernel(
-    DfFrame fr, const uint8_t* __restrict__ ref_pyr, const uint8_t* __restrict__ cur_pyr, int n,
+    DfFrame fr, const uint8_t* __restrict__ ref_base, size_t ref_pyr_bytes, const uint8_t* __restrict__ cur_pyr, int n,
     const int32_t* __restrict__ level, SeedRec* __restrict__ recs) {
   __shared__ __attribute__((aligned(16))) uint8_t s_pwb[4][112];
   __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][16];
@@ -337,7 +338,8 @@ __global__ __launch_bounds__(256) void df_search_kernel(
   if (i >= n) return;                      // wave-uniform; no block-level barrier is used below
   SeedRec* rp = recs + i;
   const int path = rp->path;
-  if (path != 0 && path != 1) return;      // not live, or the search is skipped
+  if (path != 0 && path != 1 && path != 3) return;      // not live, or the search is skipped
+  const uint8_t* ref_pyr = ref_base + (size_t)rp->pad * ref_pyr_bytes;   // pad = reference keyframe slot
   const Cam cam = fr.cam;
   uint8_t* pwb = s_pwb[wib];
   uint32_t* patch_words = s_patch[wib];
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256) void df_search_kernel(
   const int ccols = cam.width >> search_level, crows = cam.height >> search_level;
   const uint8_t* cur_img = cur_pyr + fr.cur_level_off[search_level];
   double px_cur[2] = {rp->uv0[0], rp->uv0[1]};     // path 0: midpoint of the projected segment
-  bool do_align = path == 0;
+  bool do_align = path == 0 || path == 3;
 
   if (path == 1) {
     const double step[2] = {rp->step[0], rp->step[1]};
@@ -462,8 +464,15 @@ __global__ __launch_bounds__(256) void df_search_kernel(
   bool res = false;
   if (do_align) {
     double us = px_cur[0] / (1 << search_level), vs = px_cur[1] / (1 << search_level);
-    res = align2d_wave(cur_img, ccols, crows, ccols, pwb, fr.align_max_iter, &us, &vs, &n_align);
-    if (res) {
+    if (path == 3) {
+      // EDGELET reference feature: 1-D alignment along the warped gradient direction (matcher.cpp:183-191)
+      double h_inv;
+      res = align1d_wave(cur_img, ccols, crows, ccols, (float)rp->step[0], (float)rp->step[1], pwb, fr.align_max_iter,
+                         &us, &vs, &h_inv, &n_align);
+    } else {
+      res = align2d_wave(cur_img, ccols, crows, ccols, pwb, fr.align_max_iter, &us, &vs, &n_align);
+    }
+    if (res || fr.keep_px_on_failure) {
       px_cur[0] = us * (1 << search_level);
       px_cur[1] = vs * (1 << search_level);
     }
@@ -525,6 +534,84 @@ __global__ __launch_bounds__(256) void df_finalize_kernel(
   if (z_out) z_out[i] = z;
   if (n_zmssd_out) n_zmssd_out[i] = rc.n_zmssd;
   if (n_align_out) n_align_out[i] = rc.n_align;
+}
+
+// ---- Matcher::findMatchDirect over n (map point, reference feature) pairs (S/matcher.cpp:156-202) ----
+struct MdFrame {
+  Cam cam;
+  double T_cur_w[7];
+  int n_pyr_levels;
+};
+
+// thread per item: frame test, depth, affine warp, search level -> SeedRec (path 0 = align2D, 3 = align1D)
+__global__ __launch_bounds__(256) void md_geometry_kernel(
+    MdFrame fr, int n, const double* __restrict__ T_ref_w /*[n_kf][7]*/, const int32_t* __restrict__ kf_slot,
+    const double* __restrict__ px_ref, const double* __restrict__ f_ref, const int32_t* __restrict__ level,
+    const double* __restrict__ pt_pos, const uint8_t* __restrict__ edgelet, const double* __restrict__ grad,
+    const double* __restrict__ px_cur, SeedRec* __restrict__ recs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Cam cam = fr.cam;
+  SeedRec rc;
+  rc.uv0[0] = px_cur[2 * (size_t)i]; rc.uv0[1] = px_cur[2 * (size_t)i + 1];
+  rc.step[0] = rc.step[1] = 0.0;
+  rc.a00 = rc.a01 = rc.a10 = rc.a11 = rc.prx = rc.pry = 0.0f; rc.z_inv_min = 0.0f;
+  rc.n_steps = 0; rc.search_level = 0; rc.path = -1; rc.status = 0; rc.warp_nan = 0;
+  rc.matched = 0; rc.n_zmssd = 0; rc.n_align = 0;
+  const int slot = kf_slot[i];
+  rc.pad = slot;
+  const int level_ref = level[i];
+  const double pr[2] = {px_ref[2 * (size_t)i], px_ref[2 * (size_t)i + 1]};
+  const double fi[3] = {f_ref[3 * (size_t)i], f_ref[3 * (size_t)i + 1], f_ref[3 * (size_t)i + 2]};
+  // isInFrame(px.cast<int>()/(1<<level), halfpatch_size_+2, level) (:164-166)
+  const int ox = (int)pr[0] / (1 << level_ref), oy = (int)pr[1] / (1 << level_ref);
+  if (is_in_frame_level(cam, ox, oy, 6, level_ref)) {
+    const double* Tr = T_ref_w + 7 * (size_t)slot;
+    double T_ref_inv[7], T_cur_ref[7];
+    se3_inverse(Tr, T_ref_inv);
+    se3_mul(fr.T_cur_w, T_ref_inv, T_cur_ref);
+    const double dx = T_ref_inv[0] - pt_pos[3 * (size_t)i], dy = T_ref_inv[1] - pt_pos[3 * (size_t)i + 1],
+                 dz = T_ref_inv[2] - pt_pos[3 * (size_t)i + 2];
+    const double depth = sqrt(dx * dx + dy * dy + dz * dz);
+    double Acr[4];
+    get_warp_matrix_affine(cam, pr, fi, depth, T_cur_ref, level_ref, Acr);
+    int search_level = 0;
+    {
+      double D = Acr[0] * Acr[3] - Acr[2] * Acr[1];
+      while (D > 3.0 && search_level < fr.n_pyr_levels - 1) { search_level += 1; D *= 0.25; }
+    }
+    rc.search_level = search_level;
+    const double det = Acr[0] * Acr[3] - Acr[2] * Acr[1];
+    const double invdet = 1.0 / det;
+    rc.a00 = (float)(Acr[3] * invdet); rc.a01 = (float)(-Acr[1] * invdet);
+    rc.a10 = (float)(-Acr[2] * invdet); rc.a11 = (float)(Acr[0] * invdet);
+    rc.warp_nan = rc.a00 != rc.a00;
+    rc.prx = (float)pr[0] / (1 << level_ref);
+    rc.pry = (float)pr[1] / (1 << level_ref);
+    rc.path = 0;
+    if (edgelet && edgelet[i]) {
+      double d0 = Acr[0] * grad[2 * (size_t)i] + Acr[1] * grad[2 * (size_t)i + 1];
+      double d1 = Acr[2] * grad[2 * (size_t)i] + Acr[3] * grad[2 * (size_t)i + 1];
+      const double n2 = d0 * d0 + d1 * d1;
+      if (n2 > 0.0) { const double nn = sqrt(n2); d0 = d0 / nn; d1 = d1 / nn; }
+      rc.step[0] = (double)(float)d0; rc.step[1] = (double)(float)d1;
+      rc.path = 3;
+    }
+  }
+  recs[i] = rc;
+}
+
+__global__ void md_finalize_kernel(int n, const SeedRec* __restrict__ recs, double* __restrict__ px_cur,
+                                   uint8_t* __restrict__ success, int32_t* __restrict__ search_level) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const SeedRec& rc = recs[i];
+  if (rc.path >= 0) {            // the frame test passed: px_cur is always rewritten (matcher.cpp:200)
+    px_cur[2 * (size_t)i] = rc.step[0];
+    px_cur[2 * (size_t)i + 1] = rc.step[1];
+  }
+  success[i] = rc.path >= 0 && rc.matched;
+  if (search_level) search_level[i] = rc.search_level;
 }
 
 int grid_for(int n, int block) {
@@ -694,10 +781,57 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
   const uint8_t* cur_img = cur->base + (size_t)cur_slot * cur->pyr_bytes;
   hipLaunchKernelGGL(df_geometry_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, px, f, level, mu, sigma2, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(df_search_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, fr, ref_img, cur_img, n, level, recs);
+  hipLaunchKernelGGL(df_search_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, fr, ref_img, (size_t)0, cur_img, n, level, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(df_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, f, recs, a, b, mu, z_range,
                      sigma2, status, z, xyz_world, n_zmssd, n_align_iters);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, int cur_slot,
+                                   const svo_hip_camera* cam, int n_kf, const double* T_ref_w_dev,
+                                   const double T_cur_w[7], int n, const int32_t* kf_slot_dev, const double* px_ref_dev,
+                                   const double* f_ref_dev, const int32_t* level_ref_dev, const double* pt_pos_dev,
+                                   const uint8_t* edgelet_dev, const double* grad_dev, int n_pyr_levels,
+                                   int align_max_iter, double* px_cur_dev, uint8_t* success_dev,
+                                   int32_t* search_level_dev) {
+  if (!ctx || !ref || !cur || !cam || !T_cur_w) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, cur_slot >= 0 && cur_slot < cur->batch && n_kf >= 1 && n_kf <= ref->batch);
+  SVO_REQUIRE(ctx, ref->width == cam->width && ref->height == cam->height && cur->width == cam->width && cur->height == cam->height);
+  SVO_REQUIRE(ctx, n_pyr_levels >= 1 && n_pyr_levels <= ref->n_levels && n_pyr_levels <= cur->n_levels && align_max_iter >= 0);
+  SVO_REQUIRE(ctx, cam->distortion == 0);
+  SVO_REQUIRE(ctx, n >= 0);
+  if (n == 0) return SVO_HIP_OK;
+  SVO_REQUIRE(ctx, T_ref_w_dev && kf_slot_dev && px_ref_dev && f_ref_dev && level_ref_dev && pt_pos_dev && px_cur_dev && success_dev);
+  SVO_REQUIRE(ctx, !edgelet_dev || grad_dev);
+  const size_t need = (size_t)n * sizeof(SeedRec);
+  if (ctx->scratch_bytes < need) {
+    if (ctx->scratch) { SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    void* p = nullptr;
+    int rc = svo_hip_malloc(ctx, &p, need + need / 4);
+    if (rc != SVO_HIP_OK) return rc;
+    ctx->scratch = p; ctx->scratch_bytes = need + need / 4;
+  }
+  SeedRec* recs = (SeedRec*)ctx->scratch;
+  MdFrame mf;
+  mf.cam = svo_make_cam(*cam);
+  memcpy(mf.T_cur_w, T_cur_w, sizeof(double) * 7);
+  mf.n_pyr_levels = n_pyr_levels;
+  DfFrame fr;
+  memset(&fr, 0, sizeof(fr));
+  fr.cam = mf.cam;
+  for (int l = 0; l < ref->n_levels; ++l) fr.ref_level_off[l] = ref->level_offset[l];
+  for (int l = 0; l < cur->n_levels; ++l) fr.cur_level_off[l] = cur->level_offset[l];
+  fr.n_pyr_levels = n_pyr_levels; fr.align_max_iter = align_max_iter; fr.keep_px_on_failure = 1;
+  hipLaunchKernelGGL(md_geometry_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, mf, n, T_ref_w_dev, kf_slot_dev,
+                     px_ref_dev, f_ref_dev, level_ref_dev, pt_pos_dev, edgelet_dev, grad_dev, px_cur_dev, recs);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(df_search_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, fr, ref->base, ref->pyr_bytes,
+                     cur->base + (size_t)cur_slot * cur->pyr_bytes, n, level_ref_dev, recs);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(md_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, recs, px_cur_dev, success_dev,
+                     search_level_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
 }

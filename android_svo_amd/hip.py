@@ -317,6 +317,30 @@ def align1d_batch(ctx: Context, cur: Pyramid, slot: int, level: int, pwb: np.nda
     return out
 
 
+def match_direct_batch(ctx: Context, ref: Pyramid, cur: Pyramid, cur_slot: int, cam, T_ref_w, T_cur_w, kf_slot, px_ref,
+                       f_ref, level_ref, pt_pos, px_cur, edgelet=None, grad=None, n_pyr_levels=3, align_max_iter=10):
+    """Matcher::findMatchDirect over n items; returns (success, px_cur, search_level)."""
+    n = len(px_cur)
+    T_ref_w = _f64(T_ref_w).reshape(-1, 7)
+    d = [ctx.to_device(T_ref_w), ctx.to_device(np.ascontiguousarray(kf_slot, dtype=np.int32)), ctx.to_device(_f64(px_ref)),
+         ctx.to_device(_f64(f_ref)), ctx.to_device(np.ascontiguousarray(level_ref, dtype=np.int32)),
+         ctx.to_device(_f64(pt_pos)), ctx.to_device(_f64(px_cur))]
+    d_e = ctx.to_device(np.ascontiguousarray(edgelet, dtype=np.uint8)) if edgelet is not None else None
+    d_g = ctx.to_device(_f64(grad)) if grad is not None else None
+    d_ok, d_sl = ctx.empty((n,), np.uint8), ctx.empty((n,), np.int32)
+    c = make_camera(cam)
+    Tc = _f64(T_cur_w)
+    ctx.check(ctx.lib.svo_hip_match_direct_batch_dev(
+        ctx.h, ref.h, cur.h, cur_slot, C.byref(c), len(T_ref_w), C.c_void_p(d[0].ptr), _ptr(Tc, C.c_double), n,
+        C.c_void_p(d[1].ptr), C.c_void_p(d[2].ptr), C.c_void_p(d[3].ptr), C.c_void_p(d[4].ptr), C.c_void_p(d[5].ptr),
+        C.c_void_p(d_e.ptr if d_e else None), C.c_void_p(d_g.ptr if d_g else None), n_pyr_levels, align_max_iter,
+        C.c_void_p(d[6].ptr), C.c_void_p(d_ok.ptr), C.c_void_p(d_sl.ptr)), "match_direct_batch")
+    out = d_ok.download().astype(bool), d[6].download(), d_sl.download()
+    for x in d + [d_ok, d_sl] + [v for v in (d_e, d_g) if v is not None]:
+        x.free()
+    return out
+
+
 def update_seed_batch(ctx: Context, x, tau2, a, b, mu, z_range, sigma2):
     """static DepthFilter::updateSeed over SoA float32 arrays; returns the new (a, b, mu, sigma2)."""
     n = len(x)

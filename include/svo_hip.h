@@ -182,6 +182,22 @@ int svo_hip_align1d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int 
                               const uint8_t* ref_patch_with_border_dev, const float* dir_dev, int n_iter,
                               double* px_dev, uint8_t* converged_dev, double* h_inv_dev, int32_t* iters_dev);
 
+/* ---- Matcher::findMatchDirect over a batch (I/matcher.h:108-111, matcher.cpp:156-202) ----------
+ * n (map point, reference feature) pairs against frame cur->cur_slot: frame test of the reference feature,
+ * depth = |ref_pos - pt_pos|, warp::getWarpMatrixAffine, getBestSearchLevel, warpAffine, then align2D
+ * (align1D along A*grad for EDGELET reference features).  Point::getCloseViewObs and the reprojector's
+ * first-success-per-cell policy stay on the host: the caller passes the reference feature it chose.
+ * ref holds the n_kf keyframe pyramids (slot k <-> T_ref_w_dev[k][7]); per item: kf_slot, px_ref[2], f_ref[3],
+ * level_ref, pt_pos[3], optional edgelet flag + grad[2]; px_cur[n][2] in (estimate) / out, success[n] u8,
+ * search_level[n] (may be NULL).  Device pointers except T_cur_w. */
+int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur,
+                                   int cur_slot, const svo_hip_camera* cam, int n_kf, const double* T_ref_w_dev,
+                                   const double T_cur_w[7], int n, const int32_t* kf_slot_dev,
+                                   const double* px_ref_dev, const double* f_ref_dev, const int32_t* level_ref_dev,
+                                   const double* pt_pos_dev, const uint8_t* edgelet_dev, const double* grad_dev,
+                                   int n_pyr_levels, int align_max_iter, double* px_cur_dev, uint8_t* success_dev,
+                                   int32_t* search_level_dev);
+
 /* ---- DepthFilter (I/depth_filter.h:36-166, depth_filter.cpp:237-416; matcher.cpp:207-355) -- */
 /* static DepthFilter::updateSeed over n seeds (depth_filter.cpp:368-391): SoA device arrays */
 int svo_hip_update_seed_batch_dev(svo_hip_ctx* ctx, int n, const float* x_dev, const float* tau2_dev,

@@ -215,3 +215,17 @@ def update_seeds(cam, ref_pyr, cur_pyr, T_ref_w, T_cur_w, px, f, level, a, b, mu
         C.c_int(n_pyr_levels), C.c_int(align_max_iter), C.c_int(max_steps), C.c_double(conv_thresh),
         _p(status, C.c_int), _p(z, C.c_double), _p(xyz, C.c_double), _p(nz, C.c_int), _p(na, C.c_int))
     return {"status": status, "z": z, "xyz_world": xyz, "n_zmssd": nz, "n_align_iters": na}
+
+
+def find_match_direct(cam, ref_pyr, cur_pyr, T_ref_w, T_cur_w, px_ref, f_ref, level_ref, pt_pos, px_cur, edgelet=False,
+                      grad=(1.0, 0.0), n_pyr_levels=3, align_max_iter=10):
+    c = camera(cam)
+    Tr, Tc = f64(T_ref_w), f64(T_cur_w)
+    pr, fr, pp, g = f64(px_ref), f64(f_ref), f64(pt_pos), f64(grad)
+    pc = f64(px_cur).copy()
+    sl = C.c_int(0)
+    ok = lib().svo_orc_find_match_direct(C.byref(c), pyr_ptrs(ref_pyr), pyr_ptrs(cur_pyr), _p(Tr, C.c_double),
+                                         _p(Tc, C.c_double), _p(pr, C.c_double), _p(fr, C.c_double), C.c_int(level_ref),
+                                         _p(pp, C.c_double), C.c_int(1 if edgelet else 0), _p(g, C.c_double),
+                                         C.c_int(n_pyr_levels), C.c_int(align_max_iter), _p(pc, C.c_double), C.byref(sl))
+    return bool(ok), pc, sl.value

@@ -1008,6 +1008,50 @@ int svo_orc_find_epipolar_match_direct(
   return 0;
 }
 
+/* S/matcher.cpp:156-202 without Point::getCloseViewObs (host bookkeeping: the caller passes the
+ * reference feature it selected).  Returns the success flag; px_cur in/out (level-0 pixels). */
+int svo_orc_find_match_direct(const svo_orc_camera* cam, const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr,
+                              const double T_ref_w[7], const double T_cur_w[7], const double px_ref[2],
+                              const double f_ref[3], int level_ref, const double pt_pos[3], int edgelet,
+                              const double grad[2], int n_pyr_levels, int align_max_iter, double px_cur[2],
+                              int* search_level_out) {
+  /* isInFrame(px.cast<int>()/(1<<level), halfpatch_size_+2, level) (:164-166) */
+  const int ox = (int)px_ref[0] / (1 << level_ref), oy = (int)px_ref[1] / (1 << level_ref);
+  if (!is_in_frame_level(cam, ox, oy, 4 + 2, level_ref)) return 0;
+  double T_ref_inv[7], T_cur_ref[7];
+  svo_orc_se3_inverse(T_ref_w, T_ref_inv);
+  svo_orc_se3_mul(T_cur_w, T_ref_inv, T_cur_ref);
+  const double dx = T_ref_inv[0] - pt_pos[0], dy = T_ref_inv[1] - pt_pos[1], dz = T_ref_inv[2] - pt_pos[2];
+  const double depth = sqrt(dx * dx + dy * dy + dz * dz);          /* (ref_frame.pos() - pt.pos_).norm() */
+  double A[4];
+  svo_orc_get_warp_matrix_affine(cam, cam, px_ref, f_ref, depth, T_cur_ref, level_ref, A);
+  const int search_level = svo_orc_get_best_search_level(A, n_pyr_levels - 1);
+  if (search_level_out) *search_level_out = search_level;
+  uint8_t pwb[100], patch[64];
+  memset(pwb, 0, sizeof(pwb));
+  svo_orc_warp_affine(A, ref_pyr[level_ref], cam->width >> level_ref, cam->height >> level_ref, px_ref, level_ref,
+                      search_level, 5, pwb);
+  svo_orc_patch_from_border(pwb, patch);
+  double px_scaled[2] = {px_cur[0] / (1 << search_level), px_cur[1] / (1 << search_level)};
+  const int ccols = cam->width >> search_level, crows = cam->height >> search_level;
+  int success;
+  if (edgelet) {
+    /* dir_cur = (A_cur_ref * grad).normalized(), cast to float (:187-191) */
+    double d0 = A[0] * grad[0] + A[1] * grad[1], d1 = A[2] * grad[0] + A[3] * grad[1];
+    const double n2 = d0 * d0 + d1 * d1;
+    if (n2 > 0.0) { const double nn = sqrt(n2); d0 = d0 / nn; d1 = d1 / nn; }
+    const float dir[2] = {(float)d0, (float)d1};
+    double h_inv;
+    success = svo_orc_align1d(cur_pyr[search_level], ccols, crows, ccols, dir, pwb, patch, align_max_iter, px_scaled,
+                              &h_inv, NULL);
+  } else {
+    success = svo_orc_align2d(cur_pyr[search_level], ccols, crows, ccols, pwb, patch, align_max_iter, px_scaled, NULL);
+  }
+  px_cur[0] = px_scaled[0] * (1 << search_level);
+  px_cur[1] = px_scaled[1] * (1 << search_level);
+  return success;
+}
+
 /* ------------------------------------------------------------------------ */
 /* depth filter                                                              */
 /* ------------------------------------------------------------------------ */

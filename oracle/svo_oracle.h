@@ -176,6 +176,14 @@ int svo_orc_find_epipolar_match_direct(
     double d_estimate, double d_min, double d_max, int n_pyr_levels, int align_max_iter,
     int max_epi_search_steps, svo_orc_epi_result* out);
 
+/* Matcher::findMatchDirect, matcher.cpp:156-202, for a reference feature already chosen by the caller
+ * (Point::getCloseViewObs is host bookkeeping).  px_cur in/out in level-0 pixels. */
+int svo_orc_find_match_direct(const svo_orc_camera* cam, const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr,
+                              const double T_ref_w[7], const double T_cur_w[7], const double px_ref[2],
+                              const double f_ref[3], int level_ref, const double pt_pos[3], int edgelet,
+                              const double grad[2], int n_pyr_levels, int align_max_iter, double px_cur[2],
+                              int* search_level_out);
+
 /* ---- depth filter (depth_filter.cpp:36-45, 237-341, 359-416) ------------ */
 typedef struct { float a, b, mu, z_range, sigma2; } svo_orc_seed;
 void svo_orc_seed_init(svo_orc_seed* s, float depth_mean, float depth_min);

@@ -489,3 +489,63 @@ def test_c2_align_batch_properties(ctx):
     assert conv2.mean() > 0.995 and (it2 <= 2).mean() > 0.99
     assert np.median(np.linalg.norm(px2[conv2] - px[conv][conv2], axis=1)) < 0.1
     pyr.destroy()
+
+
+def test_match_direct_batch(ctx):
+    """Matcher::findMatchDirect batched (next row f-2): map points seen in 3 keyframes, matched into a new frame."""
+    rng = np.random.default_rng(17)
+    cam = synth.Camera.default()
+    scene = synth.PlaneScene(seed=33, depth=2.0, tilt=(0.1, -0.07))
+    kf_poses = [synth.se3_from_twist(rng.uniform(-0.1, 0.1, 3) + [0, 0, 0.3 * k], rng.uniform(-0.03, 0.03, 3)) for k in range(3)]
+    T_cur_w = synth.se3_from_twist(rng.uniform(-0.05, 0.05, 3) + [0, 0, 0.8], rng.uniform(-0.02, 0.02, 3))
+    kf_pyr = [synth.build_pyramid(scene.render(cam, T)) for T in kf_poses]
+    cur_pyr = synth.build_pyramid(scene.render(cam, T_cur_w))
+    ref = hip.Pyramid(ctx, cam.width, cam.height, 5, 3)
+    cur = hip.Pyramid(ctx, cam.width, cam.height, 5, 1)
+    for k in range(3):
+        ref.upload(k, kf_pyr[k])
+    cur.upload(0, cur_pyr)
+    n = 3000
+    slot = rng.integers(0, 3, n).astype(np.int32)
+    level = rng.choice([0, 0, 1, 2], n).astype(np.int32)
+    px_ref = np.stack([rng.uniform(2, cam.width - 2, n), rng.uniform(2, cam.height - 2, n)], axis=1)   # some fail the frame test
+    f_ref = synth.cam2world(cam, px_ref)
+    pt = np.zeros((n, 3))
+    px_cur = np.zeros((n, 2))
+    for k in range(3):
+        m = slot == k
+        pt[m] = scene.intersect(cam, kf_poses[k], px_ref[m, 0], px_ref[m, 1])
+    R = synth.rot_matrix(T_cur_w[3:])
+    Xc = pt @ R.T + T_cur_w[:3]
+    px_cur[:, 0] = cam.fx * Xc[:, 0] / Xc[:, 2] + cam.cx
+    px_cur[:, 1] = cam.fy * Xc[:, 1] / Xc[:, 2] + cam.cy
+    px_cur += rng.uniform(-1.5, 1.5, (n, 2))
+    edge = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+    grad = rng.normal(size=(n, 2))
+    grad /= np.linalg.norm(grad, axis=1, keepdims=True)
+    ok, px_out, sl = hip.match_direct_batch(ctx, ref, cur, 0, cam, np.stack(kf_poses), T_cur_w, slot, px_ref, f_ref, level, pt,
+                                            px_cur, edgelet=edge, grad=grad)
+    ok_o = np.zeros(n, dtype=bool)
+    px_o = np.zeros((n, 2))
+    sl_o = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        ok_o[i], px_o[i], sl_o[i] = orc.find_match_direct(cam, kf_pyr[slot[i]], cur_pyr, kf_poses[slot[i]], T_cur_w, px_ref[i],
+                                                         f_ref[i], int(level[i]), pt[i], px_cur[i], edgelet=bool(edge[i]),
+                                                         grad=grad[i])
+    framed = np.array([(int(p[0]) // (1 << l) >= 6) and (int(p[0]) // (1 << l) < (cam.width >> l) - 6) and
+                       (int(p[1]) // (1 << l) >= 6) and (int(p[1]) // (1 << l) < (cam.height >> l) - 6)
+                       for p, l in zip(px_ref, level)])
+    assert (~framed).sum() > 10 and not ok[~framed].any()
+    np.testing.assert_array_equal(px_out[~framed], px_cur[~framed])        # untouched when the frame test fails
+    np.testing.assert_array_equal(sl[framed], sl_o[framed])                # integer decision: exact
+    c2 = framed & (edge == 0)
+    assert (ok[c2] != ok_o[c2]).mean() < 0.01
+    both = c2 & ok & ok_o
+    assert both.sum() > 1000 and sl[both].max() >= 1
+    assert np.percentile(np.abs(px_out[both] - px_o[both]).max(axis=1), 99) < 2e-3
+    e1 = framed & (edge == 1)
+    assert (ok[e1] != ok_o[e1]).mean() < 0.05
+    both1 = e1 & ok & ok_o
+    assert both1.sum() > 50
+    assert np.percentile(np.abs(px_out[both1] - px_o[both1]).max(axis=1), 95) < 2e-2
+    ref.destroy(); cur.destroy()
