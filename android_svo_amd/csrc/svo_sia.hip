@@ -616,6 +616,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   __shared__ unsigned s_npre;
   __shared__ unsigned long long s_nres, s_nmeas;
   __shared__ int s_iters[SVO_HIP_MAX_LEVELS];
+#ifdef SVO_STAMPS
+  __shared__ long long s_stamp[4];
+  if (threadIdx.x == 64) { s_stamp[0] = s_stamp[1] = s_stamp[2] = 0; }
+#endif
 
   const int b = blockIdx.x;
   const FrameConst& c = fc[b];
@@ -763,6 +767,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     // ================= Gauss-Newton loop of this level =================
     for (int iter = 0; iter < prm.n_iter; ++iter) {
       if (s_done) break;                                     // block-uniform (read after a barrier)
+#ifdef SVO_STAMPS
+      const long long t0 = __builtin_amdgcn_s_memtime();
+#endif
       double T[7];
 #pragma unroll
       for (int i = 0; i < 7; ++i) {          // block-uniform: keep the model in scalar registers
@@ -893,7 +900,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         if (lane == 28) mine = (double)tn;
       }
       if (lane < 32) red[wave][lane] = lane < 29 ? mine : 0.0;
+#ifdef SVO_STAMPS
+      const long long t1 = __builtin_amdgcn_s_memtime();
+#endif
       __syncthreads();
+#ifdef SVO_STAMPS
+      const long long t2 = __builtin_amdgcn_s_memtime();
+#endif
       if (wave == 0) {
         if (lane < 32) {
           double v = 0.0;
@@ -951,6 +964,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         }
       }
       __syncthreads();
+#ifdef SVO_STAMPS
+      if (threadIdx.x == 64) { const long long t3 = __builtin_amdgcn_s_memtime(); s_stamp[0] += t1 - t0; s_stamp[1] += t2 - t1; s_stamp[2] += t3 - t2; }
+#endif
     }
     __syncthreads();
   }
@@ -968,6 +984,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       for (int i = 0; i < 6; ++i)
         for (int j = i; j < 6; ++j) { s.H[i * 6 + j] = s_last[kk]; s.H[j * 6 + i] = s_last[kk]; ++kk; }
       for (int i = 0; i < 6; ++i) { s.Jres[i] = s_last[21 + i]; s.x[i] = s_x[i]; }
+#ifdef SVO_STAMPS
+      s.x[0] = (double)s_stamp[0]; s.x[1] = (double)s_stamp[1]; s.x[2] = (double)s_stamp[2];
+#endif
     }
     for (int i = 0; i < SVO_HIP_MAX_LEVELS; ++i) s.iters[i] = s_iters[i];
   }
@@ -1347,6 +1366,15 @@ int svo_hip_sia_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) 
   }
   return svo_hip_sia_finish(s);
 }
+
+#ifdef SVO_STAMPS
+int svo_hip_sia_debug_x(svo_hip_sia* s, int slot, double* x6) {
+  FrameState st;
+  int rc = svo_hip_memcpy_d2h(s->ctx, &st, s->st + slot, sizeof(FrameState));
+  for (int i = 0; i < 6; ++i) x6[i] = st.x[i];
+  return rc;
+}
+#endif
 
 int svo_hip_sia_last_run_mode(svo_hip_sia* s, int* mode) {
   if (!s || !mode) return SVO_HIP_ERR_INVALID;

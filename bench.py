@@ -209,7 +209,7 @@ def main():
                 except Exception:
                     pass
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N=1 only (rank 0)
             cpu = cpu_baseline(fps, n_iter=30, early_stop=args.early_stop, frames_per_thread=args.cpu_frames_per_thread)
         out = {
             "metric": "SparseImgAlign frames/s at 640x480 L4-L0; pose err vs CPU ref",

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Diagnostic (not part of the product or of bench.py): run the fused SparseImgAlign kernel from a build with
+-DSVO_STAMPS (build/libsvo_hip_stamps.so) and print where wave 1 of each workgroup spends its cycles per
+Gauss-Newton evaluation: evaluation+wave reduction / first barrier wait / 16-wave sum + one-lane solve + barrier."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from android_svo_amd import hip, synth  # noqa: E402
+
+hip.LIB_PATH = os.path.join(ROOT, "build", "libsvo_hip_stamps.so")
+ctx = hip.Context(0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+fps = [synth.make_frame_pair(seed=12345 + i, n_features=2000) for i in range(4)]
+cam = fps[0].cam
+ref = hip.Pyramid(ctx, cam.width, cam.height, 5, B)
+cur = hip.Pyramid(ctx, cam.width, cam.height, 5, B)
+sia = hip.SparseImgAlign(ctx, B, 2000)
+sia.set_frames(ref, cur)
+for s in range(B):
+    ref.upload(s, fps[s % 4].ref_pyr); cur.upload(s, fps[s % 4].cur_pyr); sia.upload_pair(s, fps[s % 4])
+prm = sia.params(early_stop=False)
+for _ in range(2):
+    sia.run(B, prm)
+ctx.sync()
+L = ctx.lib
+import ctypes as C
+# FrameState.x lives inside the download struct? not exposed: read through a dedicated debug accessor is overkill,
+# the stamps are returned in H[...]? -> the stamped build stores them in x[0..2]; fetch via svo_hip_sia_download_x
+buf = (C.c_double * 6)()
+rows = []
+for s in range(min(B, 8)):
+    L.svo_hip_sia_debug_x(sia.h, s, buf)
+    rows.append([buf[0], buf[1], buf[2]])
+rows = np.array(rows) / 150.0
+print("cycles per evaluation (100 MHz memtime ticks x?): eval+wave-reduce, barrier wait, sum+solve+barrier")
+print(rows)
