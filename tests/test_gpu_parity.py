@@ -549,3 +549,19 @@ def test_match_direct_batch(ctx):
     assert both1.sum() > 50
     assert np.percentile(np.abs(px_out[both1] - px_o[both1]).max(axis=1), 95) < 2e-2
     ref.destroy(); cur.destroy()
+
+
+@pytest.mark.parametrize("n,expect_mode", [(900, 1), (2500, 1), (2816, 1), (3000, 0)])
+def test_feature_count_classes(ctx, n, expect_mode):
+    """The fused kernel is instantiated for 1, 2 or 3 tiles per wave (<=1024 / <=2048 / <=2816 features);
+    above that svo_hip_sia_run falls back to the streaming kernels.  Same answer everywhere."""
+    fp = synth.make_frame_pair(seed=300 + n, n_features=n, border=24)
+    ref, cur, sia = _upload_pair(ctx, [fp])
+    sia.run(1, sia.params())
+    assert sia.last_run_mode() == expect_mode
+    r = sia.download(0)
+    o = orc.sparse_img_align(fp)
+    rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
+    assert rot < 1e-4 and trans < 1e-3, (rot, trans)
+    assert r.n_tracked == o.n_tracked
+    _free(sia, ref, cur)
