@@ -1,0 +1,393 @@
+// svo_host.h -- self-contained C++ host layer over the C-ABI (include/svo_hip.h).
+//
+// The reference's public classes (svo::SparseImgAlign, svo::DepthFilter, svo::Seed, Frame/Feature/Point)
+// with the same names, methods and protocol, but on minimal own data types (no Eigen, no OpenCV), so that
+// the host side can be built and RUN wherever libsvo_hip.so runs.  The bindings that plug into the
+// reference's real headers are include/svo_dropin/ (compile-checked only); this file is
+// their executable twin and carries the same host logic:
+//   * SparseImgAlign::run       S/sparse_img_align.cpp:51-92   (flatten fts_, upload, run, read back)
+//   * DepthFilter protocol      S/depth_filter.cpp:47-229,237-357 (thread, 3-deep frame queue, keyframe
+//                               hand-off with the halt flag, std::list<Seed>, age-out, convergence callback)
+// Host threads: the tracking thread and the depth-filter thread each own a svo_hip_ctx (one stream each).
+#ifndef SVO_HOST_H_
+#define SVO_HOST_H_
+
+#include <array>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <stdexcept>
+#include <thread>
+#include <vector>
+
+#include "svo_hip.h"
+
+namespace svo {
+
+struct Vector2d { double v[2]; double& operator[](int i) { return v[i]; } const double& operator[](int i) const { return v[i]; } };
+struct Vector3d { double v[3]; double& operator[](int i) { return v[i]; } const double& operator[](int i) const { return v[i]; } };
+
+/// {t, q(xyzw)} with the reference's composition rules (I/SE3.h:35-61, I/SO3.h:468-488,523-526)
+struct SE3 {
+  double p[7];
+  SE3() : p{0, 0, 0, 0, 0, 0, 1} {}
+  explicit SE3(const double* s) { std::memcpy(p, s, sizeof(p)); }
+  static void rot(const double* q, const double* x, double* o) {
+    double uv[3] = {q[1] * x[2] - q[2] * x[1], q[2] * x[0] - q[0] * x[2], q[0] * x[1] - q[1] * x[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    const double c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+    for (int i = 0; i < 3; ++i) o[i] = (x[i] + q[3] * uv[i]) + c[i];
+  }
+  SE3 inverse() const {
+    SE3 r;
+    const double qi[4] = {-p[3], -p[4], -p[5], p[6]};
+    double t[3];
+    rot(qi, p, t);
+    r.p[0] = -t[0]; r.p[1] = -t[1]; r.p[2] = -t[2];
+    r.p[3] = qi[0]; r.p[4] = qi[1]; r.p[5] = qi[2]; r.p[6] = qi[3];
+    return r;
+  }
+  Vector3d operator*(const Vector3d& x) const {
+    double t[3];
+    rot(p + 3, x.v, t);
+    return Vector3d{{p[0] + t[0], p[1] + t[1], p[2] + t[2]}};
+  }
+};
+
+struct PinholeCamera {            // distortion-free vk::PinholeCamera
+  int width, height;
+  double fx, fy, cx, cy;
+  svo_hip_camera toC() const {
+    svo_hip_camera c;
+    c.width = width; c.height = height; c.fx = fx; c.fy = fy; c.cx = cx; c.cy = cy;
+    for (double& d : c.d) d = 0.0;
+    c.distortion = 0;
+    return c;
+  }
+};
+
+struct Point { Vector3d pos_; explicit Point(const Vector3d& p) : pos_(p) {} };
+struct Frame;
+struct Feature {
+  Frame* frame; Vector2d px; Vector3d f; int level; Point* point;
+  Feature(Frame* fr, const Vector2d& px_, const Vector3d& f_, int lvl) : frame(fr), px(px_), f(f_), level(lvl), point(nullptr) {}
+};
+
+struct Frame {
+  static int frame_counter_;
+  int id_;
+  const PinholeCamera* cam_;
+  SE3 T_f_w_;
+  std::vector<std::vector<uint8_t>> img_pyr_;      // level l: (w>>l) x (h>>l), stride == cols
+  std::list<Feature*> fts_;
+  bool is_keyframe_ = false;
+  Frame(const PinholeCamera* cam, std::vector<std::vector<uint8_t>> pyr) : id_(frame_counter_++), cam_(cam), img_pyr_(std::move(pyr)) {}
+  ~Frame() { for (Feature* f : fts_) delete f; }
+  bool isKeyframe() const { return is_keyframe_; }
+  void setKeyframe() { is_keyframe_ = true; }
+};
+inline int Frame::frame_counter_ = 0;
+typedef std::shared_ptr<Frame> FramePtr;
+
+namespace hip_bridge {
+inline void check(int rc, svo_hip_ctx* ctx, const char* what) {
+  if (rc != SVO_HIP_OK) throw std::runtime_error(std::string(what) + ": " + (ctx ? svo_hip_last_error(ctx) : "no context"));
+}
+/// device copies of frame pyramids, cached by Frame::id_
+class PyramidCache {
+ public:
+  PyramidCache(svo_hip_ctx* ctx, int capacity) : ctx_(ctx), capacity_(capacity) {}
+  ~PyramidCache() { if (pyr_) svo_hip_pyramid_destroy(pyr_); }
+  int slotOf(const Frame& f) {
+    if (!pyr_) {
+      check(svo_hip_pyramid_create(ctx_, f.cam_->width, f.cam_->height, (int)f.img_pyr_.size(), capacity_, &pyr_), ctx_, "pyramid_create");
+      ids_.assign(capacity_, -1);
+    }
+    for (int s = 0; s < capacity_; ++s) if (ids_[s] == f.id_) return s;
+    const int s = next_;
+    next_ = (next_ + 1) % capacity_;
+    const uint8_t* lv[SVO_HIP_MAX_LEVELS] = {nullptr};
+    for (size_t l = 0; l < f.img_pyr_.size(); ++l) lv[l] = f.img_pyr_[l].data();
+    check(svo_hip_pyramid_upload(pyr_, s, lv), ctx_, "pyramid_upload");
+    check(svo_hip_ctx_sync(ctx_), ctx_, "sync");
+    ids_[s] = f.id_;
+    return s;
+  }
+  svo_hip_pyramid* pyramid() const { return pyr_; }
+ private:
+  svo_hip_ctx* ctx_; svo_hip_pyramid* pyr_ = nullptr; int capacity_, next_ = 0; std::vector<int> ids_;
+};
+}  // namespace hip_bridge
+
+/// I/sparse_img_align.h:33-79
+class SparseImgAlign {
+ public:
+  enum Method { GaussNewton, LevenbergMarquardt };
+  size_t n_iter_; double eps_; bool stop_ = false; size_t n_meas_ = 0;
+  SparseImgAlign(int n_levels, int min_level, int n_iter, Method method, bool display, bool verbose)
+      : n_iter_(n_iter), eps_(0.000001), max_level_(n_levels), min_level_(min_level) {
+    (void)method; (void)display; (void)verbose;
+    hip_bridge::check(svo_hip_ctx_create(&ctx_, 0, nullptr), nullptr, "ctx_create");
+    ref_.reset(new hip_bridge::PyramidCache(ctx_, 1));
+    cur_.reset(new hip_bridge::PyramidCache(ctx_, 1));
+  }
+  ~SparseImgAlign() { if (sia_) svo_hip_sia_destroy(sia_); ref_.reset(); cur_.reset(); svo_hip_ctx_destroy(ctx_); }
+
+  size_t run(FramePtr ref_frame, FramePtr cur_frame) {
+    stop_ = false; n_meas_ = 0; chi2_ = 1e10;
+    if (ref_frame->fts_.empty()) return 0;                                   // :55-59
+    const int n = (int)ref_frame->fts_.size();
+    std::vector<double> px(2 * (size_t)n), f(3 * (size_t)n), pos(3 * (size_t)n, 0.0);
+    std::vector<uint8_t> hp((size_t)n, 0);
+    size_t i = 0;
+    for (Feature* ftr : ref_frame->fts_) {                                    // list order defines the patch order
+      px[2 * i] = ftr->px[0]; px[2 * i + 1] = ftr->px[1];
+      for (int k = 0; k < 3; ++k) f[3 * i + k] = ftr->f[k];
+      if (ftr->point) { hp[i] = 1; for (int k = 0; k < 3; ++k) pos[3 * i + k] = ftr->point->pos_[k]; }
+      ++i;
+    }
+    if (!sia_ || cap_ < n) {
+      if (sia_) svo_hip_sia_destroy(sia_);
+      cap_ = n > 2048 ? n : 2048;
+      hip_bridge::check(svo_hip_sia_create(ctx_, 1, cap_, &sia_), ctx_, "sia_create");
+    }
+    const int rs = ref_->slotOf(*ref_frame), cs = cur_->slotOf(*cur_frame);
+    (void)rs; (void)cs;
+    const svo_hip_camera cam = cur_frame->cam_->toC();
+    svo_hip_sia_params prm{max_level_, min_level_, (int)n_iter_, eps_, 1};
+    svo_hip_sia_result res;
+    hip_bridge::check(svo_hip_sia_set_frames(sia_, ref_->pyramid(), cur_->pyramid()), ctx_, "set_frames");
+    hip_bridge::check(svo_hip_sia_upload_features(sia_, 0, n, px.data(), f.data(), pos.data(), hp.data()), ctx_, "upload_features");
+    hip_bridge::check(svo_hip_sia_upload_poses(sia_, 0, &cam, ref_frame->T_f_w_.p, cur_frame->T_f_w_.p), ctx_, "upload_poses");
+    hip_bridge::check(svo_hip_sia_run(sia_, 1, &prm), ctx_, "run");
+    hip_bridge::check(svo_hip_sia_download(sia_, 0, &res), ctx_, "download");
+    cur_frame->T_f_w_ = SE3(res.T_cur_w);                                     // :89
+    std::memcpy(H_.data(), res.H, sizeof(res.H));
+    chi2_ = res.chi2; stop_ = res.stop != 0; n_meas_ = (size_t)res.n_tracked * 16;
+    return (size_t)res.n_tracked;                                             // :91
+  }
+  std::array<double, 36> getFisherInformation() const {                       // :94-99
+    std::array<double, 36> I = H_;
+    const double sigma_i_sq = 5e-4 * 255 * 255;
+    for (double& v : I) v /= sigma_i_sq;
+    return I;
+  }
+  double getChi2() const { return chi2_; }
+
+ private:
+  int max_level_, min_level_;
+  svo_hip_ctx* ctx_ = nullptr;
+  svo_hip_sia* sia_ = nullptr;
+  int cap_ = 0;
+  std::unique_ptr<hip_bridge::PyramidCache> ref_, cur_;
+  std::array<double, 36> H_{};
+  double chi2_ = 1e10;
+};
+
+/// I/depth_filter.h:36-52
+struct Seed {
+  static int batch_counter, seed_counter;
+  int batch_id, id;
+  Feature* ftr;
+  float a, b, mu, z_range, sigma2;
+  Seed(Feature* ftr_, float depth_mean, float depth_min)
+      : batch_id(batch_counter), id(seed_counter++), ftr(ftr_), a(10), b(10), mu((float)(1.0 / depth_mean)),
+        z_range((float)(1.0 / depth_min)), sigma2(z_range * z_range / 36) {}
+};
+inline int Seed::batch_counter = 0;
+inline int Seed::seed_counter = 0;
+
+/// I/depth_filter.h:60-166.  The detector is out of scope: the new keyframe's features are handed in.
+class DepthFilter {
+ public:
+  typedef std::unique_lock<std::mutex> lock_t;
+  typedef std::function<void(Point*, double)> callback_t;
+  struct Options {
+    int max_n_kfs = 3;
+    double seed_convergence_sigma2_thresh = 100.0;
+    bool verbose = false;
+  } options_;
+
+  explicit DepthFilter(callback_t seed_converged_cb) : seed_converged_cb_(std::move(seed_converged_cb)) {
+    hip_bridge::check(svo_hip_ctx_create(&ctx_, 0, nullptr), nullptr, "ctx_create");   // the filter thread's own stream
+    kf_pyr_.reset(new hip_bridge::PyramidCache(ctx_, 8));
+    cur_pyr_.reset(new hip_bridge::PyramidCache(ctx_, 2));
+  }
+  virtual ~DepthFilter() { stopThread(); kf_pyr_.reset(); cur_pyr_.reset(); svo_hip_ctx_destroy(ctx_); }
+
+  void startThread() { thread_stop_ = false; thread_ = new std::thread(&DepthFilter::updateSeedsLoop, this); }
+  void stopThread() {
+    if (thread_ != nullptr) {
+      seeds_updating_halt_ = true;
+      { lock_t lock(frame_queue_mut_); thread_stop_ = true; }
+      frame_queue_cond_.notify_one();
+      if (thread_->joinable()) thread_->join();
+      delete thread_;
+      thread_ = nullptr;
+    }
+  }
+  void addFrame(FramePtr frame) {                                              // depth_filter.cpp:87-104
+    if (thread_ != nullptr) {
+      {
+        lock_t lock(frame_queue_mut_);
+        if (frame_queue_.size() > 2) frame_queue_.pop();
+        frame_queue_.push(frame);
+      }
+      seeds_updating_halt_ = false;
+      frame_queue_cond_.notify_one();
+    } else {
+      updateSeeds(frame);
+    }
+  }
+  void addKeyframe(FramePtr frame, double depth_mean, double depth_min, std::vector<Feature*> new_features) {   // :109-123
+    new_keyframe_min_depth_ = depth_min;
+    new_keyframe_mean_depth_ = depth_mean;
+    if (thread_ != nullptr) {
+      lock_t lock(frame_queue_mut_);
+      new_keyframe_ = frame;
+      new_keyframe_features_ = std::move(new_features);
+      new_keyframe_set_ = true;
+      seeds_updating_halt_ = true;
+      frame_queue_cond_.notify_one();
+    } else {
+      initializeSeeds(frame, new_features);
+    }
+  }
+  void removeKeyframe(FramePtr frame) {                                        // :153-170
+    seeds_updating_halt_ = true;
+    lock_t lock(seeds_mut_);
+    for (auto it = seeds_.begin(); it != seeds_.end();) it = (it->ftr->frame == frame.get()) ? seeds_.erase(it) : std::next(it);
+    seeds_updating_halt_ = false;
+  }
+  void reset() {                                                               // :172-186
+    seeds_updating_halt_ = true;
+    { lock_t lock(seeds_mut_); seeds_.clear(); }
+    lock_t lock(frame_queue_mut_);
+    while (!frame_queue_.empty()) frame_queue_.pop();
+    seeds_updating_halt_ = false;
+  }
+  std::list<Seed>& getSeeds() { return seeds_; }
+  void getSeedsCopy(const FramePtr& frame, std::list<Seed>& seeds) {           // :349-357
+    lock_t lock(seeds_mut_);
+    for (const Seed& s : seeds_) if (s.ftr->frame == frame.get()) seeds.push_back(s);
+  }
+  bool idle() {
+    lock_t lock(frame_queue_mut_);
+    return frame_queue_.empty() && !new_keyframe_set_ && !busy_;
+  }
+
+ protected:
+  void initializeSeeds(FramePtr frame, const std::vector<Feature*>& new_features) {   // :129-151
+    (void)frame;
+    seeds_updating_halt_ = true;
+    lock_t lock(seeds_mut_);
+    ++Seed::batch_counter;
+    for (Feature* ftr : new_features) seeds_.push_back(Seed(ftr, (float)new_keyframe_mean_depth_, (float)new_keyframe_min_depth_));
+    seeds_updating_halt_ = false;
+  }
+
+  void updateSeedsLoop() {                                                      // :191-229
+    while (true) {
+      FramePtr frame;
+      std::vector<Feature*> feats;
+      bool is_kf = false;
+      {
+        lock_t lock(frame_queue_mut_);
+        while (frame_queue_.empty() && !new_keyframe_set_ && !thread_stop_) frame_queue_cond_.wait(lock);
+        if (thread_stop_) return;
+        if (new_keyframe_set_) {
+          new_keyframe_set_ = false;
+          seeds_updating_halt_ = false;
+          while (!frame_queue_.empty()) frame_queue_.pop();
+          frame = new_keyframe_;
+          feats = std::move(new_keyframe_features_);
+          is_kf = true;
+        } else {
+          frame = frame_queue_.front();
+          frame_queue_.pop();
+        }
+        busy_ = true;
+      }
+      updateSeeds(frame);
+      if (is_kf) initializeSeeds(frame, feats);
+      { lock_t lock(frame_queue_mut_); busy_ = false; }
+    }
+  }
+
+  /// depth_filter.cpp:237-341, batched per reference keyframe on the GPU
+  virtual void updateSeeds(FramePtr frame) {
+    lock_t lock(seeds_mut_);
+    std::map<Frame*, std::vector<std::list<Seed>::iterator>> by_kf;
+    for (auto it = seeds_.begin(); it != seeds_.end();) {
+      if (seeds_updating_halt_) return;
+      if ((Seed::batch_counter - it->batch_id) > options_.max_n_kfs) { it = seeds_.erase(it); continue; }   // :256-261
+      by_kf[it->ftr->frame].push_back(it);
+      ++it;
+    }
+    if (by_kf.empty()) return;
+    const svo_hip_camera cam = frame->cam_->toC();
+    const int cur_slot = cur_pyr_->slotOf(*frame);
+    svo_hip_df_params prm{3, 10, 1000, options_.seed_convergence_sigma2_thresh};
+    for (auto& kf : by_kf) {
+      if (seeds_updating_halt_) return;                                         // halt honoured at batch boundaries (:253)
+      Frame* ref = kf.first;
+      auto& its = kf.second;
+      const int n = (int)its.size();
+      const int ref_slot = kf_pyr_->slotOf(*ref);
+      std::vector<double> px(2 * (size_t)n), f(3 * (size_t)n), z((size_t)n), xyz(3 * (size_t)n);
+      std::vector<int32_t> level((size_t)n), status((size_t)n);
+      std::vector<float> a((size_t)n), b((size_t)n), mu((size_t)n), zr((size_t)n), s2((size_t)n);
+      for (int i = 0; i < n; ++i) {
+        const Seed& s = *its[i];
+        px[2 * i] = s.ftr->px[0]; px[2 * i + 1] = s.ftr->px[1];
+        for (int k = 0; k < 3; ++k) f[3 * i + k] = s.ftr->f[k];
+        level[i] = s.ftr->level;
+        a[i] = s.a; b[i] = s.b; mu[i] = s.mu; zr[i] = s.z_range; s2[i] = s.sigma2;
+      }
+      hip_bridge::check(svo_hip_depth_filter_update(ctx_, kf_pyr_->pyramid(), ref_slot, cur_pyr_->pyramid(), cur_slot, &cam,
+                                                   ref->T_f_w_.p, frame->T_f_w_.p, n, px.data(), f.data(), level.data(),
+                                                   a.data(), b.data(), mu.data(), zr.data(), s2.data(), &prm, status.data(),
+                                                   z.data(), xyz.data(), nullptr, nullptr),
+                        ctx_, "depth_filter_update");
+      for (int i = 0; i < n; ++i) {
+        auto it = its[i];
+        it->a = a[i]; it->b = b[i]; it->mu = mu[i]; it->sigma2 = s2[i];
+        if (status[i] == SVO_HIP_SEED_CONVERGED) {                              // :310-331
+          Point* point = new Point(Vector3d{{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]}});
+          it->ftr->point = point;
+          seed_converged_cb_(point, it->sigma2);
+          seeds_.erase(it);
+        } else if (status[i] == SVO_HIP_SEED_NAN) {                             // :333-337
+          seeds_.erase(it);
+        }
+      }
+    }
+  }
+
+  callback_t seed_converged_cb_;
+  std::list<Seed> seeds_;
+  std::mutex seeds_mut_;
+  volatile bool seeds_updating_halt_ = false;
+  bool thread_stop_ = false;
+  std::thread* thread_ = nullptr;
+  std::queue<FramePtr> frame_queue_;
+  std::mutex frame_queue_mut_;
+  std::condition_variable frame_queue_cond_;
+  FramePtr new_keyframe_;
+  std::vector<Feature*> new_keyframe_features_;
+  bool new_keyframe_set_ = false, busy_ = false;
+  double new_keyframe_min_depth_ = 0.0, new_keyframe_mean_depth_ = 0.0;
+  svo_hip_ctx* ctx_ = nullptr;
+  std::unique_ptr<hip_bridge::PyramidCache> kf_pyr_, cur_pyr_;
+};
+
+}  // namespace svo
+
+#endif  // SVO_HOST_H_
