@@ -39,8 +39,8 @@ BYTES_RESIDUAL = 881             # per patch per Gauss-Newton evaluation
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic scenes tiled over the batch")
@@ -156,6 +156,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- single-pair latency with the reference's early-stop semantics (informative, outside the timed region)
+    latency_ms = None
+    if rank == 0 and not allreduce:
+        sia1 = hip.SparseImgAlign(ctx, 1, n_feat)
+        sia1.set_frames(ref, cur)
+        sia1.upload_pair(0, fps[0])
+        prm1 = sia1.params(max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=True)
+        for _ in range(3):
+            sia1.run(1, prm1)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            sia1.run(1, prm1)
+            ctx.sync()
+        latency_ms = (time.perf_counter() - t1) / 20 * 1e3
+        sia1.destroy()
+
     # ---- parity spot check (outside the timed region): slot 0 against the CPU oracle
     res = sia.download(0)
     results = sia.download_all(min(n_slots, 8))
@@ -225,6 +242,7 @@ def main():
                        "implementation": "fused (one workgroup per frame pair, one launch per solve)" if (not allreduce and sia.last_run_mode() == 1) else "streaming (one launch per Gauss-Newton evaluation)"},
             "pose_err_vs_cpu_ref": {"rot_rad": rot, "trans_m": trans, "tolerance": "1e-4 rad / 1e-3 m"},
             "gn_evaluations_per_frame": int(evals),
+            "single_pair_latency_ms_early_stop": latency_ms,
             "algorithmic_bytes_per_frame": int(bytes_frame),
             "whole_solve_algorithmic_GBps": bytes_frame * value / 1e9,
             "roofline": roofline,
