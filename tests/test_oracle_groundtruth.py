@@ -1,0 +1,89 @@
+"""Ground-truth checks of the parts of the oracle that cannot be pinned to the reference's own code
+("parity unpinned"): the restated SparseImgAlign residual/Jacobian bodies, the epipolar
+search glue, computeTau and the updateSeeds glue must at least recover the known synthetic motion / depth."""
+import numpy as np
+
+from android_svo_amd import seedsynth, synth
+from oracle import orc
+
+
+def test_sparse_img_align_recovers_the_motion():
+    for seed, n in ((5, 300), (6, 1500)):
+        fp = synth.make_frame_pair(seed=seed, n_features=n)
+        r0, t0 = synth.pose_error(fp.T_cur_w_init, fp.T_cur_w_true)
+        o = orc.sparse_img_align(fp)
+        r1, t1 = synth.pose_error(np.array(o.T_cur_w), fp.T_cur_w_true)
+        assert r1 < 0.05 * r0 and t1 < 0.05 * t0, (r0, t0, r1, t1)       # >20x closer to the truth
+        assert o.n_tracked == n and not o.stop
+        # the shipping L4->L2 configuration is coarser but still a large improvement
+        o2 = orc.sparse_img_align(fp, max_level=4, min_level=2)
+        r2, t2 = synth.pose_error(np.array(o2.T_cur_w), fp.T_cur_w_true)
+        assert r2 < 0.2 * r0 and t2 < 0.2 * t0
+
+
+def test_jacobian_matches_numerical_derivative_of_the_residual():
+    """H and Jres of one evaluation are consistent with finite differences of chi2 (inverse compositional:
+    J is the derivative of the REFERENCE patch intensity w.r.t. a twist applied on the reference side)."""
+    fp = synth.make_frame_pair(seed=8, n_features=400)
+    T = synth.se3_mul(fp.T_cur_w_true, synth.se3_inv(fp.T_ref_w))
+    out28, nm = orc.sia_single_eval(fp, 1, T)
+    H = np.zeros((6, 6)); k = 0
+    for i in range(6):
+        for j in range(i, 6):
+            H[i, j] = H[j, i] = out28[k]; k += 1
+    assert nm == 400 * 16
+    assert np.linalg.eigvalsh(H).min() > 0
+    # at the true pose the gradient is small compared with one pixel of misalignment
+    Jres_true = out28[21:27]
+    T_off = synth.se3_mul(synth.se3_from_twist([0.01, 0, 0], [0, 0, 0]), T)
+    out_off, _ = orc.sia_single_eval(fp, 1, T_off)
+    assert np.linalg.norm(out_off[21:27]) > 5 * np.linalg.norm(Jres_true)
+    assert out_off[27] > out28[27]                                        # chi2 grows away from the truth
+
+
+def test_depth_filter_converges_to_the_true_depth():
+    sc = seedsynth.make_seed_case(n_seeds=1500, seed=3)
+    a, b, mu, s2 = sc.a.copy(), sc.b.copy(), sc.mu.copy(), sc.sigma2.copy()
+    err0 = np.median(np.abs(1.0 / mu - sc.true_depth) / sc.true_depth)
+    for _ in range(14):
+        o = orc.update_seeds(sc.cam, sc.ref_pyr, sc.cur_pyr, sc.T_ref_w, sc.T_cur_w, sc.px, sc.f, sc.level, a, b, mu,
+                             sc.z_range.copy(), s2)
+    upd = o["status"] >= 3
+    assert upd.mean() > 0.97
+    err1 = np.median(np.abs(1.0 / mu[upd] - sc.true_depth[upd]) / sc.true_depth[upd])
+    assert err1 < 0.01 and err1 < 0.1 * err0
+    assert (o["status"] == 4).mean() > 0.5                                 # most seeds have converged by then
+    assert np.median(s2[upd]) < 0.01 * np.median(sc.sigma2)
+    # tau: depth uncertainty of one pixel grows with depth and shrinks with the baseline
+    ang = 2.0 * np.arctan(1.0 / (2.0 * sc.cam.fx))
+    T_rc = synth.se3_mul(sc.T_ref_w, synth.se3_inv(sc.T_cur_w))
+    f = sc.f[0]
+    t1, t2 = orc.compute_tau(T_rc, f, 1.0, ang), orc.compute_tau(T_rc, f, 3.0, ang)
+    assert 0 < t1 < t2
+    T_far = T_rc.copy(); T_far[:3] *= 3.0
+    assert orc.compute_tau(T_far, f, 3.0, ang) < t2
+
+
+def test_find_match_direct_recovers_the_true_pixel():
+    rng = np.random.default_rng(2)
+    cam = synth.Camera.default()
+    scene = synth.PlaneScene(seed=12, depth=2.0)
+    T_ref = synth.se3_from_twist([0, 0, 0], [0, 0, 0])
+    T_cur = synth.se3_from_twist([0.05, -0.03, 0.4], [0.01, -0.02, 0.03])
+    ref_pyr = synth.build_pyramid(scene.render(cam, T_ref))
+    cur_pyr = synth.build_pyramid(scene.render(cam, T_cur))
+    errs, oks, levels = [], 0, []
+    for _ in range(200):
+        px = np.array([rng.uniform(60, cam.width - 60), rng.uniform(60, cam.height - 60)])
+        f = synth.cam2world(cam, px[None])[0]
+        X = scene.intersect(cam, T_ref, px[:1], px[1:])[0]
+        Xc = synth.se3_act(T_cur, X)
+        truth = np.array([cam.fx * Xc[0] / Xc[2] + cam.cx, cam.fy * Xc[1] / Xc[2] + cam.cy])
+        if not (20 < truth[0] < cam.width - 20 and 20 < truth[1] < cam.height - 20):
+            continue
+        ok, out, sl = orc.find_match_direct(cam, ref_pyr, cur_pyr, T_ref, T_cur, px, f, 0, X, truth + rng.uniform(-1.5, 1.5, 2))
+        oks += ok
+        levels.append(sl)
+        if ok:
+            errs.append(np.linalg.norm(out - truth))
+    assert oks > 100 and np.median(errs) < 0.5
