@@ -600,7 +600,7 @@ SVO_DEV float interp_at(uint2 R, uint2 Rn, int k, float a_tl, float a_tr, float 
   return a_tl * byte_f(R, k) + a_tr * byte_f(R, k + 1) + a_bl * byte_f(Rn, k) + a_br * byte_f(Rn, k + 1);
 }
 
-template <int TPW>
+template <int TPW, bool LPP>
 __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
     const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
     const int tile = wave + FUSED_WAVES * k;
-    const int i_own = tile * TILE + 16 * r + q;
+    const int i_own = tile * TILE + (LPP ? lane : 16 * r + q);
     X[k] = make_double4(0, 0, 1, 1);
     th[k] = 0.0;
     su[k] = sv[k] = 0.0f; fl[k] = 0;
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       const int tile = wave + FUSED_WAVES * k;
       if (tile >= n_tiles) continue;                         // wave-uniform
       const int tile_base = tile * TILE;
-      const int i_own = tile_base + 16 * r + q;
+      const int i_own = tile_base + (LPP ? lane : 16 * r + q);
       bool valid = false;
       float w_tl = 0, w_tr = 0, w_bl = 0, w_br = 0;
       int off = 0;
@@ -715,6 +715,32 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         if (lane == 0 && m) atomicAdd(&s_npre, (unsigned)__popcll(m));
       }
       double sxx = 0.0, sxy = 0.0, syy = 0.0;
+      if constexpr (LPP) {
+        // lane-per-patch: the lane reads its patch's 7 footprint rows, keeps them in LDS and sums the 16 pixels
+        if (valid) {
+          uint2 F[7];
+#pragma unroll
+          for (int j = 0; j < 7; ++j) F[j] = load_row8(ref_img + off + j * stride);
+          uint2* dst = fp + (size_t)(tile_base + lane) * 7;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) dst[j] = F[j];
+          float W[6][6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int c2 = 0; c2 < 6; ++c2)
+              W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : interp_at(F[j], F[j + 1], c2, w_tl, w_tr, w_bl, w_br);
+#pragma unroll
+          for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              const float dxv = 0.5f * (W[y + 1][x + 2] - W[y + 1][x]);
+              const float dyv = 0.5f * (W[y + 2][x + 1] - W[y][x + 1]);
+              const double ddx = (double)dxv, ddy = (double)dyv;
+              sxx += ddx * ddx; sxy += ddx * ddy; syy += ddy * ddy;
+            }
+        }
+      } else {
 #define SVO_FPRE(S)                                                                                     \
       {                                                                                                 \
         const bool v_s = quad_bcast<S>((int)valid) != 0;                                                \
@@ -742,6 +768,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       }
       SVO_FPRE(0) SVO_FPRE(1) SVO_FPRE(2) SVO_FPRE(3)
 #undef SVO_FPRE
+      }
       if (valid) sxyz[(size_t)b * max_n + i_own] = make_double4(sxx, sxy, syy, 0.0);   // only re-read when a patch leaves the image
       // the tile's Hessian row: lane e keeps entry e
       {
@@ -816,9 +843,39 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         const float rw_bl = (float)((1.0 - su[k]) * sv[k]);
         const float rw_br = su[k] * sv[k];
 
-        // ---- lane-per-pixel-row: residuals of patch 16s+q, row r (:238-279)
         double sdx = 0.0, sdy = 0.0;
         float chi = 0.0f;
+        if constexpr (LPP) {
+          // ---- lane-per-patch residuals (:238-279): the lane walks the 16 pixels of its own patch; no cross-lane
+          // traffic at all.  32 interpolations of the reference footprint give ref value / dx / dy of every pixel.
+          uint2 Cr[5], F[7];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) Cr[j] = load_row8(cur_img + off + j * stride);   // off == 0 when !ok: valid memory
+          const uint2* src = fp + (size_t)(tile_base + lane) * 7;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) F[j] = src[j];
+          float W[6][6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int c2 = 0; c2 < 6; ++c2)
+              W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : interp_at(F[j], F[j + 1], c2, rw_tl, rw_tr, rw_bl, rw_br);
+#pragma unroll
+          for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              const float refv = W[y + 1][x + 1];
+              const float dxv = 0.5f * (W[y + 1][x + 2] - W[y + 1][x]);
+              const float dyv = 0.5f * (W[y + 2][x + 1] - W[y][x + 1]);
+              const float inten = interp_at(Cr[y], Cr[y + 1], x, w_tl, w_tr, w_bl, w_br);
+              const float res = inten - refv;
+              chi += res * res;
+              const double dres = (double)res;
+              sdx += (double)dxv * dres;
+              sdy += (double)dyv * dres;
+            }
+        } else {
+        // ---- lane-per-pixel-row: residuals of patch 16s+q, row r (:238-279)
         uint2 C0[4], C1[4];
 #define SVO_FROWS(S)                                                                  \
         {                                                                             \
@@ -856,6 +913,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         SVO_FRES(0) SVO_FRES(1) SVO_FRES(2) SVO_FRES(3)
 #undef SVO_FRES
 
+        }
         // ---- lane-per-patch: normal equations
         const bool lin = ok && jvalid;
         if (ok) { acc_chi += (double)chi; acc_n += 16; }
@@ -871,7 +929,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
           const int src = __ffsll((long long)gone) - 1;
           gone &= gone - 1;
           const double gx_ = __shfl(X[k].x, src, 64), gy_ = __shfl(X[k].y, src, 64), gzi = __shfl(X[k].w, src, 64);
-          const double4 G4 = sxyz[(size_t)b * max_n + tile_base + 16 * (src & 3) + (src >> 2)];
+          const double4 G4 = sxyz[(size_t)b * max_n + tile_base + (LPP ? src : 16 * (src & 3) + (src >> 2))];
           const double g_xx = G4.x, g_xy = G4.y, g_yy = G4.z;
           double A[6], B[6];
           patch_jacobian_rows(gx_, gy_, gzi, jscale, A, B);
@@ -1084,12 +1142,12 @@ int fused_tiles_per_wave(const svo_hip_sia* s, int n_slots) {
   return tpw < 1 ? 1 : tpw;
 }
 
-template <int TPW>
+template <int TPW, bool LPP>
 int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes) {
   svo_hip_ctx* ctx = s->ctx;
   static thread_local bool attr_set = false;
   if (!attr_set) {
-    SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<TPW>),
+    SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<TPW, LPP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_TILES * TILE * 56));
     attr_set = true;
   }
@@ -1104,7 +1162,7 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   fp.early_stop = prm->early_stop; fp.eps = prm->eps;
   hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
-  hipLaunchKernelGGL(sia_fused_kernel<TPW>, dim3(n_slots), dim3(FUSED_THREADS), lds_bytes, ctx->stream, s->fc, s->st,
+  hipLaunchKernelGGL((sia_fused_kernel<TPW, LPP>), dim3(n_slots), dim3(FUSED_THREADS), lds_bytes, ctx->stream, s->fc, s->st,
                      s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, fp);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   SVO_CHECK_HIP(ctx, hipGetLastError());
@@ -1126,10 +1184,19 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tp
   const size_t lds = (size_t)tiles * TILE * 56;
   s->begun = false;
   s->last_mode = 1;
+  const char* lay = getenv("SVO_HIP_SIA_FUSED");
+  const bool lpp = !(lay && strcmp(lay, "quad") == 0);
+  if (lpp) {
+    switch (tpw) {
+      case 1: return launch_fused_t<1, true>(s, n_slots, prm, lds);
+      case 2: return launch_fused_t<2, true>(s, n_slots, prm, lds);
+      default: return launch_fused_t<3, true>(s, n_slots, prm, lds);
+    }
+  }
   switch (tpw) {
-    case 1: return launch_fused_t<1>(s, n_slots, prm, lds);
-    case 2: return launch_fused_t<2>(s, n_slots, prm, lds);
-    default: return launch_fused_t<3>(s, n_slots, prm, lds);
+    case 1: return launch_fused_t<1, false>(s, n_slots, prm, lds);
+    case 2: return launch_fused_t<2, false>(s, n_slots, prm, lds);
+    default: return launch_fused_t<3, false>(s, n_slots, prm, lds);
   }
 }
 
