@@ -74,6 +74,37 @@ SVO_DEV void se3_act(const double* T, const double* p, double* out) {
   out[0] = T[0] + r[0]; out[1] = T[1] + r[1]; out[2] = T[2] + r[2];
 }
 
+// sin and cos of a small angle by their Taylor series in Horner form (|x| <= 0.5: truncation error < 2e-23,
+// rounding ~1 ulp, i.e. the same accuracy class as a libm call at a tenth of the instructions); the
+// Gauss-Newton update angles are tiny, larger arguments take the library path.
+SVO_DEV void sincos_small(double x, double* s, double* c) {
+  if (fabs(x) <= 0.5) {
+    const double z = x * x;
+    // sin x = x (1 - z/6 (1 - z/20 (1 - z/42 (1 - z/72 (1 - z/110 (1 - z/156 (1 - z/210 (1 - z/272))))))))
+    double ps = 1.0 - z * (1.0 / 272.0);
+    ps = 1.0 - z * (1.0 / 210.0) * ps;
+    ps = 1.0 - z * (1.0 / 156.0) * ps;
+    ps = 1.0 - z * (1.0 / 110.0) * ps;
+    ps = 1.0 - z * (1.0 / 72.0) * ps;
+    ps = 1.0 - z * (1.0 / 42.0) * ps;
+    ps = 1.0 - z * (1.0 / 20.0) * ps;
+    ps = 1.0 - z * (1.0 / 6.0) * ps;
+    *s = x * ps;
+    // cos x = 1 - z/2 (1 - z/12 (1 - z/30 (1 - z/56 (1 - z/90 (1 - z/132 (1 - z/182 (1 - z/240)))))))
+    double pc = 1.0 - z * (1.0 / 240.0);
+    pc = 1.0 - z * (1.0 / 182.0) * pc;
+    pc = 1.0 - z * (1.0 / 132.0) * pc;
+    pc = 1.0 - z * (1.0 / 90.0) * pc;
+    pc = 1.0 - z * (1.0 / 56.0) * pc;
+    pc = 1.0 - z * (1.0 / 30.0) * pc;
+    pc = 1.0 - z * (1.0 / 12.0) * pc;
+    *c = 1.0 - z * 0.5 * pc;
+  } else {
+    *s = sin(x);
+    *c = cos(x);
+  }
+}
+
 // I/SE3.h:153-182.  theta == 0 gives a NaN translation, as in the reference.
 SVO_DEV void se3_exp(const double* l, double* out) {
   const double p[3] = {l[0], l[1], l[2]};
@@ -82,20 +113,22 @@ SVO_DEV void se3_exp(const double* l, double* out) {
   double theta = sqrt(theta_sq);
   double half_theta = 0.5 * theta;
   double imag_factor, real_factor;
+  double sin_h, cos_h, sin_t, cos_t;
+  sincos_small(half_theta, &sin_h, &cos_h);
+  sincos_small(theta, &sin_t, &cos_t);
   if (theta < 1e-10) {
     double theta_po4 = theta_sq * theta_sq;
     imag_factor = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
     real_factor = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * theta_po4;
   } else {
-    double sin_half_theta = sin(half_theta);
-    imag_factor = sin_half_theta / theta;
-    real_factor = cos(half_theta);
+    imag_factor = sin_h / theta;
+    real_factor = cos_h;
   }
   double rxp[3], rxrxp[3];
   cross3(r, p, rxp);
   cross3(r, rxp, rxrxp);
-  double c1 = (1 - cos(theta)) / theta_sq;
-  double c2 = (theta - sin(theta)) / (theta_sq * theta);
+  double c1 = (1 - cos_t) / theta_sq;
+  double c2 = (theta - sin_t) / (theta_sq * theta);
   out[0] = (p[0] + c1 * rxp[0]) + c2 * rxrxp[0];
   out[1] = (p[1] + c1 * rxp[1]) + c2 * rxrxp[1];
   out[2] = (p[2] + c1 * rxp[2]) + c2 * rxrxp[2];
@@ -297,7 +330,9 @@ SVO_DEV double quad_sum(double v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(
 SVO_DEV float quad_sum(float v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); return v; }
 
 // Pivoted LDL^T solve of a symmetric 6x6 with every index static (registers only, no scratch):
-// same algorithm and operation order as ldlt6_solve above.
+// same algorithm and operation order as ldlt6_solve above.  MUST be called with exactly one active
+// lane per wave (the callers run it on lane 0 only): the pivot index is read with readfirstlane so that
+// the row/column swaps are real scalar branches instead of ~500 predicated moves.
 SVO_DEV void ldlt6_solve_reg(const double* Hin, const double* b, double* x) {
   constexpr int N = 6;
   double m[N][N];
@@ -315,6 +350,7 @@ SVO_DEV void ldlt6_solve_reg(const double* Hin, const double* b, double* x) {
 #pragma unroll
       for (int i = k + 1; i < N; ++i)
         if (fabs(m[i][i]) > best) { best = fabs(m[i][i]); big = i; }
+      big = __builtin_amdgcn_readfirstlane(big);
       tr[k] = big;
 #pragma unroll
       for (int c = k + 1; c < N; ++c) {

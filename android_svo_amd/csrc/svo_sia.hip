@@ -617,8 +617,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   __shared__ unsigned long long s_nres, s_nmeas;
   __shared__ int s_iters[SVO_HIP_MAX_LEVELS];
 #ifdef SVO_STAMPS
-  __shared__ long long s_stamp[4];
+  __shared__ long long s_stamp[6];
   if (threadIdx.x == 64) { s_stamp[0] = s_stamp[1] = s_stamp[2] = 0; }
+  if (threadIdx.x == 0) { s_stamp[3] = s_stamp[4] = 0; }
 #endif
 
   const int b = blockIdx.x;
@@ -993,7 +994,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
           s_nmeas = n_meas;
           s_nres += n_meas / 16;
           s_iters[level] += 1;
+#ifdef SVO_STAMPS
+          const long long q0 = __builtin_amdgcn_s_memtime();
+#endif
           ldlt6_solve_reg(H, Jres, x);
+#ifdef SVO_STAMPS
+          const long long q1 = __builtin_amdgcn_s_memtime();
+          s_stamp[3] += q1 - q0;
+#endif
 #pragma unroll
           for (int i = 0; i < 6; ++i) s_x[i] = x[i];
           if (x[0] != x[0]) s_stop = 1;                                          // NaN -> stop_ (:52-59)
@@ -1007,8 +1015,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
             for (int i = 0; i < 6; ++i) mx[i] = -x[i];
 #pragma unroll
             for (int i = 0; i < 7; ++i) cur[i] = s_model[i];
+#ifdef SVO_STAMPS
+            const long long q2 = __builtin_amdgcn_s_memtime();
+#endif
             se3_exp(mx, dT);
             se3_mul(cur, dT, nm);                                                // T_new = T_old * exp(-x) (:307)
+#ifdef SVO_STAMPS
+            s_stamp[4] += __builtin_amdgcn_s_memtime() - q2;
+#endif
 #pragma unroll
             for (int i = 0; i < 7; ++i) { s_old[i] = cur[i]; s_model[i] = nm[i]; }
             s_chi2 = new_chi2;
@@ -1043,7 +1057,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         for (int j = i; j < 6; ++j) { s.H[i * 6 + j] = s_last[kk]; s.H[j * 6 + i] = s_last[kk]; ++kk; }
       for (int i = 0; i < 6; ++i) { s.Jres[i] = s_last[21 + i]; s.x[i] = s_x[i]; }
 #ifdef SVO_STAMPS
-      s.x[0] = (double)s_stamp[0]; s.x[1] = (double)s_stamp[1]; s.x[2] = (double)s_stamp[2];
+      s.x[0] = (double)s_stamp[0]; s.x[1] = (double)s_stamp[1]; s.x[2] = (double)s_stamp[2]; s.x[3] = (double)s_stamp[3]; s.x[4] = (double)s_stamp[4];
 #endif
     }
     for (int i = 0; i < SVO_HIP_MAX_LEVELS; ++i) s.iters[i] = s_iters[i];

@@ -34,7 +34,7 @@ buf = (C.c_double * 6)()
 rows = []
 for s in range(min(B, 8)):
     L.svo_hip_sia_debug_x(sia.h, s, buf)
-    rows.append([buf[0], buf[1], buf[2]])
+    rows.append([buf[0], buf[1], buf[2], buf[3], buf[4]])
 rows = np.array(rows) / 150.0
-print("cycles per evaluation (100 MHz memtime ticks x?): eval+wave-reduce, barrier wait, sum+solve+barrier")
+print("cycles per evaluation: eval+wave-reduce, barrier wait, sum+solve+barrier, of which LDLT, exp+mul")
 print(rows)
