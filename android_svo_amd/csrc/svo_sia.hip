@@ -576,8 +576,12 @@ __global__ void sia_finish_kernel(const FrameConst* __restrict__ fc, FrameState*
 // one launch per run.  Nothing is streamed from HBM between Gauss-Newton evaluations:
 //   * the 7x8-byte reference footprint of every patch lives in LDS (56 B/patch, <= 2816 patches in
 //     160 KiB); ref value / dx / dy are recomputed from it (bit-identical to the cached form);
-//   * {x,y,z,1/z}, {sxx,sxy,syy}, the reference sub-pixel offsets, the flags and the wave's tile-H
-//     entries stay in VGPRs (lane-per-patch; a wave owns tiles wave, wave+16, wave+32);
+//   * {x,y,z,1/z}, the reference sub-pixel offsets, the flags and the wave's tile-H entries stay in
+//     VGPRs (lane-per-patch; a wave owns tiles wave, wave+16, wave+32); {sxx,sxy,syy} go to HBM once per
+//     level and are only re-read for the rare patch that leaves the image;
+//   * LPP = true (default): a lane owns one patch of the tile and walks its 16 pixels itself -- 32
+//     interpolations of the footprint give ref/dx/dy of all pixels, no cross-lane traffic inside a tile;
+//     LPP = false: the streaming kernels' layout (4 lanes per patch, DPP quad exchange), kept for A/B runs;
 //   * the Gauss-Newton state lives in LDS; the solve runs on one lane between two barriers;
 //   * only the current image is read from memory (two 8-byte rows per lane and sub-pass, L2/MALL).
 // Data-dependent exits are real `break`s here, so a converged frame costs nothing further.
