@@ -750,6 +750,7 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
   SVO_REQUIRE(ctx, n >= 0);
   if (n == 0) return SVO_HIP_OK;
   SVO_REQUIRE(ctx, px && f && level && a && b && mu && z_range && sigma2 && status);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   DfFrame fr;
   memset(&fr, 0, sizeof(fr));
   fr.cam = svo_make_cam(*cam);

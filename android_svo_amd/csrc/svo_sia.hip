@@ -1163,12 +1163,9 @@ int fused_tiles_per_wave(const svo_hip_sia* s, int n_slots) {
 template <int TPW, bool LPP>
 int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes) {
   svo_hip_ctx* ctx = s->ctx;
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<TPW, LPP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_TILES * TILE * 56));
-    attr_set = true;
-  }
+  // > 64 KiB of dynamic LDS has to be allowed explicitly (per device: set it on every launch, it is cheap)
+  SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<TPW, LPP>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_TILES * TILE * 56));
   FusedLevels lv;
   memset(&lv, 0, sizeof(lv));
   for (int l = 0; l < s->ref->n_levels; ++l) {
@@ -1189,6 +1186,7 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
 
 int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tpw) {
   svo_hip_ctx* ctx = s->ctx;
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   SVO_REQUIRE(ctx, s->ref && s->cur);
   SVO_REQUIRE(ctx, n_slots > 0 && n_slots <= s->batch);
   SVO_REQUIRE(ctx, prm->min_level >= 0 && prm->max_level >= prm->min_level && prm->max_level < s->ref->n_levels);
@@ -1337,6 +1335,7 @@ int svo_hip_sia_begin(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm
   SVO_REQUIRE(ctx, n_slots > 0 && n_slots <= s->batch);
   SVO_REQUIRE(ctx, prm->min_level >= 0 && prm->max_level >= prm->min_level && prm->max_level < s->ref->n_levels);
   SVO_REQUIRE(ctx, prm->n_iter >= 0);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   int rc = flush_fc(s);
   if (rc != SVO_HIP_OK) return rc;
   s->prm = *prm; s->n_slots = n_slots; s->level = -1; s->begun = true;

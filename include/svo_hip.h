@@ -159,7 +159,8 @@ int svo_hip_sia_last_run_mode(svo_hip_sia* sia, int* mode);
 int svo_hip_sia_set_profiling(svo_hip_sia* sia, int enable);
 int svo_hip_sia_get_profile(svo_hip_sia* sia, double* residual_ms, uint64_t* residual_launches,
                             double* precompute_ms, uint64_t* precompute_launches);
-/* cached reference patches / per-patch Jacobian records of one slot, for kernel-level tests:
+/* cached reference patches / per-patch Jacobian records of one slot, for kernel-level tests (filled by the
+ * streaming kernels, i.e. after the step-wise entry points or a run with SVO_HIP_SIA_MODE=stream):
  * ref_patch[n][16] f32, dx[n][16] f32, dy[n][16] f32, visible[n] u8 (any may be NULL) */
 int svo_hip_sia_download_caches(svo_hip_sia* sia, int slot, float* ref_patch, float* dx, float* dy,
                                 uint8_t* visible);
