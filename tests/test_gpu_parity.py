@@ -565,3 +565,44 @@ def test_feature_count_classes(ctx, n, expect_mode):
     assert rot < 1e-4 and trans < 1e-3, (rot, trans)
     assert r.n_tracked == o.n_tracked
     _free(sia, ref, cur)
+
+
+def test_random_small_configs_fuzz(ctx, sia_mode):
+    """Many small random problems (sizes around the 64-patch tile boundaries, images of several sizes, level
+    ranges, point-less features, features near/outside the border, large motions): every slot must agree with
+    its own oracle run, including the degenerate ones (NaN poses when nothing is visible)."""
+    rng = np.random.default_rng(2024)
+    cases = []
+    n_checked = n_degenerate = 0
+    for (w, h) in ((320, 240), (640, 480), (336, 208)):
+        group = []
+        for _ in range(12):
+            n = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 200, 511]))
+            border = int(rng.choice([4, 8, 24, 48]))
+            fp = synth.make_frame_pair(seed=int(rng.integers(1, 10**6)), width=w, height=h, n_features=n, border=border,
+                                       null_point_every=int(rng.choice([0, 0, 2, 5])), t_mag=float(rng.choice([0.01, 0.05, 0.2])),
+                                       r_mag=float(rng.choice([0.005, 0.03])))
+            group.append(fp)
+        cases.append(group)
+    for group in cases:
+        ref, cur, sia = _upload_pair(ctx, group, max_feat=600)
+        for (mx, mn, it, es) in ((4, 0, 30, True), (4, 2, 30, True), (3, 3, 4, False), (2, 0, 3, False)):
+            sia.run(len(group), sia.params(max_level=mx, min_level=mn, n_iter=it, early_stop=es))
+            res = sia.download_all(len(group))
+            for i, fp in enumerate(group):
+                o = orc.sparse_img_align(fp, max_level=mx, min_level=mn, n_iter=it, early_stop=es)
+                got, want = np.array(res[i].T_cur_w), np.array(o.T_cur_w)
+                assert res[i].n_precompute_patches == o.n_precompute_patches          # integer work: always exact
+                # With a handful of patches the 6x6 system is rank deficient: the pivoted LDLT then amplifies
+                # last-bit differences of H into arbitrary steps (in the reference too), so poses are only
+                # compared for well-posed problems; degenerate ones must simply not fault.
+                well_posed = o.n_tracked >= 24 and not np.isnan(want).any() and synth.pose_error(want, fp.T_cur_w_true)[0] < 0.02
+                if not well_posed:
+                    n_degenerate += 1
+                    continue
+                n_checked += 1
+                assert res[i].n_tracked == o.n_tracked, (i, mx, mn)
+                rot, trans = synth.pose_error(got, want)
+                assert rot < 1e-4 and trans < 1e-3, (i, mx, mn, it, es, rot, trans, len(fp.px))
+        _free(sia, ref, cur)
+    assert n_checked > 40 and n_degenerate > 5
