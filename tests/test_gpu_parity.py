@@ -606,3 +606,50 @@ def test_random_small_configs_fuzz(ctx, sia_mode):
                 assert rot < 1e-4 and trans < 1e-3, (i, mx, mn, it, es, rot, trans, len(fp.px))
         _free(sia, ref, cur)
     assert n_checked > 40 and n_degenerate > 5
+
+
+def test_depth_filter_all_paths(ctx):
+    """Seeds chosen to take every branch of updateSeeds / findEpipolarMatchDirect: behind the camera, outside
+    the frame, short epipolar segment (direct align), one-chunk search, multi-chunk search (> 64 steps),
+    search skipped (> 1000 steps), NaN variance, near-border features.  Integer outcomes exact vs the oracle."""
+    rng = np.random.default_rng(77)
+    sc = seedsynth.make_seed_case(n_seeds=6000, seed=31, baseline=0.35, border=12)
+    n = len(sc.px)
+    # rotate the current camera so that a part of the keyframe leaves its field of view
+    T_cur_w = synth.se3_mul(synth.se3_from_twist([0.0, 0.0, 0.0], [0.0, 0.22, 0.0]), sc.T_cur_w)
+    scene_img = sc.cur_pyr      # images of the unrotated pose: content does not matter for branch coverage
+    a, b, mu, zr, s2 = (v.copy() for v in (sc.a, sc.b, sc.mu, sc.z_range, sc.sigma2))
+    k = n // 6
+    s2[:k] *= 1e-4                                   # tight seeds: epipolar segment < 2 px -> direct align
+    s2[k:2 * k] *= 30.0                              # loose seeds: long epipolar lines (multi-chunk, some > 1000 steps)
+    mu[2 * k:2 * k + 200] = 1e-3                     # very far hypothesis
+    mu[2 * k + 200:2 * k + 400] = -0.2               # negative inverse depth: behind the camera
+    s2[2 * k + 400:2 * k + 420] = np.nan             # NaN variance
+    s2[3 * k:3 * k + 300] *= 20000.0                 # absurdly loose: > 1000 steps -> search skipped (matcher.cpp:283-288)
+    kf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
+    cf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
+    kf.upload(0, sc.ref_pyr)
+    cf.upload(0, scene_img)
+    sb = hip.SeedBatch(ctx, sc.px, sc.f, sc.level, a, b, mu, zr, s2)
+    hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, T_cur_w, sb)
+    st, nz, na = sb.status.download(), sb.n_zmssd.download(), sb.n_align.download()
+    gmu, gs2, gb, gz = sb.mu.download(), sb.sigma2.download(), sb.b.download(), sb.z.download()
+    oa, ob, om, os2 = a.copy(), b.copy(), mu.copy(), s2.copy()
+    o = orc.update_seeds(sc.cam, sc.ref_pyr, scene_img, sc.T_ref_w, T_cur_w, sc.px, sc.f, sc.level, oa, ob, om, zr.copy(), os2)
+    counts = np.bincount(o["status"], minlength=6)
+    assert counts[0] > 50 and counts[1] > 50 and counts[2] > 50 and counts[3] > 50, counts      # the case covers the branches
+    assert (o["n_zmssd"] > 64).sum() > 20                                # multi-chunk searches happened
+    assert ((o["n_zmssd"] == 0) & (o["n_align_iters"] > 0)).sum() > 50   # direct-align path happened
+    agree = st == o["status"]
+    assert agree.mean() > 0.995, np.bincount(st, minlength=6)
+    np.testing.assert_array_equal(nz, o["n_zmssd"])                      # search work is integer-exact for EVERY seed
+    assert (na == o["n_align_iters"]).mean() > 0.99
+    failed = agree & (st <= hip.SEED_NO_MATCH)
+    np.testing.assert_array_equal(gb[failed], ob[failed])                # untouched, or b++ on a failed match: exact
+    assert ((st == hip.SEED_NO_MATCH) & (gb == b + 1)).sum() == (st == hip.SEED_NO_MATCH).sum()
+    upd = agree & (st >= hip.SEED_UPDATED)
+    np.testing.assert_allclose(gz[upd], o["z"][upd], rtol=1e-3)
+    np.testing.assert_allclose(gmu[upd], om[upd], rtol=1e-3)
+    nanseed = np.isnan(s2)
+    assert (st[nanseed] == o["status"][nanseed]).all()
+    _free(sb, kf, cf)
