@@ -47,14 +47,14 @@ def parse_args():
     ap.add_argument("--mode", choices=["frames", "allreduce"], default="frames")
     ap.add_argument("--early-stop", action="store_true", help="reference GN exits instead of fixed work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames-per-thread", type=int, default=6)
+    ap.add_argument("--cpu-frames-per-thread", type=int, default=16)
     ap.add_argument("--latency-probe", action="store_true",
                     help="also time single-pair early-stop solves (extra launches of the same kernel: keep it off when the\n                    run is profiled, the kernel average in the rocprofv3 summary must be that of the timed launches)")
     ap.add_argument("--profile-events", type=int, default=1, help="record HIP events around the heavy kernels in the timed region")
     return ap.parse_args()
 
 
-def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=6):
+def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=16):
     """The CPU oracle (port of the reference algorithm) on the host cores, bounded sample."""
     from oracle import orc
     orc.lib()
