@@ -329,6 +329,31 @@ SVO_DEV T quad_bcast(T v) { return dpp_quad<S * 0x55>(v); }
 SVO_DEV double quad_sum(double v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); return v; }
 SVO_DEV float quad_sum(float v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); return v; }
 
+// Sum 8 per-lane doubles over the 64 lanes of a wave with 7 long-range exchanges instead of 48: every
+// exchange step halves the number of values a lane still carries (lanes with the exchanged bit set keep the
+// upper half of the values and hand over the lower half).  On return lanes 8j .. 8j+7 all hold the wave
+// total of v[j].  The order of the additions is fixed, so the result is reproducible run to run.
+SVO_DEV double wave_reduce8(const double* v) {
+  const int lane = threadIdx.x & 63;
+  const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+  double a[4], c[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double keep = b5 ? v[i + 4] : v[i], send = b5 ? v[i] : v[i + 4];
+    a[i] = keep + __shfl_xor(send, 32, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double keep = b4 ? a[i + 2] : a[i], send = b4 ? a[i] : a[i + 2];
+    c[i] = keep + __shfl_xor(send, 16, 64);
+  }
+  const double keep = b3 ? c[1] : c[0], send = b3 ? c[0] : c[1];
+  double r = keep + __shfl_xor(send, 8, 64);
+  r = quad_sum(r);                       // lanes xor 1, xor 2 (DPP quad_perm)
+  r += dpp_quad<0x141>(r);               // DPP row_half_mirror: the other quad of the 8-lane group
+  return r;
+}
+
 // Pivoted LDL^T solve of a symmetric 6x6 with every index static (registers only, no scratch):
 // same algorithm and operation order as ldlt6_solve above.  MUST be called with exactly one active
 // lane per wave (the callers run it on lane 0 only): the pivot index is read with readfirstlane so that

@@ -572,25 +572,29 @@ __global__ void sia_finish_kernel(const FrameConst* __restrict__ fc, FrameState*
 }
 
 // =================================================================================================
-// Fused path: the whole coarse-to-fine solve of one frame pair in ONE workgroup (1024 threads, one CU),
+// Fused path: the whole coarse-to-fine solve of one frame pair in ONE workgroup (512 threads, one CU),
 // one launch per run.  Nothing is streamed from HBM between Gauss-Newton evaluations:
 //   * the 7x8-byte reference footprint of every patch lives in LDS (56 B/patch, <= 2816 patches in
 //     160 KiB); ref value / dx / dy are recomputed from it (bit-identical to the cached form);
 //   * {x,y,z,1/z}, the reference sub-pixel offsets, the flags and the wave's tile-H entries stay in
-//     VGPRs (lane-per-patch; a wave owns tiles wave, wave+16, wave+32); {sxx,sxy,syy} go to HBM once per
-//     level and are only re-read for the rare patch that leaves the image;
-//   * LPP = true (default): a lane owns one patch of the tile and walks its 16 pixels itself -- 32
-//     interpolations of the footprint give ref/dx/dy of all pixels, no cross-lane traffic inside a tile;
-//     LPP = false: the streaming kernels' layout (4 lanes per patch, DPP quad exchange), kept for A/B runs;
+//     VGPRs (lane-per-patch; a wave owns tiles wave, wave+8, wave+16, ...); {sxx,sxy,syy} go to HBM once
+//     per level and are only re-read for the rare patch that leaves the image;
+//   * a lane owns one patch of a tile and walks its 16 pixels itself -- 32 interpolations of the footprint give
+//     ref/dx/dy of all pixels, no cross-lane traffic inside a tile;
+//   * 8 waves (2 per SIMD, 256 VGPRs per lane) measured fastest: 16 waves (128 VGPRs) spill around the solve and
+//     pay twice the wave reductions (77 k frames/s against 98 k), 12 waves 85 k, 4 waves 68 k.  Packed f32
+//     (v_pk_mul_f32 / v_pk_add_f32 over two patches per lane) was measured too: CDNA4's SIMD already issues a
+//     plain wave64 f32 op in 2 cycles, the packed forms take two passes, and the kernel ran 18 % slower;
 //   * the Gauss-Newton state lives in LDS; the solve runs on one lane between two barriers;
-//   * only the current image is read from memory (two 8-byte rows per lane and sub-pass, L2/MALL).
+//   * only the current image is read from memory (five 8-byte rows per patch and evaluation, L2/MALL).
 // Data-dependent exits are real `break`s here, so a converged frame costs nothing further.
-// Semantics are those of the streaming kernels above (same tile/quad mapping, same reductions per wave,
-// then a fixed-order sum over the 16 waves).
+// Semantics are those of the streaming kernels above (same 64-patch tiles, lane-ordered sums per wave,
+// then a fixed-order sum over the waves).
 // =================================================================================================
-constexpr int FUSED_THREADS = 1024;
+constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_WAVES = FUSED_THREADS / 64;
 constexpr int FUSED_MAX_TILES = 44;               // 44 * 64 * 56 B = 157 696 B of footprints
+constexpr int FUSED_MAX_TPW = 6;                  // ceil(44 / 8)
 
 struct FusedLevels {
   int cols[SVO_HIP_MAX_LEVELS], rows[SVO_HIP_MAX_LEVELS];
@@ -604,7 +608,41 @@ SVO_DEV float interp_at(uint2 R, uint2 Rn, int k, float a_tl, float a_tr, float 
   return a_tl * byte_f(R, k) + a_tr * byte_f(R, k + 1) + a_bl * byte_f(Rn, k) + a_br * byte_f(Rn, k + 1);
 }
 
-template <int TPW, bool LPP>
+struct LppGeom {
+  bool ok;
+  float w_tl, w_tr, w_bl, w_br;
+  int off;
+};
+
+// projection of one patch into the current level image (:220-236)
+SVO_DEV LppGeom lpp_project(const double* T, const Cam& cam, const double4& X, bool visible, float scale, int cols,
+                            int rows, int stride) {
+  LppGeom g;
+  g.ok = false; g.w_tl = g.w_tr = g.w_bl = g.w_br = 0.0f; g.off = 0;
+  if (visible) {
+    const int border = 3;
+    const double xyz_ref[3] = {X.x, X.y, X.z};
+    double xyz_cur[3], pxd[2];
+    se3_act(T, xyz_ref, xyz_cur);
+    world2cam(cam, xyz_cur, pxd);
+    const float u_cur = (float)pxd[0] * scale;
+    const float v_cur = (float)pxd[1] * scale;
+    const int u_cur_i = (int)floorf(u_cur);
+    const int v_cur_i = (int)floorf(v_cur);
+    g.ok = (u_cur_i >= 0 && v_cur_i >= 0 && u_cur_i - border >= 0 && v_cur_i - border >= 0 &&
+            u_cur_i + border < cols && v_cur_i + border < rows) && u_cur == u_cur && v_cur == v_cur;
+    const float subpix_u = u_cur - u_cur_i;
+    const float subpix_v = v_cur - v_cur_i;
+    g.w_tl = (float)((1.0 - subpix_u) * (1.0 - subpix_v));
+    g.w_tr = (float)(subpix_u * (1.0 - subpix_v));
+    g.w_bl = (float)((1.0 - subpix_u) * subpix_v);
+    g.w_br = subpix_u * subpix_v;
+    g.off = g.ok ? (v_cur_i - 2) * stride + (u_cur_i - 2) : 0;
+  }
+  return g;
+}
+
+template <int TPW>
 __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
     const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
@@ -632,10 +670,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   const int n = c.n_feat;
   const int n_tiles = (n + TILE - 1) / TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int q = lane >> 2, r = lane & 3;
   const bool empty = n <= 0;
   const int tri_i = kTriI[lane < 21 ? lane : 0], tri_j = kTriJ[lane < 21 ? lane : 0];
 
+  if (lane >= 29 && lane < 32) red[wave][lane] = 0.0;       // unused slots of the wave partial rows
   if (threadIdx.x == 0) {
     double Tinv[7], T[7];
     se3_inverse(c.T_ref_w, Tinv);
@@ -656,7 +694,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
     const int tile = wave + FUSED_WAVES * k;
-    const int i_own = tile * TILE + (LPP ? lane : 16 * r + q);
+    const int i_own = tile * TILE + lane;
     X[k] = make_double4(0, 0, 1, 1);
     th[k] = 0.0;
     su[k] = sv[k] = 0.0f; fl[k] = 0;
@@ -691,7 +729,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       const int tile = wave + FUSED_WAVES * k;
       if (tile >= n_tiles) continue;                         // wave-uniform
       const int tile_base = tile * TILE;
-      const int i_own = tile_base + (LPP ? lane : 16 * r + q);
+      const int i_own = tile_base + lane;
       bool valid = false;
       float w_tl = 0, w_tr = 0, w_bl = 0, w_br = 0;
       int off = 0;
@@ -720,7 +758,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         if (lane == 0 && m) atomicAdd(&s_npre, (unsigned)__popcll(m));
       }
       double sxx = 0.0, sxy = 0.0, syy = 0.0;
-      if constexpr (LPP) {
+      {
         // lane-per-patch: the lane reads its patch's 7 footprint rows, keeps them in LDS and sums the 16 pixels
         if (valid) {
           uint2 F[7];
@@ -745,34 +783,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
               sxx += ddx * ddx; sxy += ddx * ddy; syy += ddy * ddy;
             }
         }
-      } else {
-#define SVO_FPRE(S)                                                                                     \
-      {                                                                                                 \
-        const bool v_s = quad_bcast<S>((int)valid) != 0;                                                \
-        if (v_s) {                                                                                      \
-          const float a_tl = quad_bcast<S>(w_tl), a_tr = quad_bcast<S>(w_tr);                           \
-          const float a_bl = quad_bcast<S>(w_bl), a_br = quad_bcast<S>(w_br);                           \
-          const uint8_t* p = ref_img + quad_bcast<S>(off) + r * stride;                                 \
-          const uint2 Rm = load_row8(p), R0 = load_row8(p + stride), R1 = load_row8(p + 2 * stride),    \
-                      R2 = load_row8(p + 3 * stride);                                                   \
-          uint2* dst = fp + (size_t)(tile_base + 16 * S + q) * 7;                                       \
-          dst[r] = Rm;                                                                                  \
-          if (r == 3) { dst[4] = R0; dst[5] = R1; dst[6] = R2; }                                        \
-          double pxx = 0.0, pxy = 0.0, pyy = 0.0;                                                       \
-          _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                               \
-            const float dxv = 0.5f * (interp_at(R0, R1, x + 2, a_tl, a_tr, a_bl, a_br) -                \
-                                      interp_at(R0, R1, x, a_tl, a_tr, a_bl, a_br));                    \
-            const float dyv = 0.5f * (interp_at(R1, R2, x + 1, a_tl, a_tr, a_bl, a_br) -                \
-                                      interp_at(Rm, R0, x + 1, a_tl, a_tr, a_bl, a_br));                \
-            const double ddx = (double)dxv, ddy = (double)dyv;                                          \
-            pxx += ddx * ddx; pxy += ddx * ddy; pyy += ddy * ddy;                                       \
-          }                                                                                             \
-          pxx = quad_sum(pxx); pxy = quad_sum(pxy); pyy = quad_sum(pyy);                                \
-          if (r == S) { sxx = pxx; sxy = pxy; syy = pyy; }                                              \
-        }                                                                                               \
-      }
-      SVO_FPRE(0) SVO_FPRE(1) SVO_FPRE(2) SVO_FPRE(3)
-#undef SVO_FPRE
       }
       if (valid) sxyz[(size_t)b * max_n + i_own] = make_double4(sxx, sxy, syy, 0.0);   // only re-read when a patch leaves the image
       // the tile's Hessian row: lane e keeps entry e
@@ -816,46 +826,26 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
 #pragma unroll
       for (int k = 0; k < TPW; ++k) {
         const int tile = wave + FUSED_WAVES * k;
-        if (tile >= n_tiles) continue;
+        if (tile >= n_tiles) continue;                       // wave-uniform
         const int tile_base = tile * TILE;
-        // ---- lane-per-patch: projection into the current image (:220-236)
-        bool ok = false;
+        // ---- projection into the current image (:220-236)
+        const LppGeom g = lpp_project(T, cam, X[k], (fl[k] & F_VISIBLE) != 0, scale, cols, rows, stride);
+        const bool ok = g.ok;
         const bool jvalid = (fl[k] & F_JVALID) != 0;
-        float w_tl = 0, w_tr = 0, w_bl = 0, w_br = 0;
-        int off = 0;
-        if (fl[k] & F_VISIBLE) {
-          const double xyz_ref[3] = {X[k].x, X[k].y, X[k].z};
-          double xyz_cur[3], pxd[2];
-          se3_act(T, xyz_ref, xyz_cur);
-          world2cam(cam, xyz_cur, pxd);
-          const float u_cur = (float)pxd[0] * scale;
-          const float v_cur = (float)pxd[1] * scale;
-          const int u_cur_i = (int)floorf(u_cur);
-          const int v_cur_i = (int)floorf(v_cur);
-          ok = (u_cur_i >= 0 && v_cur_i >= 0 && u_cur_i - border >= 0 && v_cur_i - border >= 0 &&
-                u_cur_i + border < cols && v_cur_i + border < rows) && u_cur == u_cur && v_cur == v_cur;
-          const float subpix_u = u_cur - u_cur_i;
-          const float subpix_v = v_cur - v_cur_i;
-          w_tl = (float)((1.0 - subpix_u) * (1.0 - subpix_v));
-          w_tr = (float)(subpix_u * (1.0 - subpix_v));
-          w_bl = (float)((1.0 - subpix_u) * subpix_v);
-          w_br = subpix_u * subpix_v;
-          off = ok ? (v_cur_i - 2) * stride + (u_cur_i - 2) : 0;
-        }
         // weights of the cached reference patch (recomputed from the kept sub-pixel offsets)
         const float rw_tl = (float)((1.0 - su[k]) * (1.0 - sv[k]));
         const float rw_tr = (float)(su[k] * (1.0 - sv[k]));
         const float rw_bl = (float)((1.0 - su[k]) * sv[k]);
         const float rw_br = su[k] * sv[k];
 
+        // ---- residuals (:238-279): the lane walks the 16 pixels of its own patch; no cross-lane traffic at all.
+        // 32 interpolations of the reference footprint give ref value / dx / dy of every pixel.
         double sdx = 0.0, sdy = 0.0;
         float chi = 0.0f;
-        if constexpr (LPP) {
-          // ---- lane-per-patch residuals (:238-279): the lane walks the 16 pixels of its own patch; no cross-lane
-          // traffic at all.  32 interpolations of the reference footprint give ref value / dx / dy of every pixel.
+        {
           uint2 Cr[5], F[7];
 #pragma unroll
-          for (int j = 0; j < 5; ++j) Cr[j] = load_row8(cur_img + off + j * stride);   // off == 0 when !ok: valid memory
+          for (int j = 0; j < 5; ++j) Cr[j] = load_row8(cur_img + g.off + j * stride);   // off == 0 when !ok: valid memory
           const uint2* src = fp + (size_t)(tile_base + lane) * 7;
 #pragma unroll
           for (int j = 0; j < 7; ++j) F[j] = src[j];
@@ -872,61 +862,31 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
               const float refv = W[y + 1][x + 1];
               const float dxv = 0.5f * (W[y + 1][x + 2] - W[y + 1][x]);
               const float dyv = 0.5f * (W[y + 2][x + 1] - W[y][x + 1]);
-              const float inten = interp_at(Cr[y], Cr[y + 1], x, w_tl, w_tr, w_bl, w_br);
+              const float inten = interp_at(Cr[y], Cr[y + 1], x, g.w_tl, g.w_tr, g.w_bl, g.w_br);
               const float res = inten - refv;
               chi += res * res;
               const double dres = (double)res;
-              sdx += (double)dxv * dres;
-              sdy += (double)dyv * dres;
+              // f32 x f32 is exact in f64 (48-bit product): the fused form rounds exactly like mul + add
+              sdx = __builtin_fma((double)dxv, dres, sdx);
+              sdy = __builtin_fma((double)dyv, dres, sdy);
             }
-        } else {
-        // ---- lane-per-pixel-row: residuals of patch 16s+q, row r (:238-279)
-        uint2 C0[4], C1[4];
-#define SVO_FROWS(S)                                                                  \
-        {                                                                             \
-          const uint8_t* p = cur_img + quad_bcast<S>(off) + r * stride;               \
-          C0[S] = load_row8(p); C1[S] = load_row8(p + stride);                        \
         }
-        SVO_FROWS(0) SVO_FROWS(1) SVO_FROWS(2) SVO_FROWS(3)
-#undef SVO_FROWS
-#define SVO_FRES(S)                                                                                     \
-        {                                                                                               \
-          const float a_tl = quad_bcast<S>(w_tl), a_tr = quad_bcast<S>(w_tr);                           \
-          const float a_bl = quad_bcast<S>(w_bl), a_br = quad_bcast<S>(w_br);                           \
-          const float b_tl = quad_bcast<S>(rw_tl), b_tr = quad_bcast<S>(rw_tr);                         \
-          const float b_bl = quad_bcast<S>(rw_bl), b_br = quad_bcast<S>(rw_br);                         \
-          const uint2* src = fp + (size_t)(tile_base + 16 * S + q) * 7 + r;                             \
-          const uint2 Rm = src[0], R0 = src[1], R1 = src[2], R2 = src[3];                               \
-          double px_ = 0.0, py_ = 0.0;                                                                  \
-          float pc = 0.0f;                                                                              \
-          _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                               \
-            const float refv = interp_at(R0, R1, x + 1, b_tl, b_tr, b_bl, b_br);                        \
-            const float dxv = 0.5f * (interp_at(R0, R1, x + 2, b_tl, b_tr, b_bl, b_br) -                \
-                                      interp_at(R0, R1, x, b_tl, b_tr, b_bl, b_br));                    \
-            const float dyv = 0.5f * (interp_at(R1, R2, x + 1, b_tl, b_tr, b_bl, b_br) -                \
-                                      interp_at(Rm, R0, x + 1, b_tl, b_tr, b_bl, b_br));                \
-            const float inten = interp_at(C0[S], C1[S], x, a_tl, a_tr, a_bl, a_br);                     \
-            const float res = inten - refv;                                                             \
-            pc += res * res;                                                                            \
-            const double dres = (double)res;                                                            \
-            px_ += (double)dxv * dres;                                                                  \
-            py_ += (double)dyv * dres;                                                                  \
-          }                                                                                             \
-          px_ = quad_sum(px_); py_ = quad_sum(py_); pc = quad_sum(pc);                                  \
-          if (r == S) { sdx = px_; sdy = py_; chi = pc; }                                               \
-        }
-        SVO_FRES(0) SVO_FRES(1) SVO_FRES(2) SVO_FRES(3)
-#undef SVO_FRES
-
-        }
-        // ---- lane-per-patch: normal equations
+        // ---- normal equations
         const bool lin = ok && jvalid;
         if (ok) { acc_chi += (double)chi; acc_n += 16; }
         if (lin) {
-          double A[6], B[6];
-          patch_jacobian_rows(X[k].x, X[k].y, X[k].w, jscale, A, B);
-#pragma unroll
-          for (int kk = 0; kk < 6; ++kk) accJ[kk] -= A[kk] * sdx + B[kk] * sdy;
+          double zi = X[k].w;
+          asm volatile("" : "+v"(zi));                       // opaque: nothing derived from it is kept in registers across evaluations
+          // Jres_ -= J res (:273) with J = dx A + dy B summed over the patch: A sdx + B sdy written out in the
+          // normalised coordinates u = x/z, v = y/z; signs and fx/2^L are applied once after the reduction
+          const double u = X[k].x * zi, v = X[k].y * zi;
+          const double a = u * sdx + v * sdy;
+          accJ[0] += zi * sdx;
+          accJ[1] += zi * sdy;
+          accJ[2] += zi * a;
+          accJ[3] += v * a + sdy;
+          accJ[4] += u * a + sdx;
+          accJ[5] += v * sdx - u * sdy;
         }
         if (lane < 21) accH += th[k];
         unsigned long long gone = __ballot(jvalid && !ok);
@@ -934,7 +894,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
           const int src = __ffsll((long long)gone) - 1;
           gone &= gone - 1;
           const double gx_ = __shfl(X[k].x, src, 64), gy_ = __shfl(X[k].y, src, 64), gzi = __shfl(X[k].w, src, 64);
-          const double4 G4 = sxyz[(size_t)b * max_n + tile_base + (LPP ? src : 16 * (src & 3) + (src >> 2))];
+          const double4 G4 = sxyz[(size_t)b * max_n + tile_base + src];
           const double g_xx = G4.x, g_xy = G4.y, g_yy = G4.z;
           double A[6], B[6];
           patch_jacobian_rows(gx_, gy_, gzi, jscale, A, B);
@@ -949,20 +909,20 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         }
       }
 
-      // ---- wave reduction, then the 16 waves in fixed order, then the solve on one lane
-      double mine = accH;
-#pragma unroll
-      for (int kk = 0; kk < 6; ++kk) {
-        const double t = group_sum<64>(accJ[kk]);
-        if (lane == 21 + kk) mine = t;
-      }
+      // ---- wave reduction, then the waves in fixed order, then the solve on one lane
       {
-        const double t = group_sum<64>(acc_chi);
-        if (lane == 27) mine = t;
-        const int tn = group_sum<64>((int)acc_n);
-        if (lane == 28) mine = (double)tn;
+        // lanes 8j..8j+7 receive the wave total of value j: 0..5 = Jres moments (sign and fx/2^L applied here),
+        // 6 = chi2, 7 = number of measurements; red[wave][0..20] = H, [21..26] = Jres, [27] = chi2, [28] = n_meas
+        double v8[8];
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) v8[kk] = accJ[kk];
+        v8[6] = acc_chi; v8[7] = (double)acc_n;
+        const double t = wave_reduce8(v8);
+        const int j = lane >> 3;
+        const double sgn = (j == 0 || j == 1 || j == 4) ? jscale : (j < 6 ? -jscale : 1.0);
+        if (lane < 21) red[wave][lane] = accH;
+        if ((lane & 7) == 0) red[wave][21 + j] = t * sgn;
       }
-      if (lane < 32) red[wave][lane] = lane < 29 ? mine : 0.0;
 #ifdef SVO_STAMPS
       const long long t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1157,14 +1117,15 @@ int fused_tiles_per_wave(const svo_hip_sia* s, int n_slots) {
   const int tiles = (max_n + TILE - 1) / TILE;
   if (tiles > FUSED_MAX_TILES) return 0;
   const int tpw = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
+  static_assert(FUSED_MAX_TPW * FUSED_WAVES >= FUSED_MAX_TILES, "dispatch covers every tile count");
   return tpw < 1 ? 1 : tpw;
 }
 
-template <int TPW, bool LPP>
+template <int TPW>
 int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes) {
   svo_hip_ctx* ctx = s->ctx;
   // > 64 KiB of dynamic LDS has to be allowed explicitly (per device: set it on every launch, it is cheap)
-  SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<TPW, LPP>),
+  SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<TPW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_TILES * TILE * 56));
   FusedLevels lv;
   memset(&lv, 0, sizeof(lv));
@@ -1177,7 +1138,7 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   fp.early_stop = prm->early_stop; fp.eps = prm->eps;
   hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
-  hipLaunchKernelGGL((sia_fused_kernel<TPW, LPP>), dim3(n_slots), dim3(FUSED_THREADS), lds_bytes, ctx->stream, s->fc, s->st,
+  hipLaunchKernelGGL((sia_fused_kernel<TPW>), dim3(n_slots), dim3(FUSED_THREADS), lds_bytes, ctx->stream, s->fc, s->st,
                      s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, fp);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   SVO_CHECK_HIP(ctx, hipGetLastError());
@@ -1200,20 +1161,16 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tp
   const size_t lds = (size_t)tiles * TILE * 56;
   s->begun = false;
   s->last_mode = 1;
-  const char* lay = getenv("SVO_HIP_SIA_FUSED");
-  const bool lpp = !(lay && strcmp(lay, "quad") == 0);
-  if (lpp) {
-    switch (tpw) {
-      case 1: return launch_fused_t<1, true>(s, n_slots, prm, lds);
-      case 2: return launch_fused_t<2, true>(s, n_slots, prm, lds);
-      default: return launch_fused_t<3, true>(s, n_slots, prm, lds);
-    }
+  switch (tpw) {                 // tiles per wave
+    case 1: return launch_fused_t<1>(s, n_slots, prm, lds);
+    case 2: return launch_fused_t<2>(s, n_slots, prm, lds);
+    case 3: return launch_fused_t<3>(s, n_slots, prm, lds);
+    case 4: return launch_fused_t<4>(s, n_slots, prm, lds);
+    case 5: return launch_fused_t<5>(s, n_slots, prm, lds);
+    case 6: return launch_fused_t<6>(s, n_slots, prm, lds);
+    default: break;
   }
-  switch (tpw) {
-    case 1: return launch_fused_t<1, false>(s, n_slots, prm, lds);
-    case 2: return launch_fused_t<2, false>(s, n_slots, prm, lds);
-    default: return launch_fused_t<3, false>(s, n_slots, prm, lds);
-  }
+  return svo_fail(ctx, SVO_HIP_ERR_INVALID, "fused SparseImgAlign", "unsupported tiles-per-wave");
 }
 
 }  // namespace

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsvo_hip.so")
+LIB_PATH = os.environ.get("SVO_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvo_hip.so")   # override: A/B builds of the kernels
 MAX_LEVELS = 8
 REDUCE_DOUBLES = 32
 
