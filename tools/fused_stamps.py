@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (not part of the product or of bench.py): run the fused SparseImgAlign kernel from a build with
 -DSVO_STAMPS (build/libsvo_hip_stamps.so) and print where wave 1 of each workgroup spends its cycles per
-Gauss-Newton evaluation: evaluation+wave reduction / first barrier wait / 16-wave sum + one-lane solve + barrier."""
+Gauss-Newton evaluation: evaluation+wave reduction / first barrier wait / sum over the waves + one-lane solve + barrier."""
 import os
 import sys
 

@@ -3,6 +3,7 @@
 Usage: tools/pmc_summary.py counter_collection.csv [kernel-substring]"""
 import collections
 import csv
+import re
 import sys
 
 
@@ -16,7 +17,8 @@ def main():
             k = row["Kernel_Name"]
             if sub and sub not in k:
                 continue
-            k = k.split("(")[0][-40:]
+            m = re.search(r"(\w+)(<[^>]*>)?\(", k.replace("(anonymous namespace)::", ""))
+            k = (m.group(1) + (m.group(2) or "")) if m else k[:60]
             acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
             cnt[k][row["Counter_Name"]] += 1
     for k in acc:
