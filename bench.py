@@ -55,15 +55,36 @@ def parse_args():
 
 
 def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=16):
-    """The CPU oracle (port of the reference algorithm) on the host cores, bounded sample."""
+    """CPU baseline on the host cores, bounded sample.
+
+    Fixed-work workload (the default, BASELINE config C1's "30 GN iters"): the C oracle (`kind: port`) -- the
+    reference's solver cannot be made to do fixed work without editing it (its error-increase exit is unconditional).
+    Reference early-stop workload (--early-stop): the reference's OWN compiled SparseImgAlign (oracle/_ref, `kind:
+    reference`) when the prebuilt library travelled to this box, else the port.  In the fixed-work case the line
+    also carries a side-by-side early-stop timing of port and reference (`reference_check`), which shows how close
+    the port's speed is to the real thing."""
     from oracle import orc
     orc.lib()
+    try:
+        from oracle.ref import refpy
+        have_ref = refpy.available()
+        if have_ref:
+            refpy.lib()
+    except Exception:
+        have_ref = False
     n_threads = max(1, min(os.cpu_count() or 1, 16))
     done = [0] * n_threads
+    use_ref = bool(early_stop and have_ref)
+
+    def one(fp):
+        if use_ref:
+            refpy.sparse_img_align_run(fp, n_iter=n_iter)
+        else:
+            orc.sparse_img_align(fp, n_iter=n_iter, early_stop=early_stop)
 
     def work(t):
-        for k in range(frames_per_thread):
-            orc.sparse_img_align(fps[(t + k) % len(fps)], n_iter=n_iter, early_stop=early_stop)
+        for k in range(frames_per_thread * (8 if early_stop else 1)):
+            one(fps[(t + k) % len(fps)])
             done[t] += 1
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
@@ -73,12 +94,24 @@ def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=16):
     frames = sum(done)
     # single-thread figure too (the reference's run() is serial)
     t1 = time.perf_counter()
-    orc.sparse_img_align(fps[0], n_iter=n_iter, early_stop=early_stop)
+    one(fps[0])
     single = time.perf_counter() - t1
-    return {"value": frames / dt, "unit": "frames/s", "cores": n_threads, "kind": "port",
-            "sample": "%d frame pairs (640x480, %d patches, L4-L0, %s) on %d threads in %.1f s; 1 thread: %.2f frames/s" %
-                      (frames, len(fps[0].px), "early stop" if early_stop else "30 GN evaluations/level fixed work",
-                       n_threads, dt, 1.0 / single)}
+    out = {"value": frames / dt, "unit": "frames/s", "cores": n_threads, "kind": "reference" if use_ref else "port",
+           "sample": "%d frame pairs (640x480, %d patches, L4-L0, %s) on %d threads in %.1f s; 1 thread: %.2f frames/s" %
+                     (frames, len(fps[0].px), "early stop" if early_stop else "30 GN evaluations/level fixed work",
+                      n_threads, dt, 1.0 / single)}
+    if have_ref and not early_stop:
+        def timed(fn, reps=3):
+            fn()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (time.perf_counter() - t) / reps * 1e3
+        out["reference_check"] = {
+            "what": "one frame pair, reference early-stop semantics, 1 thread: the reference's own compiled SparseImgAlign (oracle/_ref) beside the port",
+            "reference_ms": timed(lambda: refpy.sparse_img_align_run(fps[0], n_iter=n_iter)),
+            "port_ms": timed(lambda: orc.sparse_img_align(fps[0], n_iter=n_iter, early_stop=True))}
+    return out
 
 
 def main():
@@ -222,7 +255,7 @@ def main():
             if os.path.exists(tr):
                 try:
                     k = json.load(open(tr))["kernels"].get(kernel)
-                    if k and k.get("batch") == n_slots:
+                    if k and k.get("batch") == n_slots and not args.early_stop:      # measured on the fixed-work run
                         roofline["traffic"] = k["bytes_per_launch"]
                         roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, 2xFETCH_SIZE+WRITE_SIZE)"
                 except Exception:

@@ -201,11 +201,128 @@ def gen_vision(rng):
                         half_odd=refpy.half_sample(img[:, :50].copy()))
 
 
+
+# ---- fixtures from the reference's own SparseImgAlign / Matcher member functions (oracle/ref/ref_objects.cpp) ----
+SIA_REF_CASES = [
+    # name, make_frame_pair kwargs, max_level, min_level, n_iter
+    ("c0_200", dict(seed=12345, n_features=200), 4, 0, 30),
+    ("c1_2000", dict(seed=12346, n_features=2000), 4, 0, 30),
+    ("c0_l2", dict(seed=12345, n_features=200), 4, 2, 30),
+    ("nulls_320", dict(seed=777, width=320, height=240, n_features=120, null_point_every=7, t_mag=0.015, r_mag=0.006), 4, 0, 30),
+    ("border_320", dict(seed=901, width=320, height=240, n_features=400, border=4, t_mag=0.02, r_mag=0.01), 4, 0, 30),
+    ("bigmotion_320", dict(seed=902, width=320, height=240, n_features=300, border=6, t_mag=0.12, r_mag=0.04), 4, 0, 30),
+    ("iters5", dict(seed=12347, n_features=600), 3, 1, 5),
+    ("empty", dict(seed=12345, n_features=0), 4, 0, 30),
+]
+
+
+def make_sia_case(kw):
+    kw = dict(kw)
+    if kw.get("n_features", 1) == 0:
+        kw["n_features"] = 8
+        fp = synth.make_frame_pair(**kw)
+        fp.px, fp.f, fp.pos, fp.has_point = fp.px[:0], fp.f[:0], fp.pos[:0], fp.has_point[:0]
+        return fp
+    return synth.make_frame_pair(**kw)
+
+
+def gen_sia_ref():
+    out = {}
+    for name, kw, max_level, min_level, n_iter in SIA_REF_CASES:
+        fp = make_sia_case(kw)
+        r = refpy.sparse_img_align_run(fp, max_level=max_level, min_level=min_level, n_iter=n_iter)
+        n = len(fp.px)
+        out[name + "_crc"] = np.array([crc(fp.ref_pyr[0]), crc(fp.cur_pyr[0]), crc(fp.px), crc(fp.pos)], dtype=np.uint64)
+        out[name + "_T"] = r["T_cur_w"]
+        out[name + "_n_tracked"] = np.array(r["n_tracked"])
+        out[name + "_H"] = r["H"]
+        out[name + "_chi2"] = np.array(r["chi2"])
+        out[name + "_stop"] = np.array(r["stop"])
+        out[name + "_iter"] = r["iter"]
+        out[name + "_n_meas"] = r["n_meas"]
+        out[name + "_visible"] = r["visible"]
+        k = min(n, 64)                      # the caches of the first 64 patches in full, checksums of everything
+        out[name + "_cache64"] = r["ref_patch_cache"][:k]
+        out[name + "_jac64"] = r["jacobian_cache"][:k * 16]
+        out[name + "_cache_crc"] = np.array([crc(r["ref_patch_cache"]), crc(r["jacobian_cache"])], dtype=np.uint64)
+        print("sia_ref", name, "n", n, "tracked", r["n_tracked"], "iter", r["iter"][:5], "stop", r["stop"])
+    np.savez_compressed(os.path.join(OUT, "sia_ref.npz"), **out)
+
+
+def epi_case_inputs():
+    """600 seeds on a 320x240 keyframe with four kinds of depth interval (see tests)."""
+    from android_svo_amd import seedsynth
+    sc = seedsynth.make_seed_case(n_seeds=600, seed=7, width=320, height=240, border=24)
+    rng = np.random.default_rng(1)
+    d_est, d_min, d_max = np.zeros(600), np.zeros(600), np.zeros(600)
+    for i in range(600):
+        d = sc.true_depth[i]
+        mode = i % 4
+        if mode == 0:
+            lo, hi = d * 0.98, d * 1.02                 # short epipolar segment: direct align2D
+        elif mode == 1:
+            lo, hi = d * 0.5, d * 3.0                   # ZMSSD search
+        elif mode == 2:
+            lo, hi = d * 0.15, d * 50.0                 # long segment, part of it outside the image
+        else:
+            lo, hi = d * rng.uniform(0.3, 0.9), d * rng.uniform(1.1, 4)
+        d_est[i], d_min[i], d_max[i] = d * rng.uniform(0.9, 1.1), lo, hi
+    return sc, d_est, d_min, d_max
+
+
+def gen_epi_ref():
+    sc, d_est, d_min, d_max = epi_case_inputs()
+    n = len(d_est)
+    ok = np.zeros(n, dtype=np.uint8)
+    depth, px_cur, lvl, epi = np.zeros(n), np.zeros((n, 2)), np.zeros(n, dtype=np.int32), np.zeros(n)
+    pwb = np.zeros((n, 100), dtype=np.uint8)
+    for i in range(n):
+        r = refpy.find_epipolar_match_direct(sc.cam, sc.ref_pyr, sc.cur_pyr, sc.T_ref_w, sc.T_cur_w, sc.px[i], sc.f[i],
+                                             int(sc.level[i]), d_est[i], d_min[i], d_max[i])
+        ok[i], depth[i], px_cur[i], lvl[i], epi[i], pwb[i] = r["ok"], r["depth"], r["px_cur"], r["search_level"], r["epi_length"], r["patch_with_border"]
+    T_cur_ref = refpy.se3_mul(sc.T_cur_w, refpy.se3_inverse(sc.T_ref_w))
+    np.savez_compressed(os.path.join(OUT, "epi_ref.npz"), crc=np.array([crc(sc.ref_pyr[0]), crc(sc.cur_pyr[0]), crc(sc.px)], dtype=np.uint64),
+                        d_est=d_est, d_min=d_min, d_max=d_max, T_cur_ref=T_cur_ref, ok=ok, depth=depth, px_cur=px_cur,
+                        search_level=lvl, epi_length=epi, pwb=pwb)
+    print("epi_ref ok", int(ok.sum()), "of", n)
+
+
+def match_direct_inputs():
+    fp = synth.make_frame_pair(seed=4711, width=320, height=240, n_features=300, border=12)
+    rng = np.random.default_rng(3)
+    n = len(fp.px)
+    px_in, lvl, edge, grad = np.zeros((n, 2)), np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.uint8), np.zeros((n, 2))
+    for i in range(n):
+        Xc = synth.se3_act(fp.T_cur_w_true, fp.pos[i])
+        px_in[i] = np.array([fp.cam.fx * Xc[0] / Xc[2] + fp.cam.cx, fp.cam.fy * Xc[1] / Xc[2] + fp.cam.cy]) + rng.uniform(-2.5, 2.5, 2)
+        lvl[i] = i % 3
+        edge[i] = 1 if i % 5 == 0 else 0
+        g = rng.normal(size=2)
+        grad[i] = g / np.linalg.norm(g)
+    return fp, px_in, lvl, edge, grad
+
+
+def gen_match_direct_ref():
+    fp, px_in, lvl, edge, grad = match_direct_inputs()
+    n = len(px_in)
+    ok, px_out, sl = np.zeros(n, dtype=np.uint8), np.zeros((n, 2)), np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        r = refpy.find_match_direct(fp.cam, fp.ref_pyr, fp.cur_pyr, fp.T_ref_w, fp.T_cur_w_true, fp.px[i], fp.f[i],
+                                    int(lvl[i]), fp.pos[i], px_in[i], edgelet=bool(edge[i]), grad=grad[i])
+        ok[i], px_out[i], sl[i] = r["ok"], r["px_cur"], r["search_level"]
+    np.savez_compressed(os.path.join(OUT, "match_direct_ref.npz"),
+                        crc=np.array([crc(fp.ref_pyr[0]), crc(fp.cur_pyr[0]), crc(fp.px)], dtype=np.uint64),
+                        px_in=px_in, level=lvl, edgelet=edge, grad=grad, ok=ok, px_out=px_out, search_level=sl)
+    print("match_direct_ref ok", int(ok.sum()), "of", n)
+
+
 def main():
     assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(OUT, exist_ok=True)
-    rng = np.random.default_rng(20240607)
-    gen_se3(rng); gen_algebra(rng); gen_gn(rng); gen_align(rng); gen_matcher(rng); gen_vision(rng)
+    if "--objects-only" not in sys.argv:
+        rng = np.random.default_rng(20240607)
+        gen_se3(rng); gen_algebra(rng); gen_gn(rng); gen_align(rng); gen_matcher(rng); gen_vision(rng)
+    gen_sia_ref(); gen_epi_ref(); gen_match_direct_ref()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

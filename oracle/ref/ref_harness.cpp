@@ -4,15 +4,14 @@
 //
 // What is compiled: the reference translation units feature_alignment.cpp,
 // matcher.cpp, vision.cpp, point.cpp, config.cpp, robust_cost.cpp, math_utils.cpp,
-// unmodified, from /root/reference, plus the reference's header-only code (SE3.h,
-// SO3.h, frame.h, nlls_solver*.h, patch_score.h, vendored Eigen 3.4.0).  These link
-// with no OpenCV symbol at all.
+// sparse_img_align.cpp, unmodified, from /root/reference, plus the reference's
+// header-only code (SE3.h, SO3.h, frame.h, nlls_solver*.h, patch_score.h, vendored
+// Eigen 3.4.0).  This file uses the free functions and header templates; the member
+// functions that need real Frame / SparseImgAlign objects are driven by ref_objects.cpp.
 //
-// What is NOT compiled (unbuildable here without stand-ins, so left unpinned):
-// sparse_img_align.cpp, frame.cpp (need the OpenCV core library: cv::Mat ctors /
-// dtor are out-of-line in 4.5.4), depth_filter.cpp (needs <android/log.h>),
-// pinhole_camera.cpp (cv::initUndistortRectifyMap).  No stub library and no fake
-// header is written for them.
+// What is NOT compiled (unbuildable here without stand-ins): frame.cpp (OpenCV core
+// library), depth_filter.cpp (needs <android/log.h>), pinhole_camera.cpp
+// (cv::initUndistortRectifyMap).  No stub library and no fake header is written.
 //
 // cv::Mat: align2D/align1D/warpAffine/interpolateMat_8u/halfSample read an image
 // only through the public fields data/rows/cols/step.  No cv::Mat can be
@@ -36,6 +35,7 @@
 #include <svo/math_utils.h>
 
 #include "../svo_oracle.h"
+#include "ref_common.h"
 
 // defined (non-static) in matcher.cpp:123-136 but not declared in matcher.h
 namespace svo {
@@ -43,54 +43,9 @@ bool depthFromTriangulation(const SE3& T_search_ref, const Vector3d& f_ref, cons
                             double& depth);
 }
 
+using namespace refh;
+
 namespace {
-
-struct MatView {
-  alignas(cv::Mat) unsigned char storage[sizeof(cv::Mat)];
-  cv::Mat& set(const uint8_t* data, int rows, int cols, int stride) {
-    std::memset(storage, 0, sizeof(storage));
-    cv::Mat& m = *reinterpret_cast<cv::Mat*>(storage);
-    m.flags = cv::Mat::MAGIC_VAL | CV_8UC1 | (stride == cols ? cv::Mat::CONTINUOUS_FLAG : 0);
-    m.dims = 2;
-    m.rows = rows;
-    m.cols = cols;
-    m.data = const_cast<uint8_t*>(data);
-    m.datastart = m.data;
-    m.dataend = m.datalimit = m.data + (size_t)rows * stride;
-    m.size.p = &m.rows;
-    m.step.p = m.step.buf;
-    m.step.buf[0] = (size_t)stride;
-    m.step.buf[1] = 1;
-    return m;
-  }
-};
-
-// Distortion-free pinhole behind the reference's vk::AbstractCamera interface
-// (the reference's PinholeCamera cannot be linked: its ctor needs OpenCV).
-class HarnessPinhole : public vk::AbstractCamera {
- public:
-  double fx_, fy_, cx_, cy_;
-  HarnessPinhole(int w, int h, double fx, double fy, double cx, double cy)
-      : vk::AbstractCamera(w, h), fx_(fx), fy_(fy), cx_(cx), cy_(cy) {}
-  Eigen::Vector3d cam2world(const double& u, const double& v) const override {
-    Eigen::Vector3d xyz((u - cx_) / fx_, (v - cy_) / fy_, 1.0);
-    return xyz.normalized();
-  }
-  Eigen::Vector3d cam2world(const Eigen::Vector2d& px) const override { return cam2world(px[0], px[1]); }
-  Eigen::Vector2d world2cam(const Eigen::Vector3d& xyz) const override { return world2cam(vk::project2d(xyz)); }
-  Eigen::Vector2d world2cam(const Eigen::Vector2d& uv) const override {
-    return Eigen::Vector2d(fx_ * uv[0] + cx_, fy_ * uv[1] + cy_);
-  }
-  double errorMultiplier2() const override { return std::fabs(fx_); }
-  double errorMultiplier() const override { return std::fabs(4.0 * fx_ * fy_); }
-};
-
-SE3 to_se3(const double* T) { return SE3(T[0], T[1], T[2], T[3], T[4], T[5], T[6]); }
-void from_se3(const SE3& s, double* T) {
-  T[0] = s.get_translation().x; T[1] = s.get_translation().y; T[2] = s.get_translation().z;
-  T[3] = s.get_rotation().x; T[4] = s.get_rotation().y; T[5] = s.get_rotation().z;
-  T[6] = s.get_rotation().w;
-}
 
 // The reference's Gauss-Newton driver (nlls_solver_impl.hpp) with the residual
 // body supplied by the C restatement; solve()/update() are the two statements of

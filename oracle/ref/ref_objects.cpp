@@ -1,0 +1,233 @@
+// ref_objects.cpp -- runs the REFERENCE's compiled SparseImgAlign and Matcher member functions on
+// real svo::Frame / svo::Feature / svo::Point objects (TEST INFRASTRUCTURE ONLY, built into
+// oracle/_ref/libsvo_ref.so by `make -C oracle ref`, only where /root/reference is mounted).
+//
+// What runs, unmodified, from the reference's own translation units:
+//   sparse_img_align.cpp : precomputeReferencePatches, computeResiduals, solve, update,
+//                          startIteration, finishIteration (reached through the class's own vtable)
+//   nlls_solver_impl.hpp : reset, optimize, optimizeGaussNewton (the header's templates)
+//   matcher.cpp          : Matcher::findEpipolarMatchDirect, Matcher::findMatchDirect and everything
+//                          they call (warp::*, align2D/align1D, ZMSSD, depthFromTriangulation)
+//   point.cpp            : Point constructors, Point::getCloseViewObs
+//
+// What does NOT run: SparseImgAlign's constructor and SparseImgAlign::run, and Frame's constructor.
+// All three call out-of-line cv::Mat constructors of the OpenCV core library, which this image does
+// not have (only Android-ABI archives are vendored); no stand-in for that library is written.  Their
+// symbols stay unresolved in the shared object (lazy binding) and are never reached.  Instead the
+// harness lays the objects out by hand in zeroed storage: the fields are set to what the inline base
+// constructor (nlls_solver.h:96-116) and the constructor body (sparse_img_align.cpp:29-41) assign, the
+// vptr is pointed at the class's own vtable, cv::Mat headers get their public fields filled (as in
+// MatView), and the dozen driver statements of run() (:51-92) are performed here through the object's
+// own members.  Every arithmetic statement that produces a compared number is reference code.
+#include <cstdlib>
+#include <list>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include <svo/global.h>
+#include <svo/config.h>
+#include <svo/frame.h>
+#include <svo/feature.h>
+#include <svo/point.h>
+#include <svo/matcher.h>
+#include <svo/robust_cost.h>
+
+// the cache members and the GN state of SparseImgAlign are protected; access specifiers do not change
+// the layout gcc gives the class
+#define protected public
+#include <svo/nlls_solver.h>
+#include <svo/sparse_img_align.h>
+#undef protected
+
+#include "ref_common.h"
+
+using namespace refh;
+
+// vtable of svo::SparseImgAlign, emitted in the reference's sparse_img_align.o
+extern "C" char _ZTVN3svo14SparseImgAlignE[];
+
+namespace {
+
+static_assert(sizeof(std::vector<cv::Mat>) == 3 * sizeof(void*), "libstdc++ vector = {begin, end, end_of_storage}");
+
+// A svo::Frame in raw storage: pose, camera, feature list and an image pyramid that aliases the caller's
+// level buffers.  Frame::Frame (frame.cpp) is never called.
+struct HandFrame {
+  void* storage = nullptr;
+  void* mats = nullptr;
+  svo::Frame* f = nullptr;
+  std::vector<svo::Point*> points;
+
+  HandFrame(vk::AbstractCamera* cam, const uint8_t* const* pyr, int width, int height, int n_levels, const double* T_f_w) {
+    storage = ::aligned_alloc(32, (sizeof(svo::Frame) + 31) / 32 * 32);
+    std::memset(storage, 0, sizeof(svo::Frame));
+    f = reinterpret_cast<svo::Frame*>(storage);
+    static int next_id = 0;            // Frame::frame_counter_ is defined in frame.cpp (not built)
+    f->id_ = next_id++;
+    f->timestamp_ = 0.0;
+    f->cam_ = cam;
+    f->T_f_w_ = to_se3(T_f_w);
+    f->is_keyframe_ = false;
+    new (&f->fts_) svo::Features();
+    new (&f->key_pts_) std::vector<svo::Feature*>(5, nullptr);
+    mats = ::aligned_alloc(32, (sizeof(cv::Mat) * n_levels + 31) / 32 * 32);
+    cv::Mat* m = reinterpret_cast<cv::Mat*>(mats);
+    for (int l = 0; l < n_levels; ++l)
+      fill_mat_header(&m[l], const_cast<uint8_t*>(pyr[l]), height >> l, width >> l, (size_t)(width >> l), CV_8UC1);
+    cv::Mat* rep[3] = {m, m + n_levels, m + n_levels};
+    std::memcpy(static_cast<void*>(&f->img_pyr_), rep, sizeof(rep));
+  }
+  svo::Feature* add_feature(const double* px, const double* fv, int level, const double* pos /*or null*/) {
+    svo::Feature* ftr = new svo::Feature(f, Eigen::Vector2d(px[0], px[1]), Eigen::Vector3d(fv[0], fv[1], fv[2]), level);
+    if (pos) {
+      svo::Point* pt = new svo::Point(Eigen::Vector3d(pos[0], pos[1], pos[2]), ftr);
+      ftr->point = pt;
+      points.push_back(pt);
+    }
+    f->fts_.push_back(ftr);
+    return ftr;
+  }
+  svo::FramePtr ptr() { return svo::FramePtr(f, [](svo::Frame*) {}); }
+  ~HandFrame() {
+    for (svo::Feature* ftr : f->fts_) delete ftr;
+    for (svo::Point* p : points) delete p;
+    f->fts_.~list();
+    f->key_pts_.~vector();
+    std::free(mats);       // the cv::Mat headers own nothing
+    std::free(storage);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+// The reference's SparseImgAlign on one frame pair (see the file header for what is hand-laid).
+// Outputs: pose, n_meas_/16, H_, chi2_, iter_ and n_meas_ per level (after that level's optimize), and the
+// caches as they stand after the last level: ref_patch_cache_ [n][16] f32, jacobian_cache_ [n*16][6] f64
+// (column-major 6 x 16n), visible_fts_ [n].
+int ref_sparse_img_align_run(int width, int height, double fx, double fy, double cx, double cy, int n_levels,
+                             const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr, int n,
+                             const double* px, const double* fv, const double* pos, const uint8_t* has_point,
+                             const double* T_ref_w, const double* T_cur_w_init, int max_level, int min_level,
+                             int n_iter, double* T_cur_w_out, size_t* n_tracked, double* H_out, double* chi2_out,
+                             int* stop_out, int* iter_per_level /*[8]*/, size_t* n_meas_per_level /*[8]*/,
+                             float* ref_patch_cache_out, double* jacobian_cache_out, uint8_t* visible_out) {
+  HarnessPinhole cam(width, height, fx, fy, cx, cy);
+  HandFrame ref(&cam, ref_pyr, width, height, n_levels, T_ref_w);
+  HandFrame cur(&cam, cur_pyr, width, height, n_levels, T_cur_w_init);
+  for (int i = 0; i < n; ++i) ref.add_feature(px + 2 * i, fv + 3 * i, 0, has_point[i] ? pos + 3 * i : nullptr);
+  svo::FramePtr ref_frame = ref.ptr(), cur_frame = cur.ptr();
+
+  void* storage = ::aligned_alloc(32, (sizeof(svo::SparseImgAlign) + 31) / 32 * 32);
+  std::memset(storage, 0, sizeof(svo::SparseImgAlign));
+  *reinterpret_cast<void**>(storage) = _ZTVN3svo14SparseImgAlignE + 2 * sizeof(void*);
+  svo::SparseImgAlign* s = reinterpret_cast<svo::SparseImgAlign*>(storage);
+  // vk::NLLSSolver<6,SE3>::NLLSSolver() (nlls_solver.h:96-116)
+  s->have_prior_ = false;
+  s->mu_init_ = 0.01f; s->mu_ = s->mu_init_;
+  s->nu_init_ = 2.0; s->nu_ = s->nu_init_;
+  s->n_trials_ = 0; s->n_trials_max_ = 5; s->n_meas_ = 0;
+  s->stop_ = false; s->iter_ = 0;
+  s->use_weights_ = false; s->scale_ = 0.0;
+  // SparseImgAlign::SparseImgAlign(max_level, min_level, n_iter, GaussNewton, false, false) (:29-41)
+  s->display_ = false; s->max_level_ = max_level; s->min_level_ = min_level;
+  s->n_iter_ = n_iter; s->n_iter_init_ = s->n_iter_;
+  s->method_ = svo::SparseImgAlign::GaussNewton;
+  s->verbose_ = false;
+  s->eps_ = 0.000001;
+
+  // SparseImgAlign::run (:51-92)
+  size_t ret = 0;
+  s->reset();
+  float* cache = nullptr;
+  if (!ref_frame->fts_.empty()) {
+    s->ref_frame_ = ref_frame;
+    s->cur_frame_ = cur_frame;
+    cache = static_cast<float*>(std::calloc((size_t)n * 16, sizeof(float)));
+    fill_mat_header(&s->ref_patch_cache_, cache, n, 16, 16 * sizeof(float), CV_32FC1);
+    s->jacobian_cache_.resize(Eigen::NoChange, s->ref_patch_cache_.rows * 16);
+    s->visible_fts_.resize(s->ref_patch_cache_.rows, false);
+    SE3 T_cur_from_ref(cur_frame->T_f_w_ * ref_frame->T_f_w_.inverse());
+    for (s->level_ = s->max_level_; s->level_ >= s->min_level_; --s->level_) {
+      s->mu_ = 0.1;
+      s->jacobian_cache_.setZero();
+      s->have_ref_patch_cache_ = false;
+      s->optimize(T_cur_from_ref);
+      if (s->level_ < 8) { iter_per_level[s->level_] = (int)s->iter_; n_meas_per_level[s->level_] = s->n_meas_; }
+    }
+    cur_frame->T_f_w_ = T_cur_from_ref * ref_frame->T_f_w_;
+    ret = s->n_meas_ / 16;
+  }
+  from_se3(cur_frame->T_f_w_, T_cur_w_out);
+  *n_tracked = ret;
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) H_out[6 * i + j] = s->H_(i, j);
+  *chi2_out = s->chi2_;
+  *stop_out = s->stop_ ? 1 : 0;
+  if (cache) {
+    if (ref_patch_cache_out) std::memcpy(ref_patch_cache_out, cache, (size_t)n * 16 * sizeof(float));
+    if (jacobian_cache_out) std::memcpy(jacobian_cache_out, s->jacobian_cache_.data(), (size_t)n * 16 * 6 * sizeof(double));
+    if (visible_out) for (int i = 0; i < n; ++i) visible_out[i] = s->visible_fts_[i] ? 1 : 0;
+  }
+  // tear down by hand (no destructor of the hand-laid object runs)
+  s->jacobian_cache_.resize(Eigen::NoChange, 0);
+  s->visible_fts_.~vector();
+  s->ref_frame_.reset();
+  s->cur_frame_.reset();
+  std::free(cache);
+  std::free(storage);
+  return 0;
+}
+
+// Matcher::findEpipolarMatchDirect (matcher.cpp:207-355) on real frames.
+int ref_find_epipolar_match_direct(int width, int height, double fx, double fy, double cx, double cy, int n_levels,
+                                   const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr,
+                                   const double* T_ref_w, const double* T_cur_w, const double* px_ref,
+                                   const double* f_ref, int level_ref, double d_estimate, double d_min, double d_max,
+                                   double* depth, double* px_cur, int* search_level, double* epi_length,
+                                   uint8_t* patch_with_border /*100*/) {
+  HarnessPinhole cam(width, height, fx, fy, cx, cy);
+  HandFrame ref(&cam, ref_pyr, width, height, n_levels, T_ref_w);
+  HandFrame cur(&cam, cur_pyr, width, height, n_levels, T_cur_w);
+  svo::Feature* ftr = ref.add_feature(px_ref, f_ref, level_ref, nullptr);
+  svo::Matcher* m = new svo::Matcher();
+  std::memset(m->patch_with_border_, 0, sizeof(m->patch_with_border_));
+  std::memset(m->patch_, 0, sizeof(m->patch_));
+  m->px_cur_ = Eigen::Vector2d(0, 0);
+  m->search_level_ = -1;
+  m->epi_length_ = -1.0;
+  double z = 0.0;
+  const bool ok = m->findEpipolarMatchDirect(*ref.f, *cur.f, *ftr, d_estimate, d_min, d_max, z);
+  *depth = z;
+  px_cur[0] = m->px_cur_[0]; px_cur[1] = m->px_cur_[1];
+  *search_level = m->search_level_;
+  *epi_length = m->epi_length_;
+  std::memcpy(patch_with_border, m->patch_with_border_, 100);
+  delete m;
+  return ok ? 1 : 0;
+}
+
+// Matcher::findMatchDirect (matcher.cpp:156-202): the point has one observation (the reference feature).
+int ref_find_match_direct(int width, int height, double fx, double fy, double cx, double cy, int n_levels,
+                          const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr, const double* T_ref_w,
+                          const double* T_cur_w, const double* px_ref, const double* f_ref, int level_ref,
+                          const double* pt_pos, int edgelet, const double* grad, double* px_cur, int* search_level) {
+  HarnessPinhole cam(width, height, fx, fy, cx, cy);
+  HandFrame ref(&cam, ref_pyr, width, height, n_levels, T_ref_w);
+  HandFrame cur(&cam, cur_pyr, width, height, n_levels, T_cur_w);
+  svo::Feature* ftr = ref.add_feature(px_ref, f_ref, level_ref, pt_pos);
+  if (edgelet) { ftr->type = svo::Feature::EDGELET; ftr->grad = Eigen::Vector2d(grad[0], grad[1]); }
+  svo::Matcher* m = new svo::Matcher();
+  std::memset(m->patch_with_border_, 0, sizeof(m->patch_with_border_));
+  std::memset(m->patch_, 0, sizeof(m->patch_));
+  m->search_level_ = -1;
+  Eigen::Vector2d p(px_cur[0], px_cur[1]);
+  const bool ok = m->findMatchDirect(*ftr->point, *cur.f, p);
+  px_cur[0] = p[0]; px_cur[1] = p[1];
+  *search_level = m->search_level_;
+  delete m;
+  return ok ? 1 : 0;
+}
+
+}  // extern "C"

@@ -24,7 +24,9 @@ def available() -> bool:
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(_LIB_PATH)
+        # RTLD_LAZY: sparse_img_align.o keeps unresolved references to OpenCV functions on paths that are never
+        # called (see oracle/ref/ref_objects.cpp); ctypes' default mode would insist on resolving them
+        _lib = C.CDLL(_LIB_PATH, mode=os.RTLD_LAZY)
         _lib.ref_interpolate_8u.restype = C.c_float
     return _lib
 
@@ -167,3 +169,59 @@ def half_sample(img, force_scalar=False):
     o = rawo[offo:offo + (h // 2) * (w // 2)].reshape(h // 2, w // 2)
     lib().ref_half_sample(_p(a, C.c_uint8), w, h, _p(o, C.c_uint8))
     return o.copy()
+
+
+# ---- the reference's own SparseImgAlign / Matcher member functions on real objects (ref_objects.cpp) ----
+def _cam_args(cam):
+    return (C.c_int(cam.width), C.c_int(cam.height), D(cam.fx), D(cam.fy), D(cam.cx), D(cam.cy))
+
+
+def sparse_img_align_run(fp, max_level=4, min_level=0, n_iter=30, T_cur_w_init=None):
+    rp, cp = orc.pyr_ptrs(fp.ref_pyr), orc.pyr_ptrs(fp.cur_pyr)
+    px, f, pos = f64(fp.px), f64(fp.f), f64(fp.pos)
+    n = len(px)
+    hp = np.ascontiguousarray(fp.has_point, dtype=np.uint8)
+    T_ref = f64(fp.T_ref_w)
+    T_init = f64(fp.T_cur_w_init if T_cur_w_init is None else T_cur_w_init)
+    T_out, H = np.zeros(7), np.zeros(36)
+    nt, chi2, stop = C.c_size_t(0), D(0), C.c_int(0)
+    iters = np.zeros(8, dtype=np.int32)
+    n_meas = np.zeros(8, dtype=np.uint64)
+    cache = np.zeros((max(n, 1), 16), dtype=np.float32)
+    jac = np.zeros((max(n, 1) * 16, 6))
+    vis = np.zeros(max(n, 1), dtype=np.uint8)
+    lib().ref_sparse_img_align_run(*_cam_args(fp.cam), C.c_int(len(fp.ref_pyr)), rp, cp, C.c_int(n), _p(px, D), _p(f, D),
+                                   _p(pos, D), _p(hp, C.c_uint8), _p(T_ref, D), _p(T_init, D), C.c_int(max_level),
+                                   C.c_int(min_level), C.c_int(n_iter), _p(T_out, D), C.byref(nt), _p(H, D),
+                                   C.byref(chi2), C.byref(stop), _p(iters, C.c_int), _p(n_meas, C.c_size_t),
+                                   _p(cache, C.c_float), _p(jac, D), _p(vis, C.c_uint8))
+    return {"T_cur_w": T_out, "n_tracked": nt.value, "H": H, "chi2": chi2.value, "stop": stop.value, "iter": iters,
+            "n_meas": n_meas, "ref_patch_cache": cache[:n], "jacobian_cache": jac[:n * 16], "visible": vis[:n]}
+
+
+def find_epipolar_match_direct(cam, ref_pyr, cur_pyr, T_ref_w, T_cur_w, px_ref, f_ref, level_ref, d_estimate, d_min,
+                               d_max):
+    rp, cp = orc.pyr_ptrs(ref_pyr), orc.pyr_ptrs(cur_pyr)
+    Tr, Tc, p, ff = f64(T_ref_w), f64(T_cur_w), f64(px_ref), f64(f_ref)
+    depth, epi = D(0), D(0)
+    px_cur = np.zeros(2)
+    lvl = C.c_int(0)
+    pwb = np.zeros(100, dtype=np.uint8)
+    ok = lib().ref_find_epipolar_match_direct(*_cam_args(cam), C.c_int(len(ref_pyr)), rp, cp, _p(Tr, D), _p(Tc, D),
+                                              _p(p, D), _p(ff, D), C.c_int(level_ref), D(d_estimate), D(d_min),
+                                              D(d_max), C.byref(depth), _p(px_cur, D), C.byref(lvl), C.byref(epi),
+                                              _p(pwb, C.c_uint8))
+    return {"ok": bool(ok), "depth": depth.value, "px_cur": px_cur, "search_level": lvl.value,
+            "epi_length": epi.value, "patch_with_border": pwb}
+
+
+def find_match_direct(cam, ref_pyr, cur_pyr, T_ref_w, T_cur_w, px_ref, f_ref, level_ref, pt_pos, px_cur, edgelet=False,
+                      grad=(1.0, 0.0)):
+    rp, cp = orc.pyr_ptrs(ref_pyr), orc.pyr_ptrs(cur_pyr)
+    Tr, Tc, p, ff, pp, g = f64(T_ref_w), f64(T_cur_w), f64(px_ref), f64(f_ref), f64(pt_pos), f64(grad)
+    pc = f64(px_cur).copy()
+    lvl = C.c_int(0)
+    ok = lib().ref_find_match_direct(*_cam_args(cam), C.c_int(len(ref_pyr)), rp, cp, _p(Tr, D), _p(Tc, D), _p(p, D),
+                                     _p(ff, D), C.c_int(level_ref), _p(pp, D), C.c_int(1 if edgelet else 0), _p(g, D),
+                                     _p(pc, D), C.byref(lvl))
+    return {"ok": bool(ok), "px_cur": pc, "search_level": lvl.value}

@@ -11,16 +11,18 @@
  * Pinning status (see oracle/README.md and DESIGN.md):
  *   pinned against the reference's own code compiled here (oracle/_ref):
  *     SE3/SO3 algebra, Frame::jacobian_xyz2uv, Eigen LDLT 6x6 solve,
- *     NLLSSolver Gauss-Newton control flow, feature_alignment::align2D/align1D,
+ *     the whole SparseImgAlign::run (precomputeReferencePatches, computeResiduals,
+ *     solve, update and the NLLSSolver Gauss-Newton control flow: H_ bit-identical,
+ *     caches bit-exact, iteration counts equal), feature_alignment::align2D/align1D,
  *     ZMSSD, warp::getWarpMatrixAffine/getBestSearchLevel/warpAffine,
- *     depthFromTriangulation, vk::interpolateMat_8u, vk::halfSample.
+ *     depthFromTriangulation, Matcher::findEpipolarMatchDirect and
+ *     Matcher::findMatchDirect end to end, vk::interpolateMat_8u, vk::halfSample.
  *   pinned by the known-answer vector recorded in SURVEY.md 8(a-9):
  *     Seed ctor + DepthFilter::updateSeed.
- *   PARITY UNPINNED (restated from source text only; the reference translation
- *   units need the OpenCV core library and the Android NDK log header, both
- *   absent here, so they are unbuildable under the no-stand-ins rule):
- *     SparseImgAlign::precomputeReferencePatches / computeResiduals bodies,
- *     Matcher::findEpipolarMatchDirect glue loop, DepthFilter::updateSeeds glue,
+ *   PARITY UNPINNED (restated from source text only; depth_filter.cpp needs the
+ *   Android NDK log header, absent here, so it is unbuildable under the
+ *   no-stand-ins rule):
+ *     the per-seed glue of DepthFilter::updateSeeds around the matcher call,
  *     DepthFilter::computeTau.
  *
  * Conventions: SE3 = double[7] {tx,ty,tz,qx,qy,qz,qw} (reference SE3.h/SO3.h

@@ -653,3 +653,67 @@ def test_depth_filter_all_paths(ctx):
     nanseed = np.isnan(s2)
     assert (st[nanseed] == o["status"][nanseed]).all()
     _free(sb, kf, cf)
+
+
+# ---- the HIP path against the reference's OWN compiled member functions (tests/golden/*_ref.npz, made by
+# ---- oracle/gen_golden.py from oracle/ref/ref_objects.cpp; see tests/test_oracle_reference_objects.py)
+def _ref_cases():
+    from oracle import gen_golden
+    return gen_golden.SIA_REF_CASES
+
+
+@pytest.mark.parametrize("case", _ref_cases(), ids=[c[0] for c in _ref_cases()])
+def test_sparse_img_align_against_reference_run(ctx, sia_mode, golden, case):
+    """svo_hip_sia_run against SparseImgAlign::run executed by the reference's own code: pose within the north-star
+    tolerance (observed: 1e-13), tracked-patch count exact, H of the last evaluation to 1e-9 relative."""
+    from oracle import gen_golden
+    name, kw, max_level, min_level, n_iter = case
+    g = golden("sia_ref.npz")
+    fp = gen_golden.make_sia_case(kw)
+    ref, cur, sia = _upload_pair(ctx, [fp], max_feat=max(len(fp.px), 1))
+    prm = sia.params(max_level=max_level, min_level=min_level, n_iter=n_iter, eps=1e-6, early_stop=True)
+    sia.run(1, prm)
+    r = sia.download(0)
+    rot, trans = synth.pose_error(np.array(r.T_cur_w), g[name + "_T"])
+    assert rot < 1e-4 and trans < 1e-3, (rot, trans)            # north_star tolerance
+    assert rot < 2e-5 and trans < 5e-5, (rot, trans)            # what chi2-order exit flips can cost at most here
+    assert r.n_tracked == int(g[name + "_n_tracked"])
+    assert int(r.stop) == int(g[name + "_stop"])
+    if len(fp.px):
+        same_iters = all(r.iters[l] == int(g[name + "_iter"][l]) + 1 for l in range(min_level, max_level + 1))
+        if same_iters:                                          # same evaluation sequence: everything agrees closely
+            assert rot < 1e-7 and trans < 1e-7, (rot, trans)     # 5e-9 in the large-motion case, 1e-13 otherwise
+            H = np.array(r.H)
+            assert np.abs(H - g[name + "_H"]).max() <= 1e-6 * np.abs(g[name + "_H"]).max()
+    _free(sia, ref, cur)
+
+
+def test_match_direct_against_reference_fixture(ctx, golden):
+    """svo_hip_match_direct_batch_dev against Matcher::findMatchDirect executed by the reference's own code."""
+    from oracle import gen_golden
+    g = golden("match_direct_ref.npz")
+    fp, px_in, lvl, edge, grad = gen_golden.match_direct_inputs()
+    cam = fp.cam
+    ref = hip.Pyramid(ctx, cam.width, cam.height, 5, 1)
+    cur = hip.Pyramid(ctx, cam.width, cam.height, 5, 1)
+    ref.upload(0, fp.ref_pyr)
+    cur.upload(0, fp.cur_pyr)
+    n = len(px_in)
+    ok, px_out, sl = hip.match_direct_batch(ctx, ref, cur, 0, cam, fp.T_ref_w[None, :], fp.T_cur_w_true,
+                                            np.zeros(n, dtype=np.int32), fp.px, fp.f, lvl, fp.pos, px_in,
+                                            edgelet=edge, grad=grad)
+    g_ok = g["ok"].astype(bool)
+    chosen = g["search_level"] >= 0                               # -1: the reference returned before choosing a level
+    np.testing.assert_array_equal(sl[chosen], g["search_level"][chosen])        # integer decision: exact
+    np.testing.assert_array_equal(px_out[~chosen], px_in[~chosen])              # untouched when the frame test fails
+    assert not ok[~chosen].any()
+    corner = chosen & (edge == 0)
+    assert (ok[corner] != g_ok[corner]).mean() < 0.02
+    both = corner & ok & g_ok
+    assert both.sum() > 100
+    assert np.abs(px_out[both] - g["px_out"][both]).max() < 5e-3    # f32 LK, wave butterfly sums instead of a serial sum
+    e1 = chosen & (edge == 1)
+    both1 = e1 & ok & g_ok
+    assert both1.sum() > 20
+    assert np.percentile(np.abs(px_out[both1] - g["px_out"][both1]).max(axis=1), 95) < 2e-2
+    ref.destroy(); cur.destroy()
