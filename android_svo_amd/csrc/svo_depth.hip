@@ -770,14 +770,12 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
   fr.conv_thresh = prm->seed_convergence_sigma2_thresh;
   // per-seed records between the stages: grow-only scratch owned by the context
   const size_t need = (size_t)n * sizeof(SeedRec);
-  if (ctx->scratch_bytes < need) {
-    if (ctx->scratch) { SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
-    void* p = nullptr;
-    int rc = svo_hip_malloc(ctx, &p, need + need / 4);
+  void* ws = nullptr;
+  {
+    const int rc = svo_ctx_scratch(ctx, need, &ws);
     if (rc != SVO_HIP_OK) return rc;
-    ctx->scratch = p; ctx->scratch_bytes = need + need / 4;
   }
-  SeedRec* recs = (SeedRec*)ctx->scratch;
+  SeedRec* recs = (SeedRec*)ws;
   const uint8_t* ref_img = ref->base + (size_t)ref_slot * ref->pyr_bytes;
   const uint8_t* cur_img = cur->base + (size_t)cur_slot * cur->pyr_bytes;
   hipLaunchKernelGGL(df_geometry_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, px, f, level, mu, sigma2, recs);
@@ -807,14 +805,12 @@ int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref,
   SVO_REQUIRE(ctx, T_ref_w_dev && kf_slot_dev && px_ref_dev && f_ref_dev && level_ref_dev && pt_pos_dev && px_cur_dev && success_dev);
   SVO_REQUIRE(ctx, !edgelet_dev || grad_dev);
   const size_t need = (size_t)n * sizeof(SeedRec);
-  if (ctx->scratch_bytes < need) {
-    if (ctx->scratch) { SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
-    void* p = nullptr;
-    int rc = svo_hip_malloc(ctx, &p, need + need / 4);
+  void* ws = nullptr;
+  {
+    const int rc = svo_ctx_scratch(ctx, need, &ws);
     if (rc != SVO_HIP_OK) return rc;
-    ctx->scratch = p; ctx->scratch_bytes = need + need / 4;
   }
-  SeedRec* recs = (SeedRec*)ctx->scratch;
+  SeedRec* recs = (SeedRec*)ws;
   MdFrame mf;
   mf.cam = svo_make_cam(*cam);
   memcpy(mf.T_cur_w, T_cur_w, sizeof(double) * 7);

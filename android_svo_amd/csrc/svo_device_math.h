@@ -212,9 +212,47 @@ SVO_DEV void jacobian_xyz2uv(const double* p, double* J) {
   J[11] = -x * z_inv;
 }
 
-// Pivoted LDL^T of a symmetric 6x6 (lower part read) and solve, one thread.
-SVO_DEV void ldlt6_solve(const double* Hin, const double* b, double* x) {
-  constexpr int N = 6;
+// Sums as Eigen 3.4 evaluates them inside its unrolled fixed-size triangular solves (Core/SolveTriangular.h,
+// Core/Redux.h): redux_tree = binary splitting [0, n/2) + [n/2, n) of the scalar unroller; redux_packet2 = the
+// SSE2 form used when both operands are contiguous (two lanes summed packet-wise, lanes added, then the remainder).
+template <int N>
+SVO_DEV double redux_tree(const double* a) {
+  if constexpr (N == 1) return a[0];
+  else return redux_tree<N / 2>(a) + redux_tree<N - N / 2>(a + N / 2);
+}
+template <int N>
+SVO_DEV double redux_packet2(const double* a) {
+  if constexpr (N < 2) return a[0];
+  else if constexpr (N == 2) return a[0] + a[1];
+  else if constexpr (N == 3) return (a[0] + a[1]) + a[2];
+  else if constexpr (N == 4) return (a[0] + a[2]) + (a[1] + a[3]);
+  else return ((a[0] + a[2]) + (a[1] + a[3])) + a[4];
+}
+// d[I] -= sum_{j<I} m[I][j] d[j]  /  d[I] -= sum_{j>I} m[j][I] d[j], statically indexed
+template <int N, int I>
+SVO_DEV void ldlt_forward_row(const double (*m)[N], double* d) {
+  if constexpr (I < N) {
+    double t[I];
+#pragma unroll
+    for (int j = 0; j < I; ++j) t[j] = m[I][j] * d[j];
+    d[I] -= redux_tree<I>(t);
+    ldlt_forward_row<N, I + 1>(m, d);
+  }
+}
+template <int N, int I>
+SVO_DEV void ldlt_backward_row(const double (*m)[N], double* d) {
+  if constexpr (I >= 0) {
+    double t[N - 1 - I];
+#pragma unroll
+    for (int j = I + 1; j < N; ++j) t[j - I - 1] = m[j][I] * d[j];
+    d[I] -= redux_packet2<N - 1 - I>(t);
+    ldlt_backward_row<N, I - 1>(m, d);
+  }
+}
+
+// Pivoted LDL^T of a symmetric NxN (lower part read) and solve, one thread (Eigen 3.4 Cholesky/LDLT.h).
+template <int N>
+SVO_DEV void ldlt_solve(const double* Hin, const double* b, double* x) {
   double m[N][N];
   int tr[N];
 #pragma unroll
@@ -259,24 +297,17 @@ SVO_DEV void ldlt6_solve(const double* Hin, const double* b, double* x) {
   for (int i = 0; i < N; ++i) d[i] = b[i];
   for (int k = 0; k < N; ++k)
     if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
-  for (int i = 0; i < N; ++i) {
-    double s = d[i];
-    for (int j = 0; j < i; ++j) s -= m[i][j] * d[j];
-    d[i] = s;
-  }
+  ldlt_forward_row<N, 1>(m, d);        // L^-1 (unit lower), Eigen's summation order
   const double tol = 2.2250738585072014e-308;   // DBL_MIN: pseudo-inverse of D
   for (int i = 0; i < N; ++i) {
     if (fabs(m[i][i]) > tol) d[i] /= m[i][i]; else d[i] = 0.0;
   }
-  for (int i = N - 1; i >= 0; --i) {
-    double s = d[i];
-    for (int j = i + 1; j < N; ++j) s -= m[j][i] * d[j];
-    d[i] = s;
-  }
+  ldlt_backward_row<N, N - 2>(m, d);   // L^-T
   for (int k = N - 1; k >= 0; --k)
     if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
   for (int i = 0; i < N; ++i) x[i] = d[i];
 }
+SVO_DEV void ldlt6_solve(const double* Hin, const double* b, double* x) { ldlt_solve<6>(Hin, b, x); }
 
 // vk::interpolateMat_8u (I/vision.h:19-36)
 SVO_DEV float interpolate_8u(const uint8_t* img, int stride, float u, float v) {
@@ -426,25 +457,13 @@ SVO_DEV void ldlt6_solve_reg(const double* Hin, const double* b, double* x) {
     for (int c = k + 1; c < N; ++c)
       if (tr[k] == c) { double t = d[k]; d[k] = d[c]; d[c] = t; }
   }
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    double s = d[i];
-#pragma unroll
-    for (int j = 0; j < i; ++j) s -= m[i][j] * d[j];
-    d[i] = s;
-  }
+  ldlt_forward_row<N, 1>(m, d);        // L^-1 (unit lower), Eigen's summation order
   const double tol = 2.2250738585072014e-308;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     if (fabs(m[i][i]) > tol) d[i] /= m[i][i]; else d[i] = 0.0;
   }
-#pragma unroll
-  for (int i = N - 1; i >= 0; --i) {
-    double s = d[i];
-#pragma unroll
-    for (int j = i + 1; j < N; ++j) s -= m[j][i] * d[j];
-    d[i] = s;
-  }
+  ldlt_backward_row<N, N - 2>(m, d);   // L^-T
 #pragma unroll
   for (int k = N - 1; k >= 0; --k) {
 #pragma unroll

@@ -42,6 +42,25 @@ inline int svo_fail(svo_hip_ctx* ctx, int code, const char* what, const char* de
     if (!(cond)) return svo_fail((ctx), SVO_HIP_ERR_INVALID, "invalid argument", #cond); \
   } while (0)
 
+// grow-only device workspace of the context (stage records, selection buffers); contents are only valid
+// within one entry point
+inline int svo_ctx_scratch(svo_hip_ctx* ctx, size_t need, void** out) {
+  if (ctx->scratch_bytes < need) {
+    if (ctx->scratch) {
+      SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->scratch);
+      ctx->scratch = nullptr;
+      ctx->scratch_bytes = 0;
+    }
+    void* p = nullptr;
+    SVO_CHECK_HIP(ctx, hipMalloc(&p, need + need / 4));
+    ctx->scratch = p;
+    ctx->scratch_bytes = need + need / 4;
+  }
+  *out = ctx->scratch;
+  return SVO_HIP_OK;
+}
+
 inline svo_dev::Cam svo_make_cam(const svo_hip_camera& c) {
   svo_dev::Cam d;
   d.fx = c.fx; d.fy = c.fy; d.cx = c.cx; d.cy = c.cy;

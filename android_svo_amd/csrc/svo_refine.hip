@@ -1,0 +1,534 @@
+// svo_refine.hip -- next rows of the hot path: the two small Gauss-Newton refinements that follow
+// SparseImgAlign and the reprojection matching in FrameHandlerMono::processFrame.
+//
+//   pose_refine_kernel   pose_optimizer::optimizeGaussNewton   S/pose_optimizer.cpp:31-181
+//   point_refine_kernel  Point::optimize                       S/point.cpp:130-192
+//   ldlt6_batch_kernel   Eigen LDLT 6x6 solve as used by both solvers (test utility: device == Eigen bit for bit)
+//
+// pose_refine_kernel: one workgroup (256 threads) per frame runs the whole refinement in one launch -- MAD scale
+// (exact k-th element by radix selection on the float bit pattern), <= n_iter robust Gauss-Newton steps (thread per
+// observation, fp64 2x6 Jacobians, Tukey weights in f32 as the reference, transposing wave reduction of the 28
+// sums, one-lane pivoted LDL^T + SE3::exp), covariance (one-lane partial-pivot LU inverse), outlier test, and the
+// two medians of the squared errors (radix selection on the f64 bit pattern).  Sums over observations are taken
+// in a fixed tree order instead of the reference's list order: results agree to rounding, run to run bit-equal.
+#include "svo_internal.h"
+
+namespace {
+
+using namespace svo_dev;
+
+constexpr int PR_THREADS = 256;
+constexpr int PR_WAVES = PR_THREADS / 64;
+
+struct PoseOptOut {               // == svo_hip_pose_opt_result
+  int ran;
+  int n_iter_done;
+  int n_deleted;
+  int pad_;
+  unsigned long long num_obs;
+  double T_f_w[7];
+  double estimated_scale, error_init, error_final;
+  double Cov[36];
+};
+static_assert(sizeof(PoseOptOut) == sizeof(svo_hip_pose_opt_result), "layout of svo_hip_pose_opt_result");
+
+// TukeyWeightFunction::value with DEFAULT_B (S/robust_cost.cpp:87-106)
+SVO_DEV float tukey_weight(float x) {
+  const float b = 8.6851f;
+  const float b_square = b * b;
+  const float x_square = x * x;
+  if (x_square <= b_square) {
+    const float tmp = 1.0f - x_square / b_square;
+    return tmp * tmp;
+  }
+  return 0.0f;
+}
+
+// reprojection error on the unit plane, scaled by 1/2^level (:54-57, :92-95, :151-153)
+SVO_DEV void unit_plane_error(const double* T, const double* f, const double* pos, int level, double* e, double* xyz) {
+  se3_act(T, pos, xyz);
+  e[0] = f[0] / f[2] - xyz[0] / xyz[2];
+  e[1] = f[1] / f[2] - xyz[1] / xyz[2];
+  const double s = 1.0 / (1 << level);
+  e[0] *= s; e[1] *= s;
+}
+
+// k-th smallest (0-based) of the keys of the valid entries, all threads of the block take part and get the key.
+// Keys are bit patterns of non-negative IEEE numbers (monotonic as unsigned integers).  hist: 256 ints of LDS.
+template <typename KeyT, typename GetKey>
+__device__ KeyT block_radix_select(int n, unsigned k, GetKey get_key, int* hist, KeyT* s_prefix, unsigned* s_k) {
+  constexpr int BITS = 8 * (int)sizeof(KeyT);
+  if (threadIdx.x == 0) { *s_prefix = 0; *s_k = k; }
+  for (int shift = BITS - 8; shift >= 0; shift -= 8) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const KeyT prefix = *s_prefix;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      KeyT key;
+      if (!get_key(i, &key)) continue;
+      const bool match = (shift == BITS - 8) ? true : ((key >> (shift + 8)) == prefix);
+      if (match) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                    // wave 0: 4 bins per lane, exclusive scan, pick the digit
+      const int lane = threadIdx.x;
+      const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const int mine = h0 + h1 + h2 + h3;
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      const unsigned before = (unsigned)(incl - mine);
+      const unsigned kk = *s_k;
+      if (kk >= before && kk < before + (unsigned)mine) {          // exactly one lane
+        unsigned r = kk - before;
+        int d = 4 * lane;
+        if (r >= (unsigned)h0) { r -= h0; ++d; if (r >= (unsigned)h1) { r -= h1; ++d; if (r >= (unsigned)h2) { r -= h2; ++d; } } }
+        *s_prefix = (KeyT)((prefix << 8) | (KeyT)d);
+        *s_k = r;
+      }
+    }
+    __syncthreads();
+  }
+  return *s_prefix;
+}
+
+// Matrix<double,6,6>::inverse() = partialPivLu().inverse() (Eigen LU/PartialPivLU.h:379-425): one thread
+SVO_DEV void inverse6(const double* Ain, double* out) {
+  constexpr int N = 6;
+  double lu[N][N];
+  int piv[N];
+  for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) lu[i][j] = Ain[i * N + j];
+  for (int k = 0; k < N; ++k) {
+    int big = k;
+    double best = fabs(lu[k][k]);
+    for (int i = k + 1; i < N; ++i) if (fabs(lu[i][k]) > best) { best = fabs(lu[i][k]); big = i; }
+    piv[k] = big;
+    if (best != 0.0) {
+      if (big != k) for (int j = 0; j < N; ++j) { const double t = lu[k][j]; lu[k][j] = lu[big][j]; lu[big][j] = t; }
+      for (int i = k + 1; i < N; ++i) lu[i][k] /= lu[k][k];
+    }
+    for (int i = k + 1; i < N; ++i)
+      for (int j = k + 1; j < N; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+  }
+  for (int c = 0; c < N; ++c) {
+    double d[N];
+    for (int i = 0; i < N; ++i) d[i] = (i == c) ? 1.0 : 0.0;
+    for (int k = 0; k < N; ++k) if (piv[k] != k) { const double t = d[k]; d[k] = d[piv[k]]; d[piv[k]] = t; }
+    for (int i = 0; i < N; ++i) { double s = d[i]; for (int j = 0; j < i; ++j) s -= lu[i][j] * d[j]; d[i] = s; }
+    for (int i = N - 1; i >= 0; --i) {
+      double s = d[i];
+      for (int j = i + 1; j < N; ++j) s -= lu[i][j] * d[j];
+      d[i] = s / lu[i][i];
+    }
+    for (int i = 0; i < N; ++i) out[i * N + c] = d[i];
+  }
+}
+
+__global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
+    int max_n, const int* __restrict__ n_feat, const double* __restrict__ T_in, const double* __restrict__ f,
+    const double* __restrict__ pos, const int* __restrict__ level, uint8_t* __restrict__ has_point, double em,
+    double reproj_thresh, int n_iter, float* __restrict__ err_ws, double* __restrict__ sq_init_ws,
+    double* __restrict__ sq_final_ws, PoseOptOut* __restrict__ out) {
+  __shared__ int hist[256];
+  __shared__ unsigned s_k;
+  __shared__ unsigned s_pref32;
+  __shared__ unsigned long long s_pref64;
+  __shared__ double red[PR_WAVES][32];
+  __shared__ double s_T[7], s_Told[7];
+  __shared__ double s_A[36];
+  __shared__ double s_chi2, s_scale;
+  __shared__ int s_done, s_iters;
+  __shared__ unsigned s_count;
+
+  const int b = blockIdx.x;
+  const int n = n_feat[b];
+  const size_t base = (size_t)b * max_n;
+  const double* fb = f + 3 * base;
+  const double* pb = pos + 3 * base;
+  const int* lb = level + base;
+  uint8_t* hb = has_point + base;
+  float* err = err_ws + base;
+  double* sq_init = sq_init_ws + base;
+  double* sq_final = sq_final_ws + base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 7; ++i) { s_T[i] = T_in[7 * b + i]; s_Told[i] = s_T[i]; }            // :45
+    for (int i = 0; i < 36; ++i) s_A[i] = 0.0;
+    s_chi2 = 0.0; s_done = 0; s_iters = 0; s_count = 0;
+  }
+  if (lane >= 28 && lane < 32) red[wave][lane] = 0.0;
+  __syncthreads();
+
+  // ---- scale of the error for the robust weights (:51-66)
+  {
+    double T[7];
+    for (int i = 0; i < 7; ++i) T[i] = s_T[i];
+    unsigned mine = 0;
+    for (int i = threadIdx.x; i < n; i += PR_THREADS) {
+      if (!hb[i]) continue;
+      double e[2], xyz[3];
+      unit_plane_error(T, fb + 3 * i, pb + 3 * i, lb[i], e, xyz);
+      err[i] = (float)sqrt(e[0] * e[0] + e[1] * e[1]);
+      ++mine;
+    }
+    if (mine) atomicAdd(&s_count, mine);
+  }
+  __syncthreads();
+  const unsigned n_obs = s_count;
+  PoseOptOut& o = out[b];
+  if (n_obs == 0) {                                                                            // :61-62
+    if (threadIdx.x == 0) {
+      o.ran = 0; o.n_iter_done = 0; o.n_deleted = 0; o.num_obs = 0;
+      for (int i = 0; i < 7; ++i) o.T_f_w[i] = s_T[i];
+      o.estimated_scale = 0.0; o.error_init = 0.0; o.error_final = 0.0;
+      for (int i = 0; i < 36; ++i) o.Cov[i] = 0.0;
+    }
+    return;
+  }
+  const unsigned med_bits = block_radix_select<unsigned>(
+      n, n_obs / 2, [&](int i, unsigned* key) { if (!hb[i]) return false; *key = __float_as_uint(err[i]); return true; },
+      hist, &s_pref32, &s_k);
+  const double estimated_scale = (double)(1.48f * __uint_as_float(med_bits));                  // MADScaleEstimator
+  if (threadIdx.x == 0) s_scale = estimated_scale;
+  __syncthreads();
+
+  // ---- robust Gauss-Newton (:70-138)
+  for (int iter = 0; iter < n_iter; ++iter) {
+    if (s_done) break;                                       // block-uniform
+    double T[7];
+    for (int i = 0; i < 7; ++i) T[i] = s_T[i];
+    const double scale = (iter >= 5) ? 0.85 / em : s_scale;  // :74-75 (the overwrite at iteration 5 stays)
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+    for (int i = threadIdx.x; i < n; i += PR_THREADS) {
+      if (!hb[i]) continue;
+      double e[2], xyz[3];
+      unit_plane_error(T, fb + 3 * i, pb + 3 * i, lb[i], e, xyz);
+      const double sqrt_inv_cov = 1.0 / (1 << lb[i]);
+      const double sq = e[0] * e[0] + e[1] * e[1];
+      if (iter == 0) sq_init[i] = sq;
+      // Frame::jacobian_xyz2uv (I/frame.h:110-132) times sqrt_inv_cov
+      const double x = xyz[0], y = xyz[1];
+      const double z_inv = 1. / xyz[2];
+      const double z_inv_2 = z_inv * z_inv;
+      double J0[6], J1[6];
+      J0[0] = -z_inv; J0[1] = 0.0; J0[2] = x * z_inv_2; J0[3] = y * J0[2]; J0[4] = -(1.0 + x * J0[2]); J0[5] = y * z_inv;
+      J1[0] = 0.0; J1[1] = -z_inv; J1[2] = y * z_inv_2; J1[3] = 1.0 + y * J1[2]; J1[4] = -J0[3]; J1[5] = -x * z_inv;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { J0[k] *= sqrt_inv_cov; J1[k] *= sqrt_inv_cov; }
+      const double weight = (double)tukey_weight((float)(sqrt(sq) / scale));
+      int kk = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) acc[kk++] += (J0[r] * J0[c] + J1[r] * J1[c]) * weight;          // A += J^T J w
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc[21 + r] -= (J0[r] * e[0] + J1[r] * e[1]) * weight;              // b -= J^T e w
+      acc[27] += sq * weight;
+    }
+    // 28 sums: four transposing wave reductions of 8 (lanes 8j..8j+7 get value j), then the waves in fixed order
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      double v8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v8[k] = (8 * g + k < 28) ? acc[8 * g + k] : 0.0;
+      const double t = wave_reduce8(v8);
+      if ((lane & 7) == 0 && 8 * g + (lane >> 3) < 28) red[wave][8 * g + (lane >> 3)] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double S[28];
+      for (int k = 0; k < 28; ++k) { double v = 0.0; for (int w = 0; w < PR_WAVES; ++w) v += red[w][k]; S[k] = v; }
+      double A[36], bb[6], dT[6];
+      int kk = 0;
+      for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { A[r * 6 + c] = S[kk]; A[c * 6 + r] = S[kk]; ++kk; }
+      for (int r = 0; r < 6; ++r) bb[r] = S[21 + r];
+      const double new_chi2 = S[27];
+      for (int k = 0; k < 36; ++k) s_A[k] = A[k];
+      ldlt6_solve_reg(A, bb, dT);
+      s_iters = iter + 1;
+      if ((iter > 0 && new_chi2 > s_chi2 * 1.2) || dT[0] != dT[0]) {                           // :106-116
+        for (int i = 0; i < 7; ++i) s_T[i] = s_Told[i];
+        s_done = 1;
+      } else {
+        double E[7], Tn[7], Tc[7];
+        for (int i = 0; i < 7; ++i) Tc[i] = s_T[i];
+        se3_exp(dT, E);
+        se3_mul(E, Tc, Tn);                                                                     // exp(dT) * T_f_w (:120)
+        for (int i = 0; i < 7; ++i) { s_Told[i] = Tc[i]; s_T[i] = Tn[i]; }
+        s_chi2 = new_chi2;
+        double mx = -1;
+        for (int k = 0; k < 6; ++k) { const double a = fabs(dT[k]); if (a > mx) mx = a; }
+        if (mx <= 0.0000000001) s_done = 1;                                                     // EPS
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- covariance (:141), outlier test (:144-159), medians (:161-166)
+  if (threadIdx.x == 0) {
+    double As[36];
+    const double em2 = em * em;                              // pow(em, 2)
+    for (int k = 0; k < 36; ++k) As[k] = s_A[k] * em2;
+    inverse6(As, o.Cov);
+    s_count = 0;
+  }
+  __syncthreads();
+  {
+    double T[7];
+    for (int i = 0; i < 7; ++i) T[i] = s_T[i];
+    const double thresh = reproj_thresh / em;
+    unsigned deleted = 0;
+    for (int i = threadIdx.x; i < n; i += PR_THREADS) {
+      if (!hb[i]) { sq_final[i] = -1.0; continue; }          // negative: not an observation
+      double e[2], xyz[3];
+      unit_plane_error(T, fb + 3 * i, pb + 3 * i, lb[i], e, xyz);
+      const double sq = e[0] * e[0] + e[1] * e[1];
+      sq_final[i] = sq;
+      if (sqrt(sq) > thresh) { hb[i] = 0; ++deleted; }
+    }
+    if (deleted) atomicAdd(&s_count, deleted);
+  }
+  __syncthreads();
+  const unsigned n_deleted = s_count;
+  // the observations of the init/final vectors are those that had a point when the function was entered:
+  // sq_final >= 0 marks them (has_point was just cleared for the outliers)
+  const unsigned long long mi = block_radix_select<unsigned long long>(
+      n, n_obs / 2, [&](int i, unsigned long long* key) {
+        if (sq_final[i] < 0.0) return false;
+        *key = (unsigned long long)__double_as_longlong(sq_init[i]);
+        return true;
+      }, hist, &s_pref64, &s_k);
+  const unsigned long long mf = block_radix_select<unsigned long long>(
+      n, n_obs / 2, [&](int i, unsigned long long* key) {
+        if (sq_final[i] < 0.0) return false;
+        *key = (unsigned long long)__double_as_longlong(sq_final[i]);
+        return true;
+      }, hist, &s_pref64, &s_k);
+  if (threadIdx.x == 0) {
+    o.ran = 1;
+    o.n_iter_done = s_iters;
+    o.n_deleted = (int)n_deleted;
+    o.num_obs = (unsigned long long)n_obs - n_deleted;
+    for (int i = 0; i < 7; ++i) o.T_f_w[i] = s_T[i];
+    o.estimated_scale = estimated_scale * em;
+    o.error_init = (n_iter > 0) ? sqrt(__longlong_as_double((long long)mi)) * em : 0.0;       // empty vector when no iteration ran
+    o.error_final = sqrt(__longlong_as_double((long long)mf)) * em;
+  }
+}
+
+// Point::jacobian_xyz2uv (I/point.h:83-97): -[1/z 0 -x/z^2; 0 1/z -y/z^2] * R_f_w, inner sums (a0 + a1) + a2
+SVO_DEV void point_jacobian(const double* p, const double* R, double* J) {
+  const double z_inv = 1.0 / p[2];
+  const double z_inv_sq = z_inv * z_inv;
+  const double j[6] = {-(z_inv), -(0.0), -(-p[0] * z_inv_sq), -(0.0), -(z_inv), -(-p[1] * z_inv_sq)};
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      J[r * 3 + c] = (j[r * 3 + 0] * R[0 * 3 + c] + j[r * 3 + 1] * R[1 * 3 + c]) + j[r * 3 + 2] * R[2 * 3 + c];
+}
+
+// Point::optimize (S/point.cpp:130-192): thread per map point, observations in CSR form, list order kept
+__global__ void point_refine_kernel(int n_points, int n_iter, double* __restrict__ pos, const int* __restrict__ obs_offset,
+                                    const double* __restrict__ obs_T, const double* __restrict__ obs_f,
+                                    int* __restrict__ iters_out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_points) return;
+  double P[3] = {pos[3 * p], pos[3 * p + 1], pos[3 * p + 2]};
+  double old_point[3] = {P[0], P[1], P[2]};
+  double chi2 = 0.0;
+  int done = 0;
+  const int o0 = obs_offset[p], o1 = obs_offset[p + 1];
+  for (int i = 0; i < n_iter; ++i) {
+    double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
+    double new_chi2 = 0.0;
+    for (int k = o0; k < o1; ++k) {
+      double T[7], q[3], R[9], J[6];
+      for (int t = 0; t < 7; ++t) T[t] = obs_T[7 * k + t];
+      const double fx = obs_f[3 * k], fy = obs_f[3 * k + 1], fz = obs_f[3 * k + 2];
+      se3_act(T, P, q);
+      se3_rotation_matrix(T, R);
+      point_jacobian(q, R, J);
+      const double e0 = fx / fz - q[0] / q[2];
+      const double e1 = fy / fz - q[1] / q[2];
+      new_chi2 += e0 * e0 + e1 * e1;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) A[r * 3 + c] += J[r] * J[c] + J[3 + r] * J[3 + c];
+        bb[r] -= J[r] * e0 + J[3 + r] * e1;
+      }
+    }
+    double dp[3];
+    ldlt_solve<3>(A, bb, dp);
+    done = i + 1;
+    if ((i > 0 && new_chi2 > chi2) || dp[0] != dp[0]) {
+      P[0] = old_point[0]; P[1] = old_point[1]; P[2] = old_point[2];
+      break;
+    }
+    old_point[0] = P[0]; old_point[1] = P[1]; old_point[2] = P[2];
+    P[0] += dp[0]; P[1] += dp[1]; P[2] += dp[2];
+    chi2 = new_chi2;
+    double mx = -1;
+    for (int k = 0; k < 3; ++k) { const double a = fabs(dp[k]); if (a > mx) mx = a; }
+    if (mx <= 0.0000000001) break;
+  }
+  pos[3 * p] = P[0]; pos[3 * p + 1] = P[1]; pos[3 * p + 2] = P[2];
+  if (iters_out) iters_out[p] = done;
+}
+
+// one system per wave (lane 0 only: ldlt6_solve_reg's contract)
+__global__ void ldlt6_batch_kernel(int n, const double* __restrict__ H, const double* __restrict__ b, double* __restrict__ x) {
+  const int i = blockIdx.x;
+  if (i >= n || threadIdx.x != 0) return;
+  double Hm[36], bv[6], xv[6];
+  for (int k = 0; k < 36; ++k) Hm[k] = H[36 * (size_t)i + k];
+  for (int k = 0; k < 6; ++k) bv[k] = b[6 * (size_t)i + k];
+  ldlt6_solve_reg(Hm, bv, xv);
+  for (int k = 0; k < 6; ++k) x[6 * (size_t)i + k] = xv[k];
+}
+
+}  // namespace
+
+extern "C" {
+
+int svo_hip_pose_optimize_batch_dev(svo_hip_ctx* ctx, int batch, int max_n, const int32_t* n_feat_dev,
+                                    const double* T_f_w_dev, const double* f_dev, const double* pos_dev,
+                                    const int32_t* level_dev, uint8_t* has_point_dev, double error_multiplier2,
+                                    double reproj_thresh, int n_iter, svo_hip_pose_opt_result* results_dev) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, batch > 0 && max_n > 0 && n_iter >= 0);
+  SVO_REQUIRE(ctx, n_feat_dev && T_f_w_dev && f_dev && pos_dev && level_dev && has_point_dev && results_dev);
+  SVO_REQUIRE(ctx, error_multiplier2 > 0.0);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t per = (size_t)batch * max_n;
+  void* ws = nullptr;
+  const int rc = svo_ctx_scratch(ctx, per * (sizeof(float) + 2 * sizeof(double)) + 64, &ws);
+  if (rc != SVO_HIP_OK) return rc;
+  double* sq_init = reinterpret_cast<double*>(ws);
+  double* sq_final = sq_init + per;
+  float* err = reinterpret_cast<float*>(sq_final + per);
+  hipLaunchKernelGGL(pose_refine_kernel, dim3(batch), dim3(PR_THREADS), 0, ctx->stream, max_n, n_feat_dev, T_f_w_dev, f_dev,
+                     pos_dev, level_dev, has_point_dev, error_multiplier2, reproj_thresh, n_iter, err, sq_init, sq_final,
+                     reinterpret_cast<PoseOptOut*>(results_dev));
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+int svo_hip_pose_optimize(svo_hip_ctx* ctx, int n, const double T_f_w[7], const double* f, const double* pos,
+                          const int32_t* level, uint8_t* has_point, double error_multiplier2, double reproj_thresh,
+                          int n_iter, svo_hip_pose_opt_result* result) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n >= 0 && T_f_w && result && (n == 0 || (f && pos && level && has_point)));
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const int max_n = n > 0 ? n : 1;
+  const size_t bytes = sizeof(int32_t) + 7 * sizeof(double) + (size_t)max_n * (6 * sizeof(double) + sizeof(int32_t) + 1) +
+                       sizeof(svo_hip_pose_opt_result) + 64;
+  char* d = nullptr;
+  SVO_CHECK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), bytes));
+  double* dT = reinterpret_cast<double*>(d);
+  double* df = dT + 7;
+  double* dp = df + 3 * (size_t)max_n;
+  svo_hip_pose_opt_result* dres = reinterpret_cast<svo_hip_pose_opt_result*>(dp + 3 * (size_t)max_n);
+  int32_t* dl = reinterpret_cast<int32_t*>(dres + 1);
+  int32_t* dn = dl + max_n;
+  uint8_t* dh = reinterpret_cast<uint8_t*>(dn + 1);
+  int rc = SVO_HIP_OK;
+  hipError_t e = hipMemcpyAsync(dT, T_f_w, 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n > 0) e = hipMemcpyAsync(df, f, 3 * sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n > 0) e = hipMemcpyAsync(dp, pos, 3 * sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n > 0) e = hipMemcpyAsync(dl, level, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n > 0) e = hipMemcpyAsync(dh, has_point, (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+  const int32_t n32 = n;
+  if (e == hipSuccess) e = hipMemcpyAsync(dn, &n32, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    rc = svo_hip_pose_optimize_batch_dev(ctx, 1, max_n, dn, dT, df, dp, dl, dh, error_multiplier2, reproj_thresh, n_iter, dres);
+    if (rc == SVO_HIP_OK) {
+      e = hipMemcpyAsync(result, dres, sizeof(*result), hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess && n > 0) e = hipMemcpyAsync(has_point, dh, (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+  }
+  (void)hipFree(d);
+  if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_pose_optimize", hipGetErrorString(e));
+  return rc;
+}
+
+int svo_hip_point_optimize_batch_dev(svo_hip_ctx* ctx, int n_points, int n_iter, double* pos_dev,
+                                     const int32_t* obs_offset_dev, const double* obs_T_f_w_dev,
+                                     const double* obs_f_dev, int32_t* iters_dev) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n_points >= 0 && n_iter >= 0);
+  if (n_points == 0) return SVO_HIP_OK;
+  SVO_REQUIRE(ctx, pos_dev && obs_offset_dev && obs_T_f_w_dev && obs_f_dev);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(point_refine_kernel, dim3((n_points + 63) / 64), dim3(64), 0, ctx->stream, n_points, n_iter, pos_dev,
+                     obs_offset_dev, obs_T_f_w_dev, obs_f_dev, iters_dev);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+int svo_hip_point_optimize_batch(svo_hip_ctx* ctx, int n_points, int n_iter, double* pos, const int32_t* obs_offset,
+                                 const double* obs_T_f_w, const double* obs_f, int32_t* iters) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n_points >= 0 && n_iter >= 0);
+  if (n_points == 0) return SVO_HIP_OK;
+  SVO_REQUIRE(ctx, pos && obs_offset);
+  const int m = obs_offset[n_points];
+  SVO_REQUIRE(ctx, m >= 0 && (m == 0 || (obs_T_f_w && obs_f)));
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t mm = m > 0 ? (size_t)m : 1;
+  char* d = nullptr;
+  SVO_CHECK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(double) * (3 * (size_t)n_points + 10 * mm) +
+                                                             sizeof(int32_t) * (2 * (size_t)n_points + 1) + 64));
+  double* dp = reinterpret_cast<double*>(d);
+  double* dT = dp + 3 * (size_t)n_points;
+  double* df = dT + 7 * mm;
+  int32_t* dof = reinterpret_cast<int32_t*>(df + 3 * mm);
+  int32_t* dit = dof + n_points + 1;
+  hipError_t e = hipMemcpyAsync(dp, pos, sizeof(double) * 3 * n_points, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dof, obs_offset, sizeof(int32_t) * (n_points + 1), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && m > 0) e = hipMemcpyAsync(dT, obs_T_f_w, sizeof(double) * 7 * m, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && m > 0) e = hipMemcpyAsync(df, obs_f, sizeof(double) * 3 * m, hipMemcpyHostToDevice, ctx->stream);
+  int rc = SVO_HIP_OK;
+  if (e == hipSuccess) {
+    rc = svo_hip_point_optimize_batch_dev(ctx, n_points, n_iter, dp, dof, dT, df, dit);
+    if (rc == SVO_HIP_OK) {
+      e = hipMemcpyAsync(pos, dp, sizeof(double) * 3 * n_points, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess && iters) e = hipMemcpyAsync(iters, dit, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+  }
+  (void)hipFree(d);
+  if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_point_optimize_batch", hipGetErrorString(e));
+  return rc;
+}
+
+int svo_hip_ldlt6_solve_batch(svo_hip_ctx* ctx, int n, const double* H, const double* b, double* x) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n >= 0 && (n == 0 || (H && b && x)));
+  if (n == 0) return SVO_HIP_OK;
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  double* d = nullptr;
+  SVO_CHECK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(double) * 48 * (size_t)n));
+  double *dH = d, *db = d + 36 * (size_t)n, *dx = db + 6 * (size_t)n;
+  hipError_t e = hipMemcpyAsync(dH, H, sizeof(double) * 36 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(db, b, sizeof(double) * 6 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(ldlt6_batch_kernel, dim3(n), dim3(64), 0, ctx->stream, n, dH, db, dx);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(x, dx, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_ldlt6_solve_batch", hipGetErrorString(e));
+  return SVO_HIP_OK;
+}
+
+}  // extern "C"

@@ -412,3 +412,70 @@ def depth_filter_update(ctx: Context, ref: Pyramid, ref_slot: int, cur: Pyramid,
         off(seeds.px, 16), off(seeds.f, 24), off(seeds.level, 4), off(seeds.a, 4), off(seeds.b, 4), off(seeds.mu, 4),
         off(seeds.z_range, 4), off(seeds.sigma2, 4), C.byref(prm), off(seeds.status, 4), off(seeds.z, 8),
         off(seeds.xyz, 24), off(seeds.n_zmssd, 4), off(seeds.n_align, 4)), "depth_filter_update")
+
+
+# ---- next rows f-4: pose_optimizer::optimizeGaussNewton, Point::optimize -----------------------------------------
+class CPoseOptResult(C.Structure):
+    _fields_ = [("ran", C.c_int32), ("n_iter_done", C.c_int32), ("n_deleted", C.c_int32), ("pad_", C.c_int32),
+                ("num_obs", C.c_uint64), ("T_f_w", C.c_double * 7), ("estimated_scale", C.c_double),
+                ("error_init", C.c_double), ("error_final", C.c_double), ("Cov", C.c_double * 36)]
+
+
+def pose_optimize(ctx: Context, T_f_w, f, pos, level, has_point, error_multiplier2: float, reproj_thresh: float = 2.0,
+                  n_iter: int = 10):
+    """pose_optimizer::optimizeGaussNewton for one frame (host buffers).  Returns (CPoseOptResult, has_point after
+    the outlier test)."""
+    T, ff, pp = _f64(T_f_w), _f64(f), _f64(pos)
+    lv = np.ascontiguousarray(level, dtype=np.int32)
+    hp = np.ascontiguousarray(has_point, dtype=np.uint8).copy()
+    res = CPoseOptResult()
+    ctx.check(ctx.lib.svo_hip_pose_optimize(ctx.h, len(lv), _ptr(T, C.c_double), _ptr(ff, C.c_double), _ptr(pp, C.c_double),
+                                            _ptr(lv, C.c_int32), _ptr(hp, C.c_uint8), C.c_double(error_multiplier2),
+                                            C.c_double(reproj_thresh), n_iter, C.byref(res)), "pose_optimize")
+    return res, hp
+
+
+def pose_optimize_batch(ctx: Context, T_f_w, f, pos, level, has_point, n_feat, error_multiplier2: float,
+                        reproj_thresh: float = 2.0, n_iter: int = 10):
+    """Batch form: T_f_w [B,7], f/pos [B,max_n,3], level/has_point [B,max_n], n_feat [B].  Returns (list of
+    CPoseOptResult, has_point [B,max_n])."""
+    T, ff, pp = _f64(T_f_w), _f64(f), _f64(pos)
+    B, max_n = ff.shape[0], ff.shape[1]
+    d = [ctx.to_device(T), ctx.to_device(ff), ctx.to_device(pp), ctx.to_device(np.ascontiguousarray(level, dtype=np.int32)),
+         ctx.to_device(np.ascontiguousarray(has_point, dtype=np.uint8)), ctx.to_device(np.ascontiguousarray(n_feat, dtype=np.int32))]
+    dres = ctx.empty((B * C.sizeof(CPoseOptResult),), np.uint8)
+    ctx.check(ctx.lib.svo_hip_pose_optimize_batch_dev(
+        ctx.h, B, max_n, C.c_void_p(d[5].ptr), C.c_void_p(d[0].ptr), C.c_void_p(d[1].ptr), C.c_void_p(d[2].ptr),
+        C.c_void_p(d[3].ptr), C.c_void_p(d[4].ptr), C.c_double(error_multiplier2), C.c_double(reproj_thresh), n_iter,
+        C.c_void_p(dres.ptr)), "pose_optimize_batch")
+    raw = dres.download()
+    hp = d[4].download().reshape(B, max_n)
+    res = [CPoseOptResult.from_buffer_copy(raw[i * C.sizeof(CPoseOptResult):(i + 1) * C.sizeof(CPoseOptResult)].tobytes())
+           for i in range(B)]
+    for v in d + [dres]:
+        v.free()
+    return res, hp
+
+
+def point_optimize_batch(ctx: Context, pos, obs_offset, obs_T, obs_f, n_iter: int = 5):
+    """Point::optimize for a batch of map points; observations in CSR form.  Returns (pos [n,3], iters [n])."""
+    n = len(pos)
+    dp = ctx.to_device(_f64(pos))
+    do = ctx.to_device(np.ascontiguousarray(obs_offset, dtype=np.int32))
+    dT, dF = ctx.to_device(_f64(obs_T)), ctx.to_device(_f64(obs_f))
+    di = ctx.empty((max(n, 1),), np.int32)
+    ctx.check(ctx.lib.svo_hip_point_optimize_batch_dev(ctx.h, n, n_iter, C.c_void_p(dp.ptr), C.c_void_p(do.ptr),
+                                                       C.c_void_p(dT.ptr), C.c_void_p(dF.ptr), C.c_void_p(di.ptr)),
+              "point_optimize_batch")
+    out, it = dp.download().reshape(n, 3), di.download()[:n]
+    for v in (dp, do, dT, dF, di):
+        v.free()
+    return out, it
+
+
+def ldlt6_solve_batch(ctx: Context, H, b):
+    Hm, bv = _f64(np.asarray(H).reshape(-1, 36)), _f64(np.asarray(b).reshape(-1, 6))
+    x = np.zeros_like(bv)
+    ctx.check(ctx.lib.svo_hip_ldlt6_solve_batch(ctx.h, len(Hm), _ptr(Hm, C.c_double), _ptr(bv, C.c_double),
+                                                _ptr(x, C.c_double)), "ldlt6_solve_batch")
+    return x

@@ -229,3 +229,60 @@ def make_frame_pair(seed: int = 12345, width: int = 640, height: int = 480, n_fe
         has_point[::null_point_every] = 0
     return FramePair(cam, build_pyramid(ref_img), build_pyramid(cur_img), px, np.ascontiguousarray(f),
                      np.ascontiguousarray(pos), has_point, T_ref_w, T_cur_w, T_ref_w.copy())
+
+
+# ---- inputs for the two small refinements (pose_optimizer::optimizeGaussNewton, Point::optimize) ----
+@dataclasses.dataclass
+class PoseOptCase:
+    cam: Camera
+    T_f_w_init: np.ndarray   # [7] pose to refine (SparseImgAlign's output in the pipeline)
+    T_f_w_true: np.ndarray
+    f: np.ndarray            # [n,3] measured unit bearings in the frame (reprojection matches)
+    pos: np.ndarray          # [n,3] map points
+    level: np.ndarray        # [n] i32 pyramid level of the matched feature
+    has_point: np.ndarray    # [n] u8
+    outlier: np.ndarray      # [n] bool: measurement deliberately corrupted
+
+
+def make_pose_opt_case(seed: int = 5, n: int = 400, px_noise: float = 0.3, outlier_frac: float = 0.08,
+                       pose_err=(0.01, 0.004), null_every: int = 11) -> PoseOptCase:
+    rng = np.random.default_rng(seed)
+    cam = Camera.default()
+    T_true = se3_from_twist(rng.uniform(-0.2, 0.2, 3), rng.uniform(-0.05, 0.05, 3))
+    px = np.stack([rng.uniform(20, cam.width - 20, n), rng.uniform(20, cam.height - 20, n)], axis=1)
+    depth = rng.uniform(1.0, 4.0, n)
+    ray = np.stack([(px[:, 0] - cam.cx) / cam.fx, (px[:, 1] - cam.cy) / cam.fy, np.ones(n)], axis=1) * depth[:, None]
+    Tinv = se3_inv(T_true)
+    pos = np.stack([se3_act(Tinv, r) for r in ray])
+    level = rng.choice([0, 0, 1, 2], n).astype(np.int32)
+    meas = px + rng.normal(size=(n, 2)) * px_noise * (1 << level)[:, None]
+    outlier = rng.uniform(size=n) < outlier_frac
+    meas[outlier] += rng.uniform(8, 40, (int(outlier.sum()), 2)) * rng.choice([-1, 1], (int(outlier.sum()), 2))
+    f = cam2world(cam, meas)
+    has = np.ones(n, dtype=np.uint8)
+    if null_every:
+        has[::null_every] = 0
+    T_init = se3_mul(se3_from_twist(rng.uniform(-1, 1, 3) * pose_err[0], rng.uniform(-1, 1, 3) * pose_err[1]), T_true)
+    return PoseOptCase(cam, T_init, T_true, np.ascontiguousarray(f), np.ascontiguousarray(pos), level, has, outlier)
+
+
+def make_point_opt_cases(seed: int = 5, n_points: int = 300):
+    """Map points with 2..8 observations each (pose of the observing keyframe + measured bearing), CSR layout.
+    Returns pos0 [n,3], obs_offset [n+1], obs_T [m,7], obs_f [m,3], pos_true [n,3], n_iter [n]."""
+    rng = np.random.default_rng(seed)
+    pos0, pos_true, off, Ts, fs, iters = [], [], [0], [], [], []
+    for t in range(n_points):
+        X = rng.uniform(-1, 1, 3) + [0, 0, 3.0]
+        n_obs = int(rng.integers(2, 9))
+        for _ in range(n_obs):
+            T = se3_from_twist(rng.uniform(-0.4, 0.4, 3), rng.uniform(-0.1, 0.1, 3))
+            p = se3_act(T, X)
+            p = p / np.linalg.norm(p) + rng.normal(size=3) * 1e-3
+            Ts.append(T)
+            fs.append(p / np.linalg.norm(p))
+        off.append(off[-1] + n_obs)
+        pos_true.append(X)
+        pos0.append(X + rng.normal(size=3) * (0.05 if t % 3 else 0.5))
+        iters.append(5 if t % 2 else 20)
+    return (np.array(pos0), np.array(off, dtype=np.int32), np.array(Ts), np.array(fs), np.array(pos_true),
+            np.array(iters, dtype=np.int32))

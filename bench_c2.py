@@ -103,6 +103,48 @@ def main():
     out["update_seed"] = {"seeds_per_s": n / t_us, "us": t_us * 1e6, "algorithmic_GBps": 44.0 * n / t_us / 1e9,
                           "frac_hbm": 44.0 * n / t_us / 1e9 / HBM_PEAK_GBS}
 
+    # ---------------- next rows f-4: pose refinement (1200 observations/frame) and structure refinement ----------------
+    from android_svo_amd import synth
+    pcs = [synth.make_pose_opt_case(seed=40 + k, n=1200) for k in range(4)]
+    em = abs(pcs[0].cam.fx)
+    for B in (1, 256):
+        T = np.stack([pcs[k % 4].T_f_w_init for k in range(B)])
+        f = np.stack([pcs[k % 4].f for k in range(B)]); pos = np.stack([pcs[k % 4].pos for k in range(B)])
+        lvl = np.stack([pcs[k % 4].level for k in range(B)]); hp0 = np.stack([pcs[k % 4].has_point for k in range(B)])
+        d = [ctx.to_device(hip._f64(T)), ctx.to_device(hip._f64(f)), ctx.to_device(hip._f64(pos)),
+             ctx.to_device(np.ascontiguousarray(lvl, dtype=np.int32)), ctx.to_device(np.ascontiguousarray(hp0, dtype=np.uint8)),
+             ctx.to_device(np.full(B, 1200, dtype=np.int32)), ctx.to_device(np.ascontiguousarray(hp0, dtype=np.uint8))]
+        dres = ctx.empty((B * C.sizeof(hip.CPoseOptResult),), np.uint8)
+
+        def run_pose():
+            ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(d[4].ptr), C.c_void_p(d[6].ptr), C.c_size_t(B * 1200)), "restore")
+            ctx.check(ctx.lib.svo_hip_pose_optimize_batch_dev(ctx.h, B, 1200, C.c_void_p(d[5].ptr), C.c_void_p(d[0].ptr), C.c_void_p(d[1].ptr),
+                                                              C.c_void_p(d[2].ptr), C.c_void_p(d[3].ptr), C.c_void_p(d[4].ptr), C.c_double(em),
+                                                              C.c_double(2.0), 10, C.c_void_p(dres.ptr)), "pose_optimize")
+        t_p = timed(ctx, run_pose, args.steps, args.warmup)
+        out["pose_refine_B%d" % B] = {"frames_per_s": B / t_p, "us_per_launch": t_p * 1e6, "observations_per_frame": 1200}
+        for v in d + [dres]:
+            v.free()
+    pos0, off, Ts, fs, _, _ = synth.make_point_opt_cases(n_points=20000)
+    dp0, dp, do, dT, dF = ctx.to_device(hip._f64(pos0)), ctx.to_device(hip._f64(pos0)), ctx.to_device(off), ctx.to_device(hip._f64(Ts)), ctx.to_device(hip._f64(fs))
+
+    def run_points():
+        ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(dp.ptr), C.c_void_p(dp0.ptr), C.c_size_t(pos0.nbytes)), "restore")
+        ctx.check(ctx.lib.svo_hip_point_optimize_batch_dev(ctx.h, len(pos0), 5, C.c_void_p(dp.ptr), C.c_void_p(do.ptr), C.c_void_p(dT.ptr),
+                                                           C.c_void_p(dF.ptr), None), "point_optimize")
+    t_pt = timed(ctx, run_points, args.steps, args.warmup)
+    out["point_refine"] = {"points_per_s": len(pos0) / t_pt, "us_per_launch": t_pt * 1e6, "points": len(pos0), "observations": int(off[-1])}
+    if not args.no_cpu_baseline:
+        t0 = time.perf_counter()
+        for k in range(20):
+            orc.pose_optimize(em, pcs[k % 4].T_f_w_init, pcs[k % 4].f, pcs[k % 4].pos, pcs[k % 4].level, pcs[k % 4].has_point)
+        t_cp = (time.perf_counter() - t0) / 20
+        t0 = time.perf_counter()
+        for i in range(2000):
+            orc.point_optimize(pos0[i], Ts[off[i]:off[i + 1]], fs[off[i]:off[i + 1]], n_iter=5)
+        t_cq = (time.perf_counter() - t0) / 2000
+        out["refine_cpu_port_1thread"] = {"pose_refine_frames_per_s": 1.0 / t_cp, "point_refine_points_per_s_incl_ctypes": 1.0 / t_cq}
+
     # ---------------- CPU oracle (bounded sample) ----------------
     if not args.no_cpu_baseline:
         n_thr = max(1, min(os.cpu_count() or 1, 16))

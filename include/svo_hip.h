@@ -247,6 +247,52 @@ int svo_hip_depth_filter_update(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, in
                                 int32_t* status, double* z, double* xyz_world, int32_t* n_zmssd,
                                 int32_t* n_align_iters);
 
+/* ---- next rows: the two small Gauss-Newton refinements of FrameHandlerMono::processFrame ------
+ * pose_optimizer::optimizeGaussNewton (I/pose_optimizer.h:36-45, pose_optimizer.cpp:31-181; caller
+ * frame_handler_mono.cpp:226-229): motion-only refinement of frame->T_f_w_ over the features that have a point:
+ * MAD scale, <= n_iter Tukey-weighted Gauss-Newton steps on the unit plane, covariance, outlier test.
+ * Per frame b of the batch: n_feat[b] observations at [b][0..max_n): f[3] unit bearing (Feature::f), pos[3]
+ * (Point::pos_), level (Feature::level), has_point u8 in/out (cleared where the reference sets
+ * (*it)->point = NULL, pose_optimizer.cpp:154-157).  error_multiplier2 = cam->errorMultiplier2(). */
+typedef struct {
+  int32_t ran;             /* 0: no observation had a point -- the reference returns before touching anything */
+  int32_t n_iter_done;     /* linear systems built and solved */
+  int32_t n_deleted;       /* observations removed by the final test */
+  int32_t pad_;
+  uint64_t num_obs;        /* observations left (the reference's num_obs) */
+  double T_f_w[7];         /* refined pose (rolled back when the last step was rejected) */
+  double estimated_scale;  /* as returned through the reference's parameter (MAD scale * errorMultiplier2) */
+  double error_init, error_final;
+  double Cov[36];          /* frame->Cov_ */
+} svo_hip_pose_opt_result;
+
+int svo_hip_pose_optimize_batch_dev(svo_hip_ctx* ctx, int batch, int max_n, const int32_t* n_feat_dev,
+                                    const double* T_f_w_dev, const double* f_dev, const double* pos_dev,
+                                    const int32_t* level_dev, uint8_t* has_point_dev, double error_multiplier2,
+                                    double reproj_thresh, int n_iter, svo_hip_pose_opt_result* results_dev);
+/* host-buffer convenience form for one frame (copies in, runs, copies out, synchronises) */
+int svo_hip_pose_optimize(svo_hip_ctx* ctx, int n, const double T_f_w[7], const double* f, const double* pos,
+                          const int32_t* level, uint8_t* has_point, double error_multiplier2, double reproj_thresh,
+                          int n_iter, svo_hip_pose_opt_result* result);
+
+/* Point::optimize (I/point.h:74, point.cpp:130-192; caller FrameHandlerBase::optimizeStructure,
+ * frame_handler_base.cpp:190-210) for n_points map points: pos[n][3] in/out; the observations of point p are
+ * obs[obs_offset[p] .. obs_offset[p+1]) in the order of Point::obs_: pose of the observing frame (T_f_w[7]) and
+ * the feature's bearing f[3].  iters (optional): linear systems solved per point. */
+int svo_hip_point_optimize_batch_dev(svo_hip_ctx* ctx, int n_points, int n_iter, double* pos_dev,
+                                     const int32_t* obs_offset_dev, const double* obs_T_f_w_dev,
+                                     const double* obs_f_dev, int32_t* iters_dev);
+
+/* host-buffer convenience form (copies in, runs, copies out, synchronises) */
+int svo_hip_point_optimize_batch(svo_hip_ctx* ctx, int n_points, int n_iter, double* pos, const int32_t* obs_offset,
+                                 const double* obs_T_f_w, const double* obs_f, int32_t* iters);
+
+/* The 6x6 pivoted LDL^T solve both Gauss-Newton solvers use (x = H.ldlt().solve(b), Eigen 3.4 semantics incl. the
+ * pseudo-inverse of D), n systems from host buffers: exposed so that the parity tests can show it is bit-identical
+ * to Eigen's result. */
+int svo_hip_ldlt6_solve_batch(svo_hip_ctx* ctx, int n, const double* H /*[n][36]*/, const double* b /*[n][6]*/,
+                              double* x /*[n][6]*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -316,13 +316,51 @@ def gen_match_direct_ref():
     print("match_direct_ref ok", int(ok.sum()), "of", n)
 
 
+def gen_refine_ref():
+    """Pieces of the two small refinements that the reference build holds: Point::optimize end to end,
+    Tukey weight, MAD scale, vk::getMedian, Eigen 6x6 inverse and 3x3 LDLT."""
+    rng = np.random.default_rng(99)
+    pos0, off, Ts, fs, _, iters = synth.make_point_opt_cases()
+    out = np.stack([refpy.point_optimize(pos0[i], Ts[off[i]:off[i + 1]], fs[off[i]:off[i + 1]], n_iter=int(iters[i]))
+                    for i in range(len(pos0))])
+    xs = np.concatenate([np.linspace(0, 12, 400), rng.uniform(0, 9, 200)]).astype(np.float32)
+    tuk = np.array([refpy.tukey_weight(float(x)) for x in xs], dtype=np.float32)
+    errs = [rng.uniform(0, 3, m).astype(np.float32) for m in (1, 2, 7, 1000, 1001)]
+    mad = np.array([refpy.mad_scale(e) for e in errs], dtype=np.float32)
+    dd = [rng.uniform(0, 9, m) for m in (1, 4, 999, 1000)]
+    med = np.array([refpy.median_d(d) for d in dd])
+    As = []
+    for i in range(32):
+        M = rng.normal(size=(30, 6)) * rng.uniform(0.1, 50, 6)
+        As.append(M.T @ M)
+    As = np.stack(As)
+    inv = np.stack([refpy.inverse6(A) for A in As])
+    A3, b3 = [], []
+    for i in range(64):
+        M = rng.normal(size=(rng.integers(2, 12), 3))
+        A3.append(M.T @ M); b3.append(rng.normal(size=3))
+    A3[5][:] = 0
+    A3, b3 = np.stack(A3), np.stack(b3)
+    x3 = np.stack([refpy.ldlt3_solve(a, b) for a, b in zip(A3, b3)])
+    save = dict(point_crc=np.array([crc(pos0), crc(Ts), crc(fs)], dtype=np.uint64), point_out=out, tukey_x=xs, tukey=tuk, mad=mad,
+                med=med, A6=As, inv6=inv, A3=A3, b3=b3, x3=x3)
+    for k, e in enumerate(errs):
+        save["err%d" % k] = e
+    for k, d in enumerate(dd):
+        save["dd%d" % k] = d
+    np.savez_compressed(os.path.join(OUT, "refine_ref.npz"), **save)
+    print("refine_ref: points", len(out))
+
+
 def main():
     assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(OUT, exist_ok=True)
-    if "--objects-only" not in sys.argv:
+    if "--objects-only" not in sys.argv and "--refine-only" not in sys.argv:
         rng = np.random.default_rng(20240607)
         gen_se3(rng); gen_algebra(rng); gen_gn(rng); gen_align(rng); gen_matcher(rng); gen_vision(rng)
-    gen_sia_ref(); gen_epi_ref(); gen_match_direct_ref()
+    if "--refine-only" not in sys.argv:
+        gen_sia_ref(); gen_epi_ref(); gen_match_direct_ref()
+    gen_refine_ref()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

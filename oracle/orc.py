@@ -229,3 +229,56 @@ def find_match_direct(cam, ref_pyr, cur_pyr, T_ref_w, T_cur_w, px_ref, f_ref, le
                                          _p(pp, C.c_double), C.c_int(1 if edgelet else 0), _p(g, C.c_double),
                                          C.c_int(n_pyr_levels), C.c_int(align_max_iter), _p(pc, C.c_double), C.byref(sl))
     return bool(ok), pc, sl.value
+
+
+# ---- next rows f-4: pose_optimizer::optimizeGaussNewton, Point::optimize ----
+class PoseOptResult(C.Structure):
+    _fields_ = [("ran", C.c_int), ("T_f_w", C.c_double * 7), ("estimated_scale", C.c_double),
+                ("error_init", C.c_double), ("error_final", C.c_double), ("num_obs", C.c_size_t),
+                ("Cov", C.c_double * 36), ("n_iter_done", C.c_int), ("n_deleted", C.c_int)]
+
+
+def pose_optimize(em, T_f_w, f, pos, level, has_point, reproj_thresh=2.0, n_iter=10):
+    """Returns (PoseOptResult, has_point after the outlier test)."""
+    T, ff, pp = f64(T_f_w), f64(f), f64(pos)
+    lv = np.ascontiguousarray(level, dtype=np.int32)
+    hp = np.ascontiguousarray(has_point, dtype=np.uint8).copy()
+    out = PoseOptResult()
+    lib().svo_orc_pose_optimize(C.c_double(em), C.c_double(reproj_thresh), C.c_int(n_iter), _p(T, C.c_double),
+                                C.c_int(len(lv)), _p(ff, C.c_double), _p(pp, C.c_double), _p(lv, C.c_int),
+                                _p(hp, C.c_uint8), C.byref(out))
+    return out, hp
+
+
+def point_optimize(pos, obs_T, obs_f, n_iter=5):
+    p = f64(pos).copy()
+    T, ff = f64(obs_T), f64(obs_f)
+    it = C.c_int(0)
+    lib().svo_orc_point_optimize(C.c_int(n_iter), _p(p, C.c_double), C.c_int(len(T)), _p(T, C.c_double),
+                                 _p(ff, C.c_double), C.byref(it))
+    return p, it.value
+
+
+def tukey_weight(x):
+    lib().svo_orc_tukey_weight.restype = C.c_float
+    return float(lib().svo_orc_tukey_weight(C.c_float(x)))
+
+
+def median_f(v):
+    a = np.ascontiguousarray(v, dtype=np.float32)
+    lib().svo_orc_median_f.restype = C.c_float
+    return float(lib().svo_orc_median_f(_p(a, C.c_float), C.c_int(len(a))))
+
+
+def inverse6(A):
+    a = f64(np.asarray(A).reshape(36))
+    out = np.zeros(36)
+    lib().svo_orc_inverse6(_p(a, C.c_double), _p(out, C.c_double))
+    return out.reshape(6, 6)
+
+
+def ldlt3_solve(A, b):
+    a, bb = f64(np.asarray(A).reshape(9)), f64(b)
+    x = np.zeros(3)
+    lib().svo_orc_ldlt3_solve(_p(a, C.c_double), _p(bb, C.c_double), _p(x, C.c_double))
+    return x

@@ -230,4 +230,53 @@ int ref_find_match_direct(int width, int height, double fx, double fy, double cx
   return ok ? 1 : 0;
 }
 
+// Point::optimize (point.cpp:130-192): one map point observed from n_obs frames (pose + bearing each).
+int ref_point_optimize(int n_iter, double* pos, int n_obs, const double* obs_T_f_w, const double* obs_f) {
+  HarnessPinhole cam(640, 480, 500, 500, 320, 240);
+  std::vector<HandFrame*> frames;
+  svo::Point* pt = new svo::Point(Eigen::Vector3d(pos[0], pos[1], pos[2]));
+  const double px0[2] = {0, 0};
+  for (int k = 0; k < n_obs; ++k) {
+    HandFrame* hf = new HandFrame(&cam, nullptr, 640, 480, 0, obs_T_f_w + 7 * k);
+    svo::Feature* ftr = hf->add_feature(px0, obs_f + 3 * k, 0, nullptr);
+    ftr->point = pt;
+    pt->obs_.push_back(ftr);
+    frames.push_back(hf);
+  }
+  pt->optimize((size_t)n_iter);
+  pos[0] = pt->pos_[0]; pos[1] = pt->pos_[1]; pos[2] = pt->pos_[2];
+  delete pt;
+  for (HandFrame* hf : frames) delete hf;
+  return 0;
+}
+
+// pieces of pose_optimizer::optimizeGaussNewton that exist outside pose_optimizer.cpp (which cannot be built:
+// its logging macros need the Android NDK header)
+float ref_tukey_weight(float x) {
+  vk::robust_cost::TukeyWeightFunction w;
+  return w.value(x);
+}
+float ref_mad_scale(const float* errors, int n) {
+  std::vector<float> v(errors, errors + n);
+  vk::robust_cost::MADScaleEstimator est;
+  return est.compute(v);
+}
+double ref_median_d(const double* data, int n) {
+  std::vector<double> v(data, data + n);
+  return vk::getMedian(v);
+}
+void ref_inverse6(const double* A, double* out) {
+  Eigen::Matrix<double, 6, 6> m;
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) m(i, j) = A[6 * i + j];
+  Eigen::Matrix<double, 6, 6> r = m.inverse();
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) out[6 * i + j] = r(i, j);
+}
+void ref_ldlt3_solve(const double* A, const double* b, double* x) {
+  Eigen::Matrix3d m;
+  Eigen::Vector3d v(b[0], b[1], b[2]);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m(i, j) = A[3 * i + j];
+  Eigen::Vector3d r = m.ldlt().solve(v);
+  x[0] = r[0]; x[1] = r[1]; x[2] = r[2];
+}
+
 }  // extern "C"

@@ -225,3 +225,32 @@ def find_match_direct(cam, ref_pyr, cur_pyr, T_ref_w, T_cur_w, px_ref, f_ref, le
                                      _p(ff, D), C.c_int(level_ref), _p(pp, D), C.c_int(1 if edgelet else 0), _p(g, D),
                                      _p(pc, D), C.byref(lvl))
     return {"ok": bool(ok), "px_cur": pc, "search_level": lvl.value}
+
+
+# ---- next rows f-4 ----
+def point_optimize(pos, obs_T, obs_f, n_iter=5):
+    p = f64(pos).copy()
+    T, ff = f64(obs_T), f64(obs_f)
+    lib().ref_point_optimize(C.c_int(n_iter), _p(p, D), C.c_int(len(T)), _p(T, D), _p(ff, D))
+    return p
+
+
+def tukey_weight(x):
+    lib().ref_tukey_weight.restype = C.c_float
+    return float(lib().ref_tukey_weight(C.c_float(x)))
+
+
+def mad_scale(errors):
+    e = np.ascontiguousarray(errors, dtype=np.float32)
+    lib().ref_mad_scale.restype = C.c_float
+    return float(lib().ref_mad_scale(_p(e, C.c_float), C.c_int(len(e))))
+
+
+def median_d(data):
+    d = f64(data)
+    lib().ref_median_d.restype = D
+    return float(lib().ref_median_d(_p(d, D), C.c_int(len(d))))
+
+
+def inverse6(A): return _call_vec("ref_inverse6", 36, np.asarray(A).reshape(36)).reshape(6, 6)
+def ldlt3_solve(A, b): return _call_vec("ref_ldlt3_solve", 3, np.asarray(A).reshape(9), b)

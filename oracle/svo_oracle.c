@@ -214,10 +214,28 @@ void svo_orc_jacobian_xyz2uv(const double p[3], double J[12]) {
 }
 
 /* Eigen 3.4.0 Cholesky/LDLT.h:297-403 (unblocked, lower) + :574-613 (solve). */
-int svo_orc_ldlt6_solve(const double Hin[36], const double b[6], double x[6]) {
-  enum { N = 6 };
-  double m[N][N];
-  int tr[N];
+/* sum of n terms as Eigen's redux_novec_unroller splits it: [0, n/2) + [n/2, n) recursively */
+static double redux_tree(const double* a, int n) {
+  if (n == 1) return a[0];
+  const int h = n / 2;
+  return redux_tree(a, h) + redux_tree(a + h, n - h);
+}
+
+/* the same sum when both operands have packet access (2 doubles per SSE2 packet): the packets are added by
+ * binary splitting, the two lanes of the result are added, then the scalar remainder (Core/Redux.h) */
+static double redux_packet2(const double* a, int n) {
+  const int np = n / 2;
+  if (np == 0) return redux_tree(a, n);
+  double lo[3], hi[3];
+  for (int k = 0; k < np; ++k) { lo[k] = a[2 * k]; hi[k] = a[2 * k + 1]; }
+  double res = redux_tree(lo, np) + redux_tree(hi, np);
+  if (2 * np != n) res = res + redux_tree(a + 2 * np, n - 2 * np);
+  return res;
+}
+
+static int ldlt_solve_n(const int N, const double* Hin, const double* b, double* x) {
+  double m[6][6];
+  int tr[6];
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) m[i][j] = Hin[i * N + j];
 
@@ -234,7 +252,7 @@ int svo_orc_ldlt6_solve(const double Hin[36], const double b[6], double x[6]) {
       for (int i = k + 1; i < big; ++i) { double t = m[i][k]; m[i][k] = m[big][i]; m[big][i] = t; }
     }
     if (k > 0) {
-      double temp[N];
+      double temp[6];
       for (int i = 0; i < k; ++i) temp[i] = m[i][i] * m[k][i];
       double s = 0.0;
       for (int i = 0; i < k; ++i) s += m[k][i] * temp[i];
@@ -255,29 +273,35 @@ int svo_orc_ldlt6_solve(const double Hin[36], const double b[6], double x[6]) {
       for (int r = k + 1; r < N; ++r) m[r][k] /= akk;
   }
 
-  double d[N];
+  double d[6];
   for (int i = 0; i < N; ++i) d[i] = b[i];
   for (int k = 0; k < N; ++k)
     if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
-  for (int i = 0; i < N; ++i) {            /* L^-1 (unit lower) */
-    double s = d[i];
-    for (int j = 0; j < i; ++j) s -= m[i][j] * d[j];
-    d[i] = s;
+  /* Eigen solves fixed-size triangular systems with an unrolled row-wise formula (Core/SolveTriangular.h:
+   * rhs(I) -= lhs.row(I).segment(..).cwiseProduct(rhs.segment(..)).sum()): the products are summed first, by the
+   * unrolled redux's binary splitting (Core/Redux.h), and the sum is subtracted once. */
+  for (int i = 1; i < N; ++i) {            /* L^-1 (unit lower) */
+    double t[6];
+    for (int j = 0; j < i; ++j) t[j] = m[i][j] * d[j];
+    d[i] -= redux_tree(t, i);
   }
   const double tol = DBL_MIN;              /* pseudo-inverse of D, :595-603 */
   for (int i = 0; i < N; ++i) {
     if (fabs(m[i][i]) > tol) d[i] /= m[i][i]; else d[i] = 0.0;
   }
-  for (int i = N - 1; i >= 0; --i) {       /* L^-T */
-    double s = d[i];
-    for (int j = i + 1; j < N; ++j) s -= m[j][i] * d[j];
-    d[i] = s;
+  for (int i = N - 2; i >= 0; --i) {       /* L^-T */
+    double t[6];
+    for (int j = i + 1; j < N; ++j) t[j - i - 1] = m[j][i] * d[j];
+    d[i] -= redux_packet2(t, N - 1 - i);   /* column i of L is contiguous: Eigen vectorises this sum (SSE2) */
   }
   for (int k = N - 1; k >= 0; --k)
     if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
   for (int i = 0; i < N; ++i) x[i] = d[i];
   return 1;
 }
+
+int svo_orc_ldlt6_solve(const double Hin[36], const double b[6], double x[6]) { return ldlt_solve_n(6, Hin, b, x); }
+int svo_orc_ldlt3_solve(const double Ain[9], const double b[3], double x[3]) { return ldlt_solve_n(3, Ain, b, x); }
 
 /* ------------------------------------------------------------------------ */
 /* image helpers                                                             */
@@ -1172,5 +1196,248 @@ int svo_orc_update_seeds(
       status[i] = SVO_SEED_UPDATED;
     }
   }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* next rows f-4: motion-only pose refinement and structure refinement       */
+/* ------------------------------------------------------------------------ */
+
+/* k-th smallest (k = floor(n/2)) as vk::getMedian does with nth_element (I/math_utils.h:124-131):
+ * the value does not depend on the selection algorithm. */
+static int cmp_float(const void* a, const void* b) {
+  float x = *(const float*)a, y = *(const float*)b;
+  return (x > y) - (x < y);
+}
+static int cmp_double(const void* a, const void* b) {
+  double x = *(const double*)a, y = *(const double*)b;
+  return (x > y) - (x < y);
+}
+float svo_orc_median_f(const float* v, int n) {
+  float* t = (float*)malloc(sizeof(float) * (size_t)n);
+  memcpy(t, v, sizeof(float) * (size_t)n);
+  qsort(t, (size_t)n, sizeof(float), cmp_float);
+  float r = t[n / 2];
+  free(t);
+  return r;
+}
+static double median_d(const double* v, int n) {
+  double* t = (double*)malloc(sizeof(double) * (size_t)n);
+  memcpy(t, v, sizeof(double) * (size_t)n);
+  qsort(t, (size_t)n, sizeof(double), cmp_double);
+  double r = t[n / 2];
+  free(t);
+  return r;
+}
+
+/* vk::robust_cost::TukeyWeightFunction::value with DEFAULT_B = 8.6851f (S/robust_cost.cpp:87-106) */
+float svo_orc_tukey_weight(float x) {
+  const float b = 8.6851f;
+  const float b_square = b * b;
+  const float x_square = x * x;
+  if (x_square <= b_square) {
+    const float tmp = 1.0f - x_square / b_square;
+    return tmp * tmp;
+  }
+  return 0.0f;
+}
+
+/* Eigen 3.4.0 Matrix<double,6,6>::inverse() = partialPivLu().inverse(): unblocked right-looking LU with
+ * partial pivoting (LU/PartialPivLU.h:379-425), then P, unit-lower and upper substitution on the identity.
+ * Eigen runs the substitutions through its blocked matrix kernel, so only a tolerance is claimed. */
+void svo_orc_inverse6(const double Ain[36], double out[36]) {
+  enum { N = 6 };
+  double lu[N][N];
+  int piv[N];
+  for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) lu[i][j] = Ain[i * N + j];
+  for (int k = 0; k < N; ++k) {
+    int big = k;
+    double best = fabs(lu[k][k]);
+    for (int i = k + 1; i < N; ++i) if (fabs(lu[i][k]) > best) { best = fabs(lu[i][k]); big = i; }
+    piv[k] = big;
+    if (best != 0.0) {
+      if (big != k) for (int j = 0; j < N; ++j) { double t = lu[k][j]; lu[k][j] = lu[big][j]; lu[big][j] = t; }
+      for (int i = k + 1; i < N; ++i) lu[i][k] /= lu[k][k];
+    }
+    for (int i = k + 1; i < N; ++i)
+      for (int j = k + 1; j < N; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+  }
+  for (int c = 0; c < N; ++c) {
+    double d[N];
+    for (int i = 0; i < N; ++i) d[i] = (i == c) ? 1.0 : 0.0;
+    for (int k = 0; k < N; ++k) if (piv[k] != k) { double t = d[k]; d[k] = d[piv[k]]; d[piv[k]] = t; }
+    for (int i = 0; i < N; ++i) { double s = d[i]; for (int j = 0; j < i; ++j) s -= lu[i][j] * d[j]; d[i] = s; }
+    for (int i = N - 1; i >= 0; --i) {
+      double s = d[i];
+      for (int j = i + 1; j < N; ++j) s -= lu[i][j] * d[j];
+      d[i] = s / lu[i][i];
+    }
+    for (int i = 0; i < N; ++i) out[i * N + c] = d[i];
+  }
+}
+
+/* pose_optimizer::optimizeGaussNewton, S/pose_optimizer.cpp:31-181 (verbose output left out).
+ * em = frame->cam_->errorMultiplier2().  has_point[i] != 0 <=> (*it)->point != NULL; cleared for the
+ * observations the final outlier test removes (:150-157). */
+int svo_orc_pose_optimize(double em, double reproj_thresh, int n_iter, const double T_f_w_in[7], int n,
+                          const double* f, const double* pos, const int* level, uint8_t* has_point,
+                          svo_orc_pose_opt_result* out) {
+  memset(out, 0, sizeof(*out));
+  double T[7], T_old[7];
+  memcpy(T, T_f_w_in, sizeof(T));
+  memcpy(T_old, T_f_w_in, sizeof(T));                                   /* :45 */
+  memcpy(out->T_f_w, T, sizeof(T));
+  double chi2 = 0.0;
+  double A[36], b[6];
+  /* :51-60 scale of the error for robust estimation */
+  float* errors = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+  int n_err = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!has_point[i]) continue;
+    double xyz[3];
+    svo_orc_se3_act(T, pos + 3 * i, xyz);
+    const double* fi = f + 3 * i;
+    double e0 = fi[0] / fi[2] - xyz[0] / xyz[2];
+    double e1 = fi[1] / fi[2] - xyz[1] / xyz[2];
+    const double s = 1.0 / (1 << level[i]);
+    e0 *= s; e1 *= s;
+    errors[n_err++] = (float)sqrt(e0 * e0 + e1 * e1);
+  }
+  if (n_err == 0) { free(errors); return 0; }                              /* :61-62 */
+  out->ran = 1;
+  double estimated_scale = (double)(1.48f * svo_orc_median_f(errors, n_err));   /* MADScaleEstimator, robust_cost.cpp:67-74 */
+  free(errors);
+  size_t num_obs = (size_t)n_err;
+  double* chi2_init = (double*)malloc(sizeof(double) * num_obs);
+  double* chi2_final = (double*)malloc(sizeof(double) * num_obs);
+  int n_init = 0, n_final = 0;
+  double scale = estimated_scale;
+  memset(A, 0, sizeof(A));
+  for (int iter = 0; iter < n_iter; ++iter) {
+    if (iter == 5) scale = 0.85 / em;                                      /* :74-75 */
+    memset(b, 0, sizeof(b));
+    memset(A, 0, sizeof(A));
+    double new_chi2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+      if (!has_point[i]) continue;
+      double xyz[3], J[12];
+      svo_orc_se3_act(T, pos + 3 * i, xyz);
+      svo_orc_jacobian_xyz2uv(xyz, J);
+      const double* fi = f + 3 * i;
+      double e0 = fi[0] / fi[2] - xyz[0] / xyz[2];
+      double e1 = fi[1] / fi[2] - xyz[1] / xyz[2];
+      const double sqrt_inv_cov = 1.0 / (1 << level[i]);
+      e0 *= sqrt_inv_cov; e1 *= sqrt_inv_cov;
+      const double sq = e0 * e0 + e1 * e1;
+      if (iter == 0) chi2_init[n_init++] = sq;
+      for (int k = 0; k < 12; ++k) J[k] *= sqrt_inv_cov;
+      const double weight = (double)svo_orc_tukey_weight((float)(sqrt(sq) / scale));
+      for (int r = 0; r < 6; ++r) {
+        for (int c = 0; c < 6; ++c) A[r * 6 + c] += (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;   /* J^T J w */
+        b[r] -= (J[r] * e0 + J[6 + r] * e1) * weight;                                                /* J^T e w */
+      }
+      new_chi2 += sq * weight;
+    }
+    double dT[6];
+    svo_orc_ldlt6_solve(A, b, dT);
+    out->n_iter_done = iter + 1;
+    if ((iter > 0 && new_chi2 > chi2 * 1.2) || isnan(dT[0])) {           /* :106-116 */
+      memcpy(T, T_old, sizeof(T));
+      break;
+    }
+    double E[7], Tn[7];
+    svo_orc_se3_exp(dT, E);
+    svo_orc_se3_mul(E, T, Tn);                                             /* SE3::exp(dT) * T_f_w (:120) */
+    memcpy(T_old, T, sizeof(T));
+    memcpy(T, Tn, sizeof(T));
+    chi2 = new_chi2;
+    double mx = -1;
+    for (int k = 0; k < 6; ++k) { double a = fabs(dT[k]); if (a > mx) mx = a; }
+    if (mx <= 0.0000000001) break;                                         /* EPS, global.h:91 */
+  }
+  /* :141 covariance = (A em^2)^-1 */
+  {
+    double As[36];
+    const double em2 = pow(em, 2);
+    for (int k = 0; k < 36; ++k) As[k] = A[k] * em2;
+    svo_orc_inverse6(As, out->Cov);
+  }
+  /* :144-159 remove measurements with too large reprojection error */
+  const double thresh = reproj_thresh / em;
+  int n_deleted = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!has_point[i]) continue;
+    double xyz[3];
+    svo_orc_se3_act(T, pos + 3 * i, xyz);
+    const double* fi = f + 3 * i;
+    double e0 = fi[0] / fi[2] - xyz[0] / xyz[2];
+    double e1 = fi[1] / fi[2] - xyz[1] / xyz[2];
+    const double s = 1.0 / (1 << level[i]);
+    e0 *= s; e1 *= s;
+    const double sq = e0 * e0 + e1 * e1;
+    chi2_final[n_final++] = sq;
+    if (sqrt(sq) > thresh) { has_point[i] = 0; ++n_deleted; }
+  }
+  out->error_init = n_init ? sqrt(median_d(chi2_init, n_init)) * em : 0.0;
+  out->error_final = n_final ? sqrt(median_d(chi2_final, n_final)) * em : 0.0;
+  out->estimated_scale = estimated_scale * em;
+  out->num_obs = num_obs - (size_t)n_deleted;
+  out->n_deleted = n_deleted;
+  memcpy(out->T_f_w, T, sizeof(T));
+  free(chi2_init); free(chi2_final);
+  return 0;
+}
+
+/* Point::jacobian_xyz2uv, I/point.h:83-97: -[1/z 0 -x/z^2; 0 1/z -y/z^2] * R_f_w.
+ * Eigen evaluates this 2x3 product a column (2 doubles = one SSE2 packet) at a time, accumulating over the
+ * inner index: (a0 + a1) + a2. */
+static void point_jacobian(const double p[3], const double R[9], double J[6]) {
+  const double z_inv = 1.0 / p[2];
+  const double z_inv_sq = z_inv * z_inv;
+  const double j[6] = {-(z_inv), -(0.0), -(-p[0] * z_inv_sq), -(0.0), -(z_inv), -(-p[1] * z_inv_sq)};
+  for (int r = 0; r < 2; ++r)
+    for (int c = 0; c < 3; ++c)
+      J[r * 3 + c] = (j[r * 3 + 0] * R[0 * 3 + c] + j[r * 3 + 1] * R[1 * 3 + c]) + j[r * 3 + 2] * R[2 * 3 + c];
+}
+
+/* Point::optimize, S/point.cpp:130-192.  obs k: pose of the observing frame T_f_w[k] and bearing f[k]. */
+int svo_orc_point_optimize(int n_iter, double pos[3], int n_obs, const double* obs_T_f_w, const double* obs_f,
+                           int* iters_done) {
+  double old_point[3] = {pos[0], pos[1], pos[2]};
+  double chi2 = 0.0;
+  int done = 0;
+  for (int i = 0; i < n_iter; ++i) {
+    double A[9] = {0}, b[3] = {0};
+    double new_chi2 = 0.0;
+    for (int k = 0; k < n_obs; ++k) {
+      const double* T = obs_T_f_w + 7 * k;
+      const double* fk = obs_f + 3 * k;
+      double p[3], R[9], J[6];
+      svo_orc_se3_act(T, pos, p);
+      svo_orc_se3_rotation_matrix(T, R);
+      point_jacobian(p, R, J);
+      const double e0 = fk[0] / fk[2] - p[0] / p[2];
+      const double e1 = fk[1] / fk[2] - p[1] / p[2];
+      new_chi2 += e0 * e0 + e1 * e1;
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) A[r * 3 + c] += J[r] * J[c] + J[3 + r] * J[3 + c];
+        b[r] -= J[r] * e0 + J[3 + r] * e1;
+      }
+    }
+    double dp[3];
+    svo_orc_ldlt3_solve(A, b, dp);
+    done = i + 1;
+    if ((i > 0 && new_chi2 > chi2) || isnan(dp[0])) {
+      pos[0] = old_point[0]; pos[1] = old_point[1]; pos[2] = old_point[2];
+      break;
+    }
+    old_point[0] = pos[0]; old_point[1] = pos[1]; old_point[2] = pos[2];
+    pos[0] += dp[0]; pos[1] += dp[1]; pos[2] += dp[2];
+    chi2 = new_chi2;
+    double mx = -1;
+    for (int k = 0; k < 3; ++k) { double a = fabs(dp[k]); if (a > mx) mx = a; }
+    if (mx <= 0.0000000001) break;
+  }
+  if (iters_done) *iters_done = done;
   return 0;
 }

@@ -215,6 +215,30 @@ int svo_orc_update_seeds(
     int* status, double* z_out, double* xyz_world /*[n][3], valid when converged*/,
     int* n_zmssd, int* n_align_iters);
 
+/* ---- next rows f-4: pose_optimizer::optimizeGaussNewton (pose_optimizer.cpp:31-181) and
+ * ---- Point::optimize (point.cpp:130-192) ------------------------------------------------ */
+int svo_orc_ldlt3_solve(const double A[9], const double b[3], double x[3]);
+float svo_orc_median_f(const float* v, int n);          /* vk::getMedian: element floor(n/2) of the sorted data */
+float svo_orc_tukey_weight(float x);                    /* TukeyWeightFunction::value, b = 8.6851f */
+void svo_orc_inverse6(const double A[36], double out[36]);   /* Matrix<double,6,6>::inverse() (partial-pivot LU) */
+
+typedef struct {
+  int ran;                /* 0: no observation with a point -> the reference returns before touching anything */
+  double T_f_w[7];        /* refined pose (rolled back when the last step was rejected)                     */
+  double estimated_scale; /* MAD scale * errorMultiplier2, as returned through the reference parameter       */
+  double error_init, error_final;
+  size_t num_obs;         /* observations left after the outlier test                                        */
+  double Cov[36];         /* frame->Cov_                                                                     */
+  int n_iter_done;        /* linear systems built and solved                                                 */
+  int n_deleted;
+} svo_orc_pose_opt_result;
+
+int svo_orc_pose_optimize(double error_multiplier2, double reproj_thresh, int n_iter, const double T_f_w[7], int n,
+                          const double* f /*[n][3]*/, const double* pos /*[n][3]*/, const int* level /*[n]*/,
+                          uint8_t* has_point /*[n] in/out*/, svo_orc_pose_opt_result* out);
+int svo_orc_point_optimize(int n_iter, double pos[3] /*in/out*/, int n_obs, const double* obs_T_f_w /*[n_obs][7]*/,
+                           const double* obs_f /*[n_obs][3]*/, int* iters_done);
+
 #ifdef __cplusplus
 }
 #endif

@@ -717,3 +717,105 @@ def test_match_direct_against_reference_fixture(ctx, golden):
     assert both1.sum() > 20
     assert np.percentile(np.abs(px_out[both1] - g["px_out"][both1]).max(axis=1), 95) < 2e-2
     ref.destroy(); cur.destroy()
+
+
+# ---- next rows f-4: pose_optimizer::optimizeGaussNewton, Point::optimize, and the shared 6x6 LDLT ----
+def test_ldlt6_device_is_bit_identical_to_eigen(ctx, golden):
+    """The one-lane pivoted LDL^T of both Gauss-Newton solvers against Eigen's own results (algebra.npz, made by the
+    reference build): bit for bit, rank-deficient and all-zero matrices included."""
+    g = golden("algebra.npz")
+    x = hip.ldlt6_solve_batch(ctx, g["H"], g["b"])
+    np.testing.assert_array_equal(x, g["x"])
+    rng = np.random.default_rng(3)
+    Hs, bs = [], []
+    for t in range(500):
+        M = rng.normal(size=(int(rng.integers(2, 40)), 6)) * rng.uniform(0.01, 100, 6)
+        Hs.append((M.T @ M).reshape(36)); bs.append(rng.normal(size=6))
+    Hs, bs = np.array(Hs), np.array(bs)
+    x = hip.ldlt6_solve_batch(ctx, Hs, bs)
+    import ctypes
+    for i in range(len(Hs)):
+        xo = np.zeros(6)
+        orc.lib().svo_orc_ldlt6_solve(orc._p(orc.f64(Hs[i]), ctypes.c_double), orc._p(orc.f64(bs[i]), ctypes.c_double),
+                                      orc._p(xo, ctypes.c_double))
+        np.testing.assert_array_equal(x[i], xo)
+
+
+def test_point_optimize_against_reference_fixture(ctx, golden):
+    """svo_hip_point_optimize_batch_dev against Point::optimize executed by the reference's own compiled point.cpp."""
+    g = golden("refine_ref.npz")
+    pos0, off, Ts, fs, pos_true, iters = synth.make_point_opt_cases()
+    for n_iter in (5, 20):
+        sel = np.where(iters == n_iter)[0]
+        o2 = np.zeros(len(sel) + 1, dtype=np.int32)
+        T2, f2 = [], []
+        for k, i in enumerate(sel):
+            T2.append(Ts[off[i]:off[i + 1]]); f2.append(fs[off[i]:off[i + 1]])
+            o2[k + 1] = o2[k] + (off[i + 1] - off[i])
+        out, it = hip.point_optimize_batch(ctx, pos0[sel], o2, np.concatenate(T2), np.concatenate(f2), n_iter=n_iter)
+        np.testing.assert_array_equal(out, g["point_out"][sel])          # same statements, same order: bit-identical
+        assert (it >= 1).all() and (it <= n_iter).all()
+
+
+@pytest.mark.parametrize("seed,n", [(5, 400), (6, 1200), (7, 37), (9, 3000)])
+def test_pose_optimize_parity(ctx, seed, n):
+    """svo_hip_pose_optimize against the oracle restatement of pose_optimizer::optimizeGaussNewton: the selection
+    steps (MAD scale, medians) exact, the pose to 1e-10, the same observations removed."""
+    pc = synth.make_pose_opt_case(seed=seed, n=n)
+    em = abs(pc.cam.fx)
+    o, hp_o = orc.pose_optimize(em, pc.T_f_w_init, pc.f, pc.pos, pc.level, pc.has_point)
+    r, hp = hip.pose_optimize(ctx, pc.T_f_w_init, pc.f, pc.pos, pc.level, pc.has_point, em)
+    assert r.ran == 1 and r.n_iter_done == o.n_iter_done
+    assert r.estimated_scale == o.estimated_scale                         # k-th element of the f32 errors: exact
+    rot, trans = synth.pose_error(np.array(r.T_f_w), np.array(o.T_f_w))
+    assert rot < 1e-10 and trans < 1e-10, (rot, trans)
+    assert abs(r.error_init - o.error_init) <= 1e-12 * o.error_init       # evaluated at the same initial pose
+    assert abs(r.error_final - o.error_final) <= 1e-8 * o.error_final
+    diff = hp != hp_o
+    assert diff.sum() <= 1                                               # only an observation sitting on the threshold may flip
+    assert abs(int(r.num_obs) - int(o.num_obs)) <= 1 and abs(r.n_deleted - o.n_deleted) <= 1
+    Co, Cr = np.array(o.Cov), np.array(r.Cov)
+    assert np.abs(Cr - Co).max() <= 1e-6 * np.abs(Co).max()
+    rot_t, tr_t = synth.pose_error(np.array(r.T_f_w), pc.T_f_w_true)
+    rot_0, tr_0 = synth.pose_error(pc.T_f_w_init, pc.T_f_w_true)
+    assert rot_t < 0.3 * rot_0 and tr_t < 0.3 * tr_0
+
+
+def test_pose_optimize_batch_and_edge_cases(ctx):
+    cases = [synth.make_pose_opt_case(seed=20 + k, n=n) for k, n in enumerate((300, 1, 800, 64))]
+    em = abs(cases[0].cam.fx)
+    B, max_n = len(cases) + 1, 800
+    T = np.zeros((B, 7)); f = np.zeros((B, max_n, 3)); pos = np.zeros((B, max_n, 3))
+    f[..., 2] = 1.0
+    lvl = np.zeros((B, max_n), dtype=np.int32); hp = np.zeros((B, max_n), dtype=np.uint8); nf = np.zeros(B, dtype=np.int32)
+    for k, pc in enumerate(cases):
+        n = len(pc.level)
+        T[k], f[k, :n], pos[k, :n], lvl[k, :n], hp[k, :n], nf[k] = pc.T_f_w_init, pc.f, pc.pos, pc.level, pc.has_point, n
+    T[B - 1] = cases[0].T_f_w_init                                        # last frame: no observation has a point
+    nf[B - 1] = 100
+    res, hp_out = hip.pose_optimize_batch(ctx, T, f, pos, lvl, hp, nf, em)
+    for k, pc in enumerate(cases):
+        o, hp_o = orc.pose_optimize(em, pc.T_f_w_init, pc.f, pc.pos, pc.level, pc.has_point)
+        n = len(pc.level)
+        assert res[k].ran == o.ran
+        if o.ran:
+            rot, trans = synth.pose_error(np.array(res[k].T_f_w), np.array(o.T_f_w))
+            assert rot < 1e-9 and trans < 1e-9, (k, rot, trans)
+            assert res[k].estimated_scale == o.estimated_scale
+            assert (hp_out[k, :n] != hp_o).sum() <= 1
+    assert res[B - 1].ran == 0 and list(res[B - 1].T_f_w) == list(T[B - 1]) and not hp_out[B - 1].any()
+
+
+def test_point_optimize_host_buffer_entry(ctx):
+    """svo_hip_point_optimize_batch (host buffers) gives what the device-pointer entry gives."""
+    pos0, off, Ts, fs, _, _ = synth.make_point_opt_cases(n_points=64)
+    ref_out, ref_it = hip.point_optimize_batch(ctx, pos0, off, Ts, fs, n_iter=5)
+    p = np.ascontiguousarray(pos0, dtype=np.float64).copy()
+    o = np.ascontiguousarray(off, dtype=np.int32)
+    T, f = np.ascontiguousarray(Ts, dtype=np.float64), np.ascontiguousarray(fs, dtype=np.float64)
+    it = np.zeros(64, dtype=np.int32)
+    ctx.check(ctx.lib.svo_hip_point_optimize_batch(ctx.h, 64, 5, p.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p),
+                                                   T.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p),
+                                                   it.ctypes.data_as(C.c_void_p)), "point_optimize_batch")
+    np.testing.assert_array_equal(p, ref_out)
+    np.testing.assert_array_equal(it, ref_it)
