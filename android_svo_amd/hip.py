@@ -479,3 +479,40 @@ def ldlt6_solve_batch(ctx: Context, H, b):
     ctx.check(ctx.lib.svo_hip_ldlt6_solve_batch(ctx.h, len(Hm), _ptr(Hm, C.c_double), _ptr(bv, C.c_double),
                                                 _ptr(x, C.c_double)), "ldlt6_solve_batch")
     return x
+
+
+# ---- next row f-3: FastDetector::detect, Seed::Seed ---------------------------------------------------------------
+def detect_grid(width: int, height: int, cell_size: int):
+    gc, gr = C.c_int(0), C.c_int(0)
+    load_library().svo_hip_detect_grid(width, height, cell_size, C.byref(gc), C.byref(gr))
+    return gc.value, gr.value
+
+
+def detect_features(ctx: Context, pyr: Pyramid, slot: int, cam=None, n_pyr_levels: int = 3, cell_size: int = 20,
+                    occupancy=None, detection_threshold: float = 10.0):
+    """FastDetector::detect on one pyramid slot.  Returns px [n,2] f64 (level-0 pixel), f [n,3] (when cam is given),
+    level [n] i32, score [n] f32 in grid-cell order."""
+    gc, gr = detect_grid(pyr.width, pyr.height, cell_size)
+    nc = gc * gr
+    px, f = np.zeros((nc, 2)), np.zeros((nc, 3))
+    lvl, sc = np.zeros(nc, dtype=np.int32), np.zeros(nc, dtype=np.float32)
+    n = C.c_int32(0)
+    occ = None if occupancy is None else np.ascontiguousarray(occupancy, dtype=np.uint8)
+    c = make_camera(cam) if cam is not None else None
+    ctx.check(ctx.lib.svo_hip_detect_features(
+        ctx.h, pyr.h, slot, C.byref(c) if c is not None else None, n_pyr_levels, cell_size,
+        None if occ is None else _ptr(occ, C.c_uint8), C.c_double(detection_threshold), C.byref(n), _ptr(px, C.c_double),
+        _ptr(f, C.c_double) if c is not None else None, _ptr(lvl, C.c_int32), _ptr(sc, C.c_float)), "detect_features")
+    k = n.value
+    return px[:k].copy(), (f[:k].copy() if c is not None else None), lvl[:k].copy(), sc[:k].copy()
+
+
+def seed_init_batch(ctx: Context, n: int, depth_mean: float, depth_min: float):
+    """Seed::Seed for n seeds; returns (a, b, mu, z_range, sigma2) f32 arrays."""
+    d = [ctx.empty((max(n, 1),), np.float32) for _ in range(5)]
+    ctx.check(ctx.lib.svo_hip_seed_init_batch_dev(ctx.h, n, C.c_double(depth_mean), C.c_double(depth_min),
+                                                  *[C.c_void_p(v.ptr) for v in d]), "seed_init_batch")
+    out = tuple(v.download()[:n] for v in d)
+    for v in d:
+        v.free()
+    return out

@@ -145,6 +145,23 @@ def main():
         t_cq = (time.perf_counter() - t0) / 2000
         out["refine_cpu_port_1thread"] = {"pose_refine_frames_per_s": 1.0 / t_cp, "point_refine_points_per_s_incl_ctypes": 1.0 / t_cq}
 
+    # ---------------- next row f-3: FastDetector::detect on a 640x480 keyframe (3 levels, 20 px cells) ----------------
+    dn, dpx, df_, dl, dsc = ctx.empty((1,), np.int32), ctx.empty((768, 2), np.float64), ctx.empty((768, 3), np.float64), ctx.empty((768,), np.int32), ctx.empty((768,), np.float32)
+    ccam = hip.make_camera(sc.cam)
+
+    def run_detect():
+        ctx.check(ctx.lib.svo_hip_detect_features_dev(ctx.h, kf.h, 0, C.byref(ccam), 3, 20, None, C.c_double(10.0), C.c_void_p(dn.ptr),
+                                                      C.c_void_p(dpx.ptr), C.c_void_p(df_.ptr), C.c_void_p(dl.ptr), C.c_void_p(dsc.ptr)), "detect")
+    t_det = timed(ctx, run_detect, args.steps, args.warmup)
+    px_bytes = sum((640 >> l) * (480 >> l) for l in range(3))
+    out["detect_features"] = {"us_per_keyframe": t_det * 1e6, "features": int(dn.download()[0]), "launches": 8,
+                              "algorithmic_bytes": 3 * px_bytes, "note": "reads each level twice (decision, suppression) and writes its score image once"}
+    if not args.no_cpu_baseline:
+        t0 = time.perf_counter()
+        for _ in range(5):
+            orc.detect_features(sc.ref_pyr)
+        out["detect_features"]["cpu_port_us_per_keyframe_1thread"] = (time.perf_counter() - t0) / 5 * 1e6
+
     # ---------------- CPU oracle (bounded sample) ----------------
     if not args.no_cpu_baseline:
         n_thr = max(1, min(os.cpu_count() or 1, 16))

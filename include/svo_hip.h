@@ -293,6 +293,27 @@ int svo_hip_point_optimize_batch(svo_hip_ctx* ctx, int n_points, int n_iter, dou
 int svo_hip_ldlt6_solve_batch(svo_hip_ctx* ctx, int n, const double* H /*[n][36]*/, const double* b /*[n][6]*/,
                               double* x /*[n][6]*/);
 
+/* ---- next row: the producer of depth-filter seeds --------------------------------------------
+ * FastDetector::detect (I/feature_detection.h:90-103, feature_detection.cpp:77-122; called by
+ * DepthFilter::initializeSeeds, depth_filter.cpp:129-151): cv::FAST(img, kp, 10, true) on the first n_pyr_levels
+ * levels of pyramid slot `slot`, one corner per grid cell (cell_size level-0 pixels) chosen by vk::shiTomasiScore,
+ * strictly above detection_threshold; cells flagged in occupancy[grid_rows*grid_cols] (setExistingFeatures) are
+ * skipped.  Outputs in cell order (capacity = number of cells): px[n][2] level-0 pixel, optional f[n][3] =
+ * cam->cam2world(px) (distortion-free cameras only), level[n], optional score[n]; *n_out = n. */
+int svo_hip_detect_grid(int width, int height, int cell_size, int* grid_cols, int* grid_rows);
+int svo_hip_detect_features_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* pyr, int slot, const svo_hip_camera* cam,
+                                int n_pyr_levels, int cell_size, const uint8_t* occupancy_dev,
+                                double detection_threshold, int32_t* n_out_dev, double* px_dev, double* f_dev,
+                                int32_t* level_dev, float* score_dev);
+/* host-buffer convenience form (copies in, runs, copies out, synchronises) */
+int svo_hip_detect_features(svo_hip_ctx* ctx, const svo_hip_pyramid* pyr, int slot, const svo_hip_camera* cam,
+                            int n_pyr_levels, int cell_size, const uint8_t* occupancy, double detection_threshold,
+                            int32_t* n_out, double* px, double* f, int32_t* level, float* score);
+/* Seed::Seed for n new seeds (depth_filter.cpp:36-45): a = b = 10, mu = 1/depth_mean, z_range = 1/depth_min,
+ * sigma2 = z_range^2/36 */
+int svo_hip_seed_init_batch_dev(svo_hip_ctx* ctx, int n, double depth_mean, double depth_min, float* a_dev, float* b_dev,
+                                float* mu_dev, float* z_range_dev, float* sigma2_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -352,15 +352,34 @@ def gen_refine_ref():
     print("refine_ref: points", len(out))
 
 
+def gen_shitomasi_ref():
+    """vk::shiTomasiScore (vision.cpp) on a rendered image and on noise, borders included."""
+    rng = np.random.default_rng(123)
+    cam, scene, T0, T1, ref, cur = small_scene()
+    noise = rng.integers(0, 256, (96, 128)).astype(np.uint8)
+    out = {}
+    for name, img in (("scene", ref), ("noise", noise)):
+        h, w = img.shape
+        uv = np.stack([rng.integers(0, w, 1500), rng.integers(0, h, 1500)], axis=1).astype(np.int32)
+        uv[:8] = [[0, 0], [4, 4], [5, 5], [w - 6, h - 6], [w - 5, h - 5], [w - 1, h - 1], [5, h - 6], [w - 6, 5]]
+        out[name + "_img"] = img
+        out[name + "_uv"] = uv
+        out[name + "_score"] = np.array([refpy.shi_tomasi_score(img, int(u), int(v)) for u, v in uv], dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, "shitomasi_ref.npz"), **out)
+    print("shitomasi_ref written")
+
+
 def main():
     assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(OUT, exist_ok=True)
-    if "--objects-only" not in sys.argv and "--refine-only" not in sys.argv:
+    if not any(a in sys.argv for a in ("--objects-only", "--refine-only", "--shitomasi-only")):
         rng = np.random.default_rng(20240607)
         gen_se3(rng); gen_algebra(rng); gen_gn(rng); gen_align(rng); gen_matcher(rng); gen_vision(rng)
-    if "--refine-only" not in sys.argv:
+    if "--refine-only" not in sys.argv and "--shitomasi-only" not in sys.argv:
         gen_sia_ref(); gen_epi_ref(); gen_match_direct_ref()
-    gen_refine_ref()
+    if "--shitomasi-only" not in sys.argv:
+        gen_refine_ref()
+    gen_shitomasi_ref()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

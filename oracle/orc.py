@@ -282,3 +282,33 @@ def ldlt3_solve(A, b):
     x = np.zeros(3)
     lib().svo_orc_ldlt3_solve(_p(a, C.c_double), _p(bb, C.c_double), _p(x, C.c_double))
     return x
+
+
+# ---- next row f-3: FastDetector::detect ----
+def fast(img, threshold=10):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    cap = w * h
+    xs, ys, ss = (np.zeros(cap, dtype=np.int32) for _ in range(3))
+    n = lib().svo_orc_fast(_p(img, C.c_uint8), w, h, C.c_int(threshold), C.c_int(cap), _p(xs, C.c_int), _p(ys, C.c_int),
+                           _p(ss, C.c_int))
+    return xs[:n].copy(), ys[:n].copy(), ss[:n].copy()
+
+
+def shi_tomasi_score(img, u, v):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    lib().svo_orc_shi_tomasi_score.restype = C.c_float
+    return float(lib().svo_orc_shi_tomasi_score(_p(img, C.c_uint8), img.shape[1], img.shape[0], C.c_int(u), C.c_int(v)))
+
+
+def detect_features(pyr, n_pyr_levels=3, cell_size=20, occupancy=None, detection_threshold=10.0):
+    h, w = pyr[0].shape
+    gc, gr = -(-w // cell_size), -(-h // cell_size)
+    px = np.zeros((gc * gr, 2), dtype=np.int32)
+    lvl = np.zeros(gc * gr, dtype=np.int32)
+    sc = np.zeros(gc * gr, dtype=np.float32)
+    occ = None if occupancy is None else np.ascontiguousarray(occupancy, dtype=np.uint8)
+    n = lib().svo_orc_detect_features(pyr_ptrs(pyr), w, h, C.c_int(n_pyr_levels), C.c_int(cell_size),
+                                      None if occ is None else _p(occ, C.c_uint8), C.c_double(detection_threshold),
+                                      _p(px, C.c_int), _p(lvl, C.c_int), _p(sc, C.c_float))
+    return px[:n].copy(), lvl[:n].copy(), sc[:n].copy()

@@ -252,4 +252,10 @@ void ref_half_sample(const uint8_t* in, int cols, int rows, uint8_t* out) {
   vk::halfSample(a.set(in, rows, cols, cols), b.set(out, rows / 2, cols / 2, cols / 2));
 }
 
+// vk::shiTomasiScore (vision.cpp:113-154)
+float ref_shi_tomasi_score(const uint8_t* img, int cols, int rows, int u, int v) {
+  MatView mv;
+  return vk::shiTomasiScore(mv.set(img, rows, cols, cols), u, v);
+}
+
 }  // extern "C"

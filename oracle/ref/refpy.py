@@ -254,3 +254,9 @@ def median_d(data):
 
 def inverse6(A): return _call_vec("ref_inverse6", 36, np.asarray(A).reshape(36)).reshape(6, 6)
 def ldlt3_solve(A, b): return _call_vec("ref_ldlt3_solve", 3, np.asarray(A).reshape(9), b)
+
+
+def shi_tomasi_score(img, u, v):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    lib().ref_shi_tomasi_score.restype = C.c_float
+    return float(lib().ref_shi_tomasi_score(_p(img, C.c_uint8), img.shape[1], img.shape[0], C.c_int(u), C.c_int(v)))

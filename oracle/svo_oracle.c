@@ -1441,3 +1441,138 @@ int svo_orc_point_optimize(int n_iter, double pos[3], int n_obs, const double* o
   if (iters_done) *iters_done = done;
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* next row f-3: FastDetector::detect (feature_detection.cpp:77-122)         */
+/* ------------------------------------------------------------------------ */
+
+/* the 16-pixel Bresenham circle of radius 3, in OpenCV's order (features2d/src/fast_score.cpp, makeOffsets) */
+static const int kFastDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+static const int kFastDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+/* FAST-9/16 decision and score of one pixel.  PARITY UNPINNED: this is cv::FAST(img, kp, threshold, true) of
+ * OpenCV 4.5.4 (features2d/src/fast.cpp FAST_t<16>, fast_score.cpp cornerScore<16>), a third-party dependency whose
+ * source and library are not present under /root/reference; restated from its published algorithm:
+ *   corner  <=>  9 contiguous circle pixels all darker than v - t or all brighter than v + t (strict);
+ *   score   =    max(t, max over the 16 arcs of min(v - x), max over the arcs of min(x - v)) - 1, stored as u8. */
+static int fast_pixel(const uint8_t* img, int stride, int x, int y, int t, int* score) {
+  const int v = img[y * stride + x];
+  int d[25];
+  for (int k = 0; k < 25; ++k) d[k] = v - img[(y + kFastDy[k & 15]) * stride + x + kFastDx[k & 15]];
+  int corner = 0;
+  for (int pol = 0; pol < 2 && !corner; ++pol) {
+    int count = 0;
+    for (int k = 0; k < 25; ++k) {
+      const int hit = pol == 0 ? (d[k] > t) : (d[k] < -t);
+      if (hit) { if (++count > 8) { corner = 1; break; } } else count = 0;
+    }
+  }
+  if (!corner) return 0;
+  int a0 = t;
+  for (int k = 0; k < 16; ++k) {
+    int mn = d[k], mx = d[k];
+    for (int j = 1; j < 9; ++j) { if (d[k + j] < mn) mn = d[k + j]; if (d[k + j] > mx) mx = d[k + j]; }
+    if (mn > a0) a0 = mn;
+    if (-mx > a0) a0 = -mx;
+  }
+  *score = (uint8_t)(a0 - 1);
+  return 1;
+}
+
+/* cv::FAST with non-maximum suppression: key points in row-major order; returns their number */
+int svo_orc_fast(const uint8_t* img, int w, int h, int threshold, int max_out, int* xs, int* ys, int* scores) {
+  uint8_t* sc = (uint8_t*)calloc((size_t)w * h, 1);
+  for (int y = 3; y < h - 3; ++y)
+    for (int x = 3; x < w - 3; ++x) {
+      int s = 0;
+      if (fast_pixel(img, w, x, y, threshold, &s)) sc[y * w + x] = (uint8_t)s;   /* a corner always scores >= t - 1 */
+    }
+  int n = 0;
+  for (int y = 3; y < h - 3; ++y)
+    for (int x = 3; x < w - 3; ++x) {
+      int s = 0;
+      if (!fast_pixel(img, w, x, y, threshold, &s)) continue;
+      const uint8_t* p = sc + y * w + x;
+      if (s > p[1] && s > p[-1] && s > p[-w - 1] && s > p[-w] && s > p[-w + 1] && s > p[w - 1] && s > p[w] && s > p[w + 1]) {
+        if (n < max_out) { xs[n] = x; ys[n] = y; scores[n] = s; }
+        ++n;
+      }
+    }
+  free(sc);
+  return n;
+}
+
+/* vk::shiTomasiScore, S/vision.cpp:113-154 */
+float svo_orc_shi_tomasi_score(const uint8_t* img, int cols, int rows, int u, int v) {
+  float dXX = 0.0, dYY = 0.0, dXY = 0.0;
+  const int halfbox_size = 4;
+  const int box_size = 2 * halfbox_size;
+  const int box_area = box_size * box_size;
+  const int x_min = u - halfbox_size, x_max = u + halfbox_size;
+  const int y_min = v - halfbox_size, y_max = v + halfbox_size;
+  if (x_min < 1 || x_max >= cols - 1 || y_min < 1 || y_max >= rows - 1) return 0.0;
+  const int stride = cols;
+  for (int y = y_min; y < y_max; ++y) {
+    const uint8_t* ptr_left = img + stride * y + x_min - 1;
+    const uint8_t* ptr_right = img + stride * y + x_min + 1;
+    const uint8_t* ptr_top = img + stride * (y - 1) + x_min;
+    const uint8_t* ptr_bottom = img + stride * (y + 1) + x_min;
+    for (int x = 0; x < box_size; ++x, ++ptr_left, ++ptr_right, ++ptr_top, ++ptr_bottom) {
+      float dx = *ptr_right - *ptr_left;
+      float dy = *ptr_bottom - *ptr_top;
+      dXX += dx * dx;
+      dYY += dy * dy;
+      dXY += dx * dy;
+    }
+  }
+  dXX = dXX / (2.0 * box_area);
+  dYY = dYY / (2.0 * box_area);
+  dXY = dXY / (2.0 * box_area);
+  /* C++ overload resolution picks sqrt(float): the parenthesis is evaluated in f32, only the 0.5 factor is double */
+  const float tr = dXX + dYY;
+  const float root = sqrtf(tr * tr - 4 * (dXX * dYY - dXY * dXY));
+  return (float)(0.5 * (tr - root));
+}
+
+/* FastDetector::detect, S/feature_detection.cpp:77-122: per pyramid level FAST corners, one corner per grid cell
+ * (best Shi-Tomasi score, strictly above detection_threshold), cells flagged in `occupancy` skipped.
+ * Outputs in cell order: px (level-0 coordinates), level, score.  The glue is PARITY UNPINNED (detect() cannot run
+ * without cv::FAST); vk::shiTomasiScore is pinned. */
+int svo_orc_detect_features(const uint8_t* const* pyr, int width, int height, int n_pyr_levels, int cell_size,
+                            const uint8_t* occupancy, double detection_threshold, int* px_out, int* level_out,
+                            float* score_out) {
+  const int gc = (int)ceil((double)width / cell_size), gr = (int)ceil((double)height / cell_size);
+  const int n_cells = gc * gr;
+  int* cx = (int*)calloc((size_t)n_cells, sizeof(int));
+  int* cy = (int*)calloc((size_t)n_cells, sizeof(int));
+  int* cl = (int*)calloc((size_t)n_cells, sizeof(int));
+  float* cs = (float*)malloc(sizeof(float) * (size_t)n_cells);
+  for (int k = 0; k < n_cells; ++k) cs[k] = (float)detection_threshold;
+  for (int L = 0; L < n_pyr_levels; ++L) {
+    const int scale = 1 << L;
+    const int w = width >> L, h = height >> L;
+    const int cap = w * h;
+    int* xs = (int*)malloc(sizeof(int) * (size_t)cap);
+    int* ys = (int*)malloc(sizeof(int) * (size_t)cap);
+    int* ss = (int*)malloc(sizeof(int) * (size_t)cap);
+    const int n = svo_orc_fast(pyr[L], w, h, 10, cap, xs, ys, ss);
+    for (int i = 0; i < n; ++i) {
+      const float fx = (float)xs[i], fy = (float)ys[i];
+      const int k = (int)((fy * scale) / cell_size) * gc + (int)((fx * scale) / cell_size);
+      if (occupancy && occupancy[k]) continue;
+      const float score = svo_orc_shi_tomasi_score(pyr[L], w, h, xs[i], ys[i]);
+      if (score > cs[k]) { cx[k] = (int)(fx * scale); cy[k] = (int)(fy * scale); cs[k] = score; cl[k] = L; }
+    }
+    free(xs); free(ys); free(ss);
+  }
+  int n_out = 0;
+  for (int k = 0; k < n_cells; ++k)
+    if ((double)cs[k] > detection_threshold) {
+      px_out[2 * n_out] = cx[k]; px_out[2 * n_out + 1] = cy[k];
+      level_out[n_out] = cl[k];
+      score_out[n_out] = cs[k];
+      ++n_out;
+    }
+  free(cx); free(cy); free(cl); free(cs);
+  return n_out;
+}

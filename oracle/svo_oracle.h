@@ -239,6 +239,16 @@ int svo_orc_pose_optimize(double error_multiplier2, double reproj_thresh, int n_
 int svo_orc_point_optimize(int n_iter, double pos[3] /*in/out*/, int n_obs, const double* obs_T_f_w /*[n_obs][7]*/,
                            const double* obs_f /*[n_obs][3]*/, int* iters_done);
 
+/* ---- next row f-3: FastDetector::detect (feature_detection.cpp:77-122) -----------------------------------
+ * cv::FAST is third-party (OpenCV 4.5.4 features2d, neither source nor library under /root/reference): PARITY
+ * UNPINNED, restated from its published algorithm.  vk::shiTomasiScore (vision.cpp:113-154) is pinned. */
+int svo_orc_fast(const uint8_t* img, int w, int h, int threshold, int max_out, int* xs, int* ys, int* scores);
+float svo_orc_shi_tomasi_score(const uint8_t* img, int cols, int rows, int u, int v);
+/* px_out[n][2] level-0 pixel (integers), level_out[n], score_out[n]; capacity = number of grid cells; returns n */
+int svo_orc_detect_features(const uint8_t* const* pyr, int width, int height, int n_pyr_levels, int cell_size,
+                            const uint8_t* occupancy /*[cells] or NULL*/, double detection_threshold, int* px_out,
+                            int* level_out, float* score_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -819,3 +819,68 @@ def test_point_optimize_host_buffer_entry(ctx):
                                                    it.ctypes.data_as(C.c_void_p)), "point_optimize_batch")
     np.testing.assert_array_equal(p, ref_out)
     np.testing.assert_array_equal(it, ref_it)
+
+
+# ---- next row f-3: FastDetector::detect and Seed::Seed on the device ----
+@pytest.mark.parametrize("kind", ["scene", "noise", "blocks"])
+def test_detect_features_exact(ctx, kind):
+    """svo_hip_detect_features against the oracle restatement of FastDetector::detect: integer / exact-f32 work, so
+    positions, levels and scores are equal bit for bit, with and without occupied cells."""
+    rng = np.random.default_rng(8)
+    cam = synth.Camera.default()
+    if kind == "scene":
+        img = synth.make_frame_pair(seed=12345, n_features=10).ref_pyr[0]
+    elif kind == "noise":
+        img = rng.integers(0, 256, (480, 640)).astype(np.uint8)
+    else:
+        img = np.kron(rng.integers(0, 256, (30, 40)), np.ones((16, 16))).astype(np.uint8)
+        img = np.clip(img.astype(np.int32) + rng.integers(-3, 4, img.shape), 0, 255).astype(np.uint8)
+    pyr_host = synth.build_pyramid(img)
+    pyr = hip.Pyramid(ctx, 640, 480, 5, 1)
+    pyr.upload(0, pyr_host)
+    for occupancy in (None, (rng.uniform(size=32 * 24) < 0.3).astype(np.uint8)):
+        px_o, lvl_o, sc_o = orc.detect_features(pyr_host, n_pyr_levels=3, cell_size=20, occupancy=occupancy)
+        px, f, lvl, sc = hip.detect_features(ctx, pyr, 0, cam, n_pyr_levels=3, cell_size=20, occupancy=occupancy)
+        assert len(px_o) > (50 if kind == "scene" else 300)
+        np.testing.assert_array_equal(px, px_o.astype(np.float64))
+        np.testing.assert_array_equal(lvl, lvl_o)
+        np.testing.assert_array_equal(sc, sc_o)
+        np.testing.assert_array_equal(f, synth.cam2world(cam, px_o.astype(np.float64)))      # Feature::f = cam2world(px)
+    # other grid sizes / level counts
+    for cell, nl in ((30, 2), (16, 5)):
+        px_o, lvl_o, sc_o = orc.detect_features(pyr_host, n_pyr_levels=nl, cell_size=cell)
+        px, _, lvl, sc = hip.detect_features(ctx, pyr, 0, None, n_pyr_levels=nl, cell_size=cell)
+        np.testing.assert_array_equal(px, px_o.astype(np.float64))
+        np.testing.assert_array_equal(lvl, lvl_o)
+        np.testing.assert_array_equal(sc, sc_o)
+    pyr.destroy()
+
+
+def test_seed_init_batch(ctx):
+    for dm, dn in ((2.2, 1.0), (3.7123, 0.49), (1e-3, 1e-4)):
+        got = hip.seed_init_batch(ctx, 1000, dm, dn)
+        want = seedsynth.seed_ctor(dm, dn, 1000)
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g, w)
+
+
+def test_detected_seeds_feed_the_depth_filter(ctx):
+    """The producer and the consumer together: seeds detected on a keyframe go through one DepthFilter update."""
+    sc = seedsynth.make_seed_case(n_seeds=16, seed=3)
+    cam = sc.cam
+    ref = hip.Pyramid(ctx, cam.width, cam.height, 5, 1); cur = hip.Pyramid(ctx, cam.width, cam.height, 5, 1)
+    ref.upload(0, sc.ref_pyr); cur.upload(0, sc.cur_pyr)
+    px, f, lvl, score = hip.detect_features(ctx, ref, 0, cam)
+    n = len(px)
+    assert n > 50
+    zbar = float(np.median(sc.true_depth))
+    a, b, mu, zr, s2 = hip.seed_init_batch(ctx, n, 1.1 * zbar, 0.5 * zbar)
+    seeds = hip.SeedBatch(ctx, px, f, lvl, a, b, mu, zr, s2)
+    hip.depth_filter_update(ctx, ref, 0, cur, 0, cam, sc.T_ref_w, sc.T_cur_w, seeds)
+    ctx.sync()
+    status = seeds.status.download()
+    a2, b2, mu2, zr2, s22 = (v.copy() for v in (a, b, mu, zr, s2))
+    o = orc.update_seeds(cam, sc.ref_pyr, sc.cur_pyr, sc.T_ref_w, sc.T_cur_w, px, f, lvl, a2, b2, mu2, zr2, s22)
+    np.testing.assert_array_equal(status, o["status"])
+    assert (status == 3).mean() > 0.5                      # most detected corners are matched and updated
+    seeds.free(); ref.destroy(); cur.destroy()
