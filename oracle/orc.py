@@ -57,8 +57,10 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_LIB_PATH)
+        override = os.environ.get("SVO_ORACLE_LIB")          # e.g. the sanitizer build of `make -C oracle asan-check`
+        if not override:
+            build()
+        _lib = C.CDLL(override or _LIB_PATH)
         _lib.svo_orc_interpolate_8u.restype = C.c_float
         _lib.svo_orc_compute_tau.restype = C.c_double
         _lib.svo_orc_sia_eval.restype = C.c_double
