@@ -389,10 +389,9 @@ SVO_DEV double wave_reduce8(const double* v) {
 // same algorithm and operation order as ldlt6_solve above.  MUST be called with exactly one active
 // lane per wave (the callers run it on lane 0 only): the pivot index is read with readfirstlane so that
 // the row/column swaps are real scalar branches instead of ~500 predicated moves.
-SVO_DEV void ldlt6_solve_reg(const double* Hin, const double* b, double* x) {
+// factorisation half: m = the in-place LDL^T (unit lower L below the diagonal, D on it), tr = the transpositions
+SVO_DEV void ldlt6_factor_reg(const double* Hin, double (*m)[6], int* tr) {
   constexpr int N = 6;
-  double m[N][N];
-  int tr[N];
 #pragma unroll
   for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -448,6 +447,11 @@ SVO_DEV void ldlt6_solve_reg(const double* Hin, const double* b, double* x) {
       }
     }
   }
+}
+
+// substitution half: x = P^T L^-T D^+ L^-1 P b with the factor above (Eigen LDLT.h:574-613)
+SVO_DEV void ldlt6_substitute_reg(const double (*m)[6], const int* tr, const double* b, double* x) {
+  constexpr int N = 6;
   double d[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) d[i] = b[i];
@@ -472,6 +476,13 @@ SVO_DEV void ldlt6_solve_reg(const double* Hin, const double* b, double* x) {
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) x[i] = d[i];
+}
+
+SVO_DEV void ldlt6_solve_reg(const double* Hin, const double* b, double* x) {
+  double m[6][6];
+  int tr[6];
+  ldlt6_factor_reg(Hin, m, tr);
+  ldlt6_substitute_reg(m, tr, b, x);
 }
 
 }  // namespace svo_dev

@@ -652,6 +652,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   uint2* fp = reinterpret_cast<uint2*>(smem);               // [n_tiles*64][7] footprint rows
   __shared__ double red[FUSED_WAVES][32];
   __shared__ double s_r[32], s_last[32], s_x[8];
+  __shared__ double s_Hc[21], s_fac[36];   // H of the previous evaluation and its LDL^T factor
+  __shared__ int s_ftr[6], s_fac_valid;
   __shared__ double s_model[8], s_old[8];
   __shared__ double s_chi2;
   __shared__ int s_done, s_stop, s_iter;
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     se3_mul(c.T_cur_w_init, Tinv, T);                        // sparse_img_align.cpp:69
     for (int i = 0; i < 7; ++i) { s_model[i] = T[i]; s_old[i] = T[i]; }
     s_chi2 = 1e10;                                           // reset(), nlls_solver_impl.hpp:299-309
-    s_stop = 0; s_done = 0; s_iter = 0; s_npre = 0; s_nres = 0; s_nmeas = 0;
+    s_stop = 0; s_done = 0; s_iter = 0; s_npre = 0; s_nres = 0; s_nmeas = 0; s_fac_valid = 0;
     for (int i = 0; i < SVO_HIP_MAX_LEVELS; ++i) s_iters[i] = 0;
     for (int i = 0; i < 32; ++i) s_last[i] = 0.0;
     for (int i = 0; i < 8; ++i) s_x[i] = 0.0;
@@ -938,18 +940,21 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
           s_r[lane] = v;
           s_last[lane] = v;                  // H_ / Jres_ of the last evaluation, reported at the end
         }
+        // H is the sum of the per-level tile rows minus the patches outside the image at this evaluation: as long as
+        // no patch leaves, it is bit for bit the H of the previous evaluation and its LDL^T factor is reused
+        // (the factorisation is a deterministic function of H, so the result is the same number)
+        bool h_same = true;
+        if (lane < 21) {
+          const double v = s_r[lane];
+          h_same = __double_as_longlong(v) == __double_as_longlong(s_Hc[lane]);
+          s_Hc[lane] = v;
+        }
+        const bool reuse = s_fac_valid != 0 && __ballot(!h_same) == 0ull;      // wave-uniform
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane == 0) {
           // I/nlls_solver_impl.hpp:35-99 with solve()/update() of S/sparse_img_align.cpp:291-308
-          double H[36], Jres[6], x[6];
-          {
-            int kk = 0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-              for (int j = i; j < 6; ++j) { H[i * 6 + j] = s_r[kk]; H[j * 6 + i] = s_r[kk]; ++kk; }
-          }
+          double Jres[6], x[6];
 #pragma unroll
           for (int i = 0; i < 6; ++i) Jres[i] = s_r[21 + i];
           const double chi2_sum = s_r[27];
@@ -961,7 +966,34 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
 #ifdef SVO_STAMPS
           const long long q0 = __builtin_amdgcn_s_memtime();
 #endif
-          ldlt6_solve_reg(H, Jres, x);
+          {
+            double m[6][6];
+            int tr[6];
+            if (reuse) {
+#pragma unroll
+              for (int i = 0; i < 6; ++i) {
+                tr[i] = __builtin_amdgcn_readfirstlane(s_ftr[i]);
+#pragma unroll
+                for (int j = 0; j <= i; ++j) m[i][j] = s_fac[i * 6 + j];
+              }
+            } else {
+              double H[36];
+              int kk = 0;
+#pragma unroll
+              for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = i; j < 6; ++j) { H[i * 6 + j] = s_r[kk]; H[j * 6 + i] = s_r[kk]; ++kk; }
+              ldlt6_factor_reg(H, m, tr);
+#pragma unroll
+              for (int i = 0; i < 6; ++i) {
+                s_ftr[i] = tr[i];
+#pragma unroll
+                for (int j = 0; j <= i; ++j) s_fac[i * 6 + j] = m[i][j];
+              }
+              s_fac_valid = 1;
+            }
+            ldlt6_substitute_reg(m, tr, Jres, x);
+          }
 #ifdef SVO_STAMPS
           const long long q1 = __builtin_amdgcn_s_memtime();
           s_stamp[3] += q1 - q0;
