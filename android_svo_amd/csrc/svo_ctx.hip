@@ -107,6 +107,22 @@ int svo_hip_free(svo_hip_ctx* ctx, void* dev_ptr) {
   return SVO_HIP_OK;
 }
 
+int svo_hip_malloc_host(svo_hip_ctx* ctx, void** host_ptr, size_t bytes) {
+  if (!ctx || !host_ptr) return SVO_HIP_ERR_INVALID;
+  *host_ptr = nullptr;
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  SVO_CHECK_HIP(ctx, hipHostMalloc(host_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_free_host(svo_hip_ctx* ctx, void* host_ptr) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  if (!host_ptr) return SVO_HIP_OK;
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SVO_CHECK_HIP(ctx, hipHostFree(host_ptr));
+  return SVO_HIP_OK;
+}
+
 int svo_hip_memcpy_h2d(svo_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
   if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return SVO_HIP_ERR_INVALID;
   if (!bytes) return SVO_HIP_OK;
@@ -181,6 +197,21 @@ int svo_hip_pyramid_upload(svo_hip_pyramid* pyr, int slot, const uint8_t* const*
     SVO_CHECK_HIP(ctx, hipMemcpyAsync(pyr->base + (size_t)slot * pyr->pyr_bytes + pyr->level_offset[l], levels[l],
                                       bytes, hipMemcpyHostToDevice, ctx->stream));
   }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_pyramid_level_offset(const svo_hip_pyramid* pyr, int level, size_t* offset) {
+  if (!pyr || !offset || level < 0 || level >= pyr->n_levels) return SVO_HIP_ERR_INVALID;
+  *offset = pyr->level_offset[level];
+  return SVO_HIP_OK;
+}
+
+int svo_hip_pyramid_upload_packed(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* packed) {
+  if (!pyr || !packed) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = pyr->ctx;
+  SVO_REQUIRE(ctx, first_slot >= 0 && n_slots > 0 && first_slot + n_slots <= pyr->batch);
+  SVO_CHECK_HIP(ctx, hipMemcpyAsync(pyr->base + (size_t)first_slot * pyr->pyr_bytes, packed, (size_t)n_slots * pyr->pyr_bytes,
+                                    hipMemcpyHostToDevice, ctx->stream));
   return SVO_HIP_OK;
 }
 

@@ -251,6 +251,14 @@ def main():
                         "algorithmic_bytes_per_launch": alg_bytes, "note": note}
             if prof["precompute_launches"]:
                 roofline["precompute_avg_launch_us"] = prof["precompute_ms"] / prof["precompute_launches"] * 1e3
+            hp = os.path.join(ROOT, "profiles", "r01_hbm_probe.json")
+            if os.path.exists(hp):
+                try:
+                    m = json.load(open(hp))
+                    roofline["measured_ceiling"] = {"copy_d2d": m["copy_d2d"], "triad": m["triad"], "fill": m["memset"], "unit": "GB/s",
+                                                    "source": "profiles/r01_hbm_probe.json (tools/hbm_probe.py on this pool)"}
+                except Exception:
+                    pass
             tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tr):
                 try:
@@ -276,6 +284,7 @@ def main():
                        "distinct_scenes": args.distinct,
                        "implementation": "fused (one workgroup per frame pair, one launch per solve)" if (not allreduce and sia.last_run_mode() == 1) else "streaming (one launch per Gauss-Newton evaluation)"},
             "pose_err_vs_cpu_ref": {"rot_rad": rot, "trans_m": trans, "tolerance": "1e-4 rad / 1e-3 m"},
+            "pose_err_vs_ground_truth": dict(zip(("rot_rad", "trans_m"), synth.pose_error(np.array(res.T_cur_w), fps[0].T_cur_w_true))),
             "gn_evaluations_per_frame": int(evals),
             "single_pair_latency_ms_early_stop": latency_ms,
             "algorithmic_bytes_per_frame": int(bytes_frame),

@@ -68,6 +68,10 @@ int svo_hip_device_count(int* count);
 
 int svo_hip_malloc(svo_hip_ctx* ctx, void** dev_ptr, size_t bytes);
 int svo_hip_free(svo_hip_ctx* ctx, void* dev_ptr);
+/* page-locked host memory for image / feature staging: uploads from it are asynchronous DMA at link rate, uploads
+ * from pageable memory are staged by the runtime (measured: profiles/r01_hbm_probe.json) */
+int svo_hip_malloc_host(svo_hip_ctx* ctx, void** host_ptr, size_t bytes);
+int svo_hip_free_host(svo_hip_ctx* ctx, void* host_ptr);
 int svo_hip_memcpy_h2d(svo_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);   /* async */
 int svo_hip_memcpy_d2h(svo_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);   /* synchronises */
 int svo_hip_copy_d2d(svo_hip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);        /* async */
@@ -86,6 +90,10 @@ int svo_hip_pyramid_upload(svo_hip_pyramid* pyr, int slot, const uint8_t* const*
  * frame.cpp:186-195).  The x86 SSE2 form of the reference rounds differently (vision.cpp:33-37). */
 int svo_hip_pyramid_upload_level0_and_build(svo_hip_pyramid* pyr, int slot, const uint8_t* level0);
 int svo_hip_pyramid_download_level(svo_hip_pyramid* pyr, int slot, int level, uint8_t* out_host);
+/* n_slots pyramids in the device layout (each pyr_bytes long, level l at svo_hip_pyramid_level_offset) in ONE
+ * transfer: from page-locked memory this runs at link rate, where per-level uploads are latency-bound */
+int svo_hip_pyramid_level_offset(const svo_hip_pyramid* pyr, int level, size_t* offset);
+int svo_hip_pyramid_upload_packed(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* packed);
 int svo_hip_pyramid_info(const svo_hip_pyramid* pyr, int* width, int* height, int* n_levels, int* batch,
                          size_t* pyr_bytes, void** base_dev);
 

@@ -884,3 +884,31 @@ def test_detected_seeds_feed_the_depth_filter(ctx):
     np.testing.assert_array_equal(status, o["status"])
     assert (status == 3).mean() > 0.5                      # most detected corners are matched and updated
     seeds.free(); ref.destroy(); cur.destroy()
+
+
+def test_packed_pyramid_upload_from_pinned_memory(ctx):
+    """svo_hip_pyramid_upload_packed: a batch of pyramids in the device layout, one transfer from page-locked memory."""
+    rng = np.random.default_rng(12)
+    B = 3
+    pyr = hip.Pyramid(ctx, 320, 240, 5, B)
+    lib = ctx.lib
+    pb, w_, h_, nl_, b_ = C.c_size_t(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    base = C.c_void_p()
+    ctx.check(lib.svo_hip_pyramid_info(pyr.h, C.byref(w_), C.byref(h_), C.byref(nl_), C.byref(b_), C.byref(pb), C.byref(base)), "info")
+    assert (w_.value, h_.value, nl_.value, b_.value) == (320, 240, 5, B)
+    host = C.c_void_p()
+    ctx.check(lib.svo_hip_malloc_host(ctx.h, C.byref(host), C.c_size_t(B * pb.value)), "malloc_host")
+    pyrs = [synth.build_pyramid(rng.integers(0, 256, (240, 320)).astype(np.uint8)) for _ in range(B)]
+    for s in range(B):
+        for l, im in enumerate(pyrs[s]):
+            o = C.c_size_t(0)
+            assert lib.svo_hip_pyramid_level_offset(pyr.h, l, C.byref(o)) == 0
+            C.memmove(host.value + s * pb.value + o.value, im.ctypes.data, im.nbytes)
+    ctx.check(lib.svo_hip_pyramid_upload_packed(pyr.h, 0, B, C.cast(host, C.POINTER(C.c_uint8))), "packed")
+    ctx.sync()
+    for s in range(B):
+        for l in range(5):
+            np.testing.assert_array_equal(pyr.download_level(s, l), pyrs[s][l])
+    assert lib.svo_hip_pyramid_upload_packed(pyr.h, 2, 2, C.cast(host, C.POINTER(C.c_uint8))) != 0      # out of range: refused
+    ctx.check(lib.svo_hip_free_host(ctx.h, host), "free_host")
+    pyr.destroy()

@@ -72,6 +72,71 @@ def main():
                 x.sum()
 
         out["read_sum"] = timed(rsum, n)
+    # host -> device upload of image pyramids through the C-ABI (pageable numpy buffers, as a caller would hand them over)
+    import numpy as np
+    from android_svo_amd import synth
+    B = 64
+    pyr = hip.Pyramid(ctx, 640, 480, 5, B)
+    levels = synth.build_pyramid(np.random.default_rng(0).integers(0, 256, (480, 640)).astype(np.uint8))
+    for s in range(4):
+        pyr.upload(s, levels)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for s in range(B):
+        pyr.upload(s, levels)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    out["pyramid_upload_h2d"] = {"GBps": B * 409200 / dt / 1e9, "pyramids_per_s": B / dt, "bytes_per_pyramid": 409200,
+                                 "note": "svo_hip_pyramid_upload from pageable host memory, one call per pyramid"}
+    # the same from page-locked memory (svo_hip_malloc_host), asynchronous, one sync at the end; and level 0 only
+    # with the pyramid built on the device
+    hp = C.c_void_p()
+    ctx.check(lib.svo_hip_malloc_host(ctx.h, C.byref(hp), C.c_size_t(409200)), "malloc_host")
+    off = 0
+    arr = (C.POINTER(C.c_uint8) * hip.MAX_LEVELS)()
+    for l, im in enumerate(levels):
+        C.memmove(hp.value + off, im.ctypes.data, im.nbytes)
+        arr[l] = C.cast(hp.value + off, C.POINTER(C.c_uint8))
+        off += im.nbytes
+    for s in range(4):
+        ctx.check(lib.svo_hip_pyramid_upload(pyr.h, s, arr), "upload")
+    ctx.sync()
+    t0 = time.perf_counter()
+    for s in range(B):
+        ctx.check(lib.svo_hip_pyramid_upload(pyr.h, s, arr), "upload")
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    out["pyramid_upload_h2d_pinned"] = {"GBps": B * 409200 / dt / 1e9, "pyramids_per_s": B / dt}
+    t0 = time.perf_counter()
+    for s in range(B):
+        ctx.check(lib.svo_hip_pyramid_upload_level0_and_build(pyr.h, s, arr[0]), "build")
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    out["level0_upload_and_device_pyramid_pinned"] = {"GBps": B * 307200 / dt / 1e9, "pyramids_per_s": B / dt}
+    # a whole batch of pyramids in the device layout, one transfer
+    pb, w_, h_, nl_, b_ = C.c_size_t(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    base = C.c_void_p()
+    ctx.check(lib.svo_hip_pyramid_info(pyr.h, C.byref(w_), C.byref(h_), C.byref(nl_), C.byref(b_), C.byref(pb), C.byref(base)), "info")
+    hpk = C.c_void_p()
+    ctx.check(lib.svo_hip_malloc_host(ctx.h, C.byref(hpk), C.c_size_t(B * pb.value)), "malloc_host")
+    for s in range(B):
+        for l, im in enumerate(levels):
+            o = C.c_size_t(0)
+            lib.svo_hip_pyramid_level_offset(pyr.h, l, C.byref(o))
+            C.memmove(hpk.value + s * pb.value + o.value, im.ctypes.data, im.nbytes)
+    for _ in range(2):
+        ctx.check(lib.svo_hip_pyramid_upload_packed(pyr.h, 0, B, C.cast(hpk, C.POINTER(C.c_uint8))), "packed")
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ctx.check(lib.svo_hip_pyramid_upload_packed(pyr.h, 0, B, C.cast(hpk, C.POINTER(C.c_uint8))), "packed")
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / 10
+    out["pyramid_upload_packed_pinned"] = {"GBps": B * pb.value / dt / 1e9, "pyramids_per_s": B / dt, "pyramids_per_transfer": B}
+    chk = pyr.download_level(B - 1, 2)
+    assert (chk == levels[2]).all()
+    ctx.check(lib.svo_hip_free_host(ctx.h, hpk), "free_host")
+    ctx.check(lib.svo_hip_free_host(ctx.h, hp), "free_host")
     out["vendor_peak"] = 8000.0
     print(json.dumps(out))
 
