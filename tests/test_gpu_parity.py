@@ -912,3 +912,32 @@ def test_packed_pyramid_upload_from_pinned_memory(ctx):
     assert lib.svo_hip_pyramid_upload_packed(pyr.h, 2, 2, C.cast(host, C.POINTER(C.c_uint8))) != 0      # out of range: refused
     ctx.check(lib.svo_hip_free_host(ctx.h, host), "free_host")
     pyr.destroy()
+
+
+def test_error_conventions(ctx):
+    """SURVEY 8b 'Error conventions': failure = status code + message, never an abort; a refused call leaves the
+    object usable."""
+    lib = ctx.lib
+    fp = synth.make_frame_pair(seed=12345, width=320, height=240, n_features=50, border=24)
+    ref, cur, sia = _upload_pair(ctx, [fp])
+    prm = sia.params(max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=True)
+    bad = sia.params(max_level=7, min_level=0, n_iter=30, eps=1e-6, early_stop=True)       # level beyond the pyramid
+    assert lib.svo_hip_sia_run(sia.h, 1, C.byref(bad)) == -1
+    assert b"invalid argument" in lib.svo_hip_last_error(ctx.h)
+    assert lib.svo_hip_sia_run(sia.h, 5, C.byref(prm)) != 0                               # more slots than the batch
+    assert lib.svo_hip_sia_run(None, 1, C.byref(prm)) == -1
+    assert lib.svo_hip_pyramid_upload(ref.h, 9, None) == -1
+    with pytest.raises(hip.SvoHipError):
+        ref.upload(3, fp.ref_pyr)                                                          # slot out of range
+    with pytest.raises(hip.SvoHipError):
+        hip.pose_optimize(ctx, fp.T_ref_w, fp.f, fp.pos, np.zeros(50, dtype=np.int32), fp.has_point, -1.0)   # error multiplier <= 0
+    px = np.zeros((4, 2)); out = C.c_int32(0)
+    assert lib.svo_hip_detect_features(ctx.h, ref.h, 0, None, 9, 20, None, C.c_double(10.0), C.byref(out),
+                                       px.ctypes.data_as(C.c_void_p), None, px.ctypes.data_as(C.c_void_p), None) == -1   # 9 levels
+    # the objects are still good
+    sia.run(1, prm)
+    r = sia.download(0)
+    o = orc.sparse_img_align(fp, n_iter=30, early_stop=True)
+    rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
+    assert rot < 1e-9 and trans < 1e-9
+    _free(sia, ref, cur)
