@@ -623,6 +623,67 @@ int grid_for(int n, int block) {
 
 }  // namespace
 
+// ---- ordered compaction of the converged seeds into packed records (the payload of the multi-GPU gather) ----
+// record = {seed id, mu, sigma2, x, y, z} as f64; order = ascending seed index (the order of the reference's callbacks)
+namespace {
+__global__ __launch_bounds__(256) void conv_count_kernel(int n, const int32_t* __restrict__ status, int* __restrict__ block_count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool c = i < n && status[i] == SVO_HIP_SEED_CONVERGED;
+  const unsigned long long m = __ballot(c);
+  __shared__ int s_w[4];
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// exclusive scan of the block counts in place, one workgroup; total -> *count
+__global__ __launch_bounds__(1024) void conv_scan_kernel(int n_blocks, int* __restrict__ block_count, int* __restrict__ count) {
+  __shared__ int s_part[1024];
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n_blocks; base += 1024) {
+    const int k = base + threadIdx.x;
+    const int v = k < n_blocks ? block_count[k] : 0;
+    s_part[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                     // Hillis-Steele inclusive scan
+      const int t = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+      __syncthreads();
+      s_part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const int incl = s_part[threadIdx.x];
+    const int carry = s_carry;
+    if (k < n_blocks) block_count[k] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = carry + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = s_carry;
+}
+
+__global__ __launch_bounds__(256) void conv_scatter_kernel(int n, long long id_offset, const int32_t* __restrict__ status,
+                                                           const float* __restrict__ mu, const float* __restrict__ sigma2,
+                                                           const double* __restrict__ xyz, const int* __restrict__ block_offset,
+                                                           double* __restrict__ records) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool c = i < n && status[i] == SVO_HIP_SEED_CONVERGED;
+  const unsigned long long m = __ballot(c);
+  __shared__ int s_w[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_w[wave] = __popcll(m);
+  __syncthreads();
+  if (!c) return;
+  int off = block_offset[blockIdx.x];
+  for (int w = 0; w < wave; ++w) off += s_w[w];
+  off += __popcll(m & ((1ull << lane) - 1ull));
+  double* r = records + 6 * (size_t)off;
+  r[0] = (double)(id_offset + i); r[1] = (double)mu[i]; r[2] = (double)sigma2[i];
+  r[3] = xyz[3 * (size_t)i]; r[4] = xyz[3 * (size_t)i + 1]; r[5] = xyz[3 * (size_t)i + 2];
+}
+}  // namespace
+
 extern "C" {
 
 int svo_hip_align2d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int slot, int level, int n,
@@ -867,6 +928,30 @@ int svo_hip_depth_filter_update(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, in
   down(n_align_iters, o_na, 4 * N);
   (void)svo_hip_free(ctx, blk);
   return rc;
+}
+
+int svo_hip_seed_compact_converged_dev(svo_hip_ctx* ctx, int n, long long id_offset, const int32_t* status_dev,
+                                       const float* mu_dev, const float* sigma2_dev, const double* xyz_world_dev,
+                                       double* records_dev, int32_t* count_dev) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n >= 0 && count_dev);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0) {
+    SVO_CHECK_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(int32_t), ctx->stream));
+    return SVO_HIP_OK;
+  }
+  SVO_REQUIRE(ctx, status_dev && mu_dev && sigma2_dev && xyz_world_dev && records_dev);
+  const int n_blocks = (n + 255) / 256;
+  void* ws = nullptr;
+  const int rc = svo_ctx_scratch(ctx, sizeof(int) * (size_t)n_blocks + 64, &ws);
+  if (rc != SVO_HIP_OK) return rc;
+  int* block_count = reinterpret_cast<int*>(ws);
+  hipLaunchKernelGGL(conv_count_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, n, status_dev, block_count);
+  hipLaunchKernelGGL(conv_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, n_blocks, block_count, reinterpret_cast<int*>(count_dev));
+  hipLaunchKernelGGL(conv_scatter_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, n, id_offset, status_dev, mu_dev, sigma2_dev,
+                     xyz_world_dev, block_count, records_dev);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
 }
 
 }  // extern "C"

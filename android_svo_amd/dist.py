@@ -98,3 +98,32 @@ def gather_converged(ids: np.ndarray, mu: np.ndarray, sigma2: np.ndarray, xyz: n
     dist.all_gather(parts, mine, group=group)
     out = [p[:c].cpu().numpy() for p, c in zip(parts, counts)]
     return np.concatenate(out, axis=0) if out else np.zeros((0, 6))
+
+
+def gather_converged_device(ctx, seeds, id_offset: int, stream, group=None):
+    """Device path of `gather_converged` for a hip.SeedBatch: the converged records are packed on the GPU
+    (svo_hip_seed_compact_converged_dev, seed order), the counts are all-gathered, then one padded all-gather of
+    device buffers (RCCL over xGMI).  Returns a [total, 6] float64 CUDA tensor ordered by rank, then by seed."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    with torch.cuda.stream(stream):
+        rec = torch.empty((max(seeds.n, 1), 6), dtype=torch.float64, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.check(ctx.lib.svo_hip_seed_compact_converged_dev(
+        ctx.h, seeds.n, C.c_longlong(id_offset), C.c_void_p(seeds.status.ptr), C.c_void_p(seeds.mu.ptr),
+        C.c_void_p(seeds.sigma2.ptr), C.c_void_p(seeds.xyz.ptr), C.c_void_p(rec.data_ptr()), C.c_void_p(cnt.data_ptr())),
+        "seed_compact_converged")
+    with torch.cuda.stream(stream):
+        if world == 1:
+            return rec[:int(cnt.item())]
+        counts = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(world)]
+        dist.all_gather(counts, cnt, group=group)
+        counts = [int(c.item()) for c in counts]
+        cap = max(max(counts), 1)
+        parts = [torch.empty((cap, 6), dtype=torch.float64, device="cuda") for _ in range(world)]
+        mine = rec[:cap] if rec.shape[0] >= cap else torch.cat([rec, rec.new_zeros((cap - rec.shape[0], 6))])
+        dist.all_gather(parts, mine.contiguous(), group=group)
+        return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)

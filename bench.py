@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
     ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--width", type=int, default=640, help="image width (1280 for BASELINE config C3)")
+    ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic scenes tiled over the batch")
     ap.add_argument("--mode", choices=["frames", "allreduce"], default="frames")
     ap.add_argument("--early-stop", action="store_true", help="reference GN exits instead of fixed work")
@@ -138,7 +140,7 @@ def main():
     n_feat = args.features
     allreduce = args.mode == "allreduce" and multi
     # ---- synthetic inputs (host), then resident in HBM before anything is timed
-    fps = [synth.make_frame_pair(seed=12345 + 17 * rank + i, n_features=n_feat) for i in range(args.distinct)]
+    fps = [synth.make_frame_pair(seed=12345 + 17 * rank + i, n_features=n_feat, width=args.width, height=args.height) for i in range(args.distinct)]
     cam = fps[0].cam
     stream = torch.cuda.Stream(device=local_rank)
     ctx = hip.Context(local_rank, stream=stream.cuda_stream)
@@ -149,7 +151,7 @@ def main():
     sia.set_frames(ref, cur)
     if allreduce:
         # every rank holds every frame of the global batch (same seeds on all ranks), evaluates its patch shard
-        fps = [synth.make_frame_pair(seed=12345 + i, n_features=n_feat) for i in range(args.distinct)]
+        fps = [synth.make_frame_pair(seed=12345 + i, n_features=n_feat, width=args.width, height=args.height) for i in range(args.distinct)]
         sia.set_shard(rank, world)
     for s in range(n_slots):
         fp = fps[s % len(fps)]
@@ -272,12 +274,12 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # reported at N=1 only (rank 0)
             cpu = cpu_baseline(fps, n_iter=30, early_stop=args.early_stop, frames_per_thread=args.cpu_frames_per_thread)
         out = {
-            "metric": "SparseImgAlign frames/s at 640x480 L4-L0; pose err vs CPU ref",
+            "metric": "SparseImgAlign frames/s at %dx%d L4-L0; pose err vs CPU ref" % (args.width, args.height),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 normal equations / f32 image math (as the reference)", "data": "synthetic",
-            "config": {"workload": "C1: SparseImgAlign 640x480, %d patches, 5 pyramid levels (L4-L0), %s" %
-                                   (n_feat, "reference early-stop GN" if args.early_stop else "30 GN evaluations per level (fixed work)"),
+            "config": {"workload": "%s: SparseImgAlign %dx%d, %d patches, 5 pyramid levels (L4-L0), %s" %
+                                   ("C1" if args.width == 640 else "C3 shape", args.width, args.height, n_feat, "reference early-stop GN" if args.early_stop else "30 GN evaluations per level (fixed work)"),
                        "frame_pairs_per_gpu_per_step": B, "global_frame_pairs_per_step": frames_global,
                        "parallelism": ("patch-sharded + per-GN-step all-reduce of H/b (C3 variant)" if allreduce
                                        else "frame-parallel (no collective)") + ", %d GPU(s)" % world,

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""bench_c4.py -- BASELINE config C4: seed-sharded DepthFilter, 1M seeds split across the GPUs of one node,
+1280x720 keyframe, RCCL gather of the converged depths.  (bench.py is the headline metric; the driver does not run
+this file.)
+
+  python bench_c4.py                       one GPU, all seeds
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench_c4.py
+                                           one rank per GPU: every rank holds the keyframe and the current frame
+                                           (two 1 227 600-byte pyramids) and a contiguous slice of the seeds; the
+                                           only exchange is the gather of converged records after the update
+                                           (counts, then one padded all-gather: SURVEY 8e).
+One step = one DepthFilter::updateSeeds pass over all seeds (inputs resident in HBM) + the gather.
+Prints one JSON line on rank 0."""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from android_svo_amd import dist as svodist, hip, seedsynth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=1000000)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--sigma-scale", type=float, default=0.0045,
+                    help="seed variance relative to a fresh seed: small enough that part of the seeds converge in this pass")
+    args = ap.parse_args()
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)                      # RCCL prints a banner on stdout
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    multi = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    torch.cuda.set_device(local_rank)
+    if multi:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # the same synthetic keyframe / frame / seed set on every rank (same generator seed); each rank keeps its slice
+    sc = seedsynth.make_seed_case(n_seeds=args.seeds, seed=9, width=args.width, height=args.height)
+    lo, hi = svodist.shard_range(args.seeds, rank, world)
+    stream = torch.cuda.Stream(device=local_rank)
+    ctx = hip.Context(local_rank, stream=stream.cuda_stream)
+    kf = hip.Pyramid(ctx, args.width, args.height, 5, 1)
+    cf = hip.Pyramid(ctx, args.width, args.height, 5, 1)
+    kf.upload(0, sc.ref_pyr)
+    cf.upload(0, sc.cur_pyr)
+    sl = slice(lo, hi)
+    # seeds that have already been observed a few times (small variance) so that a visible share converges this pass
+    sigma2 = (sc.sigma2[sl] * np.float32(args.sigma_scale)).astype(np.float32)
+    sb = hip.SeedBatch(ctx, sc.px[sl], sc.f[sl], sc.level[sl], sc.a[sl], sc.b[sl], sc.mu[sl], sc.z_range[sl], sigma2)
+    st0 = [ctx.to_device(np.ascontiguousarray(v)) for v in (sc.a[sl], sc.b[sl], sc.mu[sl], sigma2)]
+    n_conv_total = 0
+
+    def step():
+        nonlocal n_conv_total
+        for dst, src in zip((sb.a, sb.b, sb.mu, sb.sigma2), st0):        # same seed state every step
+            ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(dst.ptr), C.c_void_p(src.ptr), C.c_size_t(dst.nbytes)), "d2d")
+        hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb)
+        rec = svodist.gather_converged_device(ctx, sb, lo, stream)       # packed on the GPU, RCCL all-gather when N > 1
+        n_conv_total = int(rec.shape[0])
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        out = {"metric": "DepthFilter seed updates/s (BASELINE config C4)", "value": args.seeds * args.steps / dt, "unit": "seeds/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 geometry / f32 image math / int32 ZMSSD",
+               "data": "synthetic",
+               "config": {"workload": "C4: DepthFilter::updateSeeds, %d seeds on a %dx%d keyframe, seeds sharded over %d GPU(s), gather of converged records"
+                                      % (args.seeds, args.width, args.height, world),
+                          "seeds_per_gpu": hi - lo, "converged_records_gathered": int(n_conv_total),
+                          "note": "a step = the update pass + the on-device packing of the converged records + (N > 1) the RCCL all-gather"}}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -246,6 +246,13 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
                                     double* z_dev, double* xyz_world_dev, int32_t* n_zmssd_dev,
                                     int32_t* n_align_iters_dev);
 
+/* Converged seeds of a batch as packed records {seed id = id_offset + index, mu, sigma2, x, y, z} (f64[6]), in seed
+ * order, plus their number: the payload of the multi-GPU gather of SURVEY 8e (and of the seed_converged callbacks,
+ * depth_filter.cpp:313-329).  records_dev must hold n records. */
+int svo_hip_seed_compact_converged_dev(svo_hip_ctx* ctx, int n, long long id_offset, const int32_t* status_dev,
+                                       const float* mu_dev, const float* sigma2_dev, const double* xyz_world_dev,
+                                       double* records_dev, int32_t* count_dev);
+
 /* host-buffer convenience form of the above (copies in, runs, copies out, synchronises) */
 int svo_hip_depth_filter_update(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,
                                 const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,

@@ -941,3 +941,26 @@ def test_error_conventions(ctx):
     rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
     assert rot < 1e-9 and trans < 1e-9
     _free(sia, ref, cur)
+
+
+def test_converged_seed_records_packed_on_device(ctx):
+    """svo_hip_seed_compact_converged_dev: the gather payload, in seed order, equals what the host builds."""
+    import torch
+    from android_svo_amd import dist as svodist
+    sc = seedsynth.make_seed_case(n_seeds=20000, seed=9)
+    kf = hip.Pyramid(ctx, 640, 480, 5, 1); cf = hip.Pyramid(ctx, 640, 480, 5, 1)
+    kf.upload(0, sc.ref_pyr); cf.upload(0, sc.cur_pyr)
+    scale = np.where(np.arange(20000) % 3 == 0, 3e-4, 1.0).astype(np.float32)     # a third of the seeds is about to converge
+    sigma2 = (sc.sigma2 * scale).astype(np.float32)
+    sb = hip.SeedBatch(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, sigma2)
+    hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb)
+    ctx.sync()
+    rec = svodist.gather_converged_device(ctx, sb, 1000, torch.cuda.current_stream()).cpu().numpy()
+    status, mu, s2, xyz = sb.status.download(), sb.mu.download(), sb.sigma2.download(), sb.xyz.download()
+    conv = np.where(status == 4)[0]
+    assert 100 < len(conv) < len(status)
+    np.testing.assert_array_equal(rec[:, 0], conv + 1000)
+    np.testing.assert_array_equal(rec[:, 1], mu[conv].astype(np.float64))
+    np.testing.assert_array_equal(rec[:, 2], s2[conv].astype(np.float64))
+    np.testing.assert_array_equal(rec[:, 3:], xyz[conv])
+    sb.free(); kf.destroy(); cf.destroy()
