@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void align2d_kernel(const uint8_t* __restrict_
                                                       const uint8_t* __restrict__ pwb, int n_iter,
                                                       double* __restrict__ px, uint8_t* __restrict__ converged,
                                                       int32_t* __restrict__ iters) {
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform -> SGPRs
   if (w >= n) return;
   double u = px[2 * (size_t)w], v = px[2 * (size_t)w + 1];
   int it = 0;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void align1d_kernel(const uint8_t* __restrict_
                                                       const uint8_t* __restrict__ pwb, const float* __restrict__ dir,
                                                       int n_iter, double* __restrict__ px, uint8_t* __restrict__ converged,
                                                       double* __restrict__ h_inv, int32_t* __restrict__ iters) {
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform -> SGPRs
   if (w >= n) return;
   double u = px[2 * (size_t)w], v = px[2 * (size_t)w + 1], hi = 0.0;
   int it = 0;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void df_search_kernel(
     const int32_t* __restrict__ level, SeedRec* __restrict__ recs) {
   __shared__ __attribute__((aligned(16))) uint8_t s_pwb[4][112];
   __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][16];
-  const int wib = threadIdx.x >> 6;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: lets the per-seed record live in SGPRs
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wib;
   if (i >= n) return;                      // wave-uniform; no block-level barrier is used below

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void sia_precompute_kernel(
   int lo, hi;
   shard_range(c.n_feat, sh, &lo, &hi);
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPRs
   const int tile_base = lo + tile * TILE;
   if (tile_base >= hi) return;                       // wave-uniform
   const int q = lane >> 2, r = lane & 3;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void sia_residual_kernel(
   const int tpc = (n_tiles + chunks - 1) / chunks;
   const int t_end = min(n_tiles, (chunk + 1) * tpc);
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPRs
   const int q = lane >> 2, r = lane & 3;
   const int border = 3;
   const float scale = 1.0f / (1 << level);
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   const Cam cam = c.cam;
   const int n = c.n_feat;
   const int n_tiles = (n + TILE - 1) / TILE;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPRs
   const bool empty = n <= 0;
   const int tri_i = kTriI[lane < 21 ? lane : 0], tri_j = kTriJ[lane < 21 ? lane : 0];
 
