@@ -326,77 +326,109 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
   recs[i] = rc;
 }
 
-// One wave per seed; 4 seeds per 256-thread block.
+// Four seeds per wave, 16 per 256-thread block.  Three phases per wave:
+//   A  one seed at a time, all 64 lanes: warp::warpAffine of the 10x10 reference patch into LDS (lanes = pixels)
+//   B  the four seeds at once, 16 lanes each: ZMSSD search along the epipolar line (lane = candidate step; the
+//      usual segment has ~11 steps, so a whole wave per seed left 5/6 of the lanes idle)
+//   C  the four seeds at once, 16 lanes each: align2D / align1D (lane = 4 pixels of the 8x8 patch)
+constexpr int SEEDS_PER_WAVE = 4;
+constexpr int SEEDS_PER_BLOCK = 16;
+
 __global__ __launch_bounds__(256) void df_search_kernel(
     DfFrame fr, const uint8_t* __restrict__ ref_base, size_t ref_pyr_bytes, const uint8_t* __restrict__ cur_pyr, int n,
     const int32_t* __restrict__ level, SeedRec* __restrict__ recs) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_pwb[4][112];
-  __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][16];
-  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: lets the per-seed record live in SGPRs
+  __shared__ __attribute__((aligned(16))) uint8_t s_pwb[SEEDS_PER_BLOCK][112];
+  __shared__ __attribute__((aligned(16))) uint32_t s_patch[SEEDS_PER_BLOCK][16];
+  __shared__ double s_px[SEEDS_PER_BLOCK][2];
+  __shared__ int s_do[SEEDS_PER_BLOCK], s_nz[SEEDS_PER_BLOCK];
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform -> SGPRs
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + wib;
-  if (i >= n) return;                      // wave-uniform; no block-level barrier is used below
-  SeedRec* rp = recs + i;
-  const int path = rp->path;
-  if (path != 0 && path != 1 && path != 3) return;      // not live, or the search is skipped
-  const uint8_t* ref_pyr = ref_base + (size_t)rp->pad * ref_pyr_bytes;   // pad = reference keyframe slot
+  const int i0 = (blockIdx.x * 4 + wib) * SEEDS_PER_WAVE;
+  if (i0 >= n) return;                     // wave-uniform; no block-level barrier is used below
   const Cam cam = fr.cam;
-  uint8_t* pwb = s_pwb[wib];
-  uint32_t* patch_words = s_patch[wib];
-  const int level_ref = level[i];
-  const int search_level = rp->search_level;
-  int n_zmssd = 0, n_align = 0;
 
-  // ---- warp::warpAffine of the 10x10 reference patch (matcher.cpp:83-116), lanes 0..99
-  {
+  // ---------------- phase A: warp the reference patches ----------------
+  // the 4 x 100 samples of the wave's seeds form one flat index space: all loads of the phase are independent
+  bool any_search = false;
+  for (int sidx = 0; sidx < SEEDS_PER_WAVE; ++sidx) {
+    const int i = i0 + sidx;
+    if (i >= n) break;                                   // wave-uniform
+    const SeedRec* rp = recs + i;
+    const int path = rp->path;
+    const int slot = wib * SEEDS_PER_WAVE + sidx;
+    if (lane == 0) { s_do[slot] = (path == 0 || path == 3) ? 1 : 0; s_nz[slot] = 0; s_px[slot][0] = rp->uv0[0]; s_px[slot][1] = rp->uv0[1]; }
+    any_search |= path == 1;
+  }
+  for (int k4 = lane; k4 < 100 * SEEDS_PER_WAVE; k4 += 64) {
+    const int sidx = k4 / 100, k = k4 - sidx * 100;
+    const int i = i0 + sidx;
+    if (i >= n) continue;
+    const SeedRec* rp = recs + i;
+    const int path = rp->path;
+    if (path != 0 && path != 1 && path != 3) continue;  // not live, or the search is skipped
+    const uint8_t* ref_pyr = ref_base + (size_t)rp->pad * ref_pyr_bytes;   // pad = reference keyframe slot
+    const int level_ref = level[i];
+    const int search_level = rp->search_level;
+    // warp::warpAffine of the 10x10 reference patch (matcher.cpp:83-116)
     const int rcols = cam.width >> level_ref, rrows = cam.height >> level_ref;
     const uint8_t* img_ref = ref_pyr + fr.ref_level_off[level_ref];
-    const float a00 = rp->a00, a01 = rp->a01, a10 = rp->a10, a11 = rp->a11;
-    const bool warp_nan = rp->warp_nan != 0;   // the reference keeps the previous seed's patch; we use zeros
-    const float prx = rp->prx, pry = rp->pry;
-    for (int k = lane; k < 100; k += 64) {
-      const int yy = k / 10, xx = k - yy * 10;
-      float ppx = (float)(xx - 5), ppy = (float)(yy - 5);
-      ppx *= (1 << search_level);
-      ppy *= (1 << search_level);
-      const float qx = (a00 * ppx + a01 * ppy) + prx;
-      const float qy = (a10 * ppx + a11 * ppy) + pry;
-      uint8_t val = 0;
-      // the reference reads out of bounds when qx/qy are NaN (inf inverse of a singular A); such samples are 0
-      if (!warp_nan && qx >= 0 && qy >= 0 && qx < rcols - 1 && qy < rrows - 1)
-        val = (uint8_t)interpolate_8u(img_ref, rcols, qx, qy);
-      pwb[k] = val;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // createPatchFromPatchWithBorder (matcher.cpp:138-147): lane = pixel of the 8x8 patch
-    reinterpret_cast<uint8_t*>(patch_words)[lane] = pwb[((lane >> 3) + 1) * 10 + (lane & 7) + 1];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int yy = k / 10, xx = k - yy * 10;
+    float ppx = (float)(xx - 5), ppy = (float)(yy - 5);
+    ppx *= (1 << search_level);
+    ppy *= (1 << search_level);
+    const float qx = (rp->a00 * ppx + rp->a01 * ppy) + rp->prx;
+    const float qy = (rp->a10 * ppx + rp->a11 * ppy) + rp->pry;
+    uint8_t val = 0;
+    // the reference keeps the previous seed's patch when the inverse warp is NaN and reads out of bounds when
+    // qx/qy are NaN (inf inverse of a singular A); such samples are 0 here
+    if (!rp->warp_nan && qx >= 0 && qy >= 0 && qx < rcols - 1 && qy < rrows - 1)
+      val = (uint8_t)interpolate_8u(img_ref, rcols, qx, qy);
+    s_pwb[wib * SEEDS_PER_WAVE + sidx][k] = val;
   }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // createPatchFromPatchWithBorder (matcher.cpp:138-147): lane = pixel of the 8x8 patch
+#pragma unroll
+  for (int sidx = 0; sidx < SEEDS_PER_WAVE; ++sidx) {
+    const int slot = wib * SEEDS_PER_WAVE + sidx;
+    reinterpret_cast<uint8_t*>(s_patch[slot])[lane] = s_pwb[slot][((lane >> 3) + 1) * 10 + (lane & 7) + 1];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-  const int ccols = cam.width >> search_level, crows = cam.height >> search_level;
-  const uint8_t* cur_img = cur_pyr + fr.cur_level_off[search_level];
-  double px_cur[2] = {rp->uv0[0], rp->uv0[1]};     // path 0: midpoint of the projected segment
-  bool do_align = path == 0 || path == 3;
-
-  if (path == 1) {
+  // ---------------- phase B: epipolar ZMSSD search, 16 lanes per seed ----------------
+  if (any_search) {                                      // wave-uniform
+    const int g = lane >> 4, cl = lane & 15, gbase = lane & 48;
+    const int gi = i0 + g;
+    const int slot = wib * SEEDS_PER_WAVE + g;
+    const bool have = gi < n;
+    const SeedRec* rp = recs + (have ? gi : i0);
+    const bool live = have && rp->path == 1;
+    const int search_level = rp->search_level;
+    const int ccols = cam.width >> search_level;
+    const double inv_level = 1.0 / (1 << search_level);
+    const uint8_t* cur_img = cur_pyr + fr.cur_level_off[search_level];
+    const uint32_t* patch_words = s_patch[slot];
     const double step[2] = {rp->step[0], rp->step[1]};
     const double uv0[2] = {rp->uv0[0], rp->uv0[1]};
-    const int n_steps = rp->n_steps + 1;            // ++n_steps (matcher.cpp:297)
-    // reference patch statistics (ZMSSD ctor, patch_score.h:49-61)
+    const int n_steps = live ? rp->n_steps + 1 : 0;      // ++n_steps (matcher.cpp:297)
+    int n_max = n_steps;
+    n_max = max(n_max, __shfl_xor(n_max, 16, 64));
+    n_max = max(n_max, __shfl_xor(n_max, 32, 64));       // wave-uniform trip count
+    // reference patch statistics (ZMSSD ctor, patch_score.h:49-61): 4 pixels per lane
     int sumA, sumAA;
     {
-      const uint32_t a = reinterpret_cast<uint8_t*>(patch_words)[lane];
-      sumA = group_sum<64>((int)a);
-      sumAA = group_sum<64>((int)(a * a));
+      const uint32_t w = patch_words[cl];
+      sumA = group_sum<16>((int)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false));
+      sumAA = group_sum<16>((int)__builtin_amdgcn_udot4(w, w, 0u, false));
     }
     unsigned long long best_key = ~0ull;
-    int prev_tail_x = 0, prev_tail_y = 0;            // last_checked_pxi entering the chunk
-    double uv_tail[2] = {uv0[0], uv0[1]};            // exact uv of step index chunk0 (slow path only)
-    bool chain_exact = true;                         // uv_tail is current (no fast chunk has been taken yet)
-    for (int chunk0 = 0; chunk0 < n_steps; chunk0 += 64) {
-      const int idx = chunk0 + lane;
+    int prev_tail_x = 0, prev_tail_y = 0;                // last_checked_pxi entering the chunk
+    double uv_tail[2] = {uv0[0], uv0[1]};                // exact uv of step index chunk0 (slow path only)
+    bool chain_exact = true;                             // uv_tail is current (no fast chunk has been taken yet)
+    int n_zmssd = 0;
+    for (int chunk0 = 0; chunk0 < n_max; chunk0 += 16) {
+      const int idx = chunk0 + cl;
       const bool in_range = idx < n_steps;
       // The serial loop produces uv_i by repeated addition (matcher.cpp:299).  uv0 + i*step differs from it by
       // < 1e-13 relative, i.e. < 1e-10 px: if every candidate of the chunk is farther than 1e-7 px from a
@@ -404,23 +436,24 @@ __global__ __launch_bounds__(256) void df_search_kernel(
       double uv[2] = {uv0[0] + (double)idx * step[0], uv0[1] + (double)idx * step[1]};
       double pxs[2];
       world2cam_uv(cam, uv[0], uv[1], pxs);
-      double tx = pxs[0] / (1 << search_level) + 0.5, ty = pxs[1] / (1 << search_level) + 0.5;
+      double tx = pxs[0] * inv_level + 0.5, ty = pxs[1] * inv_level + 0.5;       // division by 2^L, exact
       const bool risky = in_range && !(fabs(tx - rint(tx)) > 1e-7 && fabs(ty - rint(ty)) > 1e-7);
-      if (__ballot(risky) != 0ull) {
+      const bool group_risky = ((__ballot(risky) >> gbase) & 0xffffull) != 0ull;      // uniform within the 16 lanes
+      if (group_risky) {
         // exact replay of the chain for this chunk: bring the tail to chunk0, then lane l adds `step` l times
         if (!chain_exact) {
           uv_tail[0] = uv0[0]; uv_tail[1] = uv0[1];
           for (int k = 0; k < chunk0; ++k) { uv_tail[0] += step[0]; uv_tail[1] += step[1]; }
         }
         uv[0] = uv_tail[0]; uv[1] = uv_tail[1];
-        for (int k = 0; k < 63; ++k) {
-          if (k < lane) { uv[0] += step[0]; uv[1] += step[1]; }
+        for (int k = 0; k < 15; ++k) {
+          if (k < cl) { uv[0] += step[0]; uv[1] += step[1]; }
         }
-        uv_tail[0] = __shfl(uv[0], 63, 64) + step[0];
-        uv_tail[1] = __shfl(uv[1], 63, 64) + step[1];
+        uv_tail[0] = __shfl(uv[0], gbase + 15, 64) + step[0];
+        uv_tail[1] = __shfl(uv[1], gbase + 15, 64) + step[1];
         chain_exact = true;
         world2cam_uv(cam, uv[0], uv[1], pxs);
-        tx = pxs[0] / (1 << search_level) + 0.5; ty = pxs[1] / (1 << search_level) + 0.5;
+        tx = pxs[0] * inv_level + 0.5; ty = pxs[1] * inv_level + 0.5;
       } else {
         chain_exact = false;
       }
@@ -428,7 +461,7 @@ __global__ __launch_bounds__(256) void df_search_kernel(
       // dedupe against the previous step (matcher.cpp:306-308): it never changes the arg-min, only the
       // count of evaluations, which we keep for the work counters
       int prev_x = __shfl_up(pxi_x, 1, 64), prev_y = __shfl_up(pxi_y, 1, 64);
-      if (lane == 0) { prev_x = prev_tail_x; prev_y = prev_tail_y; }
+      if (cl == 0) { prev_x = prev_tail_x; prev_y = prev_tail_y; }
       const bool dup = (pxi_x == prev_x && pxi_y == prev_y);
       const bool inframe = is_in_frame_level(cam, pxi_x, pxi_y, 8, search_level);
       int score = 0x7fffffff;
@@ -437,50 +470,78 @@ __global__ __launch_bounds__(256) void df_search_kernel(
         const uint8_t* cp = cur_img + (pxi_y - 4) * ccols + (pxi_x - 4);
         score = zmssd_8x8(cp, ccols, patch_words, sumA, sumAA);
       }
-      n_zmssd += __popcll(__ballot(eval));
+      n_zmssd += __popcll((__ballot(eval) >> gbase) & 0xffffull);
       if (eval && score < ZMSSD_THRESHOLD) {
         const unsigned long long key = ((unsigned long long)(unsigned)score << 32) | (unsigned long long)(unsigned)idx;
         if (key < best_key) best_key = key;
       }
-      prev_tail_x = __shfl(pxi_x, 63, 64); prev_tail_y = __shfl(pxi_y, 63, 64);
+      prev_tail_x = __shfl(pxi_x, gbase + 15, 64); prev_tail_y = __shfl(pxi_y, gbase + 15, 64);
     }
-    // wave arg-min on (score, index): the smallest score, earliest index on ties
+    // arg-min over the 16 lanes on (score, index): the smallest score, earliest index on ties
     unsigned long long k = best_key;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 8; o > 0; o >>= 1) {
       const unsigned long long other = __shfl_xor(k, o, 64);
       k = other < k ? other : k;
     }
-    if (k != ~0ull) {
-      // uv_best: replay the serial chain up to the winning index (wave-uniform loop)
-      const int best_idx = (int)(k & 0xffffffffull);
-      double bu = uv0[0], bv = uv0[1];
-      for (int t = 0; t < best_idx; ++t) { bu += step[0]; bv += step[1]; }
-      world2cam_uv(cam, bu, bv, px_cur);
-      do_align = true;
+    if (live) {
+      double px_best[2] = {uv0[0], uv0[1]};
+      const bool found = k != ~0ull;
+      if (found) {
+        // uv_best: replay the serial chain up to the winning index (uniform within the 16 lanes)
+        const int best_idx = (int)(k & 0xffffffffull);
+        double bu = uv0[0], bv = uv0[1];
+        for (int t = 0; t < best_idx; ++t) { bu += step[0]; bv += step[1]; }
+        world2cam_uv(cam, bu, bv, px_best);
+      }
+      if (cl == 0) { s_do[slot] = found ? 1 : 0; s_nz[slot] = n_zmssd; s_px[slot][0] = px_best[0]; s_px[slot][1] = px_best[1]; }
     }
   }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-  bool res = false;
-  if (do_align) {
-    double us = px_cur[0] / (1 << search_level), vs = px_cur[1] / (1 << search_level);
-    if (path == 3) {
-      // EDGELET reference feature: 1-D alignment along the warped gradient direction (matcher.cpp:183-191)
-      double h_inv;
-      res = align1d_wave(cur_img, ccols, crows, ccols, (float)rp->step[0], (float)rp->step[1], pwb, fr.align_max_iter,
-                         &us, &vs, &h_inv, &n_align);
-    } else {
-      res = align2d_wave(cur_img, ccols, crows, ccols, pwb, fr.align_max_iter, &us, &vs, &n_align);
+  // ---------------- phase C: sub-pixel alignment, 16 lanes per seed ----------------
+  {
+    const int g = lane >> 4, cl = lane & 15;
+    const int gi = i0 + g;
+    const int slot = wib * SEEDS_PER_WAVE + g;
+    const bool have = gi < n;
+    SeedRec* rp = recs + (have ? gi : i0);
+    const int path = have ? rp->path : -1;
+    const bool live = path == 0 || path == 1 || path == 3;
+    const int search_level = rp->search_level;
+    const int ccols = cam.width >> search_level, crows = cam.height >> search_level;
+    const uint8_t* cur_img = cur_pyr + fr.cur_level_off[search_level];
+    const uint8_t* pwb = s_pwb[slot];
+    double px_cur[2] = {s_px[slot][0], s_px[slot][1]};   // path 0/3: midpoint of the projected segment
+    const bool do_align = live && s_do[slot] != 0;
+    const double inv_scale = 1.0 / (1 << search_level);  // exact: a power of two
+    double us = px_cur[0] * inv_scale, vs = px_cur[1] * inv_scale;
+    int n_align = 0;
+    bool res = false;
+    const bool want1d = do_align && path == 3;
+    {
+      double u2 = us, v2 = vs;
+      int it2 = 0;
+      const bool r2 = align2d_group16(cur_img, ccols, crows, ccols, pwb, fr.align_max_iter, do_align && !want1d, &u2, &v2, &it2);
+      if (do_align && !want1d) { res = r2; us = u2; vs = v2; n_align = it2; }
     }
-    if (res || fr.keep_px_on_failure) {
+    if (__ballot(want1d) != 0ull) {                      // EDGELET reference features (matcher.cpp:183-191): rare
+      double u1 = us, v1 = vs, h_inv;
+      int it1 = 0;
+      const bool r1 = align1d_group16(cur_img, ccols, crows, ccols, (float)rp->step[0], (float)rp->step[1], pwb,
+                                      fr.align_max_iter, want1d, &u1, &v1, &h_inv, &it1);
+      if (want1d) { res = r1; us = u1; vs = v1; n_align = it1; }
+    }
+    if (do_align && (res || fr.keep_px_on_failure)) {
       px_cur[0] = us * (1 << search_level);
       px_cur[1] = vs * (1 << search_level);
     }
-  }
-  if (lane == 0) {
-    rp->matched = res ? 1 : 0;
-    rp->step[0] = px_cur[0]; rp->step[1] = px_cur[1];
-    rp->n_zmssd = n_zmssd; rp->n_align = n_align;
+    if (live && cl == 0) {
+      rp->matched = res ? 1 : 0;
+      rp->step[0] = px_cur[0]; rp->step[1] = px_cur[1];
+      rp->n_zmssd = s_nz[slot]; rp->n_align = n_align;
+    }
   }
 }
 
@@ -841,7 +902,7 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
   const uint8_t* cur_img = cur->base + (size_t)cur_slot * cur->pyr_bytes;
   hipLaunchKernelGGL(df_geometry_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, px, f, level, mu, sigma2, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(df_search_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, fr, ref_img, (size_t)0, cur_img, n, level, recs);
+  hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref_img, (size_t)0, cur_img, n, level, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(df_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, f, recs, a, b, mu, z_range,
                      sigma2, status, z, xyz_world, n_zmssd, n_align_iters);
@@ -885,7 +946,7 @@ int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref,
   hipLaunchKernelGGL(md_geometry_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, mf, n, T_ref_w_dev, kf_slot_dev,
                      px_ref_dev, f_ref_dev, level_ref_dev, pt_pos_dev, edgelet_dev, grad_dev, px_cur_dev, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(df_search_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, fr, ref->base, ref->pyr_bytes,
+  hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref->base, ref->pyr_bytes,
                      cur->base + (size_t)cur_slot * cur->pyr_bytes, n, level_ref_dev, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(md_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, recs, px_cur_dev, success_dev,
