@@ -964,3 +964,58 @@ def test_converged_seed_records_packed_on_device(ctx):
     np.testing.assert_array_equal(rec[:, 2], s2[conv].astype(np.float64))
     np.testing.assert_array_equal(rec[:, 3:], xyz[conv])
     sb.free(); kf.destroy(); cf.destroy()
+
+
+def test_frame_pipeline_stages_together(ctx):
+    """The per-frame data path of FrameHandlerMono::processFrame on the device, stage by stage against the oracle chain:
+    SparseImgAlign -> reprojection matching (findMatchDirect) -> pose_optimizer::optimizeGaussNewton -> Point::optimize."""
+    fp = synth.make_frame_pair(seed=4242, n_features=500, border=40)
+    cam = fp.cam
+    n = len(fp.px)
+    ref, cur, sia = _upload_pair(ctx, [fp])
+    prm = sia.params(max_level=4, min_level=2, n_iter=30, eps=1e-6, early_stop=True)       # shipping default L4 -> L2
+    sia.run(1, prm)
+    T_sia = np.array(sia.download(0).T_cur_w)
+    o = orc.sparse_img_align(fp, max_level=4, min_level=2, n_iter=30, early_stop=True)
+    rot, trans = synth.pose_error(T_sia, np.array(o.T_cur_w))
+    assert rot < 1e-9 and trans < 1e-9
+
+    def project(T):
+        Xc = np.stack([synth.se3_act(T, p) for p in fp.pos])
+        return np.stack([cam.fx * Xc[:, 0] / Xc[:, 2] + cam.cx, cam.fy * Xc[:, 1] / Xc[:, 2] + cam.cy], axis=1)
+
+    # reprojection matching from the aligned pose
+    px_pred = project(T_sia)
+    level = np.zeros(n, dtype=np.int32)
+    ok, px_m, sl = hip.match_direct_batch(ctx, ref, cur, 0, cam, fp.T_ref_w[None, :], T_sia, np.zeros(n, dtype=np.int32),
+                                          fp.px, fp.f, level, fp.pos, px_pred)
+    ok_o = np.zeros(n, dtype=bool); px_o = np.zeros((n, 2))
+    for i in range(n):
+        ok_o[i], px_o[i], _ = orc.find_match_direct(cam, fp.ref_pyr, fp.cur_pyr, fp.T_ref_w, T_sia, fp.px[i], fp.f[i], 0,
+                                                    fp.pos[i], px_pred[i])
+    assert (ok != ok_o).mean() < 0.01 and ok.mean() > 0.9
+    both = ok & ok_o
+    assert np.abs(px_m[both] - px_o[both]).max() < 5e-3
+
+    # motion-only refinement on the matched observations
+    f_obs = synth.cam2world(cam, px_m)
+    hp = ok.astype(np.uint8)
+    r, hp_out = hip.pose_optimize(ctx, T_sia, f_obs, fp.pos, sl.astype(np.int32), hp, abs(cam.fx))
+    ro, hp_o = orc.pose_optimize(abs(cam.fx), T_sia, f_obs, fp.pos, sl.astype(np.int32), hp)
+    rot, trans = synth.pose_error(np.array(r.T_f_w), np.array(ro.T_f_w))
+    assert rot < 1e-10 and trans < 1e-10 and (hp_out != hp_o).sum() <= 1
+    e_sia = synth.pose_error(T_sia, fp.T_cur_w_true)
+    e_ref = synth.pose_error(np.array(r.T_f_w), fp.T_cur_w_true)
+    assert e_ref[0] < 2e-4 and e_ref[1] < 1e-3, (e_sia, e_ref)       # the refined pose stays at the sub-pixel level
+
+    # structure refinement of the points seen in both frames
+    sel = np.where(hp_out.astype(bool))[0][:200]
+    obs_T = np.stack([np.stack([fp.T_ref_w, np.array(r.T_f_w)]) for _ in sel]).reshape(-1, 7)
+    obs_f = np.stack([np.stack([fp.f[i], f_obs[i]]) for i in sel]).reshape(-1, 3)
+    off = np.arange(len(sel) + 1, dtype=np.int32) * 2
+    pos0 = fp.pos[sel] + np.random.default_rng(1).normal(size=(len(sel), 3)) * 0.01
+    out, _ = hip.point_optimize_batch(ctx, pos0, off, obs_T, obs_f, n_iter=5)
+    for k in range(len(sel)):
+        want, _ = orc.point_optimize(pos0[k], obs_T[2 * k:2 * k + 2], obs_f[2 * k:2 * k + 2], n_iter=5)
+        np.testing.assert_array_equal(out[k], want)
+    _free(sia, ref, cur)
