@@ -20,6 +20,8 @@
 // epipolar abscissa uv_i is produced by the same repeated addition uv += step as
 // S/matcher.cpp:299 (each lane replays its prefix).
 #include "svo_align_device.h"
+#include <vector>
+
 #include "svo_internal.h"
 
 using namespace svo_dev;
@@ -1012,6 +1014,83 @@ int svo_hip_seed_compact_converged_dev(svo_hip_ctx* ctx, int n, long long id_off
   hipLaunchKernelGGL(conv_scatter_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, n, id_offset, status_dev, mu_dev, sigma2_dev,
                      xyz_world_dev, block_count, records_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+// The cell loop of Reprojector::reprojectMap (reprojector.cpp:149-166, 180-241) over candidates bucketed per cell in
+// trial order: every live candidate is matched in ONE batch on the device, then the serial policy (first success per
+// cell wins, later candidates untouched, stop once n_matches exceeds max_fts) is replayed on the host over the
+// results.  findMatchDirect is a pure function of its candidate, so this equals the sequential evaluation.
+int svo_hip_reproject_cells(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, int cur_slot,
+                            const svo_hip_camera* cam, int n_kf, const double* T_kf_w, const double T_cur_w[7], int n_cells,
+                            const int32_t* cell_offset, const int32_t* kf_slot, const double* px_ref, const double* f_ref,
+                            const int32_t* level_ref, const double* pt_pos, const uint8_t* edgelet, const double* grad,
+                            const uint8_t* deleted, double* px_cur, int max_fts, int n_pyr_levels, int align_max_iter,
+                            uint8_t* tried, uint8_t* matched, int32_t* search_level, int32_t* cell_winner,
+                            uint64_t* n_matches_out, uint64_t* n_trials_out) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n_cells >= 0 && cell_offset && tried && matched && cell_winner && n_matches_out && n_trials_out);
+  const int n = cell_offset[n_cells];
+  SVO_REQUIRE(ctx, n >= 0 && (n == 0 || (kf_slot && px_ref && f_ref && level_ref && pt_pos && deleted && px_cur && T_kf_w)));
+  SVO_REQUIRE(ctx, !edgelet || grad);
+  for (int c = 0; c < n_cells; ++c) cell_winner[c] = -1;
+  *n_matches_out = 0; *n_trials_out = 0;
+  if (n == 0) return SVO_HIP_OK;
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t N = (size_t)n;
+  // one device block: px_ref(16) f(24) pos(24) px_cur(16) grad(16) T_kf(56*n_kf) kf_slot(4) level(4) sl(4) edgelet(1) ok(1)
+  const size_t o_pr = 0, o_f = o_pr + 16 * N, o_pos = o_f + 24 * N, o_pc = o_pos + 24 * N, o_g = o_pc + 16 * N,
+               o_T = o_g + 16 * N, o_k = o_T + 56 * (size_t)n_kf, o_l = o_k + 4 * N, o_sl = o_l + 4 * N, o_e = o_sl + 4 * N,
+               o_ok = o_e + N, total = o_ok + N + 64;
+  char* d = nullptr;
+  SVO_CHECK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), total));
+  hipError_t e = hipSuccess;
+  auto up = [&](size_t off, const void* src, size_t bytes) { if (e == hipSuccess && src) e = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, ctx->stream); };
+  up(o_pr, px_ref, 16 * N); up(o_f, f_ref, 24 * N); up(o_pos, pt_pos, 24 * N); up(o_pc, px_cur, 16 * N);
+  up(o_g, grad, 16 * N); up(o_T, T_kf_w, 56 * (size_t)n_kf); up(o_k, kf_slot, 4 * N); up(o_l, level_ref, 4 * N);
+  up(o_e, edgelet, N);
+  int rc = SVO_HIP_OK;
+  std::vector<uint8_t> ok(N);
+  std::vector<int32_t> sl(N);
+  if (e == hipSuccess) {
+    rc = svo_hip_match_direct_batch_dev(ctx, ref, cur, cur_slot, cam, n_kf, reinterpret_cast<const double*>(d + o_T), T_cur_w, n,
+                                        reinterpret_cast<const int32_t*>(d + o_k), reinterpret_cast<const double*>(d + o_pr),
+                                        reinterpret_cast<const double*>(d + o_f), reinterpret_cast<const int32_t*>(d + o_l),
+                                        reinterpret_cast<const double*>(d + o_pos),
+                                        edgelet ? reinterpret_cast<const uint8_t*>(d + o_e) : nullptr,
+                                        edgelet ? reinterpret_cast<const double*>(d + o_g) : nullptr, n_pyr_levels, align_max_iter,
+                                        reinterpret_cast<double*>(d + o_pc), reinterpret_cast<uint8_t*>(d + o_ok),
+                                        reinterpret_cast<int32_t*>(d + o_sl));
+    if (rc == SVO_HIP_OK) {
+      e = hipMemcpyAsync(px_cur, d + o_pc, 16 * N, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(ok.data(), d + o_ok, N, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(sl.data(), d + o_sl, 4 * N, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+  }
+  (void)hipFree(d);
+  if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_reproject_cells", hipGetErrorString(e));
+  if (rc != SVO_HIP_OK) return rc;
+  // ---- the serial policy (reprojector.cpp:149-166 with reprojectCell :180-241)
+  memset(tried, 0, N);
+  memset(matched, 0, N);
+  uint64_t n_matches = 0, n_trials = 0;
+  for (int c = 0; c < n_cells; ++c) {
+    for (int i = cell_offset[c]; i < cell_offset[c + 1]; ++i) {
+      ++n_trials;
+      tried[i] = 1;
+      if (deleted[i]) continue;                              // TYPE_DELETED: erased from the cell (:190-194)
+      if (search_level) search_level[i] = sl[i];
+      if (!ok[i]) continue;                                  // the caller counts the failure on the point (:202-209)
+      matched[i] = 1;
+      cell_winner[c] = i;
+      ++n_matches;
+      break;                                                 // maximum one point per cell (:238-239)
+    }
+    if (n_matches > (uint64_t)max_fts) break;                // :164-165
+  }
+  *n_matches_out = n_matches;
+  *n_trials_out = n_trials;
   return SVO_HIP_OK;
 }
 

@@ -516,3 +516,31 @@ def seed_init_batch(ctx: Context, n: int, depth_mean: float, depth_min: float):
     for v in d:
         v.free()
     return out
+
+
+# ---- next row f-2: the cell loop of Reprojector::reprojectMap --------------------------------------------------------
+def reproject_cells(ctx: Context, ref: Pyramid, cur: Pyramid, cur_slot: int, cam, T_kf_w, T_cur_w, cell_offset, kf_slot,
+                    px_ref, f_ref, level_ref, pt_pos, deleted, px_cur, edgelet=None, grad=None, max_fts: int = 1200,
+                    n_pyr_levels: int = 3, align_max_iter: int = 10):
+    """svo_hip_reproject_cells: candidates bucketed per cell in trial order; returns dict(tried, matched, search_level,
+    cell_winner, px_cur, n_matches, n_trials)."""
+    c = make_camera(cam)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    co, ks, lr = i32(cell_offset), i32(kf_slot), i32(level_ref)
+    n_cells, n = len(co) - 1, int(co[-1])
+    Tk, Tc, pr, fr, pp = _f64(T_kf_w), _f64(T_cur_w), _f64(px_ref), _f64(f_ref), _f64(pt_pos)
+    pc = _f64(px_cur).copy()
+    de = np.ascontiguousarray(deleted, dtype=np.uint8)
+    ed = None if edgelet is None else np.ascontiguousarray(edgelet, dtype=np.uint8)
+    gr = None if grad is None else _f64(grad)
+    tried, matched = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+    sl, win = np.zeros(max(n, 1), np.int32), np.zeros(max(n_cells, 1), np.int32)
+    nm, nt = C.c_uint64(0), C.c_uint64(0)
+    ctx.check(ctx.lib.svo_hip_reproject_cells(
+        ctx.h, ref.h, cur.h, cur_slot, C.byref(c), len(Tk), _ptr(Tk, C.c_double), _ptr(Tc, C.c_double), n_cells,
+        _ptr(co, C.c_int32), _ptr(ks, C.c_int32), _ptr(pr, C.c_double), _ptr(fr, C.c_double), _ptr(lr, C.c_int32),
+        _ptr(pp, C.c_double), None if ed is None else _ptr(ed, C.c_uint8), None if gr is None else _ptr(gr, C.c_double),
+        _ptr(de, C.c_uint8), _ptr(pc, C.c_double), max_fts, n_pyr_levels, align_max_iter, _ptr(tried, C.c_uint8),
+        _ptr(matched, C.c_uint8), _ptr(sl, C.c_int32), _ptr(win, C.c_int32), C.byref(nm), C.byref(nt)), "reproject_cells")
+    return {"tried": tried[:n], "matched": matched[:n], "search_level": sl[:n], "cell_winner": win[:n_cells], "px_cur": pc,
+            "n_matches": nm.value, "n_trials": nt.value}

@@ -286,3 +286,58 @@ def make_point_opt_cases(seed: int = 5, n_points: int = 300):
         iters.append(5 if t % 2 else 20)
     return (np.array(pos0), np.array(off, dtype=np.int32), np.array(Ts), np.array(fs), np.array(pos_true),
             np.array(iters, dtype=np.int32))
+
+
+# ---- input for the reprojection cell loop (Reprojector::reprojectMap's second half) ----
+TYPE_DELETED, TYPE_CANDIDATE, TYPE_UNKNOWN, TYPE_GOOD = 0, 1, 2, 3
+
+
+def make_reproject_case(seed: int = 21, width: int = 320, height: int = 240, n_points: int = 900, n_kf: int = 3, cell_size: int = 20):
+    """Map points seen from n_kf keyframes, projected into a new frame and bucketed into grid cells in the order the
+    reference meets them (keyframe by keyframe).  Returns a dict of arrays; `order` is the trial order inside the cells
+    after the reference's stable sort by point type (GOOD > UNKNOWN > CANDIDATE > DELETED)."""
+    rng = np.random.default_rng(seed)
+    cam = Camera(width, height, 250.0 * width / 320, 250.0 * width / 320, width / 2 - 0.5, height / 2 - 0.5)
+    scene = PlaneScene(seed=seed, depth=2.0, tilt=(0.1, -0.07))
+    kf_poses = [se3_from_twist(rng.uniform(-0.1, 0.1, 3) + [0, 0, 0.2 * k], rng.uniform(-0.03, 0.03, 3)) for k in range(n_kf)]
+    T_cur_w = se3_from_twist(rng.uniform(-0.05, 0.05, 3) + [0, 0, 0.5], rng.uniform(-0.02, 0.02, 3))
+    kf_pyr = [build_pyramid(scene.render(cam, T)) for T in kf_poses]
+    cur_pyr = build_pyramid(scene.render(cam, T_cur_w))
+    slot = np.sort(rng.integers(0, n_kf, n_points)).astype(np.int32)          # keyframe by keyframe
+    level = rng.choice([0, 0, 1, 2], n_points).astype(np.int32)
+    px_ref = np.stack([rng.uniform(10, width - 10, n_points), rng.uniform(10, height - 10, n_points)], axis=1)
+    f_ref = cam2world(cam, px_ref)
+    pos = np.zeros((n_points, 3))
+    for k in range(n_kf):
+        m = slot == k
+        pos[m] = scene.intersect(cam, kf_poses[k], px_ref[m, 0], px_ref[m, 1])
+    R = rot_matrix(T_cur_w[3:])
+    Xc = pos @ R.T + T_cur_w[:3]
+    px_cur = np.stack([cam.fx * Xc[:, 0] / Xc[:, 2] + cam.cx, cam.fy * Xc[:, 1] / Xc[:, 2] + cam.cy], axis=1)
+    px_cur += rng.uniform(-1.5, 1.5, (n_points, 2))
+    bad = rng.uniform(size=n_points) < 0.3                                     # poor predictions: these candidates tend to fail
+    px_cur[bad] += rng.uniform(5, 9, (int(bad.sum()), 2)) * rng.choice([-1, 1], (int(bad.sum()), 2))
+    pxi = px_cur.astype(np.int64)                                              # Vector2d::cast<int>()
+    inside = (pxi[:, 0] >= 8) & (pxi[:, 0] < width - 8) & (pxi[:, 1] >= 8) & (pxi[:, 1] < height - 8)   # isInFrame(px, 8)
+    gc = -(-width // cell_size)
+    gr = -(-height // cell_size)
+    cell = (px_cur[:, 1] / cell_size).astype(np.int64) * gc + (px_cur[:, 0] / cell_size).astype(np.int64)
+    ptype = rng.choice([TYPE_DELETED, TYPE_CANDIDATE, TYPE_UNKNOWN, TYPE_UNKNOWN, TYPE_GOOD], n_points).astype(np.int32)
+    n_failed = np.where(ptype == TYPE_UNKNOWN, rng.integers(13, 17, n_points), rng.integers(28, 32, n_points)).astype(np.int32)
+    n_succ = rng.integers(8, 12, n_points).astype(np.int32)
+    idx = np.where(inside)[0]
+    # raw cell contents in insertion order, then the reference's stable sort by type (descending)
+    raw = [idx[cell[idx] == c] for c in range(gc * gr)]
+    trial = [r[np.argsort(-ptype[r], kind="stable")] for r in raw]
+    return dict(cam=cam, kf_pyr=kf_pyr, cur_pyr=cur_pyr, T_kf_w=np.stack(kf_poses), T_cur_w=T_cur_w, n_cells=gc * gr,
+                raw=raw, trial=trial, slot=slot, level=level, px_ref=px_ref, f_ref=np.ascontiguousarray(f_ref), pos=pos,
+                px_cur=px_cur, ptype=ptype, n_failed=n_failed, n_succeeded=n_succ)
+
+
+def flatten_cells(case, cells):
+    """CSR view of per-cell candidate index lists: (cell_offset, candidate ids)."""
+    off = np.zeros(case["n_cells"] + 1, dtype=np.int32)
+    for c, r in enumerate(cells):
+        off[c + 1] = off[c] + len(r)
+    ids = np.concatenate([r for r in cells]) if off[-1] else np.zeros(0, dtype=np.int64)
+    return off, ids.astype(np.int64)

@@ -102,6 +102,19 @@ class PyramidCache {
     slot_frame_[s] = frame.id_;
     return s;
   }
+  /// make slot `want` hold `frame`'s pyramid (uploading it unless it is already there); returns `want` or -1
+  int slotOfAt(const Frame& frame, int want) {
+    if (want < 0 || want >= capacity_) return -1;
+    if (pyr_ && slot_frame_[want] == frame.id_) return want;
+    if (pyr_)
+      for (int s = 0; s < capacity_; ++s)
+        if (slot_frame_[s] == frame.id_) slot_frame_[s] = -1;      // it will live in `want` from now on
+    const int saved = next_;
+    next_ = want;
+    const int got = slotOf(frame);
+    next_ = saved;
+    return got == want ? want : -1;
+  }
   svo_hip_pyramid* pyramid() const { return pyr_; }
 
  private:

@@ -207,6 +207,22 @@ int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref,
                                    int n_pyr_levels, int align_max_iter, double* px_cur_dev, uint8_t* success_dev,
                                    int32_t* search_level_dev);
 
+/* The cell loop of Reprojector::reprojectMap (I/reprojector.h:57-59, reprojector.cpp:149-166 with reprojectCell
+ * :180-241) on host buffers: candidates bucketed per grid cell in trial order (cell.sort(pointQualityComparator)
+ * applied by the caller); candidates of cell c = [cell_offset[c], cell_offset[c+1]).  All candidates are matched in
+ * one batch, then the reference's serial policy is replayed (first success per cell wins, candidates behind the
+ * winner untouched, stop once n_matches exceeds max_fts = Config::maxFts()).  deleted[i] <=> the point's type is
+ * TYPE_DELETED.  Outputs: tried[i] / matched[i] (what the caller needs for the point bookkeeping of :202-215),
+ * px_cur[i] and search_level[i] of the visited candidates, cell_winner[c] (candidate index or -1), n_matches_,
+ * n_trials_. */
+int svo_hip_reproject_cells(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, int cur_slot,
+                            const svo_hip_camera* cam, int n_kf, const double* T_kf_w, const double T_cur_w[7], int n_cells,
+                            const int32_t* cell_offset, const int32_t* kf_slot, const double* px_ref, const double* f_ref,
+                            const int32_t* level_ref, const double* pt_pos, const uint8_t* edgelet, const double* grad,
+                            const uint8_t* deleted, double* px_cur, int max_fts, int n_pyr_levels, int align_max_iter,
+                            uint8_t* tried, uint8_t* matched, int32_t* search_level, int32_t* cell_winner,
+                            uint64_t* n_matches, uint64_t* n_trials);
+
 /* ---- DepthFilter (I/depth_filter.h:36-166, depth_filter.cpp:237-416; matcher.cpp:207-355) -- */
 /* static DepthFilter::updateSeed over n seeds (depth_filter.cpp:368-391): SoA device arrays */
 int svo_hip_update_seed_batch_dev(svo_hip_ctx* ctx, int n, const float* x_dev, const float* tau2_dev,

@@ -369,17 +369,47 @@ def gen_shitomasi_ref():
     print("shitomasi_ref written")
 
 
+def run_reproject_reference(cs, max_fts):
+    off_raw, ids_raw = synth.flatten_cells(cs, cs["raw"])
+    n = len(ids_raw)
+    g = lambda a: a[ids_raw]
+    return refpy.reproject_cells(cs["cam"], cs["kf_pyr"], cs["T_kf_w"], cs["cur_pyr"], cs["T_cur_w"], off_raw, g(cs["slot"]),
+                                 g(cs["px_ref"]), g(cs["f_ref"]), g(cs["level"]), g(cs["pos"]), np.zeros(n, np.uint8),
+                                 np.tile([1.0, 0.0], (n, 1)), g(cs["ptype"]), g(cs["n_failed"]), g(cs["n_succeeded"]),
+                                 g(cs["px_cur"]), max_fts=max_fts), ids_raw
+
+
+def gen_reproject_ref():
+    """The cell loop of Reprojector::reprojectMap executed by the reference's own compiled Reprojector::reprojectCell
+    (with Matcher::findMatchDirect, the point bookkeeping and Frame::addFeature) on two settings of Config::maxFts()."""
+    cs = synth.make_reproject_case()
+    out = dict(crc=np.array([crc(cs["cur_pyr"][0]), crc(cs["px_cur"]), crc(cs["pos"])], dtype=np.uint64))
+    for tag, max_fts in (("full", 1200), ("cap", 40)):
+        r, ids_raw = run_reproject_reference(cs, max_fts)
+        out[tag + "_n"] = np.array([r["n_matches"], r["n_trials"]], dtype=np.int64)
+        out[tag + "_feat_point"] = ids_raw[r["feat_cand"]]                 # map point of every new feature, creation order
+        out[tag + "_feat_px"] = r["feat_px"]
+        out[tag + "_feat_level"] = r["feat_level"]
+        pt_nf, pt_ns, pt_ty, left = (np.full(len(cs["ptype"]), -1, np.int32) for _ in range(4))
+        pt_nf[ids_raw], pt_ns[ids_raw], pt_ty[ids_raw], left[ids_raw] = r["n_failed"], r["n_succeeded"], r["type"], r["left_in_cell"]
+        out[tag + "_n_failed"], out[tag + "_n_succeeded"], out[tag + "_type"], out[tag + "_left"] = pt_nf, pt_ns, pt_ty, left
+        print("reproject_ref", tag, r["n_matches"], r["n_trials"])
+    np.savez_compressed(os.path.join(OUT, "reproject_ref.npz"), **out)
+
+
 def main():
     assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(OUT, exist_ok=True)
-    if not any(a in sys.argv for a in ("--objects-only", "--refine-only", "--shitomasi-only")):
+    if not any(a in sys.argv for a in ("--objects-only", "--refine-only", "--shitomasi-only", "--reproject-only")):
         rng = np.random.default_rng(20240607)
         gen_se3(rng); gen_algebra(rng); gen_gn(rng); gen_align(rng); gen_matcher(rng); gen_vision(rng)
-    if "--refine-only" not in sys.argv and "--shitomasi-only" not in sys.argv:
+    if not any(a in sys.argv for a in ("--refine-only", "--shitomasi-only", "--reproject-only")):
         gen_sia_ref(); gen_epi_ref(); gen_match_direct_ref()
-    if "--shitomasi-only" not in sys.argv:
+    if "--shitomasi-only" not in sys.argv and "--reproject-only" not in sys.argv:
         gen_refine_ref()
-    gen_shitomasi_ref()
+    if "--reproject-only" not in sys.argv:
+        gen_shitomasi_ref()
+    gen_reproject_ref()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

@@ -314,3 +314,32 @@ def detect_features(pyr, n_pyr_levels=3, cell_size=20, occupancy=None, detection
                                       None if occ is None else _p(occ, C.c_uint8), C.c_double(detection_threshold),
                                       _p(px, C.c_int), _p(lvl, C.c_int), _p(sc, C.c_float))
     return px[:n].copy(), lvl[:n].copy(), sc[:n].copy()
+
+
+# ---- next row f-2: the cell loop of Reprojector::reprojectMap ----
+def reproject_cells(cam, kf_pyrs, T_kf_w, cur_pyr, T_cur_w, cell_offset, kf_slot, px_ref, f_ref, level_ref, pt_pos, edgelet,
+                    grad, deleted, px_cur, max_fts=1200, n_pyr_levels=3, align_max_iter=10):
+    c = camera(cam)
+    n_kf, n_cells, n = len(kf_pyrs), len(cell_offset) - 1, int(cell_offset[-1])
+    kp = (C.POINTER(C.POINTER(C.c_uint8)) * n_kf)()
+    keep = []
+    for k in range(n_kf):
+        pp = pyr_ptrs(kf_pyrs[k])
+        keep.append(pp)
+        kp[k] = C.cast(pp, C.POINTER(C.POINTER(C.c_uint8)))
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    co, ks, lr = i32(cell_offset), i32(kf_slot), i32(level_ref)
+    Tk, Tc, pr, fr, pp3, gr = f64(T_kf_w), f64(T_cur_w), f64(px_ref), f64(f_ref), f64(pt_pos), f64(grad)
+    pc = f64(px_cur).copy()
+    ed, de = np.ascontiguousarray(edgelet, dtype=np.uint8), np.ascontiguousarray(deleted, dtype=np.uint8)
+    tried, matched = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+    sl, win = np.zeros(max(n, 1), np.int32), np.zeros(max(n_cells, 1), np.int32)
+    nm, nt = C.c_size_t(0), C.c_size_t(0)
+    I, DD = C.c_int, C.c_double
+    lib().svo_orc_reproject_cells(C.byref(c), C.c_int(n_kf), kp, _p(Tk, DD), pyr_ptrs(cur_pyr), _p(Tc, DD), C.c_int(n_cells),
+                                  _p(co, I), _p(ks, I), _p(pr, DD), _p(fr, DD), _p(lr, I), _p(pp3, DD), _p(ed, C.c_uint8),
+                                  _p(gr, DD), _p(de, C.c_uint8), _p(pc, DD), C.c_int(max_fts), C.c_int(n_pyr_levels),
+                                  C.c_int(align_max_iter), _p(tried, C.c_uint8), _p(matched, C.c_uint8), _p(sl, I), _p(win, I),
+                                  C.byref(nm), C.byref(nt))
+    return {"tried": tried[:n], "matched": matched[:n], "search_level": sl[:n], "cell_winner": win[:n_cells], "px_cur": pc,
+            "n_matches": nm.value, "n_trials": nt.value}

@@ -40,6 +40,12 @@
 #include <svo/sparse_img_align.h>
 #undef protected
 
+// Reprojector keeps its grid and reprojectCell private
+#include <svo/map.h>
+#define private public
+#include <svo/reprojector.h>
+#undef private
+
 #include "ref_common.h"
 
 using namespace refh;
@@ -277,6 +283,83 @@ void ref_ldlt3_solve(const double* A, const double* b, double* x) {
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m(i, j) = A[3 * i + j];
   Eigen::Vector3d r = m.ldlt().solve(v);
   x[0] = r[0]; x[1] = r[1]; x[2] = r[2];
+}
+
+// The cell loop of Reprojector::reprojectMap (reprojector.cpp:149-166) on a real Reprojector with a real (empty) Map:
+// the candidates are put into grid_.cells in the given order, then reprojectCell (the reference's compiled member,
+// with its cell.sort, Matcher::findMatchDirect, point bookkeeping and frame->addFeature) is called cell by cell exactly
+// as reprojectMap does.  One map point per candidate, observed once from keyframe kf_slot[i].
+// Outputs per candidate: n_failed / n_succeeded / type of its point afterwards and whether it is still in its cell;
+// per new feature of the frame (in creation order): candidate index, px, level, type, grad.
+int ref_reproject_cells(int width, int height, double fx, double fy, double cx, double cy, int n_levels, int n_kf,
+                        const uint8_t* const* const* kf_pyr, const double* T_kf_w, const uint8_t* const* cur_pyr,
+                        const double* T_cur_w, int n_cells, const int* cell_offset, const int* kf_slot, const double* px_ref,
+                        const double* f_ref, const int* level_ref, const double* pt_pos, const uint8_t* edgelet,
+                        const double* grad, const int* point_type, const int* n_failed_in, const int* n_succeeded_in,
+                        const double* px_cur_in, int max_fts, int* n_failed_out, int* n_succeeded_out, int* type_out,
+                        uint8_t* left_in_cell, int* feat_cand, double* feat_px, int* feat_level, int* feat_type,
+                        double* feat_grad, size_t* n_matches, size_t* n_trials) {
+  HarnessPinhole cam(width, height, fx, fy, cx, cy);
+  std::vector<HandFrame*> kfs;
+  for (int k = 0; k < n_kf; ++k) kfs.push_back(new HandFrame(&cam, kf_pyr[k], width, height, n_levels, T_kf_w + 7 * k));
+  HandFrame cur(&cam, cur_pyr, width, height, n_levels, T_cur_w);
+  svo::FramePtr frame = cur.ptr();
+  const int n = cell_offset[n_cells];
+  std::vector<svo::Point*> pts((size_t)n);
+  svo::Map* map = new svo::Map();
+  svo::Reprojector* rp = new svo::Reprojector(&cam, *map);
+  if ((int)rp->grid_.cells.size() < n_cells) return -1;
+  for (int c = 0; c < n_cells; ++c)
+    for (int i = cell_offset[c]; i < cell_offset[c + 1]; ++i) {
+      svo::Feature* ftr = kfs[kf_slot[i]]->add_feature(px_ref + 2 * i, f_ref + 3 * i, level_ref[i], pt_pos + 3 * i);
+      kfs[kf_slot[i]]->points.pop_back();                   // ownership below: deleted points go to the map's trash
+      if (edgelet && edgelet[i]) { ftr->type = svo::Feature::EDGELET; ftr->grad = Eigen::Vector2d(grad[2 * i], grad[2 * i + 1]); }
+      svo::Point* pt = ftr->point;
+      pt->type_ = (svo::Point::PointType)point_type[i];
+      pt->n_failed_reproj_ = n_failed_in[i];
+      pt->n_succeeded_reproj_ = n_succeeded_in[i];
+      pts[i] = pt;
+      Eigen::Vector2d px(px_cur_in[2 * i], px_cur_in[2 * i + 1]);
+      rp->grid_.cells.at(c)->push_back(svo::Reprojector::Candidate(pt, px));
+    }
+  // reprojectMap :149-166 (resetGrid() zeroes the counters at :63-64)
+  rp->n_matches_ = 0;
+  rp->n_trials_ = 0;
+  const size_t cap = (size_t)max_fts;
+  for (size_t i = 0; i < rp->grid_.cells.size() && (int)i < n_cells; ++i) {
+    if (rp->reprojectCell(*rp->grid_.cells.at(rp->grid_.cell_order[i]), frame)) ++rp->n_matches_;
+    if (rp->n_matches_ > cap) break;
+  }
+  *n_matches = rp->n_matches_;
+  *n_trials = rp->n_trials_;
+  for (int c = 0; c < n_cells; ++c) {
+    for (int i = cell_offset[c]; i < cell_offset[c + 1]; ++i) left_in_cell[i] = 0;
+    for (auto& cand : *rp->grid_.cells.at(c))
+      for (int i = cell_offset[c]; i < cell_offset[c + 1]; ++i)
+        if (pts[i] == cand.pt) left_in_cell[i] = 1;
+  }
+  for (int i = 0; i < n; ++i) {
+    n_failed_out[i] = pts[i]->n_failed_reproj_;
+    n_succeeded_out[i] = pts[i]->n_succeeded_reproj_;
+    type_out[i] = (int)pts[i]->type_;
+  }
+  int nf = 0;
+  for (svo::Feature* ftr : cur.f->fts_) {
+    int idx = -1;
+    for (int i = 0; i < n; ++i) if (pts[i] == ftr->point) idx = i;
+    feat_cand[nf] = idx;
+    feat_px[2 * nf] = ftr->px[0]; feat_px[2 * nf + 1] = ftr->px[1];
+    feat_level[nf] = ftr->level;
+    feat_type[nf] = (int)ftr->type;
+    feat_grad[2 * nf] = ftr->grad[0]; feat_grad[2 * nf + 1] = ftr->grad[1];
+    ++nf;
+  }
+  // tear down: points that were not deleted are ours, deleted ones sit in the map's trash (freed by ~Map)
+  for (int i = 0; i < n; ++i) if (pts[i]->type_ != svo::Point::TYPE_DELETED) delete pts[i];
+  delete rp;
+  delete map;
+  for (HandFrame* k : kfs) delete k;
+  return nf;
 }
 
 }  // extern "C"

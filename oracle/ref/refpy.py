@@ -260,3 +260,32 @@ def shi_tomasi_score(img, u, v):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     lib().ref_shi_tomasi_score.restype = C.c_float
     return float(lib().ref_shi_tomasi_score(_p(img, C.c_uint8), img.shape[1], img.shape[0], C.c_int(u), C.c_int(v)))
+
+
+# ---- next row f-2: the cell loop of Reprojector::reprojectMap on a real Reprojector (ref_objects.cpp) ----
+def reproject_cells(cam, kf_pyrs, T_kf_w, cur_pyr, T_cur_w, cell_offset, kf_slot, px_ref, f_ref, level_ref, pt_pos, edgelet,
+                    grad, point_type, n_failed, n_succeeded, px_cur, max_fts=1200):
+    n_kf, n_cells, n = len(kf_pyrs), len(cell_offset) - 1, int(cell_offset[-1])
+    kp = (C.POINTER(C.POINTER(C.c_uint8)) * n_kf)()
+    keep = []
+    for k in range(n_kf):
+        pp = orc.pyr_ptrs(kf_pyrs[k])
+        keep.append(pp)
+        kp[k] = C.cast(pp, C.POINTER(C.POINTER(C.c_uint8)))
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    co, ks, lr, pt, nf, ns = i32(cell_offset), i32(kf_slot), i32(level_ref), i32(point_type), i32(n_failed), i32(n_succeeded)
+    Tk, Tc, pr, fr, pp3, gr, pc = f64(T_kf_w), f64(T_cur_w), f64(px_ref), f64(f_ref), f64(pt_pos), f64(grad), f64(px_cur)
+    ed = np.ascontiguousarray(edgelet, dtype=np.uint8)
+    nf_o, ns_o, ty_o = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    left = np.zeros(n, np.uint8)
+    fc, fpx, fl, ft, fg = np.zeros(n_cells, np.int32), np.zeros((n_cells, 2)), np.zeros(n_cells, np.int32), np.zeros(n_cells, np.int32), np.zeros((n_cells, 2))
+    nm, nt = C.c_size_t(0), C.c_size_t(0)
+    I = C.c_int
+    k = lib().ref_reproject_cells(*_cam_args(cam), C.c_int(len(cur_pyr)), C.c_int(n_kf), kp, _p(Tk, D), orc.pyr_ptrs(cur_pyr), _p(Tc, D),
+                                  C.c_int(n_cells), _p(co, I), _p(ks, I), _p(pr, D), _p(fr, D), _p(lr, I), _p(pp3, D),
+                                  _p(ed, C.c_uint8), _p(gr, D), _p(pt, I), _p(nf, I), _p(ns, I), _p(pc, D), C.c_int(max_fts),
+                                  _p(nf_o, I), _p(ns_o, I), _p(ty_o, I), _p(left, C.c_uint8), _p(fc, I), _p(fpx, D), _p(fl, I),
+                                  _p(ft, I), _p(fg, D), C.byref(nm), C.byref(nt))
+    assert k >= 0
+    return {"n_failed": nf_o, "n_succeeded": ns_o, "type": ty_o, "left_in_cell": left, "feat_cand": fc[:k], "feat_px": fpx[:k],
+            "feat_level": fl[:k], "feat_type": ft[:k], "feat_grad": fg[:k], "n_matches": nm.value, "n_trials": nt.value}

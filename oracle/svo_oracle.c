@@ -1576,3 +1576,53 @@ int svo_orc_detect_features(const uint8_t* const* pyr, int width, int height, in
   free(cx); free(cy); free(cl); free(cs);
   return n_out;
 }
+
+
+/* ------------------------------------------------------------------------ */
+/* next row f-2: the cell loop of Reprojector::reprojectMap                   */
+/* ------------------------------------------------------------------------ */
+
+/* Reprojector::reprojectMap, the loop over the grid cells (S/reprojector.cpp:149-166) with
+ * Reprojector::reprojectCell (:180-241), on candidates that are already bucketed per cell and sorted by point
+ * quality (cell.sort(pointQualityComparator), :183).  Serial semantics: the candidates of a cell are tried in
+ * order until one matches (at most one feature per cell); candidates behind the winner are not touched; the loop
+ * stops once n_matches exceeds max_fts.  deleted[i] <=> it->pt->type_ == TYPE_DELETED (counted as a trial, :190-194).
+ * Point bookkeeping (n_failed_reproj_, n_succeeded_reproj_, type changes, :202-215) is the caller's: tried[] and
+ * matched[] tell it which candidates were visited and with what result. */
+int svo_orc_reproject_cells(const svo_orc_camera* cam, int n_kf, const uint8_t* const* const* kf_pyr, const double* T_kf_w,
+                            const uint8_t* const* cur_pyr, const double T_cur_w[7], int n_cells, const int* cell_offset,
+                            const int* kf_slot, const double* px_ref, const double* f_ref, const int* level_ref,
+                            const double* pt_pos, const uint8_t* edgelet, const double* grad, const uint8_t* deleted,
+                            double* px_cur, int max_fts, int n_pyr_levels, int align_max_iter, uint8_t* tried,
+                            uint8_t* matched, int* search_level, int* cell_winner, size_t* n_matches_out,
+                            size_t* n_trials_out) {
+  (void)n_kf;
+  size_t n_matches = 0, n_trials = 0;
+  const int n_cand = cell_offset[n_cells];
+  memset(tried, 0, (size_t)n_cand);
+  memset(matched, 0, (size_t)n_cand);
+  for (int c = 0; c < n_cells; ++c) cell_winner[c] = -1;
+  for (int c = 0; c < n_cells; ++c) {
+    for (int i = cell_offset[c]; i < cell_offset[c + 1]; ++i) {
+      ++n_trials;
+      tried[i] = 1;
+      if (deleted[i]) continue;
+      const double g[2] = {grad ? grad[2 * i] : 1.0, grad ? grad[2 * i + 1] : 0.0};
+      int sl = 0;
+      const int k = kf_slot[i];
+      const int ok = svo_orc_find_match_direct(cam, kf_pyr[k], cur_pyr, T_kf_w + 7 * k, T_cur_w, px_ref + 2 * i, f_ref + 3 * i,
+                                               level_ref[i], pt_pos + 3 * i, edgelet ? edgelet[i] : 0, g, n_pyr_levels,
+                                               align_max_iter, px_cur + 2 * i, &sl);
+      if (search_level) search_level[i] = sl;
+      if (!ok) continue;
+      matched[i] = 1;
+      cell_winner[c] = i;
+      ++n_matches;
+      break;                                  /* maximum one point per cell (:238-239) */
+    }
+    if (n_matches > (size_t)max_fts) break;    /* :164-165 */
+  }
+  *n_matches_out = n_matches;
+  *n_trials_out = n_trials;
+  return 0;
+}

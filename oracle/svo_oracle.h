@@ -249,6 +249,15 @@ int svo_orc_detect_features(const uint8_t* const* pyr, int width, int height, in
                             const uint8_t* occupancy /*[cells] or NULL*/, double detection_threshold, int* px_out,
                             int* level_out, float* score_out);
 
+/* ---- next row f-2: the cell loop of Reprojector::reprojectMap (reprojector.cpp:149-166, 180-241) ----
+ * candidates of cell c: [cell_offset[c], cell_offset[c+1]) in trial order; see svo_oracle.c */
+int svo_orc_reproject_cells(const svo_orc_camera* cam, int n_kf, const uint8_t* const* const* kf_pyr, const double* T_kf_w,
+                            const uint8_t* const* cur_pyr, const double T_cur_w[7], int n_cells, const int* cell_offset,
+                            const int* kf_slot, const double* px_ref, const double* f_ref, const int* level_ref,
+                            const double* pt_pos, const uint8_t* edgelet, const double* grad, const uint8_t* deleted,
+                            double* px_cur /*in/out*/, int max_fts, int n_pyr_levels, int align_max_iter, uint8_t* tried,
+                            uint8_t* matched, int* search_level, int* cell_winner, size_t* n_matches, size_t* n_trials);
+
 #ifdef __cplusplus
 }
 #endif
