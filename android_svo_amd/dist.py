@@ -127,3 +127,40 @@ def gather_converged_device(ctx, seeds, id_offset: int, stream, group=None):
         mine = rec[:cap] if rec.shape[0] >= cap else torch.cat([rec, rec.new_zeros((cap - rec.shape[0], 6))])
         dist.all_gather(parts, mine.contiguous(), group=group)
         return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+
+class GraphedAllreduceSolver:
+    """The patch-sharded solve (`run_allreduce`) with the launch-bound inner loop captured in HIP graphs: one graph per
+    pyramid level holding level_begin + n_iter x (accumulate, all-reduce of the normal equations, solve_update).
+    The kernels skip frames that have finished, so replaying the full iteration budget keeps the reference's early-exit
+    semantics.  Capture happens once per solver configuration; a solve is begin() + one replay per level + finish()."""
+
+    def __init__(self, aligner, max_level: int, min_level: int, n_iter: int, stream, group=None):
+        import torch
+        import torch.distributed as dist
+        self.aligner, self.stream = aligner, stream
+        self.graphs = []
+        # one eager solve first: creates the communicator and every lazily allocated buffer outside of capture
+        with torch.cuda.stream(stream):
+            run_allreduce(aligner, max_level, min_level, n_iter, group)
+        torch.cuda.synchronize()
+        aligner.begin()
+        for level in range(max_level, min_level - 1, -1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                aligner.level_begin(level)
+                for _ in range(n_iter):
+                    aligner.accumulate()
+                    dist.all_reduce(aligner.reduce_tensor, op=dist.ReduceOp.SUM, group=group)
+                    aligner.solve_update()
+            self.graphs.append(g)
+        aligner.finish()
+        torch.cuda.synchronize()
+
+    def run(self):
+        import torch
+        with torch.cuda.stream(self.stream):
+            self.aligner.begin()
+            for g in self.graphs:
+                g.replay()
+            self.aligner.finish()

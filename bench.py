@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic scenes tiled over the batch")
     ap.add_argument("--mode", choices=["frames", "allreduce"], default="frames")
     ap.add_argument("--early-stop", action="store_true", help="reference GN exits instead of fixed work")
+    ap.add_argument("--graph", action="store_true", help="--mode allreduce: replay the per-level loops from HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames-per-thread", type=int, default=16)
     ap.add_argument("--latency-probe", action="store_true",
@@ -163,10 +164,14 @@ def main():
     if allreduce:
         from android_svo_amd import dist as svodist
         aligner = svodist.HipShardedAligner(sia, n_slots, prm, rank, world, stream)
+        graphed = svodist.GraphedAllreduceSolver(aligner, prm.max_level, prm.min_level, prm.n_iter, stream) if args.graph else None
 
     def step():
         if not allreduce:
             sia.run(n_slots, prm)
+            return
+        if graphed is not None:
+            graphed.run()
             return
         with torch.cuda.stream(stream):      # kernels and the RCCL all-reduce share this stream
             svodist.run_allreduce(aligner, prm.max_level, prm.min_level, prm.n_iter)
@@ -281,7 +286,7 @@ def main():
             "config": {"workload": "%s: SparseImgAlign %dx%d, %d patches, 5 pyramid levels (L4-L0), %s" %
                                    ("C1" if args.width == 640 else "C3 shape", args.width, args.height, n_feat, "reference early-stop GN" if args.early_stop else "30 GN evaluations per level (fixed work)"),
                        "frame_pairs_per_gpu_per_step": B, "global_frame_pairs_per_step": frames_global,
-                       "parallelism": ("patch-sharded + per-GN-step all-reduce of H/b (C3 variant)" if allreduce
+                       "parallelism": ("patch-sharded + per-GN-step all-reduce of H/b (C3 variant)" + (", HIP-graph replay" if args.graph else "") if allreduce
                                        else "frame-parallel (no collective)") + ", %d GPU(s)" % world,
                        "distinct_scenes": args.distinct,
                        "implementation": "fused (one workgroup per frame pair, one launch per solve)" if (not allreduce and sia.last_run_mode() == 1) else "streaming (one launch per Gauss-Newton evaluation)"},
