@@ -4,7 +4,13 @@
 // precomputeReferencePatches (:105-178), computeResiduals (:184-286), solve/update
 // (:291-308) driven by NLLSSolver::optimizeGaussNewton (I/nlls_solver_impl.hpp:25-100).
 //
-// Design (MI355X-first, not the reference's loop structure):
+// Two implementations of svo_hip_sia_run with the same semantics:
+//   (F) the fused kernel (second half of this file, the default): one workgroup per frame pair runs the whole
+//       coarse-to-fine solve in one launch with the reference footprints in LDS;
+//   (S) the streaming kernels described next: one launch per Gauss-Newton evaluation; used by the step-wise entry
+//       points (multi-GPU all-reduce of the normal equations) and for frames with more than 2816 features.
+//
+// Design of (S) (MI355X-first, not the reference's loop structure):
 //   * B independent frame pairs are solved at once; the whole coarse-to-fine loop is a
 //     fixed sequence of kernels on one stream with the Gauss-Newton control state
 //     (model, rollback copy, chi2, stop, iteration) resident in HBM -- no host round trip;
@@ -24,10 +30,10 @@
 //       sum_px J J^T = sxx AA^T + sxy (AB^T+BA^T) + syy BB^T,   sum_px J r = A sum(dx r) + B sum(dy r).
 //     We keep 3 f32 per pixel (ref, dx, dy), {x,y,z,1/z} and {sxx,sxy,syy} per patch instead of the
 //     reference's 768 B/patch fp64 Jacobian cache.  The 21 distinct entries of each tile's
-//     sum_patches H_patch are stored once per level; an evaluation whose tile has every
-//     linearised patch inside the current image adds that row (lane e adds entry e), any
-//     other tile recomputes its H from the patches that are visible now -- H is therefore
-//     rebuilt from the visible set at every evaluation, as computeResiduals does.
+//     sum_patches H_patch are stored once per level; every evaluation adds that row (lane e adds
+//     entry e) and takes out, one at a time, the linearised patches that are outside the current
+//     image at this evaluation -- H is therefore the sum over the patches visible now, as
+//     computeResiduals builds it.
 //   * fp64 for H/Jres and their partial sums; residual/chi2 in f32 per pixel row, widened per
 //     patch.  Reductions are in fixed order (bitwise reproducible run to run, no atomics).
 #include <cstdlib>
