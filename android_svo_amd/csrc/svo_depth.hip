@@ -972,8 +972,8 @@ int svo_hip_depth_filter_update(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, in
   const size_t o_px = 0, o_f = o_px + 16 * N, o_z = o_f + 24 * N, o_xyz = o_z + 8 * N, o_lvl = o_xyz + 24 * N,
                o_a = o_lvl + 4 * N, o_b = o_a + 4 * N, o_mu = o_b + 4 * N, o_zr = o_mu + 4 * N, o_s2 = o_zr + 4 * N,
                o_st = o_s2 + 4 * N, o_nz = o_st + 4 * N, o_na = o_nz + 4 * N, total = o_na + 4 * N;
-  void* blk = nullptr;
-  int rc = svo_hip_malloc(ctx, &blk, total);
+  char* blk = nullptr;
+  int rc = svo_ctx_staging(ctx, total, &blk);
   if (rc != SVO_HIP_OK) return rc;
   uint8_t* d = (uint8_t*)blk;
   auto up = [&](size_t off, const void* src, size_t bytes) { if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d + off, src, bytes); };
@@ -989,7 +989,6 @@ int svo_hip_depth_filter_update(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, in
   down(a, o_a, 4 * N); down(b, o_b, 4 * N); down(mu, o_mu, 4 * N); down(sigma2, o_s2, 4 * N);
   down(status, o_st, 4 * N); down(z, o_z, 8 * N); down(xyz_world, o_xyz, 24 * N); down(n_zmssd, o_nz, 4 * N);
   down(n_align_iters, o_na, 4 * N);
-  (void)svo_hip_free(ctx, blk);
   return rc;
 }
 
@@ -1043,7 +1042,10 @@ int svo_hip_reproject_cells(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const 
                o_T = o_g + 16 * N, o_k = o_T + 56 * (size_t)n_kf, o_l = o_k + 4 * N, o_sl = o_l + 4 * N, o_e = o_sl + 4 * N,
                o_ok = o_e + N, total = o_ok + N + 64;
   char* d = nullptr;
-  SVO_CHECK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), total));
+  {
+    const int rc_st = svo_ctx_staging(ctx, total, &d);
+    if (rc_st != SVO_HIP_OK) return rc_st;
+  }
   hipError_t e = hipSuccess;
   auto up = [&](size_t off, const void* src, size_t bytes) { if (e == hipSuccess && src) e = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, ctx->stream); };
   up(o_pr, px_ref, 16 * N); up(o_f, f_ref, 24 * N); up(o_pos, pt_pos, 24 * N); up(o_pc, px_cur, 16 * N);
@@ -1068,7 +1070,6 @@ int svo_hip_reproject_cells(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const 
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
   }
-  (void)hipFree(d);
   if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_reproject_cells", hipGetErrorString(e));
   if (rc != SVO_HIP_OK) return rc;
   // ---- the serial policy (reprojector.cpp:149-166 with reprojectCell :180-241)

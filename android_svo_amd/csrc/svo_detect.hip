@@ -236,7 +236,10 @@ int svo_hip_detect_features(svo_hip_ctx* ctx, const svo_hip_pyramid* pyr, int sl
   const size_t nc = (size_t)gc * gr;
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   char* d = nullptr;
-  SVO_CHECK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), nc * (5 * sizeof(double) + sizeof(int32_t) + sizeof(float) + 1) + 64));
+  {
+    const int rc_st = svo_ctx_staging(ctx, nc * (5 * sizeof(double) + sizeof(int32_t) + sizeof(float) + 1) + 64, &d);
+    if (rc_st != SVO_HIP_OK) return rc_st;
+  }
   double* dpx = reinterpret_cast<double*>(d);
   double* df = dpx + 2 * nc;
   int32_t* dl = reinterpret_cast<int32_t*>(df + 3 * nc);
@@ -259,7 +262,6 @@ int svo_hip_detect_features(svo_hip_ctx* ctx, const svo_hip_pyramid* pyr, int sl
       if (e == hipSuccess && n && score) e = hipMemcpy(score, ds, n * sizeof(float), hipMemcpyDeviceToHost);
     }
   }
-  (void)hipFree(d);
   if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_detect_features", hipGetErrorString(e));
   return rc;
 }

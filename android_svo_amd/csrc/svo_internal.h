@@ -15,6 +15,8 @@ struct svo_hip_ctx {
   bool own_stream = false;
   void* scratch = nullptr;          // grow-only device workspace (depth-filter stage records)
   size_t scratch_bytes = 0;
+  void* staging = nullptr;          // grow-only device staging area of the host-buffer convenience entry points
+  size_t staging_bytes = 0;
   char err[512] = {0};
 };
 
@@ -58,6 +60,25 @@ inline int svo_ctx_scratch(svo_hip_ctx* ctx, size_t need, void** out) {
     ctx->scratch_bytes = need + need / 4;
   }
   *out = ctx->scratch;
+  return SVO_HIP_OK;
+}
+
+// grow-only device staging area of the host-buffer entry points (they copy in, run, copy out and synchronise, so
+// the area is free again when they return; a context is used by one host thread at a time)
+inline int svo_ctx_staging(svo_hip_ctx* ctx, size_t need, char** out) {
+  if (ctx->staging_bytes < need) {
+    if (ctx->staging) {
+      SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->staging);
+      ctx->staging = nullptr;
+      ctx->staging_bytes = 0;
+    }
+    void* p = nullptr;
+    SVO_CHECK_HIP(ctx, hipMalloc(&p, need + need / 4));
+    ctx->staging = p;
+    ctx->staging_bytes = need + need / 4;
+  }
+  *out = static_cast<char*>(ctx->staging);
   return SVO_HIP_OK;
 }
 

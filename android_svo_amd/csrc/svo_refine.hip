@@ -431,7 +431,10 @@ int svo_hip_pose_optimize(svo_hip_ctx* ctx, int n, const double T_f_w[7], const 
   const size_t bytes = sizeof(int32_t) + 7 * sizeof(double) + (size_t)max_n * (6 * sizeof(double) + sizeof(int32_t) + 1) +
                        sizeof(svo_hip_pose_opt_result) + 64;
   char* d = nullptr;
-  SVO_CHECK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), bytes));
+  {
+    const int rc_st = svo_ctx_staging(ctx, bytes, &d);
+    if (rc_st != SVO_HIP_OK) return rc_st;
+  }
   double* dT = reinterpret_cast<double*>(d);
   double* df = dT + 7;
   double* dp = df + 3 * (size_t)max_n;
@@ -455,7 +458,6 @@ int svo_hip_pose_optimize(svo_hip_ctx* ctx, int n, const double T_f_w[7], const 
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
   }
-  (void)hipFree(d);
   if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_pose_optimize", hipGetErrorString(e));
   return rc;
 }
@@ -485,8 +487,11 @@ int svo_hip_point_optimize_batch(svo_hip_ctx* ctx, int n_points, int n_iter, dou
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   const size_t mm = m > 0 ? (size_t)m : 1;
   char* d = nullptr;
-  SVO_CHECK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(double) * (3 * (size_t)n_points + 10 * mm) +
-                                                             sizeof(int32_t) * (2 * (size_t)n_points + 1) + 64));
+  {
+    const int rc_st = svo_ctx_staging(ctx, sizeof(double) * (3 * (size_t)n_points + 10 * mm) +
+                                                             sizeof(int32_t) * (2 * (size_t)n_points + 1) + 64, &d);
+    if (rc_st != SVO_HIP_OK) return rc_st;
+  }
   double* dp = reinterpret_cast<double*>(d);
   double* dT = dp + 3 * (size_t)n_points;
   double* df = dT + 7 * mm;
@@ -505,7 +510,6 @@ int svo_hip_point_optimize_batch(svo_hip_ctx* ctx, int n_points, int n_iter, dou
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
   }
-  (void)hipFree(d);
   if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_point_optimize_batch", hipGetErrorString(e));
   return rc;
 }
@@ -515,8 +519,12 @@ int svo_hip_ldlt6_solve_batch(svo_hip_ctx* ctx, int n, const double* H, const do
   SVO_REQUIRE(ctx, n >= 0 && (n == 0 || (H && b && x)));
   if (n == 0) return SVO_HIP_OK;
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  double* d = nullptr;
-  SVO_CHECK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(double) * 48 * (size_t)n));
+  char* dc = nullptr;
+  {
+    const int rc_st = svo_ctx_staging(ctx, sizeof(double) * 48 * (size_t)n, &dc);
+    if (rc_st != SVO_HIP_OK) return rc_st;
+  }
+  double* d = reinterpret_cast<double*>(dc);
   double *dH = d, *db = d + 36 * (size_t)n, *dx = db + 6 * (size_t)n;
   hipError_t e = hipMemcpyAsync(dH, H, sizeof(double) * 36 * n, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(db, b, sizeof(double) * 6 * n, hipMemcpyHostToDevice, ctx->stream);
@@ -526,7 +534,6 @@ int svo_hip_ldlt6_solve_batch(svo_hip_ctx* ctx, int n, const double* H, const do
   }
   if (e == hipSuccess) e = hipMemcpyAsync(x, dx, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d);
   if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_ldlt6_solve_batch", hipGetErrorString(e));
   return SVO_HIP_OK;
 }

@@ -145,6 +145,31 @@ def main():
         t_cq = (time.perf_counter() - t0) / 2000
         out["refine_cpu_port_1thread"] = {"pose_refine_frames_per_s": 1.0 / t_cp, "point_refine_points_per_s_incl_ctypes": 1.0 / t_cq}
 
+    # ---------------- next row f-2: the cell loop of Reprojector::reprojectMap (3000 candidates, 768 cells) ----------------
+    rc = synth.make_reproject_case(seed=21, width=640, height=480, n_points=3000)
+    rref = hip.Pyramid(ctx, 640, 480, 5, 3)
+    rcur = hip.Pyramid(ctx, 640, 480, 5, 1)
+    for k in range(3):
+        rref.upload(k, rc["kf_pyr"][k])
+    rcur.upload(0, rc["cur_pyr"])
+    off, ids = synth.flatten_cells(rc, rc["trial"])
+    rdel = (rc["ptype"][ids] == synth.TYPE_DELETED).astype(np.uint8)
+    rargs = (rc["T_kf_w"], rc["T_cur_w"], off, rc["slot"][ids], rc["px_ref"][ids], rc["f_ref"][ids], rc["level"][ids], rc["pos"][ids], rdel, rc["px_cur"][ids])
+
+    def run_reproject():
+        return hip.reproject_cells(ctx, rref, rcur, 0, rc["cam"], *rargs)
+    t_rp = timed(ctx, run_reproject, args.steps, args.warmup)
+    rres = run_reproject()
+    out["reproject_cells"] = {"us_per_frame_incl_host_copies": t_rp * 1e6, "candidates": int(len(ids)), "cells": int(rc["n_cells"]),
+                              "n_matches": int(rres["n_matches"]), "n_trials": int(rres["n_trials"])}
+    if not args.no_cpu_baseline:
+        t0 = time.perf_counter()
+        for _ in range(3):
+            orc.reproject_cells(rc["cam"], rc["kf_pyr"], rc["T_kf_w"], rc["cur_pyr"], rc["T_cur_w"], off, rc["slot"][ids], rc["px_ref"][ids],
+                                rc["f_ref"][ids], rc["level"][ids], rc["pos"][ids], np.zeros(len(ids), np.uint8), np.tile([1.0, 0.0], (len(ids), 1)),
+                                rdel, rc["px_cur"][ids])
+        out["reproject_cells"]["cpu_port_us_per_frame_1thread"] = (time.perf_counter() - t0) / 3 * 1e6
+
     # ---------------- next row f-3: FastDetector::detect on a 640x480 keyframe (3 levels, 20 px cells) ----------------
     dn, dpx, df_, dl, dsc = ctx.empty((1,), np.int32), ctx.empty((768, 2), np.float64), ctx.empty((768, 3), np.float64), ctx.empty((768,), np.int32), ctx.empty((768,), np.float32)
     ccam = hip.make_camera(sc.cam)
