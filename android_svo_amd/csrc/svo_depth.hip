@@ -870,7 +870,6 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
   SVO_REQUIRE(ctx, cur->width == cam->width && cur->height == cam->height);
   SVO_REQUIRE(ctx, prm->n_pyr_levels >= 1 && prm->n_pyr_levels <= ref->n_levels && prm->n_pyr_levels <= cur->n_levels);
   SVO_REQUIRE(ctx, prm->align_max_iter >= 0 && prm->max_epi_search_steps >= 0);
-  SVO_REQUIRE(ctx, cam->distortion == 0);      // cam2world needs the iterative undistort otherwise
   SVO_REQUIRE(ctx, n >= 0);
   if (n == 0) return SVO_HIP_OK;
   SVO_REQUIRE(ctx, px && f && level && a && b && mu && z_range && sigma2 && status);
@@ -923,7 +922,6 @@ int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref,
   SVO_REQUIRE(ctx, cur_slot >= 0 && cur_slot < cur->batch && n_kf >= 1 && n_kf <= ref->batch);
   SVO_REQUIRE(ctx, ref->width == cam->width && ref->height == cam->height && cur->width == cam->width && cur->height == cam->height);
   SVO_REQUIRE(ctx, n_pyr_levels >= 1 && n_pyr_levels <= ref->n_levels && n_pyr_levels <= cur->n_levels && align_max_iter >= 0);
-  SVO_REQUIRE(ctx, cam->distortion == 0);
   SVO_REQUIRE(ctx, n >= 0);
   if (n == 0) return SVO_HIP_OK;
   SVO_REQUIRE(ctx, T_ref_w_dev && kf_slot_dev && px_ref_dev && f_ref_dev && level_ref_dev && pt_pos_dev && px_cur_dev && success_dev);

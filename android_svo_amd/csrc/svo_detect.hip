@@ -189,7 +189,7 @@ int svo_hip_detect_features_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* pyr, in
   SVO_REQUIRE(ctx, pyr && slot >= 0 && slot < pyr->batch);
   SVO_REQUIRE(ctx, n_pyr_levels > 0 && n_pyr_levels <= pyr->n_levels && cell_size > 0);
   SVO_REQUIRE(ctx, n_out_dev && px_dev && level_dev);
-  SVO_REQUIRE(ctx, !f_dev || (cam && !cam->distortion));        // cam2world with distortion is not on the device
+  SVO_REQUIRE(ctx, !f_dev || cam);
   SVO_REQUIRE(ctx, (size_t)pyr->width * pyr->height < (1u << 24));
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   int gc = 0, gr = 0;

@@ -174,10 +174,35 @@ SVO_DEV void world2cam(const Cam& c, const double* xyz, double* px) {
   world2cam_uv(c, xyz[0] / xyz[2], xyz[1] / xyz[2], px);
 }
 
-// distortion-free branch (S/pinhole_camera.cpp:47-52,64)
+// PinholeCamera::cam2world (S/pinhole_camera.cpp:44-71).  Distorted cameras: cv::undistortPoints on float points with
+// float K / D (:54-63, :31-32) -- OpenCV 4.5.4 calib3d, third-party and absent from the reference tree (parity
+// unpinned): five fixed-point iterations of the radial-tangential model in double, result stored as float.
 SVO_DEV void cam2world(const Cam& c, double u, double v, double* f) {
-  double x = (u - c.cx) / c.fx;
-  double y = (v - c.cy) / c.fy;
+  double x, y;
+  if (!c.distortion) {
+    x = (u - c.cx) / c.fx;
+    y = (v - c.cy) / c.fy;
+  } else {
+    const double fx = (double)(float)c.fx, fy = (double)(float)c.fy, cx = (double)(float)c.cx, cy = (double)(float)c.cy;
+    const double k1 = (double)(float)c.d[0], k2 = (double)(float)c.d[1], p1 = (double)(float)c.d[2],
+                 p2 = (double)(float)c.d[3], k3 = (double)(float)c.d[4];
+    const double uf = (double)(float)u, vf = (double)(float)v;
+    const double ifx = 1. / fx, ify = 1. / fy;
+    x = (uf - cx) * ifx;
+    y = (vf - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; ++j) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2) / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+      if (icdist < 0) { x = (uf - cx) * ifx; y = (vf - cy) * ify; break; }
+      const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x) + 0.0 * r2 + 0.0 * r2 * r2;
+      const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y + 0.0 * r2 + 0.0 * r2 * r2;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    x = (double)(float)x;
+    y = (double)(float)y;
+  }
   double z = 1.0;
   double n2 = x * x + y * y + z * z;
   if (n2 > 0.0) {

@@ -63,6 +63,8 @@ def load_library() -> C.CDLL:
 
 
 def make_camera(cam, dist: Optional[Sequence[float]] = None) -> CCamera:
+    if dist is None:
+        dist = getattr(cam, "dist", None)        # a camera object may carry its radtan coefficients
     c = CCamera()
     c.width, c.height = int(cam.width), int(cam.height)
     c.fx, c.fy, c.cx, c.cy = cam.fx, cam.fy, cam.cx, cam.cy

@@ -69,6 +69,8 @@ def lib() -> C.CDLL:
 
 
 def camera(cam, dist: Sequence[float] | None = None) -> Camera:
+    if dist is None:
+        dist = getattr(cam, "dist", None)        # a camera object may carry its radtan coefficients
     c = Camera()
     c.width, c.height = int(cam.width), int(cam.height)
     c.fx, c.fy, c.cx, c.cy = cam.fx, cam.fy, cam.cx, cam.cy

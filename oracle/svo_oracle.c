@@ -169,11 +169,40 @@ void svo_orc_world2cam(const svo_orc_camera* c, const double xyz[3], double px[2
   svo_orc_world2cam_uv(c, uv, px);
 }
 
-/* S/pinhole_camera.cpp:44-71, distortion-free branch; Eigen normalized() =
- * v / sqrt(squaredNorm) when squaredNorm > 0. */
+/* S/pinhole_camera.cpp:44-71; Eigen normalized() = v / sqrt(squaredNorm) when squaredNorm > 0.
+ * Distorted cameras (:54-63) go through cv::undistortPoints(src CV_32FC2, dst CV_32FC2, cvK_, cvD_) with cvK_/cvD_
+ * float matrices (:31-32).  PARITY UNPINNED: OpenCV 4.5.4 calib3d (undistort.dispatch.cpp, cvUndistortPointsInternal)
+ * is third-party code that is not under /root/reference; restated from its published algorithm: the point and the
+ * parameters are read as floats, x0 = (u - cx)/fx, y0 = (v - cy)/fy, five fixed-point iterations
+ *   icdist = 1/(1 + ((k3 r2 + k2) r2 + k1) r2),  x = (x0 - dx) icdist,  y = (y0 - dy) icdist
+ * with the tangential terms dx = 2 p1 x y + p2 (r2 + 2 x^2), dy = p1 (r2 + 2 y^2) + 2 p2 x y (a negative icdist
+ * keeps the undistorted start value), in double, the result stored as float. */
 void svo_orc_cam2world(const svo_orc_camera* c, double u, double v, double f[3]) {
-  double x = (u - c->cx) / c->fx;
-  double y = (v - c->cy) / c->fy;
+  double x, y;
+  if (!c->distortion) {
+    x = (u - c->cx) / c->fx;
+    y = (v - c->cy) / c->fy;
+  } else {
+    const double fx = (double)(float)c->fx, fy = (double)(float)c->fy, cx = (double)(float)c->cx, cy = (double)(float)c->cy;
+    const double k1 = (double)(float)c->d[0], k2 = (double)(float)c->d[1], p1 = (double)(float)c->d[2],
+                 p2 = (double)(float)c->d[3], k3 = (double)(float)c->d[4];
+    const double uf = (double)(float)u, vf = (double)(float)v;
+    const double ifx = 1. / fx, ify = 1. / fy;
+    x = (uf - cx) * ifx;
+    y = (vf - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; ++j) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2) / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+      if (icdist < 0) { x = (uf - cx) * ifx; y = (vf - cy) * ify; break; }
+      const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x) + 0.0 * r2 + 0.0 * r2 * r2;
+      const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y + 0.0 * r2 + 0.0 * r2 * r2;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    x = (double)(float)x;
+    y = (double)(float)y;
+  }
   double z = 1.0;
   double n2 = x * x + y * y + z * z;
   if (n2 > 0.0) {

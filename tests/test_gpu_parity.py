@@ -1046,3 +1046,40 @@ def test_reproject_cells_against_reference_fixture(ctx, golden, tag, max_fts):
     win = check_against_fixture(g, tag, cs, ids, res)
     assert np.abs(res["px_cur"][win] - g[tag + "_feat_px"]).max() < 5e-3
     ref.destroy(); cur.destroy()
+
+
+def test_depth_filter_and_detector_with_a_distorted_camera(ctx):
+    """cam2world for radtan cameras on the device (the depth filter's triangulation and the detector's bearings): same
+    inputs through the oracle and the HIP path."""
+    import copy
+    sc = seedsynth.make_seed_case(n_seeds=3000, seed=5)
+    cam = copy.copy(sc.cam)
+    cam.dist = (-0.12, 0.03, 2e-4, -1e-4, 0.0)
+    f = np.zeros((3000, 3))
+    c = orc.camera(cam)
+    import ctypes
+    for i in range(3000):
+        orc.lib().svo_orc_cam2world(ctypes.byref(c), ctypes.c_double(sc.px[i, 0]), ctypes.c_double(sc.px[i, 1]),
+                                    orc._p(f[i], ctypes.c_double))
+    kf = hip.Pyramid(ctx, 640, 480, 5, 1); cf = hip.Pyramid(ctx, 640, 480, 5, 1)
+    kf.upload(0, sc.ref_pyr); cf.upload(0, sc.cur_pyr)
+    sb = hip.SeedBatch(ctx, sc.px, f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, sc.sigma2)
+    hip.depth_filter_update(ctx, kf, 0, cf, 0, cam, sc.T_ref_w, sc.T_cur_w, sb)
+    ctx.sync()
+    a, b, mu, s2 = (v.copy() for v in (sc.a, sc.b, sc.mu, sc.sigma2))
+    o = orc.update_seeds(cam, sc.ref_pyr, sc.cur_pyr, sc.T_ref_w, sc.T_cur_w, sc.px, f, sc.level, a, b, mu, sc.z_range.copy(), s2)
+    status = sb.status.download()
+    assert (status != o["status"]).mean() < 0.01
+    same = status == o["status"]
+    upd = same & (status == 3)
+    assert upd.sum() > 1000
+    assert np.abs(sb.mu.download()[upd] - mu[upd]).max() < 1e-4 * np.abs(mu[upd]).max()
+    z_h = sb.z.download()
+    assert np.abs(z_h[upd] - o["z"][upd]).max() < 1e-3
+    # the detector's bearings for the same camera
+    px, fd, lvl, score = hip.detect_features(ctx, kf, 0, cam)
+    for i in range(0, len(px), 7):
+        want = np.zeros(3)
+        orc.lib().svo_orc_cam2world(ctypes.byref(c), ctypes.c_double(px[i, 0]), ctypes.c_double(px[i, 1]), orc._p(want, ctypes.c_double))
+        np.testing.assert_array_equal(fd[i], want)
+    sb.free(); kf.destroy(); cf.destroy()
