@@ -198,11 +198,11 @@ SVO_DEV bool align2d_group16(const uint8_t* __restrict__ cur_img, int cols, int 
     h0 += jx[k] * jx[k]; h1 += jx[k] * jy[k]; h2 += jx[k]; h4 += jy[k] * jy[k]; h5 += jy[k];
   }
   float H[9];
-  H[0] = group_sum<16>(h0);
-  H[1] = group_sum<16>(h1);
-  H[2] = group_sum<16>(h2);
-  H[4] = group_sum<16>(h4);
-  H[5] = group_sum<16>(h5);
+  H[0] = row16_sum(h0);
+  H[1] = row16_sum(h1);
+  H[2] = row16_sum(h2);
+  H[4] = row16_sum(h4);
+  H[5] = row16_sum(h5);
   H[8] = 64.0f;
   H[3] = H[1]; H[6] = H[2]; H[7] = H[5];
   float Hinv[9];
@@ -247,9 +247,9 @@ SVO_DEV bool align2d_group16(const uint8_t* __restrict__ cur_img, int cols, int 
         J0 += res * jx[k]; J1 += res * jy[k]; J2 += res;
       }
     }
-    J0 = -group_sum<16>(J0);
-    J1 = -group_sum<16>(J1);
-    J2 = -group_sum<16>(J2);
+    J0 = -row16_sum(J0);
+    J1 = -row16_sum(J1);
+    J2 = -row16_sum(J2);
     if (running) {
       const float up0 = Hinv[0] * J0 + (Hinv[1] * J1 + Hinv[2] * J2);
       const float up1 = Hinv[3] * J0 + (Hinv[4] * J1 + Hinv[5] * J2);
@@ -281,8 +281,8 @@ SVO_DEV bool align1d_group16(const uint8_t* __restrict__ cur_img, int cols, int 
     j0[k] = (float)(0.5 * (dir0 * ((int)pwb[c + 1] - (int)pwb[c - 1]) + dir1 * ((int)pwb[c + 10] - (int)pwb[c - 10])));
     h00 += j0[k] * j0[k]; h01 += j0[k];
   }
-  const float H00 = group_sum<16>(h00);
-  const float H01 = group_sum<16>(h01);
+  const float H00 = row16_sum(h00);
+  const float H01 = row16_sum(h01);
   const float H11 = 64.0f;
   *h_inv = 1.0 / H00 * 8 * 8;
   const float det = H00 * H11 - H01 * H01;
@@ -327,9 +327,9 @@ SVO_DEV bool align1d_group16(const uint8_t* __restrict__ cur_img, int cols, int 
         J0 += res * j0[k]; J1 += res; c2 += res * res;
       }
     }
-    J0 = -group_sum<16>(J0);
-    J1 = -group_sum<16>(J1);
-    const float new_chi2 = group_sum<16>(c2);
+    J0 = -row16_sum(J0);
+    J1 = -row16_sum(J1);
+    const float new_chi2 = row16_sum(c2);
     if (running) {
       if (iter > 0 && new_chi2 > chi2) {
         u -= up0;

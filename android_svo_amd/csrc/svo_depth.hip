@@ -421,8 +421,8 @@ __global__ __launch_bounds__(256) void df_search_kernel(
     int sumA, sumAA;
     {
       const uint32_t w = patch_words[cl];
-      sumA = group_sum<16>((int)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false));
-      sumAA = group_sum<16>((int)__builtin_amdgcn_udot4(w, w, 0u, false));
+      sumA = row16_sum((int)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false));
+      sumAA = row16_sum((int)__builtin_amdgcn_udot4(w, w, 0u, false));
     }
     unsigned long long best_key = ~0ull;
     int prev_tail_x = 0, prev_tail_y = 0;                // last_checked_pxi entering the chunk

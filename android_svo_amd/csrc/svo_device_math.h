@@ -385,6 +385,24 @@ SVO_DEV T quad_bcast(T v) { return dpp_quad<S * 0x55>(v); }
 SVO_DEV double quad_sum(double v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); return v; }
 SVO_DEV float quad_sum(float v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); return v; }
 
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), every lane gets it, no LDS traffic and no index
+// arithmetic: quad_perm for lanes ^1 and ^2, row_half_mirror for the other quad of the half row, row_mirror for the
+// other half.  The additions pair the same partial sums as the xor butterfly, so the value is bit-identical to it.
+SVO_DEV float row16_sum(float v) {
+  v += dpp_quad<0xB1>(v);
+  v += dpp_quad<0x4E>(v);
+  v += dpp_quad<0x141>(v);               // row_half_mirror
+  v += dpp_quad<0x140>(v);               // row_mirror
+  return v;
+}
+SVO_DEV int row16_sum(int v) {
+  v += dpp_quad<0xB1>(v);
+  v += dpp_quad<0x4E>(v);
+  v += dpp_quad<0x141>(v);
+  v += dpp_quad<0x140>(v);
+  return v;
+}
+
 // Sum 8 per-lane doubles over the 64 lanes of a wave with 7 long-range exchanges instead of 48: every
 // exchange step halves the number of values a lane still carries (lanes with the exchanged bit set keep the
 // upper half of the values and hand over the lower half).  On return lanes 8j .. 8j+7 all hold the wave
