@@ -350,7 +350,6 @@ __global__ __launch_bounds__(256) void df_search_kernel(
   const Cam cam = fr.cam;
 
   // ---------------- phase A: warp the reference patches ----------------
-  // the 4 x 100 samples of the wave's seeds form one flat index space: all loads of the phase are independent
   bool any_search = false;
   for (int sidx = 0; sidx < SEEDS_PER_WAVE; ++sidx) {
     const int i = i0 + sidx;
@@ -361,31 +360,42 @@ __global__ __launch_bounds__(256) void df_search_kernel(
     if (lane == 0) { s_do[slot] = (path == 0 || path == 3) ? 1 : 0; s_nz[slot] = 0; s_px[slot][0] = rp->uv0[0]; s_px[slot][1] = rp->uv0[1]; }
     any_search |= path == 1;
   }
-  for (int k4 = lane; k4 < 100 * SEEDS_PER_WAVE; k4 += 64) {
-    const int sidx = k4 / 100, k = k4 - sidx * 100;
-    const int i = i0 + sidx;
-    if (i >= n) continue;
-    const SeedRec* rp = recs + i;
-    const int path = rp->path;
-    if (path != 0 && path != 1 && path != 3) continue;  // not live, or the search is skipped
-    const uint8_t* ref_pyr = ref_base + (size_t)rp->pad * ref_pyr_bytes;   // pad = reference keyframe slot
-    const int level_ref = level[i];
-    const int search_level = rp->search_level;
-    // warp::warpAffine of the 10x10 reference patch (matcher.cpp:83-116)
-    const int rcols = cam.width >> level_ref, rrows = cam.height >> level_ref;
-    const uint8_t* img_ref = ref_pyr + fr.ref_level_off[level_ref];
-    const int yy = k / 10, xx = k - yy * 10;
-    float ppx = (float)(xx - 5), ppy = (float)(yy - 5);
-    ppx *= (1 << search_level);
-    ppy *= (1 << search_level);
-    const float qx = (rp->a00 * ppx + rp->a01 * ppy) + rp->prx;
-    const float qy = (rp->a10 * ppx + rp->a11 * ppy) + rp->pry;
-    uint8_t val = 0;
-    // the reference keeps the previous seed's patch when the inverse warp is NaN and reads out of bounds when
-    // qx/qy are NaN (inf inverse of a singular A); such samples are 0 here
-    if (!rp->warp_nan && qx >= 0 && qy >= 0 && qx < rcols - 1 && qy < rrows - 1)
-      val = (uint8_t)interpolate_8u(img_ref, rcols, qx, qy);
-    s_pwb[wib * SEEDS_PER_WAVE + sidx][k] = val;
+  {
+    // 16 lanes per seed, 7 samples per lane: the seed's warp parameters are read once per lane
+    const int g = lane >> 4, cl = lane & 15;
+    const int i = i0 + g;
+    const bool have = i < n;
+    const SeedRec* rp = recs + (have ? i : i0);
+    const int path = have ? rp->path : -1;
+    if (path == 0 || path == 1 || path == 3) {
+      const uint8_t* ref_pyr = ref_base + (size_t)rp->pad * ref_pyr_bytes;   // pad = reference keyframe slot
+      const int level_ref = level[i];
+      const int search_level = rp->search_level;
+      // warp::warpAffine of the 10x10 reference patch (matcher.cpp:83-116)
+      const int rcols = cam.width >> level_ref, rrows = cam.height >> level_ref;
+      const uint8_t* img_ref = ref_pyr + fr.ref_level_off[level_ref];
+      const float a00 = rp->a00, a01 = rp->a01, a10 = rp->a10, a11 = rp->a11, prx = rp->prx, pry = rp->pry;
+      const bool warp_nan = rp->warp_nan != 0;
+      const float lscale = (float)(1 << search_level);
+      uint8_t* pwb = s_pwb[wib * SEEDS_PER_WAVE + g];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int k = cl + 16 * j;
+        if (k >= 100) break;
+        const int yy = k / 10, xx = k - yy * 10;
+        float ppx = (float)(xx - 5), ppy = (float)(yy - 5);
+        ppx *= lscale;
+        ppy *= lscale;
+        const float qx = (a00 * ppx + a01 * ppy) + prx;
+        const float qy = (a10 * ppx + a11 * ppy) + pry;
+        uint8_t val = 0;
+        // the reference keeps the previous seed's patch when the inverse warp is NaN and reads out of bounds when
+        // qx/qy are NaN (inf inverse of a singular A); such samples are 0 here
+        if (!warp_nan && qx >= 0 && qy >= 0 && qx < rcols - 1 && qy < rrows - 1)
+          val = (uint8_t)interpolate_8u(img_ref, rcols, qx, qy);
+        pwb[k] = val;
+      }
+    }
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
