@@ -30,17 +30,18 @@ namespace {
 
 constexpr int ZMSSD_THRESHOLD = 2000 * 64;     // I/patch_score.h:46
 
-// ---- align2D over n patches: one wave per patch, 4 waves per block --------------------------
+// ---- align2D over n patches: 16 lanes per patch, four patches per wave, 16 per block ------------------
 __global__ __launch_bounds__(256) void align2d_kernel(const uint8_t* __restrict__ img, int cols, int rows, int n,
                                                       const uint8_t* __restrict__ pwb, int n_iter,
                                                       double* __restrict__ px, uint8_t* __restrict__ converged,
                                                       int32_t* __restrict__ iters) {
-  const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform -> SGPRs
-  if (w >= n) return;
-  double u = px[2 * (size_t)w], v = px[2 * (size_t)w + 1];
+  const int w = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool have = w < n;
+  const int wi = have ? w : 0;
+  double u = px[2 * (size_t)wi], v = px[2 * (size_t)wi + 1];
   int it = 0;
-  const bool ok = align2d_wave(img, cols, rows, cols, pwb + (size_t)w * 100, n_iter, &u, &v, &it);
-  if ((threadIdx.x & 63) == 0) {
+  const bool ok = align2d_group16(img, cols, rows, cols, pwb + (size_t)wi * 100, n_iter, have, &u, &v, &it);
+  if (have && (threadIdx.x & 15) == 0) {
     px[2 * (size_t)w] = u;
     px[2 * (size_t)w + 1] = v;
     converged[w] = ok ? 1 : 0;
@@ -53,13 +54,14 @@ __global__ __launch_bounds__(256) void align1d_kernel(const uint8_t* __restrict_
                                                       const uint8_t* __restrict__ pwb, const float* __restrict__ dir,
                                                       int n_iter, double* __restrict__ px, uint8_t* __restrict__ converged,
                                                       double* __restrict__ h_inv, int32_t* __restrict__ iters) {
-  const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform -> SGPRs
-  if (w >= n) return;
-  double u = px[2 * (size_t)w], v = px[2 * (size_t)w + 1], hi = 0.0;
+  const int w = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool have = w < n;
+  const int wi = have ? w : 0;
+  double u = px[2 * (size_t)wi], v = px[2 * (size_t)wi + 1], hi = 0.0;
   int it = 0;
-  const bool ok = align1d_wave(img, cols, rows, cols, dir[2 * (size_t)w], dir[2 * (size_t)w + 1], pwb + (size_t)w * 100,
-                               n_iter, &u, &v, &hi, &it);
-  if ((threadIdx.x & 63) == 0) {
+  const bool ok = align1d_group16(img, cols, rows, cols, dir[2 * (size_t)wi], dir[2 * (size_t)wi + 1], pwb + (size_t)wi * 100,
+                                  n_iter, have, &u, &v, &hi, &it);
+  if (have && (threadIdx.x & 15) == 0) {
     px[2 * (size_t)w] = u;
     px[2 * (size_t)w + 1] = v;
     converged[w] = ok ? 1 : 0;
@@ -769,7 +771,7 @@ int svo_hip_align2d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int 
   SVO_REQUIRE(ctx, pwb_dev && px_dev && converged_dev);
   (void)ref_patch_dev;   // the 8x8 patch is the interior of the bordered one (matcher.cpp:138-147)
   const uint8_t* img = cur->base + (size_t)slot * cur->pyr_bytes + cur->level_offset[level];
-  hipLaunchKernelGGL(align2d_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, img, cur->width >> level,
+  hipLaunchKernelGGL(align2d_kernel, dim3((n + 15) / 16), dim3(256), 0, ctx->stream, img, cur->width >> level,
                      cur->height >> level, n, pwb_dev, n_iter, px_dev, converged_dev, iters_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
@@ -784,7 +786,7 @@ int svo_hip_align1d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int 
   if (n == 0) return SVO_HIP_OK;
   SVO_REQUIRE(ctx, pwb_dev && dir_dev && px_dev && converged_dev);
   const uint8_t* img = cur->base + (size_t)slot * cur->pyr_bytes + cur->level_offset[level];
-  hipLaunchKernelGGL(align1d_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, img, cur->width >> level,
+  hipLaunchKernelGGL(align1d_kernel, dim3((n + 15) / 16), dim3(256), 0, ctx->stream, img, cur->width >> level,
                      cur->height >> level, n, pwb_dev, dir_dev, n_iter, px_dev, converged_dev, h_inv_dev, iters_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
