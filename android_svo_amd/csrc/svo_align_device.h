@@ -1,15 +1,14 @@
-// svo_align_device.h -- feature_alignment::align2D as a wave64 device routine.
+// svo_align_device.h -- feature_alignment::align2D / align1D as device routines, 16 lanes per 8x8 patch.
 //
-// One wavefront refines one 8x8 patch: lane = pixel (row = lane/8, col = lane%8).
-// Follows S/feature_alignment.cpp:167-281 (the scalar path, canonical on arm64/x86):
-// inverse-compositional LK with a mean-offset parameter, f32 throughout,
-// min_update^2 = 0.5^2 (this port's value, :203), border test before the NaN test
-// (:211-215), `break` on the border leaves converged = false but still writes u,v.
+// Follows S/feature_alignment.cpp:167-281 (the scalar path, canonical on arm64/x86) and :35-152:
+// inverse-compositional LK with a mean-offset parameter, f32 throughout, min_update^2 = 0.5^2 for align2D (this
+// port's value, :203) and 0.03^2 for align1D, border test before the NaN test (:211-215), `break` on the border
+// leaves converged = false but still writes u,v; align1D has the chi2-increase rollback (:117-125, which subtracts
+// update[0] from u and update[1] from v as the reference does) and h_inv = 1/H(0,0) * 64 (:63).
 //
-// Numerics vs the CPU path: H = sum J J^T is exact in f32 in any summation order
-// (entries are multiples of 1/4 below 2^24), so Hinv is bit-identical; Jres is reduced
-// by a 6-stage xor butterfly instead of a 64-term serial sum, so updates differ by
-// f32 rounding (parity tolerance is stated in tests/).
+// Numerics vs the CPU path: H = sum J J^T is exact in f32 in any summation order (entries are multiples of 1/4
+// below 2^24), so Hinv is bit-identical; Jres is summed four pixels per lane in pixel order and then by a 16-lane
+// butterfly instead of a 64-term serial sum, so updates differ by f32 rounding (parity tolerance is stated in tests/).
 #pragma once
 #include "svo_device_math.h"
 
@@ -30,138 +29,9 @@ SVO_DEV void inverse3f(const float* m, float* inv) {
 #undef SVO_M
 }
 
-// pwb: the wave's 10x10 reference patch with border (any address space), read by every lane.
-// Returns converged; u,v in/out (level coordinates); *iters = iterations executed.
-// Must be called by all 64 lanes of the wave.
-template <typename PatchPtr>
-SVO_DEV bool align2d_wave(const uint8_t* __restrict__ cur_img, int cols, int rows, int cur_step,
-                          PatchPtr pwb, int n_iter, double* px_u, double* px_v, int* iters) {
-  const int lane = threadIdx.x & 63;
-  const int py = lane >> 3, pxx = lane & 7;
-  const int c = (py + 1) * 10 + (pxx + 1);
-  const float ref_px = (float)pwb[c];
-  const float jx = (float)(0.5 * ((int)pwb[c + 1] - (int)pwb[c - 1]));
-  const float jy = (float)(0.5 * ((int)pwb[c + 10] - (int)pwb[c - 10]));
-  float H[9];
-  H[0] = group_sum<64>(jx * jx);
-  H[1] = group_sum<64>(jx * jy);
-  H[2] = group_sum<64>(jx);
-  H[4] = group_sum<64>(jy * jy);
-  H[5] = group_sum<64>(jy);
-  H[8] = 64.0f;
-  H[3] = H[1]; H[6] = H[2]; H[7] = H[5];
-  float Hinv[9];
-  inverse3f(H, Hinv);
-
-  float mean_diff = 0;
-  float u = (float)*px_u;
-  float v = (float)*px_v;
-  const float min_update_squared = 0.25f;
-  bool converged = false;
-  int it_count = 0;
-  for (int iter = 0; iter < n_iter; ++iter) {
-    const int u_r = (int)floorf(u);
-    const int v_r = (int)floorf(v);
-    if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) break;
-    // (a NaN u/v fails none of the comparisons above in C++ and hits the isnan test of :214;
-    //  floorf(NaN) cast to int is 0 on this target, so NaN always leaves through the border test
-    //  with converged == false, which is also what :214 returns)
-    if (u != u || v != v) break;
-    ++it_count;
-    const float subpix_x = u - u_r;
-    const float subpix_y = v - v_r;
-    const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
-    const float wTR = (float)(subpix_x * (1.0 - subpix_y));
-    const float wBL = (float)((1.0 - subpix_x) * subpix_y);
-    const float wBR = subpix_x * subpix_y;
-    const uint8_t* it = cur_img + (v_r + py - 4) * cur_step + (u_r - 4) + pxx;
-    const float search_pixel = wTL * it[0] + wTR * it[1] + wBL * it[cur_step] + wBR * it[cur_step + 1];
-    const float res = search_pixel - ref_px + mean_diff;
-    const float J0 = -group_sum<64>(res * jx);
-    const float J1 = -group_sum<64>(res * jy);
-    const float J2 = -group_sum<64>(res);
-    const float up0 = Hinv[0] * J0 + (Hinv[1] * J1 + Hinv[2] * J2);
-    const float up1 = Hinv[3] * J0 + (Hinv[4] * J1 + Hinv[5] * J2);
-    const float up2 = Hinv[6] * J0 + (Hinv[7] * J1 + Hinv[8] * J2);
-    u += up0;
-    v += up1;
-    mean_diff += up2;
-    if (up0 * up0 + up1 * up1 < min_update_squared) { converged = true; break; }
-  }
-  *px_u = (double)u;
-  *px_v = (double)v;
-  *iters = it_count;
-  return converged;
-}
-
-// feature_alignment::align1D (S/feature_alignment.cpp:35-152) as a wave64 routine: the patch may
-// only move along `dir`; 2 parameters (step along dir, mean offset), min_update^2 = 0.03^2,
-// chi2-increase rollback (:117-125, which subtracts update[0] from u and update[1] from v as the
-// reference does), h_inv = 1/H(0,0) * 64 (:63).
-template <typename PatchPtr>
-SVO_DEV bool align1d_wave(const uint8_t* __restrict__ cur_img, int cols, int rows, int cur_step, float dir0,
-                          float dir1, PatchPtr pwb, int n_iter, double* px_u, double* px_v, double* h_inv,
-                          int* iters) {
-  const int lane = threadIdx.x & 63;
-  const int py = lane >> 3, pxx = lane & 7;
-  const int c = (py + 1) * 10 + (pxx + 1);
-  const float ref_px = (float)pwb[c];
-  const float j0 = (float)(0.5 * (dir0 * ((int)pwb[c + 1] - (int)pwb[c - 1]) + dir1 * ((int)pwb[c + 10] - (int)pwb[c - 10])));
-  const float H00 = group_sum<64>(j0 * j0);
-  const float H01 = group_sum<64>(j0);
-  const float H11 = 64.0f;
-  *h_inv = 1.0 / H00 * 8 * 8;
-  const float det = H00 * H11 - H01 * H01;
-  const float invdet = 1.0f / det;
-  const float Hi00 = H11 * invdet, Hi01 = -H01 * invdet, Hi10 = -H01 * invdet, Hi11 = H00 * invdet;
-  float mean_diff = 0;
-  float u = (float)*px_u;
-  float v = (float)*px_v;
-  const float min_update_squared = (float)(0.03 * 0.03);
-  float chi2 = 0;
-  float up0 = 0, up1 = 0;
-  bool converged = false;
-  int it_count = 0;
-  for (int iter = 0; iter < n_iter; ++iter) {
-    const int u_r = (int)floorf(u);
-    const int v_r = (int)floorf(v);
-    if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) break;
-    if (u != u || v != v) break;
-    ++it_count;
-    const float subpix_x = u - u_r;
-    const float subpix_y = v - v_r;
-    const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
-    const float wTR = (float)(subpix_x * (1.0 - subpix_y));
-    const float wBL = (float)((1.0 - subpix_x) * subpix_y);
-    const float wBR = subpix_x * subpix_y;
-    const uint8_t* it = cur_img + (v_r + py - 4) * cur_step + (u_r - 4) + pxx;
-    const float search_pixel = wTL * it[0] + wTR * it[1] + wBL * it[cur_step] + wBR * it[cur_step + 1];
-    const float res = search_pixel - ref_px + mean_diff;
-    const float J0 = -group_sum<64>(res * j0);
-    const float J1 = -group_sum<64>(res);
-    const float new_chi2 = group_sum<64>(res * res);
-    if (iter > 0 && new_chi2 > chi2) {
-      u -= up0;
-      v -= up1;
-      break;
-    }
-    chi2 = new_chi2;
-    up0 = Hi00 * J0 + Hi01 * J1;
-    up1 = Hi10 * J0 + Hi11 * J1;
-    u += up0 * dir0;
-    v += up0 * dir1;
-    mean_diff += up1;
-    if (up0 * up0 + up1 * up1 < min_update_squared) { converged = true; break; }
-  }
-  *px_u = (double)u;
-  *px_v = (double)v;
-  *iters = it_count;
-  return converged;
-}
-
 // ---- 16 lanes per patch: four patches per wavefront ---------------------------------------------------------
-// The same two routines with a quarter wave per 8x8 patch: lane cl of the group owns pixels (row cl/2, columns
-// 4*(cl%2) .. +3).  A wave then refines four patches at once and issues a quarter of the instructions per patch
+// A quarter wave per 8x8 patch: lane cl of the group owns pixels (row cl/2, columns 4*(cl%2) .. +3).  A wave then
+// refines four patches at once and issues a quarter of the instructions per patch
 // (the per-iteration arithmetic on u, v and the weights is uniform within a patch and costs the same whether 16 or 64
 // lanes carry it).  Sums: four pixels in pixel order per lane, then a 16-lane butterfly; H is exact in any order.
 // All 64 lanes must call these; `active` = this lane's group has a patch to refine.  Every group-level value
