@@ -1083,3 +1083,76 @@ def test_depth_filter_and_detector_with_a_distorted_camera(ctx):
         orc.lib().svo_orc_cam2world(ctypes.byref(c), ctypes.c_double(px[i, 0]), ctypes.c_double(px[i, 1]), orc._p(want, ctypes.c_double))
         np.testing.assert_array_equal(fd[i], want)
     sb.free(); kf.destroy(); cf.destroy()
+
+
+def test_next_row_kernels_fuzz(ctx):
+    """Odd sizes and degenerate inputs for the next-row kernels, device against oracle."""
+    rng = np.random.default_rng(77)
+    # detector: image sizes that are not multiples of the cell size, 2..5 levels
+    for (w, h, cell, nl) in ((752, 480, 30, 3), (1280, 720, 40, 4), (200, 136, 25, 2), (96, 64, 20, 2)):
+        img = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        img[h // 4:h // 2, w // 4:w // 2] = 200
+        pyr_host = synth.build_pyramid(img, 5)
+        pyr = hip.Pyramid(ctx, w, h, 5, 1)
+        pyr.upload(0, pyr_host)
+        px_o, lvl_o, sc_o = orc.detect_features(pyr_host, n_pyr_levels=nl, cell_size=cell)
+        px, _, lvl, sc = hip.detect_features(ctx, pyr, 0, None, n_pyr_levels=nl, cell_size=cell)
+        np.testing.assert_array_equal(px, px_o.astype(np.float64))
+        np.testing.assert_array_equal(lvl, lvl_o)
+        np.testing.assert_array_equal(sc, sc_o)
+        pyr.destroy()
+    # a featureless image: nothing detected
+    pyr = hip.Pyramid(ctx, 160, 120, 5, 1)
+    pyr.upload(0, synth.build_pyramid(np.full((120, 160), 77, dtype=np.uint8), 5))
+    px, _, lvl, sc = hip.detect_features(ctx, pyr, 0, None)
+    assert len(px) == 0
+    pyr.destroy()
+    # structure refinement: one observation (singular 3x3: LDLT pseudo-inverse), identical observations, far start
+    T0 = synth.se3_from_twist([0, 0, 0], [0, 0, 0])
+    T1 = synth.se3_from_twist([0.3, 0, 0], [0, 0.05, 0])
+    X = np.array([0.2, -0.1, 3.0])
+    f0 = X / np.linalg.norm(X)
+    X1 = synth.se3_act(T1, X)
+    f1 = X1 / np.linalg.norm(X1)
+    pos0 = np.stack([X + 0.05, X + 0.05, X * 3.0, X + [0.0, 0.0, -2.9]])
+    off = np.array([0, 1, 3, 5, 7], dtype=np.int32)
+    obs_T = np.stack([T0, T0, T0, T0, T1, T0, T1])
+    obs_f = np.stack([f0, f0, f0, f0, f1, f0, f1])
+    out, it = hip.point_optimize_batch(ctx, pos0, off, obs_T, obs_f, n_iter=8)
+    for k in range(4):
+        want, it_o = orc.point_optimize(pos0[k], obs_T[off[k]:off[k + 1]], obs_f[off[k]:off[k + 1]], n_iter=8)
+        np.testing.assert_array_equal(out[k], want)          # NaNs compare equal
+        assert it[k] == it_o
+    # pose refinement: few observations, all outliers, mixed levels
+    for seed, n, frac in ((31, 7, 0.0), (32, 40, 0.9), (33, 3, 0.0), (34, 500, 0.5)):
+        pc = synth.make_pose_opt_case(seed=seed, n=n, outlier_frac=frac, null_every=0)
+        em = abs(pc.cam.fx)
+        o, hp_o = orc.pose_optimize(em, pc.T_f_w_init, pc.f, pc.pos, pc.level, pc.has_point)
+        r, hp = hip.pose_optimize(ctx, pc.T_f_w_init, pc.f, pc.pos, pc.level, pc.has_point, em)
+        assert r.ran == o.ran
+        assert r.estimated_scale == o.estimated_scale                   # selection: exact whatever the data
+        if frac > 0.8:
+            # nine observations in ten are gross outliers: the weighted problem is ill-posed, rounding decides which of
+            # two nearly equal chi2 values is larger and the two runs may stop at different iterations
+            assert 1 <= r.n_iter_done <= 10 and np.isfinite(np.array(r.T_f_w)).all()
+            continue
+        assert r.n_iter_done == o.n_iter_done, (seed, r.n_iter_done, o.n_iter_done)
+        To, Tr = np.array(o.T_f_w), np.array(r.T_f_w)
+        if np.isfinite(To).all():
+            rot, trans = synth.pose_error(Tr, To)
+            assert rot < 1e-8 and trans < 1e-8, (seed, rot, trans)
+        else:
+            assert not np.isfinite(Tr).all()
+        assert (hp != hp_o).sum() <= 1
+    # reprojection cell loop: no candidates at all
+    cs = synth.make_reproject_case(seed=5, n_points=40)
+    ref = hip.Pyramid(ctx, 320, 240, 5, 3); cur = hip.Pyramid(ctx, 320, 240, 5, 1)
+    for k in range(3):
+        ref.upload(k, cs["kf_pyr"][k])
+    cur.upload(0, cs["cur_pyr"])
+    off0 = np.zeros(cs["n_cells"] + 1, dtype=np.int32)
+    e = np.zeros((0, 3))
+    res = hip.reproject_cells(ctx, ref, cur, 0, cs["cam"], cs["T_kf_w"], cs["T_cur_w"], off0, np.zeros(0, np.int32), e[:, :2], e,
+                              np.zeros(0, np.int32), e, np.zeros(0, np.uint8), e[:, :2])
+    assert res["n_matches"] == 0 and res["n_trials"] == 0 and (res["cell_winner"] == -1).all()
+    ref.destroy(); cur.destroy()
