@@ -19,6 +19,7 @@
 #include <svo/point.h>
 #include <svo/pose_optimizer.h>
 
+#include "pose_optimizer_hip.h"
 #include "svo_hip_bridge.h"
 
 namespace svo {
