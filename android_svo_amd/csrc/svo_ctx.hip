@@ -11,7 +11,10 @@ namespace {
 // 2x2 truncating mean, one thread per 4 output pixels (reads 2 x 8 B, writes 4 B):
 // vk::halfSample scalar / NEON form, vision.cpp:49-67,89-110.  HBM-bound: 1.25 B moved
 // per input byte.
-__global__ void half_sample_kernel(const uint8_t* __restrict__ in, int w, int h, uint8_t* __restrict__ out) {
+// in / out point at the level inside pyramid slot 0 of the launch; blockIdx.z selects the slot (stride pyr_bytes)
+__global__ void half_sample_kernel(const uint8_t* __restrict__ in, int w, int h, uint8_t* __restrict__ out, size_t slot_stride = 0) {
+  in += (size_t)blockIdx.z * slot_stride;
+  out += (size_t)blockIdx.z * slot_stride;
   const int ow = w >> 1, oh = h >> 1;
   const int quads = (ow + 3) >> 2;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -228,6 +231,25 @@ int svo_hip_pyramid_upload_level0_and_build(svo_hip_pyramid* pyr, int slot, cons
     dim3 block(64), grid(((ow + 3) / 4 + 63) / 64, oh);
     hipLaunchKernelGGL(half_sample_kernel, grid, block, 0, ctx->stream, base + pyr->level_offset[l - 1], w, h,
                        base + pyr->level_offset[l]);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_pyramid_upload_level0_batch_and_build(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* level0_packed) {
+  if (!pyr || !level0_packed) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = pyr->ctx;
+  SVO_REQUIRE(ctx, first_slot >= 0 && n_slots > 0 && first_slot + n_slots <= pyr->batch);
+  uint8_t* base = pyr->base + (size_t)first_slot * pyr->pyr_bytes;
+  const size_t l0 = (size_t)pyr->width * pyr->height;
+  // n_slots level-0 images, back to back on the host, into their slots (one strided transfer)
+  SVO_CHECK_HIP(ctx, hipMemcpy2DAsync(base, pyr->pyr_bytes, level0_packed, l0, l0, (size_t)n_slots, hipMemcpyHostToDevice, ctx->stream));
+  for (int l = 1; l < pyr->n_levels; ++l) {
+    const int w = pyr->width >> (l - 1), h = pyr->height >> (l - 1);
+    const int ow = w >> 1, oh = h >> 1;
+    dim3 block(64), grid(((ow + 3) / 4 + 63) / 64, oh, n_slots);
+    hipLaunchKernelGGL(half_sample_kernel, grid, block, 0, ctx->stream, base + pyr->level_offset[l - 1], w, h,
+                       base + pyr->level_offset[l], pyr->pyr_bytes);
     SVO_CHECK_HIP(ctx, hipGetLastError());
   }
   return SVO_HIP_OK;

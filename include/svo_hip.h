@@ -94,6 +94,10 @@ int svo_hip_pyramid_download_level(svo_hip_pyramid* pyr, int slot, int level, ui
  * transfer: from page-locked memory this runs at link rate, where per-level uploads are latency-bound */
 int svo_hip_pyramid_level_offset(const svo_hip_pyramid* pyr, int level, size_t* offset);
 int svo_hip_pyramid_upload_packed(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* packed);
+/* n_slots level-0 images (back to back on the host) in one strided transfer, then the coarser levels of all of them
+ * on the device: 4 launches for the whole batch, and only level 0 (75 % of the pyramid bytes) crosses the link */
+int svo_hip_pyramid_upload_level0_batch_and_build(svo_hip_pyramid* pyr, int first_slot, int n_slots,
+                                                  const uint8_t* level0_packed);
 int svo_hip_pyramid_info(const svo_hip_pyramid* pyr, int* width, int* height, int* n_levels, int* batch,
                          size_t* pyr_bytes, void** base_dev);
 

@@ -1156,3 +1156,32 @@ def test_next_row_kernels_fuzz(ctx):
                               np.zeros(0, np.int32), e, np.zeros(0, np.uint8), e[:, :2])
     assert res["n_matches"] == 0 and res["n_trials"] == 0 and (res["cell_winner"] == -1).all()
     ref.destroy(); cur.destroy()
+
+
+@pytest.mark.parametrize("wh", [(320, 240), (752, 480), (100, 68)])
+def test_level0_batch_upload_builds_all_pyramids_on_device(ctx, wh):
+    """svo_hip_pyramid_upload_level0_batch_and_build: level 0 of a run of slots in one strided transfer, coarser
+    levels of all of them by one launch per level; same bytes as frame_utils::createImgPyramid per image."""
+    w, h = wh
+    rng = np.random.default_rng(w)
+    B, first = 5, 2
+    pyr = hip.Pyramid(ctx, w, h, 4, B + first + 1)
+    lib = ctx.lib
+    sentinel = synth.build_pyramid(rng.integers(0, 256, (h, w)).astype(np.uint8), 4)
+    for slot in (first - 1, first + B):
+        pyr.upload(slot, sentinel)
+    imgs = [rng.integers(0, 256, (h, w)).astype(np.uint8) for _ in range(B)]
+    packed = np.ascontiguousarray(np.stack(imgs))
+    ctx.check(lib.svo_hip_pyramid_upload_level0_batch_and_build(
+        pyr.h, first, B, packed.ctypes.data_as(C.POINTER(C.c_uint8))), "l0batch")
+    ctx.sync()
+    for s in range(B):
+        want = synth.build_pyramid(imgs[s], 4)
+        for l in range(4):
+            np.testing.assert_array_equal(pyr.download_level(first + s, l), want[l])
+    for slot in (first - 1, first + B):            # neighbours untouched
+        for l in range(4):
+            np.testing.assert_array_equal(pyr.download_level(slot, l), sentinel[l])
+    assert lib.svo_hip_pyramid_upload_level0_batch_and_build(
+        pyr.h, first, B + 2, packed.ctypes.data_as(C.POINTER(C.c_uint8))) != 0
+    pyr.destroy()

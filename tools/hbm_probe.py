@@ -135,6 +135,23 @@ def main():
     out["pyramid_upload_packed_pinned"] = {"GBps": B * pb.value / dt / 1e9, "pyramids_per_s": B / dt, "pyramids_per_transfer": B}
     chk = pyr.download_level(B - 1, 2)
     assert (chk == levels[2]).all()
+    # level 0 of the whole batch in one strided transfer, coarser levels built on the device (4 launches per batch)
+    hl0 = C.c_void_p()
+    ctx.check(lib.svo_hip_malloc_host(ctx.h, C.byref(hl0), C.c_size_t(B * 307200)), "malloc_host")
+    for s in range(B):
+        C.memmove(hl0.value + s * 307200, levels[0].ctypes.data, 307200)
+    for _ in range(2):
+        ctx.check(lib.svo_hip_pyramid_upload_level0_batch_and_build(pyr.h, 0, B, C.cast(hl0, C.POINTER(C.c_uint8))), "l0batch")
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ctx.check(lib.svo_hip_pyramid_upload_level0_batch_and_build(pyr.h, 0, B, C.cast(hl0, C.POINTER(C.c_uint8))), "l0batch")
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / 10
+    out["level0_batch_upload_and_device_pyramids_pinned"] = {"GBps": B * 307200 / dt / 1e9, "pyramids_per_s": B / dt, "pyramids_per_transfer": B}
+    for l in range(5):
+        assert (pyr.download_level(B - 1, l) == levels[l]).all()
+    ctx.check(lib.svo_hip_free_host(ctx.h, hl0), "free_host")
     ctx.check(lib.svo_hip_free_host(ctx.h, hpk), "free_host")
     ctx.check(lib.svo_hip_free_host(ctx.h, hp), "free_host")
     out["vendor_peak"] = 8000.0
