@@ -53,6 +53,7 @@ constexpr int TILE = 64;                        // patches per wavefront pass
 constexpr int TILE_ROW = 24;                    // doubles per tile-H row (21 used)
 constexpr uint8_t F_VISIBLE = 1;                // visible_fts_ (sticky across levels)
 constexpr uint8_t F_JVALID = 2;                 // jacobian_cache_ column block non-zero at this level
+constexpr uint8_t F_GONE = 4;                   // fused kernel: outside the current image at the previous evaluation
 
 // per-frame constants
 struct FrameConst {
@@ -600,7 +601,7 @@ __global__ void sia_finish_kernel(const FrameConst* __restrict__ fc, FrameState*
 constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_WAVES = FUSED_THREADS / 64;
 constexpr int FUSED_MAX_TILES = 44;               // 44 * 64 * 56 B = 157 696 B of footprints
-constexpr int FUSED_MAX_TPW = 6;                  // ceil(44 / 8)
+constexpr int FUSED_MAX_TPW = 6;                  // the older wave's share of a SIMD's 11 tiles
 
 struct FusedLevels {
   int cols[SVO_HIP_MAX_LEVELS], rows[SVO_HIP_MAX_LEVELS];
@@ -620,8 +621,15 @@ struct LppGeom {
   int off;
 };
 
-// projection of one patch into the current level image (:220-236)
-SVO_DEV LppGeom lpp_project(const double* T, const Cam& cam, const double4& X, bool visible, float scale, int cols,
+// what the hot loop keeps of the camera in scalar registers; the distortion coefficients stay in memory and are
+// only fetched (wave-uniform scalar loads) by a distorted camera
+struct LeanCam {
+  double fx, fy, cx, cy;
+  const double* d;      // null: pinhole without distortion
+};
+
+// projection of one patch into the current level image (:220-236); the weights come back halved (see the caller)
+SVO_DEV LppGeom lpp_project(const double* T, const LeanCam& cam, const double4& X, bool visible, float scale, int cols,
                             int rows, int stride) {
   LppGeom g;
   g.ok = false; g.w_tl = g.w_tr = g.w_bl = g.w_br = 0.0f; g.off = 0;
@@ -630,7 +638,18 @@ SVO_DEV LppGeom lpp_project(const double* T, const Cam& cam, const double4& X, b
     const double xyz_ref[3] = {X.x, X.y, X.z};
     double xyz_cur[3], pxd[2];
     se3_act(T, xyz_ref, xyz_cur);
-    world2cam(cam, xyz_cur, pxd);
+    const double un = xyz_cur[0] / xyz_cur[2], vn = xyz_cur[1] / xyz_cur[2];
+    if (cam.d == nullptr) {
+      pxd[0] = cam.fx * un + cam.cx;
+      pxd[1] = cam.fy * vn + cam.cy;
+    } else {
+      Cam full;
+      full.fx = cam.fx; full.fy = cam.fy; full.cx = cam.cx; full.cy = cam.cy;
+      full.distortion = 1; full.width = full.height = 0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) full.d[i] = cam.d[i];
+      world2cam_uv(full, un, vn, pxd);
+    }
     const float u_cur = (float)pxd[0] * scale;
     const float v_cur = (float)pxd[1] * scale;
     const int u_cur_i = (int)floorf(u_cur);
@@ -639,10 +658,10 @@ SVO_DEV LppGeom lpp_project(const double* T, const Cam& cam, const double4& X, b
             u_cur_i + border < cols && v_cur_i + border < rows) && u_cur == u_cur && v_cur == v_cur;
     const float subpix_u = u_cur - u_cur_i;
     const float subpix_v = v_cur - v_cur_i;
-    g.w_tl = (float)((1.0 - subpix_u) * (1.0 - subpix_v));
-    g.w_tr = (float)(subpix_u * (1.0 - subpix_v));
-    g.w_bl = (float)((1.0 - subpix_u) * subpix_v);
-    g.w_br = subpix_u * subpix_v;
+    g.w_tl = 0.5f * (float)((1.0 - subpix_u) * (1.0 - subpix_v));
+    g.w_tr = 0.5f * (float)(subpix_u * (1.0 - subpix_v));
+    g.w_bl = 0.5f * (float)((1.0 - subpix_u) * subpix_v);
+    g.w_br = 0.5f * (subpix_u * subpix_v);
     g.off = g.ok ? (v_cur_i - 2) * stride + (u_cur_i - 2) : 0;
   }
   return g;
@@ -653,7 +672,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
     const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
     const double* __restrict__ f, const double* __restrict__ pos, const uint8_t* __restrict__ has_point,
-    double4* __restrict__ sxyz, FusedParams prm) {
+    double4* __restrict__ sxyz, double* __restrict__ tile_h, int max_tiles, FusedParams prm, int tiles_young) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint2* fp = reinterpret_cast<uint2*>(smem);               // [n_tiles*64][7] footprint rows
   __shared__ double red[FUSED_WAVES][32];
@@ -668,18 +687,33 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   __shared__ int s_iters[SVO_HIP_MAX_LEVELS];
 #ifdef SVO_STAMPS
   __shared__ long long s_stamp[6];
+  __shared__ long long s_wst[16];
+  if (threadIdx.x < 16) s_wst[threadIdx.x] = 0;
   if (threadIdx.x == 64) { s_stamp[0] = s_stamp[1] = s_stamp[2] = 0; }
   if (threadIdx.x == 0) { s_stamp[3] = s_stamp[4] = 0; }
 #endif
 
   const int b = blockIdx.x;
   const FrameConst& c = fc[b];
-  const Cam cam = c.cam;
+  LeanCam cam;
+  cam.fx = c.cam.fx; cam.fy = c.cam.fy; cam.cx = c.cam.cx; cam.cy = c.cam.cy;
+  cam.d = c.cam.distortion ? c.cam.d : nullptr;
   const int n = c.n_feat;
   const int n_tiles = (n + TILE - 1) / TILE;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPRs
   const bool empty = n <= 0;
   const int tri_i = kTriI[lane < 21 ? lane : 0], tri_j = kTriJ[lane < 21 ? lane : 0];
+  // Tile ownership.  Waves w and w+4 share SIMD w&3, and the SIMD's arbiter favours the older one (w < 4): it runs
+  // at the pace of a wave that is alone on its SIMD (one instruction per 4 cycles, whatever the type), the younger
+  // one gets the issue cycles that are left (measured: 57 % of that pace) and finishes an equal share 40 % later,
+  // alone on a half-used SIMD.  The tiles of a SIMD (s, s+4, s+8, ...) are split evenly, the older wave takes the
+  // first TPW of them and the younger one the tiles_young that follow; during the first half of its tiles the younger
+  // wave raises its priority (s_setprio), so that each wave is the favoured one for half of the evaluation and both
+  // reach the barrier together (measured per-wave cycles per evaluation: 15.0 k / 21.5 k before, 18.2 k / 19.7 k after).
+  const int simd = wave & 3;
+  const int my_tiles = wave < 4 ? TPW : tiles_young;                    // wave-uniform
+  const int first_j = wave < 4 ? 0 : TPW;
+  auto tile_of = [&](int k) -> int { return k < my_tiles ? simd + 4 * (first_j + k) : n_tiles; };
 
   if (lane >= 29 && lane < 32) red[wave][lane] = 0.0;       // unused slots of the wave partial rows
   if (threadIdx.x == 0) {
@@ -701,7 +735,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   uint8_t fl[TPW];
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
-    const int tile = wave + FUSED_WAVES * k;
+    const int tile = tile_of(k);
     const int i_own = tile * TILE + lane;
     X[k] = make_double4(0, 0, 1, 1);
     th[k] = 0.0;
@@ -734,7 +768,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     // ================= precomputeReferencePatches for the wave's tiles =================
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
-      const int tile = wave + FUSED_WAVES * k;
+      const int tile = tile_of(k);
       if (tile >= n_tiles) continue;                         // wave-uniform
       const int tile_base = tile * TILE;
       const int i_own = tile_base + lane;
@@ -810,6 +844,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
             ++e;
           }
         th[k] = mine;
+        // the untouched row goes to memory: it is only needed again when the set of patches outside the image changes
+        if (lane < 21) tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane] = mine;
       }
     }
     __syncthreads();      // s_done / s_old of this level, footprints (own wave) in place
@@ -833,18 +869,25 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       unsigned acc_n = 0;
 #pragma unroll
       for (int k = 0; k < TPW; ++k) {
-        const int tile = wave + FUSED_WAVES * k;
+        const int tile = tile_of(k);
+        // the younger wave of a SIMD is favoured by the arbiter during the first half of its tiles (see tile_of)
+        if (wave >= 4) { if (2 * k < my_tiles) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+
         if (tile >= n_tiles) continue;                       // wave-uniform
         const int tile_base = tile * TILE;
         // ---- projection into the current image (:220-236)
         const LppGeom g = lpp_project(T, cam, X[k], (fl[k] & F_VISIBLE) != 0, scale, cols, rows, stride);
         const bool ok = g.ok;
         const bool jvalid = (fl[k] & F_JVALID) != 0;
-        // weights of the cached reference patch (recomputed from the kept sub-pixel offsets)
-        const float rw_tl = (float)((1.0 - su[k]) * (1.0 - sv[k]));
-        const float rw_tr = (float)(su[k] * (1.0 - sv[k]));
-        const float rw_bl = (float)((1.0 - su[k]) * sv[k]);
-        const float rw_br = su[k] * sv[k];
+        // weights of the cached reference patch (recomputed from the kept sub-pixel offsets).  All interpolation
+        // weights of the evaluation are HALVED: a power-of-two scale commutes with every rounding, so W below is
+        // exactly half the reference's interpolated value, a difference of two W is its 0.5*(a - b) gradient, res is
+        // half the residual, chi a quarter of the patch's chi2 and sdx/sdy half the sums -- the 32 multiplications by
+        // 0.5 disappear and the factors 2 and 4 are applied once per evaluation after the wave reduction (exact).
+        const float rw_tl = 0.5f * (float)((1.0 - su[k]) * (1.0 - sv[k]));
+        const float rw_tr = 0.5f * (float)(su[k] * (1.0 - sv[k]));
+        const float rw_bl = 0.5f * (float)((1.0 - su[k]) * sv[k]);
+        const float rw_br = 0.5f * (su[k] * sv[k]);
 
         // ---- residuals (:238-279): the lane walks the 16 pixels of its own patch; no cross-lane traffic at all.
         // 32 interpolations of the reference footprint give ref value / dx / dy of every pixel.
@@ -867,11 +910,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
           for (int y = 0; y < 4; ++y)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-              const float refv = W[y + 1][x + 1];
-              const float dxv = 0.5f * (W[y + 1][x + 2] - W[y + 1][x]);
-              const float dyv = 0.5f * (W[y + 2][x + 1] - W[y][x + 1]);
+              const float refv = W[y + 1][x + 1];                                  // half the reference value
+              const float dxv = W[y + 1][x + 2] - W[y + 1][x];                     // = 0.5f * (a - b) of the full values
+              const float dyv = W[y + 2][x + 1] - W[y][x + 1];
               const float inten = interp_at(Cr[y], Cr[y + 1], x, g.w_tl, g.w_tr, g.w_bl, g.w_br);
-              const float res = inten - refv;
+              const float res = inten - refv;                                      // half the residual
               chi += res * res;
               const double dres = (double)res;
               // f32 x f32 is exact in f64 (48-bit product): the fused form rounds exactly like mul + add
@@ -896,27 +939,42 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
           accJ[4] += u * a + sdx;
           accJ[5] += v * sdx - u * sdy;
         }
-        if (lane < 21) accH += th[k];
-        unsigned long long gone = __ballot(jvalid && !ok);
-        while (gone) {
-          const int src = __ffsll((long long)gone) - 1;
-          gone &= gone - 1;
-          const double gx_ = __shfl(X[k].x, src, 64), gy_ = __shfl(X[k].y, src, 64), gzi = __shfl(X[k].w, src, 64);
-          const double4 G4 = sxyz[(size_t)b * max_n + tile_base + src];
-          const double g_xx = G4.x, g_xy = G4.y, g_yy = G4.z;
-          double A[6], B[6];
-          patch_jacobian_rows(gx_, gy_, gzi, jscale, A, B);
-          double Ai = A[0], Aj = A[0], Bi = B[0], Bj = B[0];
+        // H of the tile = its per-level row minus the patches that are outside the current image now (:76, :226-229).
+        // th[k] holds the row with the patches that were outside at the previous evaluation already taken out; that
+        // set changes rarely (after convergence it does not change at all), so the correction -- one dependent
+        // memory access and a 21-entry rank update per patch, done one patch after the other -- is only redone
+        // when the set differs from the last evaluation's
+        const bool out_now = jvalid && !ok;
+        const unsigned long long gone_now = __ballot(out_now);
+        const unsigned long long gone_prev = __ballot((fl[k] & F_GONE) != 0);
+        if (gone_now != gone_prev) {                           // wave-uniform
+          double t = 0.0;
+          if (lane < 21) t = tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane];
+          unsigned long long gone = gone_now;
+          while (gone) {
+            const int src = __ffsll((long long)gone) - 1;
+            gone &= gone - 1;
+            const double gx_ = __shfl(X[k].x, src, 64), gy_ = __shfl(X[k].y, src, 64), gzi = __shfl(X[k].w, src, 64);
+            const double4 G4 = sxyz[(size_t)b * max_n + tile_base + src];
+            const double g_xx = G4.x, g_xy = G4.y, g_yy = G4.z;
+            double A[6], B[6];
+            patch_jacobian_rows(gx_, gy_, gzi, jscale, A, B);
+            double Ai = A[0], Aj = A[0], Bi = B[0], Bj = B[0];
 #pragma unroll
-          for (int kk = 1; kk < 6; ++kk) {
-            if (tri_i == kk) { Ai = A[kk]; Bi = B[kk]; }
-            if (tri_j == kk) { Aj = A[kk]; Bj = B[kk]; }
+            for (int kk = 1; kk < 6; ++kk) {
+              if (tri_i == kk) { Ai = A[kk]; Bi = B[kk]; }
+              if (tri_j == kk) { Aj = A[kk]; Bj = B[kk]; }
+            }
+            const double h = g_xx * (Ai * Aj) + g_xy * (Ai * Bj + Bi * Aj) + g_yy * (Bi * Bj);
+            t -= h;
           }
-          const double h = g_xx * (Ai * Aj) + g_xy * (Ai * Bj + Bi * Aj) + g_yy * (Bi * Bj);
-          if (lane < 21) accH -= h;
+          th[k] = t;
+          fl[k] = (uint8_t)((fl[k] & ~F_GONE) | (out_now ? F_GONE : 0));
         }
+        if (lane < 21) accH += th[k];
       }
 
+      __builtin_amdgcn_s_setprio(0);
       // ---- wave reduction, then the waves in fixed order, then the solve on one lane
       {
         // lanes 8j..8j+7 receive the wave total of value j: 0..5 = Jres moments (sign and fx/2^L applied here),
@@ -927,7 +985,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         v8[6] = acc_chi; v8[7] = (double)acc_n;
         const double t = wave_reduce8(v8);
         const int j = lane >> 3;
-        const double sgn = (j == 0 || j == 1 || j == 4) ? jscale : (j < 6 ? -jscale : 1.0);
+        // undo the halved weights: Jres moments x2, chi2 x4 (exact)
+        const double sgn = (j == 0 || j == 1 || j == 4) ? 2.0 * jscale : (j < 6 ? -2.0 * jscale : (j == 6 ? 4.0 : 1.0));
         if (lane < 21) red[wave][lane] = accH;
         if ((lane & 7) == 0) red[wave][21 + j] = t * sgn;
       }
@@ -1040,6 +1099,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       __syncthreads();
 #ifdef SVO_STAMPS
       if (threadIdx.x == 64) { const long long t3 = __builtin_amdgcn_s_memtime(); s_stamp[0] += t1 - t0; s_stamp[1] += t2 - t1; s_stamp[2] += t3 - t2; }
+      if (lane == 0) { s_wst[wave] += t1 - t0; s_wst[8 + wave] += t2 - t1; }
 #endif
     }
     __syncthreads();
@@ -1059,6 +1119,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         for (int j = i; j < 6; ++j) { s.H[i * 6 + j] = s_last[kk]; s.H[j * 6 + i] = s_last[kk]; ++kk; }
       for (int i = 0; i < 6; ++i) { s.Jres[i] = s_last[21 + i]; s.x[i] = s_x[i]; }
 #ifdef SVO_STAMPS
+      for (int i = 0; i < 16; ++i) s.H[i] = (double)s_wst[i];
       s.x[0] = (double)s_stamp[0]; s.x[1] = (double)s_stamp[1]; s.x[2] = (double)s_stamp[2]; s.x[3] = (double)s_stamp[3]; s.x[4] = (double)s_stamp[4];
 #endif
     }
@@ -1154,13 +1215,17 @@ int fused_tiles_per_wave(const svo_hip_sia* s, int n_slots) {
   for (int i = 0; i < n_slots; ++i) max_n = s->h_fc[i].n_feat > max_n ? s->h_fc[i].n_feat : max_n;
   const int tiles = (max_n + TILE - 1) / TILE;
   if (tiles > FUSED_MAX_TILES) return 0;
-  const int tpw = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
-  static_assert(FUSED_MAX_TPW * FUSED_WAVES >= FUSED_MAX_TILES, "dispatch covers every tile count");
-  return tpw < 1 ? 1 : tpw;
+  // tiles per SIMD, split between its older and its younger wave (see tile_of in the kernel); returns the older share
+  const int per_simd = (tiles + 3) / 4;
+  int old_share = (per_simd + 1) / 2;
+  const char* ovr = getenv("SVO_HIP_SIA_OLD_TILES");                     // diagnostic override
+  if (ovr && atoi(ovr) >= (per_simd + 1) / 2 && atoi(ovr) <= per_simd && atoi(ovr) <= FUSED_MAX_TPW) old_share = atoi(ovr);
+  static_assert(FUSED_MAX_TPW * 2 * 4 >= FUSED_MAX_TILES, "dispatch covers every tile count");
+  return old_share < 1 ? 1 : old_share;
 }
 
 template <int TPW>
-int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes) {
+int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes, int tiles_young) {
   svo_hip_ctx* ctx = s->ctx;
   // > 64 KiB of dynamic LDS has to be allowed explicitly (per device: set it on every launch, it is cheap)
   SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<TPW>),
@@ -1177,7 +1242,8 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
   hipLaunchKernelGGL((sia_fused_kernel<TPW>), dim3(n_slots), dim3(FUSED_THREADS), lds_bytes, ctx->stream, s->fc, s->st,
-                     s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, fp);
+                     s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, s->tile_h,
+                     s->max_tiles, fp, tiles_young);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
@@ -1199,13 +1265,15 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tp
   const size_t lds = (size_t)tiles * TILE * 56;
   s->begun = false;
   s->last_mode = 1;
-  switch (tpw) {                 // tiles per wave
-    case 1: return launch_fused_t<1>(s, n_slots, prm, lds);
-    case 2: return launch_fused_t<2>(s, n_slots, prm, lds);
-    case 3: return launch_fused_t<3>(s, n_slots, prm, lds);
-    case 4: return launch_fused_t<4>(s, n_slots, prm, lds);
-    case 5: return launch_fused_t<5>(s, n_slots, prm, lds);
-    case 6: return launch_fused_t<6>(s, n_slots, prm, lds);
+  const int ty = (tiles + 3) / 4 - tpw;      // the younger wave's share of a SIMD's tiles
+  SVO_REQUIRE(ctx, ty >= 0 && ty <= tpw);
+  switch (tpw) {                 // tiles of an older wave
+    case 1: return launch_fused_t<1>(s, n_slots, prm, lds, ty);
+    case 2: return launch_fused_t<2>(s, n_slots, prm, lds, ty);
+    case 3: return launch_fused_t<3>(s, n_slots, prm, lds, ty);
+    case 4: return launch_fused_t<4>(s, n_slots, prm, lds, ty);
+    case 5: return launch_fused_t<5>(s, n_slots, prm, lds, ty);
+    case 6: return launch_fused_t<6>(s, n_slots, prm, lds, ty);
     default: break;
   }
   return svo_fail(ctx, SVO_HIP_ERR_INVALID, "fused SparseImgAlign", "unsupported tiles-per-wave");
@@ -1451,6 +1519,7 @@ int svo_hip_sia_debug_x(svo_hip_sia* s, int slot, double* x6) {
   FrameState st;
   int rc = svo_hip_memcpy_d2h(s->ctx, &st, s->st + slot, sizeof(FrameState));
   for (int i = 0; i < 6; ++i) x6[i] = st.x[i];
+  for (int i = 0; i < 16; ++i) x6[6 + i] = st.H[i];      // caller passes 22 doubles
   return rc;
 }
 #endif
