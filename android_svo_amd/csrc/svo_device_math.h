@@ -23,6 +23,11 @@ struct Cam {
   int width, height;
 };
 
+// wave-uniform copy of lane l's value
+SVO_DEV double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 SVO_DEV void cross3(const double* a, const double* b, double* o) {
   double x = a[1] * b[2] - a[2] * b[1];
   double y = a[2] * b[0] - a[0] * b[2];

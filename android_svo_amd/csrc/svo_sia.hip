@@ -676,8 +676,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint2* fp = reinterpret_cast<uint2*>(smem);               // [n_tiles*64][7] footprint rows
   __shared__ double red[FUSED_WAVES][32];
-  __shared__ double s_r[32], s_last[32], s_x[8];
-  __shared__ double s_Hc[21], s_fac[36];   // H of the previous evaluation and its LDL^T factor
+  __shared__ double s_last[32], s_x[8];
+  __shared__ double s_Hc[21], s_fac[36], s_inv[36];   // H of the previous evaluation, its LDL^T factor, H^-1 by columns
   __shared__ int s_ftr[6], s_fac_valid;
   __shared__ double s_model[8], s_old[8];
   __shared__ double s_chi2;
@@ -998,71 +998,93 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       const long long t2 = __builtin_amdgcn_s_memtime();
 #endif
       if (wave == 0) {
+        double v = 0.0;
         if (lane < 32) {
-          double v = 0.0;
 #pragma unroll
           for (int w = 0; w < FUSED_WAVES; ++w) v += red[w][lane];
-          s_r[lane] = v;
           s_last[lane] = v;                  // H_ / Jres_ of the last evaluation, reported at the end
         }
         // H is the sum of the per-level tile rows minus the patches outside the image at this evaluation: as long as
-        // no patch leaves, it is bit for bit the H of the previous evaluation and its LDL^T factor is reused
-        // (the factorisation is a deterministic function of H, so the result is the same number)
+        // that set does not change it is bit for bit the H of the previous evaluation, and what was derived from it
+        // is reused (a deterministic function of H, so the result is the same number)
         bool h_same = true;
         if (lane < 21) {
-          const double v = s_r[lane];
           h_same = __double_as_longlong(v) == __double_as_longlong(s_Hc[lane]);
           s_Hc[lane] = v;
         }
         const bool reuse = s_fac_valid != 0 && __ballot(!h_same) == 0ull;      // wave-uniform
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane == 0) {
-          // I/nlls_solver_impl.hpp:35-99 with solve()/update() of S/sparse_img_align.cpp:291-308
-          double Jres[6], x[6];
+        // lanes 21..28 hold Jres, chi2 and the number of measurements: wave-uniform copies, no trip through LDS
+        double Jres[6];
 #pragma unroll
-          for (int i = 0; i < 6; ++i) Jres[i] = s_r[21 + i];
-          const double chi2_sum = s_r[27];
-          const unsigned long long n_meas = (unsigned long long)(s_r[28] + 0.5);
+        for (int i = 0; i < 6; ++i) Jres[i] = readlane_f64(v, 21 + i);
+        const double chi2_sum = readlane_f64(v, 27);
+        const double n_meas_d = readlane_f64(v, 28);
+#ifdef SVO_STAMPS
+        const long long q0 = __builtin_amdgcn_s_memtime();
+#endif
+        if (!reuse) {
+          // H changed: lane 0 factors it (pivoted LDL^T, I/nlls_solver_impl.hpp:35-99 -> Eigen LDLT), then lanes 0..5
+          // each push one unit vector through the substitution -- six right-hand sides in the time of one -- and keep
+          // the columns of H^-1.  Every evaluation after that is a 6x6 matrix-vector product on six lanes instead of a
+          // serial substitution with six divisions.
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (lane == 0) {
+            double H[36], m[6][6];
+            int tr[6];
+            int kk = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+              for (int j = i; j < 6; ++j) { H[i * 6 + j] = s_Hc[kk]; H[j * 6 + i] = s_Hc[kk]; ++kk; }
+            ldlt6_factor_reg(H, m, tr);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+              s_ftr[i] = tr[i];
+#pragma unroll
+              for (int j = 0; j <= i; ++j) s_fac[i * 6 + j] = m[i][j];
+            }
+            s_fac_valid = 1;
+          }
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (lane < 6) {
+            double m[6][6], e[6], col[6];
+            int tr[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+              tr[i] = __builtin_amdgcn_readfirstlane(s_ftr[i]);
+              e[i] = lane == i ? 1.0 : 0.0;
+#pragma unroll
+              for (int j = 0; j <= i; ++j) m[i][j] = s_fac[i * 6 + j];
+            }
+            ldlt6_substitute_reg(m, tr, e, col);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s_inv[lane * 6 + j] = col[j];
+          }
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        // x = H^-1 Jres, one component per lane (H^-1 is symmetric: lane i uses the column it computed as row i)
+        double xi = 0.0;
+        if (lane < 6) {
+          xi = s_inv[lane * 6] * Jres[0];
+#pragma unroll
+          for (int j = 1; j < 6; ++j) xi += s_inv[lane * 6 + j] * Jres[j];
+        }
+        double x[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] = readlane_f64(xi, i);
+#ifdef SVO_STAMPS
+        if (lane == 0) s_stamp[3] += __builtin_amdgcn_s_memtime() - q0;
+#endif
+        if (lane == 0) {
+          // solve()/update() of S/sparse_img_align.cpp:291-308 inside the loop of I/nlls_solver_impl.hpp:35-99
+          const unsigned long long n_meas = (unsigned long long)(n_meas_d + 0.5);
           const double new_chi2 = (double)((float)chi2_sum / (float)n_meas);     // (:285)
           s_nmeas = n_meas;
           s_nres += n_meas / 16;
           s_iters[level] += 1;
-#ifdef SVO_STAMPS
-          const long long q0 = __builtin_amdgcn_s_memtime();
-#endif
-          {
-            double m[6][6];
-            int tr[6];
-            if (reuse) {
-#pragma unroll
-              for (int i = 0; i < 6; ++i) {
-                tr[i] = __builtin_amdgcn_readfirstlane(s_ftr[i]);
-#pragma unroll
-                for (int j = 0; j <= i; ++j) m[i][j] = s_fac[i * 6 + j];
-              }
-            } else {
-              double H[36];
-              int kk = 0;
-#pragma unroll
-              for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = i; j < 6; ++j) { H[i * 6 + j] = s_r[kk]; H[j * 6 + i] = s_r[kk]; ++kk; }
-              ldlt6_factor_reg(H, m, tr);
-#pragma unroll
-              for (int i = 0; i < 6; ++i) {
-                s_ftr[i] = tr[i];
-#pragma unroll
-                for (int j = 0; j <= i; ++j) s_fac[i * 6 + j] = m[i][j];
-              }
-              s_fac_valid = 1;
-            }
-            ldlt6_substitute_reg(m, tr, Jres, x);
-          }
-#ifdef SVO_STAMPS
-          const long long q1 = __builtin_amdgcn_s_memtime();
-          s_stamp[3] += q1 - q0;
-#endif
 #pragma unroll
           for (int i = 0; i < 6; ++i) s_x[i] = x[i];
           if (x[0] != x[0]) s_stop = 1;                                          // NaN -> stop_ (:52-59)
