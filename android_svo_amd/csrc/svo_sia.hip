@@ -601,6 +601,9 @@ __global__ void sia_finish_kernel(const FrameConst* __restrict__ fc, FrameState*
 constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_WAVES = FUSED_THREADS / 64;
 constexpr int FUSED_MAX_TILES = 44;               // 44 * 64 * 56 B = 157 696 B of footprints
+constexpr int FUSED_FP_BYTES = TILE * 56;         // footprints of one tile
+constexpr int FUSED_WC_BYTES = TILE * 128;        // interpolated reference patches of one tile
+constexpr size_t FUSED_LDS_BUDGET = 160 * 1024 - 4608;   // dynamic LDS next to the kernel's static 3.9 KiB
 constexpr int FUSED_MAX_TPW = 6;                  // the older wave's share of a SIMD's 11 tiles
 
 struct FusedLevels {
@@ -667,14 +670,20 @@ SVO_DEV LppGeom lpp_project(const double* T, const LeanCam& cam, const double4& 
   return g;
 }
 
-template <int TPW>
+template <int TPW, int CK>
 __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
     const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
     const double* __restrict__ f, const double* __restrict__ pos, const uint8_t* __restrict__ has_point,
     double4* __restrict__ sxyz, double* __restrict__ tile_h, int max_tiles, FusedParams prm, int tiles_young) {
+  constexpr int cached_tiles = CK;      // tiles per wave that keep interpolated patches instead of footprints
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint2* fp = reinterpret_cast<uint2*>(smem);               // [n_tiles*64][7] footprint rows
+  // LDS: [8 * cached_tiles][8][64] float4 of interpolated reference patches, then [slot][64][7] footprint rows.
+  // The first cached_tiles tiles of every wave keep the 32 interpolated values W of each patch (128 B) instead of its
+  // footprint (56 B): their evaluations skip the interpolation of the footprint (a third of the instructions of a
+  // tile).  The host fills the LDS that the footprints leave free with as many of them as fit.
+  float4* wc = reinterpret_cast<float4*>(smem);
+  uint2* fp = reinterpret_cast<uint2*>(smem + (size_t)FUSED_WAVES * cached_tiles * FUSED_WC_BYTES);
   __shared__ double red[FUSED_WAVES][32];
   __shared__ double s_last[32], s_x[8];
   __shared__ double s_Hc[21], s_fac[36], s_inv[36];   // H of the previous evaluation, its LDL^T factor, H^-1 by columns
@@ -686,11 +695,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   __shared__ unsigned long long s_nres, s_nmeas;
   __shared__ int s_iters[SVO_HIP_MAX_LEVELS];
 #ifdef SVO_STAMPS
-  __shared__ long long s_stamp[6];
+  __shared__ long long s_stamp[10];
   __shared__ long long s_wst[16];
   if (threadIdx.x < 16) s_wst[threadIdx.x] = 0;
   if (threadIdx.x == 64) { s_stamp[0] = s_stamp[1] = s_stamp[2] = 0; }
-  if (threadIdx.x == 0) { s_stamp[3] = s_stamp[4] = 0; }
+  if (threadIdx.x == 0) { for (int i = 3; i < 10; ++i) s_stamp[i] = 0; }
 #endif
 
   const int b = blockIdx.x;
@@ -707,12 +716,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   // at the pace of a wave that is alone on its SIMD (one instruction per 4 cycles, whatever the type), the younger
   // one gets the issue cycles that are left (measured: 57 % of that pace) and finishes an equal share 40 % later,
   // alone on a half-used SIMD.  The tiles of a SIMD (s, s+4, s+8, ...) are split evenly, the older wave takes the
-  // first TPW of them and the younger one the tiles_young that follow; during the first half of its tiles the younger
-  // wave raises its priority (s_setprio), so that each wave is the favoured one for half of the evaluation and both
+  // first TPW of them and the younger one the tiles_young that follow; during the first 5/8 of its tiles the younger
+  // wave raises its priority (s_setprio), so that each wave is the favoured one for about half of the evaluation and both
   // reach the barrier together (measured per-wave cycles per evaluation: 15.0 k / 21.5 k before, 18.2 k / 19.7 k after).
   const int simd = wave & 3;
   const int my_tiles = wave < 4 ? TPW : tiles_young;                    // wave-uniform
   const int first_j = wave < 4 ? 0 : TPW;
+  const int favoured_tiles = (5 * my_tiles + 4) / 8;                    // 3 of 4 measured best (2 of 4: -0.8 %)
   auto tile_of = [&](int k) -> int { return k < my_tiles ? simd + 4 * (first_j + k) : n_tiles; };
 
   if (lane >= 29 && lane < 32) red[wave][lane] = 0.0;       // unused slots of the wave partial rows
@@ -806,15 +816,30 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
           uint2 F[7];
 #pragma unroll
           for (int j = 0; j < 7; ++j) F[j] = load_row8(ref_img + off + j * stride);
-          uint2* dst = fp + (size_t)(tile_base + lane) * 7;
+          if (k >= cached_tiles) {
+            uint2* dst = fp + (size_t)(((k - cached_tiles) * FUSED_WAVES + wave) * TILE + lane) * 7;
 #pragma unroll
-          for (int j = 0; j < 7; ++j) dst[j] = F[j];
+            for (int j = 0; j < 7; ++j) dst[j] = F[j];
+          }
           float W[6][6];
 #pragma unroll
           for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int c2 = 0; c2 < 6; ++c2)
               W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : interp_at(F[j], F[j + 1], c2, w_tl, w_tr, w_bl, w_br);
+          if (k < cached_tiles) {
+            // halved (exact), in the order the evaluation reads them: rows 0 and 5 without their corners
+            float4* dst = wc + (size_t)((k * FUSED_WAVES + wave) * 8) * TILE + lane;
+            float q[32];
+            int e = 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+              for (int c2 = 0; c2 < 6; ++c2)
+                if (!((j == 0 || j == 5) && (c2 == 0 || c2 == 5))) q[e++] = 0.5f * W[j][c2];
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4) dst[c4 * TILE] = make_float4(q[4 * c4], q[4 * c4 + 1], q[4 * c4 + 2], q[4 * c4 + 3]);
+          }
 #pragma unroll
           for (int y = 0; y < 4; ++y)
 #pragma unroll
@@ -870,8 +895,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
 #pragma unroll
       for (int k = 0; k < TPW; ++k) {
         const int tile = tile_of(k);
-        // the younger wave of a SIMD is favoured by the arbiter during the first half of its tiles (see tile_of)
-        if (wave >= 4) { if (2 * k < my_tiles) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        // the younger wave of a SIMD is favoured by the arbiter during its first tiles (see tile_of)
+        if (wave >= 4) { if (k < favoured_tiles) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 
         if (tile >= n_tiles) continue;                       // wave-uniform
         const int tile_base = tile * TILE;
@@ -879,15 +904,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         const LppGeom g = lpp_project(T, cam, X[k], (fl[k] & F_VISIBLE) != 0, scale, cols, rows, stride);
         const bool ok = g.ok;
         const bool jvalid = (fl[k] & F_JVALID) != 0;
-        // weights of the cached reference patch (recomputed from the kept sub-pixel offsets).  All interpolation
-        // weights of the evaluation are HALVED: a power-of-two scale commutes with every rounding, so W below is
-        // exactly half the reference's interpolated value, a difference of two W is its 0.5*(a - b) gradient, res is
-        // half the residual, chi a quarter of the patch's chi2 and sdx/sdy half the sums -- the 32 multiplications by
-        // 0.5 disappear and the factors 2 and 4 are applied once per evaluation after the wave reduction (exact).
-        const float rw_tl = 0.5f * (float)((1.0 - su[k]) * (1.0 - sv[k]));
-        const float rw_tr = 0.5f * (float)(su[k] * (1.0 - sv[k]));
-        const float rw_bl = 0.5f * (float)((1.0 - su[k]) * sv[k]);
-        const float rw_br = 0.5f * (su[k] * sv[k]);
+        // All interpolation weights of the evaluation are HALVED: a power-of-two scale commutes with every rounding, so
+        // W below is exactly half the reference's interpolated value, a difference of two W is its 0.5*(a - b)
+        // gradient, res is half the residual, chi a quarter of the patch's chi2 and sdx/sdy half the sums -- the 32
+        // multiplications by 0.5 disappear and the factors 2 and 4 are applied once per evaluation after the wave
+        // reduction (exact).
 
         // ---- residuals (:238-279): the lane walks the 16 pixels of its own patch; no cross-lane traffic at all.
         // 32 interpolations of the reference footprint give ref value / dx / dy of every pixel.
@@ -897,15 +918,36 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
           uint2 Cr[5], F[7];
 #pragma unroll
           for (int j = 0; j < 5; ++j) Cr[j] = load_row8(cur_img + g.off + j * stride);   // off == 0 when !ok: valid memory
-          const uint2* src = fp + (size_t)(tile_base + lane) * 7;
-#pragma unroll
-          for (int j = 0; j < 7; ++j) F[j] = src[j];
           float W[6][6];
+          if (k < cached_tiles) {                              // compile-time
+            const float4* src = wc + (size_t)((k * FUSED_WAVES + wave) * 8) * TILE + lane;
+            float q[32];
 #pragma unroll
-          for (int j = 0; j < 6; ++j)
+            for (int c4 = 0; c4 < 8; ++c4) {
+              const float4 t4 = src[c4 * TILE];
+              q[4 * c4] = t4.x; q[4 * c4 + 1] = t4.y; q[4 * c4 + 2] = t4.z; q[4 * c4 + 3] = t4.w;
+            }
+            int e = 0;
 #pragma unroll
-            for (int c2 = 0; c2 < 6; ++c2)
-              W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : interp_at(F[j], F[j + 1], c2, rw_tl, rw_tr, rw_bl, rw_br);
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+              for (int c2 = 0; c2 < 6; ++c2)
+                W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : q[e++];
+          } else {
+            const uint2* src = fp + (size_t)(((k - cached_tiles) * FUSED_WAVES + wave) * TILE + lane) * 7;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) F[j] = src[j];
+            // weights of the cached reference patch (recomputed from the kept sub-pixel offsets), halved
+            const float rw_tl = 0.5f * (float)((1.0 - su[k]) * (1.0 - sv[k]));
+            const float rw_tr = 0.5f * (float)(su[k] * (1.0 - sv[k]));
+            const float rw_bl = 0.5f * (float)((1.0 - su[k]) * sv[k]);
+            const float rw_br = 0.5f * (su[k] * sv[k]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+              for (int c2 = 0; c2 < 6; ++c2)
+                W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : interp_at(F[j], F[j + 1], c2, rw_tl, rw_tr, rw_bl, rw_br);
+          }
 #pragma unroll
           for (int y = 0; y < 4; ++y)
 #pragma unroll
@@ -998,6 +1040,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       const long long t2 = __builtin_amdgcn_s_memtime();
 #endif
       if (wave == 0) {
+        // the solver state lane 0 needs further down: asked for now, together with the wave partials, so that the
+        // serial part below does not pay one LDS round trip per item
+        double cur[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) cur[i] = s_model[i];
+        const double chi2_old = s_chi2;
+        const int it = s_iter, stop_old = s_stop, iters_l = s_iters[level];
+        const unsigned long long nres_old = s_nres;
         double v = 0.0;
         if (lane < 32) {
 #pragma unroll
@@ -1021,6 +1071,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         const double n_meas_d = readlane_f64(v, 28);
 #ifdef SVO_STAMPS
         const long long q0 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) s_stamp[5] += q0 - t2;
 #endif
         if (!reuse) {
           // H changed: lane 0 factors it (pivoted LDL^T, I/nlls_solver_impl.hpp:35-99 -> Eigen LDLT), then lanes 0..5
@@ -1076,35 +1127,36 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
 #pragma unroll
         for (int i = 0; i < 6; ++i) x[i] = readlane_f64(xi, i);
 #ifdef SVO_STAMPS
-        if (lane == 0) s_stamp[3] += __builtin_amdgcn_s_memtime() - q0;
+        const long long q1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) s_stamp[3] += q1 - q0;
 #endif
         if (lane == 0) {
           // solve()/update() of S/sparse_img_align.cpp:291-308 inside the loop of I/nlls_solver_impl.hpp:35-99
           const unsigned long long n_meas = (unsigned long long)(n_meas_d + 0.5);
           const double new_chi2 = (double)((float)chi2_sum / (float)n_meas);     // (:285)
           s_nmeas = n_meas;
-          s_nres += n_meas / 16;
-          s_iters[level] += 1;
+          s_nres = nres_old + n_meas / 16;
+          s_iters[level] = iters_l + 1;
 #pragma unroll
           for (int i = 0; i < 6; ++i) s_x[i] = x[i];
-          if (x[0] != x[0]) s_stop = 1;                                          // NaN -> stop_ (:52-59)
-          const int it = s_iter;
-          if ((prm.early_stop && it > 0 && new_chi2 > s_chi2) || s_stop) {
+          const bool stop_now = stop_old != 0 || x[0] != x[0];                   // NaN -> stop_ (:52-59)
+          if (stop_now) s_stop = 1;
+          if ((prm.early_stop && it > 0 && new_chi2 > chi2_old) || stop_now) {
             for (int i = 0; i < 7; ++i) s_model[i] = s_old[i];                   // rollback (:72)
             s_done = 1;
           } else {
-            double mx[6], dT[7], nm[7], cur[7];
+            double mx[6], dT[7], nm[7];
 #pragma unroll
             for (int i = 0; i < 6; ++i) mx[i] = -x[i];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) cur[i] = s_model[i];
 #ifdef SVO_STAMPS
             const long long q2 = __builtin_amdgcn_s_memtime();
+            s_stamp[6] += q2 - q1;
 #endif
             se3_exp(mx, dT);
             se3_mul(cur, dT, nm);                                                // T_new = T_old * exp(-x) (:307)
 #ifdef SVO_STAMPS
-            s_stamp[4] += __builtin_amdgcn_s_memtime() - q2;
+            const long long q3 = __builtin_amdgcn_s_memtime();
+            s_stamp[4] += q3 - q2;
 #endif
 #pragma unroll
             for (int i = 0; i < 7; ++i) { s_old[i] = cur[i]; s_model[i] = nm[i]; }
@@ -1115,8 +1167,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
             if (prm.early_stop && mxn <= prm.eps) s_done = 1;                    // :97-98
             s_iter = it + 1;
             if (it + 1 >= prm.n_iter) s_done = 1;
+#ifdef SVO_STAMPS
+            s_stamp[7] += __builtin_amdgcn_s_memtime() - q3;
+#endif
           }
         }
+#ifdef SVO_STAMPS
+        if (lane == 0) s_stamp[8] += __builtin_amdgcn_s_memtime() - t2;
+#endif
       }
       __syncthreads();
 #ifdef SVO_STAMPS
@@ -1142,6 +1200,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       for (int i = 0; i < 6; ++i) { s.Jres[i] = s_last[21 + i]; s.x[i] = s_x[i]; }
 #ifdef SVO_STAMPS
       for (int i = 0; i < 16; ++i) s.H[i] = (double)s_wst[i];
+      for (int i = 5; i < 9; ++i) s.H[16 + i - 5] = (double)s_stamp[i];
       s.x[0] = (double)s_stamp[0]; s.x[1] = (double)s_stamp[1]; s.x[2] = (double)s_stamp[2]; s.x[3] = (double)s_stamp[3]; s.x[4] = (double)s_stamp[4];
 #endif
     }
@@ -1246,12 +1305,12 @@ int fused_tiles_per_wave(const svo_hip_sia* s, int n_slots) {
   return old_share < 1 ? 1 : old_share;
 }
 
-template <int TPW>
+template <int TPW, int CK>
 int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes, int tiles_young) {
   svo_hip_ctx* ctx = s->ctx;
   // > 64 KiB of dynamic LDS has to be allowed explicitly (per device: set it on every launch, it is cheap)
-  SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<TPW>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_TILES * TILE * 56));
+  SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<TPW, CK>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BUDGET));
   FusedLevels lv;
   memset(&lv, 0, sizeof(lv));
   for (int l = 0; l < s->ref->n_levels; ++l) {
@@ -1263,7 +1322,7 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   fp.early_stop = prm->early_stop; fp.eps = prm->eps;
   hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
-  hipLaunchKernelGGL((sia_fused_kernel<TPW>), dim3(n_slots), dim3(FUSED_THREADS), lds_bytes, ctx->stream, s->fc, s->st,
+  hipLaunchKernelGGL((sia_fused_kernel<TPW, CK>), dim3(n_slots), dim3(FUSED_THREADS), lds_bytes, ctx->stream, s->fc, s->st,
                      s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, s->tile_h,
                      s->max_tiles, fp, tiles_young);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
@@ -1284,18 +1343,28 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tp
   int max_n = 0;
   for (int i = 0; i < n_slots; ++i) max_n = s->h_fc[i].n_feat > max_n ? s->h_fc[i].n_feat : max_n;
   const int tiles = max_n > 0 ? (max_n + TILE - 1) / TILE : 1;
-  const size_t lds = (size_t)tiles * TILE * 56;
-  s->begun = false;
-  s->last_mode = 1;
   const int ty = (tiles + 3) / 4 - tpw;      // the younger wave's share of a SIMD's tiles
   SVO_REQUIRE(ctx, ty >= 0 && ty <= tpw);
-  switch (tpw) {                 // tiles of an older wave
-    case 1: return launch_fused_t<1>(s, n_slots, prm, lds, ty);
-    case 2: return launch_fused_t<2>(s, n_slots, prm, lds, ty);
-    case 3: return launch_fused_t<3>(s, n_slots, prm, lds, ty);
-    case 4: return launch_fused_t<4>(s, n_slots, prm, lds, ty);
-    case 5: return launch_fused_t<5>(s, n_slots, prm, lds, ty);
-    case 6: return launch_fused_t<6>(s, n_slots, prm, lds, ty);
+  // LDS plan: every wave keeps interpolated patches for its first ck tiles and footprints for the others; the
+  // footprint slot of (wave, k) is (k - ck) * 8 + wave, and the last k only exists on the four older waves when the
+  // younger ones own one tile less.  The largest ck that fits next to the kernel's static LDS wins.
+  auto fp_slots = [&](int c) { return c >= tpw ? 0 : (tpw - 1 - c) * FUSED_WAVES + (ty >= tpw ? FUSED_WAVES : 4); };
+  auto lds_need = [&](int c) { return (size_t)FUSED_WAVES * c * FUSED_WC_BYTES + (size_t)fp_slots(c) * FUSED_FP_BYTES; };
+  int ck = 0;
+  while (ck < tpw && lds_need(ck + 1) <= FUSED_LDS_BUDGET) ++ck;
+  const size_t lds = lds_need(ck);
+  SVO_REQUIRE(ctx, lds <= FUSED_LDS_BUDGET);
+  s->begun = false;
+  s->last_mode = 1;
+  // (tiles of an older wave, cached tiles per wave): the pairs the plan above can produce for 1..44 tiles
+  switch (tpw * 10 + ck) {
+    case 11: return launch_fused_t<1, 1>(s, n_slots, prm, lds, ty);
+    case 22: return launch_fused_t<2, 2>(s, n_slots, prm, lds, ty);
+    case 32: return launch_fused_t<3, 2>(s, n_slots, prm, lds, ty);
+    case 31: return launch_fused_t<3, 1>(s, n_slots, prm, lds, ty);
+    case 41: return launch_fused_t<4, 1>(s, n_slots, prm, lds, ty);
+    case 50: return launch_fused_t<5, 0>(s, n_slots, prm, lds, ty);
+    case 60: return launch_fused_t<6, 0>(s, n_slots, prm, lds, ty);
     default: break;
   }
   return svo_fail(ctx, SVO_HIP_ERR_INVALID, "fused SparseImgAlign", "unsupported tiles-per-wave");
@@ -1541,7 +1610,7 @@ int svo_hip_sia_debug_x(svo_hip_sia* s, int slot, double* x6) {
   FrameState st;
   int rc = svo_hip_memcpy_d2h(s->ctx, &st, s->st + slot, sizeof(FrameState));
   for (int i = 0; i < 6; ++i) x6[i] = st.x[i];
-  for (int i = 0; i < 16; ++i) x6[6 + i] = st.H[i];      // caller passes 22 doubles
+  for (int i = 0; i < 20; ++i) x6[6 + i] = st.H[i];      // caller passes 26 doubles
   return rc;
 }
 #endif
