@@ -600,10 +600,8 @@ __global__ void sia_finish_kernel(const FrameConst* __restrict__ fc, FrameState*
 // =================================================================================================
 constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_WAVES = FUSED_THREADS / 64;
-constexpr int FUSED_MAX_TILES = 44;               // 44 * 64 * 56 B = 157 696 B of footprints
-constexpr int FUSED_FP_BYTES = TILE * 56;         // footprints of one tile
+constexpr int FUSED_MAX_TILES = 44;               // 2816 patches: 6 tiles on an older wave, 5 on a younger one
 constexpr int FUSED_WC_BYTES = TILE * 128;        // interpolated reference patches of one tile
-constexpr size_t FUSED_LDS_BUDGET = 160 * 1024 - 4608;   // dynamic LDS next to the kernel's static 3.9 KiB
 constexpr int FUSED_MAX_TPW = 6;                  // the older wave's share of a SIMD's 11 tiles
 
 struct FusedLevels {
@@ -670,20 +668,42 @@ SVO_DEV LppGeom lpp_project(const double* T, const LeanCam& cam, const double4& 
   return g;
 }
 
+// which of a wave's TPW tiles keep their interpolated patches in LDS (CK of them) and which in memory, in the order
+// they are processed: alternating, LDS first, so that every tile read from memory has a predecessor whose computation
+// covers the latency of its prefetch
+template <int TPW, int CK>
+struct FusedPlan {
+  static constexpr bool in_lds(int p) {
+    int l = CK, g = TPW - CK;
+    bool last_l = false, pick_l = false;
+    for (int i = 0; i <= p; ++i) {
+      pick_l = l > 0 && (g == 0 || !last_l);
+      if (pick_l) --l; else --g;
+      last_l = pick_l;
+    }
+    return pick_l;
+  }
+  static constexpr int lds_slot(int p) {       // number of LDS tiles before position p
+    int c = 0;
+    for (int i = 0; i < p; ++i) c += in_lds(i) ? 1 : 0;
+    return c;
+  }
+};
+
 template <int TPW, int CK>
 __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
     const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
     const double* __restrict__ f, const double* __restrict__ pos, const uint8_t* __restrict__ has_point,
-    double4* __restrict__ sxyz, double* __restrict__ tile_h, int max_tiles, FusedParams prm, int tiles_young) {
-  constexpr int cached_tiles = CK;      // tiles per wave that keep interpolated patches instead of footprints
+    double4* __restrict__ sxyz, double* __restrict__ tile_h, float4* __restrict__ wmem, int max_tiles, FusedParams prm,
+    int tiles_young) {
+  using Plan = FusedPlan<TPW, CK>;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // LDS: [8 * cached_tiles][8][64] float4 of interpolated reference patches, then [slot][64][7] footprint rows.
-  // The first cached_tiles tiles of every wave keep the 32 interpolated values W of each patch (128 B) instead of its
-  // footprint (56 B): their evaluations skip the interpolation of the footprint (a third of the instructions of a
-  // tile).  The host fills the LDS that the footprints leave free with as many of them as fit.
+  // The interpolated reference patch of every feature -- the 32 values W from which reference value, dx and dy of its
+  // 16 pixels are differences (128 B, halved, see below) -- is formed once per level.  CK tiles of every wave keep
+  // theirs in LDS ([slot][8][64] float4, slot = position * 8 + wave), the others in memory ([frame][tile][8][64]
+  // float4, L2 / Infinity-Cache resident: 8 coalesced 1-KiB loads per tile and evaluation, issued one tile ahead).
   float4* wc = reinterpret_cast<float4*>(smem);
-  uint2* fp = reinterpret_cast<uint2*>(smem + (size_t)FUSED_WAVES * cached_tiles * FUSED_WC_BYTES);
   __shared__ double red[FUSED_WAVES][32];
   __shared__ double s_last[32], s_x[8];
   __shared__ double s_Hc[21], s_fac[36], s_inv[36];   // H of the previous evaluation, its LDL^T factor, H^-1 by columns
@@ -741,7 +761,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   // ---- lane-per-patch persistent state of the wave's tiles
   double4 X[TPW];
   double th[TPW];
-  float su[TPW], sv[TPW];
   uint8_t fl[TPW];
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
@@ -749,7 +768,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     const int i_own = tile * TILE + lane;
     X[k] = make_double4(0, 0, 1, 1);
     th[k] = 0.0;
-    su[k] = sv[k] = 0.0f; fl[k] = 0;
+    fl[k] = 0;
     if (tile < n_tiles && i_own < n) {
       const size_t fi = (size_t)b * max_n + i_own;
       const double dxp = pos[3 * fi] - c.ref_pos[0];
@@ -794,42 +813,38 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         valid = has_point[fo] && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= cols ||
                                    v_ref_i + border >= rows);
         if (valid) {
-          su[k] = u_ref - u_ref_i;                            // kept: the cached patch is defined by them
-          sv[k] = v_ref - v_ref_i;
+          const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
+          w_tl = (float)((1.0 - su) * (1.0 - sv));
+          w_tr = (float)(su * (1.0 - sv));
+          w_bl = (float)((1.0 - su) * sv);
+          w_br = su * sv;
           off = (v_ref_i - 3) * stride + (u_ref_i - 3);
         }
         // visible_fts_ is only ever set (:128); the Jacobian block is zero unless recomputed now (:76)
         fl[k] = valid ? (uint8_t)(F_VISIBLE | F_JVALID) : (uint8_t)(fl[k] & F_VISIBLE);
       }
-      w_tl = (float)((1.0 - su[k]) * (1.0 - sv[k]));
-      w_tr = (float)(su[k] * (1.0 - sv[k]));
-      w_bl = (float)((1.0 - su[k]) * sv[k]);
-      w_br = su[k] * sv[k];
       {
         const unsigned long long m = __ballot(valid);
         if (lane == 0 && m) atomicAdd(&s_npre, (unsigned)__popcll(m));
       }
       double sxx = 0.0, sxy = 0.0, syy = 0.0;
       {
-        // lane-per-patch: the lane reads its patch's 7 footprint rows, keeps them in LDS and sums the 16 pixels
+        // lane-per-patch: the lane reads its patch's 7 footprint rows, interpolates and sums the 16 pixels.  A patch
+        // that is not valid at this level keeps the values of the level before (the reference's stale cache row).
         if (valid) {
           uint2 F[7];
 #pragma unroll
           for (int j = 0; j < 7; ++j) F[j] = load_row8(ref_img + off + j * stride);
-          if (k >= cached_tiles) {
-            uint2* dst = fp + (size_t)(((k - cached_tiles) * FUSED_WAVES + wave) * TILE + lane) * 7;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) dst[j] = F[j];
-          }
           float W[6][6];
 #pragma unroll
           for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int c2 = 0; c2 < 6; ++c2)
               W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : interp_at(F[j], F[j + 1], c2, w_tl, w_tr, w_bl, w_br);
-          if (k < cached_tiles) {
+          {
             // halved (exact), in the order the evaluation reads them: rows 0 and 5 without their corners
-            float4* dst = wc + (size_t)((k * FUSED_WAVES + wave) * 8) * TILE + lane;
+            float4* dst = Plan::in_lds(k) ? wc + (size_t)((Plan::lds_slot(k) * FUSED_WAVES + wave) * 8) * TILE + lane
+                                          : wmem + ((size_t)b * max_tiles + tile) * 8 * TILE + lane;
             float q[32];
             int e = 0;
 #pragma unroll
@@ -892,16 +907,48 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       double accJ[6] = {0, 0, 0, 0, 0, 0};
       double acc_chi = 0.0;
       unsigned acc_n = 0;
+      // Software pipeline over the wave's tiles: while tile k is computed, the projection of tile k+1 is done, its five
+      // current-image rows are on their way (L1 / L2) and so are its interpolated patches if they live in memory.
+      // Loads return in order and nothing here is conditional, so the compiler's wait for tile k's rows leaves exactly
+      // the next tile's loads in flight.  (A tile that does not exist projects nothing: its rows are read from offset
+      // 0 of the image and its patches from this tile's address range, both always allocated.)
+      float4 Wn[8];                                           // patches of the next tile, on their way from memory
+      LppGeom gq[2];
+      uint2 Crq[2][5];
+      gq[0] = lpp_project(T, cam, X[0], (fl[0] & F_VISIBLE) != 0, scale, cols, rows, stride);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) Crq[0][j] = load_row8(cur_img + gq[0].off + j * stride);
 #pragma unroll
       for (int k = 0; k < TPW; ++k) {
         const int tile = tile_of(k);
         // the younger wave of a SIMD is favoured by the arbiter during its first tiles (see tile_of)
         if (wave >= 4) { if (k < favoured_tiles) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 
-        if (tile >= n_tiles) continue;                       // wave-uniform
+        // this tile's interpolated patches: from LDS, or what was asked for while the previous tile was computed
+        float4 Wq[8];
+        if (Plan::in_lds(k)) {
+          const float4* src = wc + (size_t)((Plan::lds_slot(k) * FUSED_WAVES + wave) * 8) * TILE + lane;
+#pragma unroll
+          for (int c4 = 0; c4 < 8; ++c4) Wq[c4] = src[c4 * TILE];
+        } else {
+#pragma unroll
+          for (int c4 = 0; c4 < 8; ++c4) Wq[c4] = Wn[c4];
+        }
+        if (k + 1 < TPW) {
+          gq[(k + 1) & 1] = lpp_project(T, cam, X[k + 1], (fl[k + 1] & F_VISIBLE) != 0, scale, cols, rows, stride);
+#pragma unroll
+          for (int j = 0; j < 5; ++j) Crq[(k + 1) & 1][j] = load_row8(cur_img + gq[(k + 1) & 1].off + j * stride);
+          if (!Plan::in_lds(k + 1)) {
+            const int tile_n = tile_of(k + 1) < n_tiles ? tile_of(k + 1) : (tile < n_tiles ? tile : 0);
+            const float4* src = wmem + ((size_t)b * max_tiles + tile_n) * 8 * TILE + lane;
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4) Wn[c4] = src[c4 * TILE];
+          }
+        }
+        if (tile >= n_tiles) continue;                       // wave-uniform: the tiles that follow do not exist either
         const int tile_base = tile * TILE;
-        // ---- projection into the current image (:220-236)
-        const LppGeom g = lpp_project(T, cam, X[k], (fl[k] & F_VISIBLE) != 0, scale, cols, rows, stride);
+        // ---- projection into the current image (:220-236): done one tile ahead
+        const LppGeom g = gq[k & 1];
         const bool ok = g.ok;
         const bool jvalid = (fl[k] & F_JVALID) != 0;
         // All interpolation weights of the evaluation are HALVED: a power-of-two scale commutes with every rounding, so
@@ -911,42 +958,25 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         // reduction (exact).
 
         // ---- residuals (:238-279): the lane walks the 16 pixels of its own patch; no cross-lane traffic at all.
-        // 32 interpolations of the reference footprint give ref value / dx / dy of every pixel.
+        // ref value / dx / dy of every pixel are differences of the 32 interpolated values formed once per level.
         double sdx = 0.0, sdy = 0.0;
         float chi = 0.0f;
         {
-          uint2 Cr[5], F[7];
+          uint2 Cr[5];
 #pragma unroll
-          for (int j = 0; j < 5; ++j) Cr[j] = load_row8(cur_img + g.off + j * stride);   // off == 0 when !ok: valid memory
+          for (int j = 0; j < 5; ++j) Cr[j] = Crq[k & 1][j];
           float W[6][6];
-          if (k < cached_tiles) {                              // compile-time
-            const float4* src = wc + (size_t)((k * FUSED_WAVES + wave) * 8) * TILE + lane;
-            float q[32];
-#pragma unroll
-            for (int c4 = 0; c4 < 8; ++c4) {
-              const float4 t4 = src[c4 * TILE];
-              q[4 * c4] = t4.x; q[4 * c4 + 1] = t4.y; q[4 * c4 + 2] = t4.z; q[4 * c4 + 3] = t4.w;
-            }
+          {
             int e = 0;
 #pragma unroll
             for (int j = 0; j < 6; ++j)
 #pragma unroll
-              for (int c2 = 0; c2 < 6; ++c2)
-                W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : q[e++];
-          } else {
-            const uint2* src = fp + (size_t)(((k - cached_tiles) * FUSED_WAVES + wave) * TILE + lane) * 7;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) F[j] = src[j];
-            // weights of the cached reference patch (recomputed from the kept sub-pixel offsets), halved
-            const float rw_tl = 0.5f * (float)((1.0 - su[k]) * (1.0 - sv[k]));
-            const float rw_tr = 0.5f * (float)(su[k] * (1.0 - sv[k]));
-            const float rw_bl = 0.5f * (float)((1.0 - su[k]) * sv[k]);
-            const float rw_br = 0.5f * (su[k] * sv[k]);
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-              for (int c2 = 0; c2 < 6; ++c2)
-                W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : interp_at(F[j], F[j + 1], c2, rw_tl, rw_tr, rw_bl, rw_br);
+              for (int c2 = 0; c2 < 6; ++c2) {
+                if ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) { W[j][c2] = 0.0f; continue; }
+                const float4 t4 = Wq[e >> 2];
+                W[j][c2] = (e & 3) == 0 ? t4.x : (e & 3) == 1 ? t4.y : (e & 3) == 2 ? t4.z : t4.w;
+                ++e;
+              }
           }
 #pragma unroll
           for (int y = 0; y < 4; ++y)
@@ -1223,6 +1253,7 @@ struct svo_hip_sia {
   float4 *ref_cache = nullptr, *dxc = nullptr, *dyc = nullptr;   // [batch][max_n][4 rows] x float4
   double4 *sxyz = nullptr, *xyz4 = nullptr;                      // {sxx,sxy,syy,-}, {x,y,z,1/z} per patch
   double* tile_h = nullptr;                                      // [batch][max_tiles][TILE_ROW]
+  float4* wmem = nullptr;                                        // fused kernel: [batch][max_tiles][8][TILE] interpolated patches
   int max_tiles = 0;
   double* partial = nullptr;
   double* reduce_own = nullptr;
@@ -1310,7 +1341,7 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   svo_hip_ctx* ctx = s->ctx;
   // > 64 KiB of dynamic LDS has to be allowed explicitly (per device: set it on every launch, it is cheap)
   SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<TPW, CK>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BUDGET));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FUSED_WAVES * FUSED_WC_BYTES));
   FusedLevels lv;
   memset(&lv, 0, sizeof(lv));
   for (int l = 0; l < s->ref->n_levels; ++l) {
@@ -1324,7 +1355,7 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
   hipLaunchKernelGGL((sia_fused_kernel<TPW, CK>), dim3(n_slots), dim3(FUSED_THREADS), lds_bytes, ctx->stream, s->fc, s->st,
                      s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, s->tile_h,
-                     s->max_tiles, fp, tiles_young);
+                     s->wmem, s->max_tiles, fp, tiles_young);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
@@ -1345,26 +1376,18 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tp
   const int tiles = max_n > 0 ? (max_n + TILE - 1) / TILE : 1;
   const int ty = (tiles + 3) / 4 - tpw;      // the younger wave's share of a SIMD's tiles
   SVO_REQUIRE(ctx, ty >= 0 && ty <= tpw);
-  // LDS plan: every wave keeps interpolated patches for its first ck tiles and footprints for the others; the
-  // footprint slot of (wave, k) is (k - ck) * 8 + wave, and the last k only exists on the four older waves when the
-  // younger ones own one tile less.  The largest ck that fits next to the kernel's static LDS wins.
-  auto fp_slots = [&](int c) { return c >= tpw ? 0 : (tpw - 1 - c) * FUSED_WAVES + (ty >= tpw ? FUSED_WAVES : 4); };
-  auto lds_need = [&](int c) { return (size_t)FUSED_WAVES * c * FUSED_WC_BYTES + (size_t)fp_slots(c) * FUSED_FP_BYTES; };
-  int ck = 0;
-  while (ck < tpw && lds_need(ck + 1) <= FUSED_LDS_BUDGET) ++ck;
-  const size_t lds = lds_need(ck);
-  SVO_REQUIRE(ctx, lds <= FUSED_LDS_BUDGET);
+  // two tiles per wave keep their interpolated patches in LDS (8 waves x 2 x 8 KiB), the others in memory
+  const int ck = tpw < 2 ? tpw : 2;
+  const size_t lds = (size_t)FUSED_WAVES * ck * FUSED_WC_BYTES;
   s->begun = false;
   s->last_mode = 1;
-  // (tiles of an older wave, cached tiles per wave): the pairs the plan above can produce for 1..44 tiles
-  switch (tpw * 10 + ck) {
-    case 11: return launch_fused_t<1, 1>(s, n_slots, prm, lds, ty);
-    case 22: return launch_fused_t<2, 2>(s, n_slots, prm, lds, ty);
-    case 32: return launch_fused_t<3, 2>(s, n_slots, prm, lds, ty);
-    case 31: return launch_fused_t<3, 1>(s, n_slots, prm, lds, ty);
-    case 41: return launch_fused_t<4, 1>(s, n_slots, prm, lds, ty);
-    case 50: return launch_fused_t<5, 0>(s, n_slots, prm, lds, ty);
-    case 60: return launch_fused_t<6, 0>(s, n_slots, prm, lds, ty);
+  switch (tpw) {                 // tiles of an older wave
+    case 1: return launch_fused_t<1, 1>(s, n_slots, prm, lds, ty);
+    case 2: return launch_fused_t<2, 2>(s, n_slots, prm, lds, ty);
+    case 3: return launch_fused_t<3, 2>(s, n_slots, prm, lds, ty);
+    case 4: return launch_fused_t<4, 2>(s, n_slots, prm, lds, ty);
+    case 5: return launch_fused_t<5, 2>(s, n_slots, prm, lds, ty);
+    case 6: return launch_fused_t<6, 2>(s, n_slots, prm, lds, ty);
     default: break;
   }
   return svo_fail(ctx, SVO_HIP_ERR_INVALID, "fused SparseImgAlign", "unsupported tiles-per-wave");
@@ -1391,6 +1414,7 @@ int svo_hip_sia_create(svo_hip_ctx* ctx, int batch, int max_features, svo_hip_si
   A(dev_alloc(ctx, &s->ref_cache, bn * 4 + 256)); A(dev_alloc(ctx, &s->dxc, bn * 4 + 256)); A(dev_alloc(ctx, &s->dyc, bn * 4 + 256));
   A(dev_alloc(ctx, &s->sxyz, bn + 64)); A(dev_alloc(ctx, &s->xyz4, bn + 64));
   A(dev_alloc(ctx, &s->tile_h, (size_t)batch * s->max_tiles * TILE_ROW));
+  A(dev_alloc(ctx, &s->wmem, (size_t)batch * s->max_tiles * 8 * TILE));
   A(dev_alloc(ctx, &s->partial, (size_t)batch * MAX_CHUNKS * RED));
   A(dev_alloc(ctx, &s->reduce_own, (size_t)batch * RED));
   A(dev_alloc(ctx, &s->n_pre_count, batch));
@@ -1414,7 +1438,7 @@ int svo_hip_sia_destroy(svo_hip_sia* s) {
   svo_hip_ctx* ctx = s->ctx;
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {s->fc, s->st, s->px, s->f, s->pos, s->has_point, s->visible, s->ref_cache, s->dxc, s->dyc,
-                  s->sxyz, s->xyz4, s->tile_h, s->partial, s->reduce_own, s->n_pre_count};
+                  s->sxyz, s->xyz4, s->tile_h, s->wmem, s->partial, s->reduce_own, s->n_pre_count};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev_res) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_pre) (void)hipEventDestroy(e);
