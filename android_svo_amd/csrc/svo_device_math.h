@@ -143,6 +143,65 @@ SVO_DEV void se3_exp(const double* l, double* out) {
   out[6] = real_factor;
 }
 
+// se3_exp for the Gauss-Newton updates of the fused SparseImgAlign kernel (one lane, every other wave of the
+// workgroup waiting for it): the same four series as sincos_small, but the quotients of I/SE3.h:153-182 are taken
+// from the series themselves -- sin(h)/theta = ps_h / 2, (1 - cos t)/t^2 = pc_t / 2, (t - sin t)/t^3 = (inner
+// sine series)/6 -- so there is no square root and no division on the critical path, and none of the cancellation
+// the quotient forms have at small angles.  theta == 0 keeps the reference's NaN translation; angles above 0.5 rad
+// take se3_exp.
+SVO_DEV void se3_exp_small(const double* l, double* out) {
+  const double p[3] = {l[0], l[1], l[2]};
+  const double r[3] = {l[3], l[4], l[5]};
+  const double zt = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];      // theta^2
+  if (!(zt <= 0.25)) { se3_exp(l, out); return; }
+  const double zh = 0.25 * zt;                                    // (theta/2)^2
+  // sin x = x ps(z), ps = 1 - z/6 qs, qs = 1 - z/20 (1 - z/42 (...));  cos x = 1 - z/2 pc(z)
+  double qs_t = 1.0 - zt * (1.0 / 272.0);
+  qs_t = 1.0 - zt * (1.0 / 210.0) * qs_t;
+  qs_t = 1.0 - zt * (1.0 / 156.0) * qs_t;
+  qs_t = 1.0 - zt * (1.0 / 110.0) * qs_t;
+  qs_t = 1.0 - zt * (1.0 / 72.0) * qs_t;
+  qs_t = 1.0 - zt * (1.0 / 42.0) * qs_t;
+  qs_t = 1.0 - zt * (1.0 / 20.0) * qs_t;
+  double pc_t = 1.0 - zt * (1.0 / 240.0);
+  pc_t = 1.0 - zt * (1.0 / 182.0) * pc_t;
+  pc_t = 1.0 - zt * (1.0 / 132.0) * pc_t;
+  pc_t = 1.0 - zt * (1.0 / 90.0) * pc_t;
+  pc_t = 1.0 - zt * (1.0 / 56.0) * pc_t;
+  pc_t = 1.0 - zt * (1.0 / 30.0) * pc_t;
+  pc_t = 1.0 - zt * (1.0 / 12.0) * pc_t;
+  double ps_h = 1.0 - zh * (1.0 / 272.0);
+  ps_h = 1.0 - zh * (1.0 / 210.0) * ps_h;
+  ps_h = 1.0 - zh * (1.0 / 156.0) * ps_h;
+  ps_h = 1.0 - zh * (1.0 / 110.0) * ps_h;
+  ps_h = 1.0 - zh * (1.0 / 72.0) * ps_h;
+  ps_h = 1.0 - zh * (1.0 / 42.0) * ps_h;
+  ps_h = 1.0 - zh * (1.0 / 20.0) * ps_h;
+  ps_h = 1.0 - zh * (1.0 / 6.0) * ps_h;
+  double pc_h = 1.0 - zh * (1.0 / 240.0);
+  pc_h = 1.0 - zh * (1.0 / 182.0) * pc_h;
+  pc_h = 1.0 - zh * (1.0 / 132.0) * pc_h;
+  pc_h = 1.0 - zh * (1.0 / 90.0) * pc_h;
+  pc_h = 1.0 - zh * (1.0 / 56.0) * pc_h;
+  pc_h = 1.0 - zh * (1.0 / 30.0) * pc_h;
+  pc_h = 1.0 - zh * (1.0 / 12.0) * pc_h;
+  const double imag_factor = 0.5 * ps_h;                          // sin(theta/2) / theta
+  const double real_factor = 1.0 - zh * 0.5 * pc_h;               // cos(theta/2)
+  double c1 = 0.5 * pc_t;                                         // (1 - cos theta) / theta^2
+  double c2 = (1.0 / 6.0) * qs_t;                                 // (theta - sin theta) / theta^3
+  if (zt == 0.0) { c1 = __longlong_as_double(0x7ff8000000000000LL); c2 = c1; }   // 0/0 of the reference's quotients
+  double rxp[3], rxrxp[3];
+  cross3(r, p, rxp);
+  cross3(r, rxp, rxrxp);
+  out[0] = (p[0] + c1 * rxp[0]) + c2 * rxrxp[0];
+  out[1] = (p[1] + c1 * rxp[1]) + c2 * rxrxp[1];
+  out[2] = (p[2] + c1 * rxp[2]) + c2 * rxrxp[2];
+  out[3] = imag_factor * r[0];
+  out[4] = imag_factor * r[1];
+  out[5] = imag_factor * r[2];
+  out[6] = real_factor;
+}
+
 // row-major 3x3 (I/SO3.h:391-406)
 SVO_DEV void se3_rotation_matrix(const double* T, double* m) {
   double x = T[3], y = T[4], z = T[5], w = T[6];

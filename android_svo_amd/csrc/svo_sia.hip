@@ -712,7 +712,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   __shared__ double s_chi2;
   __shared__ int s_done, s_stop, s_iter;
   __shared__ unsigned s_npre;
-  __shared__ unsigned long long s_nres, s_nmeas;
+  __shared__ double s_nres, s_nmeas;             // exact integer counts, carried as doubles
   __shared__ int s_iters[SVO_HIP_MAX_LEVELS];
 #ifdef SVO_STAMPS
   __shared__ long long s_stamp[10];
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         for (int i = 0; i < 7; ++i) cur[i] = s_model[i];
         const double chi2_old = s_chi2;
         const int it = s_iter, stop_old = s_stop, iters_l = s_iters[level];
-        const unsigned long long nres_old = s_nres;
+        const double nres_old = s_nres;
         double v = 0.0;
         if (lane < 32) {
 #pragma unroll
@@ -1162,10 +1162,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
 #endif
         if (lane == 0) {
           // solve()/update() of S/sparse_img_align.cpp:291-308 inside the loop of I/nlls_solver_impl.hpp:35-99
-          const unsigned long long n_meas = (unsigned long long)(n_meas_d + 0.5);
-          const double new_chi2 = (double)((float)chi2_sum / (float)n_meas);     // (:285)
-          s_nmeas = n_meas;
-          s_nres = nres_old + n_meas / 16;
+          // the counts are exact integers (multiples of 16) carried as doubles: no 64-bit integer conversions here
+          const double new_chi2 = (double)((float)chi2_sum / (float)n_meas_d);   // (:285)
+          s_nmeas = n_meas_d;
+          s_nres = nres_old + n_meas_d * 0.0625;
           s_iters[level] = iters_l + 1;
 #pragma unroll
           for (int i = 0; i < 6; ++i) s_x[i] = x[i];
@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
             const long long q2 = __builtin_amdgcn_s_memtime();
             s_stamp[6] += q2 - q1;
 #endif
-            se3_exp(mx, dT);
+            se3_exp_small(mx, dT);
             se3_mul(cur, dT, nm);                                                // T_new = T_old * exp(-x) (:307)
 #ifdef SVO_STAMPS
             const long long q3 = __builtin_amdgcn_s_memtime();
@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
     se3_mul(m, c.T_ref_w, T);                                                    // :89
     for (int i = 0; i < 7; ++i) s.T_cur_w[i] = empty ? c.T_cur_w_init[i] : T[i];
     s.chi2 = s_chi2; s.stop = s_stop; s.iter = s_iter; s.level_done = 1; s.empty = empty;
-    s.n_meas = s_nmeas; s.n_res = s_nres; s.n_pre = s_npre;
+    s.n_meas = (unsigned long long)(s_nmeas + 0.5); s.n_res = (unsigned long long)(s_nres + 0.5); s.n_pre = s_npre;
     {
       int kk = 0;
       for (int i = 0; i < 6; ++i)
