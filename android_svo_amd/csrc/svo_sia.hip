@@ -6,7 +6,7 @@
 //
 // Two implementations of svo_hip_sia_run with the same semantics:
 //   (F) the fused kernel (second half of this file, the default): one workgroup per frame pair runs the whole
-//       coarse-to-fine solve in one launch with the reference footprints in LDS;
+//       coarse-to-fine solve in one launch with the interpolated reference patches in LDS / L2-resident memory;
 //   (S) the streaming kernels described next: one launch per Gauss-Newton evaluation; used by the step-wise entry
 //       points (multi-GPU all-reduce of the normal equations) and for frames with more than 2816 features.
 //
@@ -580,20 +580,21 @@ __global__ void sia_finish_kernel(const FrameConst* __restrict__ fc, FrameState*
 
 // =================================================================================================
 // Fused path: the whole coarse-to-fine solve of one frame pair in ONE workgroup (512 threads, one CU),
-// one launch per run.  Nothing is streamed from HBM between Gauss-Newton evaluations:
-//   * the 7x8-byte reference footprint of every patch lives in LDS (56 B/patch, <= 2816 patches in
-//     160 KiB); ref value / dx / dy are recomputed from it (bit-identical to the cached form);
-//   * {x,y,z,1/z}, the reference sub-pixel offsets, the flags and the wave's tile-H entries stay in
-//     VGPRs (lane-per-patch; a wave owns tiles wave, wave+8, wave+16, ...); {sxx,sxy,syy} go to HBM once
-//     per level and are only re-read for the rare patch that leaves the image;
-//   * a lane owns one patch of a tile and walks its 16 pixels itself -- 32 interpolations of the footprint give
-//     ref/dx/dy of all pixels, no cross-lane traffic inside a tile;
-//   * 8 waves (2 per SIMD, 256 VGPRs per lane) measured fastest: 16 waves (128 VGPRs) spill around the solve and
-//     pay twice the wave reductions (77 k frames/s against 98 k), 12 waves 85 k, 4 waves 68 k.  Packed f32
-//     (v_pk_mul_f32 / v_pk_add_f32 over two patches per lane) was measured too: CDNA4's SIMD already issues a
-//     plain wave64 f32 op in 2 cycles, the packed forms take two passes, and the kernel ran 18 % slower;
-//   * the Gauss-Newton state lives in LDS; the solve runs on one lane between two barriers;
-//   * only the current image is read from memory (five 8-byte rows per patch and evaluation, L2/MALL).
+// one launch per run.
+//   * a wave owns tiles of 64 patches, a lane one patch of a tile; the lane walks the 16 pixels itself, so there is no
+//     cross-lane traffic inside a tile;
+//   * per level a lane interpolates its patch once: the 32 values W whose differences are reference value, dx and dy
+//     of the 16 pixels (bit-identical to the reference's cache).  W (128 B per patch) stays in LDS for two tiles of
+//     every wave and in L2 / Infinity-Cache resident memory for the others; {x,y,z,1/z}, the flags and the wave's
+//     tile-H entries stay in VGPRs; {sxx,sxy,syy} go to memory once per level and are only re-read when the set of
+//     patches outside the current image changes;
+//   * the loop over a wave's tiles is software-pipelined by one tile (projection, image rows, W from memory);
+//   * 8 waves (2 per SIMD, 256 VGPRs per lane) measured fastest: 16 waves (128 VGPRs) 77 k frames/s against 98 k at the
+//     time, 12 waves 85 k, 4 waves 68 k.  Packed f32 (v_pk_mul_f32 / v_pk_add_f32) was measured too: CDNA4's SIMD
+//     already issues a plain wave64 f32 op in 2 cycles, the packed forms take two passes (18 % slower);
+//   * the two waves of a SIMD are balanced with s_setprio (see tile_of in the kernel);
+//   * the Gauss-Newton state lives in LDS; the solve runs between two barriers: H^-1 by columns on six lanes when H
+//     changed, a 6x6 matrix-vector product otherwise, SE3::exp and the pose product on one lane.
 // Data-dependent exits are real `break`s here, so a converged frame costs nothing further.
 // Semantics are those of the streaming kernels above (same 64-patch tiles, lane-ordered sums per wave,
 // then a fixed-order sum over the waves).

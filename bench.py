@@ -243,8 +243,10 @@ def main():
                 # fused: ONE launch runs the whole coarse-to-fine solve of every frame pair of this rank
                 kernel = "sia_fused_kernel"
                 alg_bytes = float(bytes_frame) * n_slots
-                note = ("one launch = whole solve of %d frame pairs; reference footprints stay in LDS, so the HBM "
-                        "stream the algorithmic bytes describe does not exist: the kernel is VALU-issue bound" % n_slots)
+                note = ("one launch = whole solve of %d frame pairs; the interpolated reference patches (128 B/patch "
+                        "instead of the reference layout's 881 B) stay in LDS for two tiles per wave and are streamed "
+                        "from L2 / Infinity Cache for the others, so most of the algorithmic bytes are never moved: "
+                        "the kernel is bound by VALU issue plus a serial solve phase" % n_slots)
             else:
                 # streaming: one launch evaluates every live patch of every frame of this rank once
                 kernel = "sia_residual_kernel"
