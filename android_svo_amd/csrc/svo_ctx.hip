@@ -62,6 +62,7 @@ int svo_hip_ctx_create(svo_hip_ctx** out, int device, void* stream) {
   if (!c) return SVO_HIP_ERR_NOMEM;
   c->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete c; return SVO_HIP_ERR_DEVICE; }
+  if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu <= 0) c->n_cu = 256;
   if (stream) {
     c->stream = (hipStream_t)stream;
     c->own_stream = false;

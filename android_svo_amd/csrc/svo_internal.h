@@ -11,6 +11,7 @@
 
 struct svo_hip_ctx {
   int device = 0;
+  int n_cu = 0;                     // compute units of the device
   hipStream_t stream = nullptr;
   bool own_stream = false;
   void* scratch = nullptr;          // grow-only device workspace (depth-filter stage records)

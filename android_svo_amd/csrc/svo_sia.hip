@@ -691,8 +691,12 @@ struct FusedPlan {
   }
 };
 
-template <int TPW, int CK>
-__global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
+// NW = 8: one workgroup (one frame pair) per CU, two waves of it on every SIMD.  NW = 4: one wave per SIMD and 256
+// VGPRs, so that TWO workgroups -- two independent frame pairs -- share a CU: while one of them is in the one-lane
+// phase between its barriers the other one has the SIMDs to itself (used when a launch holds at least two pairs per
+// CU).  Per-tile H rows then live in LDS instead of VGPRs (a wave owns twice as many tiles).
+template <int NW, int TPW, int CK>
+__global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
     const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
     const double* __restrict__ f, const double* __restrict__ pos, const uint8_t* __restrict__ has_point,
@@ -705,7 +709,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   // theirs in LDS ([slot][8][64] float4, slot = position * 8 + wave), the others in memory ([frame][tile][8][64]
   // float4, L2 / Infinity-Cache resident: 8 coalesced 1-KiB loads per tile and evaluation, issued one tile ahead).
   float4* wc = reinterpret_cast<float4*>(smem);
-  __shared__ double red[FUSED_WAVES][32];
+  __shared__ double red[NW][32];
+  __shared__ double s_th[NW == 4 ? NW * TPW * 21 : 1];        // NW = 4: per-tile H rows (lane e keeps entry e)
   __shared__ double s_last[32], s_x[8];
   __shared__ double s_Hc[21], s_fac[36], s_inv[36];   // H of the previous evaluation, its LDL^T factor, H^-1 by columns
   __shared__ int s_ftr[6], s_fac_valid;
@@ -741,10 +746,20 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
   // wave raises its priority (s_setprio), so that each wave is the favoured one for about half of the evaluation and both
   // reach the barrier together (measured per-wave cycles per evaluation: 15.0 k / 21.5 k before, 18.2 k / 19.7 k after).
   const int simd = wave & 3;
-  const int my_tiles = wave < 4 ? TPW : tiles_young;                    // wave-uniform
-  const int first_j = wave < 4 ? 0 : TPW;
+  const int my_tiles = (NW == 4 || wave < 4) ? TPW : tiles_young;       // wave-uniform
+  const int first_j = (NW == 4 || wave < 4) ? 0 : TPW;
   const int favoured_tiles = (5 * my_tiles + 4) / 8;                    // 3 of 4 measured best (2 of 4: -0.8 %)
   auto tile_of = [&](int k) -> int { return k < my_tiles ? simd + 4 * (first_j + k) : n_tiles; };
+  // per-tile H row of this wave: VGPRs (NW = 8) or LDS (NW = 4)
+  double th_reg[NW == 4 ? 1 : TPW];
+  auto th_get = [&](int k) -> double {
+    if (NW == 4) return lane < 21 ? s_th[(wave * TPW + k) * 21 + lane] : 0.0;
+    return th_reg[NW == 4 ? 0 : k];
+  };
+  auto th_set = [&](int k, double v) {
+    if (NW == 4) { if (lane < 21) s_th[(wave * TPW + k) * 21 + lane] = v; }
+    else th_reg[NW == 4 ? 0 : k] = v;
+  };
 
   if (lane >= 29 && lane < 32) red[wave][lane] = 0.0;       // unused slots of the wave partial rows
   if (threadIdx.x == 0) {
@@ -761,14 +776,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
 
   // ---- lane-per-patch persistent state of the wave's tiles
   double4 X[TPW];
-  double th[TPW];
   uint8_t fl[TPW];
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
     const int tile = tile_of(k);
     const int i_own = tile * TILE + lane;
     X[k] = make_double4(0, 0, 1, 1);
-    th[k] = 0.0;
+    th_set(k, 0.0);
     fl[k] = 0;
     if (tile < n_tiles && i_own < n) {
       const size_t fi = (size_t)b * max_n + i_own;
@@ -844,7 +858,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
               W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : interp_at(F[j], F[j + 1], c2, w_tl, w_tr, w_bl, w_br);
           {
             // halved (exact), in the order the evaluation reads them: rows 0 and 5 without their corners
-            float4* dst = Plan::in_lds(k) ? wc + (size_t)((Plan::lds_slot(k) * FUSED_WAVES + wave) * 8) * TILE + lane
+            float4* dst = Plan::in_lds(k) ? wc + (size_t)((Plan::lds_slot(k) * NW + wave) * 8) * TILE + lane
                                           : wmem + ((size_t)b * max_tiles + tile) * 8 * TILE + lane;
             float q[32];
             int e = 0;
@@ -884,7 +898,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
             if (lane == e) mine = t;
             ++e;
           }
-        th[k] = mine;
+        th_set(k, mine);
         // the untouched row goes to memory: it is only needed again when the set of patches outside the image changes
         if (lane < 21) tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane] = mine;
       }
@@ -923,12 +937,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
       for (int k = 0; k < TPW; ++k) {
         const int tile = tile_of(k);
         // the younger wave of a SIMD is favoured by the arbiter during its first tiles (see tile_of)
-        if (wave >= 4) { if (k < favoured_tiles) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        if (NW == 8 && wave >= 4) { if (k < favoured_tiles) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 
         // this tile's interpolated patches: from LDS, or what was asked for while the previous tile was computed
         float4 Wq[8];
         if (Plan::in_lds(k)) {
-          const float4* src = wc + (size_t)((Plan::lds_slot(k) * FUSED_WAVES + wave) * 8) * TILE + lane;
+          const float4* src = wc + (size_t)((Plan::lds_slot(k) * NW + wave) * 8) * TILE + lane;
 #pragma unroll
           for (int c4 = 0; c4 < 8; ++c4) Wq[c4] = src[c4 * TILE];
         } else {
@@ -1041,10 +1055,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
             const double h = g_xx * (Ai * Aj) + g_xy * (Ai * Bj + Bi * Aj) + g_yy * (Bi * Bj);
             t -= h;
           }
-          th[k] = t;
+          th_set(k, t);
           fl[k] = (uint8_t)((fl[k] & ~F_GONE) | (out_now ? F_GONE : 0));
         }
-        if (lane < 21) accH += th[k];
+        { const double thk = th_get(k); if (lane < 21) accH += thk; }
       }
 
       __builtin_amdgcn_s_setprio(0);
@@ -1082,7 +1096,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void sia_fused_kernel(
         double v = 0.0;
         if (lane < 32) {
 #pragma unroll
-          for (int w = 0; w < FUSED_WAVES; ++w) v += red[w][lane];
+          for (int w = 0; w < NW; ++w) v += red[w][lane];
           s_last[lane] = v;                  // H_ / Jres_ of the last evaluation, reported at the end
         }
         // H is the sum of the per-level tile rows minus the patches outside the image at this evaluation: as long as
@@ -1337,12 +1351,12 @@ int fused_tiles_per_wave(const svo_hip_sia* s, int n_slots) {
   return old_share < 1 ? 1 : old_share;
 }
 
-template <int TPW, int CK>
+template <int NW, int TPW, int CK>
 int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes, int tiles_young) {
   svo_hip_ctx* ctx = s->ctx;
   // > 64 KiB of dynamic LDS has to be allowed explicitly (per device: set it on every launch, it is cheap)
-  SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<TPW, CK>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FUSED_WAVES * FUSED_WC_BYTES));
+  SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<NW, TPW, CK>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NW * FUSED_WC_BYTES));
   FusedLevels lv;
   memset(&lv, 0, sizeof(lv));
   for (int l = 0; l < s->ref->n_levels; ++l) {
@@ -1354,7 +1368,7 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   fp.early_stop = prm->early_stop; fp.eps = prm->eps;
   hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
-  hipLaunchKernelGGL((sia_fused_kernel<TPW, CK>), dim3(n_slots), dim3(FUSED_THREADS), lds_bytes, ctx->stream, s->fc, s->st,
+  hipLaunchKernelGGL((sia_fused_kernel<NW, TPW, CK>), dim3(n_slots), dim3(NW * 64), lds_bytes, ctx->stream, s->fc, s->st,
                      s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, s->tile_h,
                      s->wmem, s->max_tiles, fp, tiles_young);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
@@ -1375,20 +1389,38 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tp
   int max_n = 0;
   for (int i = 0; i < n_slots; ++i) max_n = s->h_fc[i].n_feat > max_n ? s->h_fc[i].n_feat : max_n;
   const int tiles = max_n > 0 ? (max_n + TILE - 1) / TILE : 1;
-  const int ty = (tiles + 3) / 4 - tpw;      // the younger wave's share of a SIMD's tiles
+  s->begun = false;
+  s->last_mode = 1;
+  // Two frame pairs per CU (4-wave workgroups) when the launch has at least two pairs for every CU and a wave can hold
+  // a quarter of the tiles: the one-lane solve phase of one pair then overlaps the evaluation of the other.
+  const char* wv = getenv("SVO_HIP_SIA_WAVES");                        // diagnostic override: 4 or 8
+  const int per_simd = (tiles + 3) / 4;
+  // (measured with 512 pairs per launch: 200 patches 715 k against 444 k frames/s, 500: 549 k / 393 k, 1000: 314 k /
+  // 277 k; at 2000 patches a wave would own 8 tiles and their {x,y,z,1/z} no longer fit in 256 VGPRs: 97 k / 163 k)
+  bool four = n_slots >= 2 * ctx->n_cu && per_simd <= 4;
+  if (wv) four = atoi(wv) == 4 && per_simd <= 4;
+  if (four) {
+    const size_t lds4 = (size_t)4 * (per_simd < 2 ? 1 : 2) * FUSED_WC_BYTES;
+    switch (per_simd) {                                                // tiles per wave (3 runs as 4 with an empty slot)
+      case 1: return launch_fused_t<4, 1, 1>(s, n_slots, prm, lds4, 0);
+      case 2: return launch_fused_t<4, 2, 2>(s, n_slots, prm, lds4, 0);
+      case 3:
+      case 4: return launch_fused_t<4, 4, 2>(s, n_slots, prm, lds4, 0);
+      default: break;
+    }
+  }
+  const int ty = per_simd - tpw;             // the younger wave's share of a SIMD's tiles
   SVO_REQUIRE(ctx, ty >= 0 && ty <= tpw);
   // two tiles per wave keep their interpolated patches in LDS (8 waves x 2 x 8 KiB), the others in memory
   const int ck = tpw < 2 ? tpw : 2;
   const size_t lds = (size_t)FUSED_WAVES * ck * FUSED_WC_BYTES;
-  s->begun = false;
-  s->last_mode = 1;
   switch (tpw) {                 // tiles of an older wave
-    case 1: return launch_fused_t<1, 1>(s, n_slots, prm, lds, ty);
-    case 2: return launch_fused_t<2, 2>(s, n_slots, prm, lds, ty);
-    case 3: return launch_fused_t<3, 2>(s, n_slots, prm, lds, ty);
-    case 4: return launch_fused_t<4, 2>(s, n_slots, prm, lds, ty);
-    case 5: return launch_fused_t<5, 2>(s, n_slots, prm, lds, ty);
-    case 6: return launch_fused_t<6, 2>(s, n_slots, prm, lds, ty);
+    case 1: return launch_fused_t<8, 1, 1>(s, n_slots, prm, lds, ty);
+    case 2: return launch_fused_t<8, 2, 2>(s, n_slots, prm, lds, ty);
+    case 3: return launch_fused_t<8, 3, 2>(s, n_slots, prm, lds, ty);
+    case 4: return launch_fused_t<8, 4, 2>(s, n_slots, prm, lds, ty);
+    case 5: return launch_fused_t<8, 5, 2>(s, n_slots, prm, lds, ty);
+    case 6: return launch_fused_t<8, 6, 2>(s, n_slots, prm, lds, ty);
     default: break;
   }
   return svo_fail(ctx, SVO_HIP_ERR_INVALID, "fused SparseImgAlign", "unsupported tiles-per-wave");

@@ -23,13 +23,17 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=["fused", "stream"])
+@pytest.fixture(params=["fused", "fused4", "stream"])
 def sia_mode(request):
     """svo_hip_sia_run has two implementations (one fused launch per run / one launch per Gauss-Newton
-    evaluation); every run()-level parity test is executed against both."""
+    evaluation), and the fused kernel two shapes (8 waves per frame pair; 4 waves, two pairs per CU, which large
+    launches of small frames get -- forced here); every run()-level parity test is executed against all three."""
     old = os.environ.get("SVO_HIP_SIA_MODE")
-    os.environ["SVO_HIP_SIA_MODE"] = request.param
-    yield request.param
+    os.environ["SVO_HIP_SIA_MODE"] = "fused" if request.param == "fused4" else request.param
+    if request.param == "fused4":
+        os.environ["SVO_HIP_SIA_WAVES"] = "4"
+    yield "fused" if request.param == "fused4" else request.param
+    os.environ.pop("SVO_HIP_SIA_WAVES", None)
     if old is None:
         os.environ.pop("SVO_HIP_SIA_MODE", None)
     else:
