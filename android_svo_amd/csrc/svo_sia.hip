@@ -906,6 +906,14 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     __syncthreads();      // s_done / s_old of this level, footprints (own wave) in place
 
     // ================= Gauss-Newton loop of this level =================
+    // Image rows of the wave's first tile, asked for again as soon as an evaluation is through with its tiles: they
+    // arrive while the wave sits in the reduction, the barriers and the one-lane solve.  The next evaluation takes
+    // them from the registers if the new pose moved none of the tile's patches to another pixel (the usual case
+    // after the first evaluations of a level) and otherwise loads as before.
+    uint2 pf[5];
+    int pf_off = -1;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) pf[j] = make_uint2(0u, 0u);
     for (int iter = 0; iter < prm.n_iter; ++iter) {
       if (s_done) break;                                     // block-uniform (read after a barrier)
 #ifdef SVO_STAMPS
@@ -931,8 +939,14 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       LppGeom gq[2];
       uint2 Crq[2][5];
       gq[0] = lpp_project(T, cam, X[0], (fl[0] & F_VISIBLE) != 0, scale, cols, rows, stride);
+      const int off0 = gq[0].off;
+      if (__ballot(off0 != pf_off) == 0ull) {                 // wave-uniform
 #pragma unroll
-      for (int j = 0; j < 5; ++j) Crq[0][j] = load_row8(cur_img + gq[0].off + j * stride);
+        for (int j = 0; j < 5; ++j) Crq[0][j] = pf[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) Crq[0][j] = load_row8(cur_img + off0 + j * stride);
+      }
 #pragma unroll
       for (int k = 0; k < TPW; ++k) {
         const int tile = tile_of(k);
@@ -1062,6 +1076,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       }
 
       __builtin_amdgcn_s_setprio(0);
+      pf_off = off0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) pf[j] = load_row8(cur_img + off0 + j * stride);
       // ---- wave reduction, then the waves in fixed order, then the solve on one lane
       {
         // lanes 8j..8j+7 receive the wave total of value j: 0..5 = Jres moments (sign and fx/2^L applied here),
