@@ -159,9 +159,11 @@ int svo_hip_sia_reduce_buffer(svo_hip_sia* sia, void** dev_ptr, size_t* n_double
 /* use a caller-owned device buffer instead (e.g. a torch tensor that RCCL all-reduces in place) */
 int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
 /* Which implementation the last svo_hip_sia_run used: 1 = the fused kernel (one workgroup per frame pair,
- * reference footprints in LDS, whole coarse-to-fine loop in one launch; chosen when every frame has at most
- * 2816 features and no patch shard is set), 0 = the streaming kernels (one launch per Gauss-Newton
- * evaluation; always used by the step-wise entry points).  SVO_HIP_SIA_MODE=stream forces 0. */
+ * interpolated reference patches in LDS / L2-resident memory, whole coarse-to-fine loop in one launch; chosen
+ * when every frame has at most 2816 features and no patch shard is set; launches with at least two frame pairs
+ * per compute unit and at most 1024 features per frame use its 4-wave shape, two pairs per compute unit),
+ * 0 = the streaming kernels (one launch per Gauss-Newton evaluation; always used by the step-wise entry
+ * points).  SVO_HIP_SIA_MODE=stream forces 0. */
 int svo_hip_sia_last_run_mode(svo_hip_sia* sia, int* mode);
 /* Optional timing of the two heavy kernels with HIP events recorded on the context stream around
  * each launch (precompute: one per level; residual: one per Gauss-Newton evaluation; in fused mode the single
