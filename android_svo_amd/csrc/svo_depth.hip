@@ -350,15 +350,29 @@ __global__ __launch_bounds__(256) void df_search_kernel(
   const int i0 = (blockIdx.x * 4 + wib) * SEEDS_PER_WAVE;
   if (i0 >= n) return;                     // wave-uniform; no block-level barrier is used below
   const Cam cam = fr.cam;
+  // the wave's four records (384 contiguous bytes) and levels go to LDS in one round trip: every phase below reads
+  // its per-seed parameters from there instead of paying a memory latency per dependent field access
+  __shared__ __attribute__((aligned(16))) SeedRec s_rec[SEEDS_PER_BLOCK];
+  __shared__ int s_level[SEEDS_PER_BLOCK];
+  {
+    const int n_here = n - i0 < SEEDS_PER_WAVE ? n - i0 : SEEDS_PER_WAVE;
+    static_assert(sizeof(SeedRec) == 96, "six 16-byte words per record");
+    const uint4* src = reinterpret_cast<const uint4*>(recs + i0);
+    uint4* dst = reinterpret_cast<uint4*>(s_rec + wib * SEEDS_PER_WAVE);
+    if (lane < 6 * n_here) dst[lane] = src[lane];
+    if (lane >= 32 && lane < 32 + n_here) s_level[wib * SEEDS_PER_WAVE + lane - 32] = level[i0 + lane - 32];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
   // ---------------- phase A: warp the reference patches ----------------
   bool any_search = false;
   for (int sidx = 0; sidx < SEEDS_PER_WAVE; ++sidx) {
     const int i = i0 + sidx;
     if (i >= n) break;                                   // wave-uniform
-    const SeedRec* rp = recs + i;
-    const int path = rp->path;
     const int slot = wib * SEEDS_PER_WAVE + sidx;
+    const SeedRec* rp = s_rec + slot;
+    const int path = rp->path;
     if (lane == 0) { s_do[slot] = (path == 0 || path == 3) ? 1 : 0; s_nz[slot] = 0; s_px[slot][0] = rp->uv0[0]; s_px[slot][1] = rp->uv0[1]; }
     any_search |= path == 1;
   }
@@ -367,11 +381,11 @@ __global__ __launch_bounds__(256) void df_search_kernel(
     const int g = lane >> 4, cl = lane & 15;
     const int i = i0 + g;
     const bool have = i < n;
-    const SeedRec* rp = recs + (have ? i : i0);
+    const SeedRec* rp = s_rec + wib * SEEDS_PER_WAVE + (have ? g : 0);
     const int path = have ? rp->path : -1;
     if (path == 0 || path == 1 || path == 3) {
       const uint8_t* ref_pyr = ref_base + (size_t)rp->pad * ref_pyr_bytes;   // pad = reference keyframe slot
-      const int level_ref = level[i];
+      const int level_ref = s_level[wib * SEEDS_PER_WAVE + g];
       const int search_level = rp->search_level;
       // warp::warpAffine of the 10x10 reference patch (matcher.cpp:83-116)
       const int rcols = cam.width >> level_ref, rrows = cam.height >> level_ref;
@@ -380,22 +394,42 @@ __global__ __launch_bounds__(256) void df_search_kernel(
       const bool warp_nan = rp->warp_nan != 0;
       const float lscale = (float)(1 << search_level);
       uint8_t* pwb = s_pwb[wib * SEEDS_PER_WAVE + g];
+      // Two passes so that the 7 x 2 loads of a lane are in flight together (one memory latency instead of seven):
+      // first every sample's address and weights -- a sample that is not interpolated reads offset 0 of the level,
+      // which is always valid memory -- then the arithmetic of vk::interpolateMat_8u (I/vision.h:19-36) in its order.
+      float w00[7], w01[7], w10[7], w11[7];
+      unsigned r0[7], r1[7];
+      bool ok[7];
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
         const int k = cl + 16 * j;
-        if (k >= 100) break;
         const int yy = k / 10, xx = k - yy * 10;
         float ppx = (float)(xx - 5), ppy = (float)(yy - 5);
         ppx *= lscale;
         ppy *= lscale;
         const float qx = (a00 * ppx + a01 * ppy) + prx;
         const float qy = (a10 * ppx + a11 * ppy) + pry;
-        uint8_t val = 0;
         // the reference keeps the previous seed's patch when the inverse warp is NaN and reads out of bounds when
         // qx/qy are NaN (inf inverse of a singular A); such samples are 0 here
-        if (!warp_nan && qx >= 0 && qy >= 0 && qx < rcols - 1 && qy < rrows - 1)
-          val = (uint8_t)interpolate_8u(img_ref, rcols, qx, qy);
-        pwb[k] = val;
+        ok[j] = k < 100 && !warp_nan && qx >= 0 && qy >= 0 && qx < rcols - 1 && qy < rrows - 1;
+        const float u = ok[j] ? qx : 0.0f, v = ok[j] ? qy : 0.0f;
+        const int x = (int)floorf(u), y = (int)floorf(v);
+        const float subpix_x = u - x, subpix_y = v - y;
+        w00[j] = (1.0f - subpix_x) * (1.0f - subpix_y);
+        w01[j] = (1.0f - subpix_x) * subpix_y;
+        w10[j] = subpix_x * (1.0f - subpix_y);
+        w11[j] = 1.0f - w00[j] - w01[j] - w10[j];
+        const uint8_t* ptr = img_ref + y * rcols + x;
+        typedef unsigned short __attribute__((aligned(1))) u16u;
+        r0[j] = *reinterpret_cast<const u16u*>(ptr);              // the two neighbours of a row in one unaligned load
+        r1[j] = *reinterpret_cast<const u16u*>(ptr + rcols);
+      }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int k = cl + 16 * j;
+        const float val = w00[j] * (float)(r0[j] & 0xff) + w01[j] * (float)(r1[j] & 0xff) + w10[j] * (float)(r0[j] >> 8) +
+                          w11[j] * (float)(r1[j] >> 8);
+        if (k < 100) pwb[k] = ok[j] ? (uint8_t)val : (uint8_t)0;
       }
     }
   }
@@ -416,7 +450,7 @@ __global__ __launch_bounds__(256) void df_search_kernel(
     const int gi = i0 + g;
     const int slot = wib * SEEDS_PER_WAVE + g;
     const bool have = gi < n;
-    const SeedRec* rp = recs + (have ? gi : i0);
+    const SeedRec* rp = s_rec + wib * SEEDS_PER_WAVE + (have ? g : 0);
     const bool live = have && rp->path == 1;
     const int search_level = rp->search_level;
     const int ccols = cam.width >> search_level;
@@ -520,7 +554,8 @@ __global__ __launch_bounds__(256) void df_search_kernel(
     const int gi = i0 + g;
     const int slot = wib * SEEDS_PER_WAVE + g;
     const bool have = gi < n;
-    SeedRec* rp = recs + (have ? gi : i0);
+    const SeedRec* rp = s_rec + wib * SEEDS_PER_WAVE + (have ? g : 0);
+    SeedRec* rp_out = recs + (have ? gi : i0);
     const int path = have ? rp->path : -1;
     const bool live = path == 0 || path == 1 || path == 3;
     const int search_level = rp->search_level;
@@ -552,9 +587,9 @@ __global__ __launch_bounds__(256) void df_search_kernel(
       px_cur[1] = vs * (1 << search_level);
     }
     if (live && cl == 0) {
-      rp->matched = res ? 1 : 0;
-      rp->step[0] = px_cur[0]; rp->step[1] = px_cur[1];
-      rp->n_zmssd = s_nz[slot]; rp->n_align = n_align;
+      rp_out->matched = res ? 1 : 0;
+      rp_out->step[0] = px_cur[0]; rp_out->step[1] = px_cur[1];
+      rp_out->n_zmssd = s_nz[slot]; rp_out->n_align = n_align;
     }
   }
 }
