@@ -724,8 +724,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   __shared__ long long s_stamp[10];
   __shared__ long long s_wst[16];
   if (threadIdx.x < 16) s_wst[threadIdx.x] = 0;
-  if (threadIdx.x == 64) { s_stamp[0] = s_stamp[1] = s_stamp[2] = 0; }
-  if (threadIdx.x == 0) { for (int i = 3; i < 10; ++i) s_stamp[i] = 0; }
+  if (threadIdx.x == 64) { s_stamp[0] = s_stamp[1] = s_stamp[2] = 0; s_stamp[9] = 0; }
+  if (threadIdx.x == 0) { for (int i = 3; i < 9; ++i) s_stamp[i] = 0; }
 #endif
 
   const int b = blockIdx.x;
@@ -810,100 +810,124 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     }
 
     // ================= precomputeReferencePatches for the wave's tiles =================
+#ifdef SVO_STAMPS
+    const long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
+    // Pass 1: where every patch of the wave's tiles sits in the reference level (the feature loads of all tiles are
+    // independent of each other and go out together).  Pass 2: footprint rows one tile ahead of the arithmetic.
+    int pre_off[TPW];
+    float pre_w[TPW][4];
+    bool pre_valid[TPW];
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
       const int tile = tile_of(k);
-      if (tile >= n_tiles) continue;                         // wave-uniform
-      const int tile_base = tile * TILE;
-      const int i_own = tile_base + lane;
-      bool valid = false;
-      float w_tl = 0, w_tr = 0, w_bl = 0, w_br = 0;
-      int off = 0;
-      if (i_own < n) {
-        const size_t fo = (size_t)b * max_n + i_own;
-        const float u_ref = (float)(px[2 * fo] * scale);
-        const float v_ref = (float)(px[2 * fo + 1] * scale);
-        const int u_ref_i = (int)floorf(u_ref);
-        const int v_ref_i = (int)floorf(v_ref);
-        valid = has_point[fo] && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= cols ||
-                                   v_ref_i + border >= rows);
-        if (valid) {
-          const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
-          w_tl = (float)((1.0 - su) * (1.0 - sv));
-          w_tr = (float)(su * (1.0 - sv));
-          w_bl = (float)((1.0 - su) * sv);
-          w_br = su * sv;
-          off = (v_ref_i - 3) * stride + (u_ref_i - 3);
-        }
-        // visible_fts_ is only ever set (:128); the Jacobian block is zero unless recomputed now (:76)
-        fl[k] = valid ? (uint8_t)(F_VISIBLE | F_JVALID) : (uint8_t)(fl[k] & F_VISIBLE);
+      const int i_own = tile * TILE + lane;
+      const bool have = tile < n_tiles && i_own < n;
+      const size_t fo = (size_t)b * max_n + (have ? i_own : 0);
+      const float u_ref = (float)(px[2 * fo] * scale);
+      const float v_ref = (float)(px[2 * fo + 1] * scale);
+      const int u_ref_i = (int)floorf(u_ref);
+      const int v_ref_i = (int)floorf(v_ref);
+      const bool valid = have && has_point[fo] && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= cols ||
+                                                    v_ref_i + border >= rows);
+      const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
+      pre_w[k][0] = (float)((1.0 - su) * (1.0 - sv));
+      pre_w[k][1] = (float)(su * (1.0 - sv));
+      pre_w[k][2] = (float)((1.0 - su) * sv);
+      pre_w[k][3] = su * sv;
+      pre_off[k] = valid ? (v_ref_i - 3) * stride + (u_ref_i - 3) : 0;   // offset 0: always valid memory
+      pre_valid[k] = valid;
+      // visible_fts_ is only ever set (:128); the Jacobian block is zero unless recomputed now (:76)
+      if (have) fl[k] = valid ? (uint8_t)(F_VISIBLE | F_JVALID) : (uint8_t)(fl[k] & F_VISIBLE);
+    }
+    uint2 Fq[2][7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) Fq[0][j] = load_row8(ref_img + pre_off[0] + j * stride);
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+      const int tile = tile_of(k);
+      if (k + 1 < TPW) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) Fq[(k + 1) & 1][j] = load_row8(ref_img + pre_off[k + 1] + j * stride);
       }
+      if (tile >= n_tiles) continue;                         // wave-uniform
+      const int i_own = tile * TILE + lane;
+      const bool valid = pre_valid[k];
+      const float w_tl = pre_w[k][0], w_tr = pre_w[k][1], w_bl = pre_w[k][2], w_br = pre_w[k][3];
       {
         const unsigned long long m = __ballot(valid);
         if (lane == 0 && m) atomicAdd(&s_npre, (unsigned)__popcll(m));
       }
       double sxx = 0.0, sxy = 0.0, syy = 0.0;
       {
-        // lane-per-patch: the lane reads its patch's 7 footprint rows, interpolates and sums the 16 pixels.  A patch
+        // lane-per-patch: the lane interpolates its patch's 7 footprint rows and sums the 16 pixels.  A patch
         // that is not valid at this level keeps the values of the level before (the reference's stale cache row).
-        if (valid) {
-          uint2 F[7];
+        float W[6][6];
 #pragma unroll
-          for (int j = 0; j < 7; ++j) F[j] = load_row8(ref_img + off + j * stride);
-          float W[6][6];
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int c2 = 0; c2 < 6; ++c2)
+            W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : interp_at(Fq[k & 1][j], Fq[k & 1][j + 1], c2, w_tl, w_tr, w_bl, w_br);
+        if (valid) {
+          // halved (exact), in the order the evaluation reads them: rows 0 and 5 without their corners
+          float4* dst = Plan::in_lds(k) ? wc + (size_t)((Plan::lds_slot(k) * NW + wave) * 8) * TILE + lane
+                                        : wmem + ((size_t)b * max_tiles + tile) * 8 * TILE + lane;
+          float q[32];
+          int e = 0;
 #pragma unroll
           for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int c2 = 0; c2 < 6; ++c2)
-              W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : interp_at(F[j], F[j + 1], c2, w_tl, w_tr, w_bl, w_br);
-          {
-            // halved (exact), in the order the evaluation reads them: rows 0 and 5 without their corners
-            float4* dst = Plan::in_lds(k) ? wc + (size_t)((Plan::lds_slot(k) * NW + wave) * 8) * TILE + lane
-                                          : wmem + ((size_t)b * max_tiles + tile) * 8 * TILE + lane;
-            float q[32];
-            int e = 0;
+              if (!((j == 0 || j == 5) && (c2 == 0 || c2 == 5))) q[e++] = 0.5f * W[j][c2];
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-              for (int c2 = 0; c2 < 6; ++c2)
-                if (!((j == 0 || j == 5) && (c2 == 0 || c2 == 5))) q[e++] = 0.5f * W[j][c2];
-#pragma unroll
-            for (int c4 = 0; c4 < 8; ++c4) dst[c4 * TILE] = make_float4(q[4 * c4], q[4 * c4 + 1], q[4 * c4 + 2], q[4 * c4 + 3]);
-          }
-#pragma unroll
-          for (int y = 0; y < 4; ++y)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-              const float dxv = 0.5f * (W[y + 1][x + 2] - W[y + 1][x]);
-              const float dyv = 0.5f * (W[y + 2][x + 1] - W[y][x + 1]);
-              const double ddx = (double)dxv, ddy = (double)dyv;
-              sxx += ddx * ddx; sxy += ddx * ddy; syy += ddy * ddy;
-            }
+          for (int c4 = 0; c4 < 8; ++c4) dst[c4 * TILE] = make_float4(q[4 * c4], q[4 * c4 + 1], q[4 * c4 + 2], q[4 * c4 + 3]);
         }
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float dxv = 0.5f * (W[y + 1][x + 2] - W[y + 1][x]);
+            const float dyv = 0.5f * (W[y + 2][x + 1] - W[y][x + 1]);
+            const double ddx = (double)dxv, ddy = (double)dyv;
+            sxx += ddx * ddx; sxy += ddx * ddy; syy += ddy * ddy;
+          }
       }
       if (valid) sxyz[(size_t)b * max_n + i_own] = make_double4(sxx, sxy, syy, 0.0);   // only re-read when a patch leaves the image
-      // the tile's Hessian row: lane e keeps entry e
+      // the tile's Hessian row: lane e keeps entry e.  The 21 wave sums go through three transposing reductions
+      // (7 long-range exchanges each) instead of 21 butterflies.
       {
         double A[6], B[6];
         patch_jacobian_rows(X[k].x, X[k].y, X[k].w, jscale, A, B);
-        double mine = 0.0;
+        double h[24];
         int e = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
           for (int j = i; j < 6; ++j) {
-            double h = 0.0;
-            if (valid) h = sxx * (A[i] * A[j]) + sxy * (A[i] * B[j] + B[i] * A[j]) + syy * (B[i] * B[j]);
-            const double t = group_sum<64>(h);
-            if (lane == e) mine = t;
+            h[e] = valid ? sxx * (A[i] * A[j]) + sxy * (A[i] * B[j] + B[i] * A[j]) + syy * (B[i] * B[j]) : 0.0;
             ++e;
           }
+        h[21] = h[22] = h[23] = 0.0;
+        double mine = 0.0;
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+          const double r = wave_reduce8(h + 8 * c3);           // lanes 8j..8j+7: total of entry 8*c3 + j
+          const double t = __shfl(r, 8 * (lane & 7), 64);
+          if ((lane >> 3) == c3) mine = t;
+        }
         th_set(k, mine);
         // the untouched row goes to memory: it is only needed again when the set of patches outside the image changes
         if (lane < 21) tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane] = mine;
       }
     }
+#ifdef SVO_STAMPS
+    const long long tp1 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();      // s_done / s_old of this level, footprints (own wave) in place
+#ifdef SVO_STAMPS
+    if (threadIdx.x == 64) s_stamp[9] += __builtin_amdgcn_s_memtime() - tp0;
+    if (threadIdx.x == 0) s_stamp[5] += 0 * (tp1 - tp0);
+#endif
 
     // ================= Gauss-Newton loop of this level =================
     // Image rows of the wave's first tile, asked for again as soon as an evaluation is through with its tiles: they
@@ -1262,7 +1286,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       for (int i = 0; i < 6; ++i) { s.Jres[i] = s_last[21 + i]; s.x[i] = s_x[i]; }
 #ifdef SVO_STAMPS
       for (int i = 0; i < 16; ++i) s.H[i] = (double)s_wst[i];
-      for (int i = 5; i < 9; ++i) s.H[16 + i - 5] = (double)s_stamp[i];
+      for (int i = 5; i < 10; ++i) s.H[16 + i - 5] = (double)s_stamp[i];
       s.x[0] = (double)s_stamp[0]; s.x[1] = (double)s_stamp[1]; s.x[2] = (double)s_stamp[2]; s.x[3] = (double)s_stamp[3]; s.x[4] = (double)s_stamp[4];
 #endif
     }
@@ -1684,7 +1708,7 @@ int svo_hip_sia_debug_x(svo_hip_sia* s, int slot, double* x6) {
   FrameState st;
   int rc = svo_hip_memcpy_d2h(s->ctx, &st, s->st + slot, sizeof(FrameState));
   for (int i = 0; i < 6; ++i) x6[i] = st.x[i];
-  for (int i = 0; i < 20; ++i) x6[6 + i] = st.H[i];      // caller passes 26 doubles
+  for (int i = 0; i < 21; ++i) x6[6 + i] = st.H[i];      // caller passes 27 doubles
   return rc;
 }
 #endif

@@ -30,7 +30,7 @@ L = ctx.lib
 import ctypes as C
 # FrameState.x lives inside the download struct? not exposed: read through a dedicated debug accessor is overkill,
 # the stamps are returned in H[...]? -> the stamped build stores them in x[0..2]; fetch via svo_hip_sia_download_x
-buf = (C.c_double * 26)()
+buf = (C.c_double * 27)()
 rows = []
 for s in range(min(B, 8)):
     L.svo_hip_sia_debug_x(sia.h, s, buf)
@@ -44,3 +44,4 @@ print(np.array(list(buf[6:14])) / 150.0)
 print(np.array(list(buf[14:22])) / 150.0)
 print("wave 0 between the barriers: sum+compare+readlane, (solve), solve->exp, (exp+mul), after exp, whole")
 print(np.array(list(buf[22:26])) / 150.0)
+print("precompute + its barrier, cycles per level (wave 1):", buf[26] / 5.0)
