@@ -467,26 +467,46 @@ SVO_DEV int row16_sum(int v) {
   return v;
 }
 
-// Sum 8 per-lane doubles over the 64 lanes of a wave with 7 long-range exchanges instead of 48: every
+// Sum 8 per-lane doubles over the 64 lanes of a wave with 7 long-range exchanges (lane swaps and DPP, no LDS
+// traffic) instead of 48: every
 // exchange step halves the number of values a lane still carries (lanes with the exchanged bit set keep the
 // upper half of the values and hand over the lower half).  On return lanes 8j .. 8j+7 all hold the wave
 // total of v[j].  The order of the additions is fixed, so the result is reproducible run to run.
+// gfx950 lane swaps (VALU, no LDS round trip): v_permlane32_swap exchanges lanes 32..63 of the first operand with
+// lanes 0..31 of the second, v_permlane16_swap the odd 16-lane rows of the first with the even rows of the second.
+SVO_DEV void permlane32_swap(double& a, double& b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]);
+  b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+SVO_DEV void permlane16_swap(double& a, double& b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]);
+  b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
 SVO_DEV double wave_reduce8(const double* v) {
   const int lane = threadIdx.x & 63;
-  const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+  const bool b3 = (lane & 8) != 0;
   double a[4], c[2];
+  // lanes 0..31 keep v[i] and add the other half's v[i]; lanes 32..63 keep v[i+4] and add the other half's v[i+4]:
+  // after the swap the first operand holds {own v[i] | partner's v[i+4]} and the second {partner's v[i] | own v[i+4]}
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const double keep = b5 ? v[i + 4] : v[i], send = b5 ? v[i] : v[i + 4];
-    a[i] = keep + __shfl_xor(send, 32, 64);
+    double p = v[i], q = v[i + 4];
+    permlane32_swap(p, q);
+    a[i] = p + q;
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const double keep = b4 ? a[i + 2] : a[i], send = b4 ? a[i] : a[i + 2];
-    c[i] = keep + __shfl_xor(send, 16, 64);
+    double p = a[i], q = a[i + 2];
+    permlane16_swap(p, q);
+    c[i] = p + q;
   }
   const double keep = b3 ? c[1] : c[0], send = b3 ? c[0] : c[1];
-  double r = keep + __shfl_xor(send, 8, 64);
+  double r = keep + dpp_quad<0x128>(send);   // DPP row_ror:8 = the lane 8 further on in the 16-lane row (xor 8)
   r = quad_sum(r);                       // lanes xor 1, xor 2 (DPP quad_perm)
   r += dpp_quad<0x141>(r);               // DPP row_half_mirror: the other quad of the 8-lane group
   return r;

@@ -53,7 +53,8 @@ constexpr int TILE = 64;                        // patches per wavefront pass
 constexpr int TILE_ROW = 24;                    // doubles per tile-H row (21 used)
 constexpr uint8_t F_VISIBLE = 1;                // visible_fts_ (sticky across levels)
 constexpr uint8_t F_JVALID = 2;                 // jacobian_cache_ column block non-zero at this level
-constexpr uint8_t F_GONE = 4;                   // fused kernel: outside the current image at the previous evaluation
+constexpr uint8_t F_GONE = 4;
+constexpr uint8_t F_HASPOINT = 8;              // fused kernel: the feature has a map point (sticky)                   // fused kernel: outside the current image at the previous evaluation
 
 // per-frame constants
 struct FrameConst {
@@ -92,6 +93,9 @@ struct Shard { int rank, world; };
 
 // upper-triangle (row-major) index -> (i, j)
 __device__ __constant__ int8_t kTriI[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+// the same tables for compile-time indices (unrolled loops)
+constexpr int kTriIc[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+constexpr int kTriJc[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
 __device__ __constant__ int8_t kTriJ[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
 
 SVO_DEV void shard_range(int n, Shard sh, int* lo, int* hi) {
@@ -777,6 +781,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   // ---- lane-per-patch persistent state of the wave's tiles
   double4 X[TPW];
   uint8_t fl[TPW];
+  float pxf[TPW][2];
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
     const int tile = tile_of(k);
@@ -784,8 +789,11 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     X[k] = make_double4(0, 0, 1, 1);
     th_set(k, 0.0);
     fl[k] = 0;
+    pxf[k][0] = pxf[k][1] = 0.0f;
     if (tile < n_tiles && i_own < n) {
       const size_t fi = (size_t)b * max_n + i_own;
+      if (has_point[fi]) fl[k] = F_HASPOINT;
+      pxf[k][0] = (float)px[2 * fi]; pxf[k][1] = (float)px[2 * fi + 1];
       const double dxp = pos[3 * fi] - c.ref_pos[0];
       const double dyp = pos[3 * fi + 1] - c.ref_pos[1];
       const double dzp = pos[3 * fi + 2] - c.ref_pos[2];
@@ -823,12 +831,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       const int tile = tile_of(k);
       const int i_own = tile * TILE + lane;
       const bool have = tile < n_tiles && i_own < n;
-      const size_t fo = (size_t)b * max_n + (have ? i_own : 0);
-      const float u_ref = (float)(px[2 * fo] * scale);
-      const float v_ref = (float)(px[2 * fo + 1] * scale);
+      // (float)(px * 2^-L) == (float)(px) * 2^-L: the level-0 position in f32 is kept, no feature loads per level
+      const float u_ref = pxf[k][0] * scale;
+      const float v_ref = pxf[k][1] * scale;
       const int u_ref_i = (int)floorf(u_ref);
       const int v_ref_i = (int)floorf(v_ref);
-      const bool valid = have && has_point[fo] && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= cols ||
+      const bool valid = have && (fl[k] & F_HASPOINT) != 0 && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= cols ||
                                                     v_ref_i + border >= rows);
       const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
       pre_w[k][0] = (float)((1.0 - su) * (1.0 - sv));
@@ -838,14 +846,17 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       pre_off[k] = valid ? (v_ref_i - 3) * stride + (u_ref_i - 3) : 0;   // offset 0: always valid memory
       pre_valid[k] = valid;
       // visible_fts_ is only ever set (:128); the Jacobian block is zero unless recomputed now (:76)
-      if (have) fl[k] = valid ? (uint8_t)(F_VISIBLE | F_JVALID) : (uint8_t)(fl[k] & F_VISIBLE);
+      if (have) fl[k] = valid ? (uint8_t)(F_VISIBLE | F_JVALID | F_HASPOINT) : (uint8_t)(fl[k] & (F_VISIBLE | F_HASPOINT));
     }
     uint2 Fq[2][7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) Fq[0][j] = load_row8(ref_img + pre_off[0] + j * stride);
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
-      const int tile = tile_of(k);
+      // (opaque: the store addresses derived from the tile number are formed here, per level, instead of being
+      // hoisted out of the level loop into registers that then spill)
+      int tile = tile_of(k);
+      asm volatile("" : "+s"(tile));
       if (k + 1 < TPW) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) Fq[(k + 1) & 1][j] = load_row8(ref_img + pre_off[k + 1] + j * stride);
@@ -854,6 +865,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       const int i_own = tile * TILE + lane;
       const bool valid = pre_valid[k];
       const float w_tl = pre_w[k][0], w_tr = pre_w[k][1], w_bl = pre_w[k][2], w_br = pre_w[k][3];
+#ifdef SVO_STAMPS
+      const long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
       {
         const unsigned long long m = __ballot(valid);
         if (lane == 0 && m) atomicAdd(&s_npre, (unsigned)__popcll(m));
@@ -892,26 +906,31 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
             sxx += ddx * ddx; sxy += ddx * ddy; syy += ddy * ddy;
           }
       }
+#ifdef SVO_STAMPS
+      const long long tq1 = __builtin_amdgcn_s_memtime();
+#endif
       if (valid) sxyz[(size_t)b * max_n + i_own] = make_double4(sxx, sxy, syy, 0.0);   // only re-read when a patch leaves the image
       // the tile's Hessian row: lane e keeps entry e.  The 21 wave sums go through three transposing reductions
       // (7 long-range exchanges each) instead of 21 butterflies.
       {
         double A[6], B[6];
         patch_jacobian_rows(X[k].x, X[k].y, X[k].w, jscale, A, B);
-        double h[24];
-        int e = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int j = i; j < 6; ++j) {
-            h[e] = valid ? sxx * (A[i] * A[j]) + sxy * (A[i] * B[j] + B[i] * A[j]) + syy * (B[i] * B[j]) : 0.0;
-            ++e;
-          }
-        h[21] = h[22] = h[23] = 0.0;
+        // entry e of the row = (i, j) of the upper triangle in row-major order; eight entries per reduction
         double mine = 0.0;
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) {
-          const double r = wave_reduce8(h + 8 * c3);           // lanes 8j..8j+7: total of entry 8*c3 + j
+          double h[8];
+#pragma unroll
+          for (int q8 = 0; q8 < 8; ++q8) {
+            const int e = 8 * c3 + q8;
+            h[q8] = 0.0;
+            if (e < 21) {
+              const int i = kTriIc[e], j = kTriJc[e];
+              const double he = sxx * (A[i] * A[j]) + sxy * (A[i] * B[j] + B[i] * A[j]) + syy * (B[i] * B[j]);
+              h[q8] = valid ? he : 0.0;               // a select, not a branch per entry
+            }
+          }
+          const double r = wave_reduce8(h);                    // lanes 8j..8j+7: total of entry 8*c3 + j
           const double t = __shfl(r, 8 * (lane & 7), 64);
           if ((lane >> 3) == c3) mine = t;
         }
@@ -919,6 +938,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         // the untouched row goes to memory: it is only needed again when the set of patches outside the image changes
         if (lane < 21) tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane] = mine;
       }
+#ifdef SVO_STAMPS
+      if (threadIdx.x == 64) { const long long tq2 = __builtin_amdgcn_s_memtime(); s_stamp[6] += tq1 - tq0; s_stamp[7] += tq2 - tq1; }
+#endif
     }
 #ifdef SVO_STAMPS
     const long long tp1 = __builtin_amdgcn_s_memtime();
@@ -1236,7 +1258,6 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
             for (int i = 0; i < 6; ++i) mx[i] = -x[i];
 #ifdef SVO_STAMPS
             const long long q2 = __builtin_amdgcn_s_memtime();
-            s_stamp[6] += q2 - q1;
 #endif
             se3_exp_small(mx, dT);
             se3_mul(cur, dT, nm);                                                // T_new = T_old * exp(-x) (:307)
@@ -1254,7 +1275,6 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
             s_iter = it + 1;
             if (it + 1 >= prm.n_iter) s_done = 1;
 #ifdef SVO_STAMPS
-            s_stamp[7] += __builtin_amdgcn_s_memtime() - q3;
 #endif
           }
         }

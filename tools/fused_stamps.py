@@ -44,4 +44,4 @@ print(np.array(list(buf[6:14])) / 150.0)
 print(np.array(list(buf[14:22])) / 150.0)
 print("wave 0 between the barriers: sum+compare+readlane, (solve), solve->exp, (exp+mul), after exp, whole")
 print(np.array(list(buf[22:26])) / 150.0)
-print("precompute + its barrier, cycles per level (wave 1):", buf[26] / 5.0)
+print("precompute + its barrier, cycles per level (wave 1):", buf[26] / 5.0, " of which interpolation+W store+gradient sums:", buf[23] / 5.0, " H rows:", buf[24] / 5.0)
