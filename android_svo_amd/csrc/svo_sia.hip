@@ -698,7 +698,7 @@ struct FusedPlan {
 // NW = 8: one workgroup (one frame pair) per CU, two waves of it on every SIMD.  NW = 4: one wave per SIMD and 256
 // VGPRs, so that TWO workgroups -- two independent frame pairs -- share a CU: while one of them is in the one-lane
 // phase between its barriers the other one has the SIMDs to itself (used when a launch holds at least two pairs per
-// CU).  Per-tile H rows then live in LDS instead of VGPRs (a wave owns twice as many tiles).
+// CU).
 template <int NW, int TPW, int CK>
 __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   // float4, L2 / Infinity-Cache resident: 8 coalesced 1-KiB loads per tile and evaluation, issued one tile ahead).
   float4* wc = reinterpret_cast<float4*>(smem);
   __shared__ double red[NW][32];
-  __shared__ double s_th[NW == 4 ? NW * TPW * 21 : 1];        // NW = 4: per-tile H rows (lane e keeps entry e)
+  __shared__ double s_th[NW * TPW * 21];                      // per-tile H rows (lane e keeps entry e)
   __shared__ double s_last[32], s_x[8];
   __shared__ double s_Hc[21], s_fac[36], s_inv[36];   // H of the previous evaluation, its LDL^T factor, H^-1 by columns
   __shared__ int s_ftr[6], s_fac_valid;
@@ -754,16 +754,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   const int first_j = (NW == 4 || wave < 4) ? 0 : TPW;
   const int favoured_tiles = (5 * my_tiles + 4) / 8;                    // 3 of 4 measured best (2 of 4: -0.8 %)
   auto tile_of = [&](int k) -> int { return k < my_tiles ? simd + 4 * (first_j + k) : n_tiles; };
-  // per-tile H row of this wave: VGPRs (NW = 8) or LDS (NW = 4)
-  double th_reg[NW == 4 ? 1 : TPW];
-  auto th_get = [&](int k) -> double {
-    if (NW == 4) return lane < 21 ? s_th[(wave * TPW + k) * 21 + lane] : 0.0;
-    return th_reg[NW == 4 ? 0 : k];
-  };
-  auto th_set = [&](int k, double v) {
-    if (NW == 4) { if (lane < 21) s_th[(wave * TPW + k) * 21 + lane] = v; }
-    else th_reg[NW == 4 ? 0 : k] = v;
-  };
+  // per-tile H row of this wave (lane e keeps entry e): in LDS, read once per tile and evaluation
+  auto th_get = [&](int k) -> double { return lane < 21 ? s_th[(wave * TPW + k) * 21 + lane] : 0.0; };
+  auto th_set = [&](int k, double v) { if (lane < 21) s_th[(wave * TPW + k) * 21 + lane] = v; };
 
   if (lane >= 29 && lane < 32) red[wave][lane] = 0.0;       // unused slots of the wave partial rows
   if (threadIdx.x == 0) {
