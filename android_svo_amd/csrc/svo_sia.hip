@@ -746,13 +746,15 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   // at the pace of a wave that is alone on its SIMD (one instruction per 4 cycles, whatever the type), the younger
   // one gets the issue cycles that are left (measured: 57 % of that pace) and finishes an equal share 40 % later,
   // alone on a half-used SIMD.  The tiles of a SIMD (s, s+4, s+8, ...) are split evenly, the older wave takes the
-  // first TPW of them and the younger one the tiles_young that follow; during the first 5/8 of its tiles the younger
+  // first TPW of them and the younger one the tiles_young that follow; during the first 5/8 of its tiles (to half a tile) the younger
   // wave raises its priority (s_setprio), so that each wave is the favoured one for about half of the evaluation and both
   // reach the barrier together (measured per-wave cycles per evaluation: 15.0 k / 21.5 k before, 18.2 k / 19.7 k after).
   const int simd = wave & 3;
   const int my_tiles = (NW == 4 || wave < 4) ? TPW : tiles_young;       // wave-uniform
   const int first_j = (NW == 4 || wave < 4) ? 0 : TPW;
-  const int favoured_tiles = (5 * my_tiles + 4) / 8;                    // 3 of 4 measured best (2 of 4: -0.8 %)
+  // favoured for 5/8 of its tiles, to half a tile: 2.5 of 4 measured best (2 of 4: -1.2 %, 3 of 4: -1.4 %)
+  const int favoured_tiles = (5 * my_tiles) / 8;                        // whole tiles at raised priority
+  const int favoured_half = (5 * my_tiles) % 8 >= 4 ? favoured_tiles : -1;   // then the first half of this one
   auto tile_of = [&](int k) -> int { return k < my_tiles ? simd + 4 * (first_j + k) : n_tiles; };
   // per-tile H row of this wave (lane e keeps entry e): in LDS, read once per tile and evaluation
   auto th_get = [&](int k) -> double { return lane < 21 ? s_th[(wave * TPW + k) * 21 + lane] : 0.0; };
@@ -990,7 +992,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       for (int k = 0; k < TPW; ++k) {
         const int tile = tile_of(k);
         // the younger wave of a SIMD is favoured by the arbiter during its first tiles (see tile_of)
-        if (NW == 8 && wave >= 4) { if (k < favoured_tiles) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        if (NW == 8 && wave >= 4) { if (k < favoured_tiles || k == favoured_half) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 
         // this tile's interpolated patches: from LDS, or what was asked for while the previous tile was computed
         float4 Wq[8];
@@ -1047,7 +1049,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
               }
           }
 #pragma unroll
-          for (int y = 0; y < 4; ++y)
+          for (int y = 0; y < 4; ++y) {
+            if (NW == 8 && y == 2 && k == favoured_half && wave >= 4) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
               const float refv = W[y + 1][x + 1];                                  // half the reference value
@@ -1061,6 +1064,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
               sdx = __builtin_fma((double)dxv, dres, sdx);
               sdy = __builtin_fma((double)dyv, dres, sdy);
             }
+          }
         }
         // ---- normal equations
         const bool lin = ok && jvalid;
