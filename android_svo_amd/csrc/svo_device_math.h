@@ -143,48 +143,38 @@ SVO_DEV void se3_exp(const double* l, double* out) {
   out[6] = real_factor;
 }
 
-// se3_exp for the Gauss-Newton updates of the fused SparseImgAlign kernel (one lane, every other wave of the
-// workgroup waiting for it): the same four series as sincos_small, but the quotients of I/SE3.h:153-182 are taken
-// from the series themselves -- sin(h)/theta = ps_h / 2, (1 - cos t)/t^2 = pc_t / 2, (t - sin t)/t^3 = (inner
-// sine series)/6 -- so there is no square root and no division on the critical path, and none of the cancellation
-// the quotient forms have at small angles.  theta == 0 keeps the reference's NaN translation; angles above 0.5 rad
-// take se3_exp.
-SVO_DEV void se3_exp_small(const double* l, double* out) {
+// se3_exp for the Gauss-Newton updates of the fused SparseImgAlign kernel (every other wave of the workgroup is
+// waiting for it): the same four series as sincos_small, but the quotients of I/SE3.h:153-182 are taken from the
+// series themselves -- sin(h)/theta = ps_h / 2, (1 - cos t)/t^2 = pc_t / 2, (t - sin t)/t^3 = (inner sine
+// series)/6 -- so there is no square root and no division on the critical path, and none of the cancellation the
+// quotient forms have at small angles.  theta == 0 keeps the reference's NaN translation.
+// The four series are 8 dependent steps p <- 1 - (z c_k) p each; on one lane they cost ~1.2 k cycles of latency, so
+// they run on four lanes at once: lane l & 3 takes column l & 3 of the coefficient table (a leading zero pads the
+// 7-step series: 1 - (z 0) 1 = 1) and the caller collects the four values with readlane.
+//   column 0: qs_t (inner sine series of theta^2)   column 1: pc_t (cosine series of theta^2)
+//   column 2: ps_h (sine series of (theta/2)^2)     column 3: pc_h (cosine series of (theta/2)^2)
+SVO_DEV void se3_exp_series_table(double* tab /* [8][4] */) {
+  const double sn[8] = {1.0 / 272.0, 1.0 / 210.0, 1.0 / 156.0, 1.0 / 110.0, 1.0 / 72.0, 1.0 / 42.0, 1.0 / 20.0, 1.0 / 6.0};
+  const double cs[7] = {1.0 / 240.0, 1.0 / 182.0, 1.0 / 132.0, 1.0 / 90.0, 1.0 / 56.0, 1.0 / 30.0, 1.0 / 12.0};
+  for (int k = 0; k < 8; ++k) {
+    tab[k * 4 + 0] = k == 0 ? 0.0 : sn[k - 1];
+    tab[k * 4 + 1] = k == 0 ? 0.0 : cs[k - 1];
+    tab[k * 4 + 2] = sn[k];
+    tab[k * 4 + 3] = k == 0 ? 0.0 : cs[k - 1];
+  }
+}
+// one lane's series: c[0..7] = its column, z = theta^2 (columns 0, 1) or theta^2 / 4 (columns 2, 3)
+SVO_DEV double se3_exp_series_lane(const double* c, double z) {
+  double p = 1.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) p = 1.0 - z * c[k] * p;
+  return p;
+}
+// the rest of the exponential, given the four series values (small angles only: zt <= 0.25)
+SVO_DEV void se3_exp_small_finish(const double* l, double zt, double qs_t, double pc_t, double ps_h, double pc_h, double* out) {
   const double p[3] = {l[0], l[1], l[2]};
   const double r[3] = {l[3], l[4], l[5]};
-  const double zt = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];      // theta^2
-  if (!(zt <= 0.25)) { se3_exp(l, out); return; }
   const double zh = 0.25 * zt;                                    // (theta/2)^2
-  // sin x = x ps(z), ps = 1 - z/6 qs, qs = 1 - z/20 (1 - z/42 (...));  cos x = 1 - z/2 pc(z)
-  double qs_t = 1.0 - zt * (1.0 / 272.0);
-  qs_t = 1.0 - zt * (1.0 / 210.0) * qs_t;
-  qs_t = 1.0 - zt * (1.0 / 156.0) * qs_t;
-  qs_t = 1.0 - zt * (1.0 / 110.0) * qs_t;
-  qs_t = 1.0 - zt * (1.0 / 72.0) * qs_t;
-  qs_t = 1.0 - zt * (1.0 / 42.0) * qs_t;
-  qs_t = 1.0 - zt * (1.0 / 20.0) * qs_t;
-  double pc_t = 1.0 - zt * (1.0 / 240.0);
-  pc_t = 1.0 - zt * (1.0 / 182.0) * pc_t;
-  pc_t = 1.0 - zt * (1.0 / 132.0) * pc_t;
-  pc_t = 1.0 - zt * (1.0 / 90.0) * pc_t;
-  pc_t = 1.0 - zt * (1.0 / 56.0) * pc_t;
-  pc_t = 1.0 - zt * (1.0 / 30.0) * pc_t;
-  pc_t = 1.0 - zt * (1.0 / 12.0) * pc_t;
-  double ps_h = 1.0 - zh * (1.0 / 272.0);
-  ps_h = 1.0 - zh * (1.0 / 210.0) * ps_h;
-  ps_h = 1.0 - zh * (1.0 / 156.0) * ps_h;
-  ps_h = 1.0 - zh * (1.0 / 110.0) * ps_h;
-  ps_h = 1.0 - zh * (1.0 / 72.0) * ps_h;
-  ps_h = 1.0 - zh * (1.0 / 42.0) * ps_h;
-  ps_h = 1.0 - zh * (1.0 / 20.0) * ps_h;
-  ps_h = 1.0 - zh * (1.0 / 6.0) * ps_h;
-  double pc_h = 1.0 - zh * (1.0 / 240.0);
-  pc_h = 1.0 - zh * (1.0 / 182.0) * pc_h;
-  pc_h = 1.0 - zh * (1.0 / 132.0) * pc_h;
-  pc_h = 1.0 - zh * (1.0 / 90.0) * pc_h;
-  pc_h = 1.0 - zh * (1.0 / 56.0) * pc_h;
-  pc_h = 1.0 - zh * (1.0 / 30.0) * pc_h;
-  pc_h = 1.0 - zh * (1.0 / 12.0) * pc_h;
   const double imag_factor = 0.5 * ps_h;                          // sin(theta/2) / theta
   const double real_factor = 1.0 - zh * 0.5 * pc_h;               // cos(theta/2)
   double c1 = 0.5 * pc_t;                                         // (1 - cos theta) / theta^2

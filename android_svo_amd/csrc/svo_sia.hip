@@ -719,6 +719,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   __shared__ double s_Hc[21], s_fac[36], s_inv[36];   // H of the previous evaluation, its LDL^T factor, H^-1 by columns
   __shared__ int s_ftr[6], s_fac_valid;
   __shared__ double s_model[8], s_old[8];
+  __shared__ double s_coef[32];                               // se3_exp_series_table
   __shared__ double s_chi2;
   __shared__ int s_done, s_stop, s_iter;
   __shared__ unsigned s_npre;
@@ -766,6 +767,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     se3_inverse(c.T_ref_w, Tinv);
     se3_mul(c.T_cur_w_init, Tinv, T);                        // sparse_img_align.cpp:69
     for (int i = 0; i < 7; ++i) { s_model[i] = T[i]; s_old[i] = T[i]; }
+    se3_exp_series_table(s_coef);
     s_chi2 = 1e10;                                           // reset(), nlls_solver_impl.hpp:299-309
     s_stop = 0; s_done = 0; s_iter = 0; s_npre = 0; s_nres = 0; s_nmeas = 0; s_fac_valid = 0;
     for (int i = 0; i < SVO_HIP_MAX_LEVELS; ++i) s_iters[i] = 0;
@@ -1151,6 +1153,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
 #pragma unroll
         for (int i = 0; i < 7; ++i) cur[i] = s_model[i];
         const double chi2_old = s_chi2;
+        double coef[8];                      // this lane's column of the exp series table
+#pragma unroll
+        for (int k = 0; k < 8; ++k) coef[k] = s_coef[k * 4 + (lane & 3)];
         const int it = s_iter, stop_old = s_stop, iters_l = s_iters[level];
         const double nres_old = s_nres;
         double v = 0.0;
@@ -1231,6 +1236,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         double x[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) x[i] = readlane_f64(xi, i);
+        // the four series of exp(-x) on lanes 0..3 (theta^2 is the same for x and -x), collected wave-uniform
+        const double zt = x[3] * x[3] + x[4] * x[4] + x[5] * x[5];
+        const double ser = se3_exp_series_lane(coef, (lane & 2) ? 0.25 * zt : zt);
+        const double qs_t = readlane_f64(ser, 0), pc_t = readlane_f64(ser, 1), ps_h = readlane_f64(ser, 2), pc_h = readlane_f64(ser, 3);
 #ifdef SVO_STAMPS
         const long long q1 = __builtin_amdgcn_s_memtime();
         if (lane == 0) s_stamp[3] += q1 - q0;
@@ -1256,7 +1265,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
 #ifdef SVO_STAMPS
             const long long q2 = __builtin_amdgcn_s_memtime();
 #endif
-            se3_exp_small(mx, dT);
+            if (zt <= 0.25) se3_exp_small_finish(mx, zt, qs_t, pc_t, ps_h, pc_h, dT);
+            else se3_exp(mx, dT);                                                // large angles: the library path
             se3_mul(cur, dT, nm);                                                // T_new = T_old * exp(-x) (:307)
 #ifdef SVO_STAMPS
             const long long q3 = __builtin_amdgcn_s_memtime();
