@@ -1156,6 +1156,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         double coef[8];                      // this lane's column of the exp series table
 #pragma unroll
         for (int k = 0; k < 8; ++k) coef[k] = s_coef[k * 4 + (lane & 3)];
+        double inv_row[6];                   // lanes 0..5: their row of H^-1 (re-read below if H changed)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) inv_row[j] = s_inv[(lane < 6 ? lane : 0) * 6 + j];
         const int it = s_iter, stop_old = s_stop, iters_l = s_iters[level];
         const double nres_old = s_nres;
         double v = 0.0;
@@ -1225,14 +1228,13 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           }
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+          for (int j = 0; j < 6; ++j) inv_row[j] = s_inv[(lane < 6 ? lane : 0) * 6 + j];
         }
         // x = H^-1 Jres, one component per lane (H^-1 is symmetric: lane i uses the column it computed as row i)
-        double xi = 0.0;
-        if (lane < 6) {
-          xi = s_inv[lane * 6] * Jres[0];
+        double xi = inv_row[0] * Jres[0];
 #pragma unroll
-          for (int j = 1; j < 6; ++j) xi += s_inv[lane * 6 + j] * Jres[j];
-        }
+        for (int j = 1; j < 6; ++j) xi += inv_row[j] * Jres[j];
         double x[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) x[i] = readlane_f64(xi, i);
@@ -1275,10 +1277,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
 #pragma unroll
             for (int i = 0; i < 7; ++i) { s_old[i] = cur[i]; s_model[i] = nm[i]; }
             s_chi2 = new_chi2;
-            double mxn = -1;
+            if (prm.early_stop) {                                                // :97-98
+              double mxn = -1;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { double a = fabs(x[i]); if (a > mxn) mxn = a; }
-            if (prm.early_stop && mxn <= prm.eps) s_done = 1;                    // :97-98
+              for (int i = 0; i < 6; ++i) { double a = fabs(x[i]); if (a > mxn) mxn = a; }
+              if (mxn <= prm.eps) s_done = 1;
+            }
             s_iter = it + 1;
             if (it + 1 >= prm.n_iter) s_done = 1;
 #ifdef SVO_STAMPS
