@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (not part of the product or of bench.py): run the fused SparseImgAlign kernel from a build with
--DSVO_STAMPS (build/libsvo_hip_stamps.so) and print where wave 1 of each workgroup spends its cycles per
+-DSVO_STAMPS (`make -C android_svo_amd/csrc stamps` -> build/libsvo_hip_stamps.so) and print where wave 1 of each workgroup spends its cycles per
 Gauss-Newton evaluation: evaluation+wave reduction / first barrier wait / sum over the waves + one-lane solve + barrier."""
 import os
 import sys
