@@ -607,6 +607,7 @@ constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_WAVES = FUSED_THREADS / 64;
 constexpr int FUSED_MAX_TILES = 44;               // 2816 patches: 6 tiles on an older wave, 5 on a younger one
 constexpr int FUSED_WC_BYTES = TILE * 128;        // interpolated reference patches of one tile
+constexpr int FUSED_EXTRA_TILES = 2;              // 8-wave shape: LDS tiles beyond two per wave (160 KiB - static LDS)
 constexpr int FUSED_MAX_TPW = 6;                  // the older wave's share of a SIMD's 11 tiles
 
 struct FusedLevels {
@@ -699,14 +700,19 @@ struct FusedPlan {
 // VGPRs, so that TWO workgroups -- two independent frame pairs -- share a CU: while one of them is in the one-lane
 // phase between its barriers the other one has the SIMDs to itself (used when a launch holds at least two pairs per
 // CU).
+SVO_DEV int wave_of_thread() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
 template <int NW, int TPW, int CK>
 __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
     const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
     const double* __restrict__ f, const double* __restrict__ pos, const uint8_t* __restrict__ has_point,
     double4* __restrict__ sxyz, double* __restrict__ tile_h, float4* __restrict__ wmem, int max_tiles, FusedParams prm,
-    int tiles_young) {
+    int tiles_young, int n_extra) {
   using Plan = FusedPlan<TPW, CK>;
+  // the LDS left over holds one more tile -- the first one the plan keeps in memory -- for the first n_extra waves
+  constexpr int P_EXTRA = (CK > 0 && TPW > CK) ? 1 : -1;         // plan order is L G L G ...: position 1
+  const bool extra_lds = wave_of_thread() < n_extra;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // The interpolated reference patch of every feature -- the 32 values W from which reference value, dx and dy of its
   // 16 pixels are differences (128 B, halved, see below) -- is formed once per level.  CK tiles of every wave keep
@@ -882,7 +888,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         if (valid) {
           // halved (exact), in the order the evaluation reads them: rows 0 and 5 without their corners
           float4* dst = Plan::in_lds(k) ? wc + (size_t)((Plan::lds_slot(k) * NW + wave) * 8) * TILE + lane
-                                        : wmem + ((size_t)b * max_tiles + tile) * 8 * TILE + lane;
+                        : (k == P_EXTRA && extra_lds) ? wc + (size_t)((CK * NW + wave) * 8) * TILE + lane
+                                                      : wmem + ((size_t)b * max_tiles + tile) * 8 * TILE + lane;
           float q[32];
           int e = 0;
 #pragma unroll
@@ -1002,6 +1009,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           const float4* src = wc + (size_t)((Plan::lds_slot(k) * NW + wave) * 8) * TILE + lane;
 #pragma unroll
           for (int c4 = 0; c4 < 8; ++c4) Wq[c4] = src[c4 * TILE];
+        } else if (k == P_EXTRA && extra_lds) {                // wave-uniform: this wave's extra LDS tile
+          const float4* src = wc + (size_t)((CK * NW + wave) * 8) * TILE + lane;
+#pragma unroll
+          for (int c4 = 0; c4 < 8; ++c4) Wq[c4] = src[c4 * TILE];
         } else {
 #pragma unroll
           for (int c4 = 0; c4 < 8; ++c4) Wq[c4] = Wn[c4];
@@ -1013,8 +1024,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           if (!Plan::in_lds(k + 1)) {
             const int tile_n = tile_of(k + 1) < n_tiles ? tile_of(k + 1) : (tile < n_tiles ? tile : 0);
             const float4* src = wmem + ((size_t)b * max_tiles + tile_n) * 8 * TILE + lane;
+            // (a wave that keeps this tile in LDS asks for the same 1 KiB eight times instead: no branch, no traffic)
+            const int c4_stride = (k + 1 == P_EXTRA && extra_lds) ? 0 : TILE;
 #pragma unroll
-            for (int c4 = 0; c4 < 8; ++c4) Wn[c4] = src[c4 * TILE];
+            for (int c4 = 0; c4 < 8; ++c4) Wn[c4] = src[c4 * c4_stride];
           }
         }
         if (tile >= n_tiles) continue;                       // wave-uniform: the tiles that follow do not exist either
@@ -1424,11 +1437,11 @@ int fused_tiles_per_wave(const svo_hip_sia* s, int n_slots) {
 }
 
 template <int NW, int TPW, int CK>
-int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes, int tiles_young) {
+int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes, int tiles_young, int n_extra = 0) {
   svo_hip_ctx* ctx = s->ctx;
   // > 64 KiB of dynamic LDS has to be allowed explicitly (per device: set it on every launch, it is cheap)
   SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<NW, TPW, CK>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NW * FUSED_WC_BYTES));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (2 * NW + FUSED_EXTRA_TILES) * FUSED_WC_BYTES));
   FusedLevels lv;
   memset(&lv, 0, sizeof(lv));
   for (int l = 0; l < s->ref->n_levels; ++l) {
@@ -1442,7 +1455,7 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
   hipLaunchKernelGGL((sia_fused_kernel<NW, TPW, CK>), dim3(n_slots), dim3(NW * 64), lds_bytes, ctx->stream, s->fc, s->st,
                      s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, s->tile_h,
-                     s->wmem, s->max_tiles, fp, tiles_young);
+                     s->wmem, s->max_tiles, fp, tiles_young, n_extra);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
@@ -1485,14 +1498,17 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tp
   SVO_REQUIRE(ctx, ty >= 0 && ty <= tpw);
   // two tiles per wave keep their interpolated patches in LDS (8 waves x 2 x 8 KiB), the others in memory
   const int ck = tpw < 2 ? tpw : 2;
-  const size_t lds = (size_t)FUSED_WAVES * ck * FUSED_WC_BYTES;
+  int n_extra = tpw > ck ? FUSED_EXTRA_TILES : 0;
+  { const char* ex = getenv("SVO_HIP_SIA_EXTRA_LDS"); if (ex) n_extra = tpw > ck ? atoi(ex) : 0; }   // diagnostic override
+  if (n_extra < 0 || n_extra > FUSED_EXTRA_TILES) n_extra = 0;
+  const size_t lds = (size_t)(FUSED_WAVES * ck + n_extra) * FUSED_WC_BYTES;
   switch (tpw) {                 // tiles of an older wave
     case 1: return launch_fused_t<8, 1, 1>(s, n_slots, prm, lds, ty);
     case 2: return launch_fused_t<8, 2, 2>(s, n_slots, prm, lds, ty);
-    case 3: return launch_fused_t<8, 3, 2>(s, n_slots, prm, lds, ty);
-    case 4: return launch_fused_t<8, 4, 2>(s, n_slots, prm, lds, ty);
-    case 5: return launch_fused_t<8, 5, 2>(s, n_slots, prm, lds, ty);
-    case 6: return launch_fused_t<8, 6, 2>(s, n_slots, prm, lds, ty);
+    case 3: return launch_fused_t<8, 3, 2>(s, n_slots, prm, lds, ty, n_extra);
+    case 4: return launch_fused_t<8, 4, 2>(s, n_slots, prm, lds, ty, n_extra);
+    case 5: return launch_fused_t<8, 5, 2>(s, n_slots, prm, lds, ty, n_extra);
+    case 6: return launch_fused_t<8, 6, 2>(s, n_slots, prm, lds, ty, n_extra);
     default: break;
   }
   return svo_fail(ctx, SVO_HIP_ERR_INVALID, "fused SparseImgAlign", "unsupported tiles-per-wave");
