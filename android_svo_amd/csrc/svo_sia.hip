@@ -977,6 +977,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
                                 __builtin_amdgcn_readfirstlane(__double2loint(v)));
       }
       double accH = 0.0;
+      unsigned gone_changed = 0;                              // bit k: tile k's outside-the-image set changed
       double accJ[6] = {0, 0, 0, 0, 0, 0};
       double acc_chi = 0.0;
       unsigned acc_n = 0;
@@ -1031,7 +1032,6 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           }
         }
         if (tile >= n_tiles) continue;                       // wave-uniform: the tiles that follow do not exist either
-        const int tile_base = tile * TILE;
         // ---- projection into the current image (:220-236): done one tile ahead
         const LppGeom g = gq[k & 1];
         const bool ok = g.ok;
@@ -1099,17 +1099,31 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           accJ[5] += v * sdx - u * sdy;
         }
         // H of the tile = its per-level row minus the patches that are outside the current image now (:76, :226-229).
-        // th[k] holds the row with the patches that were outside at the previous evaluation already taken out; that
-        // set changes rarely (after convergence it does not change at all), so the correction -- one dependent
-        // memory access and a 21-entry rank update per patch, done one patch after the other -- is only redone
-        // when the set differs from the last evaluation's
+        // The stored row has the patches that were outside at the previous evaluation already taken out; that set
+        // changes rarely (after convergence it does not change at all).  Here only the change is noted: the
+        // correction itself reads memory, and a load inside this loop -- even in a branch that is almost never taken
+        // -- makes the compiler drain the loads in flight at every tile.
         const bool out_now = jvalid && !ok;
         const unsigned long long gone_now = __ballot(out_now);
         const unsigned long long gone_prev = __ballot((fl[k] & F_GONE) != 0);
         if (gone_now != gone_prev) {                           // wave-uniform
+          gone_changed |= 1u << k;
+          fl[k] = (uint8_t)((fl[k] & ~F_GONE) | (out_now ? F_GONE : 0));
+        }
+      }
+
+      __builtin_amdgcn_s_setprio(0);
+      // rows of the tiles whose outside-the-image set changed: one dependent memory access and a 21-entry rank update
+      // per patch, one patch after the other (rare)
+      if (gone_changed) {                                      // wave-uniform
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+          if (!((gone_changed >> k) & 1u)) continue;
+          const int tile = tile_of(k);
+          const int tile_base = tile * TILE;
           double t = 0.0;
           if (lane < 21) t = tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane];
-          unsigned long long gone = gone_now;
+          unsigned long long gone = __ballot((fl[k] & F_GONE) != 0);
           while (gone) {
             const int src = __ffsll((long long)gone) - 1;
             gone &= gone - 1;
@@ -1128,12 +1142,14 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
             t -= h;
           }
           th_set(k, t);
-          fl[k] = (uint8_t)((fl[k] & ~F_GONE) | (out_now ? F_GONE : 0));
         }
-        { const double thk = th_get(k); if (lane < 21) accH += thk; }
+      }
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {                          // rows of tiles that do not exist are zero
+        const double thk = th_get(k);
+        if (lane < 21) accH += thk;
       }
 
-      __builtin_amdgcn_s_setprio(0);
       pf_off = off0;
 #pragma unroll
       for (int j = 0; j < 5; ++j) pf[j] = load_row8(cur_img + off0 + j * stride);
