@@ -92,6 +92,16 @@ struct LevelGeom {
 struct Shard { int rank, world; };
 
 // upper-triangle (row-major) index -> (i, j)
+// se3_exp_series_table (svo_device_math.h), [step][column]
+__device__ __constant__ double kExpSeries[32] = {
+    0.0,         0.0,         1.0 / 272.0, 0.0,
+    1.0 / 272.0, 1.0 / 240.0, 1.0 / 210.0, 1.0 / 240.0,
+    1.0 / 210.0, 1.0 / 182.0, 1.0 / 156.0, 1.0 / 182.0,
+    1.0 / 156.0, 1.0 / 132.0, 1.0 / 110.0, 1.0 / 132.0,
+    1.0 / 110.0, 1.0 / 90.0,  1.0 / 72.0,  1.0 / 90.0,
+    1.0 / 72.0,  1.0 / 56.0,  1.0 / 42.0,  1.0 / 56.0,
+    1.0 / 42.0,  1.0 / 30.0,  1.0 / 20.0,  1.0 / 30.0,
+    1.0 / 20.0,  1.0 / 12.0,  1.0 / 6.0,   1.0 / 12.0};
 __device__ __constant__ int8_t kTriI[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
 // the same tables for compile-time indices (unrolled loops)
 constexpr int kTriIc[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
@@ -607,7 +617,7 @@ constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_WAVES = FUSED_THREADS / 64;
 constexpr int FUSED_MAX_TILES = 44;               // 2816 patches: 6 tiles on an older wave, 5 on a younger one
 constexpr int FUSED_WC_BYTES = TILE * 128;        // interpolated reference patches of one tile
-constexpr int FUSED_EXTRA_TILES = 2;              // 8-wave shape: LDS tiles beyond two per wave (160 KiB - static LDS)
+constexpr int FUSED_EXTRA_TILES = 3;              // 8-wave shape: at most this many LDS tiles beyond two per wave
 constexpr int FUSED_MAX_TPW = 6;                  // the older wave's share of a SIMD's 11 tiles
 
 struct FusedLevels {
@@ -711,7 +721,11 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     int tiles_young, int n_extra) {
   using Plan = FusedPlan<TPW, CK>;
   // the LDS left over holds one more tile -- the first one the plan keeps in memory -- for the first n_extra waves
-  constexpr int P_EXTRA = (CK > 0 && TPW > CK) ? 1 : -1;         // plan order is L G L G ...: position 1
+  // (kernels whose waves own five or six tiles are register-bound: for them the extra LDS slot and the deferred
+  // outside-the-image correction below cost more in spills than they save -- measured at 2500 patches: 2.02 ms
+  // without either, 2.36 ms with the slot, 2.98 ms with both)
+  constexpr bool LEAN = TPW >= 5;
+  constexpr int P_EXTRA = (!LEAN && CK > 0 && TPW > CK) ? 1 : -1;   // plan order is L G L G ...: position 1
   const bool extra_lds = wave_of_thread() < n_extra;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // The interpolated reference patch of every feature -- the 32 values W from which reference value, dx and dy of its
@@ -719,13 +733,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   // theirs in LDS ([slot][8][64] float4, slot = position * 8 + wave), the others in memory ([frame][tile][8][64]
   // float4, L2 / Infinity-Cache resident: 8 coalesced 1-KiB loads per tile and evaluation, issued one tile ahead).
   float4* wc = reinterpret_cast<float4*>(smem);
-  __shared__ double red[NW][32];
+  __shared__ double red[NW][29];                              // 21 H + 6 Jres + chi2 + n_meas per wave
   __shared__ double s_th[NW * TPW * 21];                      // per-tile H rows (lane e keeps entry e)
-  __shared__ double s_last[32], s_x[8];
-  __shared__ double s_Hc[21], s_fac[36], s_inv[36];   // H of the previous evaluation, its LDL^T factor, H^-1 by columns
+  __shared__ double s_x[8];
+  __shared__ double s_Hc[21], s_fac[21], s_inv[36];   // H of the previous evaluation, its LDL^T factor (lower triangle), H^-1 by columns
   __shared__ int s_ftr[6], s_fac_valid;
   __shared__ double s_model[8], s_old[8];
-  __shared__ double s_coef[32];                               // se3_exp_series_table
   __shared__ double s_chi2;
   __shared__ int s_done, s_stop, s_iter;
   __shared__ unsigned s_npre;
@@ -767,20 +780,18 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   auto th_get = [&](int k) -> double { return lane < 21 ? s_th[(wave * TPW + k) * 21 + lane] : 0.0; };
   auto th_set = [&](int k, double v) { if (lane < 21) s_th[(wave * TPW + k) * 21 + lane] = v; };
 
-  if (lane >= 29 && lane < 32) red[wave][lane] = 0.0;       // unused slots of the wave partial rows
   if (threadIdx.x == 0) {
     double Tinv[7], T[7];
     se3_inverse(c.T_ref_w, Tinv);
     se3_mul(c.T_cur_w_init, Tinv, T);                        // sparse_img_align.cpp:69
     for (int i = 0; i < 7; ++i) { s_model[i] = T[i]; s_old[i] = T[i]; }
-    se3_exp_series_table(s_coef);
     s_chi2 = 1e10;                                           // reset(), nlls_solver_impl.hpp:299-309
     s_stop = 0; s_done = 0; s_iter = 0; s_npre = 0; s_nres = 0; s_nmeas = 0; s_fac_valid = 0;
     for (int i = 0; i < SVO_HIP_MAX_LEVELS; ++i) s_iters[i] = 0;
-    for (int i = 0; i < 32; ++i) s_last[i] = 0.0;
     for (int i = 0; i < 8; ++i) s_x[i] = 0.0;
   }
 
+  double v_last = 0.0;                                       // wave 0, lanes 0..28: sums of the last evaluation
   // ---- lane-per-patch persistent state of the wave's tiles
   double4 X[TPW];
   uint8_t fl[TPW];
@@ -1109,13 +1120,38 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         if (gone_now != gone_prev) {                           // wave-uniform
           gone_changed |= 1u << k;
           fl[k] = (uint8_t)((fl[k] & ~F_GONE) | (out_now ? F_GONE : 0));
+          if (LEAN) {                                          // register-bound shapes: correct the row right here
+            const int tile_base = tile * TILE;
+            double t = 0.0;
+            if (lane < 21) t = tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane];
+            unsigned long long gone = gone_now;
+            while (gone) {
+              const int src = __ffsll((long long)gone) - 1;
+              gone &= gone - 1;
+              const double gx_ = __shfl(X[k].x, src, 64), gy_ = __shfl(X[k].y, src, 64), gzi = __shfl(X[k].w, src, 64);
+              const double4 G4 = sxyz[(size_t)b * max_n + tile_base + src];
+              const double g_xx = G4.x, g_xy = G4.y, g_yy = G4.z;
+              double A[6], B[6];
+              patch_jacobian_rows(gx_, gy_, gzi, jscale, A, B);
+              double Ai = A[0], Aj = A[0], Bi = B[0], Bj = B[0];
+#pragma unroll
+              for (int kk = 1; kk < 6; ++kk) {
+                if (tri_i == kk) { Ai = A[kk]; Bi = B[kk]; }
+                if (tri_j == kk) { Aj = A[kk]; Bj = B[kk]; }
+              }
+              const double h = g_xx * (Ai * Aj) + g_xy * (Ai * Bj + Bi * Aj) + g_yy * (Bi * Bj);
+              t -= h;
+            }
+            th_set(k, t);
+          }
         }
+        if (LEAN) { const double thk = th_get(k); if (lane < 21) accH += thk; }
       }
 
       __builtin_amdgcn_s_setprio(0);
       // rows of the tiles whose outside-the-image set changed: one dependent memory access and a 21-entry rank update
       // per patch, one patch after the other (rare)
-      if (gone_changed) {                                      // wave-uniform
+      if (!LEAN && gone_changed) {                             // wave-uniform
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
           if (!((gone_changed >> k) & 1u)) continue;
@@ -1144,10 +1180,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           th_set(k, t);
         }
       }
+      if (!LEAN) {
 #pragma unroll
-      for (int k = 0; k < TPW; ++k) {                          // rows of tiles that do not exist are zero
-        const double thk = th_get(k);
-        if (lane < 21) accH += thk;
+        for (int k = 0; k < TPW; ++k) {                        // rows of tiles that do not exist are zero
+          const double thk = th_get(k);
+          if (lane < 21) accH += thk;
+        }
       }
 
       pf_off = off0;
@@ -1184,18 +1222,18 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         const double chi2_old = s_chi2;
         double coef[8];                      // this lane's column of the exp series table
 #pragma unroll
-        for (int k = 0; k < 8; ++k) coef[k] = s_coef[k * 4 + (lane & 3)];
+        for (int k = 0; k < 8; ++k) coef[k] = kExpSeries[k * 4 + (lane & 3)];
         double inv_row[6];                   // lanes 0..5: their row of H^-1 (re-read below if H changed)
 #pragma unroll
         for (int j = 0; j < 6; ++j) inv_row[j] = s_inv[(lane < 6 ? lane : 0) * 6 + j];
         const int it = s_iter, stop_old = s_stop, iters_l = s_iters[level];
         const double nres_old = s_nres;
         double v = 0.0;
-        if (lane < 32) {
+        if (lane < 29) {
 #pragma unroll
           for (int w = 0; w < NW; ++w) v += red[w][lane];
-          s_last[lane] = v;                  // H_ / Jres_ of the last evaluation, reported at the end
         }
+        v_last = v;                          // H_ / Jres_ of the last evaluation, reported at the end
         // H is the sum of the per-level tile rows minus the patches outside the image at this evaluation: as long as
         // that set does not change it is bit for bit the H of the previous evaluation, and what was derived from it
         // is reused (a deterministic function of H, so the result is the same number)
@@ -1235,7 +1273,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
             for (int i = 0; i < 6; ++i) {
               s_ftr[i] = tr[i];
 #pragma unroll
-              for (int j = 0; j <= i; ++j) s_fac[i * 6 + j] = m[i][j];
+              for (int j = 0; j <= i; ++j) s_fac[i * (i + 1) / 2 + j] = m[i][j];
             }
             s_fac_valid = 1;
           }
@@ -1249,7 +1287,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
               tr[i] = __builtin_amdgcn_readfirstlane(s_ftr[i]);
               e[i] = lane == i ? 1.0 : 0.0;
 #pragma unroll
-              for (int j = 0; j <= i; ++j) m[i][j] = s_fac[i * 6 + j];
+              for (int j = 0; j <= i; ++j) m[i][j] = s_fac[i * (i + 1) / 2 + j];
             }
             ldlt6_substitute_reg(m, tr, e, col);
 #pragma unroll
@@ -1331,6 +1369,11 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     __syncthreads();
   }
 
+  if (wave == 0 && lane < 27) {                              // H_ (upper triangle, mirrored) and Jres_ of the last evaluation
+    FrameState& s = st[b];
+    if (lane < 21) { s.H[tri_i * 6 + tri_j] = v_last; s.H[tri_j * 6 + tri_i] = v_last; }
+    else s.Jres[lane - 21] = v_last;
+  }
   if (threadIdx.x == 0) {
     FrameState& s = st[b];
     double T[7], m[7];
@@ -1340,10 +1383,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     s.chi2 = s_chi2; s.stop = s_stop; s.iter = s_iter; s.level_done = 1; s.empty = empty;
     s.n_meas = (unsigned long long)(s_nmeas + 0.5); s.n_res = (unsigned long long)(s_nres + 0.5); s.n_pre = s_npre;
     {
-      int kk = 0;
-      for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) { s.H[i * 6 + j] = s_last[kk]; s.H[j * 6 + i] = s_last[kk]; ++kk; }
-      for (int i = 0; i < 6; ++i) { s.Jres[i] = s_last[21 + i]; s.x[i] = s_x[i]; }
+      for (int i = 0; i < 6; ++i) s.x[i] = s_x[i];
 #ifdef SVO_STAMPS
       for (int i = 0; i < 16; ++i) s.H[i] = (double)s_wst[i];
       for (int i = 5; i < 10; ++i) s.H[16 + i - 5] = (double)s_stamp[i];
@@ -1457,7 +1497,7 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   svo_hip_ctx* ctx = s->ctx;
   // > 64 KiB of dynamic LDS has to be allowed explicitly (per device: set it on every launch, it is cheap)
   SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<NW, TPW, CK>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (2 * NW + FUSED_EXTRA_TILES) * FUSED_WC_BYTES));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   FusedLevels lv;
   memset(&lv, 0, sizeof(lv));
   for (int l = 0; l < s->ref->n_levels; ++l) {
@@ -1475,6 +1515,30 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
+}
+
+// LDS tiles (8 KiB) the 8-wave shape can hold beyond ck per wave: what 160 KiB leave next to the kernel's static LDS
+template <int TPW, int CK>
+int fused_extra_tiles_t() {
+  static int cached = -1;
+  if (cached < 0) {
+    hipFuncAttributes at;
+    cached = 0;
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&sia_fused_kernel<8, TPW, CK>)) == hipSuccess) {
+      const long free_b = 160L * 1024 - (long)at.sharedSizeBytes - (long)FUSED_WAVES * CK * FUSED_WC_BYTES;
+      cached = free_b > 0 ? (int)(free_b / FUSED_WC_BYTES) : 0;
+      if (cached > FUSED_EXTRA_TILES) cached = FUSED_EXTRA_TILES;
+    }
+  }
+  return cached;
+}
+int fused_extra_tiles(int tpw, int ck) {
+  (void)ck;
+  switch (tpw) {
+    case 3: return fused_extra_tiles_t<3, 2>();
+    case 4: return fused_extra_tiles_t<4, 2>();
+    default: return 0;
+  }
 }
 
 int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tpw) {
@@ -1514,9 +1578,9 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tp
   SVO_REQUIRE(ctx, ty >= 0 && ty <= tpw);
   // two tiles per wave keep their interpolated patches in LDS (8 waves x 2 x 8 KiB), the others in memory
   const int ck = tpw < 2 ? tpw : 2;
-  int n_extra = tpw > ck ? FUSED_EXTRA_TILES : 0;
+  int n_extra = tpw > ck ? fused_extra_tiles(tpw, ck) : 0;
   { const char* ex = getenv("SVO_HIP_SIA_EXTRA_LDS"); if (ex) n_extra = tpw > ck ? atoi(ex) : 0; }   // diagnostic override
-  if (n_extra < 0 || n_extra > FUSED_EXTRA_TILES) n_extra = 0;
+  if (n_extra < 0 || n_extra > (tpw > ck ? fused_extra_tiles(tpw, ck) : 0)) n_extra = 0;
   const size_t lds = (size_t)(FUSED_WAVES * ck + n_extra) * FUSED_WC_BYTES;
   switch (tpw) {                 // tiles of an older wave
     case 1: return launch_fused_t<8, 1, 1>(s, n_slots, prm, lds, ty);
