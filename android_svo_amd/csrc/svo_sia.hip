@@ -736,6 +736,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   __shared__ double red[NW][29];                              // 21 H + 6 Jres + chi2 + n_meas per wave
   __shared__ double s_th[NW * TPW * 21];                      // per-tile H rows (lane e keeps entry e)
   __shared__ double s_x[8];
+  __shared__ double s_last[TPW >= 5 ? 29 : 1];               // register-bound shapes only (see LEAN below)
   __shared__ double s_Hc[21], s_fac[21], s_inv[36];   // H of the previous evaluation, its LDL^T factor (lower triangle), H^-1 by columns
   __shared__ int s_ftr[6], s_fac_valid;
   __shared__ double s_model[8], s_old[8];
@@ -792,6 +793,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   }
 
   double v_last = 0.0;                                       // wave 0, lanes 0..28: sums of the last evaluation
+  if (LEAN && threadIdx.x < 29) s_last[threadIdx.x] = 0.0;
   // ---- lane-per-patch persistent state of the wave's tiles
   double4 X[TPW];
   uint8_t fl[TPW];
@@ -1233,7 +1235,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
 #pragma unroll
           for (int w = 0; w < NW; ++w) v += red[w][lane];
         }
-        v_last = v;                          // H_ / Jres_ of the last evaluation, reported at the end
+        // H_ / Jres_ of the last evaluation are reported at the end: carried in a register, or -- by the register-bound
+        // shapes, which have the LDS to spare -- kept in LDS
+        if (!LEAN) v_last = v;
+        else if (lane < 29) s_last[lane] = v;
         // H is the sum of the per-level tile rows minus the patches outside the image at this evaluation: as long as
         // that set does not change it is bit for bit the H of the previous evaluation, and what was derived from it
         // is reused (a deterministic function of H, so the result is the same number)
@@ -1369,7 +1374,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     __syncthreads();
   }
 
-  if (wave == 0 && lane < 27) {                              // H_ (upper triangle, mirrored) and Jres_ of the last evaluation
+  if (!LEAN && wave == 0 && lane < 27) {                     // H_ (upper triangle, mirrored) and Jres_ of the last evaluation
     FrameState& s = st[b];
     if (lane < 21) { s.H[tri_i * 6 + tri_j] = v_last; s.H[tri_j * 6 + tri_i] = v_last; }
     else s.Jres[lane - 21] = v_last;
@@ -1384,6 +1389,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     s.n_meas = (unsigned long long)(s_nmeas + 0.5); s.n_res = (unsigned long long)(s_nres + 0.5); s.n_pre = s_npre;
     {
       for (int i = 0; i < 6; ++i) s.x[i] = s_x[i];
+      if (LEAN) {
+        int kk = 0;
+        for (int i = 0; i < 6; ++i)
+          for (int j = i; j < 6; ++j) { s.H[i * 6 + j] = s_last[kk]; s.H[j * 6 + i] = s_last[kk]; ++kk; }
+        for (int i = 0; i < 6; ++i) s.Jres[i] = s_last[21 + i];
+      }
 #ifdef SVO_STAMPS
       for (int i = 0; i < 16; ++i) s.H[i] = (double)s_wst[i];
       for (int i = 5; i < 10; ++i) s.H[16 + i - 5] = (double)s_stamp[i];
