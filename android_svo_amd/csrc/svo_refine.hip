@@ -19,6 +19,7 @@ using namespace svo_dev;
 
 constexpr int PR_THREADS = 256;
 constexpr int PR_WAVES = PR_THREADS / 64;
+constexpr int PR_CACHED = 8;                    // feature slots per thread kept in registers (frames up to 2048 features)
 
 struct PoseOptOut {               // == svo_hip_pose_opt_result
   int ran;
@@ -53,22 +54,21 @@ SVO_DEV void unit_plane_error(const double* T, const double* f, const double* po
   e[0] *= s; e[1] *= s;
 }
 
-// k-th smallest (0-based) of the keys of the valid entries, all threads of the block take part and get the key.
+// k-th smallest (0-based) of the keys for_each_key enumerates (every thread its own), all threads of the block take
+// part and get the key.
 // Keys are bit patterns of non-negative IEEE numbers (monotonic as unsigned integers).  hist: 256 ints of LDS.
-template <typename KeyT, typename GetKey>
-__device__ KeyT block_radix_select(int n, unsigned k, GetKey get_key, int* hist, KeyT* s_prefix, unsigned* s_k) {
+template <typename KeyT, typename ForEachKey>
+__device__ KeyT block_radix_select(unsigned k, ForEachKey for_each_key, int* hist, KeyT* s_prefix, unsigned* s_k) {
   constexpr int BITS = 8 * (int)sizeof(KeyT);
   if (threadIdx.x == 0) { *s_prefix = 0; *s_k = k; }
   for (int shift = BITS - 8; shift >= 0; shift -= 8) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     const KeyT prefix = *s_prefix;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      KeyT key;
-      if (!get_key(i, &key)) continue;
+    for_each_key([&](KeyT key) {
       const bool match = (shift == BITS - 8) ? true : ((key >> (shift + 8)) == prefix);
       if (match) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
-    }
+    });
     __syncthreads();
     if (threadIdx.x < 64) {                    // wave 0: 4 bins per lane, exclusive scan, pick the digit
       const int lane = threadIdx.x;
@@ -155,6 +155,39 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
   double* sq_final = sq_final_ws + base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
+  // The observations are read 13 times (scale, 10 Gauss-Newton steps, outlier test, ...): the first PR_CACHED ones of
+  // every thread stay in registers -- with one workgroup per frame a pass over them from memory is a chain of
+  // dependent latencies, not bandwidth -- and only what lies beyond (frames above 2048 features) is re-read.
+  double cf[PR_CACHED][3], cp[PR_CACHED][3];
+  int cl[PR_CACHED];
+  bool ch[PR_CACHED], ch0[PR_CACHED];                       // has a point now / had one on entry
+  float cerr[PR_CACHED];                                     // keys of the three medians
+  double csqi[PR_CACHED], csqf[PR_CACHED];
+#pragma unroll
+  for (int j = 0; j < PR_CACHED; ++j) {
+    const int i = threadIdx.x + PR_THREADS * j;
+    const bool in = i < n;
+    const int ii = in ? i : 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { cf[j][c] = in ? fb[3 * ii + c] : 0.0; cp[j][c] = in ? pb[3 * ii + c] : 0.0; }
+    cl[j] = in ? lb[ii] : 0;
+    ch[j] = in && hb[ii] != 0;
+    ch0[j] = ch[j];
+    cerr[j] = 0.0f; csqi[j] = 0.0; csqf[j] = -1.0;
+  }
+  // body(i, j, f, pos, level, has_point&) for every feature slot of this thread; j = register slot, -1 beyond
+  auto for_each_obs = [&](auto&& body) {
+#pragma unroll
+    for (int j = 0; j < PR_CACHED; ++j) {
+      const int i = threadIdx.x + PR_THREADS * j;
+      if (i < n) body(i, j, cf[j], cp[j], cl[j], ch[j]);
+    }
+    for (int i = threadIdx.x + PR_THREADS * PR_CACHED; i < n; i += PR_THREADS) {
+      bool hp = hb[i] != 0;
+      body(i, -1, fb + 3 * i, pb + 3 * i, lb[i], hp);
+    }
+  };
+
   if (threadIdx.x == 0) {
     for (int i = 0; i < 7; ++i) { s_T[i] = T_in[7 * b + i]; s_Told[i] = s_T[i]; }            // :45
     for (int i = 0; i < 36; ++i) s_A[i] = 0.0;
@@ -168,13 +201,14 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
     double T[7];
     for (int i = 0; i < 7; ++i) T[i] = s_T[i];
     unsigned mine = 0;
-    for (int i = threadIdx.x; i < n; i += PR_THREADS) {
-      if (!hb[i]) continue;
+    for_each_obs([&](int i, int j, const double* fo, const double* po, int lv, bool& hp) {
+      if (!hp) return;
       double e[2], xyz[3];
-      unit_plane_error(T, fb + 3 * i, pb + 3 * i, lb[i], e, xyz);
-      err[i] = (float)sqrt(e[0] * e[0] + e[1] * e[1]);
+      unit_plane_error(T, fo, po, lv, e, xyz);
+      const float ef = (float)sqrt(e[0] * e[0] + e[1] * e[1]);
+      if (j >= 0) cerr[j < 0 ? 0 : j] = ef; else err[i] = ef;
       ++mine;
-    }
+    });
     if (mine) atomicAdd(&s_count, mine);
   }
   __syncthreads();
@@ -190,8 +224,11 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
     return;
   }
   const unsigned med_bits = block_radix_select<unsigned>(
-      n, n_obs / 2, [&](int i, unsigned* key) { if (!hb[i]) return false; *key = __float_as_uint(err[i]); return true; },
-      hist, &s_pref32, &s_k);
+      n_obs / 2, [&](auto&& emit) {
+#pragma unroll
+        for (int j = 0; j < PR_CACHED; ++j) if (ch[j]) emit(__float_as_uint(cerr[j]));
+        for (int i = threadIdx.x + PR_THREADS * PR_CACHED; i < n; i += PR_THREADS) if (hb[i]) emit(__float_as_uint(err[i]));
+      }, hist, &s_pref32, &s_k);
   const double estimated_scale = (double)(1.48f * __uint_as_float(med_bits));                  // MADScaleEstimator
   if (threadIdx.x == 0) s_scale = estimated_scale;
   __syncthreads();
@@ -205,13 +242,13 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-    for (int i = threadIdx.x; i < n; i += PR_THREADS) {
-      if (!hb[i]) continue;
+    for_each_obs([&](int i, int j, const double* fo, const double* po, int lv, bool& hp) {
+      if (!hp) return;
       double e[2], xyz[3];
-      unit_plane_error(T, fb + 3 * i, pb + 3 * i, lb[i], e, xyz);
-      const double sqrt_inv_cov = 1.0 / (1 << lb[i]);
+      unit_plane_error(T, fo, po, lv, e, xyz);
+      const double sqrt_inv_cov = 1.0 / (1 << lv);
       const double sq = e[0] * e[0] + e[1] * e[1];
-      if (iter == 0) sq_init[i] = sq;
+      if (iter == 0) { if (j >= 0) csqi[j < 0 ? 0 : j] = sq; else sq_init[i] = sq; }
       // Frame::jacobian_xyz2uv (I/frame.h:110-132) times sqrt_inv_cov
       const double x = xyz[0], y = xyz[1];
       const double z_inv = 1. / xyz[2];
@@ -230,7 +267,7 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
 #pragma unroll
       for (int r = 0; r < 6; ++r) acc[21 + r] -= (J0[r] * e[0] + J1[r] * e[1]) * weight;              // b -= J^T e w
       acc[27] += sq * weight;
-    }
+    });
     // 28 sums: four transposing wave reductions of 8 (lanes 8j..8j+7 get value j), then the waves in fixed order
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -284,14 +321,14 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
     for (int i = 0; i < 7; ++i) T[i] = s_T[i];
     const double thresh = reproj_thresh / em;
     unsigned deleted = 0;
-    for (int i = threadIdx.x; i < n; i += PR_THREADS) {
-      if (!hb[i]) { sq_final[i] = -1.0; continue; }          // negative: not an observation
+    for_each_obs([&](int i, int j, const double* fo, const double* po, int lv, bool& hp) {
+      if (!hp) { if (j < 0) sq_final[i] = -1.0; return; }    // negative: not an observation
       double e[2], xyz[3];
-      unit_plane_error(T, fb + 3 * i, pb + 3 * i, lb[i], e, xyz);
+      unit_plane_error(T, fo, po, lv, e, xyz);
       const double sq = e[0] * e[0] + e[1] * e[1];
-      sq_final[i] = sq;
-      if (sqrt(sq) > thresh) { hb[i] = 0; ++deleted; }
-    }
+      if (j >= 0) csqf[j < 0 ? 0 : j] = sq; else sq_final[i] = sq;
+      if (sqrt(sq) > thresh) { hb[i] = 0; hp = false; ++deleted; }
+    });
     if (deleted) atomicAdd(&s_count, deleted);
   }
   __syncthreads();
@@ -299,16 +336,18 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
   // the observations of the init/final vectors are those that had a point when the function was entered:
   // sq_final >= 0 marks them (has_point was just cleared for the outliers)
   const unsigned long long mi = block_radix_select<unsigned long long>(
-      n, n_obs / 2, [&](int i, unsigned long long* key) {
-        if (sq_final[i] < 0.0) return false;
-        *key = (unsigned long long)__double_as_longlong(sq_init[i]);
-        return true;
+      n_obs / 2, [&](auto&& emit) {
+#pragma unroll
+        for (int j = 0; j < PR_CACHED; ++j) if (ch0[j]) emit((unsigned long long)__double_as_longlong(csqi[j]));
+        for (int i = threadIdx.x + PR_THREADS * PR_CACHED; i < n; i += PR_THREADS)
+          if (sq_final[i] >= 0.0) emit((unsigned long long)__double_as_longlong(sq_init[i]));
       }, hist, &s_pref64, &s_k);
   const unsigned long long mf = block_radix_select<unsigned long long>(
-      n, n_obs / 2, [&](int i, unsigned long long* key) {
-        if (sq_final[i] < 0.0) return false;
-        *key = (unsigned long long)__double_as_longlong(sq_final[i]);
-        return true;
+      n_obs / 2, [&](auto&& emit) {
+#pragma unroll
+        for (int j = 0; j < PR_CACHED; ++j) if (ch0[j]) emit((unsigned long long)__double_as_longlong(csqf[j]));
+        for (int i = threadIdx.x + PR_THREADS * PR_CACHED; i < n; i += PR_THREADS)
+          if (sq_final[i] >= 0.0) emit((unsigned long long)__double_as_longlong(sq_final[i]));
       }, hist, &s_pref64, &s_k);
   if (threadIdx.x == 0) {
     o.ran = 1;
