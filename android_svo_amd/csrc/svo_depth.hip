@@ -1083,22 +1083,27 @@ int svo_hip_reproject_cells(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const 
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   const size_t N = (size_t)n;
   // one device block: px_ref(16) f(24) pos(24) px_cur(16) grad(16) T_kf(56*n_kf) kf_slot(4) level(4) sl(4) edgelet(1) ok(1)
-  const size_t o_pr = 0, o_f = o_pr + 16 * N, o_pos = o_f + 24 * N, o_pc = o_pos + 24 * N, o_g = o_pc + 16 * N,
-               o_T = o_g + 16 * N, o_k = o_T + 56 * (size_t)n_kf, o_l = o_k + 4 * N, o_sl = o_l + 4 * N, o_e = o_sl + 4 * N,
-               o_ok = o_e + N, total = o_ok + N + 64;
+  // one staging layout on both sides: [inputs ...][px_cur (in/out)][search level][matched]; the pageable arguments are
+  // gathered in page-locked memory and cross the link in one transfer each way (nine + three transfers of ~10 us before)
+  const size_t o_pr = 0, o_f = o_pr + 16 * N, o_pos = o_f + 24 * N, o_g = o_pos + 24 * N, o_T = o_g + 16 * N,
+               o_k = o_T + 56 * (size_t)n_kf, o_l = o_k + 4 * N, o_e = o_l + 4 * N, o_pc = (o_e + N + 15) & ~(size_t)15,
+               o_sl = o_pc + 16 * N, o_ok = o_sl + 4 * N, total = o_ok + N + 64;
   char* d = nullptr;
+  char* hs = nullptr;
   {
     const int rc_st = svo_ctx_staging(ctx, total, &d);
     if (rc_st != SVO_HIP_OK) return rc_st;
+    const int rc_hs = svo_ctx_host_staging(ctx, total, &hs);
+    if (rc_hs != SVO_HIP_OK) return rc_hs;
   }
-  hipError_t e = hipSuccess;
-  auto up = [&](size_t off, const void* src, size_t bytes) { if (e == hipSuccess && src) e = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, ctx->stream); };
-  up(o_pr, px_ref, 16 * N); up(o_f, f_ref, 24 * N); up(o_pos, pt_pos, 24 * N); up(o_pc, px_cur, 16 * N);
-  up(o_g, grad, 16 * N); up(o_T, T_kf_w, 56 * (size_t)n_kf); up(o_k, kf_slot, 4 * N); up(o_l, level_ref, 4 * N);
-  up(o_e, edgelet, N);
+  auto put = [&](size_t off, const void* src, size_t bytes) { if (src) memcpy(hs + off, src, bytes); };
+  put(o_pr, px_ref, 16 * N); put(o_f, f_ref, 24 * N); put(o_pos, pt_pos, 24 * N); put(o_g, grad, 16 * N);
+  put(o_T, T_kf_w, 56 * (size_t)n_kf); put(o_k, kf_slot, 4 * N); put(o_l, level_ref, 4 * N); put(o_e, edgelet, N);
+  put(o_pc, px_cur, 16 * N);
+  hipError_t e = hipMemcpyAsync(d, hs, o_pc + 16 * N, hipMemcpyHostToDevice, ctx->stream);
   int rc = SVO_HIP_OK;
-  std::vector<uint8_t> ok(N);
-  std::vector<int32_t> sl(N);
+  const uint8_t* ok = reinterpret_cast<const uint8_t*>(hs + o_ok);
+  const int32_t* sl = reinterpret_cast<const int32_t*>(hs + o_sl);
   if (e == hipSuccess) {
     rc = svo_hip_match_direct_batch_dev(ctx, ref, cur, cur_slot, cam, n_kf, reinterpret_cast<const double*>(d + o_T), T_cur_w, n,
                                         reinterpret_cast<const int32_t*>(d + o_k), reinterpret_cast<const double*>(d + o_pr),
@@ -1109,10 +1114,9 @@ int svo_hip_reproject_cells(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const 
                                         reinterpret_cast<double*>(d + o_pc), reinterpret_cast<uint8_t*>(d + o_ok),
                                         reinterpret_cast<int32_t*>(d + o_sl));
     if (rc == SVO_HIP_OK) {
-      e = hipMemcpyAsync(px_cur, d + o_pc, 16 * N, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(ok.data(), d + o_ok, N, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(sl.data(), d + o_sl, 4 * N, hipMemcpyDeviceToHost, ctx->stream);
+      e = hipMemcpyAsync(hs + o_pc, d + o_pc, o_ok + N - o_pc, hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess) memcpy(px_cur, hs + o_pc, 16 * N);
     }
   }
   if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_reproject_cells", hipGetErrorString(e));
