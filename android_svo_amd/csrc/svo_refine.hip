@@ -467,34 +467,41 @@ int svo_hip_pose_optimize(svo_hip_ctx* ctx, int n, const double T_f_w[7], const 
   SVO_REQUIRE(ctx, n >= 0 && T_f_w && result && (n == 0 || (f && pos && level && has_point)));
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   const int max_n = n > 0 ? n : 1;
-  const size_t bytes = sizeof(int32_t) + 7 * sizeof(double) + (size_t)max_n * (6 * sizeof(double) + sizeof(int32_t) + 1) +
-                       sizeof(svo_hip_pose_opt_result) + 64;
+  // one layout on both sides -- [T][f][pos][level][n][result][has_point] -- gathered in page-locked memory: one transfer in,
+  // one out ([result][has_point]) instead of six and two
+  const size_t o_T = 0, o_f = o_T + 7 * sizeof(double), o_p = o_f + 3 * sizeof(double) * max_n,
+               o_l = o_p + 3 * sizeof(double) * max_n, o_n = o_l + sizeof(int32_t) * max_n,
+               o_r = (o_n + sizeof(int32_t) + 7) & ~(size_t)7, o_h = o_r + sizeof(svo_hip_pose_opt_result),
+               bytes = o_h + (size_t)max_n + 64;
   char* d = nullptr;
+  char* hs = nullptr;
   {
     const int rc_st = svo_ctx_staging(ctx, bytes, &d);
     if (rc_st != SVO_HIP_OK) return rc_st;
+    const int rc_hs = svo_ctx_host_staging(ctx, bytes, &hs);
+    if (rc_hs != SVO_HIP_OK) return rc_hs;
   }
-  double* dT = reinterpret_cast<double*>(d);
-  double* df = dT + 7;
-  double* dp = df + 3 * (size_t)max_n;
-  svo_hip_pose_opt_result* dres = reinterpret_cast<svo_hip_pose_opt_result*>(dp + 3 * (size_t)max_n);
-  int32_t* dl = reinterpret_cast<int32_t*>(dres + 1);
-  int32_t* dn = dl + max_n;
-  uint8_t* dh = reinterpret_cast<uint8_t*>(dn + 1);
-  int rc = SVO_HIP_OK;
-  hipError_t e = hipMemcpyAsync(dT, T_f_w, 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && n > 0) e = hipMemcpyAsync(df, f, 3 * sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && n > 0) e = hipMemcpyAsync(dp, pos, 3 * sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && n > 0) e = hipMemcpyAsync(dl, level, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && n > 0) e = hipMemcpyAsync(dh, has_point, (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+  memcpy(hs + o_T, T_f_w, 7 * sizeof(double));
+  if (n > 0) {
+    memcpy(hs + o_f, f, 3 * sizeof(double) * n); memcpy(hs + o_p, pos, 3 * sizeof(double) * n);
+    memcpy(hs + o_l, level, sizeof(int32_t) * n); memcpy(hs + o_h, has_point, (size_t)n);
+  }
   const int32_t n32 = n;
-  if (e == hipSuccess) e = hipMemcpyAsync(dn, &n32, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+  memcpy(hs + o_n, &n32, sizeof(int32_t));
+  int rc = SVO_HIP_OK;
+  hipError_t e = hipMemcpyAsync(d, hs, o_h + (size_t)max_n, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    rc = svo_hip_pose_optimize_batch_dev(ctx, 1, max_n, dn, dT, df, dp, dl, dh, error_multiplier2, reproj_thresh, n_iter, dres);
+    rc = svo_hip_pose_optimize_batch_dev(ctx, 1, max_n, reinterpret_cast<int32_t*>(d + o_n), reinterpret_cast<double*>(d + o_T),
+                                         reinterpret_cast<double*>(d + o_f), reinterpret_cast<double*>(d + o_p),
+                                         reinterpret_cast<int32_t*>(d + o_l), reinterpret_cast<uint8_t*>(d + o_h), error_multiplier2,
+                                         reproj_thresh, n_iter, reinterpret_cast<svo_hip_pose_opt_result*>(d + o_r));
     if (rc == SVO_HIP_OK) {
-      e = hipMemcpyAsync(result, dres, sizeof(*result), hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess && n > 0) e = hipMemcpyAsync(has_point, dh, (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+      e = hipMemcpyAsync(hs + o_r, d + o_r, sizeof(svo_hip_pose_opt_result) + (size_t)max_n, hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess) {
+        memcpy(result, hs + o_r, sizeof(*result));
+        if (n > 0) memcpy(has_point, hs + o_h, (size_t)n);
+      }
     }
   }
   if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_pose_optimize", hipGetErrorString(e));
