@@ -236,9 +236,13 @@ int svo_hip_detect_features(svo_hip_ctx* ctx, const svo_hip_pyramid* pyr, int sl
   const size_t nc = (size_t)gc * gr;
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   char* d = nullptr;
+  char* hs = nullptr;
   {
-    const int rc_st = svo_ctx_staging(ctx, nc * (5 * sizeof(double) + sizeof(int32_t) + sizeof(float) + 1) + 64, &d);
+    const size_t bytes = nc * (5 * sizeof(double) + sizeof(int32_t) + sizeof(float) + 1) + 64;
+    const int rc_st = svo_ctx_staging(ctx, bytes, &d);
     if (rc_st != SVO_HIP_OK) return rc_st;
+    const int rc_hs = svo_ctx_host_staging(ctx, bytes, &hs);
+    if (rc_hs != SVO_HIP_OK) return rc_hs;
   }
   double* dpx = reinterpret_cast<double*>(d);
   double* df = dpx + 2 * nc;
@@ -253,13 +257,21 @@ int svo_hip_detect_features(svo_hip_ctx* ctx, const svo_hip_pyramid* pyr, int sl
     rc = svo_hip_detect_features_dev(ctx, pyr, slot, cam, n_pyr_levels, cell_size, occupancy ? docc : nullptr,
                                      detection_threshold, dn, dpx, f ? df : nullptr, dl, ds);
     if (rc == SVO_HIP_OK) {
-      e = hipMemcpyAsync(n_out, dn, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+      // the whole result block (one slot per grid cell, 48 B each, then the count) in one transfer to page-locked
+      // memory; the first n entries of every array go to the caller
+      const size_t out_bytes = (size_t)(reinterpret_cast<char*>(dn + 1) - d);
+      e = hipMemcpyAsync(hs, d, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      const size_t n = (e == hipSuccess) ? (size_t)*n_out : 0;
-      if (e == hipSuccess && n) e = hipMemcpy(px, dpx, 2 * n * sizeof(double), hipMemcpyDeviceToHost);
-      if (e == hipSuccess && n && f) e = hipMemcpy(f, df, 3 * n * sizeof(double), hipMemcpyDeviceToHost);
-      if (e == hipSuccess && n) e = hipMemcpy(level, dl, n * sizeof(int32_t), hipMemcpyDeviceToHost);
-      if (e == hipSuccess && n && score) e = hipMemcpy(score, ds, n * sizeof(float), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) {
+        *n_out = *reinterpret_cast<const int32_t*>(hs + (reinterpret_cast<char*>(dn) - d));
+        const size_t n = (size_t)*n_out;
+        if (n) {
+          memcpy(px, hs + (reinterpret_cast<char*>(dpx) - d), 2 * n * sizeof(double));
+          if (f) memcpy(f, hs + (reinterpret_cast<char*>(df) - d), 3 * n * sizeof(double));
+          memcpy(level, hs + (reinterpret_cast<char*>(dl) - d), n * sizeof(int32_t));
+          if (score) memcpy(score, hs + (reinterpret_cast<char*>(ds) - d), n * sizeof(float));
+        }
+      }
     }
   }
   if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_detect_features", hipGetErrorString(e));

@@ -532,28 +532,34 @@ int svo_hip_point_optimize_batch(svo_hip_ctx* ctx, int n_points, int n_iter, dou
   SVO_REQUIRE(ctx, m >= 0 && (m == 0 || (obs_T_f_w && obs_f)));
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   const size_t mm = m > 0 ? (size_t)m : 1;
+  // [T][f][offsets][pos][iterations]: gathered in page-locked memory, one transfer in, one out ([pos][iterations])
+  const size_t o_T = 0, o_f = o_T + sizeof(double) * 7 * mm, o_o = o_f + sizeof(double) * 3 * mm,
+               o_p = (o_o + sizeof(int32_t) * ((size_t)n_points + 1) + 7) & ~(size_t)7, o_i = o_p + sizeof(double) * 3 * n_points,
+               bytes = o_i + sizeof(int32_t) * (size_t)n_points + 64;
   char* d = nullptr;
+  char* hs = nullptr;
   {
-    const int rc_st = svo_ctx_staging(ctx, sizeof(double) * (3 * (size_t)n_points + 10 * mm) +
-                                                             sizeof(int32_t) * (2 * (size_t)n_points + 1) + 64, &d);
+    const int rc_st = svo_ctx_staging(ctx, bytes, &d);
     if (rc_st != SVO_HIP_OK) return rc_st;
+    const int rc_hs = svo_ctx_host_staging(ctx, bytes, &hs);
+    if (rc_hs != SVO_HIP_OK) return rc_hs;
   }
-  double* dp = reinterpret_cast<double*>(d);
-  double* dT = dp + 3 * (size_t)n_points;
-  double* df = dT + 7 * mm;
-  int32_t* dof = reinterpret_cast<int32_t*>(df + 3 * mm);
-  int32_t* dit = dof + n_points + 1;
-  hipError_t e = hipMemcpyAsync(dp, pos, sizeof(double) * 3 * n_points, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(dof, obs_offset, sizeof(int32_t) * (n_points + 1), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && m > 0) e = hipMemcpyAsync(dT, obs_T_f_w, sizeof(double) * 7 * m, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && m > 0) e = hipMemcpyAsync(df, obs_f, sizeof(double) * 3 * m, hipMemcpyHostToDevice, ctx->stream);
+  if (m > 0) { memcpy(hs + o_T, obs_T_f_w, sizeof(double) * 7 * m); memcpy(hs + o_f, obs_f, sizeof(double) * 3 * m); }
+  memcpy(hs + o_o, obs_offset, sizeof(int32_t) * ((size_t)n_points + 1));
+  memcpy(hs + o_p, pos, sizeof(double) * 3 * n_points);
+  hipError_t e = hipMemcpyAsync(d, hs, o_i, hipMemcpyHostToDevice, ctx->stream);
   int rc = SVO_HIP_OK;
   if (e == hipSuccess) {
-    rc = svo_hip_point_optimize_batch_dev(ctx, n_points, n_iter, dp, dof, dT, df, dit);
+    rc = svo_hip_point_optimize_batch_dev(ctx, n_points, n_iter, reinterpret_cast<double*>(d + o_p), reinterpret_cast<int32_t*>(d + o_o),
+                                          reinterpret_cast<double*>(d + o_T), reinterpret_cast<double*>(d + o_f),
+                                          reinterpret_cast<int32_t*>(d + o_i));
     if (rc == SVO_HIP_OK) {
-      e = hipMemcpyAsync(pos, dp, sizeof(double) * 3 * n_points, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess && iters) e = hipMemcpyAsync(iters, dit, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost, ctx->stream);
+      e = hipMemcpyAsync(hs + o_p, d + o_p, bytes - 64 - o_p, hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess) {
+        memcpy(pos, hs + o_p, sizeof(double) * 3 * n_points);
+        if (iters) memcpy(iters, hs + o_i, sizeof(int32_t) * (size_t)n_points);
+      }
     }
   }
   if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_point_optimize_batch", hipGetErrorString(e));
