@@ -1,4 +1,4 @@
-// svo_align_device.h -- feature_alignment::align2D / align1D as device routines, 16 lanes per 8x8 patch.
+// svo_align_device.h -- feature_alignment::align2D / align1D as device routines, ONE LANE PER 8x8 PATCH.
 //
 // Follows S/feature_alignment.cpp:167-281 (the scalar path, canonical on arm64/x86) and :35-152:
 // inverse-compositional LK with a mean-offset parameter, f32 throughout, min_update^2 = 0.5^2 for align2D (this
@@ -6,9 +6,16 @@
 // leaves converged = false but still writes u,v; align1D has the chi2-increase rollback (:117-125, which subtracts
 // update[0] from u and update[1] from v as the reference does) and h_inv = 1/H(0,0) * 64 (:63).
 //
-// Numerics vs the CPU path: H = sum J J^T is exact in f32 in any summation order (entries are multiples of 1/4
-// below 2^24), so Hinv is bit-identical; Jres is summed four pixels per lane in pixel order and then by a 16-lane
-// butterfly instead of a 64-term serial sum, so updates differ by f32 rounding (parity tolerance is stated in tests/).
+// Result-identical to the CPU path by construction: a lane walks the 64 pixels of its patch y-then-x exactly as the
+// reference's two loops do, so Jres (and align1D's H(0,0) and chi2) are the same 64-term serial f32 sums, rounded at
+// the same places (the file is built with -ffp-contract=off: no fused multiply-add anywhere).  64 patches per
+// wavefront; nothing crosses lanes.  This is also the instruction-cheapest layout on gfx950: ~15 VALU instructions
+// per pixel and iteration with no reduction at all (the earlier 16-lanes-per-patch form paid a butterfly per sum and
+// summed in another order, which flipped ~1 % of the `converged` flags).
+//
+// Register plan per lane: the template gradients dx, dy as 2 x 64 f32 (align1D: 64), the 8x8 template as 16 packed
+// words (converted with v_cvt_f32_ubyteN at use), the 9 x 12 bytes of the current image's footprint as 27 words
+// (nine unaligned global_load_dwordx3, all in flight together), two rows of nine converted pixels.
 #pragma once
 #include "svo_device_math.h"
 
@@ -29,52 +36,65 @@ SVO_DEV void inverse3f(const float* m, float* inv) {
 #undef SVO_M
 }
 
-// ---- 16 lanes per patch: four patches per wavefront ---------------------------------------------------------
-// A quarter wave per 8x8 patch: lane cl of the group owns pixels (row cl/2, columns 4*(cl%2) .. +3).  A wave then
-// refines four patches at once and issues a quarter of the instructions per patch
-// (the per-iteration arithmetic on u, v and the weights is uniform within a patch and costs the same whether 16 or 64
-// lanes carry it).  Sums: four pixels in pixel order per lane, then a 16-lane butterfly; H is exact in any order.
-// All 64 lanes must call these; `active` = this lane's group has a patch to refine.  Every group-level value
-// (u, v, converged, iterations) is identical on the 16 lanes of a group.
 SVO_DEV unsigned long long load8u(const uint8_t* p) {
   unsigned long long w;
   __builtin_memcpy(&w, p, 8);       // unaligned 8-byte load
   return w;
 }
 
-// the low five bytes of a 64-bit word as floats (v_cvt_f32_ubyteN: one instruction per byte)
-SVO_DEV void bytes5_f(unsigned long long w, float* f) {
-  const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
-  f[0] = (float)(lo & 0xffu);
-  f[1] = (float)((lo >> 8) & 0xffu);
-  f[2] = (float)((lo >> 16) & 0xffu);
-  f[3] = (float)(lo >> 24);
-  f[4] = (float)(hi & 0xffu);
+// A 10x10 ref_patch_with_border as 25 little-endian words and an 8x8 ref_patch as 16: what a lane keeps of its patch.
+struct PatchWords {
+  uint32_t b[25];   // ref_patch_with_border, byte c = row*10 + col
+  uint32_t p[16];   // ref_patch, byte r = y*8 + x
+};
+
+// byte k (compile-time constant after unrolling) of a packed word array
+#define SVO_BYTE(arr, k) (((arr)[(k) >> 2] >> (8 * ((k) & 3))) & 0xffu)
+
+// createPatchFromPatchWithBorder (S/matcher.cpp:138-147): the interior of the bordered patch
+SVO_DEV void patch_from_border(PatchWords& pw) {
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = 4 * w + k, y = r >> 3, x = r & 7, c = (y + 1) * 10 + (x + 1);
+      v |= SVO_BYTE(pw.b, c) << (8 * k);
+    }
+    pw.p[w] = v;
+  }
 }
 
-template <typename PatchPtr>
-SVO_DEV bool align2d_group16(const uint8_t* __restrict__ cur_img, int cols, int rows, int cur_step, PatchPtr pwb,
-                             int n_iter, bool active, double* px_u, double* px_v, int* iters) {
-  const int cl = threadIdx.x & 15;
-  const int py = cl >> 1, x0 = (cl & 1) * 4;
-  float ref_px[4], jx[4], jy[4];
-  float h0 = 0, h1 = 0, h2 = 0, h4 = 0, h5 = 0;
+// 12 bytes of an image row from an arbitrary address (global_load_dwordx3; the pyramid allocation has tail slack)
+struct __attribute__((packed, aligned(1))) Row12 { uint32_t w[3]; };
+SVO_DEV void load_row12(const uint8_t* p, uint32_t* out) {
+  Row12 t;
+  __builtin_memcpy(&t, p, 12);
+  out[0] = t.w[0]; out[1] = t.w[1]; out[2] = t.w[2];
+}
+SVO_DEV void row9_f(const uint32_t* w, float* f) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = (py + 1) * 10 + (x0 + k + 1);
-    ref_px[k] = (float)pwb[c];
-    jx[k] = (float)(0.5 * ((int)pwb[c + 1] - (int)pwb[c - 1]));
-    jy[k] = (float)(0.5 * ((int)pwb[c + 10] - (int)pwb[c - 10]));
-    h0 += jx[k] * jx[k]; h1 += jx[k] * jy[k]; h2 += jx[k]; h4 += jy[k] * jy[k]; h5 += jy[k];
-  }
+  for (int k = 0; k < 9; ++k) f[k] = (float)SVO_BYTE(w, k);
+}
+
+// feature_alignment::align2D for the patch of this lane.  `active` lanes run; the loop is left when no lane of the
+// wave is running any more.  Returns `converged`; *px_u, *px_v are rewritten as the reference rewrites
+// cur_px_estimate (always, also on failure); *iters = iterations that reached the pixel loop.
+SVO_DEV bool align2d_lane(const uint8_t* __restrict__ cur_img, int cols, int rows, int cur_step, const PatchWords& pw,
+                          int n_iter, bool active, double* px_u, double* px_v, int* iters) {
+  float jx[64], jy[64];
   float H[9];
-  H[0] = row16_sum(h0);
-  H[1] = row16_sum(h1);
-  H[2] = row16_sum(h2);
-  H[4] = row16_sum(h4);
-  H[5] = row16_sum(h5);
-  H[8] = 64.0f;
-  H[3] = H[1]; H[6] = H[2]; H[7] = H[5];
+  {
+    float h0 = 0, h1 = 0, h2 = 0, h4 = 0, h5 = 0;     // exact in f32: multiples of 1/4 below 2^22
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+      const int y = r >> 3, x = r & 7, c = (y + 1) * 10 + (x + 1);
+      jx[r] = (float)(0.5 * ((int)SVO_BYTE(pw.b, c + 1) - (int)SVO_BYTE(pw.b, c - 1)));
+      jy[r] = (float)(0.5 * ((int)SVO_BYTE(pw.b, c + 10) - (int)SVO_BYTE(pw.b, c - 10)));
+      h0 += jx[r] * jx[r]; h1 += jx[r] * jy[r]; h2 += jx[r]; h4 += jy[r] * jy[r]; h5 += jy[r];
+    }
+    H[0] = h0; H[1] = h1; H[2] = h2; H[3] = h1; H[4] = h4; H[5] = h5; H[6] = h2; H[7] = h5; H[8] = 64.0f;
+  }
   float Hinv[9];
   inverse3f(H, Hinv);
 
@@ -86,12 +106,11 @@ SVO_DEV bool align2d_group16(const uint8_t* __restrict__ cur_img, int cols, int 
   bool running = active;
   int it_count = 0;
   for (int iter = 0; iter < n_iter; ++iter) {
-    if (__ballot(running) == 0ull) break;                  // wave-uniform
     const int u_r = (int)floorf(u);
     const int v_r = (int)floorf(v);
-    if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) running = false;
-    if (u != u || v != v) running = false;
-    float J0 = 0, J1 = 0, J2 = 0;
+    if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) running = false;   // `break`
+    if (u != u || v != v) running = false;                                             // `return false`
+    if (__builtin_amdgcn_ballot_w64(running) == 0ull) break;                           // wave-uniform
     if (running) {
       ++it_count;
       const float subpix_x = u - u_r;
@@ -100,27 +119,28 @@ SVO_DEV bool align2d_group16(const uint8_t* __restrict__ cur_img, int cols, int 
       const float wTR = (float)(subpix_x * (1.0 - subpix_y));
       const float wBL = (float)((1.0 - subpix_x) * subpix_y);
       const float wBR = subpix_x * subpix_y;
-      // 8-byte loads that stay inside the 9-pixel footprint row: the left half reads columns 0..7, the right half
-      // columns 1..8 (its pixels start at byte 3)
-      const uint8_t* it = cur_img + (v_r + py - 4) * cur_step + (u_r - 4) + (x0 ? 1 : 0);
-      const int sh = x0 ? 24 : 0;
-      const unsigned long long a = load8u(it) >> sh, b = load8u(it + cur_step) >> sh;
-      float fa[5], fb[5];
-      bytes5_f(a, fa);
-      bytes5_f(b, fb);
+      const uint8_t* base = cur_img + (v_r - 4) * cur_step + (u_r - 4);
+      uint32_t rw[9][3];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float a0 = fa[k], a1 = fa[k + 1];
-        const float b0 = fb[k], b1 = fb[k + 1];
-        const float search_pixel = wTL * a0 + wTR * a1 + wBL * b0 + wBR * b1;
-        const float res = search_pixel - ref_px[k] + mean_diff;
-        J0 += res * jx[k]; J1 += res * jy[k]; J2 += res;
+      for (int y = 0; y < 9; ++y) load_row12(base + y * cur_step, rw[y]);
+      float J0 = 0, J1 = 0, J2 = 0;
+      float f0[9], f1[9];
+      row9_f(rw[0], f0);
+#pragma unroll
+      for (int y = 0; y < 8; ++y) {
+        row9_f(rw[y + 1], f1);
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          const int r = y * 8 + x;
+          const float search_pixel = wTL * f0[x] + wTR * f0[x + 1] + wBL * f1[x] + wBR * f1[x + 1];
+          const float res = search_pixel - (float)SVO_BYTE(pw.p, r) + mean_diff;
+          J0 -= res * jx[r];
+          J1 -= res * jy[r];
+          J2 -= res;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f0[k] = f1[k];
       }
-    }
-    J0 = -row16_sum(J0);
-    J1 = -row16_sum(J1);
-    J2 = -row16_sum(J2);
-    if (running) {
       const float up0 = Hinv[0] * J0 + (Hinv[1] * J1 + Hinv[2] * J2);
       const float up1 = Hinv[3] * J0 + (Hinv[4] * J1 + Hinv[5] * J2);
       const float up2 = Hinv[6] * J0 + (Hinv[7] * J1 + Hinv[8] * J2);
@@ -136,28 +156,24 @@ SVO_DEV bool align2d_group16(const uint8_t* __restrict__ cur_img, int cols, int 
   return converged;
 }
 
-template <typename PatchPtr>
-SVO_DEV bool align1d_group16(const uint8_t* __restrict__ cur_img, int cols, int rows, int cur_step, float dir0, float dir1,
-                             PatchPtr pwb, int n_iter, bool active, double* px_u, double* px_v, double* h_inv,
-                             int* iters) {
-  const int cl = threadIdx.x & 15;
-  const int py = cl >> 1, x0 = (cl & 1) * 4;
-  float ref_px[4], j0[4];
-  float h00 = 0, h01 = 0;
+// feature_alignment::align1D for the patch of this lane (S/feature_alignment.cpp:35-152)
+SVO_DEV bool align1d_lane(const uint8_t* __restrict__ cur_img, int cols, int rows, int cur_step, float dir0, float dir1,
+                          const PatchWords& pw, int n_iter, bool active, double* px_u, double* px_v, double* h_inv,
+                          int* iters) {
+  float dv[64];
+  float H00 = 0, H01 = 0, H10 = 0, H11 = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = (py + 1) * 10 + (x0 + k + 1);
-    ref_px[k] = (float)pwb[c];
-    j0[k] = (float)(0.5 * (dir0 * ((int)pwb[c + 1] - (int)pwb[c - 1]) + dir1 * ((int)pwb[c + 10] - (int)pwb[c - 10])));
-    h00 += j0[k] * j0[k]; h01 += j0[k];
+  for (int r = 0; r < 64; ++r) {
+    const int y = r >> 3, x = r & 7, c = (y + 1) * 10 + (x + 1);
+    const float j0 = (float)(0.5 * (dir0 * ((int)SVO_BYTE(pw.b, c + 1) - (int)SVO_BYTE(pw.b, c - 1)) +
+                                    dir1 * ((int)SVO_BYTE(pw.b, c + 10) - (int)SVO_BYTE(pw.b, c - 10))));
+    dv[r] = j0;
+    H00 += j0 * j0; H01 += j0 * 1.0f; H10 += 1.0f * j0; H11 += 1.0f;     // H += J*J^T, serial (:66)
   }
-  const float H00 = row16_sum(h00);
-  const float H01 = row16_sum(h01);
-  const float H11 = 64.0f;
   *h_inv = 1.0 / H00 * 8 * 8;
-  const float det = H00 * H11 - H01 * H01;
+  const float det = H00 * H11 - H10 * H01;
   const float invdet = 1.0f / det;
-  const float Hi00 = H11 * invdet, Hi01 = -H01 * invdet, Hi10 = -H01 * invdet, Hi11 = H00 * invdet;
+  const float Hi00 = H11 * invdet, Hi01 = -H01 * invdet, Hi10 = -H10 * invdet, Hi11 = H00 * invdet;
   float mean_diff = 0;
   float u = (float)*px_u;
   float v = (float)*px_v;
@@ -168,12 +184,11 @@ SVO_DEV bool align1d_group16(const uint8_t* __restrict__ cur_img, int cols, int 
   bool running = active;
   int it_count = 0;
   for (int iter = 0; iter < n_iter; ++iter) {
-    if (__ballot(running) == 0ull) break;                  // wave-uniform
     const int u_r = (int)floorf(u);
     const int v_r = (int)floorf(v);
     if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) running = false;
     if (u != u || v != v) running = false;
-    float J0 = 0, J1 = 0, c2 = 0;
+    if (__builtin_amdgcn_ballot_w64(running) == 0ull) break;
     if (running) {
       ++it_count;
       const float subpix_x = u - u_r;
@@ -182,25 +197,28 @@ SVO_DEV bool align1d_group16(const uint8_t* __restrict__ cur_img, int cols, int 
       const float wTR = (float)(subpix_x * (1.0 - subpix_y));
       const float wBL = (float)((1.0 - subpix_x) * subpix_y);
       const float wBR = subpix_x * subpix_y;
-      const uint8_t* it = cur_img + (v_r + py - 4) * cur_step + (u_r - 4) + (x0 ? 1 : 0);
-      const int sh = x0 ? 24 : 0;
-      const unsigned long long a = load8u(it) >> sh, b = load8u(it + cur_step) >> sh;
-      float fa[5], fb[5];
-      bytes5_f(a, fa);
-      bytes5_f(b, fb);
+      const uint8_t* base = cur_img + (v_r - 4) * cur_step + (u_r - 4);
+      uint32_t rw[9][3];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float a0 = fa[k], a1 = fa[k + 1];
-        const float b0 = fb[k], b1 = fb[k + 1];
-        const float search_pixel = wTL * a0 + wTR * a1 + wBL * b0 + wBR * b1;
-        const float res = search_pixel - ref_px[k] + mean_diff;
-        J0 += res * j0[k]; J1 += res; c2 += res * res;
+      for (int y = 0; y < 9; ++y) load_row12(base + y * cur_step, rw[y]);
+      float J0 = 0, J1 = 0, new_chi2 = 0;
+      float f0[9], f1[9];
+      row9_f(rw[0], f0);
+#pragma unroll
+      for (int y = 0; y < 8; ++y) {
+        row9_f(rw[y + 1], f1);
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          const int r = y * 8 + x;
+          const float search_pixel = wTL * f0[x] + wTR * f0[x + 1] + wBL * f1[x] + wBR * f1[x + 1];
+          const float res = search_pixel - (float)SVO_BYTE(pw.p, r) + mean_diff;
+          J0 -= res * dv[r];
+          J1 -= res;
+          new_chi2 += res * res;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f0[k] = f1[k];
       }
-    }
-    J0 = -row16_sum(J0);
-    J1 = -row16_sum(J1);
-    const float new_chi2 = row16_sum(c2);
-    if (running) {
       if (iter > 0 && new_chi2 > chi2) {
         u -= up0;
         v -= up1;

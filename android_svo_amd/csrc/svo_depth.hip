@@ -30,18 +30,62 @@ namespace {
 
 constexpr int ZMSSD_THRESHOLD = 2000 * 64;     // I/patch_score.h:46
 
-// ---- align2D over n patches: 16 lanes per patch, four patches per wave, 16 per block ------------------
-__global__ __launch_bounds__(256) void align2d_kernel(const uint8_t* __restrict__ img, int cols, int rows, int n,
-                                                      const uint8_t* __restrict__ pwb, int n_iter,
-                                                      double* __restrict__ px, uint8_t* __restrict__ converged,
-                                                      int32_t* __restrict__ iters) {
-  const int w = blockIdx.x * 16 + (threadIdx.x >> 4);
+// ---- align2D / align1D over n patches: one lane per patch, one wave per workgroup ---------------------
+// The [n][100] (and optional [n][64]) patch arrays are read with coalesced word loads into LDS and handed to the
+// lanes from there (a lane's 25 words sit 100 bytes apart: word stride 25 is odd, so the LDS reads are conflict-free).
+constexpr int ALIGN_LANES = 64;
+
+SVO_DEV void stage_patch_words(const uint8_t* __restrict__ pwb, const uint8_t* __restrict__ ref_patch, int first, int n,
+                               uint32_t* s_words, PatchWords& pw) {
+  const int lane = threadIdx.x;
+  const int n_here = min(ALIGN_LANES, n - first);
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(pwb + (size_t)first * 100);
+  // unconditional loads at a clamped index: all 25 are in flight together (words beyond the last patch are never used)
+  const int last = n_here * 25 - 1;
+#pragma unroll
+  for (int k = 0; k < 25; ++k) {
+    const int w = k * ALIGN_LANES + lane;
+    s_words[w] = src[min(w, last)];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (int k = 0; k < 25; ++k) pw.b[k] = s_words[lane * 25 + k];
+  if (ref_patch) {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint32_t* src2 = reinterpret_cast<const uint32_t*>(ref_patch + (size_t)first * 64);
+    const int last2 = n_here * 16 - 1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int w = k * ALIGN_LANES + lane;
+      s_words[w + (w >> 4)] = src2[min(w, last2)];                 // row stride 17 words: conflict-free reads
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pw.p[k] = s_words[lane * 17 + k];
+  } else {
+    patch_from_border(pw);
+  }
+}
+
+__global__ __launch_bounds__(ALIGN_LANES, 2) void align2d_kernel(const uint8_t* __restrict__ img, int cols, int rows, int n,
+                                                              const uint8_t* __restrict__ pwb,
+                                                              const uint8_t* __restrict__ ref_patch, int n_iter,
+                                                              double* __restrict__ px, uint8_t* __restrict__ converged,
+                                                              int32_t* __restrict__ iters) {
+  __shared__ uint32_t s_words[ALIGN_LANES * 25];
+  const int first = blockIdx.x * ALIGN_LANES;
+  const int w = first + threadIdx.x;
   const bool have = w < n;
-  const int wi = have ? w : 0;
-  double u = px[2 * (size_t)wi], v = px[2 * (size_t)wi + 1];
+  PatchWords pw;
+  stage_patch_words(pwb, ref_patch, first, n, s_words, pw);
+  double u = 0.0, v = 0.0;
+  if (have) { u = px[2 * (size_t)w]; v = px[2 * (size_t)w + 1]; }
   int it = 0;
-  const bool ok = align2d_group16(img, cols, rows, cols, pwb + (size_t)wi * 100, n_iter, have, &u, &v, &it);
-  if (have && (threadIdx.x & 15) == 0) {
+  const bool ok = align2d_lane(img, cols, rows, cols, pw, n_iter, have, &u, &v, &it);
+  if (have) {
     px[2 * (size_t)w] = u;
     px[2 * (size_t)w + 1] = v;
     converged[w] = ok ? 1 : 0;
@@ -49,19 +93,25 @@ __global__ __launch_bounds__(256) void align2d_kernel(const uint8_t* __restrict_
   }
 }
 
-// ---- align1D over n patches (edgelets / Matcher::Options::align_1d; ★-secondary) ------
-__global__ __launch_bounds__(256) void align1d_kernel(const uint8_t* __restrict__ img, int cols, int rows, int n,
-                                                      const uint8_t* __restrict__ pwb, const float* __restrict__ dir,
-                                                      int n_iter, double* __restrict__ px, uint8_t* __restrict__ converged,
-                                                      double* __restrict__ h_inv, int32_t* __restrict__ iters) {
-  const int w = blockIdx.x * 16 + (threadIdx.x >> 4);
+// align1D over n patches (edgelets / Matcher::Options::align_1d; secondary)
+__global__ __launch_bounds__(ALIGN_LANES, 2) void align1d_kernel(const uint8_t* __restrict__ img, int cols, int rows, int n,
+                                                              const uint8_t* __restrict__ pwb,
+                                                              const uint8_t* __restrict__ ref_patch,
+                                                              const float* __restrict__ dir, int n_iter,
+                                                              double* __restrict__ px, uint8_t* __restrict__ converged,
+                                                              double* __restrict__ h_inv, int32_t* __restrict__ iters) {
+  __shared__ uint32_t s_words[ALIGN_LANES * 25];
+  const int first = blockIdx.x * ALIGN_LANES;
+  const int w = first + threadIdx.x;
   const bool have = w < n;
-  const int wi = have ? w : 0;
-  double u = px[2 * (size_t)wi], v = px[2 * (size_t)wi + 1], hi = 0.0;
+  PatchWords pw;
+  stage_patch_words(pwb, ref_patch, first, n, s_words, pw);
+  double u = 0.0, v = 0.0, hi = 0.0;
+  float d0 = 0.0f, d1 = 0.0f;
+  if (have) { u = px[2 * (size_t)w]; v = px[2 * (size_t)w + 1]; d0 = dir[2 * (size_t)w]; d1 = dir[2 * (size_t)w + 1]; }
   int it = 0;
-  const bool ok = align1d_group16(img, cols, rows, cols, dir[2 * (size_t)wi], dir[2 * (size_t)wi + 1], pwb + (size_t)wi * 100,
-                                  n_iter, have, &u, &v, &hi, &it);
-  if (have && (threadIdx.x & 15) == 0) {
+  const bool ok = align1d_lane(img, cols, rows, cols, d0, d1, pw, n_iter, have, &u, &v, &hi, &it);
+  if (have) {
     px[2 * (size_t)w] = u;
     px[2 * (size_t)w + 1] = v;
     converged[w] = ok ? 1 : 0;
@@ -241,9 +291,14 @@ struct SeedRec {                 // 96 B, one per seed of the batch (device scra
   int pad;
 };
 
+// EXPLICIT_DEPTH = false: the per-seed body of DepthFilter::updateSeeds (visibility test, depth interval from mu/sigma2);
+// EXPLICIT_DEPTH = true: Matcher::findEpipolarMatchDirect as a caller would use it directly, with d_estimate / d_min /
+// d_max given per item (dep[3][n]) and no visibility test.
+template <bool EXPLICIT_DEPTH>
 __global__ __launch_bounds__(256) void df_geometry_kernel(
     DfFrame fr, int n, const double* __restrict__ px, const double* __restrict__ f, const int32_t* __restrict__ level,
-    const float* __restrict__ smu, const float* __restrict__ ssigma2, SeedRec* __restrict__ recs) {
+    const float* __restrict__ smu, const float* __restrict__ ssigma2, const double* __restrict__ dep,
+    double* __restrict__ epi_len_out, SeedRec* __restrict__ recs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const Cam cam = fr.cam;
@@ -255,26 +310,32 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
   const double fi[3] = {f[3 * (size_t)i], f[3 * (size_t)i + 1], f[3 * (size_t)i + 2]};
   const double px_ref[2] = {px[2 * (size_t)i], px[2 * (size_t)i + 1]};
   const int level_ref = level[i];
-  const float mu = smu[i], sigma2 = ssigma2[i];
-  // ---- visibility in the current frame (depth_filter.cpp:264-275)
-  const double inv_mu = 1.0 / mu;
-  const double pf[3] = {inv_mu * fi[0], inv_mu * fi[1], inv_mu * fi[2]};
-  double xyz_f[3];
-  se3_act(fr.T_cur_ref_vis, pf, xyz_f);
   bool live = true;
-  if (xyz_f[2] < 0.0) { rc.status = SVO_HIP_SEED_BEHIND; live = false; }
-  if (live) {
-    double pc[2];
-    world2cam(cam, xyz_f, pc);
-    const int ox = (int)pc[0], oy = (int)pc[1];
-    if (!(ox >= 0 && ox < cam.width && oy >= 0 && oy < cam.height)) { rc.status = SVO_HIP_SEED_NOT_IN_FRAME; live = false; }
-  }
-  const float z_inv_min = mu + sqrtf(sigma2);
-  rc.z_inv_min = z_inv_min;
-  if (live) {
+  double d_estimate, d_min, d_max;
+  if (EXPLICIT_DEPTH) {
+    d_estimate = dep[i]; d_min = dep[(size_t)n + i]; d_max = dep[2 * (size_t)n + i];
+    rc.z_inv_min = 0.0f;
+  } else {
+    const float mu = smu[i], sigma2 = ssigma2[i];
+    // ---- visibility in the current frame (depth_filter.cpp:264-275)
+    const double inv_mu = 1.0 / mu;
+    const double pf[3] = {inv_mu * fi[0], inv_mu * fi[1], inv_mu * fi[2]};
+    double xyz_f[3];
+    se3_act(fr.T_cur_ref_vis, pf, xyz_f);
+    if (xyz_f[2] < 0.0) { rc.status = SVO_HIP_SEED_BEHIND; live = false; }
+    if (live) {
+      double pc[2];
+      world2cam(cam, xyz_f, pc);
+      const int ox = (int)pc[0], oy = (int)pc[1];
+      if (!(ox >= 0 && ox < cam.width && oy >= 0 && oy < cam.height)) { rc.status = SVO_HIP_SEED_NOT_IN_FRAME; live = false; }
+    }
+    const float z_inv_min = mu + sqrtf(sigma2);
+    rc.z_inv_min = z_inv_min;
     const float z_inv_lo = mu - sqrtf(sigma2);
     const float z_inv_max = (z_inv_lo < 0.00000001f) ? 0.00000001f : z_inv_lo;
-    const double d_estimate = 1.0 / mu, d_min = 1.0 / z_inv_min, d_max = 1.0 / z_inv_max;
+    d_estimate = 1.0 / mu; d_min = 1.0 / z_inv_min; d_max = 1.0 / z_inv_max;
+  }
+  if (live) {
     // ---- Matcher::findEpipolarMatchDirect up to the search plan (matcher.cpp:216-296)
     const double* T_cur_ref = fr.T_cur_ref;
     double pa[3], pb[3], tmp[3];
@@ -311,6 +372,7 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
       rc.prx = (float)px_ref[0] / (1 << level_ref);
       rc.pry = (float)px_ref[1] / (1 << level_ref);
     }
+    if (epi_len_out) epi_len_out[i] = epi_length;
     if (epi_length < 2.0) {
       rc.path = 0;
       rc.uv0[0] = (px_A[0] + px_B[0]) / 2.0;
@@ -340,7 +402,7 @@ constexpr int SEEDS_PER_BLOCK = 16;
 
 __global__ __launch_bounds__(256) void df_search_kernel(
     DfFrame fr, const uint8_t* __restrict__ ref_base, size_t ref_pyr_bytes, const uint8_t* __restrict__ cur_pyr, int n,
-    const int32_t* __restrict__ level, SeedRec* __restrict__ recs) {
+    const int32_t* __restrict__ level, SeedRec* __restrict__ recs, uint32_t* __restrict__ pwb_t, int n_pad) {
   __shared__ __attribute__((aligned(16))) uint8_t s_pwb[SEEDS_PER_BLOCK][112];
   __shared__ __attribute__((aligned(16))) uint32_t s_patch[SEEDS_PER_BLOCK][16];
   __shared__ double s_px[SEEDS_PER_BLOCK][2];
@@ -548,49 +610,78 @@ __global__ __launch_bounds__(256) void df_search_kernel(
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-  // ---------------- phase C: sub-pixel alignment, 16 lanes per seed ----------------
+  // ---------------- hand-over to the alignment stage ----------------
+  // the warped 10x10 patch goes to memory word-transposed (word w of seed i at pwb_t[w * n_pad + i]: the lane-per-seed
+  // alignment kernel reads it with fully coalesced loads), the start pixel and the "align this seed" flag into the record
   {
     const int g = lane >> 4, cl = lane & 15;
     const int gi = i0 + g;
     const int slot = wib * SEEDS_PER_WAVE + g;
     const bool have = gi < n;
     const SeedRec* rp = s_rec + wib * SEEDS_PER_WAVE + (have ? g : 0);
-    SeedRec* rp_out = recs + (have ? gi : i0);
     const int path = have ? rp->path : -1;
     const bool live = path == 0 || path == 1 || path == 3;
-    const int search_level = rp->search_level;
-    const int ccols = cam.width >> search_level, crows = cam.height >> search_level;
-    const uint8_t* cur_img = cur_pyr + fr.cur_level_off[search_level];
-    const uint8_t* pwb = s_pwb[slot];
-    double px_cur[2] = {s_px[slot][0], s_px[slot][1]};   // path 0/3: midpoint of the projected segment
     const bool do_align = live && s_do[slot] != 0;
-    const double inv_scale = 1.0 / (1 << search_level);  // exact: a power of two
-    double us = px_cur[0] * inv_scale, vs = px_cur[1] * inv_scale;
-    int n_align = 0;
-    bool res = false;
-    const bool want1d = do_align && path == 3;
-    {
-      double u2 = us, v2 = vs;
-      int it2 = 0;
-      const bool r2 = align2d_group16(cur_img, ccols, crows, ccols, pwb, fr.align_max_iter, do_align && !want1d, &u2, &v2, &it2);
-      if (do_align && !want1d) { res = r2; us = u2; vs = v2; n_align = it2; }
+    if (do_align) {
+      const uint32_t* words = reinterpret_cast<const uint32_t*>(s_pwb[slot]);
+      pwb_t[(size_t)cl * n_pad + gi] = words[cl];
+      if (cl < 9) pwb_t[(size_t)(cl + 16) * n_pad + gi] = words[cl + 16];
     }
-    if (__ballot(want1d) != 0ull) {                      // EDGELET reference features (matcher.cpp:183-191): rare
-      double u1 = us, v1 = vs, h_inv;
-      int it1 = 0;
-      const bool r1 = align1d_group16(cur_img, ccols, crows, ccols, (float)rp->step[0], (float)rp->step[1], pwb,
-                                      fr.align_max_iter, want1d, &u1, &v1, &h_inv, &it1);
-      if (want1d) { res = r1; us = u1; vs = v1; n_align = it1; }
+    if (live && cl == 0) {
+      SeedRec* rp_out = recs + gi;
+      rp_out->matched = do_align ? 2 : 0;                // 2 = "to be aligned" (df_align_kernel settles it to 0 / 1)
+      if (path != 3) { rp_out->step[0] = s_px[slot][0]; rp_out->step[1] = s_px[slot][1]; }   // path 3 keeps its direction there
+      rp_out->n_zmssd = s_nz[slot]; rp_out->n_align = 0;
     }
-    if (do_align && (res || fr.keep_px_on_failure)) {
+  }
+}
+
+// Sub-pixel refinement of every seed the search stage flagged: one lane per seed, the reference's serial pixel order
+// (svo_align_device.h), so `converged`, the refined pixel and the iteration count equal the CPU path's bit for bit.
+// ONE_D = false refines the corner features with align2D; ONE_D = true the EDGELET reference features of
+// findMatchDirect with align1D (matcher.cpp:183-191; the depth filter never produces them) -- two instantiations so
+// that each keeps its gradient tables within 256 registers (two waves per SIMD).
+template <bool ONE_D>
+__global__ __launch_bounds__(ALIGN_LANES, 2) void df_align_kernel(DfFrame fr, const uint8_t* __restrict__ cur_pyr, int n, int n_pad,
+                                                               const uint32_t* __restrict__ pwb_t, SeedRec* __restrict__ recs) {
+  const int i = blockIdx.x * ALIGN_LANES + threadIdx.x;
+  const bool have = i < n;
+  SeedRec* rp = recs + (have ? i : 0);
+  const int path = have ? rp->path : -1;
+  const bool mine = ONE_D ? path == 3 : (path == 0 || path == 1);
+  const bool do_align = mine && rp->matched == 2;
+  if (__builtin_amdgcn_ballot_w64(do_align) == 0ull) return;      // wave-uniform
+  const int search_level = do_align ? rp->search_level : 0;
+  const int ccols = fr.cam.width >> search_level, crows = fr.cam.height >> search_level;
+  const uint8_t* cur_img = cur_pyr + fr.cur_level_off[search_level];
+  PatchWords pw;
+#pragma unroll
+  for (int k = 0; k < 25; ++k) pw.b[k] = do_align ? pwb_t[(size_t)k * n_pad + i] : 0u;
+  patch_from_border(pw);
+  double px_cur[2] = {0.0, 0.0};
+  float dir0 = 0.0f, dir1 = 0.0f;
+  if (do_align) {
+    if (ONE_D) { px_cur[0] = rp->uv0[0]; px_cur[1] = rp->uv0[1]; dir0 = (float)rp->step[0]; dir1 = (float)rp->step[1]; }
+    else { px_cur[0] = rp->step[0]; px_cur[1] = rp->step[1]; }
+  }
+  const double inv_scale = 1.0 / (1 << search_level);    // exact: a power of two
+  double us = px_cur[0] * inv_scale, vs = px_cur[1] * inv_scale;
+  int n_align = 0;
+  bool res;
+  if (ONE_D) {
+    double h_inv;
+    res = align1d_lane(cur_img, ccols, crows, ccols, dir0, dir1, pw, fr.align_max_iter, do_align, &us, &vs, &h_inv, &n_align);
+  } else {
+    res = align2d_lane(cur_img, ccols, crows, ccols, pw, fr.align_max_iter, do_align, &us, &vs, &n_align);
+  }
+  if (do_align) {
+    if (res || fr.keep_px_on_failure) {
       px_cur[0] = us * (1 << search_level);
       px_cur[1] = vs * (1 << search_level);
     }
-    if (live && cl == 0) {
-      rp_out->matched = res ? 1 : 0;
-      rp_out->step[0] = px_cur[0]; rp_out->step[1] = px_cur[1];
-      rp_out->n_zmssd = s_nz[slot]; rp_out->n_align = n_align;
-    }
+    rp->matched = res ? 1 : 0;
+    rp->step[0] = px_cur[0]; rp->step[1] = px_cur[1];
+    rp->n_align = n_align;
   }
 }
 
@@ -598,7 +689,8 @@ __global__ __launch_bounds__(256) void df_finalize_kernel(
     DfFrame fr, int n, const double* __restrict__ f, const SeedRec* __restrict__ recs, float* __restrict__ sa,
     float* __restrict__ sb, float* __restrict__ smu, const float* __restrict__ sz_range, float* __restrict__ ssigma2,
     int32_t* __restrict__ status, double* __restrict__ z_out, double* __restrict__ xyz_world,
-    int32_t* __restrict__ n_zmssd_out, int32_t* __restrict__ n_align_out) {
+    int32_t* __restrict__ n_zmssd_out, int32_t* __restrict__ n_align_out, double* __restrict__ px_cur_out,
+    int32_t* __restrict__ search_level_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const SeedRec rc = recs[i];
@@ -644,6 +736,45 @@ __global__ __launch_bounds__(256) void df_finalize_kernel(
   if (z_out) z_out[i] = z;
   if (n_zmssd_out) n_zmssd_out[i] = rc.n_zmssd;
   if (n_align_out) n_align_out[i] = rc.n_align;
+  // Matcher::px_cur_ / search_level_ of this seed's findEpipolarMatchDirect call (matcher.cpp:345-346): what
+  // DepthFilter::updateSeeds hands to feature_detector_->setGridOccpuancy on keyframes (depth_filter.cpp:302-306)
+  if (px_cur_out) {
+    const bool updated = st >= SVO_HIP_SEED_UPDATED;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    px_cur_out[2 * (size_t)i] = updated ? rc.step[0] : qnan;
+    px_cur_out[2 * (size_t)i + 1] = updated ? rc.step[1] : qnan;
+  }
+  if (search_level_out) search_level_out[i] = rc.path >= 0 ? rc.search_level : -1;
+}
+
+// Matcher::findEpipolarMatchDirect called directly (explicit depth interval): the tail of the function,
+// matcher.cpp:340-354 -- cam2world of the refined pixel, depthFromTriangulation.
+__global__ __launch_bounds__(256) void epi_finalize_kernel(
+    DfFrame fr, int n, const double* __restrict__ f, const SeedRec* __restrict__ recs, uint8_t* __restrict__ ok_out,
+    double* __restrict__ depth_out, double* __restrict__ px_cur_out, int32_t* __restrict__ search_level_out,
+    int32_t* __restrict__ n_zmssd_out, int32_t* __restrict__ n_align_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const SeedRec rc = recs[i];
+  bool ok = false;
+  double z = 0.0;
+  if (rc.path >= 0 && rc.matched) {
+    const double fi[3] = {f[3 * (size_t)i], f[3 * (size_t)i + 1], f[3 * (size_t)i + 2]};
+    double fc[3];
+    cam2world(fr.cam, rc.step[0], rc.step[1], fc);
+    ok = depth_from_triangulation(fr.T_cur_ref, fi, fc, &z);
+  }
+  ok_out[i] = ok ? 1 : 0;
+  if (depth_out) depth_out[i] = ok ? z : 0.0;
+  if (px_cur_out) {
+    const bool have = rc.path >= 0 && rc.matched;        // px_cur_ is assigned when the alignment succeeded (:345)
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    px_cur_out[2 * (size_t)i] = have ? rc.step[0] : qnan;
+    px_cur_out[2 * (size_t)i + 1] = have ? rc.step[1] : qnan;
+  }
+  if (search_level_out) search_level_out[i] = rc.path >= 0 ? rc.search_level : -1;
+  if (n_zmssd_out) n_zmssd_out[i] = rc.n_zmssd;
+  if (n_align_out) n_align_out[i] = rc.n_align;
 }
 
 // ---- Matcher::findMatchDirect over n (map point, reference feature) pairs (S/matcher.cpp:156-202) ----
@@ -651,6 +782,7 @@ struct MdFrame {
   Cam cam;
   double T_cur_w[7];
   int n_pyr_levels;
+  int n_kf, n_ref_levels;      // valid ranges of the caller's kf_slot / level values
 };
 
 // thread per item: frame test, depth, affine warp, search level -> SeedRec (path 0 = align2D, 3 = align1D)
@@ -674,8 +806,10 @@ __global__ __launch_bounds__(256) void md_geometry_kernel(
   const double pr[2] = {px_ref[2 * (size_t)i], px_ref[2 * (size_t)i + 1]};
   const double fi[3] = {f_ref[3 * (size_t)i], f_ref[3 * (size_t)i + 1], f_ref[3 * (size_t)i + 2]};
   // isInFrame(px.cast<int>()/(1<<level), halfpatch_size_+2, level) (:164-166)
-  const int ox = (int)pr[0] / (1 << level_ref), oy = (int)pr[1] / (1 << level_ref);
-  if (is_in_frame_level(cam, ox, oy, 6, level_ref)) {
+  // a slot or level outside the pyramids the caller handed over is rejected like a failed frame test (never indexed)
+  const bool in_range = slot >= 0 && slot < fr.n_kf && level_ref >= 0 && level_ref < fr.n_ref_levels;
+  const int ox = in_range ? (int)pr[0] / (1 << level_ref) : -1, oy = in_range ? (int)pr[1] / (1 << level_ref) : -1;
+  if (in_range && is_in_frame_level(cam, ox, oy, 6, level_ref)) {
     const double* Tr = T_ref_w + 7 * (size_t)slot;
     double T_ref_inv[7], T_cur_ref[7];
     se3_inverse(Tr, T_ref_inv);
@@ -804,10 +938,13 @@ int svo_hip_align2d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int 
   SVO_REQUIRE(ctx, n >= 0 && n_iter >= 0);
   if (n == 0) return SVO_HIP_OK;
   SVO_REQUIRE(ctx, pwb_dev && px_dev && converged_dev);
-  (void)ref_patch_dev;   // the 8x8 patch is the interior of the bordered one (matcher.cpp:138-147)
+  // ref_patch_dev == NULL: the 8x8 patch is the interior of the bordered one (createPatchFromPatchWithBorder,
+  // matcher.cpp:138-147), which is how every caller of the reference fills it
+  SVO_REQUIRE(ctx, ((uintptr_t)pwb_dev & 3) == 0 && ((uintptr_t)ref_patch_dev & 3) == 0);
   const uint8_t* img = cur->base + (size_t)slot * cur->pyr_bytes + cur->level_offset[level];
-  hipLaunchKernelGGL(align2d_kernel, dim3((n + 15) / 16), dim3(256), 0, ctx->stream, img, cur->width >> level,
-                     cur->height >> level, n, pwb_dev, n_iter, px_dev, converged_dev, iters_dev);
+  hipLaunchKernelGGL(align2d_kernel, dim3((n + ALIGN_LANES - 1) / ALIGN_LANES), dim3(ALIGN_LANES), 0, ctx->stream, img,
+                     cur->width >> level, cur->height >> level, n, pwb_dev, ref_patch_dev, n_iter, px_dev, converged_dev,
+                     iters_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
 }
@@ -821,8 +958,10 @@ int svo_hip_align1d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int 
   if (n == 0) return SVO_HIP_OK;
   SVO_REQUIRE(ctx, pwb_dev && dir_dev && px_dev && converged_dev);
   const uint8_t* img = cur->base + (size_t)slot * cur->pyr_bytes + cur->level_offset[level];
-  hipLaunchKernelGGL(align1d_kernel, dim3((n + 15) / 16), dim3(256), 0, ctx->stream, img, cur->width >> level,
-                     cur->height >> level, n, pwb_dev, dir_dev, n_iter, px_dev, converged_dev, h_inv_dev, iters_dev);
+  SVO_REQUIRE(ctx, ((uintptr_t)pwb_dev & 3) == 0);
+  hipLaunchKernelGGL(align1d_kernel, dim3((n + ALIGN_LANES - 1) / ALIGN_LANES), dim3(ALIGN_LANES), 0, ctx->stream, img,
+                     cur->width >> level, cur->height >> level, n, pwb_dev, (const uint8_t*)nullptr, dir_dev, n_iter, px_dev,
+                     converged_dev, h_inv_dev, iters_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
 }
@@ -833,21 +972,22 @@ int svo_hip_align2d_batch(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int slot
   if (!ctx || !cur) return SVO_HIP_ERR_INVALID;
   if (n == 0) return SVO_HIP_OK;
   SVO_REQUIRE(ctx, n > 0 && pwb && px && converged);
-  (void)ref_patch;
-  void *d_pwb = nullptr, *d_px = nullptr, *d_conv = nullptr, *d_it = nullptr;
-  int rc = svo_hip_malloc(ctx, &d_pwb, (size_t)n * 100);
-  if (rc == SVO_HIP_OK) rc = svo_hip_malloc(ctx, &d_px, (size_t)n * 16);
-  if (rc == SVO_HIP_OK) rc = svo_hip_malloc(ctx, &d_conv, (size_t)n);
-  if (rc == SVO_HIP_OK) rc = svo_hip_malloc(ctx, &d_it, (size_t)n * 4);
-  if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d_pwb, pwb, (size_t)n * 100);
-  if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d_px, px, (size_t)n * 16);
+  // one device block from the context's staging area: px(16) pwb(100) patch(64) iters(4) converged(1) per patch
+  const size_t N = (size_t)n;
+  const size_t o_px = 0, o_pwb = o_px + 16 * N, o_rp = o_pwb + 100 * N, o_it = o_rp + 64 * N, o_cv = o_it + 4 * N,
+               total = o_cv + N;
+  char* d = nullptr;
+  int rc = svo_ctx_staging(ctx, total, &d);
+  if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d + o_pwb, pwb, 100 * N);
+  if (rc == SVO_HIP_OK && ref_patch) rc = svo_hip_memcpy_h2d(ctx, d + o_rp, ref_patch, 64 * N);
+  if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d + o_px, px, 16 * N);
   if (rc == SVO_HIP_OK)
-    rc = svo_hip_align2d_batch_dev(ctx, cur, slot, level, n, (const uint8_t*)d_pwb, nullptr, n_iter, (double*)d_px,
-                                   (uint8_t*)d_conv, (int32_t*)d_it);
-  if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, px, d_px, (size_t)n * 16);
-  if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, converged, d_conv, (size_t)n);
-  if (rc == SVO_HIP_OK && iters) rc = svo_hip_memcpy_d2h(ctx, iters, d_it, (size_t)n * 4);
-  (void)svo_hip_free(ctx, d_pwb); (void)svo_hip_free(ctx, d_px); (void)svo_hip_free(ctx, d_conv); (void)svo_hip_free(ctx, d_it);
+    rc = svo_hip_align2d_batch_dev(ctx, cur, slot, level, n, (const uint8_t*)(d + o_pwb),
+                                   ref_patch ? (const uint8_t*)(d + o_rp) : nullptr, n_iter, (double*)(d + o_px),
+                                   (uint8_t*)(d + o_cv), (int32_t*)(d + o_it));
+  if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, px, d + o_px, 16 * N);
+  if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, converged, d + o_cv, N);
+  if (rc == SVO_HIP_OK && iters) rc = svo_hip_memcpy_d2h(ctx, iters, d + o_it, 4 * N);
   return rc;
 }
 
@@ -904,24 +1044,9 @@ static void h_mul(const double* A, const double* B, double* o) {
   o[0] = t0; o[1] = t1; o[2] = t2; o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3];
 }
 
-int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,
-                                    const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
-                                    const double T_ref_w[7], const double T_cur_w[7], int n, const double* px,
-                                    const double* f, const int32_t* level, float* a, float* b, float* mu,
-                                    const float* z_range, float* sigma2, const svo_hip_df_params* prm,
-                                    int32_t* status, double* z, double* xyz_world, int32_t* n_zmssd,
-                                    int32_t* n_align_iters) {
-  if (!ctx || !ref || !cur || !cam || !T_ref_w || !T_cur_w || !prm) return SVO_HIP_ERR_INVALID;
-  SVO_REQUIRE(ctx, ref_slot >= 0 && ref_slot < ref->batch && cur_slot >= 0 && cur_slot < cur->batch);
-  SVO_REQUIRE(ctx, ref->width == cam->width && ref->height == cam->height);
-  SVO_REQUIRE(ctx, cur->width == cam->width && cur->height == cam->height);
-  SVO_REQUIRE(ctx, prm->n_pyr_levels >= 1 && prm->n_pyr_levels <= ref->n_levels && prm->n_pyr_levels <= cur->n_levels);
-  SVO_REQUIRE(ctx, prm->align_max_iter >= 0 && prm->max_epi_search_steps >= 0);
-  SVO_REQUIRE(ctx, n >= 0);
-  if (n == 0) return SVO_HIP_OK;
-  SVO_REQUIRE(ctx, px && f && level && a && b && mu && z_range && sigma2 && status);
-  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  DfFrame fr;
+// frame-level constants of one updateSeeds / findEpipolarMatchDirect batch
+static void df_make_frame(const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, const svo_hip_camera* cam,
+                          const double T_ref_w[7], const double T_cur_w[7], const svo_hip_df_params* prm, DfFrame& fr) {
   memset(&fr, 0, sizeof(fr));
   fr.cam = svo_make_cam(*cam);
   double T_cur_inv[7];
@@ -938,22 +1063,99 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
   fr.align_max_iter = prm->align_max_iter;
   fr.max_epi_search_steps = prm->max_epi_search_steps;
   fr.conv_thresh = prm->seed_convergence_sigma2_thresh;
-  // per-seed records between the stages: grow-only scratch owned by the context
-  const size_t need = (size_t)n * sizeof(SeedRec);
+}
+
+// per-seed records between the stages + the word-transposed warped patches: grow-only scratch owned by the context
+static int df_scratch(svo_hip_ctx* ctx, int n, SeedRec** recs, uint32_t** pwb_t, int* n_pad) {
+  *n_pad = (n + ALIGN_LANES - 1) / ALIGN_LANES * ALIGN_LANES;
+  const size_t rec_bytes = ((size_t)n * sizeof(SeedRec) + 255) & ~(size_t)255;
+  const size_t need = rec_bytes + (size_t)25 * *n_pad * sizeof(uint32_t);
   void* ws = nullptr;
+  const int rc = svo_ctx_scratch(ctx, need, &ws);
+  if (rc != SVO_HIP_OK) return rc;
+  *recs = (SeedRec*)ws;
+  *pwb_t = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + rec_bytes);
+  return SVO_HIP_OK;
+}
+
+int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,
+                                    const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                                    const double T_ref_w[7], const double T_cur_w[7], int n, const double* px,
+                                    const double* f, const int32_t* level, float* a, float* b, float* mu,
+                                    const float* z_range, float* sigma2, const svo_hip_df_params* prm,
+                                    int32_t* status, double* z, double* xyz_world, int32_t* n_zmssd,
+                                    int32_t* n_align_iters, double* px_cur, int32_t* search_level) {
+  if (!ctx || !ref || !cur || !cam || !T_ref_w || !T_cur_w || !prm) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, ref_slot >= 0 && ref_slot < ref->batch && cur_slot >= 0 && cur_slot < cur->batch);
+  SVO_REQUIRE(ctx, ref->width == cam->width && ref->height == cam->height);
+  SVO_REQUIRE(ctx, cur->width == cam->width && cur->height == cam->height);
+  SVO_REQUIRE(ctx, prm->n_pyr_levels >= 1 && prm->n_pyr_levels <= ref->n_levels && prm->n_pyr_levels <= cur->n_levels);
+  SVO_REQUIRE(ctx, prm->align_max_iter >= 0 && prm->max_epi_search_steps >= 0);
+  SVO_REQUIRE(ctx, n >= 0);
+  if (n == 0) return SVO_HIP_OK;
+  SVO_REQUIRE(ctx, px && f && level && a && b && mu && z_range && sigma2 && status);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  DfFrame fr;
+  df_make_frame(ref, cur, cam, T_ref_w, T_cur_w, prm, fr);
+  SeedRec* recs = nullptr;
+  uint32_t* pwb_t = nullptr;
+  int n_pad = 0;
   {
-    const int rc = svo_ctx_scratch(ctx, need, &ws);
+    const int rc = df_scratch(ctx, n, &recs, &pwb_t, &n_pad);
     if (rc != SVO_HIP_OK) return rc;
   }
-  SeedRec* recs = (SeedRec*)ws;
   const uint8_t* ref_img = ref->base + (size_t)ref_slot * ref->pyr_bytes;
   const uint8_t* cur_img = cur->base + (size_t)cur_slot * cur->pyr_bytes;
-  hipLaunchKernelGGL(df_geometry_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, px, f, level, mu, sigma2, recs);
+  hipLaunchKernelGGL(df_geometry_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, px, f, level, mu, sigma2,
+                     (const double*)nullptr, (double*)nullptr, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref_img, (size_t)0, cur_img, n, level, recs);
+  hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref_img, (size_t)0, cur_img, n, level, recs, pwb_t, n_pad);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(df_align_kernel<false>, dim3(n_pad / ALIGN_LANES), dim3(ALIGN_LANES), 0, ctx->stream, fr, cur_img, n, n_pad, pwb_t, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(df_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, f, recs, a, b, mu, z_range,
-                     sigma2, status, z, xyz_world, n_zmssd, n_align_iters);
+                     sigma2, status, z, xyz_world, n_zmssd, n_align_iters, px_cur, search_level);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
+int svo_hip_epipolar_match_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,
+                                     const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                                     const double T_ref_w[7], const double T_cur_w[7], int n, const double* px,
+                                     const double* f, const int32_t* level, const double* depth_est_min_max,
+                                     const svo_hip_df_params* prm, uint8_t* ok, double* depth, double* px_cur,
+                                     int32_t* search_level, double* epi_length, int32_t* n_zmssd,
+                                     int32_t* n_align_iters) {
+  if (!ctx || !ref || !cur || !cam || !T_ref_w || !T_cur_w || !prm) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, ref_slot >= 0 && ref_slot < ref->batch && cur_slot >= 0 && cur_slot < cur->batch);
+  SVO_REQUIRE(ctx, ref->width == cam->width && ref->height == cam->height);
+  SVO_REQUIRE(ctx, cur->width == cam->width && cur->height == cam->height);
+  SVO_REQUIRE(ctx, prm->n_pyr_levels >= 1 && prm->n_pyr_levels <= ref->n_levels && prm->n_pyr_levels <= cur->n_levels);
+  SVO_REQUIRE(ctx, prm->align_max_iter >= 0 && prm->max_epi_search_steps >= 0);
+  SVO_REQUIRE(ctx, n >= 0);
+  if (n == 0) return SVO_HIP_OK;
+  SVO_REQUIRE(ctx, px && f && level && depth_est_min_max && ok);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  DfFrame fr;
+  df_make_frame(ref, cur, cam, T_ref_w, T_cur_w, prm, fr);
+  SeedRec* recs = nullptr;
+  uint32_t* pwb_t = nullptr;
+  int n_pad = 0;
+  {
+    const int rc = df_scratch(ctx, n, &recs, &pwb_t, &n_pad);
+    if (rc != SVO_HIP_OK) return rc;
+  }
+  const uint8_t* ref_img = ref->base + (size_t)ref_slot * ref->pyr_bytes;
+  const uint8_t* cur_img = cur->base + (size_t)cur_slot * cur->pyr_bytes;
+  hipLaunchKernelGGL(df_geometry_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, px, f, level,
+                     (const float*)nullptr, (const float*)nullptr, depth_est_min_max, epi_length, recs);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref_img, (size_t)0, cur_img, n, level, recs, pwb_t, n_pad);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(df_align_kernel<false>, dim3(n_pad / ALIGN_LANES), dim3(ALIGN_LANES), 0, ctx->stream, fr, cur_img, n, n_pad, pwb_t, recs);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(epi_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, f, recs, ok, depth, px_cur,
+                     search_level, n_zmssd, n_align_iters);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
 }
@@ -973,17 +1175,18 @@ int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref,
   if (n == 0) return SVO_HIP_OK;
   SVO_REQUIRE(ctx, T_ref_w_dev && kf_slot_dev && px_ref_dev && f_ref_dev && level_ref_dev && pt_pos_dev && px_cur_dev && success_dev);
   SVO_REQUIRE(ctx, !edgelet_dev || grad_dev);
-  const size_t need = (size_t)n * sizeof(SeedRec);
-  void* ws = nullptr;
+  SeedRec* recs = nullptr;
+  uint32_t* pwb_t = nullptr;
+  int n_pad = 0;
   {
-    const int rc = svo_ctx_scratch(ctx, need, &ws);
+    const int rc = df_scratch(ctx, n, &recs, &pwb_t, &n_pad);
     if (rc != SVO_HIP_OK) return rc;
   }
-  SeedRec* recs = (SeedRec*)ws;
   MdFrame mf;
   mf.cam = svo_make_cam(*cam);
   memcpy(mf.T_cur_w, T_cur_w, sizeof(double) * 7);
   mf.n_pyr_levels = n_pyr_levels;
+  mf.n_kf = n_kf; mf.n_ref_levels = ref->n_levels;
   DfFrame fr;
   memset(&fr, 0, sizeof(fr));
   fr.cam = mf.cam;
@@ -994,8 +1197,16 @@ int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref,
                      px_ref_dev, f_ref_dev, level_ref_dev, pt_pos_dev, edgelet_dev, grad_dev, px_cur_dev, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref->base, ref->pyr_bytes,
-                     cur->base + (size_t)cur_slot * cur->pyr_bytes, n, level_ref_dev, recs);
+                     cur->base + (size_t)cur_slot * cur->pyr_bytes, n, level_ref_dev, recs, pwb_t, n_pad);
   SVO_CHECK_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(df_align_kernel<false>, dim3(n_pad / ALIGN_LANES), dim3(ALIGN_LANES), 0, ctx->stream, fr,
+                     cur->base + (size_t)cur_slot * cur->pyr_bytes, n, n_pad, pwb_t, recs);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  if (edgelet_dev) {
+    hipLaunchKernelGGL(df_align_kernel<true>, dim3(n_pad / ALIGN_LANES), dim3(ALIGN_LANES), 0, ctx->stream, fr,
+                       cur->base + (size_t)cur_slot * cur->pyr_bytes, n, n_pad, pwb_t, recs);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+  }
   hipLaunchKernelGGL(md_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, recs, px_cur_dev, success_dev,
                      search_level_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
@@ -1007,34 +1218,52 @@ int svo_hip_depth_filter_update(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, in
                                 int cur_slot, const svo_hip_camera* cam, const double T_ref_w[7], const double T_cur_w[7],
                                 int n, const double* px, const double* f, const int32_t* level, float* a, float* b,
                                 float* mu, const float* z_range, float* sigma2, const svo_hip_df_params* prm,
-                                int32_t* status, double* z, double* xyz_world, int32_t* n_zmssd, int32_t* n_align_iters) {
+                                int32_t* status, double* z, double* xyz_world, int32_t* n_zmssd, int32_t* n_align_iters,
+                                double* px_cur, int32_t* search_level) {
   if (!ctx) return SVO_HIP_ERR_INVALID;
   SVO_REQUIRE(ctx, n >= 0);
   if (n == 0) return SVO_HIP_OK;
   SVO_REQUIRE(ctx, px && f && level && a && b && mu && z_range && sigma2 && status);
   const size_t N = (size_t)n;
-  // one device block: px(16) f(24) z(8) xyz(24) level(4) a b mu zr s2 (5x4) status nz na (3x4) = 108 B / seed
-  const size_t o_px = 0, o_f = o_px + 16 * N, o_z = o_f + 24 * N, o_xyz = o_z + 8 * N, o_lvl = o_xyz + 24 * N,
-               o_a = o_lvl + 4 * N, o_b = o_a + 4 * N, o_mu = o_b + 4 * N, o_zr = o_mu + 4 * N, o_s2 = o_zr + 4 * N,
-               o_st = o_s2 + 4 * N, o_nz = o_st + 4 * N, o_na = o_nz + 4 * N, total = o_na + 4 * N;
+  // One staging layout on both sides, the pageable arguments gathered in page-locked memory: one transfer each way.
+  // inputs  : px(16) f(24) level(4) z_range(4) | in/out: a b mu sigma2 (4x4) | outputs: z(8) xyz(24) px_cur(16) status nz na sl (4x4)
+  const size_t o_px = 0, o_f = o_px + 16 * N, o_z = o_f + 24 * N, o_xyz = o_z + 8 * N, o_pc = o_xyz + 24 * N,
+               o_lvl = o_pc + 16 * N, o_zr = o_lvl + 4 * N, o_a = o_zr + 4 * N, o_b = o_a + 4 * N, o_mu = o_b + 4 * N,
+               o_s2 = o_mu + 4 * N, o_st = o_s2 + 4 * N, o_nz = o_st + 4 * N, o_na = o_nz + 4 * N, o_sl = o_na + 4 * N,
+               total = o_sl + 4 * N;
   char* blk = nullptr;
+  char* hs = nullptr;
   int rc = svo_ctx_staging(ctx, total, &blk);
   if (rc != SVO_HIP_OK) return rc;
+  rc = svo_ctx_host_staging(ctx, total, &hs);
+  if (rc != SVO_HIP_OK) return rc;
   uint8_t* d = (uint8_t*)blk;
-  auto up = [&](size_t off, const void* src, size_t bytes) { if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d + off, src, bytes); };
-  up(o_px, px, 16 * N); up(o_f, f, 24 * N); up(o_lvl, level, 4 * N); up(o_a, a, 4 * N); up(o_b, b, 4 * N);
-  up(o_mu, mu, 4 * N); up(o_zr, z_range, 4 * N); up(o_s2, sigma2, 4 * N);
-  if (rc == SVO_HIP_OK)
-    rc = svo_hip_depth_filter_update_dev(ctx, ref, ref_slot, cur, cur_slot, cam, T_ref_w, T_cur_w, n, (double*)(d + o_px),
-                                         (double*)(d + o_f), (int32_t*)(d + o_lvl), (float*)(d + o_a), (float*)(d + o_b),
-                                         (float*)(d + o_mu), (float*)(d + o_zr), (float*)(d + o_s2), prm,
-                                         (int32_t*)(d + o_st), (double*)(d + o_z), (double*)(d + o_xyz),
-                                         (int32_t*)(d + o_nz), (int32_t*)(d + o_na));
-  auto down = [&](void* dst, size_t off, size_t bytes) { if (rc == SVO_HIP_OK && dst) rc = svo_hip_memcpy_d2h(ctx, dst, d + off, bytes); };
-  down(a, o_a, 4 * N); down(b, o_b, 4 * N); down(mu, o_mu, 4 * N); down(sigma2, o_s2, 4 * N);
-  down(status, o_st, 4 * N); down(z, o_z, 8 * N); down(xyz_world, o_xyz, 24 * N); down(n_zmssd, o_nz, 4 * N);
-  down(n_align_iters, o_na, 4 * N);
-  return rc;
+  memcpy(hs + o_px, px, 16 * N); memcpy(hs + o_f, f, 24 * N); memcpy(hs + o_lvl, level, 4 * N);
+  memcpy(hs + o_zr, z_range, 4 * N); memcpy(hs + o_a, a, 4 * N); memcpy(hs + o_b, b, 4 * N);
+  memcpy(hs + o_mu, mu, 4 * N); memcpy(hs + o_s2, sigma2, 4 * N);
+  // two uploads (the output block in the middle does not cross the link): [px f] and [level .. sigma2]
+  hipError_t e = hipMemcpyAsync(d + o_px, hs + o_px, 40 * N, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d + o_lvl, hs + o_lvl, o_st - o_lvl, hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_depth_filter_update", hipGetErrorString(e));
+  rc = svo_hip_depth_filter_update_dev(ctx, ref, ref_slot, cur, cur_slot, cam, T_ref_w, T_cur_w, n, (double*)(d + o_px),
+                                       (double*)(d + o_f), (int32_t*)(d + o_lvl), (float*)(d + o_a), (float*)(d + o_b),
+                                       (float*)(d + o_mu), (float*)(d + o_zr), (float*)(d + o_s2), prm,
+                                       (int32_t*)(d + o_st), (double*)(d + o_z), (double*)(d + o_xyz),
+                                       (int32_t*)(d + o_nz), (int32_t*)(d + o_na), (double*)(d + o_pc), (int32_t*)(d + o_sl));
+  if (rc != SVO_HIP_OK) return rc;
+  e = hipMemcpyAsync(hs + o_z, d + o_z, o_lvl - o_z, hipMemcpyDeviceToHost, ctx->stream);                 // z xyz px_cur
+  if (e == hipSuccess) e = hipMemcpyAsync(hs + o_a, d + o_a, total - o_a, hipMemcpyDeviceToHost, ctx->stream);   // a .. search level
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_depth_filter_update", hipGetErrorString(e));
+  memcpy(a, hs + o_a, 4 * N); memcpy(b, hs + o_b, 4 * N); memcpy(mu, hs + o_mu, 4 * N); memcpy(sigma2, hs + o_s2, 4 * N);
+  memcpy(status, hs + o_st, 4 * N);
+  if (z) memcpy(z, hs + o_z, 8 * N);
+  if (xyz_world) memcpy(xyz_world, hs + o_xyz, 24 * N);
+  if (px_cur) memcpy(px_cur, hs + o_pc, 16 * N);
+  if (n_zmssd) memcpy(n_zmssd, hs + o_nz, 4 * N);
+  if (n_align_iters) memcpy(n_align_iters, hs + o_na, 4 * N);
+  if (search_level) memcpy(search_level, hs + o_sl, 4 * N);
+  return SVO_HIP_OK;
 }
 
 int svo_hip_seed_compact_converged_dev(svo_hip_ctx* ctx, int n, long long id_offset, const int32_t* status_dev,
@@ -1116,7 +1345,6 @@ int svo_hip_reproject_cells(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const 
     if (rc == SVO_HIP_OK) {
       e = hipMemcpyAsync(hs + o_pc, d + o_pc, o_ok + N - o_pc, hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      if (e == hipSuccess) memcpy(px_cur, hs + o_pc, 16 * N);
     }
   }
   if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_reproject_cells", hipGetErrorString(e));
@@ -1130,6 +1358,9 @@ int svo_hip_reproject_cells(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const 
       ++n_trials;
       tried[i] = 1;
       if (deleted[i]) continue;                              // TYPE_DELETED: erased from the cell (:190-194)
+      // findMatchDirect ran for this candidate: its px_cur is rewritten (matcher.cpp:200); candidates the serial
+      // loop never reaches keep the caller's values
+      memcpy(px_cur + 2 * (size_t)i, hs + o_pc + 16 * (size_t)i, 16);
       if (search_level) search_level[i] = sl[i];
       if (!ok[i]) continue;                                  // the caller counts the failure on the point (:202-209)
       matched[i] = 1;

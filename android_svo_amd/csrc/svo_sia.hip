@@ -1726,6 +1726,7 @@ int svo_hip_sia_begin(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm
   SVO_REQUIRE(ctx, prm->min_level >= 0 && prm->max_level >= prm->min_level && prm->max_level < s->ref->n_levels);
   SVO_REQUIRE(ctx, prm->n_iter >= 0);
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  s->last_mode = 0;             // the step-wise entry points always run the streaming kernels
   int rc = flush_fc(s);
   if (rc != SVO_HIP_OK) return rc;
   s->prm = *prm; s->n_slots = n_slots; s->level = -1; s->begun = true;
@@ -1936,6 +1937,10 @@ int svo_hip_sia_download_caches(svo_hip_sia* s, int slot, float* ref_patch, floa
   if (!s) return SVO_HIP_ERR_INVALID;
   svo_hip_ctx* ctx = s->ctx;
   SVO_REQUIRE(ctx, slot >= 0 && slot < s->batch);
+  // the per-pixel caches exist only in the streaming implementation: after a fused run they would be stale
+  if (s->last_mode == 1)
+    return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_download_caches",
+                    "the last run used the fused kernel, which keeps no per-pixel caches in memory (use the step-wise entry points or SVO_HIP_SIA_MODE=stream)");
   const size_t o = (size_t)slot * s->max_n;
   const int n = s->h_fc[slot].n_feat;
   int rc = SVO_HIP_OK;

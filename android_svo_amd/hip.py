@@ -384,6 +384,8 @@ class SeedBatch:
         self.xyz = ctx.empty((self.n, 3), np.float64)
         self.n_zmssd = ctx.empty((self.n,), np.int32)
         self.n_align = ctx.empty((self.n,), np.int32)
+        self.px_cur = ctx.empty((self.n, 2), np.float64)          # Matcher::px_cur_ of each seed's match
+        self.search_level = ctx.empty((self.n,), np.int32)        # Matcher::search_level_
 
     def reset_state(self, a, b, mu, sigma2):
         for d, v in ((self.a, a), (self.b, b), (self.mu, mu), (self.sigma2, sigma2)):
@@ -391,7 +393,7 @@ class SeedBatch:
 
     def free(self):
         for d in (self.px, self.f, self.level, self.a, self.b, self.mu, self.z_range, self.sigma2, self.status, self.z,
-                  self.xyz, self.n_zmssd, self.n_align):
+                  self.xyz, self.n_zmssd, self.n_align, self.px_cur, self.search_level):
             d.free()
 
 
@@ -413,7 +415,35 @@ def depth_filter_update(ctx: Context, ref: Pyramid, ref_slot: int, cur: Pyramid,
         ctx.h, ref.h, ref_slot, cur.h, cur_slot, C.byref(c), _ptr(Tr, C.c_double), _ptr(Tc, C.c_double), hi - lo,
         off(seeds.px, 16), off(seeds.f, 24), off(seeds.level, 4), off(seeds.a, 4), off(seeds.b, 4), off(seeds.mu, 4),
         off(seeds.z_range, 4), off(seeds.sigma2, 4), C.byref(prm), off(seeds.status, 4), off(seeds.z, 8),
-        off(seeds.xyz, 24), off(seeds.n_zmssd, 4), off(seeds.n_align, 4)), "depth_filter_update")
+        off(seeds.xyz, 24), off(seeds.n_zmssd, 4), off(seeds.n_align, 4), off(seeds.px_cur, 16),
+        off(seeds.search_level, 4)), "depth_filter_update")
+
+
+def epipolar_match_batch(ctx: Context, ref: Pyramid, ref_slot: int, cur: Pyramid, cur_slot: int, cam, T_ref_w, T_cur_w,
+                         px, f, level, d_est, d_min, d_max, prm: Optional[CDfParams] = None):
+    """Matcher::findEpipolarMatchDirect over n reference features with explicit depth intervals; returns a dict of
+    ok, depth, px_cur, search_level, epi_length, n_zmssd, n_align_iters."""
+    prm = prm or depth_filter_params()
+    n = len(px)
+    c = make_camera(cam)
+    Tr, Tc = _f64(T_ref_w), _f64(T_cur_w)
+    d_px, d_f = ctx.to_device(_f64(px)), ctx.to_device(_f64(f))
+    d_lvl = ctx.to_device(np.ascontiguousarray(level, dtype=np.int32))
+    d_dep = ctx.to_device(_f64(np.stack([d_est, d_min, d_max])))
+    o = {"ok": ctx.empty((n,), np.uint8), "depth": ctx.empty((n,), np.float64), "px_cur": ctx.empty((n, 2), np.float64),
+         "search_level": ctx.empty((n,), np.int32), "epi_length": ctx.empty((n,), np.float64),
+         "n_zmssd": ctx.empty((n,), np.int32), "n_align_iters": ctx.empty((n,), np.int32)}
+    ctx.check(ctx.lib.svo_hip_epipolar_match_batch_dev(
+        ctx.h, ref.h, ref_slot, cur.h, cur_slot, C.byref(c), _ptr(Tr, C.c_double), _ptr(Tc, C.c_double), n,
+        C.c_void_p(d_px.ptr), C.c_void_p(d_f.ptr), C.c_void_p(d_lvl.ptr), C.c_void_p(d_dep.ptr), C.byref(prm),
+        C.c_void_p(o["ok"].ptr), C.c_void_p(o["depth"].ptr), C.c_void_p(o["px_cur"].ptr), C.c_void_p(o["search_level"].ptr),
+        C.c_void_p(o["epi_length"].ptr), C.c_void_p(o["n_zmssd"].ptr), C.c_void_p(o["n_align_iters"].ptr)),
+        "epipolar_match_batch")
+    out = {k: v.download() for k, v in o.items()}
+    out["ok"] = out["ok"].astype(bool)
+    for v in list(o.values()) + [d_px, d_f, d_lvl, d_dep]:
+        v.free()
+    return out
 
 
 # ---- next rows f-4: pose_optimizer::optimizeGaussNewton, Point::optimize -----------------------------------------

@@ -89,58 +89,71 @@ int main(int argc, char** argv) {
       const SE3 before = cur2->T_f_w_;
       if (align.run(empty_ref, cur2) != 0 || std::memcmp(before.p, cur2->T_f_w_.p, sizeof(before.p)) != 0) throw std::runtime_error("empty-frame contract violated");
 
-      // ---- DepthFilter, keyframe = frame 0, seeds from the case file
-      const auto spx = read_bin<double>(dir + "/seed_px.bin"), sf = read_bin<double>(dir + "/seed_f.bin");
-      const auto slevel = read_bin<int32_t>(dir + "/seed_level.bin");
+      // ---- DepthFilter: keyframe 0 with seed batch A, frames 1..kf2-1, keyframe kf2 with seed batch B (the update on a
+      // ---- keyframe marks the detector grid), then the remaining frames update seeds of BOTH keyframes
       const auto dm = read_bin<double>(dir + "/depth_mean_min.bin");
-      const size_t n_seeds = slevel.size();
-      auto make_features = [&](std::map<Feature*, int>& index) {
+      const int kf2 = (int)read_bin<double>(dir + "/second_keyframe.bin")[0];
+      struct SeedSet { std::vector<double> px, f; std::vector<int32_t> level; };
+      SeedSet setA{read_bin<double>(dir + "/seed_px.bin"), read_bin<double>(dir + "/seed_f.bin"), read_bin<int32_t>(dir + "/seed_level.bin")};
+      SeedSet setB{read_bin<double>(dir + "/seedB_px.bin"), read_bin<double>(dir + "/seedB_f.bin"), read_bin<int32_t>(dir + "/seedB_level.bin")};
+      auto make_features = [&](const SeedSet& ss, Frame* kf, int id0, std::map<Feature*, int>& index) {
         std::vector<Feature*> fts;
-        for (size_t i = 0; i < n_seeds; ++i) {
-          fts.push_back(new Feature(c.frames[0].get(), Vector2d{{spx[2 * i], spx[2 * i + 1]}}, Vector3d{{sf[3 * i], sf[3 * i + 1], sf[3 * i + 2]}}, slevel[i]));
-          index[fts.back()] = (int)i;
+        for (size_t i = 0; i < ss.level.size(); ++i) {
+          fts.push_back(new Feature(kf, Vector2d{{ss.px[2 * i], ss.px[2 * i + 1]}}, Vector3d{{ss.f[3 * i], ss.f[3 * i + 1], ss.f[3 * i + 2]}}, ss.level[i]));
+          index[fts.back()] = id0 + (int)i;
         }
         return fts;
       };
-      // (a) synchronous protocol (no thread): addKeyframe -> initializeSeeds, addFrame -> updateSeeds
-      std::vector<double> conv_a, conv_b;
-      std::map<Feature*, int> index_a, index_b;
-      std::vector<Feature*> fa, fb;
-      {
-        Seed::batch_counter = 0;
-        std::map<Point*, int> dummy;
-        DepthFilter df([&](Point* p, double s2) { conv_a.insert(conv_a.end(), {p->pos_[0], p->pos_[1], p->pos_[2], s2}); delete p; });
-        fa = make_features(index_a);
-        c.frames[0]->setKeyframe();
-        df.addKeyframe(c.frames[0], dm[0], dm[1], fa);
-        for (int k = 1; k < c.n_frames; ++k) df.addFrame(c.frames[k]);
-        dump_filter(df, index_a, conv_a, out, "sync");
-      }
-      // (b) with the worker thread, while this thread keeps running SparseImgAlign (its own context)
+      const int nA = (int)setA.level.size();
+      c.frames[0]->setKeyframe();
+      c.frames[kf2]->setKeyframe();
       size_t align_runs = 0;
-      {
+      std::vector<double> conv_count;
+      auto run_protocol = [&](bool threaded, int sub_batch, const std::string& tag) {
         Seed::batch_counter = 0;
-        DepthFilter df([&](Point* p, double s2) { conv_b.insert(conv_b.end(), {p->pos_[0], p->pos_[1], p->pos_[2], s2}); delete p; });
-        fb = make_features(index_b);
-        df.startThread();
-        df.addKeyframe(c.frames[0], dm[0], dm[1], fb);
-        auto wait_idle = [&]() {
-          while (!df.idle()) {
-            FramePtr cur3 = load_frame(dir, &c.cam, 1, c.n_levels);
-            cur3->T_f_w_ = ref->T_f_w_;
-            if (align.run(ref, cur3) != n_tracked) throw std::runtime_error("alignment changed under concurrency");
-            if (std::memcmp(cur3->T_f_w_.p, cur->T_f_w_.p, sizeof(double) * 7) != 0) throw std::runtime_error("pose changed under concurrency");
-            ++align_runs;
+        std::vector<double> conv;                 // per callback, in callback order: seed id, x, y, z, sigma2
+        std::map<Feature*, int> index;
+        DetectorGrid grid(c.cam.width, c.cam.height, 30);
+        std::vector<Feature*> fa, fb;
+        {
+          DepthFilter df([&](Point* p, double s2) {
+            conv.insert(conv.end(), {(double)index.at(p->obs_.front()), p->pos_[0], p->pos_[1], p->pos_[2], s2});
+            delete p;
+          }, &grid);
+          df.sub_batch_ = sub_batch;
+          fa = make_features(setA, c.frames[0].get(), 0, index);
+          fb = make_features(setB, c.frames[kf2].get(), nA, index);
+          auto wait_idle = [&]() {
+            if (!threaded) return;
+            while (!df.idle()) {
+              FramePtr cur3 = load_frame(dir, &c.cam, 1, c.n_levels);
+              cur3->T_f_w_ = ref->T_f_w_;
+              if (align.run(ref, cur3) != n_tracked) throw std::runtime_error("alignment changed under concurrency");
+              if (std::memcmp(cur3->T_f_w_.p, cur->T_f_w_.p, sizeof(double) * 7) != 0) throw std::runtime_error("pose changed under concurrency");
+              ++align_runs;
+            }
+          };
+          if (threaded) df.startThread();
+          df.addKeyframe(c.frames[0], dm[0], dm[1], fa);
+          wait_idle();
+          for (int k = 1; k < c.n_frames; ++k) {
+            if (k == kf2) df.addKeyframe(c.frames[k], dm[0], dm[1], fb);
+            else df.addFrame(c.frames[k]);
+            wait_idle();
           }
-        };
-        wait_idle();
-        for (int k = 1; k < c.n_frames; ++k) { df.addFrame(c.frames[k]); wait_idle(); }
-        df.stopThread();
-        dump_filter(df, index_b, conv_b, out, "thread");
-      }
-      write_bin(out + "/summary.bin", std::vector<double>{(double)align_runs, (double)conv_a.size() / 4, (double)conv_b.size() / 4});
-      for (Feature* f2 : fa) delete f2;
-      for (Feature* f2 : fb) delete f2;
+          if (threaded) df.stopThread();
+          dump_filter(df, index, conv, out, tag);
+        }
+        std::vector<uint8_t> occ(grid.grid_occupancy_.begin(), grid.grid_occupancy_.end());
+        write_bin(out + "/" + tag + "_grid.bin", occ);
+        conv_count.push_back((double)conv.size() / 5);
+        for (Feature* f2 : fa) delete f2;
+        for (Feature* f2 : fb) delete f2;
+      };
+      run_protocol(false, 4096, "sync");          // (a) synchronous protocol (no thread)
+      run_protocol(false, 700, "sync_small");     // (b) the same with small device sub-batches: identical results
+      run_protocol(true, 4096, "thread");         // (c) worker thread, while this thread keeps running SparseImgAlign
+      write_bin(out + "/summary.bin", std::vector<double>{(double)align_runs, conv_count[0], conv_count[1], conv_count[2]});
     }
     std::printf("svo_host_demo OK\n");
     return 0;

@@ -4,7 +4,9 @@
 // with the same names, methods and protocol, but on minimal own data types (no Eigen, no OpenCV), so that
 // the host side can be built and RUN wherever libsvo_hip.so runs.  The bindings that plug into the
 // reference's real headers are include/svo_dropin/ (compile-checked only); this file is
-// their executable twin and carries the same host logic:
+// their executable counterpart.  DepthFilter::updateSeeds is NOT a second copy: both sides instantiate
+// hip_bridge::updateSeedsBatched (include/svo_dropin/depth_filter_batch.h) with a small Host policy, so the
+// batching / ordering / halt logic the GPU tests exercise is the code the drop-in ships.  Host logic here:
 //   * SparseImgAlign::run       S/sparse_img_align.cpp:51-92   (flatten fts_, upload, run, read back)
 //   * DepthFilter protocol      S/depth_filter.cpp:47-229,237-357 (thread, 3-deep frame queue, keyframe
 //                               hand-off with the halt flag, std::list<Seed>, age-out, convergence callback)
@@ -28,6 +30,7 @@
 #include <vector>
 
 #include "svo_hip.h"
+#include "svo_dropin/depth_filter_batch.h"
 
 namespace svo {
 
@@ -73,7 +76,13 @@ struct PinholeCamera {            // distortion-free vk::PinholeCamera
   }
 };
 
-struct Point { Vector3d pos_; explicit Point(const Vector3d& p) : pos_(p) {} };
+struct Feature;
+struct Point {                                      // I/point.h: position + the features that observe it
+  Vector3d pos_;
+  std::list<Feature*> obs_;
+  explicit Point(const Vector3d& p) : pos_(p) {}
+  Point(const Vector3d& p, Feature* ftr) : pos_(p) { obs_.push_front(ftr); }     // S/point.cpp:39-48
+};
 struct Frame;
 struct Feature {
   Frame* frame; Vector2d px; Vector3d f; int level; Point* point;
@@ -191,6 +200,20 @@ class SparseImgAlign {
   double chi2_ = 1e10;
 };
 
+/// The detector grid of feature_detection::AbstractDetector (S/feature_detection.cpp:24-64): cells the depth filter
+/// marks on keyframes so that initializeSeeds does not seed again where a live seed was just matched.
+struct DetectorGrid {
+  int cell_size_, grid_n_cols_, grid_n_rows_;
+  std::vector<bool> grid_occupancy_;
+  DetectorGrid(int img_width, int img_height, int cell_size)
+      : cell_size_(cell_size), grid_n_cols_((int)std::ceil((double)img_width / cell_size)),
+        grid_n_rows_((int)std::ceil((double)img_height / cell_size)), grid_occupancy_((size_t)grid_n_cols_ * grid_n_rows_, false) {}
+  void resetGrid() { std::fill(grid_occupancy_.begin(), grid_occupancy_.end(), false); }
+  void setGridOccpuancy(const Vector2d& px) {                                   // :58-64 (spelling as in the reference)
+    grid_occupancy_.at((size_t)((int)(px[1] / cell_size_) * grid_n_cols_ + (int)(px[0] / cell_size_))) = true;
+  }
+};
+
 /// I/depth_filter.h:36-52
 struct Seed {
   static int batch_counter, seed_counter;
@@ -215,7 +238,8 @@ class DepthFilter {
     bool verbose = false;
   } options_;
 
-  explicit DepthFilter(callback_t seed_converged_cb) : seed_converged_cb_(std::move(seed_converged_cb)) {
+  explicit DepthFilter(callback_t seed_converged_cb, DetectorGrid* feature_detector = nullptr)
+      : feature_detector_(feature_detector), seed_converged_cb_(std::move(seed_converged_cb)) {
     hip_bridge::check(svo_hip_ctx_create(&ctx_, 0, nullptr), nullptr, "ctx_create");   // the filter thread's own stream
     kf_pyr_.reset(new hip_bridge::PyramidCache(ctx_, 8));
     cur_pyr_.reset(new hip_bridge::PyramidCache(ctx_, 2));
@@ -321,56 +345,48 @@ class DepthFilter {
     }
   }
 
-  /// depth_filter.cpp:237-341, batched per reference keyframe on the GPU
+  /// Host policy of hip_bridge::updateSeedsBatched on this file's data model
+  struct BatchHost {
+    DepthFilter* df;
+    Frame* keyframeOf(const Seed& s) const { return s.ftr->frame; }
+    void feature(const Seed& s, double px[2], double f[3], int* level) const {
+      px[0] = s.ftr->px[0]; px[1] = s.ftr->px[1];
+      for (int k = 0; k < 3; ++k) f[k] = s.ftr->f[k];
+      *level = s.ftr->level;
+    }
+    void pose7(const Frame& fr, double T[7]) const { std::memcpy(T, fr.T_f_w_.p, sizeof(double) * 7); }
+    int keyframeSlot(Frame& fr) { return df->kf_pyr_->slotOf(fr); }
+    int currentSlot(Frame& fr) { return df->cur_pyr_->slotOf(fr); }
+    svo_hip_pyramid* keyframePyramids() const { return df->kf_pyr_->pyramid(); }
+    svo_hip_pyramid* currentPyramids() const { return df->cur_pyr_->pyramid(); }
+    svo_hip_camera camera(const Frame& fr) const { return fr.cam_->toC(); }
+    bool isKeyframe(const Frame& fr) const { return fr.isKeyframe(); }
+    void setGridOccupancy(const double px_cur[2]) {                              // depth_filter.cpp:302-306
+      if (df->feature_detector_) df->feature_detector_->setGridOccpuancy(Vector2d{{px_cur[0], px_cur[1]}});
+    }
+    void converged(Seed& s, const double xyz[3]) {                               // :310-331
+      Point* point = new Point(Vector3d{{xyz[0], xyz[1], xyz[2]}}, s.ftr);
+      s.ftr->point = point;
+      df->seed_converged_cb_(point, s.sigma2);
+    }
+  };
+
+  /// depth_filter.cpp:237-341 through the shared batched implementation
   virtual void updateSeeds(FramePtr frame) {
     lock_t lock(seeds_mut_);
-    std::map<Frame*, std::vector<std::list<Seed>::iterator>> by_kf;
-    for (auto it = seeds_.begin(); it != seeds_.end();) {
-      if (seeds_updating_halt_) return;
-      if ((Seed::batch_counter - it->batch_id) > options_.max_n_kfs) { it = seeds_.erase(it); continue; }   // :256-261
-      by_kf[it->ftr->frame].push_back(it);
-      ++it;
-    }
-    if (by_kf.empty()) return;
-    const svo_hip_camera cam = frame->cam_->toC();
-    const int cur_slot = cur_pyr_->slotOf(*frame);
+    if (seeds_.empty()) return;
     svo_hip_df_params prm{3, 10, 1000, options_.seed_convergence_sigma2_thresh};
-    for (auto& kf : by_kf) {
-      if (seeds_updating_halt_) return;                                         // halt honoured at batch boundaries (:253)
-      Frame* ref = kf.first;
-      auto& its = kf.second;
-      const int n = (int)its.size();
-      const int ref_slot = kf_pyr_->slotOf(*ref);
-      std::vector<double> px(2 * (size_t)n), f(3 * (size_t)n), z((size_t)n), xyz(3 * (size_t)n);
-      std::vector<int32_t> level((size_t)n), status((size_t)n);
-      std::vector<float> a((size_t)n), b((size_t)n), mu((size_t)n), zr((size_t)n), s2((size_t)n);
-      for (int i = 0; i < n; ++i) {
-        const Seed& s = *its[i];
-        px[2 * i] = s.ftr->px[0]; px[2 * i + 1] = s.ftr->px[1];
-        for (int k = 0; k < 3; ++k) f[3 * i + k] = s.ftr->f[k];
-        level[i] = s.ftr->level;
-        a[i] = s.a; b[i] = s.b; mu[i] = s.mu; zr[i] = s.z_range; s2[i] = s.sigma2;
-      }
-      hip_bridge::check(svo_hip_depth_filter_update(ctx_, kf_pyr_->pyramid(), ref_slot, cur_pyr_->pyramid(), cur_slot, &cam,
-                                                   ref->T_f_w_.p, frame->T_f_w_.p, n, px.data(), f.data(), level.data(),
-                                                   a.data(), b.data(), mu.data(), zr.data(), s2.data(), &prm, status.data(),
-                                                   z.data(), xyz.data(), nullptr, nullptr),
-                        ctx_, "depth_filter_update");
-      for (int i = 0; i < n; ++i) {
-        auto it = its[i];
-        it->a = a[i]; it->b = b[i]; it->mu = mu[i]; it->sigma2 = s2[i];
-        if (status[i] == SVO_HIP_SEED_CONVERGED) {                              // :310-331
-          Point* point = new Point(Vector3d{{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]}});
-          it->ftr->point = point;
-          seed_converged_cb_(point, it->sigma2);
-          seeds_.erase(it);
-        } else if (status[i] == SVO_HIP_SEED_NAN) {                             // :333-337
-          seeds_.erase(it);
-        }
-      }
-    }
+    BatchHost host{this};
+    last_stats_ = hip_bridge::updateSeedsBatched(host, ctx_, seeds_, *frame, prm, Seed::batch_counter, options_.max_n_kfs,
+                                                 seeds_updating_halt_, sub_batch_);
+    if (last_stats_.n_device_errors) throw std::runtime_error(std::string("depth_filter_update: ") + svo_hip_last_error(ctx_));
   }
 
+ public:
+  int sub_batch_ = 4096;                         ///< seeds per device call (the halt flag is polled in between)
+  hip_bridge::SeedBatchStats last_stats_;
+ protected:
+  DetectorGrid* feature_detector_ = nullptr;
   callback_t seed_converged_cb_;
   std::list<Seed> seeds_;
   std::mutex seeds_mut_;

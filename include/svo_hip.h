@@ -175,14 +175,19 @@ int svo_hip_sia_get_profile(svo_hip_sia* sia, double* residual_ms, uint64_t* res
                             double* precompute_ms, uint64_t* precompute_launches);
 /* cached reference patches / per-patch Jacobian records of one slot, for kernel-level tests (filled by the
  * streaming kernels, i.e. after the step-wise entry points or a run with SVO_HIP_SIA_MODE=stream):
- * ref_patch[n][16] f32, dx[n][16] f32, dy[n][16] f32, visible[n] u8 (any may be NULL) */
+ * ref_patch[n][16] f32, dx[n][16] f32, dy[n][16] f32, visible[n] u8 (any may be NULL).  Returns SVO_HIP_ERR_STATE when
+ * the last svo_hip_sia_run used the fused kernel (it keeps no per-pixel caches in memory). */
 int svo_hip_sia_download_caches(svo_hip_sia* sia, int slot, float* ref_patch, float* dx, float* dy,
                                 uint8_t* visible);
 
 /* ---- feature_alignment::align2D (I/feature_alignment.h:40-47, feature_alignment.cpp:154-282) */
 /* n independent 8x8 patches refined on level `level` of cur->slot: ref_patch_with_border
- * [n][100] u8, ref_patch [n][64] u8, px [n][2] f64 in/out (level coordinates), converged [n] u8,
- * iters [n] i32 (iterations executed; may be NULL).  All pointers are device pointers. */
+ * [n][100] u8, ref_patch [n][64] u8 (NULL: the interior of the bordered patch, which is how every caller of the
+ * reference fills it, matcher.cpp:138-147), px [n][2] f64 in/out (level coordinates), converged [n] u8,
+ * iters [n] i32 (iterations executed; may be NULL).  All pointers are device pointers; the patch arrays must be
+ * 4-byte aligned (the reference's are 16-byte aligned members of Matcher).
+ * One lane per patch walks the 64 pixels in the reference's order: `converged` and px equal the CPU path's bit for
+ * bit. */
 int svo_hip_align2d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int slot, int level, int n,
                               const uint8_t* ref_patch_with_border_dev, const uint8_t* ref_patch_dev,
                               int n_iter, double* px_dev, uint8_t* converged_dev, int32_t* iters_dev);
@@ -257,8 +262,12 @@ typedef struct {
  * cur->cur_slot: visibility test, Matcher::findEpipolarMatchDirect (epipolar ZMSSD search +
  * align2D + triangulation), computeTau, updateSeed, convergence test.  SoA device arrays:
  * px[n][2] f64, f[n][3] f64, level[n] i32 (Feature px/f/level), a,b,mu,sigma2 in/out f32, z_range f32;
- * outputs status[n] i32, z[n] f64, xyz_world[n][3] f64 (valid when converged), and the work
- * counters n_zmssd[n], n_align_iters[n] i32 (any output except status may be NULL). */
+ * outputs status[n] i32, z[n] f64, xyz_world[n][3] f64 (valid when converged), the work
+ * counters n_zmssd[n], n_align_iters[n] i32, and the matcher's public results of the seed's call:
+ * px_cur[n][2] f64 = Matcher::px_cur_ (level-0 pixel of the match, matcher.cpp:345; valid where status >=
+ * SVO_HIP_SEED_UPDATED, NaN elsewhere) -- what updateSeeds passes to feature_detector_->setGridOccpuancy on
+ * keyframes (depth_filter.cpp:302-306) -- and search_level[n] i32 = Matcher::search_level_ (-1 for seeds that
+ * never reached the matcher).  Any output except status may be NULL. */
 int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,
                                     const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
                                     const double T_ref_w[7], const double T_cur_w[7], int n,
@@ -266,7 +275,20 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
                                     float* a_dev, float* b_dev, float* mu_dev, const float* z_range_dev,
                                     float* sigma2_dev, const svo_hip_df_params* prm, int32_t* status_dev,
                                     double* z_dev, double* xyz_world_dev, int32_t* n_zmssd_dev,
-                                    int32_t* n_align_iters_dev);
+                                    int32_t* n_align_iters_dev, double* px_cur_dev, int32_t* search_level_dev);
+
+/* Matcher::findEpipolarMatchDirect over n reference features (I/matcher.h:113-121, matcher.cpp:207-355) with the
+ * depth interval given by the caller: depth_est_min_max[3][n] f64 = d_estimate[n], d_min[n], d_max[n].  Outputs:
+ * ok[n] u8 (the return value), depth[n] f64 (the `depth` out-parameter), and the public members the call leaves
+ * behind: px_cur[n][2] (px_cur_; NaN when the alignment failed), search_level[n] (search_level_), epi_length[n]
+ * (epi_length_), plus the work counters.  Any output except ok may be NULL.  Device pointers. */
+int svo_hip_epipolar_match_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,
+                                     const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                                     const double T_ref_w[7], const double T_cur_w[7], int n, const double* px_dev,
+                                     const double* f_dev, const int32_t* level_dev,
+                                     const double* depth_est_min_max_dev, const svo_hip_df_params* prm,
+                                     uint8_t* ok_dev, double* depth_dev, double* px_cur_dev, int32_t* search_level_dev,
+                                     double* epi_length_dev, int32_t* n_zmssd_dev, int32_t* n_align_iters_dev);
 
 /* Converged seeds of a batch as packed records {seed id = id_offset + index, mu, sigma2, x, y, z} (f64[6]), in seed
  * order, plus their number: the payload of the multi-GPU gather of SURVEY 8e (and of the seed_converged callbacks,
@@ -282,7 +304,7 @@ int svo_hip_depth_filter_update(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, in
                                 const double* f, const int32_t* level, float* a, float* b, float* mu,
                                 const float* z_range, float* sigma2, const svo_hip_df_params* prm,
                                 int32_t* status, double* z, double* xyz_world, int32_t* n_zmssd,
-                                int32_t* n_align_iters);
+                                int32_t* n_align_iters, double* px_cur, int32_t* search_level);
 
 /* ---- next rows: the two small Gauss-Newton refinements of FrameHandlerMono::processFrame ------
  * pose_optimizer::optimizeGaussNewton (I/pose_optimizer.h:36-45, pose_optimizer.cpp:31-181; caller

@@ -212,13 +212,17 @@ def update_seeds(cam, ref_pyr, cur_pyr, T_ref_w, T_cur_w, px, f, level, a, b, mu
     nz = np.zeros(n, dtype=np.int32)
     na = np.zeros(n, dtype=np.int32)
     Tr, Tc = f64(T_ref_w), f64(T_cur_w)
-    lib().svo_orc_update_seeds(
+    px_cur = np.zeros((n, 2))
+    sl = np.zeros(n, dtype=np.int32)
+    lib().svo_orc_update_seeds_ex(
         C.byref(c), pyr_ptrs(ref_pyr), pyr_ptrs(cur_pyr), _p(Tr, C.c_double), _p(Tc, C.c_double),
         C.c_int(n), _p(px, C.c_double), _p(f, C.c_double), _p(level, C.c_int), _p(a, C.c_float),
         _p(b, C.c_float), _p(mu, C.c_float), _p(z_range, C.c_float), _p(sigma2, C.c_float),
         C.c_int(n_pyr_levels), C.c_int(align_max_iter), C.c_int(max_steps), C.c_double(conv_thresh),
-        _p(status, C.c_int), _p(z, C.c_double), _p(xyz, C.c_double), _p(nz, C.c_int), _p(na, C.c_int))
-    return {"status": status, "z": z, "xyz_world": xyz, "n_zmssd": nz, "n_align_iters": na}
+        _p(status, C.c_int), _p(z, C.c_double), _p(xyz, C.c_double), _p(nz, C.c_int), _p(na, C.c_int),
+        _p(px_cur, C.c_double), _p(sl, C.c_int))
+    return {"status": status, "z": z, "xyz_world": xyz, "n_zmssd": nz, "n_align_iters": na, "px_cur": px_cur,
+            "search_level": sl}
 
 
 def find_match_direct(cam, ref_pyr, cur_pyr, T_ref_w, T_cur_w, px_ref, f_ref, level_ref, pt_pos, px_cur, edgelet=False,

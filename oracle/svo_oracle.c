@@ -1162,13 +1162,13 @@ double svo_orc_compute_tau(const double T_ref_cur[7], const double f[3], double 
 }
 
 /* S/depth_filter.cpp:237-341 (per-seed body; list/ageing/halt bookkeeping is host-side) */
-int svo_orc_update_seeds(
+int svo_orc_update_seeds_ex(
     const svo_orc_camera* cam, const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr,
     const double T_ref_w[7], const double T_cur_w[7], int n_seeds, const double* px,
     const double* f, const int* level, float* a, float* b, float* mu, const float* z_range,
     float* sigma2, int n_pyr_levels, int align_max_iter, int max_epi_search_steps,
     double convergence_sigma2_thresh, int* status, double* z_out, double* xyz_world,
-    int* n_zmssd, int* n_align_iters) {
+    int* n_zmssd, int* n_align_iters, double* px_cur_out, int* search_level_out) {
   const double focal_length = fabs(cam->fx);
   const double px_noise = 1.0;
   const double px_error_angle = atan(px_noise / (2.0 * focal_length)) * 2.0;
@@ -1183,6 +1183,8 @@ int svo_orc_update_seeds(
     if (z_out) z_out[i] = 0.0;
     if (n_zmssd) n_zmssd[i] = 0;
     if (n_align_iters) n_align_iters[i] = 0;
+    if (px_cur_out) { px_cur_out[2 * i] = NAN; px_cur_out[2 * i + 1] = NAN; }
+    if (search_level_out) search_level_out[i] = -1;
     const double inv_mu = 1.0 / mu[i];
     const double pf[3] = {inv_mu * fi[0], inv_mu * fi[1], inv_mu * fi[2]};
     double xyz_f[3];
@@ -1203,7 +1205,9 @@ int svo_orc_update_seeds(
         1.0 / z_inv_min, 1.0 / z_inv_max, n_pyr_levels, align_max_iter, max_epi_search_steps, &er);
     if (n_zmssd) n_zmssd[i] = er.n_zmssd;
     if (n_align_iters) n_align_iters[i] = er.n_align_iters;
+    if (search_level_out) search_level_out[i] = er.search_level;       /* matcher_.search_level_ */
     if (!ok) { b[i] += 1.0f; status[i] = SVO_SEED_NO_MATCH; continue; }
+    if (px_cur_out) { px_cur_out[2 * i] = er.px_cur[0]; px_cur_out[2 * i + 1] = er.px_cur[1]; }   /* matcher_.px_cur_, :302-306 */
     const double z = er.depth;
     if (z_out) z_out[i] = z;
     double tau = svo_orc_compute_tau(T_ref_cur, fi, z, px_error_angle);
@@ -1226,6 +1230,18 @@ int svo_orc_update_seeds(
     }
   }
   return 0;
+}
+
+int svo_orc_update_seeds(
+    const svo_orc_camera* cam, const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr,
+    const double T_ref_w[7], const double T_cur_w[7], int n_seeds, const double* px,
+    const double* f, const int* level, float* a, float* b, float* mu, const float* z_range,
+    float* sigma2, int n_pyr_levels, int align_max_iter, int max_epi_search_steps,
+    double convergence_sigma2_thresh, int* status, double* z_out, double* xyz_world,
+    int* n_zmssd, int* n_align_iters) {
+  return svo_orc_update_seeds_ex(cam, ref_pyr, cur_pyr, T_ref_w, T_cur_w, n_seeds, px, f, level, a, b, mu, z_range, sigma2,
+                                 n_pyr_levels, align_max_iter, max_epi_search_steps, convergence_sigma2_thresh, status,
+                                 z_out, xyz_world, n_zmssd, n_align_iters, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------ */

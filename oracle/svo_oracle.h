@@ -214,6 +214,18 @@ int svo_orc_update_seeds(
     double convergence_sigma2_thresh,
     int* status, double* z_out, double* xyz_world /*[n][3], valid when converged*/,
     int* n_zmssd, int* n_align_iters);
+/* the same, also reporting the matcher's public members after each seed's findEpipolarMatchDirect call:
+ * px_cur[n][2] (Matcher::px_cur_, what updateSeeds hands to setGridOccpuancy on keyframes,
+ * depth_filter.cpp:302-306; NaN unless the seed was updated) and search_level[n] (-1: matcher not reached) */
+int svo_orc_update_seeds_ex(
+    const svo_orc_camera* cam, const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr,
+    const double T_ref_w[7], const double T_cur_w[7],
+    int n_seeds, const double* px, const double* f, const int* level,
+    float* a, float* b, float* mu, const float* z_range, float* sigma2,
+    int n_pyr_levels, int align_max_iter, int max_epi_search_steps,
+    double convergence_sigma2_thresh,
+    int* status, double* z_out, double* xyz_world,
+    int* n_zmssd, int* n_align_iters, double* px_cur_out, int* search_level_out);
 
 /* ---- next rows f-4: pose_optimizer::optimizeGaussNewton (pose_optimizer.cpp:31-181) and
  * ---- Point::optimize (point.cpp:130-192) ------------------------------------------------ */

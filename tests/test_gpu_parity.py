@@ -252,56 +252,54 @@ def test_stepwise_equals_run_and_sharded_sum(ctx):
     _free(sia, ref, cur)
 
 
+def _assert_px_bits_equal(got, want):
+    """bitwise equality of two float64 pixel arrays (NaN payloads included)"""
+    np.testing.assert_array_equal(np.ascontiguousarray(got, dtype=np.float64).view(np.uint64),
+                                  np.ascontiguousarray(want, dtype=np.float64).view(np.uint64))
+
+
 def test_align2d_against_reference_fixture(ctx, golden):
-    """feature_alignment::align2D outputs recorded from the reference's own code."""
+    """feature_alignment::align2D outputs recorded from the reference's own code: the lane-per-patch kernel walks the
+    pixels in the reference's order, so the converged flags are EQUAL and the refined pixels BIT-IDENTICAL."""
     g = golden("align.npz")
     cur = g["cur"]
     h, w = cur.shape
     pyr = hip.Pyramid(ctx, w, h, 1, 1)
     pyr.upload(0, [cur])
-    sel = np.where(g["n_iter"] == 10)[0]
-    conv, px, iters = hip.align2d_batch(ctx, pyr, 0, 0, g["pwb"][sel], g["patch"][sel], 10, g["px_in"][sel])
-    want_ok = g["ok"][sel].astype(bool)
-    want_px = g["px_out"][sel]
-    # convergence flag: a 0.5 px update threshold, decided on f32 sums reduced in another order
-    assert (conv != want_ok).mean() <= 0.01
-    both = conv & want_ok
-    err = np.abs(px[both] - want_px[both]).max(axis=1)
-    assert np.percentile(err, 99) < 2e-4 and err.max() < 5e-3, (np.percentile(err, 99), err.max())
-    # border / flat-template cases behave like the reference: not converged; NaN stays NaN
-    for i in (0, 1, 2, 3):
-        j = int(np.where(sel == i)[0][0])
-        assert not conv[j]
-        np.testing.assert_array_equal(np.isnan(px[j]), np.isnan(want_px[j]))
-    for k in (4, 5, 6):      # other iteration budgets
-        c2, p2, _ = hip.align2d_batch(ctx, pyr, 0, 0, g["pwb"][k:k + 1], g["patch"][k:k + 1], int(g["n_iter"][k]),
-                                      g["px_in"][k:k + 1])
-        assert bool(c2[0]) == bool(g["ok"][k])
-        np.testing.assert_allclose(p2[0], g["px_out"][k], atol=2e-4)
+    for budget in np.unique(g["n_iter"]):
+        sel = np.where(g["n_iter"] == budget)[0]
+        conv, px, iters = hip.align2d_batch(ctx, pyr, 0, 0, g["pwb"][sel], g["patch"][sel], int(budget), g["px_in"][sel])
+        np.testing.assert_array_equal(conv, g["ok"][sel].astype(bool))
+        _assert_px_bits_equal(px, g["px_out"][sel])
+    # the separate 8x8 ref_patch argument is honoured (the reference reads it, not the interior of the bordered patch)
+    sel = np.where(g["n_iter"] == 10)[0][:64]
+    other = g["patch"][sel][::-1].copy()
+    c1, p1, _ = hip.align2d_batch(ctx, pyr, 0, 0, g["pwb"][sel], other, 10, g["px_in"][sel])
+    for j, i in enumerate(sel):
+        ok_o, px_o, _ = orc.align2d(cur, g["pwb"][i], other[j], 10, g["px_in"][i])
+        assert bool(c1[j]) == bool(ok_o)
+        _assert_px_bits_equal(p1[j], px_o)
     pyr.destroy()
 
 
 def test_align1d_against_reference_fixture(ctx, golden):
-    """feature_alignment::align1D outputs recorded from the reference's own code (secondary row a-7)."""
+    """feature_alignment::align1D outputs recorded from the reference's own code (secondary row a-7): equal flags,
+    bit-identical pixels and h_inv (the serial f32 sum of J0^2 included)."""
     g = golden("align.npz")
     cur = g["cur"]
     pyr = hip.Pyramid(ctx, cur.shape[1], cur.shape[0], 1, 1)
     pyr.upload(0, [cur])
     sel = np.where(g["n_iter"] == 10)[0]
     conv, px, hinv, iters = hip.align1d_batch(ctx, pyr, 0, 0, g["pwb"][sel], g["dirs"][sel], 10, g["px_in"][sel])
-    want_ok, want_px, want_h = g["ok1"][sel].astype(bool), g["px_out1"][sel], g["hinv"][sel]
-    finite = np.isfinite(want_h)
-    np.testing.assert_allclose(hinv[finite], want_h[finite], rtol=2e-6)      # f32 sum of J0^2 in another order
-    # convergence needs |update| < 0.03 px and no chi2 increase: decided on f32 sums -> a few borderline flips
-    assert (conv != want_ok).mean() <= 0.03
-    both = conv & want_ok
-    assert both.sum() > 100
-    err = np.abs(px[both] - want_px[both]).max(axis=1)
-    assert np.percentile(err, 95) < 5e-3 and err.max() < 5e-2, (np.percentile(err, 95), err.max())
+    np.testing.assert_array_equal(conv, g["ok1"][sel].astype(bool))
+    _assert_px_bits_equal(px, g["px_out1"][sel])
+    _assert_px_bits_equal(hinv, g["hinv"][sel])
+    assert conv.sum() > 100
     pyr.destroy()
 
 
 def test_align2d_batch_c2_shape(ctx):
+    """BASELINE config C2's align2D batch (5000 patches) against the oracle: everything equal."""
     ac = seedsynth.make_align_case(n=5000)
     pyr = hip.Pyramid(ctx, ac.cam.width, ac.cam.height, 5, 1)
     pyr.upload(0, ac.cur_pyr)
@@ -311,11 +309,14 @@ def test_align2d_batch_c2_shape(ctx):
     it_o = np.zeros(len(px), dtype=np.int32)
     for i in range(len(px)):
         ok_o[i], px_o[i], it_o[i] = orc.align2d(ac.cur_pyr[0], ac.pwb[i], ac.patch[i], 10, ac.px_init[i])
-    assert (conv != ok_o).mean() < 0.002
-    both = conv & ok_o
-    err = np.abs(px[both] - px_o[both]).max(axis=1)
-    assert np.percentile(err, 99.9) < 1e-3, np.percentile(err, 99.9)
-    assert (iters == it_o).mean() > 0.998
+    np.testing.assert_array_equal(conv, ok_o)
+    np.testing.assert_array_equal(iters, it_o)
+    _assert_px_bits_equal(px, px_o)
+    # ragged tails: every batch size around the 64-patch wave boundary gives the same per-patch answers
+    for n in (1, 63, 64, 65, 127, 129):
+        c, p, it = hip.align2d_batch(ctx, pyr, 0, 0, ac.pwb[:n], ac.patch[:n], 10, ac.px_init[:n])
+        np.testing.assert_array_equal(c, ok_o[:n])
+        _assert_px_bits_equal(p, px_o[:n])
     pyr.destroy()
 
 
@@ -364,15 +365,16 @@ def test_depth_filter_update_parity(ctx):
                              sc.z_range, s2)
         st = sb.status.download()
         nz = sb.n_zmssd.download()
-        assert (st == o["status"]).mean() > 0.999, it
-        same = st == o["status"]
-        np.testing.assert_array_equal(nz[same], o["n_zmssd"][same])         # integer search work: exact
-        upd = same & (st >= hip.SEED_UPDATED)
+        np.testing.assert_array_equal(st, o["status"])                      # every seed takes the reference's decision
+        np.testing.assert_array_equal(nz, o["n_zmssd"])                     # integer search work: exact
+        np.testing.assert_array_equal(sb.n_align.download(), o["n_align_iters"])
+        np.testing.assert_array_equal(sb.search_level.download(), o["search_level"])      # Matcher::search_level_
+        _assert_px_bits_equal(sb.px_cur.download(), o["px_cur"])                          # Matcher::px_cur_ (NaN unless updated)
+        upd = st >= hip.SEED_UPDATED
         z = sb.z.download()
-        np.testing.assert_allclose(z[upd], o["z"][upd], rtol=2e-4)
+        np.testing.assert_allclose(z[upd], o["z"][upd], rtol=1e-12)         # bit-identical match pixel -> same triangulation
         gmu = sb.mu.download()
-        np.testing.assert_allclose(gmu[upd], mu[upd], rtol=2e-4)
-        assert np.median(np.abs(z[upd] - o["z"][upd]) / o["z"][upd]) < 1e-6
+        np.testing.assert_allclose(gmu[upd], mu[upd], rtol=3e-6)            # exp()/acos() differ by ulps between libms
         # keep both sides in lock-step for the next round
         sb.reset_state(a, b, mu, s2)
     assert (o["status"] == hip.SEED_CONVERGED).sum() > 0 or True
@@ -504,11 +506,11 @@ def test_full_size_c4_seeds_properties(ctx):
     a, b, m, v = (x[idx].copy() for x in (sc.a, sc.b, sc.mu, sc.sigma2))
     o = orc.update_seeds(sc.cam, sc.ref_pyr, sc.cur_pyr, sc.T_ref_w, sc.T_cur_w, sc.px[idx], sc.f[idx], sc.level[idx], a, b, m,
                          sc.z_range[idx].copy(), v)
-    assert (o["status"] == st[idx]).mean() > 0.998
-    same = o["status"] == st[idx]
-    np.testing.assert_array_equal(o["n_zmssd"][same], nz[idx][same])
-    good = same & (st[idx] >= hip.SEED_UPDATED)
-    np.testing.assert_allclose(mu[idx][good], m[good], rtol=2e-4)
+    np.testing.assert_array_equal(o["status"], st[idx])
+    np.testing.assert_array_equal(o["n_zmssd"], nz[idx])
+    good = st[idx] >= hip.SEED_UPDATED
+    np.testing.assert_allclose(z[idx][good], o["z"][good], rtol=1e-12)
+    np.testing.assert_allclose(mu[idx][good], m[good], rtol=3e-6)
     _free(sb, kf, cf)
 
 
@@ -574,16 +576,11 @@ def test_match_direct_batch(ctx):
     assert (~framed).sum() > 10 and not ok[~framed].any()
     np.testing.assert_array_equal(px_out[~framed], px_cur[~framed])        # untouched when the frame test fails
     np.testing.assert_array_equal(sl[framed], sl_o[framed])                # integer decision: exact
-    c2 = framed & (edge == 0)
-    assert (ok[c2] != ok_o[c2]).mean() < 0.01
-    both = c2 & ok & ok_o
-    assert both.sum() > 1000 and sl[both].max() >= 1
-    assert np.percentile(np.abs(px_out[both] - px_o[both]).max(axis=1), 99) < 2e-3
-    e1 = framed & (edge == 1)
-    assert (ok[e1] != ok_o[e1]).mean() < 0.05
-    both1 = e1 & ok & ok_o
-    assert both1.sum() > 50
-    assert np.percentile(np.abs(px_out[both1] - px_o[both1]).max(axis=1), 95) < 2e-2
+    np.testing.assert_array_equal(ok, ok_o)                                # corners (align2D) and edgelets (align1D) alike
+    _assert_px_bits_equal(px_out[framed], px_o[framed])
+    c2 = framed & (edge == 0) & ok
+    assert c2.sum() > 1000 and sl[c2].max() >= 1
+    assert (framed & (edge == 1) & ok).sum() > 50
     ref.destroy(); cur.destroy()
 
 
@@ -676,16 +673,17 @@ def test_depth_filter_all_paths(ctx):
     assert counts[0] > 50 and counts[1] > 50 and counts[2] > 50 and counts[3] > 50, counts      # the case covers the branches
     assert (o["n_zmssd"] > 64).sum() > 20                                # multi-chunk searches happened
     assert ((o["n_zmssd"] == 0) & (o["n_align_iters"] > 0)).sum() > 50   # direct-align path happened
-    agree = st == o["status"]
-    assert agree.mean() > 0.995, np.bincount(st, minlength=6)
+    np.testing.assert_array_equal(st, o["status"])                       # every branch decision equals the CPU path's
     np.testing.assert_array_equal(nz, o["n_zmssd"])                      # search work is integer-exact for EVERY seed
-    assert (na == o["n_align_iters"]).mean() > 0.99
-    failed = agree & (st <= hip.SEED_NO_MATCH)
+    np.testing.assert_array_equal(na, o["n_align_iters"])
+    np.testing.assert_array_equal(sb.search_level.download(), o["search_level"])
+    _assert_px_bits_equal(sb.px_cur.download(), o["px_cur"])
+    failed = st <= hip.SEED_NO_MATCH
     np.testing.assert_array_equal(gb[failed], ob[failed])                # untouched, or b++ on a failed match: exact
     assert ((st == hip.SEED_NO_MATCH) & (gb == b + 1)).sum() == (st == hip.SEED_NO_MATCH).sum()
-    upd = agree & (st >= hip.SEED_UPDATED)
-    np.testing.assert_allclose(gz[upd], o["z"][upd], rtol=1e-3)
-    np.testing.assert_allclose(gmu[upd], om[upd], rtol=1e-3)
+    upd = st >= hip.SEED_UPDATED
+    np.testing.assert_allclose(gz[upd], o["z"][upd], rtol=1e-12)
+    np.testing.assert_allclose(gmu[upd], om[upd], rtol=3e-6)
     nanseed = np.isnan(s2)
     assert (st[nanseed] == o["status"][nanseed]).all()
     _free(sb, kf, cf)
@@ -724,6 +722,29 @@ def test_sparse_img_align_against_reference_run(ctx, sia_mode, golden, case):
     _free(sia, ref, cur)
 
 
+def test_find_epipolar_match_direct_against_reference_fixture(ctx, golden):
+    """svo_hip_epipolar_match_batch_dev against Matcher::findEpipolarMatchDirect executed by the reference's own code on
+    real frames (epi_ref.npz: 600 seeds, four kinds of depth interval, 21 failures): the return value, the search level
+    and the refined pixel of EVERY seed equal the reference's; epipolar length and depth to 1e-12."""
+    from oracle import gen_golden
+    g = golden("epi_ref.npz")
+    sc, d_est, d_min, d_max = gen_golden.epi_case_inputs()
+    kf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
+    cf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
+    kf.upload(0, sc.ref_pyr)
+    cf.upload(0, sc.cur_pyr)
+    r = hip.epipolar_match_batch(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sc.px, sc.f, sc.level, d_est, d_min, d_max)
+    g_ok = g["ok"].astype(bool)
+    np.testing.assert_array_equal(r["ok"], g_ok)
+    np.testing.assert_array_equal(r["search_level"], g["search_level"])
+    np.testing.assert_allclose(r["epi_length"], g["epi_length"], rtol=1e-12)
+    _assert_px_bits_equal(r["px_cur"][g_ok], g["px_cur"][g_ok])
+    np.testing.assert_allclose(r["depth"][g_ok], g["depth"][g_ok], rtol=1e-12)
+    assert (r["depth"][~g_ok] == 0).all()
+    assert 0 < (~g_ok).sum() < 100 and ((r["n_zmssd"] == 0) & g_ok).sum() > 100 and (r["n_zmssd"] > 0).sum() > 300
+    _free(kf, cf)
+
+
 def test_match_direct_against_reference_fixture(ctx, golden):
     """svo_hip_match_direct_batch_dev against Matcher::findMatchDirect executed by the reference's own code."""
     from oracle import gen_golden
@@ -743,15 +764,9 @@ def test_match_direct_against_reference_fixture(ctx, golden):
     np.testing.assert_array_equal(sl[chosen], g["search_level"][chosen])        # integer decision: exact
     np.testing.assert_array_equal(px_out[~chosen], px_in[~chosen])              # untouched when the frame test fails
     assert not ok[~chosen].any()
-    corner = chosen & (edge == 0)
-    assert (ok[corner] != g_ok[corner]).mean() < 0.02
-    both = corner & ok & g_ok
-    assert both.sum() > 100
-    assert np.abs(px_out[both] - g["px_out"][both]).max() < 5e-3    # f32 LK, wave butterfly sums instead of a serial sum
-    e1 = chosen & (edge == 1)
-    both1 = e1 & ok & g_ok
-    assert both1.sum() > 20
-    assert np.percentile(np.abs(px_out[both1] - g["px_out"][both1]).max(axis=1), 95) < 2e-2
+    np.testing.assert_array_equal(ok, g_ok)                                     # every item: the reference's verdict
+    _assert_px_bits_equal(px_out, g["px_out"])                                  # and its pixel, bit for bit
+    assert (chosen & (edge == 0) & ok).sum() > 100 and (chosen & (edge == 1) & ok).sum() > 20
     ref.destroy(); cur.destroy()
 
 
@@ -972,6 +987,16 @@ def test_error_conventions(ctx):
                                        px.ctypes.data_as(C.c_void_p), None, px.ctypes.data_as(C.c_void_p), None) == -1   # 9 levels
     # the objects are still good
     sia.run(1, prm)
+    if sia.last_run_mode() == 1:     # the fused kernel keeps no per-pixel caches: asking for them is a state error, not stale data
+        buf = np.zeros((50, 16), dtype=np.float32)
+        assert lib.svo_hip_sia_download_caches(sia.h, 0, buf.ctypes.data_as(C.c_void_p), None, None, None) == -4
+    # a keyframe slot / level outside the pyramids handed to findMatchDirect is refused per item, never indexed
+    n = 8
+    ok, px_out, _ = hip.match_direct_batch(ctx, ref, cur, 0, fp.cam, fp.T_ref_w[None, :], fp.T_cur_w_true,
+                                           np.array([0, 1, -1, 0, 7, 0, 0, 0], dtype=np.int32), fp.px[:n], fp.f[:n],
+                                           np.array([0, 0, 0, 9, 0, -1, 0, 0], dtype=np.int32), fp.pos[:n], fp.px[:n].copy())
+    assert not ok[[1, 2, 3, 4, 5]].any()
+    np.testing.assert_array_equal(px_out[[1, 2, 3, 4, 5]], fp.px[[1, 2, 3, 4, 5]])
     r = sia.download(0)
     o = orc.sparse_img_align(fp, n_iter=30, early_stop=True)
     rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
@@ -1029,9 +1054,9 @@ def test_frame_pipeline_stages_together(ctx):
     for i in range(n):
         ok_o[i], px_o[i], _ = orc.find_match_direct(cam, fp.ref_pyr, fp.cur_pyr, fp.T_ref_w, T_sia, fp.px[i], fp.f[i], 0,
                                                     fp.pos[i], px_pred[i])
-    assert (ok != ok_o).mean() < 0.01 and ok.mean() > 0.9
-    both = ok & ok_o
-    assert np.abs(px_m[both] - px_o[both]).max() < 5e-3
+    np.testing.assert_array_equal(ok, ok_o)
+    assert ok.mean() > 0.9
+    _assert_px_bits_equal(px_m, px_o)
 
     # motion-only refinement on the matched observations
     f_obs = synth.cam2world(cam, px_m)
@@ -1039,7 +1064,8 @@ def test_frame_pipeline_stages_together(ctx):
     r, hp_out = hip.pose_optimize(ctx, T_sia, f_obs, fp.pos, sl.astype(np.int32), hp, abs(cam.fx))
     ro, hp_o = orc.pose_optimize(abs(cam.fx), T_sia, f_obs, fp.pos, sl.astype(np.int32), hp)
     rot, trans = synth.pose_error(np.array(r.T_f_w), np.array(ro.T_f_w))
-    assert rot < 1e-10 and trans < 1e-10 and (hp_out != hp_o).sum() <= 1
+    assert rot < 1e-10 and trans < 1e-10
+    np.testing.assert_array_equal(hp_out, hp_o)
     e_sia = synth.pose_error(T_sia, fp.T_cur_w_true)
     e_ref = synth.pose_error(np.array(r.T_f_w), fp.T_cur_w_true)
     assert e_ref[0] < 2e-4 and e_ref[1] < 1e-3, (e_sia, e_ref)       # the refined pose stays at the sub-pixel level
@@ -1060,7 +1086,7 @@ def test_frame_pipeline_stages_together(ctx):
 @pytest.mark.parametrize("tag,max_fts", [("full", 1200), ("cap", 40)])
 def test_reproject_cells_against_reference_fixture(ctx, golden, tag, max_fts):
     """svo_hip_reproject_cells (one batched match + the serial cell policy) against the reference's own
-    Reprojector::reprojectCell loop: same winners, counters and point bookkeeping; matched pixels to 5e-3."""
+    Reprojector::reprojectCell loop: same winners, counters and point bookkeeping; matched pixels bit-identical."""
     from test_oracle_reproject import check_against_fixture
     g = golden("reproject_ref.npz")
     cs = synth.make_reproject_case()
@@ -1076,11 +1102,10 @@ def test_reproject_cells_against_reference_fixture(ctx, golden, tag, max_fts):
     o = orc.reproject_cells(cam, cs["kf_pyr"], cs["T_kf_w"], cs["cur_pyr"], cs["T_cur_w"], off, cs["slot"][ids], cs["px_ref"][ids],
                             cs["f_ref"][ids], cs["level"][ids], cs["pos"][ids], np.zeros(len(ids), np.uint8),
                             np.tile([1.0, 0.0], (len(ids), 1)), deleted, cs["px_cur"][ids], max_fts=max_fts)
-    # a candidate whose f32 alignment sits on the convergence threshold may flip; the fixture case has none
     np.testing.assert_array_equal(res["tried"], o["tried"])
     np.testing.assert_array_equal(res["matched"], o["matched"])
     win = check_against_fixture(g, tag, cs, ids, res)
-    assert np.abs(res["px_cur"][win] - g[tag + "_feat_px"]).max() < 5e-3
+    _assert_px_bits_equal(res["px_cur"][win], g[tag + "_feat_px"])
     ref.destroy(); cur.destroy()
 
 
@@ -1105,9 +1130,8 @@ def test_depth_filter_and_detector_with_a_distorted_camera(ctx):
     a, b, mu, s2 = (v.copy() for v in (sc.a, sc.b, sc.mu, sc.sigma2))
     o = orc.update_seeds(cam, sc.ref_pyr, sc.cur_pyr, sc.T_ref_w, sc.T_cur_w, sc.px, f, sc.level, a, b, mu, sc.z_range.copy(), s2)
     status = sb.status.download()
-    assert (status != o["status"]).mean() < 0.01
-    same = status == o["status"]
-    upd = same & (status == 3)
+    np.testing.assert_array_equal(status, o["status"])
+    upd = status == 3
     assert upd.sum() > 1000
     assert np.abs(sb.mu.download()[upd] - mu[upd]).max() < 1e-4 * np.abs(mu[upd]).max()
     z_h = sb.z.download()
