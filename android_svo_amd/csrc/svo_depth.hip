@@ -30,62 +30,67 @@ namespace {
 
 constexpr int ZMSSD_THRESHOLD = 2000 * 64;     // I/patch_score.h:46
 
-// ---- align2D / align1D over n patches: one lane per patch, one wave per workgroup ---------------------
+// ---- align2D / align1D over n patches: one DPP quad per patch, 16 patches per single-wave workgroup ------------
 // The [n][100] (and optional [n][64]) patch arrays are read with coalesced word loads into LDS and handed to the
-// lanes from there (a lane's 25 words sit 100 bytes apart: word stride 25 is odd, so the LDS reads are conflict-free).
-constexpr int ALIGN_LANES = 64;
+// lanes from there: lane q of a patch takes the ten words of border rows 2q .. 2q+3 (svo_align_device.h).
+// One wave per workgroup: a wave leaves as soon as its own 16 patches are done and its slot is refilled at once
+// (with 4-wave workgroups the next workgroup waited for the slowest of 64 patches: measured average residency 2.0 of
+// 4 waves per SIMD at 200 000 patches).
+constexpr int ALIGN_BLOCK = 64;
+constexpr int ALIGN_PATCHES = ALIGN_BLOCK / ALIGN_LANES_PER_PATCH;     // patches per workgroup
+constexpr int ALIGN_STAGE_ROUNDS = (ALIGN_PATCHES * 25 + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
+constexpr int ALIGN_STAGE_WORDS = ALIGN_STAGE_ROUNDS * ALIGN_BLOCK;   // >= ALIGN_PATCHES * 25: no bounds test while staging
 
 SVO_DEV void stage_patch_words(const uint8_t* __restrict__ pwb, const uint8_t* __restrict__ ref_patch, int first, int n,
-                               uint32_t* s_words, PatchWords& pw) {
-  const int lane = threadIdx.x;
-  const int n_here = min(ALIGN_LANES, n - first);
+                               uint32_t* s_words, QuadPatch& qp) {
+  const int tid = threadIdx.x;
+  const int pl = tid >> 2, q = tid & 3;
+  const int n_here = min(ALIGN_PATCHES, n - first);
   const uint32_t* src = reinterpret_cast<const uint32_t*>(pwb + (size_t)first * 100);
-  // unconditional loads at a clamped index: all 25 are in flight together (words beyond the last patch are never used)
+  // unconditional loads at a clamped index: all of a thread's loads are in flight together (words beyond the last
+  // patch are never used)
   const int last = n_here * 25 - 1;
+  uint32_t stage[ALIGN_STAGE_ROUNDS];
 #pragma unroll
-  for (int k = 0; k < 25; ++k) {
-    const int w = k * ALIGN_LANES + lane;
-    s_words[w] = src[min(w, last)];
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int k = 0; k < ALIGN_STAGE_ROUNDS; ++k) stage[k] = src[min(k * ALIGN_BLOCK + tid, last)];      // all in flight together
 #pragma unroll
-  for (int k = 0; k < 25; ++k) pw.b[k] = s_words[lane * 25 + k];
+  for (int k = 0; k < ALIGN_STAGE_ROUNDS; ++k) s_words[k * ALIGN_BLOCK + tid] = stage[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 10; ++k) qp.b[k] = s_words[pl * 25 + 5 * q + k];
   if (ref_patch) {
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __syncthreads();
     const uint32_t* src2 = reinterpret_cast<const uint32_t*>(ref_patch + (size_t)first * 64);
     const int last2 = n_here * 16 - 1;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int w = k * ALIGN_LANES + lane;
+    for (int k = 0; k < ALIGN_PATCHES * 16 / ALIGN_BLOCK; ++k) {
+      const int w = k * ALIGN_BLOCK + tid;
       s_words[w + (w >> 4)] = src2[min(w, last2)];                 // row stride 17 words: conflict-free reads
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) pw.p[k] = s_words[lane * 17 + k];
+    for (int k = 0; k < 4; ++k) qp.p[k] = s_words[pl * 17 + 4 * q + k];
   } else {
-    patch_from_border(pw);
+    patch_from_border(qp);
   }
 }
 
-__global__ __launch_bounds__(ALIGN_LANES, 2) void align2d_kernel(const uint8_t* __restrict__ img, int cols, int rows, int n,
+__global__ __launch_bounds__(ALIGN_BLOCK) void align2d_kernel(const uint8_t* __restrict__ img, int cols, int rows, int n,
                                                               const uint8_t* __restrict__ pwb,
                                                               const uint8_t* __restrict__ ref_patch, int n_iter,
                                                               double* __restrict__ px, uint8_t* __restrict__ converged,
                                                               int32_t* __restrict__ iters) {
-  __shared__ uint32_t s_words[ALIGN_LANES * 25];
-  const int first = blockIdx.x * ALIGN_LANES;
-  const int w = first + threadIdx.x;
+  __shared__ uint32_t s_words[ALIGN_STAGE_WORDS];
+  const int first = blockIdx.x * ALIGN_PATCHES;
+  const int w = first + (threadIdx.x >> 2);
   const bool have = w < n;
-  PatchWords pw;
-  stage_patch_words(pwb, ref_patch, first, n, s_words, pw);
+  QuadPatch qp;
+  stage_patch_words(pwb, ref_patch, first, n, s_words, qp);
   double u = 0.0, v = 0.0;
   if (have) { u = px[2 * (size_t)w]; v = px[2 * (size_t)w + 1]; }
   int it = 0;
-  const bool ok = align2d_lane(img, cols, rows, cols, pw, n_iter, have, &u, &v, &it);
-  if (have) {
+  const bool ok = align2d_quad(img, cols, rows, cols, qp, n_iter, have, &u, &v, &it);
+  if (have && (threadIdx.x & 3) == 0) {
     px[2 * (size_t)w] = u;
     px[2 * (size_t)w + 1] = v;
     converged[w] = ok ? 1 : 0;
@@ -94,24 +99,24 @@ __global__ __launch_bounds__(ALIGN_LANES, 2) void align2d_kernel(const uint8_t* 
 }
 
 // align1D over n patches (edgelets / Matcher::Options::align_1d; secondary)
-__global__ __launch_bounds__(ALIGN_LANES, 2) void align1d_kernel(const uint8_t* __restrict__ img, int cols, int rows, int n,
+__global__ __launch_bounds__(ALIGN_BLOCK) void align1d_kernel(const uint8_t* __restrict__ img, int cols, int rows, int n,
                                                               const uint8_t* __restrict__ pwb,
                                                               const uint8_t* __restrict__ ref_patch,
                                                               const float* __restrict__ dir, int n_iter,
                                                               double* __restrict__ px, uint8_t* __restrict__ converged,
                                                               double* __restrict__ h_inv, int32_t* __restrict__ iters) {
-  __shared__ uint32_t s_words[ALIGN_LANES * 25];
-  const int first = blockIdx.x * ALIGN_LANES;
-  const int w = first + threadIdx.x;
+  __shared__ uint32_t s_words[ALIGN_STAGE_WORDS];
+  const int first = blockIdx.x * ALIGN_PATCHES;
+  const int w = first + (threadIdx.x >> 2);
   const bool have = w < n;
-  PatchWords pw;
-  stage_patch_words(pwb, ref_patch, first, n, s_words, pw);
+  QuadPatch qp;
+  stage_patch_words(pwb, ref_patch, first, n, s_words, qp);
   double u = 0.0, v = 0.0, hi = 0.0;
   float d0 = 0.0f, d1 = 0.0f;
   if (have) { u = px[2 * (size_t)w]; v = px[2 * (size_t)w + 1]; d0 = dir[2 * (size_t)w]; d1 = dir[2 * (size_t)w + 1]; }
   int it = 0;
-  const bool ok = align1d_lane(img, cols, rows, cols, d0, d1, pw, n_iter, have, &u, &v, &hi, &it);
-  if (have) {
+  const bool ok = align1d_quad(img, cols, rows, cols, d0, d1, qp, n_iter, have, &u, &v, &hi, &it);
+  if (have && (threadIdx.x & 3) == 0) {
     px[2 * (size_t)w] = u;
     px[2 * (size_t)w + 1] = v;
     converged[w] = ok ? 1 : 0;
@@ -184,6 +189,27 @@ __global__ void compute_tau_kernel(int n, Vec3 t, const double* __restrict__ f, 
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const double fi[3] = {f[3 * (size_t)i], f[3 * (size_t)i + 1], f[3 * (size_t)i + 2]};
     tau[i] = compute_tau(t.v, fi, z[i], px_error_angle);
+  }
+}
+
+// ---- the camera model exactly as every kernel evaluates it, over a batch (parity tests against the reference's
+// ---- compiled vk::PinholeCamera, tests/golden/camera_ref.npz) -------------------------------------------------
+__global__ void camera_batch_kernel(Cam cam, int n, const double* __restrict__ xyz, const double* __restrict__ uv,
+                                    const double* __restrict__ px, const int32_t* __restrict__ obs, int boundary, int level,
+                                    double* __restrict__ px_of_xyz, double* __restrict__ px_of_uv,
+                                    double* __restrict__ f_of_px, uint8_t* __restrict__ in_frame) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (xyz && px_of_xyz) {
+    const double p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+    world2cam(cam, p, px_of_xyz + 2 * (size_t)i);
+  }
+  if (uv && px_of_uv) world2cam_uv(cam, uv[2 * (size_t)i], uv[2 * (size_t)i + 1], px_of_uv + 2 * (size_t)i);
+  if (px && f_of_px) cam2world(cam, px[2 * (size_t)i], px[2 * (size_t)i + 1], f_of_px + 3 * (size_t)i);
+  if (obs && in_frame) {
+    const int ox = obs[2 * (size_t)i], oy = obs[2 * (size_t)i + 1];
+    in_frame[i] = level < 0 ? (ox >= boundary && ox < cam.width - boundary && oy >= boundary && oy < cam.height - boundary)
+                            : is_in_frame_level(cam, ox, oy, boundary, level);
   }
 }
 
@@ -636,15 +662,15 @@ __global__ __launch_bounds__(256) void df_search_kernel(
   }
 }
 
-// Sub-pixel refinement of every seed the search stage flagged: one lane per seed, the reference's serial pixel order
+// Sub-pixel refinement of every seed the search stage flagged: one quad per seed, the reference's serial pixel order
 // (svo_align_device.h), so `converged`, the refined pixel and the iteration count equal the CPU path's bit for bit.
 // ONE_D = false refines the corner features with align2D; ONE_D = true the EDGELET reference features of
-// findMatchDirect with align1D (matcher.cpp:183-191; the depth filter never produces them) -- two instantiations so
-// that each keeps its gradient tables within 256 registers (two waves per SIMD).
+// findMatchDirect with align1D (matcher.cpp:183-191; the depth filter never produces them).
 template <bool ONE_D>
-__global__ __launch_bounds__(ALIGN_LANES, 2) void df_align_kernel(DfFrame fr, const uint8_t* __restrict__ cur_pyr, int n, int n_pad,
+__global__ __launch_bounds__(ALIGN_BLOCK) void df_align_kernel(DfFrame fr, const uint8_t* __restrict__ cur_pyr, int n, int n_pad,
                                                                const uint32_t* __restrict__ pwb_t, SeedRec* __restrict__ recs) {
-  const int i = blockIdx.x * ALIGN_LANES + threadIdx.x;
+  const int i = blockIdx.x * ALIGN_PATCHES + (threadIdx.x >> 2);
+  const int q = threadIdx.x & 3;
   const bool have = i < n;
   SeedRec* rp = recs + (have ? i : 0);
   const int path = have ? rp->path : -1;
@@ -654,10 +680,10 @@ __global__ __launch_bounds__(ALIGN_LANES, 2) void df_align_kernel(DfFrame fr, co
   const int search_level = do_align ? rp->search_level : 0;
   const int ccols = fr.cam.width >> search_level, crows = fr.cam.height >> search_level;
   const uint8_t* cur_img = cur_pyr + fr.cur_level_off[search_level];
-  PatchWords pw;
+  QuadPatch qp;
 #pragma unroll
-  for (int k = 0; k < 25; ++k) pw.b[k] = do_align ? pwb_t[(size_t)k * n_pad + i] : 0u;
-  patch_from_border(pw);
+  for (int k = 0; k < 10; ++k) qp.b[k] = do_align ? pwb_t[(size_t)(5 * q + k) * n_pad + i] : 0u;
+  patch_from_border(qp);
   double px_cur[2] = {0.0, 0.0};
   float dir0 = 0.0f, dir1 = 0.0f;
   if (do_align) {
@@ -670,11 +696,11 @@ __global__ __launch_bounds__(ALIGN_LANES, 2) void df_align_kernel(DfFrame fr, co
   bool res;
   if (ONE_D) {
     double h_inv;
-    res = align1d_lane(cur_img, ccols, crows, ccols, dir0, dir1, pw, fr.align_max_iter, do_align, &us, &vs, &h_inv, &n_align);
+    res = align1d_quad(cur_img, ccols, crows, ccols, dir0, dir1, qp, fr.align_max_iter, do_align, &us, &vs, &h_inv, &n_align);
   } else {
-    res = align2d_lane(cur_img, ccols, crows, ccols, pw, fr.align_max_iter, do_align, &us, &vs, &n_align);
+    res = align2d_quad(cur_img, ccols, crows, ccols, qp, fr.align_max_iter, do_align, &us, &vs, &n_align);
   }
-  if (do_align) {
+  if (do_align && q == 0) {
     if (res || fr.keep_px_on_failure) {
       px_cur[0] = us * (1 << search_level);
       px_cur[1] = vs * (1 << search_level);
@@ -942,7 +968,7 @@ int svo_hip_align2d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int 
   // matcher.cpp:138-147), which is how every caller of the reference fills it
   SVO_REQUIRE(ctx, ((uintptr_t)pwb_dev & 3) == 0 && ((uintptr_t)ref_patch_dev & 3) == 0);
   const uint8_t* img = cur->base + (size_t)slot * cur->pyr_bytes + cur->level_offset[level];
-  hipLaunchKernelGGL(align2d_kernel, dim3((n + ALIGN_LANES - 1) / ALIGN_LANES), dim3(ALIGN_LANES), 0, ctx->stream, img,
+  hipLaunchKernelGGL(align2d_kernel, dim3((n + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, img,
                      cur->width >> level, cur->height >> level, n, pwb_dev, ref_patch_dev, n_iter, px_dev, converged_dev,
                      iters_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
@@ -959,7 +985,7 @@ int svo_hip_align1d_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int 
   SVO_REQUIRE(ctx, pwb_dev && dir_dev && px_dev && converged_dev);
   const uint8_t* img = cur->base + (size_t)slot * cur->pyr_bytes + cur->level_offset[level];
   SVO_REQUIRE(ctx, ((uintptr_t)pwb_dev & 3) == 0);
-  hipLaunchKernelGGL(align1d_kernel, dim3((n + ALIGN_LANES - 1) / ALIGN_LANES), dim3(ALIGN_LANES), 0, ctx->stream, img,
+  hipLaunchKernelGGL(align1d_kernel, dim3((n + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, img,
                      cur->width >> level, cur->height >> level, n, pwb_dev, (const uint8_t*)nullptr, dir_dev, n_iter, px_dev,
                      converged_dev, h_inv_dev, iters_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
@@ -988,6 +1014,38 @@ int svo_hip_align2d_batch(svo_hip_ctx* ctx, const svo_hip_pyramid* cur, int slot
   if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, px, d + o_px, 16 * N);
   if (rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, converged, d + o_cv, N);
   if (rc == SVO_HIP_OK && iters) rc = svo_hip_memcpy_d2h(ctx, iters, d + o_it, 4 * N);
+  return rc;
+}
+
+int svo_hip_camera_batch(svo_hip_ctx* ctx, const svo_hip_camera* cam, int n, const double* xyz, const double* uv,
+                         const double* px, const int32_t* obs, int boundary, int level, double* px_of_xyz,
+                         double* px_of_uv, double* f_of_px, uint8_t* in_frame) {
+  if (!ctx || !cam) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n >= 0 && boundary >= 0 && level < SVO_HIP_MAX_LEVELS);
+  if (n == 0) return SVO_HIP_OK;
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t N = (size_t)n;
+  // one staging block: xyz(24) uv(16) px(16) px_of_xyz(16) px_of_uv(16) f_of_px(24) obs(8) in_frame(1)
+  const size_t o_xyz = 0, o_uv = o_xyz + 24 * N, o_px = o_uv + 16 * N, o_a = o_px + 16 * N, o_b = o_a + 16 * N,
+               o_f = o_b + 16 * N, o_obs = o_f + 24 * N, o_in = o_obs + 8 * N, total = o_in + N;
+  char* d = nullptr;
+  int rc = svo_ctx_staging(ctx, total, &d);
+  if (rc != SVO_HIP_OK) return rc;
+  if (xyz && rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d + o_xyz, xyz, 24 * N);
+  if (uv && rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d + o_uv, uv, 16 * N);
+  if (px && rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d + o_px, px, 16 * N);
+  if (obs && rc == SVO_HIP_OK) rc = svo_hip_memcpy_h2d(ctx, d + o_obs, obs, 8 * N);
+  if (rc != SVO_HIP_OK) return rc;
+  hipLaunchKernelGGL(camera_batch_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, svo_make_cam(*cam), n,
+                     xyz ? (const double*)(d + o_xyz) : nullptr, uv ? (const double*)(d + o_uv) : nullptr,
+                     px ? (const double*)(d + o_px) : nullptr, obs ? (const int32_t*)(d + o_obs) : nullptr, boundary, level,
+                     px_of_xyz ? (double*)(d + o_a) : nullptr, px_of_uv ? (double*)(d + o_b) : nullptr,
+                     f_of_px ? (double*)(d + o_f) : nullptr, in_frame ? (uint8_t*)(d + o_in) : nullptr);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  if (xyz && px_of_xyz && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, px_of_xyz, d + o_a, 16 * N);
+  if (uv && px_of_uv && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, px_of_uv, d + o_b, 16 * N);
+  if (px && f_of_px && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, f_of_px, d + o_f, 24 * N);
+  if (obs && in_frame && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, in_frame, d + o_in, N);
   return rc;
 }
 
@@ -1067,7 +1125,7 @@ static void df_make_frame(const svo_hip_pyramid* ref, const svo_hip_pyramid* cur
 
 // per-seed records between the stages + the word-transposed warped patches: grow-only scratch owned by the context
 static int df_scratch(svo_hip_ctx* ctx, int n, SeedRec** recs, uint32_t** pwb_t, int* n_pad) {
-  *n_pad = (n + ALIGN_LANES - 1) / ALIGN_LANES * ALIGN_LANES;
+  *n_pad = (n + 63) / 64 * 64;
   const size_t rec_bytes = ((size_t)n * sizeof(SeedRec) + 255) & ~(size_t)255;
   const size_t need = rec_bytes + (size_t)25 * *n_pad * sizeof(uint32_t);
   void* ws = nullptr;
@@ -1111,7 +1169,7 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref_img, (size_t)0, cur_img, n, level, recs, pwb_t, n_pad);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(df_align_kernel<false>, dim3(n_pad / ALIGN_LANES), dim3(ALIGN_LANES), 0, ctx->stream, fr, cur_img, n, n_pad, pwb_t, recs);
+  hipLaunchKernelGGL(df_align_kernel<false>, dim3((n + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr, cur_img, n, n_pad, pwb_t, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(df_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, f, recs, a, b, mu, z_range,
                      sigma2, status, z, xyz_world, n_zmssd, n_align_iters, px_cur, search_level);
@@ -1152,7 +1210,7 @@ int svo_hip_epipolar_match_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* re
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref_img, (size_t)0, cur_img, n, level, recs, pwb_t, n_pad);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(df_align_kernel<false>, dim3(n_pad / ALIGN_LANES), dim3(ALIGN_LANES), 0, ctx->stream, fr, cur_img, n, n_pad, pwb_t, recs);
+  hipLaunchKernelGGL(df_align_kernel<false>, dim3((n + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr, cur_img, n, n_pad, pwb_t, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(epi_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, f, recs, ok, depth, px_cur,
                      search_level, n_zmssd, n_align_iters);
@@ -1199,11 +1257,11 @@ int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref,
   hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref->base, ref->pyr_bytes,
                      cur->base + (size_t)cur_slot * cur->pyr_bytes, n, level_ref_dev, recs, pwb_t, n_pad);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(df_align_kernel<false>, dim3(n_pad / ALIGN_LANES), dim3(ALIGN_LANES), 0, ctx->stream, fr,
+  hipLaunchKernelGGL(df_align_kernel<false>, dim3((n + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr,
                      cur->base + (size_t)cur_slot * cur->pyr_bytes, n, n_pad, pwb_t, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   if (edgelet_dev) {
-    hipLaunchKernelGGL(df_align_kernel<true>, dim3(n_pad / ALIGN_LANES), dim3(ALIGN_LANES), 0, ctx->stream, fr,
+    hipLaunchKernelGGL(df_align_kernel<true>, dim3((n + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr,
                        cur->base + (size_t)cur_slot * cur->pyr_bytes, n, n_pad, pwb_t, recs);
     SVO_CHECK_HIP(ctx, hipGetLastError());
   }

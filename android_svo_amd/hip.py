@@ -357,6 +357,28 @@ def update_seed_batch(ctx: Context, x, tau2, a, b, mu, z_range, sigma2):
     return out
 
 
+def camera_batch(ctx: Context, cam, xyz=None, uv=None, px=None, obs=None, boundary=0, level=-1):
+    """The device camera model over a batch: returns (px_of_xyz, px_of_uv, f_of_px, in_frame), None where not asked."""
+    c = make_camera(cam)
+    arrs = [a for a in (xyz, uv, px, obs) if a is not None]
+    n = len(arrs[0])
+    xyz = _f64(xyz).reshape(n, 3) if xyz is not None else None
+    uv = _f64(uv).reshape(n, 2) if uv is not None else None
+    px = _f64(px).reshape(n, 2) if px is not None else None
+    obs = np.ascontiguousarray(obs, dtype=np.int32).reshape(n, 2) if obs is not None else None
+    o_xyz = np.zeros((n, 2)) if xyz is not None else None
+    o_uv = np.zeros((n, 2)) if uv is not None else None
+    o_f = np.zeros((n, 3)) if px is not None else None
+    o_in = np.zeros(n, dtype=np.uint8) if obs is not None else None
+
+    def ptr(a, t):
+        return _ptr(a, t) if a is not None else None
+    ctx.check(ctx.lib.svo_hip_camera_batch(ctx.h, C.byref(c), n, ptr(xyz, C.c_double), ptr(uv, C.c_double), ptr(px, C.c_double),
+                                           ptr(obs, C.c_int32), int(boundary), int(level), ptr(o_xyz, C.c_double),
+                                           ptr(o_uv, C.c_double), ptr(o_f, C.c_double), ptr(o_in, C.c_uint8)), "camera_batch")
+    return o_xyz, o_uv, o_f, o_in
+
+
 def compute_tau_batch(ctx: Context, T_ref_cur, f, z, px_error_angle):
     n = len(z)
     df, dz, dt = ctx.to_device(_f64(f)), ctx.to_device(_f64(z)), ctx.empty((n,), np.float64)

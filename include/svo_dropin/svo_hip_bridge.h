@@ -102,19 +102,40 @@ class PyramidCache {
     slot_frame_[s] = frame.id_;
     return s;
   }
-  /// make slot `want` hold `frame`'s pyramid (uploading it unless it is already there); returns `want` or -1
-  int slotOfAt(const Frame& frame, int want) {
-    if (want < 0 || want >= capacity_) return -1;
-    if (pyr_ && slot_frame_[want] == frame.id_) return want;
-    if (pyr_)
+  /// Slots holding the pyramids of ALL `frames` at once (the reprojector matches against every keyframe that observes
+  /// a candidate point: the map is unbounded, so is their number).  Frames already resident keep their slot; the
+  /// others go to slots no frame of this call uses; the cache grows (in steps of 16 slots) when the set does not
+  /// fit.  Returns false on a device error.
+  bool acquire(const std::vector<const Frame*>& frames, std::vector<int>& slots) {
+    slots.assign(frames.size(), -1);
+    if (frames.empty()) return true;
+    if ((int)frames.size() > capacity_ || !pyr_) {
+      if ((int)frames.size() > capacity_) {
+        if (pyr_) { svo_hip_pyramid_destroy(pyr_); pyr_ = NULL; }
+        capacity_ = ((int)frames.size() + 15) / 16 * 16;
+        next_ = 0;
+      }
+      if (!pyr_) {
+        const cv::Mat& l0 = frames[0]->img_pyr_[0];
+        if (svo_hip_pyramid_create(ctx_, l0.cols, l0.rows, (int)frames[0]->img_pyr_.size(), capacity_, &pyr_) != SVO_HIP_OK) return false;
+        slot_frame_.assign(capacity_, -1);
+      }
+    }
+    std::vector<char> used(capacity_, 0);
+    for (size_t k = 0; k < frames.size(); ++k)
       for (int s = 0; s < capacity_; ++s)
-        if (slot_frame_[s] == frame.id_) slot_frame_[s] = -1;      // it will live in `want` from now on
-    const int saved = next_;
-    next_ = want;
-    const int got = slotOf(frame);
-    next_ = saved;
-    return got == want ? want : -1;
+        if (slot_frame_[s] == frames[k]->id_) { slots[k] = s; used[s] = 1; break; }
+    for (size_t k = 0; k < frames.size(); ++k) {
+      if (slots[k] >= 0) continue;
+      while (used[next_]) next_ = (next_ + 1) % capacity_;       // terminates: frames.size() <= capacity_
+      slot_frame_[next_] = -1;
+      const int got = slotOf(*frames[k]);                          // uploads into next_
+      if (got < 0) return false;
+      slots[k] = got; used[got] = 1;
+    }
+    return true;
   }
+  int capacity() const { return capacity_; }
   svo_hip_pyramid* pyramid() const { return pyr_; }
 
  private:

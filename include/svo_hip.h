@@ -77,6 +77,14 @@ int svo_hip_memcpy_d2h(svo_hip_ctx* ctx, void* dst_host, const void* src_dev, si
 int svo_hip_copy_d2d(svo_hip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);        /* async */
 int svo_hip_memset(svo_hip_ctx* ctx, void* dst_dev, int value, size_t bytes);
 
+/* The camera model exactly as every kernel evaluates it, over n host items (vk::PinholeCamera::world2cam for
+ * camera-frame points xyz[n][3] and for unit-plane points uv[n][2], pinhole_camera.cpp:73-106; ::cam2world for
+ * pixels px[n][2], :44-71; vk::AbstractCamera::isInFrame(obs[n][2], boundary) when level < 0, else
+ * isInFrame(obs, boundary, level), I/abstract_camera.h:58-72).  Each input/output pair may be NULL.  Synchronises. */
+int svo_hip_camera_batch(svo_hip_ctx* ctx, const svo_hip_camera* cam, int n, const double* xyz, const double* uv,
+                         const double* px, const int32_t* obs, int boundary, int level, double* px_of_xyz,
+                         double* px_of_uv, double* f_of_px, uint8_t* in_frame);
+
 /* ---- image pyramids resident in HBM (Frame::img_pyr_, frame.cpp:63,186-195) ------------ */
 /* A batch of `batch` pyramids of identical geometry, one contiguous allocation:
  * slot s, level l starts at s*pyr_bytes + level_offset[l]. */

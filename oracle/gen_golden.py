@@ -397,7 +397,59 @@ def gen_reproject_ref():
     np.savez_compressed(os.path.join(OUT, "reproject_ref.npz"), **out)
 
 
+CAMERA_REF_CASES = (
+    # name, width, height, fx, fy, cx, cy, (k1, k2, p1, p2, k3)
+    ("pinhole_vga", 640, 480, 500.0, 500.0, 319.5, 239.5, (0.0, 0.0, 0.0, 0.0, 0.0)),
+    ("radtan_strong", 640, 480, 458.654, 457.296, 367.215, 248.375, (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)),
+    ("radtan_k3", 752, 480, 420.0, 418.5, 371.3, 236.9, (-0.12, 0.03, 2e-4, -1e-4, 0.004)),
+    ("radtan_hd", 1280, 720, 1000.0, 1002.0, 639.5, 359.5, (0.05, -0.02, -3e-4, 5e-4, 0.001)),
+    ("tiny_k1", 640, 480, 500.0, 500.0, 319.5, 239.5, (5e-8, 0.3, 0.1, 0.1, 0.1)),       # |d0| <= 1e-7: distortion_ stays false
+)
+
+
+def camera_ref_inputs(case):
+    """Deterministic inputs of one camera case: camera-frame points (some behind the camera, some far off axis), unit-plane
+    points, pixels, integer observations around the image border."""
+    name, w, h, fx, fy, cx, cy, dist = case
+    rng = np.random.default_rng(sum(ord(ch) for ch in name))     # a fixed seed per case name
+    cam = synth.Camera(w, h, fx, fy, cx, cy)
+    cam.dist = dist
+    n = 400
+    xyz = np.stack([rng.uniform(-2.5, 2.5, n), rng.uniform(-2.0, 2.0, n), rng.uniform(0.3, 6.0, n)], axis=1)
+    xyz[::37, 2] *= -1.0                       # behind the camera: still plain arithmetic
+    uv = np.stack([rng.uniform(-1.2, 1.2, n), rng.uniform(-0.9, 0.9, n)], axis=1)
+    px = np.stack([rng.uniform(-20, w + 20, n), rng.uniform(-20, h + 20, n)], axis=1)
+    obs = np.stack([rng.integers(-12, w + 12, n), rng.integers(-12, h + 12, n)], axis=1).astype(np.int32)
+    obs[:40, 0] = rng.choice([0, 1, 7, 8, 9, w - 10, w - 9, w - 8, w - 1, w], 40)
+    obs[40:80, 1] = rng.choice([0, 1, 7, 8, 9, h - 10, h - 9, h - 8, h - 1, h], 40)
+    return cam, xyz, uv, px, obs
+
+
+def gen_camera_ref():
+    """vk::PinholeCamera::world2cam (both overloads, pinhole and radtan), the distortion-free cam2world and
+    vk::AbstractCamera::isInFrame, executed by the reference's own compiled members (ref_camera.cpp)."""
+    out = {}
+    for case in CAMERA_REF_CASES:
+        name = case[0]
+        cam, xyz, uv, px, obs = camera_ref_inputs(case)
+        out[name + "_crc"] = np.array([crc(xyz), crc(uv), crc(px), crc(obs)], dtype=np.uint64)
+        out[name + "_px_of_xyz"] = refpy.pinhole_world2cam(cam, xyz)
+        out[name + "_px_of_uv"] = refpy.pinhole_world2cam_uv(cam, uv)
+        if abs(cam.dist[0]) <= 1e-7:
+            out[name + "_f_of_px"] = refpy.pinhole_cam2world(cam, px)
+        for boundary, level in ((0, 0), (8, 0), (8, 1), (6, 2), (9, 3)):
+            plain, lev = refpy.camera_is_in_frame(cam.width, cam.height, obs, boundary, level)
+            out["%s_in_b%d" % (name, boundary)] = plain
+            out["%s_in_b%d_l%d" % (name, boundary, level)] = lev
+    np.savez_compressed(os.path.join(OUT, "camera_ref.npz"), **out)
+    print("camera_ref", len(out), "arrays")
+
+
 def main():
+    if "--camera-only" in sys.argv:
+        assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
+        gen_camera_ref()
+        return
     assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(OUT, exist_ok=True)
     if not any(a in sys.argv for a in ("--objects-only", "--refine-only", "--shitomasi-only", "--reproject-only")):
@@ -410,6 +462,7 @@ def main():
     if "--reproject-only" not in sys.argv:
         gen_shitomasi_ref()
     gen_reproject_ref()
+    gen_camera_ref()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

@@ -349,3 +349,39 @@ def reproject_cells(cam, kf_pyrs, T_kf_w, cur_pyr, T_cur_w, cell_offset, kf_slot
                                   C.byref(nm), C.byref(nt))
     return {"tried": tried[:n], "matched": matched[:n], "search_level": sl[:n], "cell_winner": win[:n_cells], "px_cur": pc,
             "n_matches": nm.value, "n_trials": nt.value}
+
+
+# ---- camera model (a-13): vk::PinholeCamera::world2cam / cam2world, vk::AbstractCamera::isInFrame ----
+def world2cam(cam, xyz):
+    c = camera(cam)
+    xyz = f64(xyz).reshape(-1, 3)
+    out = np.zeros((len(xyz), 2))
+    for i in range(len(xyz)):
+        lib().svo_orc_world2cam(C.byref(c), _p(xyz[i], C.c_double), _p(out[i], C.c_double))
+    return out
+
+
+def world2cam_uv(cam, uv):
+    c = camera(cam)
+    uv = f64(uv).reshape(-1, 2)
+    out = np.zeros((len(uv), 2))
+    for i in range(len(uv)):
+        lib().svo_orc_world2cam_uv(C.byref(c), _p(uv[i], C.c_double), _p(out[i], C.c_double))
+    return out
+
+
+def cam2world(cam, px):
+    c = camera(cam)
+    px = f64(px).reshape(-1, 2)
+    out = np.zeros((len(px), 3))
+    for i in range(len(px)):
+        lib().svo_orc_cam2world(C.byref(c), C.c_double(px[i, 0]), C.c_double(px[i, 1]), _p(out[i], C.c_double))
+    return out
+
+
+def is_in_frame(cam, obs, boundary, level=-1):
+    c = camera(cam)
+    obs = np.ascontiguousarray(obs, dtype=np.int32).reshape(-1, 2)
+    return np.array([lib().svo_orc_is_in_frame(C.byref(c), int(o[0]), int(o[1]), int(boundary), int(level)) for o in obs],
+                    dtype=np.uint8)
+

@@ -289,3 +289,49 @@ def reproject_cells(cam, kf_pyrs, T_kf_w, cur_pyr, T_cur_w, cell_offset, kf_slot
     assert k >= 0
     return {"n_failed": nf_o, "n_succeeded": ns_o, "type": ty_o, "left_in_cell": left, "feat_cand": fc[:k], "feat_px": fpx[:k],
             "feat_level": fl[:k], "feat_type": ft[:k], "feat_grad": fg[:k], "n_matches": nm.value, "n_trials": nt.value}
+
+
+# ---- the reference's own compiled vk::PinholeCamera members (ref_camera.cpp) ----
+def _cam_d(cam):
+    d = np.zeros(5)
+    dist = getattr(cam, "dist", None)
+    if dist is not None:
+        d[:] = dist
+    return d
+
+
+def pinhole_world2cam(cam, xyz):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros((len(xyz), 2))
+    d = _cam_d(cam)
+    rc = lib().ref_pinhole_world2cam(*_cam_args(cam), _p(d, D), C.c_int(len(xyz)), _p(xyz, D), _p(out, D))
+    assert rc == 0
+    return out
+
+
+def pinhole_world2cam_uv(cam, uv):
+    uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros((len(uv), 2))
+    d = _cam_d(cam)
+    rc = lib().ref_pinhole_world2cam_uv(*_cam_args(cam), _p(d, D), C.c_int(len(uv)), _p(uv, D), _p(out, D))
+    assert rc == 0
+    return out
+
+
+def pinhole_cam2world(cam, px):
+    """distortion-free cameras only (the distorted branch calls cv::undistortPoints, absent here)"""
+    px = np.ascontiguousarray(px, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros((len(px), 3))
+    d = _cam_d(cam)
+    rc = lib().ref_pinhole_cam2world(*_cam_args(cam), _p(d, D), C.c_int(len(px)), _p(px, D), _p(out, D))
+    assert rc == 0
+    return out
+
+
+def camera_is_in_frame(width, height, obs, boundary, level):
+    obs = np.ascontiguousarray(obs, dtype=np.int32).reshape(-1, 2)
+    plain, lev = np.zeros(len(obs), dtype=np.uint8), np.zeros(len(obs), dtype=np.uint8)
+    lib().ref_camera_is_in_frame(C.c_int(width), C.c_int(height), C.c_int(len(obs)), _p(obs, C.c_int), C.c_int(boundary),
+                                 C.c_int(level), _p(plain, C.c_uint8), _p(lev, C.c_uint8))
+    return plain, lev
+

@@ -219,6 +219,13 @@ static int is_in_frame_level(const svo_orc_camera* c, int ox, int oy, int bounda
          oy >= boundary && oy < c->height / (1 << level) - boundary;
 }
 
+/* I/abstract_camera.h:58-72 -- both overloads: level < 0 selects isInFrame(obs, boundary) */
+int svo_orc_is_in_frame(const svo_orc_camera* c, int ox, int oy, int boundary, int level) {
+  if (level < 0)
+    return ox >= boundary && ox < c->width - boundary && oy >= boundary && oy < c->height - boundary;
+  return is_in_frame_level(c, ox, oy, boundary, level);
+}
+
 /* ------------------------------------------------------------------------ */
 /* small algebra                                                             */
 /* ------------------------------------------------------------------------ */

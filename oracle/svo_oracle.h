@@ -64,6 +64,8 @@ void svo_orc_world2cam_uv(const svo_orc_camera* cam, const double uv[2], double 
 void svo_orc_world2cam(const svo_orc_camera* cam, const double xyz[3], double px[2]);
 /* distortion-free branch only (pinhole_camera.cpp:47-52,64) */
 void svo_orc_cam2world(const svo_orc_camera* cam, double u, double v, double f[3]);
+/* vk::AbstractCamera::isInFrame (I/abstract_camera.h:58-72): level < 0 selects the overload without a level */
+int svo_orc_is_in_frame(const svo_orc_camera* cam, int ox, int oy, int boundary, int level);
 
 /* ---- small algebra ------------------------------------------------------ */
 /* Frame::jacobian_xyz2uv, frame.h:110-132. J is 2x6 row-major. */

@@ -745,6 +745,33 @@ def test_find_epipolar_match_direct_against_reference_fixture(ctx, golden):
     _free(kf, cf)
 
 
+def _camera_cases():
+    from oracle import gen_golden
+    return gen_golden.CAMERA_REF_CASES
+
+
+@pytest.mark.parametrize("case", _camera_cases(), ids=[c[0] for c in _camera_cases()])
+def test_camera_model_against_reference_fixture(ctx, golden, case):
+    """The device's world2cam (pinhole and radtan), distortion-free cam2world and isInFrame against the reference's own
+    compiled vk::PinholeCamera / vk::AbstractCamera members (camera_ref.npz): bit-identical pixels and bearings, equal flags."""
+    from oracle import gen_golden
+    g = golden("camera_ref.npz")
+    name = case[0]
+    cam, xyz, uv, px, obs = gen_golden.camera_ref_inputs(case)
+    p_xyz, p_uv, f_px, _ = hip.camera_batch(ctx, cam, xyz=xyz, uv=uv, px=px)
+    _assert_px_bits_equal(p_xyz, g[name + "_px_of_xyz"])
+    _assert_px_bits_equal(p_uv, g[name + "_px_of_uv"])
+    if name + "_f_of_px" in g.files:
+        _assert_px_bits_equal(f_px, g[name + "_f_of_px"])
+    else:       # distorted cam2world: cv::undistortPoints is third-party (parity unpinned): HIP == oracle restatement
+        np.testing.assert_allclose(f_px, orc.cam2world(cam, px), rtol=0, atol=1e-15)
+    for boundary, level in ((0, 0), (8, 0), (8, 1), (6, 2), (9, 3)):
+        _, _, _, plain = hip.camera_batch(ctx, cam, obs=obs, boundary=boundary, level=-1)
+        _, _, _, lev = hip.camera_batch(ctx, cam, obs=obs, boundary=boundary, level=level)
+        np.testing.assert_array_equal(plain, g["%s_in_b%d" % (name, boundary)])
+        np.testing.assert_array_equal(lev, g["%s_in_b%d_l%d" % (name, boundary, level)])
+
+
 def test_match_direct_against_reference_fixture(ctx, golden):
     """svo_hip_match_direct_batch_dev against Matcher::findMatchDirect executed by the reference's own code."""
     from oracle import gen_golden
