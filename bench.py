@@ -11,12 +11,23 @@ independent 640x480 pairs with 2000 patches each, inputs already resident in HBM
   BASELINE config C3's variant instead: every frame's patches are split over the ranks and the
   per-frame 6x6 H / 6x1 b sums are all-reduced (RCCL over xGMI) at every Gauss-Newton step.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
-dominant kernel (sia_residual_kernel) and `cpu_baseline` (the C oracle on the host cores).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel and
+`cpu_baseline` (host cores).  What the roofline object says and where every number in it comes from:
+  * the dominant kernel (sia_fused_kernel) is bound by VALU issue, not by HBM: `bound` = "valu", `achieved` = issue
+    cycles it needs per second (per-type VALU instruction counts from rocprofv3 PMC passes of this very command, stored
+    in profiles/r*_pmc_fused.json: 2 cycles per wave64 f32/int instruction, 4 per f64, 8 per transcendental), `peak` =
+    1024 SIMDs x 2.4 GHz, `frac` <= 1; the launch time is measured live with HIP events on the context stream;
+  * `traffic` / `hbm`: physical bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (lower bound as counted,
+    upper bound with the gfx950 x2 correction of wide reads) against the 8 TB/s peak;
+  * `algorithmic`: SURVEY 8(d)'s reference-layout bytes (945 B / patch / level + 881 B / patch / evaluation) over the
+    same launch time -- above the HBM peak because the kernel never moves the 768 B/patch fp64 Jacobian stream;
+  * `roofline_jacobian_pass`: the streaming implementation of the same pass (sia_residual_kernel), which IS bound by
+    HBM: physical GB/s against the peak (north_star: >= 50 %).
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -45,7 +56,7 @@ def parse_args():
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--width", type=int, default=640, help="image width (1280 for BASELINE config C3)")
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic scenes tiled over the batch")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic scenes tiled over the batch")
     ap.add_argument("--mode", choices=["frames", "allreduce"], default="frames")
     ap.add_argument("--early-stop", action="store_true", help="reference GN exits instead of fixed work")
     ap.add_argument("--graph", action="store_true", help="--mode allreduce: replay the per-level loops from HIP graphs")
@@ -54,6 +65,8 @@ def parse_args():
     ap.add_argument("--latency-probe", action="store_true",
                     help="also time single-pair early-stop solves (extra launches of the same kernel: keep it off when the\n                    run is profiled, the kernel average in the rocprofv3 summary must be that of the timed launches)")
     ap.add_argument("--profile-events", type=int, default=1, help="record HIP events around the heavy kernels in the timed region")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the extra measurements outside the timed region (reference early-stop semantics, streaming Jacobian pass)")
     return ap.parse_args()
 
 
@@ -115,6 +128,38 @@ def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=16):
             "reference_ms": timed(lambda: refpy.sparse_img_align_run(fps[0], n_iter=n_iter)),
             "port_ms": timed(lambda: orc.sparse_img_align(fps[0], n_iter=n_iter, early_stop=True))}
     return out
+
+
+N_SIMD = 1024                    # 256 CUs x 4 SIMD-32
+PEAK_CLOCK_GHZ = 2.4             # MI355X_MICROARCH.md, chip-level parameters
+
+
+def latest_profile(pattern):
+    """newest profiles/<pattern> (files are named per round: r02_..., r03_...)"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
+
+
+def pmc_of(path, kernel_prefix):
+    """counters per dispatch of the first kernel whose name starts with kernel_prefix (tools/pmc_json.py output)"""
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    for name, ctr in d.get("kernels", {}).items():
+        if name.startswith(kernel_prefix):
+            return dict(ctr, _kernel=name, _file=os.path.relpath(path, ROOT), _command=d.get("command", ""))
+    return None
+
+
+def valu_issue_cycles(c):
+    """VALU issue cycles of one launch from the per-type instruction counters: a wave64 f32 / int / conversion
+    instruction holds its SIMD-32 for 2 cycles, an f64 one for 4, a transcendental for 8 (MI355X_MICROARCH.md,
+    'Per-instruction cycle constants'; fp64 vector peak is half the fp32 one)."""
+    f64 = c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_FMA_F64", 0.0)
+    trans = c.get("SQ_INSTS_VALU_TRANS_F64", 0.0) + c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    total = c["SQ_INSTS_VALU"]
+    return 2.0 * (total - f64 - trans) + 4.0 * f64 + 8.0 * trans, f64, trans
 
 
 def main():
@@ -236,28 +281,67 @@ def main():
         bytes_frame = n_pre_per_frame * BYTES_PRECOMPUTE + n_res_per_frame * BYTES_RESIDUAL
         roofline = None
         mode = sia.last_run_mode() if not allreduce else 0
+        default_c1 = (not allreduce and not args.early_stop and B == 256 and n_feat == 2000 and args.width == 640 and
+                      args.height == 480 and args.distinct == 64)       # the configuration the committed PMC passes profiled
         if prof and prof["residual_launches"]:
             launches = prof["residual_launches"]
             avg_ms = prof["residual_ms"] / launches
+            avg_s = avg_ms * 1e-3
             if mode == 1:
                 # fused: ONE launch runs the whole coarse-to-fine solve of every frame pair of this rank
                 kernel = "sia_fused_kernel"
                 alg_bytes = float(bytes_frame) * n_slots
-                note = ("one launch = whole solve of %d frame pairs; the interpolated reference patches (128 B/patch "
-                        "instead of the reference layout's 881 B) stay in LDS for two tiles per wave and are streamed "
-                        "from L2 / Infinity Cache for the others, so most of the algorithmic bytes are never moved: "
-                        "the kernel is bound by VALU issue plus a serial solve phase" % n_slots)
             else:
                 # streaming: one launch evaluates every live patch of every frame of this rank once
                 kernel = "sia_residual_kernel"
                 units = (n_res_per_frame / max(evals, 1)) * n_slots / (world if allreduce else 1)
                 alg_bytes = units * BYTES_RESIDUAL
-                note = "one launch = one Gauss-Newton evaluation of %d frame pairs" % n_slots
-            ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                        "avg_launch_us": avg_ms * 1e3, "launches": int(launches),
-                        "algorithmic_bytes_per_launch": alg_bytes, "note": note}
+            alg = {"bytes_per_launch": alg_bytes, "GBps": alg_bytes / avg_s / 1e9, "ratio_to_hbm_peak": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
+                   "note": "SURVEY 8(d): 945 B/patch/level + 881 B/patch/evaluation in the REFERENCE's data layout (768 B of fp64 Jacobian "
+                           "cache per patch); the kernels form H and Jres from {sum dx^2, sum dx dy, sum dy^2} and two moments per patch and "
+                           "never move that stream, so this ratio is not a roofline fraction"}
+            pmc_file = latest_profile("r*_pmc_fused.json" if mode == 1 else "r*_pmc_stream.json")
+            ctr = pmc_of(pmc_file, kernel) if (pmc_file and default_c1) else None
+            if mode == 1:
+                roofline = {"bound": "valu", "kernel": kernel, "achieved": None, "peak": N_SIMD * PEAK_CLOCK_GHZ,
+                            "unit": "G VALU issue-cycles/s (1024 SIMD-32 x 2.4 GHz)", "frac": None, "traffic": None,
+                            "avg_launch_us": avg_ms * 1e3, "launches": int(launches), "algorithmic": alg,
+                            "note": "one launch = whole coarse-to-fine solve of %d frame pairs (150 Gauss-Newton evaluations each); the kernel is "
+                                    "bound by VALU issue (f32 image math + fp64 projection / normal equations) plus a serial solve phase between two "
+                                    "barriers per evaluation, not by HBM" % n_slots}
+                if ctr:
+                    cyc, n_f64, n_trans = valu_issue_cycles(ctr)
+                    roofline["achieved"] = cyc / avg_s / 1e9
+                    roofline["frac"] = roofline["achieved"] / roofline["peak"]
+                    clk = None
+                    if ctr.get("GRBM_GUI_ACTIVE") and ctr.get("_kernel_avg_us"):
+                        clk = ctr["GRBM_GUI_ACTIVE"] / 8.0 / (ctr["_kernel_avg_us"] * 1e-6) / 1e9
+                    roofline["valu"] = {"insts_per_launch": ctr["SQ_INSTS_VALU"], "f64_insts": n_f64, "transcendental_insts": n_trans,
+                                        "issue_cycles_per_launch": cyc,
+                                        "rule": "2 cycles per wave64 f32/int/cvt instruction, 4 per f64 add/mul/fma, 8 per transcendental",
+                                        "effective_clock_GHz_under_profiler": clk,
+                                        "frac_at_that_clock": (cyc / avg_s / 1e9) / (N_SIMD * clk) if clk else None}
+                    lo = (ctr.get("FETCH_SIZE", 0.0) + ctr.get("WRITE_SIZE", 0.0)) * 1024.0
+                    hi = (2.0 * ctr.get("FETCH_SIZE", 0.0) + ctr.get("WRITE_SIZE", 0.0)) * 1024.0
+                    compulsory = n_slots * (2 * 409200 + n_feat * 65)       # both pyramids once + px/f/pos/has_point per feature
+                    roofline["traffic"] = hi
+                    roofline["hbm"] = {"bytes_per_launch_as_counted": lo, "bytes_per_launch_wide_read_corrected": hi,
+                                       "GBps": [lo / avg_s / 1e9, hi / avg_s / 1e9], "peak": HBM_PEAK_GBS,
+                                       "frac": [lo / avg_s / 1e9 / HBM_PEAK_GBS, hi / avg_s / 1e9 / HBM_PEAK_GBS],
+                                       "compulsory_bytes_per_launch": compulsory,
+                                       "note": "(FETCH_SIZE + WRITE_SIZE) KB as counted (Infinity-Cache hits included) and with the gfx950 x2 "
+                                               "correction of FETCH_SIZE, which holds for 16 B/lane streams (the stored interpolated patches) "
+                                               "but not for the 8 B/lane image rows: lower and upper bound"}
+                    roofline["sources"] = [ctr["_file"], "profiles/%s" % os.path.basename(pmc_file).replace("_pmc_fused.json", "_kernel_stats.md")]
+            else:
+                ach = alg_bytes / avg_s / 1e9
+                roofline = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_ms * 1e3, "launches": int(launches),
+                            "algorithmic": alg, "note": "one launch = one Gauss-Newton evaluation of %d frame pairs" % n_slots}
+                if ctr:
+                    phys = (2.0 * ctr.get("FETCH_SIZE", 0.0) + ctr.get("WRITE_SIZE", 0.0)) * 1024.0
+                    roofline.update({"achieved": phys / avg_s / 1e9, "frac": phys / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": phys,
+                                     "sources": [ctr["_file"]]})
             if prof["precompute_launches"]:
                 roofline["precompute_avg_launch_us"] = prof["precompute_ms"] / prof["precompute_launches"] * 1e3
             hp = os.path.join(ROOT, "profiles", "r01_hbm_probe.json")
@@ -268,18 +352,64 @@ def main():
                                                     "source": "profiles/r01_hbm_probe.json (tools/hbm_probe.py on this pool)"}
                 except Exception:
                     pass
-            tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tr):
-                try:
-                    k = json.load(open(tr))["kernels"].get(kernel)
-                    if k and k.get("batch") == n_slots and not args.early_stop:      # measured on the fixed-work run
-                        roofline["traffic"] = k["bytes_per_launch"]
-                        roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, 2xFETCH_SIZE+WRITE_SIZE)"
-                except Exception:
-                    pass
+
+        # ---- secondary measurements, outside the timed region (rank 0, one GPU, default workload)
+        early = None
+        jac = None
+        if not allreduce and world == 1 and not args.no_secondary and not args.early_stop:
+            # (1) the same batch with the REFERENCE's Gauss-Newton exits (error increase, |x| <= eps)
+            prm_es = sia.params(max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=True)
+            for _ in range(2):
+                sia.run(n_slots, prm_es)
+            ctx.sync()
+            es_steps = max(5, min(args.steps, 20))
+            t1 = time.perf_counter()
+            for _ in range(es_steps):
+                sia.run(n_slots, prm_es)
+            ctx.sync()
+            dt_es = time.perf_counter() - t1
+            r_es = sia.download(0)
+            o_es = orc.sparse_img_align(fps[0], n_iter=30, early_stop=True)
+            rot_es, trans_es = synth.pose_error(np.array(r_es.T_cur_w), np.array(o_es.T_cur_w))
+            early = {"what": "the same %d frame pairs with the reference's own Gauss-Newton exits (svo_hip_sia_params.early_stop = 1)" % n_slots,
+                     "value": n_slots * es_steps / dt_es, "unit": "frames/s", "steps": es_steps, "ms_per_step": dt_es / es_steps * 1e3,
+                     "gn_evaluations_frame0": int(sum(r_es.iters[:5])),
+                     "pose_err_vs_cpu_ref": {"rot_rad": rot_es, "trans_m": trans_es},
+                     "pose_err_vs_ground_truth": dict(zip(("rot_rad", "trans_m"), synth.pose_error(np.array(r_es.T_cur_w), fps[0].T_cur_w_true)))}
+            assert rot_es < 1e-4 and trans_es < 1e-3, "early-stop pose parity violated: %g rad %g m" % (rot_es, trans_es)
+            # (2) the streaming implementation of the Jacobian / residual pass: the HBM-bound form (north_star: >= 50 % of the HBM roofline)
+            os.environ["SVO_HIP_SIA_MODE"] = "stream"
+            try:
+                sia.run(n_slots, prm)
+                ctx.sync()
+                sia.set_profiling(True)
+                sia.run(n_slots, prm)
+                sp = sia.get_profile()
+                sia.set_profiling(False)
+            finally:
+                del os.environ["SVO_HIP_SIA_MODE"]
+            if sp["residual_launches"]:
+                s_avg = sp["residual_ms"] / sp["residual_launches"] * 1e-3
+                units = (n_res_per_frame / max(evals, 1)) * n_slots
+                jac = {"kernel": "sia_residual_kernel", "bound": "hbm", "avg_launch_us": s_avg * 1e6, "launches": int(sp["residual_launches"]),
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": None, "frac": None, "traffic": None,
+                       "algorithmic": {"bytes_per_launch": units * BYTES_RESIDUAL, "GBps": units * BYTES_RESIDUAL / s_avg / 1e9},
+                       "note": "one launch = one Gauss-Newton evaluation of %d frame pairs: per-pixel f32 caches + {x,y,z,1/z} + "
+                               "{sum dx^2, sum dx dy, sum dy^2} streamed from HBM (227 B/patch instead of the reference layout's 881 B)" % n_slots}
+                sfile = latest_profile("r*_pmc_stream.json")
+                sc = pmc_of(sfile, "sia_residual_kernel") if (sfile and default_c1) else None
+                if sc:
+                    phys = (2.0 * sc.get("FETCH_SIZE", 0.0) + sc.get("WRITE_SIZE", 0.0)) * 1024.0
+                    jac.update({"achieved": phys / s_avg / 1e9, "frac": phys / s_avg / 1e9 / HBM_PEAK_GBS, "traffic": phys,
+                                "traffic_rule": "2 x FETCH_SIZE + WRITE_SIZE: every stream of this kernel is a 16 B/lane coalesced read, the case the "
+                                                "gfx950 FETCH_SIZE correction is calibrated for (MI355X_MICROARCH.md, HBM)",
+                                "sources": [sc["_file"]]})
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # reported at N=1 only (rank 0)
-            cpu = cpu_baseline(fps, n_iter=30, early_stop=args.early_stop, frames_per_thread=args.cpu_frames_per_thread)
+            cpu = cpu_baseline(fps[:16], n_iter=30, early_stop=args.early_stop, frames_per_thread=args.cpu_frames_per_thread)
+            if early is not None:
+                # the reference's OWN compiled SparseImgAlign (oracle/_ref, kind "reference") on the early-stop workload
+                early["cpu_baseline"] = cpu_baseline(fps[:16], n_iter=30, early_stop=True, frames_per_thread=max(1, args.cpu_frames_per_thread // 4))
         out = {
             "metric": "SparseImgAlign frames/s at %dx%d L4-L0; pose err vs CPU ref" % (args.width, args.height),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -300,6 +430,8 @@ def main():
             "whole_solve_algorithmic_GBps": bytes_frame * value / 1e9,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "roofline_jacobian_pass": jac,
+            "reference_semantics": early,
         }
         assert rot < 1e-4 and trans < 1e-3, "pose parity violated: %g rad %g m" % (rot, trans)
         # all replicated slots of one scene must agree bit for bit (deterministic reductions)

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Turn the text written by tools/pmc_pass.sh (per-kernel means of rocprofv3 --pmc counters) into JSON.
+Usage: tools/pmc_json.py in.txt out.json "<command the passes profiled>" """
+import json
+import re
+import sys
+
+
+def main():
+    src, dst, cmd = sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else ""
+    kernels = {}
+    cur = None
+    for line in open(src):
+        if line.startswith("#") or not line.strip():
+            continue
+        m = re.match(r"\s+(\S+)\s+mean/dispatch\s+(\S+)\s+\(n=(\d+)\)", line)
+        if m and cur is not None:
+            kernels[cur][m.group(1)] = float(m.group(2))
+            kernels[cur].setdefault("_dispatches", {})[m.group(1)] = int(m.group(3))
+        elif not line.startswith(" "):
+            cur = line.strip()
+            kernels.setdefault(cur, {})
+    json.dump({"command": cmd, "unit": "counter value per dispatch (mean over the dispatches of the pass)",
+               "kernels": kernels}, open(dst, "w"), indent=1)
+    print(dst, {k: len(v) - 1 for k, v in kernels.items()})
+
+
+if __name__ == "__main__":
+    main()
