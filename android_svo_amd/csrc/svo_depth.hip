@@ -952,6 +952,13 @@ __global__ __launch_bounds__(256) void conv_scatter_kernel(int n, long long id_o
   r[0] = (double)(id_offset + i); r[1] = (double)mu[i]; r[2] = (double)sigma2[i];
   r[3] = xyz[3 * (size_t)i]; r[4] = xyz[3 * (size_t)i + 1]; r[5] = xyz[3 * (size_t)i + 2];
 }
+// up to `cap` of the packed records and the clamped count into this rank's block of the gather buffers
+__global__ void records_clamp_copy_kernel(const double* __restrict__ rec, const int* __restrict__ count, int cap,
+                                          double* __restrict__ dst, int32_t* __restrict__ dst_count) {
+  const int n = min(*count, cap);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 6 * n; i += gridDim.x * blockDim.x) dst[i] = rec[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *dst_count = *count;      // the true count: > cap tells the caller about the overflow
+}
 }  // namespace
 
 extern "C" {
@@ -1346,6 +1353,38 @@ int svo_hip_seed_compact_converged_dev(svo_hip_ctx* ctx, int n, long long id_off
                      xyz_world_dev, block_count, records_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
+}
+
+// The exchange step of the seed-sharded depth filter (BASELINE config C4): this rank's converged seeds are
+// packed on the device in seed order, clamped to `cap` records, and all-gathered together with the per-rank counts:
+// records_all[world][cap][6] f64, counts_all[world] i32 (a count above cap = that rank had more: raise cap).
+// Two collectives of fixed size, no host round trip in between.
+int svo_hip_seed_gather_converged_dev(svo_hip_ctx* ctx, svo_hip_comm* comm, int n, long long id_offset, const int32_t* status_dev,
+                                      const float* mu_dev, const float* sigma2_dev, const double* xyz_world_dev, int cap,
+                                      double* records_all_dev, int32_t* counts_all_dev) {
+  if (!ctx || !comm) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n >= 0 && cap >= 1 && records_all_dev && counts_all_dev);
+  int rank = 0, world = 1;
+  svo_hip_comm_info(comm, &rank, &world, nullptr);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  // scratch: [block counts of the compaction][n records][count]
+  const int n_blocks = (n + 255) / 256;
+  const size_t o_rec = ((sizeof(int) * (size_t)n_blocks + 64) + 255) & ~(size_t)255;
+  const size_t o_cnt = o_rec + (size_t)(n > 0 ? n : 1) * 6 * sizeof(double);
+  void* ws = nullptr;
+  int rc = svo_ctx_scratch(ctx, o_cnt + 64, &ws);
+  if (rc != SVO_HIP_OK) return rc;
+  // (svo_hip_seed_compact_converged_dev takes its block counts from the start of the same scratch area)
+  double* rec = reinterpret_cast<double*>(static_cast<char*>(ws) + o_rec);
+  int32_t* cnt = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + o_cnt);
+  rc = svo_hip_seed_compact_converged_dev(ctx, n, id_offset, status_dev, mu_dev, sigma2_dev, xyz_world_dev, rec, cnt);
+  if (rc != SVO_HIP_OK) return rc;
+  hipLaunchKernelGGL(records_clamp_copy_kernel, dim3(64), dim3(256), 0, ctx->stream, rec, reinterpret_cast<const int*>(cnt), cap,
+                     records_all_dev + (size_t)rank * cap * 6, counts_all_dev + rank);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  rc = svo_comm_all_gather(comm, records_all_dev, (size_t)cap * 6 * sizeof(double));
+  if (rc != SVO_HIP_OK) return rc;
+  return svo_comm_all_gather(comm, counts_all_dev, sizeof(int32_t));
 }
 
 // The cell loop of Reprojector::reprojectMap (reprojector.cpp:149-166, 180-241) over candidates bucketed per cell in

@@ -112,3 +112,11 @@ inline svo_dev::Cam svo_make_cam(const svo_hip_camera& c) {
   d.width = c.width; d.height = c.height;
   return d;
 }
+
+// ---- multi-GPU exchange (svo_comm.hip): RCCL over xGMI, or a host-staged shared-memory transport for bring-up / tests.
+// Both all-reduce in place on the communicator's context stream and give every rank bitwise the same result.
+struct svo_hip_comm;
+int svo_comm_all_reduce_sum_f64(svo_hip_comm* c, double* dev, size_t count);
+int svo_comm_all_gather(svo_hip_comm* c, void* recv_dev, size_t bytes_per_rank);     // rank r's block at recv_dev + r * bytes, in place
+extern "C" int svo_hip_comm_info(const svo_hip_comm* c, int* rank, int* world, int* kind);
+

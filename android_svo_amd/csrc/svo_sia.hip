@@ -1842,6 +1842,31 @@ int svo_hip_sia_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) 
   return svo_hip_sia_finish(s);
 }
 
+// BASELINE config C3's variant behind the C-ABI: every frame's patches are split contiguously over the ranks of
+// `comm`, every rank reduces its shard to SVO_HIP_REDUCE_DOUBLES doubles per frame, ONE batched all-reduce of
+// n_slots x 32 doubles per Gauss-Newton step (RCCL over xGMI, enqueued on the context stream between the two kernels:
+// no host round trip), then every rank runs the identical solve on identical sums -- identical decisions, no further
+// exchange.  Finished frames contribute zeros (the kernels skip them), so the fixed launch sequence keeps the
+// reference's early-exit semantics.
+int svo_hip_sia_run_sharded(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, const svo_hip_sia_params* prm) {
+  if (!s || !comm || !prm) return SVO_HIP_ERR_INVALID;
+  int rank = 0, world = 1;
+  svo_hip_comm_info(comm, &rank, &world, nullptr);
+  int rc = svo_hip_sia_set_shard(s, rank, world);
+  if (rc != SVO_HIP_OK) return rc;
+  rc = svo_hip_sia_begin(s, n_slots, prm);
+  if (rc != SVO_HIP_OK) return rc;
+  for (int level = prm->max_level; level >= prm->min_level; --level) {
+    if ((rc = svo_hip_sia_level_begin(s, level)) != SVO_HIP_OK) return rc;
+    for (int it = 0; it < prm->n_iter; ++it) {
+      if ((rc = svo_hip_sia_accumulate(s)) != SVO_HIP_OK) return rc;
+      if ((rc = svo_comm_all_reduce_sum_f64(comm, s->reduce, (size_t)n_slots * SVO_HIP_REDUCE_DOUBLES)) != SVO_HIP_OK) return rc;
+      if ((rc = svo_hip_sia_solve_update(s)) != SVO_HIP_OK) return rc;
+    }
+  }
+  return svo_hip_sia_finish(s);
+}
+
 #ifdef SVO_STAMPS
 int svo_hip_sia_debug_x(svo_hip_sia* s, int slot, double* x6) {
   FrameState st;

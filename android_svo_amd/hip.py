@@ -379,6 +379,54 @@ def camera_batch(ctx: Context, cam, xyz=None, uv=None, px=None, obs=None, bounda
     return o_xyz, o_uv, o_f, o_in
 
 
+class Comm:
+    """svo_hip_comm: RCCL (kind="rccl": `unique_id` = the 128 bytes rank 0 got from Comm.unique_id()) or the host-staged
+    shared-memory transport (kind="shm": `name` = "/segment-name")."""
+
+    def __init__(self, ctx: Context, rank: int, world: int, kind: str = "rccl", unique_id: Optional[bytes] = None,
+                 name: Optional[str] = None, slot_bytes: int = 1 << 20):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.h = C.c_void_p()
+        if kind == "rccl":
+            buf = (C.c_char * 128).from_buffer_copy(unique_id)
+            ctx.check(ctx.lib.svo_hip_comm_create_rccl(ctx.h, buf, rank, world, C.byref(self.h)), "comm_create_rccl")
+        else:
+            ctx.check(ctx.lib.svo_hip_comm_create_shm(ctx.h, name.encode(), rank, world, C.c_size_t(slot_bytes), C.byref(self.h)),
+                      "comm_create_shm")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * 128)()
+        rc = load_library().svo_hip_comm_unique_id(buf)
+        if rc != 0:
+            raise SvoHipError("svo_hip_comm_unique_id failed (%d): is librccl loadable?" % rc)
+        return bytes(buf)
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.svo_hip_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def sia_run_sharded(sia, comm: Comm, n_slots: int, prm):
+    sia.ctx.check(sia.ctx.lib.svo_hip_sia_run_sharded(sia.h, comm.h, n_slots, C.byref(prm)), "sia_run_sharded")
+
+
+def seed_gather_converged(ctx: Context, comm: Comm, seeds, id_offset: int, cap: int):
+    """Returns (records [total][6] ordered by rank then seed, counts[world]) after the device-side gather."""
+    rec = ctx.empty((comm.world * cap, 6), np.float64)
+    cnt = ctx.empty((comm.world,), np.int32)
+    ctx.check(ctx.lib.svo_hip_seed_gather_converged_dev(
+        ctx.h, comm.h, seeds.n, C.c_longlong(id_offset), C.c_void_p(seeds.status.ptr), C.c_void_p(seeds.mu.ptr),
+        C.c_void_p(seeds.sigma2.ptr), C.c_void_p(seeds.xyz.ptr), cap, C.c_void_p(rec.ptr), C.c_void_p(cnt.ptr)),
+        "seed_gather_converged")
+    counts = cnt.download()
+    r = rec.download().reshape(comm.world, cap, 6)
+    out = np.concatenate([r[k, :min(int(counts[k]), cap)] for k in range(comm.world)], axis=0)
+    rec.free(); cnt.free()
+    return out, counts
+
+
 def compute_tau_batch(ctx: Context, T_ref_cur, f, z, px_error_angle):
     n = len(z)
     df, dz, dt = ctx.to_device(_f64(f)), ctx.to_device(_f64(z)), ctx.empty((n,), np.float64)

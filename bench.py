@@ -409,7 +409,7 @@ def main():
             cpu = cpu_baseline(fps[:16], n_iter=30, early_stop=args.early_stop, frames_per_thread=args.cpu_frames_per_thread)
             if early is not None:
                 # the reference's OWN compiled SparseImgAlign (oracle/_ref, kind "reference") on the early-stop workload
-                early["cpu_baseline"] = cpu_baseline(fps[:16], n_iter=30, early_stop=True, frames_per_thread=max(1, args.cpu_frames_per_thread // 4))
+                early["cpu_baseline"] = cpu_baseline(fps[:16], n_iter=30, early_stop=True, frames_per_thread=5 * args.cpu_frames_per_thread)
         out = {
             "metric": "SparseImgAlign frames/s at %dx%d L4-L0; pose err vs CPU ref" % (args.width, args.height),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -146,6 +146,30 @@ int svo_hip_sia_upload_poses(svo_hip_sia* sia, int slot, const svo_hip_camera* c
  * the per-frame sums must then be all-reduced across ranks between accumulate and solve_update. */
 int svo_hip_sia_set_shard(svo_hip_sia* sia, int rank, int world);
 
+/* ---- multi-GPU exchange: the reference has none; these entries let the C++ host shard the path ----
+ * A communicator binds a context (its stream) to a rank of a group.  Transports:
+ *   RCCL over xGMI: either the library creates the communicator from a 128-byte ncclUniqueId that rank 0 obtained
+ *     with svo_hip_comm_unique_id and the application distributed (MPI, a file, a socket ...), or it adopts an existing
+ *     ncclComm_t (svo_hip_comm_from_nccl; the application keeps ownership).  librccl is resolved at run time.
+ *   host-staged exchange through a POSIX shared-memory segment `name` ("/..."; unique per group): for ranks that
+ *     share one device or have no peer path (bring-up, tests).  slot_bytes = largest message of one rank.  Blocks the
+ *     calling thread at every exchange.
+ * Both give every rank bitwise the same all-reduce result, so the ranks' Gauss-Newton decisions stay in lock-step. */
+typedef struct svo_hip_comm svo_hip_comm;
+int svo_hip_comm_unique_id(void* id128);
+int svo_hip_comm_create_rccl(svo_hip_ctx* ctx, const void* id128, int rank, int world, svo_hip_comm** out);
+int svo_hip_comm_from_nccl(svo_hip_ctx* ctx, void* nccl_comm, int rank, int world, svo_hip_comm** out);
+int svo_hip_comm_create_shm(svo_hip_ctx* ctx, const char* name, int rank, int world, size_t slot_bytes, svo_hip_comm** out);
+int svo_hip_comm_destroy(svo_hip_comm* comm);
+int svo_hip_comm_info(const svo_hip_comm* comm, int* rank, int* world, int* kind /* 0 RCCL, 1 shared memory */);
+
+/* SparseImgAlign::run with every frame's patches split over the ranks of `comm` (BASELINE config C3's variant): each
+ * rank evaluates patches [n*rank/world, n*(rank+1)/world) of every slot, ONE all-reduce of n_slots x
+ * SVO_HIP_REDUCE_DOUBLES doubles per Gauss-Newton step on the context stream, then the identical solve on every rank.
+ * Every rank must hold the same features, poses and pyramids and call this with the same arguments; all ranks end
+ * with the same result (svo_hip_sia_download). */
+int svo_hip_sia_run_sharded(svo_hip_sia* sia, svo_hip_comm* comm, int n_slots, const svo_hip_sia_params* prm);
+
 /* run(): the whole coarse-to-fine solve for slots [0, n_slots), enqueued on the stream with no
  * host round trip.  Poses restart from the uploaded initial poses on every call. */
 int svo_hip_sia_run(svo_hip_sia* sia, int n_slots, const svo_hip_sia_params* prm);
@@ -304,6 +328,15 @@ int svo_hip_epipolar_match_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* re
 int svo_hip_seed_compact_converged_dev(svo_hip_ctx* ctx, int n, long long id_offset, const int32_t* status_dev,
                                        const float* mu_dev, const float* sigma2_dev, const double* xyz_world_dev,
                                        double* records_dev, int32_t* count_dev);
+
+/* The exchange step of the seed-sharded depth filter (BASELINE config C4): this rank's converged seeds (packed as
+ * above, clamped to `cap` records) and every other rank's, plus the per-rank counts: records_all[world][cap][6] f64,
+ * counts_all[world] i32 (a count above cap means that rank had more: call again with a larger cap).  Two fixed-size
+ * all-gathers on the context stream. */
+int svo_hip_seed_gather_converged_dev(svo_hip_ctx* ctx, svo_hip_comm* comm, int n, long long id_offset,
+                                      const int32_t* status_dev, const float* mu_dev, const float* sigma2_dev,
+                                      const double* xyz_world_dev, int cap, double* records_all_dev,
+                                      int32_t* counts_all_dev);
 
 /* host-buffer convenience form of the above (copies in, runs, copies out, synchronises) */
 int svo_hip_depth_filter_update(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,

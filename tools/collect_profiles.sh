@@ -15,14 +15,14 @@ export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/prof_$tag
 # 1. kernel trace (program directly after --, no launcher in between)
-rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag/trace -o trace -- python3 "$root/bench.py" --steps 20 --warmup 3 --no-cpu-baseline "$@" > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_rocprof.log"
+rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag/trace -o trace -- python3 "$root/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-secondary "$@" > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_rocprof.log"
 db=$(find /tmp/prof_$tag/trace -name '*.db' | head -1)
 python3 "$root/tools/rocpd_summary.py" "$db" "$out/${tag}_kernel_stats.md" > /dev/null
 echo "kernel stats -> $out/${tag}_kernel_stats.md"
 # 2. PMC passes, each in its own run, with kernel-trace only
 : > "$out/${tag}_pmc.txt"
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/prof_$tag/$ctr -o pmc -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --profile-events 0 "$@" > /dev/null 2>> "$out/${tag}_rocprof.log"
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/prof_$tag/$ctr -o pmc -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --profile-events 0 "$@" > /dev/null 2>> "$out/${tag}_rocprof.log"
   csv=$(find /tmp/prof_$tag/$ctr -name '*counter_collection.csv' | head -1)
   python3 "$root/tools/pmc_summary.py" "$csv" sia_ >> "$out/${tag}_pmc.txt"
 done

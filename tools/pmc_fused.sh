@@ -4,7 +4,7 @@
 # One rocprofv3 --pmc pass per counter group (8 SQ slots / 4 TCC slots per pass), kernel-trace only.
 set -e -o pipefail
 tag=${1:?tag}; shift || true
-export PMC_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --profile-events 0 $*"
+export PMC_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-secondary --profile-events 0 $*"
 export PMC_KERNEL="sia_"
 bash tools/pmc_pass.sh "$tag" \
   "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT64" \
