@@ -318,7 +318,9 @@ def main():
                         clk = ctr["GRBM_GUI_ACTIVE"] / 8.0 / (ctr["_kernel_avg_us"] * 1e-6) / 1e9
                     roofline["valu"] = {"insts_per_launch": ctr["SQ_INSTS_VALU"], "f64_insts": n_f64, "transcendental_insts": n_trans,
                                         "issue_cycles_per_launch": cyc,
-                                        "rule": "2 cycles per wave64 f32/int/cvt instruction, 4 per f64 add/mul/fma, 8 per transcendental",
+                                        "rule": "2 cycles per wave64 f32/int/cvt instruction, 4 per f64 add/mul/fma, 8 per transcendental "
+                                                "(conversions to/from f64 counted at 2: a lower bound)",
+                                        "cvt_insts": ctr.get("SQ_INSTS_VALU_CVT"),
                                         "effective_clock_GHz_under_profiler": clk,
                                         "frac_at_that_clock": (cyc / avg_s / 1e9) / (N_SIMD * clk) if clk else None}
                     lo = (ctr.get("FETCH_SIZE", 0.0) + ctr.get("WRITE_SIZE", 0.0)) * 1024.0
@@ -421,7 +423,7 @@ def main():
                        "parallelism": ("patch-sharded + per-GN-step all-reduce of H/b (C3 variant)" + (", HIP-graph replay" if args.graph else "") if allreduce
                                        else "frame-parallel (no collective)") + ", %d GPU(s)" % world,
                        "distinct_scenes": args.distinct,
-                       "implementation": "fused (one workgroup per frame pair, one launch per solve)" if (not allreduce and sia.last_run_mode() == 1) else "streaming (one launch per Gauss-Newton evaluation)"},
+                       "implementation": "fused (one workgroup per frame pair, one launch per solve)" if (not allreduce and mode == 1) else "streaming (one launch per Gauss-Newton evaluation)"},
             "pose_err_vs_cpu_ref": {"rot_rad": rot, "trans_m": trans, "tolerance": "1e-4 rad / 1e-3 m"},
             "pose_err_vs_ground_truth": dict(zip(("rot_rad", "trans_m"), synth.pose_error(np.array(res.T_cur_w), fps[0].T_cur_w_true))),
             "gn_evaluations_per_frame": int(evals),
