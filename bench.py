@@ -57,7 +57,9 @@ def parse_args():
     ap.add_argument("--width", type=int, default=640, help="image width (1280 for BASELINE config C3)")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic scenes tiled over the batch")
-    ap.add_argument("--mode", choices=["frames", "allreduce"], default="frames")
+    ap.add_argument("--mode", choices=["frames", "allreduce", "allreduce-torch"], default="frames",
+                    help="allreduce: patch-sharded solve through the C-ABI (svo_hip_sia_run_sharded, RCCL called by libsvo_hip.so); "
+                         "allreduce-torch: the same exchange driven from Python through torch.distributed (android_svo_amd/dist.py)")
     ap.add_argument("--early-stop", action="store_true", help="reference GN exits instead of fixed work")
     ap.add_argument("--graph", action="store_true", help="--mode allreduce: replay the per-level loops from HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -248,7 +250,8 @@ def main():
 
     B = args.batch
     n_feat = args.features
-    allreduce = args.mode == "allreduce" and multi
+    allreduce = args.mode in ("allreduce", "allreduce-torch") and multi
+    native = args.mode == "allreduce"
     # ---- synthetic inputs (host), then resident in HBM before anything is timed
     fps = [synth.make_frame_pair(seed=12345 + 17 * rank + i, n_features=n_feat, width=args.width, height=args.height) for i in range(args.distinct)]
     cam = fps[0].cam
@@ -270,7 +273,15 @@ def main():
         sia.upload_pair(s, fp)
     prm = sia.params(max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=args.early_stop)
     aligner = None
-    if allreduce:
+    graphed = None
+    comm = None
+    if allreduce and native:
+        # the communicator of the C-ABI: rank 0's ncclUniqueId reaches the other ranks through the process group that
+        # torch.distributed.run set up (any side channel would do); from here on the exchange is libsvo_hip.so -> RCCL
+        uid = [hip.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = hip.Comm(ctx, rank, world, kind="rccl", unique_id=uid[0])
+    elif allreduce:
         from android_svo_amd import dist as svodist
         aligner = svodist.HipShardedAligner(sia, n_slots, prm, rank, world, stream)
         graphed = svodist.GraphedAllreduceSolver(aligner, prm.max_level, prm.min_level, prm.n_iter, stream) if args.graph else None
@@ -278,6 +289,9 @@ def main():
     def step():
         if not allreduce:
             sia.run(n_slots, prm)
+            return
+        if comm is not None:
+            hip.sia_run_sharded(sia, comm, n_slots, prm)
             return
         if graphed is not None:
             graphed.run()
@@ -491,7 +505,9 @@ def main():
             "config": {"workload": "%s: SparseImgAlign %dx%d, %d patches, 5 pyramid levels (L4-L0), %s" %
                                    ("C1" if args.width == 640 else "C3 shape", args.width, args.height, n_feat, "reference early-stop GN" if args.early_stop else "30 GN evaluations per level (fixed work)"),
                        "frame_pairs_per_gpu_per_step": B, "global_frame_pairs_per_step": frames_global,
-                       "parallelism": ("patch-sharded + per-GN-step all-reduce of H/b (C3 variant)" + (", HIP-graph replay" if args.graph else "") if allreduce
+                       "parallelism": ("patch-sharded + per-GN-step all-reduce of H/b (C3 variant), " +
+                                       ("RCCL called by libsvo_hip.so (svo_hip_sia_run_sharded)" if native else "torch.distributed driver") +
+                                       (", HIP-graph replay" if args.graph else "") if allreduce
                                        else "frame-parallel (no collective)") + ", %d GPU(s)" % world,
                        "distinct_scenes": args.distinct,
                        "implementation": "fused (one workgroup per frame pair, one launch per solve)" if (not allreduce and mode == 1) else "streaming (one launch per Gauss-Newton evaluation)"},
@@ -516,6 +532,12 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
+        graphed = None          # captured graphs hold RCCL kernels: release them before the communicator goes away
+        aligner = None
+        if comm is not None:
+            ctx.sync()
+            comm.destroy()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

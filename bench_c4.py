@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--gather", choices=["native", "torch"], default="native",
+                    help="native: svo_hip_seed_gather_converged_dev (libsvo_hip.so calls RCCL); torch: android_svo_amd/dist.py driver")
     ap.add_argument("--sigma-scale", type=float, default=0.0045,
                     help="seed variance relative to a fresh seed: small enough that part of the seeds converge in this pass")
     args = ap.parse_args()
@@ -66,14 +68,30 @@ def main():
     sb = hip.SeedBatch(ctx, sc.px[sl], sc.f[sl], sc.level[sl], sc.a[sl], sc.b[sl], sc.mu[sl], sc.z_range[sl], sigma2)
     st0 = [ctx.to_device(np.ascontiguousarray(v)) for v in (sc.a[sl], sc.b[sl], sc.mu[sl], sigma2)]
     n_conv_total = 0
+    comm = None
+    rec_all = cnt_all = None
+    cap = hi - lo if world == 1 else max(1, (args.seeds + world - 1) // world)
+    if multi and args.gather == "native":
+        # the C-ABI's own communicator: rank 0's ncclUniqueId travels through torch.distributed.run's process group
+        uid = [hip.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = hip.Comm(ctx, rank, world, kind="rccl", unique_id=uid[0])
+        rec_all = ctx.empty((world * cap, 6), np.float64)
+        cnt_all = ctx.empty((world,), np.int32)
 
     def step():
         nonlocal n_conv_total
         for dst, src in zip((sb.a, sb.b, sb.mu, sb.sigma2), st0):        # same seed state every step
             ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(dst.ptr), C.c_void_p(src.ptr), C.c_size_t(dst.nbytes)), "d2d")
         hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb)
-        rec = svodist.gather_converged_device(ctx, sb, lo, stream)       # packed on the GPU, RCCL all-gather when N > 1
-        n_conv_total = int(rec.shape[0])
+        if comm is not None:
+            # packed on the GPU, two fixed-size RCCL all-gathers enqueued by libsvo_hip.so, no host round trip
+            ctx.check(ctx.lib.svo_hip_seed_gather_converged_dev(
+                ctx.h, comm.h, sb.n, C.c_longlong(lo), C.c_void_p(sb.status.ptr), C.c_void_p(sb.mu.ptr), C.c_void_p(sb.sigma2.ptr),
+                C.c_void_p(sb.xyz.ptr), cap, C.c_void_p(rec_all.ptr), C.c_void_p(cnt_all.ptr)), "seed_gather_converged")
+        else:
+            rec = svodist.gather_converged_device(ctx, sb, lo, stream)   # torch.distributed driver
+            n_conv_total = int(rec.shape[0])
 
     def fence():
         ctx.sync()
@@ -93,6 +111,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if comm is not None:
+        n_conv_total = int(np.minimum(cnt_all.download(), cap).sum())
     if rank == 0:
         out = {"metric": "DepthFilter seed updates/s (BASELINE config C4)", "value": args.seeds * args.steps / dt, "unit": "seeds/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -101,10 +121,15 @@ def main():
                "config": {"workload": "C4: DepthFilter::updateSeeds, %d seeds on a %dx%d keyframe, seeds sharded over %d GPU(s), gather of converged records"
                                       % (args.seeds, args.width, args.height, world),
                           "seeds_per_gpu": hi - lo, "converged_records_gathered": int(n_conv_total),
-                          "note": "a step = the update pass + the on-device packing of the converged records + (N > 1) the RCCL all-gather"}}
+                          "gather": "svo_hip_seed_gather_converged_dev (RCCL called by libsvo_hip.so)" if comm is not None else "torch.distributed driver",
+                          "note": "a step = the update pass + the on-device packing of the converged records + the RCCL all-gather"}}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
+        if comm is not None:
+            ctx.sync()
+            comm.destroy()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -1,6 +1,7 @@
 """The NCCL (= RCCL) code paths on the one GPU this build can reach: a single rank under torch.distributed.run.
-The patch-sharded all-reduce solve of bench.py --mode allreduce, eager and replayed from HIP graphs, and the
-seed-sharded depth filter with the on-device gather (bench_c4.py).  More ranks are covered by the gloo tests."""
+The patch-sharded all-reduce solve of bench.py --mode allreduce (RCCL called by libsvo_hip.so) and --mode allreduce-torch
+(the torch.distributed driver), and the seed-sharded depth filter with the on-device gather (bench_c4.py).  More ranks:
+tests/test_gpu_comm.py (several processes on the one GPU over the host-staged transport) and the gloo tests on the CPU."""
 import json
 import os
 import subprocess
@@ -23,16 +24,19 @@ def _torchrun(script_args, port):
     return json.loads(lines[0])
 
 
-def test_allreduce_solve_eager_and_graph_replay():
-    common = ["bench.py", "--gpus", "1", "--mode", "allreduce", "--batch", "4", "--features", "600", "--steps", "2", "--warmup", "1",
+def test_allreduce_solve_native_and_torch_driver():
+    """BASELINE config C3's variant with one rank: the patch-sharded solve with the all-reduce of the normal equations
+    (a) through the C-ABI (svo_hip_sia_run_sharded: libsvo_hip.so calls RCCL itself) and (b) driven from Python through
+    torch.distributed -- the same kernels and the same sums, so the same bits."""
+    common = ["bench.py", "--gpus", "1", "--batch", "4", "--features", "600", "--steps", "2", "--warmup", "1", "--distinct", "4",
               "--no-cpu-baseline", "--profile-events", "0"]
-    eager = _torchrun(common, 29541)
-    graph = _torchrun(common + ["--graph"], 29542)
-    for d in (eager, graph):
+    native = _torchrun(common + ["--mode", "allreduce"], 29541)
+    torch_driver = _torchrun(common + ["--mode", "allreduce-torch"], 29542)
+    for d in (native, torch_driver):
         assert d["n_gpus"] == 1 and d["pose_err_vs_cpu_ref"]["rot_rad"] < 1e-9 and d["pose_err_vs_cpu_ref"]["trans_m"] < 1e-9
         assert "all-reduce" in d["config"]["parallelism"]
-    assert graph["pose_err_vs_cpu_ref"] == eager["pose_err_vs_cpu_ref"]      # the same kernels, the same bits
-    assert "HIP-graph" in graph["config"]["parallelism"]
+    assert "libsvo_hip.so" in native["config"]["parallelism"]
+    assert native["pose_err_vs_cpu_ref"] == torch_driver["pose_err_vs_cpu_ref"]
 
 
 def test_seed_sharded_depth_filter_with_device_gather():
