@@ -69,6 +69,19 @@ def test_sharded_sparse_img_align_rccl_one_rank(tmp_path):
     _check_sia(_run_ranks("sia", "rccl", 1, tmp_path))
 
 
+def test_config_c3_shape_two_ranks_on_one_gpu(tmp_path):
+    """1280x720 frame pairs with 2000 patches each through the patch-sharded all-reduce path at world size 2."""
+    res = _run_ranks("sia_c3", "shm", 2, tmp_path)
+    np.testing.assert_array_equal(res[0]["T"], res[1]["T"])
+    np.testing.assert_array_equal(res[0]["H"], res[1]["H"])
+    for s in range(2):
+        fp = synth.make_frame_pair(seed=3300 + s, n_features=2000, width=1280, height=720)
+        o = orc.sparse_img_align(fp, n_iter=4, early_stop=False)
+        rot, trans = synth.pose_error(res[0]["T"][s], np.array(o.T_cur_w))
+        assert rot < 1e-9 and trans < 1e-9, (s, rot, trans)
+        assert int(res[0]["n"][s]) == o.n_tracked == 2000
+
+
 def _check_seeds(results, world):
     n = 6000
     total = sum(int(r["n_conv_local"]) for r in results)
