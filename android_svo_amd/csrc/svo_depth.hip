@@ -418,6 +418,67 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
   recs[i] = rc;
 }
 
+// ---- image windows in LDS -------------------------------------------------------------------------------------
+// Both pixel phases of the search kernel gather bytes around one place of an image: the 100 bilinear samples of the
+// affine warp, and the up to 16 overlapping 8x8 candidate patches of one chunk of the epipolar walk.  Read straight
+// from memory that is 14 + 16 scattered load instructions per lane with ~40 cache-line accesses each, and the kernel
+// is bound by L1 address processing (PMC: 0.8 line accesses per cycle and CU, TA busy 69 %).  Instead the 16 lanes of
+// a seed copy the bounding box of what they need -- at most WIN_ROWS rows of WIN_PITCH bytes, one or two unaligned
+// 16-byte loads per row, one row (two if the box is taller than 16) per lane -- into LDS and gather from there.  A box
+// that does not fit (a strongly scaled warp, a segment steeper than the chunk allows) falls back to the direct loads.
+constexpr int WIN_PITCH = 32;
+constexpr int WIN_ROWS = 32;
+constexpr int WIN_BYTES = WIN_ROWS * WIN_PITCH;
+
+// lane cl (0..15) of a seed copies rows cl and cl + 16 of the h x WIN_PITCH box whose top-left byte is `src`
+SVO_DEV void win_fill(const uint8_t* __restrict__ src, int pitch, int h, int cl, uint8_t* win) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int r = cl + 16 * half;
+    if (r < h) {
+      const uint8_t* p = src + (size_t)r * pitch;
+      uint4 a, b;
+      __builtin_memcpy(&a, p, 16);                       // unaligned global_load_dwordx4
+      __builtin_memcpy(&b, p + 16, 16);
+      *reinterpret_cast<uint4*>(win + r * WIN_PITCH) = a;
+      *reinterpret_cast<uint4*>(win + r * WIN_PITCH + 16) = b;
+    }
+  }
+}
+
+// min / max over the 16 lanes of a DPP row, every lane gets it (the reductions of row16_sum with another operator)
+SVO_DEV int row16_min(int v) {
+  v = min(v, dpp_quad<0xB1>(v)); v = min(v, dpp_quad<0x4E>(v)); v = min(v, dpp_quad<0x141>(v)); v = min(v, dpp_quad<0x140>(v));
+  return v;
+}
+SVO_DEV int row16_max(int v) {
+  v = max(v, dpp_quad<0xB1>(v)); v = max(v, dpp_quad<0x4E>(v)); v = max(v, dpp_quad<0x141>(v)); v = max(v, dpp_quad<0x140>(v));
+  return v;
+}
+
+// zmssd_8x8 with the candidate's 8x8 patch taken from an LDS window: `row0` = window row of the patch's first row,
+// ox = byte offset of its first column (any value 0 .. WIN_PITCH - 8; dword-aligned reads + v_alignbyte)
+SVO_DEV int zmssd_8x8_win(const uint8_t* row0, int ox, const uint32_t* patch_words, int sumA, int sumAA) {
+  uint32_t sumB = 0, sumBB = 0, sumAB = 0;
+  const int sh = ox & 3;
+  const uint32_t* base = reinterpret_cast<const uint32_t*>(row0 + (ox & ~3));
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    const uint32_t* r = base + y * (WIN_PITCH / 4);
+    const uint32_t d0 = r[0], d1 = r[1], d2 = r[2];       // d2 may belong to the next row (or the pad): unused when sh == 0
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    const uint32_t a0 = patch_words[2 * y], a1 = patch_words[2 * y + 1];
+    sumB = __builtin_amdgcn_udot4(w0, 0x01010101u, sumB, false);
+    sumB = __builtin_amdgcn_udot4(w1, 0x01010101u, sumB, false);
+    sumBB = __builtin_amdgcn_udot4(w0, w0, sumBB, false);
+    sumBB = __builtin_amdgcn_udot4(w1, w1, sumBB, false);
+    sumAB = __builtin_amdgcn_udot4(w0, a0, sumAB, false);
+    sumAB = __builtin_amdgcn_udot4(w1, a1, sumAB, false);
+  }
+  const int sB = (int)sumB, sBB = (int)sumBB, sAB = (int)sumAB;
+  return sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
+}
+
 // Four seeds per wave, 16 per 256-thread block.  Three phases per wave:
 //   A  one seed at a time, all 64 lanes: warp::warpAffine of the 10x10 reference patch into LDS (lanes = pixels)
 //   B  the four seeds at once, 16 lanes each: ZMSSD search along the epipolar line (lane = candidate step; the
@@ -426,13 +487,14 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
 constexpr int SEEDS_PER_WAVE = 4;
 constexpr int SEEDS_PER_BLOCK = 16;
 
-__global__ __launch_bounds__(256) void df_search_kernel(
+__global__ __launch_bounds__(256, 7) void df_search_kernel(
     DfFrame fr, const uint8_t* __restrict__ ref_base, size_t ref_pyr_bytes, const uint8_t* __restrict__ cur_pyr, int n,
     const int32_t* __restrict__ level, SeedRec* __restrict__ recs, uint32_t* __restrict__ pwb_t, int n_pad) {
   __shared__ __attribute__((aligned(16))) uint8_t s_pwb[SEEDS_PER_BLOCK][112];
   __shared__ __attribute__((aligned(16))) uint32_t s_patch[SEEDS_PER_BLOCK][16];
   __shared__ double s_px[SEEDS_PER_BLOCK][2];
   __shared__ int s_do[SEEDS_PER_BLOCK], s_nz[SEEDS_PER_BLOCK];
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[SEEDS_PER_BLOCK * WIN_BYTES + 16];   // image windows (+ pad: see zmssd_8x8_win)
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform -> SGPRs
   const int lane = threadIdx.x & 63;
   const int i0 = (blockIdx.x * 4 + wib) * SEEDS_PER_WAVE;
@@ -482,12 +544,38 @@ __global__ __launch_bounds__(256) void df_search_kernel(
       const bool warp_nan = rp->warp_nan != 0;
       const float lscale = (float)(1 << search_level);
       uint8_t* pwb = s_pwb[wib * SEEDS_PER_WAVE + g];
+      // The source footprint of the patch: the four corners bound every sample (each f32 operation of the affine map is
+      // monotone in the patch coordinate), the samples that are interpolated lie in [0, rcols-1) x [0, rrows-1).
+      uint8_t* win = s_win + (wib * SEEDS_PER_WAVE + g) * WIN_BYTES;
+      int wx0 = 0, wy0 = 0;
+      bool use_win = false;
+      {
+        float xmin = 0, xmax = 0, ymin = 0, ymax = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float ppx = (float)((c & 1) ? 4 : -5) * lscale, ppy = (float)((c & 2) ? 4 : -5) * lscale;
+          const float qx = (a00 * ppx + a01 * ppy) + prx, qy = (a10 * ppx + a11 * ppy) + pry;
+          xmin = c == 0 ? qx : fminf(xmin, qx); xmax = c == 0 ? qx : fmaxf(xmax, qx);
+          ymin = c == 0 ? qy : fminf(ymin, qy); ymax = c == 0 ? qy : fmaxf(ymax, qy);
+        }
+        // (comparisons with a NaN are false: a NaN box, like a NaN warp, keeps the direct path, which zeroes the patch)
+        if (!warp_nan && xmin > -1e6f && ymin > -1e6f && xmax < 1e6f && ymax < 1e6f) {
+          wx0 = max((int)floorf(xmin), 0); wy0 = max((int)floorf(ymin), 0);
+          const int wx1 = min((int)floorf(xmax), rcols - 2) + 1, wy1 = min((int)floorf(ymax), rrows - 2) + 1;
+          const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
+          if (ww > 0 && wh > 0 && ww <= WIN_PITCH && wh <= WIN_ROWS) {
+            use_win = true;
+            win_fill(img_ref + (size_t)wy0 * rcols + wx0, rcols, wh, cl, win);
+          }
+        }
+      }
       // Two passes so that the 7 x 2 loads of a lane are in flight together (one memory latency instead of seven):
       // first every sample's address and weights -- a sample that is not interpolated reads offset 0 of the level,
       // which is always valid memory -- then the arithmetic of vk::interpolateMat_8u (I/vision.h:19-36) in its order.
       float w00[7], w01[7], w10[7], w11[7];
       unsigned r0[7], r1[7];
       bool ok[7];
+      int woff[7];
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
         const int k = cl + 16 * j;
@@ -507,10 +595,25 @@ __global__ __launch_bounds__(256) void df_search_kernel(
         w01[j] = (1.0f - subpix_x) * subpix_y;
         w10[j] = subpix_x * (1.0f - subpix_y);
         w11[j] = 1.0f - w00[j] - w01[j] - w10[j];
-        const uint8_t* ptr = img_ref + y * rcols + x;
-        typedef unsigned short __attribute__((aligned(1))) u16u;
-        r0[j] = *reinterpret_cast<const u16u*>(ptr);              // the two neighbours of a row in one unaligned load
-        r1[j] = *reinterpret_cast<const u16u*>(ptr + rcols);
+        woff[j] = ok[j] ? (y - wy0) * WIN_PITCH + (x - wx0) : 0;
+        if (!use_win) {
+          const uint8_t* ptr = img_ref + y * rcols + x;
+          typedef unsigned short __attribute__((aligned(1))) u16u;
+          r0[j] = *reinterpret_cast<const u16u*>(ptr);            // the two neighbours of a row in one unaligned load
+          r1[j] = *reinterpret_cast<const u16u*>(ptr + rcols);
+        }
+      }
+      if (use_win) {
+        // the window of this seed was written by its own 16 lanes: order the LDS writes before the gathers
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      }
+      if (use_win) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          const uint8_t* q = win + woff[j];
+          r0[j] = (unsigned)q[0] | ((unsigned)q[1] << 8);
+          r1[j] = (unsigned)q[WIN_PITCH] | ((unsigned)q[WIN_PITCH + 1] << 8);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
@@ -602,9 +705,25 @@ __global__ __launch_bounds__(256) void df_search_kernel(
       const bool inframe = is_in_frame_level(cam, pxi_x, pxi_y, 8, search_level);
       int score = 0x7fffffff;
       const bool eval = in_range && !dup && inframe;
+      // bounding box of the chunk's candidate patches (uniform within the 16 lanes): if it fits, one window fill
+      // replaces the 16 row loads of every candidate
+      const int bx0 = row16_min(eval ? pxi_x : 0x7fffffff), bx1 = row16_max(eval ? pxi_x : -0x7fffffff);
+      const int by0 = row16_min(eval ? pxi_y : 0x7fffffff), by1 = row16_max(eval ? pxi_y : -0x7fffffff);
+      const bool any_eval = bx1 >= bx0;
+      const bool fits = any_eval && bx1 - bx0 + 8 <= WIN_PITCH && by1 - by0 + 8 <= WIN_ROWS;
+      uint8_t* win = s_win + slot * WIN_BYTES;
+      if (chunk0 > 0) {                                    // wave-uniform: the window of the previous chunk has been read
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+      if (fits) win_fill(cur_img + (size_t)(by0 - 4) * ccols + (bx0 - 4), ccols, by1 - by0 + 8, cl, win);
       if (eval) {
-        const uint8_t* cp = cur_img + (pxi_y - 4) * ccols + (pxi_x - 4);
-        score = zmssd_8x8(cp, ccols, patch_words, sumA, sumAA);
+        if (fits) {
+          score = zmssd_8x8_win(win + (pxi_y - by0) * WIN_PITCH, pxi_x - bx0, patch_words, sumA, sumAA);
+        } else {
+          const uint8_t* cp = cur_img + (pxi_y - 4) * ccols + (pxi_x - 4);
+          score = zmssd_8x8(cp, ccols, patch_words, sumA, sumAA);
+        }
       }
       n_zmssd += __popcll((__ballot(eval) >> gbase) & 0xffffull);
       if (eval && score < ZMSSD_THRESHOLD) {
