@@ -332,10 +332,12 @@ def test_update_seed_and_tau_batches(ctx):
     x = (mu + rng.normal(size=n).astype(np.float32) * np.sqrt(tau2)).astype(np.float32)
     tau2[7] = -1.0                                # NaN guard: seed untouched
     ga, gb, gmu, gs2 = hip.update_seed_batch(ctx, x, tau2, a, b, mu, zr, s2)
-    for i in list(range(0, 2000)) + [7]:
-        want = orc.update_seed(float(x[i]), float(tau2[i]), [a[i], b[i], mu[i], zr[i], s2[i]])
-        got = np.array([ga[i], gb[i], gmu[i], zr[i], gs2[i]], dtype=np.float32)
-        np.testing.assert_allclose(got, want, rtol=3e-6, atol=0)      # exp() differs by ulps between libms
+    m = 5000
+    want = np.array([orc.update_seed(float(x[i]), float(tau2[i]), [a[i], b[i], mu[i], zr[i], s2[i]]) for i in range(m)], dtype=np.float32)
+    got = np.stack([ga[:m], gb[:m], gmu[:m], zr[:m], gs2[:m]], axis=1)
+    np.testing.assert_allclose(got, want, rtol=3e-6, atol=0)           # the bound if exp() differed by an ulp between the libms ...
+    same = (got.view(np.uint32) == want.view(np.uint32)).all(axis=1)
+    assert same.mean() >= 0.999, same.mean()                           # ... in fact bit-identical (20 000 of 20 000 when probed)
     assert ga[7] == a[7] and gs2[7] == s2[7]
     # known-answer vector of the reference
     ka, kb, kmu, ks2 = hip.update_seed_batch(ctx, [0.52], [0.01], [10.0], [10.0], [0.5], [1.0], [np.float32(1.0) / 36])
@@ -347,7 +349,7 @@ def test_update_seed_and_tau_batches(ctx):
     ang = 2.0 * np.arctan(1.0 / (2.0 * 500.0))
     tau = hip.compute_tau_batch(ctx, T, f, z, ang)
     want = np.array([orc.compute_tau(T, f[i], z[i], ang) for i in range(4096)])
-    np.testing.assert_allclose(tau, want, rtol=1e-9)
+    np.testing.assert_allclose(tau, want, rtol=1e-11)                  # acos / sin differ by ulps between the libms (observed 4e-13)
 
 
 def test_depth_filter_update_parity(ctx):
