@@ -1439,9 +1439,19 @@ struct svo_hip_sia {
   bool profiling = false;
   std::vector<hipEvent_t> ev_res, ev_pre;     // start/stop pairs
   size_t ev_res_used = 0, ev_pre_used = 0;
+  // svo_hip_sia_run_sharded with graph replay: one instantiated graph per pyramid level (level_begin + n_iter x
+  // {accumulate, all-reduce, solve_update}), valid for the configuration in graph_key
+  bool sharded_graph = false;
+  hipGraphExec_t level_graph[SVO_HIP_MAX_LEVELS] = {nullptr};
+  struct { const void* comm; int n_slots, n_iter, early_stop, max_level, min_level, rank, world; double eps; const void *ref, *cur, *reduce; } graph_key = {};
 };
 
 namespace {
+
+void drop_level_graphs(svo_hip_sia* s) {
+  for (int l = 0; l < SVO_HIP_MAX_LEVELS; ++l)
+    if (s->level_graph[l]) { (void)hipGraphExecDestroy(s->level_graph[l]); s->level_graph[l] = nullptr; }
+}
 
 template <typename T>
 int dev_alloc(svo_hip_ctx* ctx, T** p, size_t count) {
@@ -1649,6 +1659,7 @@ int svo_hip_sia_destroy(svo_hip_sia* s) {
   if (!s) return SVO_HIP_ERR_INVALID;
   svo_hip_ctx* ctx = s->ctx;
   (void)hipStreamSynchronize(ctx->stream);
+  drop_level_graphs(s);
   void* ptrs[] = {s->fc, s->st, s->px, s->f, s->pos, s->has_point, s->visible, s->ref_cache, s->dxc, s->dyc,
                   s->sxyz, s->xyz4, s->tile_h, s->wmem, s->partial, s->reduce_own, s->n_pre_count};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1848,23 +1859,65 @@ int svo_hip_sia_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) 
 // no host round trip), then every rank runs the identical solve on identical sums -- identical decisions, no further
 // exchange.  Finished frames contribute zeros (the kernels skip them), so the fixed launch sequence keeps the
 // reference's early-exit semantics.
+static int sharded_level(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, const svo_hip_sia_params* prm, int level) {
+  int rc = svo_hip_sia_level_begin(s, level);
+  if (rc != SVO_HIP_OK) return rc;
+  for (int it = 0; it < prm->n_iter; ++it) {
+    if ((rc = svo_hip_sia_accumulate(s)) != SVO_HIP_OK) return rc;
+    if ((rc = svo_comm_all_reduce_sum_f64(comm, s->reduce, (size_t)n_slots * SVO_HIP_REDUCE_DOUBLES)) != SVO_HIP_OK) return rc;
+    if ((rc = svo_hip_sia_solve_update(s)) != SVO_HIP_OK) return rc;
+  }
+  return SVO_HIP_OK;
+}
+
 int svo_hip_sia_run_sharded(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, const svo_hip_sia_params* prm) {
   if (!s || !comm || !prm) return SVO_HIP_ERR_INVALID;
-  int rank = 0, world = 1;
-  svo_hip_comm_info(comm, &rank, &world, nullptr);
+  svo_hip_ctx* ctx = s->ctx;
+  int rank = 0, world = 1, kind = 0;
+  svo_hip_comm_info(comm, &rank, &world, &kind);
   int rc = svo_hip_sia_set_shard(s, rank, world);
   if (rc != SVO_HIP_OK) return rc;
   rc = svo_hip_sia_begin(s, n_slots, prm);
   if (rc != SVO_HIP_OK) return rc;
+  // Graph replay (opt-in, RCCL transport only: the host-staged transport blocks the host and cannot be captured): the
+  // launch sequence of a level does not depend on the data -- finished frames are skipped inside the kernels -- so it
+  // is captured once per configuration and replayed; what it saves is the host's launch time (3 kernels + 1 collective
+  // per Gauss-Newton step), not device time.
+  const bool graph = s->sharded_graph && kind == 0 && !s->profiling;
+  if (graph) {
+    const decltype(s->graph_key) key = {comm, n_slots, prm->n_iter, prm->early_stop, prm->max_level, prm->min_level, rank, world, prm->eps,
+                                        s->ref, s->cur, s->reduce};
+    if (memcmp(&key, &s->graph_key, sizeof(key)) != 0) { drop_level_graphs(s); s->graph_key = key; }
+  }
   for (int level = prm->max_level; level >= prm->min_level; --level) {
-    if ((rc = svo_hip_sia_level_begin(s, level)) != SVO_HIP_OK) return rc;
-    for (int it = 0; it < prm->n_iter; ++it) {
-      if ((rc = svo_hip_sia_accumulate(s)) != SVO_HIP_OK) return rc;
-      if ((rc = svo_comm_all_reduce_sum_f64(comm, s->reduce, (size_t)n_slots * SVO_HIP_REDUCE_DOUBLES)) != SVO_HIP_OK) return rc;
-      if ((rc = svo_hip_sia_solve_update(s)) != SVO_HIP_OK) return rc;
+    if (!graph) {
+      if ((rc = sharded_level(s, comm, n_slots, prm, level)) != SVO_HIP_OK) return rc;
+      continue;
     }
+    if (!s->level_graph[level]) {
+      hipGraph_t g = nullptr;
+      SVO_CHECK_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+      rc = sharded_level(s, comm, n_slots, prm, level);
+      const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+      if (rc != SVO_HIP_OK || e != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc != SVO_HIP_OK ? rc : svo_fail(ctx, SVO_HIP_ERR_DEVICE, "hipStreamEndCapture", hipGetErrorString(e));
+      }
+      const hipError_t ei = hipGraphInstantiate(&s->level_graph[level], g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (ei != hipSuccess) { s->level_graph[level] = nullptr; return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "hipGraphInstantiate", hipGetErrorString(ei)); }
+    }
+    s->level = level;
+    SVO_CHECK_HIP(ctx, hipGraphLaunch(s->level_graph[level], ctx->stream));
   }
   return svo_hip_sia_finish(s);
+}
+
+int svo_hip_sia_set_sharded_graph(svo_hip_sia* s, int enable) {
+  if (!s) return SVO_HIP_ERR_INVALID;
+  s->sharded_graph = enable != 0;
+  if (!enable) drop_level_graphs(s);
+  return SVO_HIP_OK;
 }
 
 #ifdef SVO_STAMPS

@@ -408,7 +408,9 @@ class Comm:
             self.h = C.c_void_p()
 
 
-def sia_run_sharded(sia, comm: Comm, n_slots: int, prm):
+def sia_run_sharded(sia, comm: Comm, n_slots: int, prm, graph: Optional[bool] = None):
+    if graph is not None:
+        sia.ctx.check(sia.ctx.lib.svo_hip_sia_set_sharded_graph(sia.h, 1 if graph else 0), "sia_set_sharded_graph")
     sia.ctx.check(sia.ctx.lib.svo_hip_sia_run_sharded(sia.h, comm.h, n_slots, C.byref(prm)), "sia_run_sharded")
 
 

@@ -61,7 +61,8 @@ def parse_args():
                     help="allreduce: patch-sharded solve through the C-ABI (svo_hip_sia_run_sharded, RCCL called by libsvo_hip.so); "
                          "allreduce-torch: the same exchange driven from Python through torch.distributed (android_svo_amd/dist.py)")
     ap.add_argument("--early-stop", action="store_true", help="reference GN exits instead of fixed work")
-    ap.add_argument("--graph", action="store_true", help="--mode allreduce: replay the per-level loops from HIP graphs")
+    ap.add_argument("--graph", action="store_true",
+                    help="--mode allreduce: svo_hip_sia_set_sharded_graph (one HIP graph per level inside the library); --mode allreduce-torch: torch graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames-per-thread", type=int, default=16)
     ap.add_argument("--latency-probe", action="store_true",
@@ -291,7 +292,7 @@ def main():
             sia.run(n_slots, prm)
             return
         if comm is not None:
-            hip.sia_run_sharded(sia, comm, n_slots, prm)
+            hip.sia_run_sharded(sia, comm, n_slots, prm, graph=bool(args.graph))
             return
         if graphed is not None:
             graphed.run()

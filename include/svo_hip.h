@@ -169,6 +169,10 @@ int svo_hip_comm_info(const svo_hip_comm* comm, int* rank, int* world, int* kind
  * Every rank must hold the same features, poses and pyramids and call this with the same arguments; all ranks end
  * with the same result (svo_hip_sia_download). */
 int svo_hip_sia_run_sharded(svo_hip_sia* sia, svo_hip_comm* comm, int n_slots, const svo_hip_sia_params* prm);
+/* Opt-in: replay the per-level launch sequence of svo_hip_sia_run_sharded (level_begin + n_iter x {accumulate,
+ * all-reduce, solve_update}) from one HIP graph per pyramid level, captured at the first call of a configuration (RCCL
+ * transport only).  Saves host launch time, not device time. */
+int svo_hip_sia_set_sharded_graph(svo_hip_sia* sia, int enable);
 
 /* run(): the whole coarse-to-fine solve for slots [0, n_slots), enqueued on the stream with no
  * host round trip.  Poses restart from the uploaded initial poses on every call. */

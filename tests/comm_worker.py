@@ -47,7 +47,9 @@ def main():
         res = {}
         for tag, es in (("early", True), ("fixed", False)):
             prm = sia.params(max_level=4, min_level=0, n_iter=30 if es else 6, eps=1e-6, early_stop=es)
-            hip.sia_run_sharded(sia, comm, len(fps), prm)
+            hip.sia_run_sharded(sia, comm, len(fps), prm, graph=(transport == "rccl" and os.environ.get("SVO_TEST_GRAPH") == "1"))
+            if transport == "rccl" and os.environ.get("SVO_TEST_GRAPH") == "1":
+                hip.sia_run_sharded(sia, comm, len(fps), prm)       # a second solve replays the instantiated graphs
             r = sia.download_all(len(fps))
             res[tag + "_T"] = np.array([list(x.T_cur_w) for x in r])
             res[tag + "_n"] = np.array([x.n_tracked for x in r])

@@ -36,7 +36,7 @@ def _run_ranks(what, transport, world, tmp_path):
     for p in procs:
         so, se = p.communicate(timeout=300)
         assert p.returncode == 0, se.decode()[-3000:]
-    return [np.load(o) for o in outs]
+    return [dict(np.load(o)) for o in outs]          # materialised: a later run may reuse the file names
 
 
 def _check_sia(results):
@@ -67,6 +67,18 @@ def test_sharded_sparse_img_align_three_ranks_on_one_gpu(tmp_path):
 
 def test_sharded_sparse_img_align_rccl_one_rank(tmp_path):
     _check_sia(_run_ranks("sia", "rccl", 1, tmp_path))
+
+
+def test_sharded_sparse_img_align_rccl_graph_replay(tmp_path, monkeypatch):
+    """svo_hip_sia_set_sharded_graph: the per-level launch sequence (kernels + ncclAllReduce) captured once and replayed:
+    the same bits as the eager sequence."""
+    eager = _run_ranks("sia", "rccl", 1, tmp_path)
+    monkeypatch.setenv("SVO_TEST_GRAPH", "1")
+    graph = _run_ranks("sia", "rccl", 1, tmp_path)
+    _check_sia(graph)
+    for tag in ("early", "fixed"):
+        np.testing.assert_array_equal(graph[0][tag + "_T"], eager[0][tag + "_T"])
+        np.testing.assert_array_equal(graph[0][tag + "_H"], eager[0][tag + "_H"])
 
 
 def test_config_c3_shape_two_ranks_on_one_gpu(tmp_path):
