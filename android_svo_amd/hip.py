@@ -469,6 +469,44 @@ class SeedBatch:
             d.free()
 
 
+class DeviceView:
+    """A typed window into somebody else's device allocation (never freed through the view)."""
+
+    def __init__(self, ctx: Context, ptr: int, shape, dtype):
+        self.ctx, self.ptr, self.shape, self.dtype = ctx, ptr, tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.ctx.check(self.ctx.lib.svo_hip_memcpy_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+                                                       C.c_size_t(self.nbytes)), "d2h")
+        return out
+
+    def upload(self, arr: np.ndarray):
+        a = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert a.nbytes == self.nbytes
+        self.ctx.check(self.ctx.lib.svo_hip_memcpy_h2d(self.ctx.h, C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p),
+                                                       C.c_size_t(self.nbytes)), "h2d")
+        self.ctx.sync()
+
+    def free(self):
+        pass
+
+
+def pack_seed_state(sb: "SeedBatch"):
+    """Move a, b, mu, sigma2 of a SeedBatch into ONE device block (so that a benchmark can restore the state of all seeds
+    with one device-to-device copy); returns (block, pristine copy of the block)."""
+    ctx, n = sb.ctx, sb.n
+    block = ctx.empty((4, n), np.float32)
+    host = np.stack([sb.a.download(), sb.b.download(), sb.mu.download(), sb.sigma2.download()])
+    block.upload(host)
+    for k, name in enumerate(("a", "b", "mu", "sigma2")):
+        getattr(sb, name).free()
+        setattr(sb, name, DeviceView(ctx, block.ptr + 4 * n * k, (n,), np.float32))
+    pristine = ctx.to_device(host)
+    return block, pristine
+
+
 def depth_filter_params(n_pyr_levels=3, align_max_iter=10, max_epi_search_steps=1000, conv_thresh=100.0) -> CDfParams:
     return CDfParams(n_pyr_levels, align_max_iter, max_epi_search_steps, conv_thresh)
 

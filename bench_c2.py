@@ -76,11 +76,11 @@ def main():
     kf.upload(0, sc.ref_pyr)
     cf.upload(0, sc.cur_pyr)
     sb = hip.SeedBatch(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, sc.sigma2)
-    st0 = [ctx.to_device(v) for v in (sc.a, sc.b, sc.mu, sc.sigma2)]
+    state, state0 = hip.pack_seed_state(sb)          # a | b | mu | sigma2 in one block: one copy restores all seeds
 
     def run_df():
-        for dst, src in zip((sb.a, sb.b, sb.mu, sb.sigma2), st0):        # same seed state every step
-            ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(dst.ptr), C.c_void_p(src.ptr), C.c_size_t(dst.nbytes)), "d2d")
+        # same seed state every step (one 16 B/seed device-to-device copy), then the pass
+        ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(state.ptr), C.c_void_p(state0.ptr), C.c_size_t(state.nbytes)), "d2d")
         hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb)
     t_df = timed(ctx, run_df, args.steps, args.warmup)
     nz, na, st = sb.n_zmssd.download(), sb.n_align.download(), sb.status.download()

@@ -66,7 +66,7 @@ def main():
     # seeds that have already been observed a few times (small variance) so that a visible share converges this pass
     sigma2 = (sc.sigma2[sl] * np.float32(args.sigma_scale)).astype(np.float32)
     sb = hip.SeedBatch(ctx, sc.px[sl], sc.f[sl], sc.level[sl], sc.a[sl], sc.b[sl], sc.mu[sl], sc.z_range[sl], sigma2)
-    st0 = [ctx.to_device(np.ascontiguousarray(v)) for v in (sc.a[sl], sc.b[sl], sc.mu[sl], sigma2)]
+    state, state0 = hip.pack_seed_state(sb)          # a | b | mu | sigma2 in one block: one copy restores all seeds
     n_conv_total = 0
     comm = None
     rec_all = cnt_all = None
@@ -81,8 +81,8 @@ def main():
 
     def step():
         nonlocal n_conv_total
-        for dst, src in zip((sb.a, sb.b, sb.mu, sb.sigma2), st0):        # same seed state every step
-            ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(dst.ptr), C.c_void_p(src.ptr), C.c_size_t(dst.nbytes)), "d2d")
+        # same seed state every step
+        ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(state.ptr), C.c_void_p(state0.ptr), C.c_size_t(state.nbytes)), "d2d")
         hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb)
         if comm is not None:
             # packed on the GPU, two fixed-size RCCL all-gathers enqueued by libsvo_hip.so, no host round trip

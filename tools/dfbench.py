@@ -6,10 +6,9 @@ sc = seedsynth.make_seed_case(n_seeds=100000, seed=9)
 kf = hip.Pyramid(ctx, 640, 480, 5, 1); cf = hip.Pyramid(ctx, 640, 480, 5, 1)
 kf.upload(0, sc.ref_pyr); cf.upload(0, sc.cur_pyr)
 sb = hip.SeedBatch(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, sc.sigma2)
-st0 = [ctx.to_device(v) for v in (sc.a, sc.b, sc.mu, sc.sigma2)]
+state, state0 = hip.pack_seed_state(sb)
 def run():
-    for dst, src in zip((sb.a, sb.b, sb.mu, sb.sigma2), st0):
-        ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(dst.ptr), C.c_void_p(src.ptr), C.c_size_t(dst.nbytes)), "d2d")
+    ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(state.ptr), C.c_void_p(state0.ptr), C.c_size_t(state.nbytes)), "d2d")
     hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb)
 for _ in range(3): run()
 ctx.sync(); t0=time.perf_counter()
