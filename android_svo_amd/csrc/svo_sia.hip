@@ -238,8 +238,8 @@ __global__ __launch_bounds__(256) void sia_precompute_kernel(
     const float v_ref = (float)(px[2 * fo + 1] * scale);
     const int u_ref_i = (int)floorf(u_ref);
     const int v_ref_i = (int)floorf(v_ref);
-    valid = has_point[fo] && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= g.cols ||
-                               v_ref_i + border >= g.rows);
+    valid = has_point[fo] && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i >= g.cols - border ||
+                               v_ref_i >= g.rows - border);
     const float subpix_u = u_ref - u_ref_i;
     const float subpix_v = v_ref - v_ref_i;
     w_tl = (float)((1.0 - subpix_u) * (1.0 - subpix_v));
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void sia_residual_kernel(
         // NaN projections compare false everywhere in the reference and would read out of bounds
         // there; here they are outside the image.
         ok = (u_cur_i >= 0 && v_cur_i >= 0 && u_cur_i - border >= 0 && v_cur_i - border >= 0 &&
-              u_cur_i + border < g.cols && v_cur_i + border < g.rows) && u_cur == u_cur && v_cur == v_cur;
+              u_cur_i < g.cols - border && v_cur_i < g.rows - border) && u_cur == u_cur && v_cur == v_cur;   // (no u_cur_i + border: the conversion saturates)
         const float subpix_u = u_cur - u_cur_i;
         const float subpix_v = v_cur - v_cur_i;
         w_tl = (float)((1.0 - subpix_u) * (1.0 - subpix_v));
@@ -645,6 +645,32 @@ struct LeanCam {
   const double* d;      // null: pinhole without distortion
 };
 
+// x/z and y/z for the projection of the hot loop.  The compiler's expansion of an fp64 division is v_div_scale (both
+// operands), v_rcp_f64, two Newton steps on the reciprocal, the quotient with one residual correction (v_div_fmas) and
+// v_div_fixup for the special operands; the scaling only acts when an exponent is near the end of the range.  Here
+// the refined reciprocal is formed ONCE for both quotients and the same residual correction is applied: for a
+// denominator whose exponent is in the middle 1800 binades these are, operation for operation, the roundings of the
+// expansion (bit-identical quotients for every numerator whose quotient is a normal number; a quotient that is
+// subnormal, overflows or is NaN is outside every image either way).  Any other denominator in the wave takes
+// the two plain divisions.
+SVO_DEV void div2_by(double x, double y, double z, double& qx, double& qy) {
+  const unsigned ez = (unsigned)__double2hiint(z) & 0x7ff00000u;                  // biased exponent << 20
+  const bool mid = ez - (123u << 20) < (1800u << 20);                             // 2^-900 <= |z| < 2^900 (no 0, inf, NaN, subnormal)
+  if (__ballot(!mid) == 0ull) {                                                   // wave-uniform
+    double r = __builtin_amdgcn_rcp(z);
+    double e = __builtin_fma(-z, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-z, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q0 = x * r, p0 = y * r;
+    qx = __builtin_fma(__builtin_fma(-z, q0, x), r, q0);
+    qy = __builtin_fma(__builtin_fma(-z, p0, y), r, p0);
+  } else {
+    qx = x / z;
+    qy = y / z;
+  }
+}
+
 // projection of one patch into the current level image (:220-236); the weights come back halved (see the caller)
 SVO_DEV LppGeom lpp_project(const double* T, const LeanCam& cam, const double4& X, bool visible, float scale, int cols,
                             int rows, int stride) {
@@ -655,7 +681,8 @@ SVO_DEV LppGeom lpp_project(const double* T, const LeanCam& cam, const double4& 
     const double xyz_ref[3] = {X.x, X.y, X.z};
     double xyz_cur[3], pxd[2];
     se3_act(T, xyz_ref, xyz_cur);
-    const double un = xyz_cur[0] / xyz_cur[2], vn = xyz_cur[1] / xyz_cur[2];
+    double un, vn;
+    div2_by(xyz_cur[0], xyz_cur[1], xyz_cur[2], un, vn);
     if (cam.d == nullptr) {
       pxd[0] = cam.fx * un + cam.cx;
       pxd[1] = cam.fy * vn + cam.cy;
@@ -672,12 +699,16 @@ SVO_DEV LppGeom lpp_project(const double* T, const LeanCam& cam, const double4& 
     const int u_cur_i = (int)floorf(u_cur);
     const int v_cur_i = (int)floorf(v_cur);
     g.ok = (u_cur_i >= 0 && v_cur_i >= 0 && u_cur_i - border >= 0 && v_cur_i - border >= 0 &&
-            u_cur_i + border < cols && v_cur_i + border < rows) && u_cur == u_cur && v_cur == v_cur;
+            u_cur_i < cols - border && v_cur_i < rows - border) && u_cur == u_cur && v_cur == v_cur;       // (no u_cur_i + border: the conversion saturates)
     const float subpix_u = u_cur - u_cur_i;
     const float subpix_v = v_cur - v_cur_i;
-    g.w_tl = 0.5f * (float)((1.0 - subpix_u) * (1.0 - subpix_v));
-    g.w_tr = 0.5f * (float)(subpix_u * (1.0 - subpix_v));
-    g.w_bl = 0.5f * (float)((1.0 - subpix_u) * subpix_v);
+    // (float)((1.0 - su) * (1.0 - sv)) of the reference, in f32: inside the image u_cur >= 3, so su = u_cur - floor(u_cur)
+    // is a multiple of 2^-22 below 1, 1 - su is exact in f32 (<= 22 significant bits) and the product of two such
+    // numbers (<= 44 bits, exact in f64) is rounded to f32 once on either path.  Outside the image the weights are not used.
+    const float ou = 1.0f - subpix_u, ov = 1.0f - subpix_v;
+    g.w_tl = 0.5f * (ou * ov);
+    g.w_tr = 0.5f * (subpix_u * ov);
+    g.w_bl = 0.5f * (ou * subpix_v);
     g.w_br = 0.5f * (subpix_u * subpix_v);
     g.off = g.ok ? (v_cur_i - 2) * stride + (u_cur_i - 2) : 0;
   }
@@ -711,6 +742,56 @@ struct FusedPlan {
 // phase between its barriers the other one has the SIMDs to itself (used when a launch holds at least two pairs per
 // CU).
 SVO_DEV int wave_of_thread() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+// Cold parts of the fused kernel, kept out of line: they run a handful of times per frame pair, and inlined their
+// register demand (H[36] + m[6][6] in registers, the library sine / cosine) shapes the allocation of the whole kernel.
+//
+// H changed: lane 0 factors it (pivoted LDL^T, I/nlls_solver_impl.hpp:35-99 -> Eigen LDLT), then lanes 0..5 each push
+// one unit vector through the substitution -- six right-hand sides in the time of one -- and keep the columns of H^-1.
+// Every evaluation after that is a 6x6 matrix-vector product on six lanes instead of a serial substitution with six
+// divisions.  Called by a whole wave; the arrays live in LDS.
+__device__ __noinline__ void fused_refactor_cold(const double* s_Hc, double* s_fac, int* s_ftr, int* s_fac_valid, double* s_inv, int lane) {
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane == 0) {
+    double H[36], m[6][6];
+    int tr[6];
+    int kk = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) { H[i * 6 + j] = s_Hc[kk]; H[j * 6 + i] = s_Hc[kk]; ++kk; }
+    ldlt6_factor_reg(H, m, tr);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      s_ftr[i] = tr[i];
+#pragma unroll
+      for (int j = 0; j <= i; ++j) s_fac[i * (i + 1) / 2 + j] = m[i][j];
+    }
+    *s_fac_valid = 1;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane < 6) {
+    double m[6][6], e[6], col[6];
+    int tr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      tr[i] = __builtin_amdgcn_readfirstlane(s_ftr[i]);
+      e[i] = lane == i ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) m[i][j] = s_fac[i * (i + 1) / 2 + j];
+    }
+    ldlt6_substitute_reg(m, tr, e, col);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s_inv[lane * 6 + j] = col[j];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// large update angles (theta^2 > 0.25): the library path of SE3::exp
+__device__ __noinline__ void se3_exp_cold(const double* l, double* out) { se3_exp(l, out); }
 
 template <int NW, int TPW, int CK>
 __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
@@ -746,6 +827,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   __shared__ double s_nres, s_nmeas;             // exact integer counts, carried as doubles
   __shared__ int s_iters[SVO_HIP_MAX_LEVELS];
 #ifdef SVO_STAMPS
+  const long long k_m0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();   // core clock / constant 100 MHz
   __shared__ long long s_stamp[10];
   __shared__ long long s_wst[16];
   if (threadIdx.x < 16) s_wst[threadIdx.x] = 0;
@@ -852,8 +934,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       const float v_ref = pxf[k][1] * scale;
       const int u_ref_i = (int)floorf(u_ref);
       const int v_ref_i = (int)floorf(v_ref);
-      const bool valid = have && (fl[k] & F_HASPOINT) != 0 && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= cols ||
-                                                    v_ref_i + border >= rows);
+      const bool valid = have && (fl[k] & F_HASPOINT) != 0 && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i >= cols - border ||
+                                                    v_ref_i >= rows - border);
       const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
       pre_w[k][0] = (float)((1.0 - su) * (1.0 - sv));
       pre_w[k][1] = (float)(su * (1.0 - sv));
@@ -1102,14 +1184,15 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           asm volatile("" : "+v"(zi));                       // opaque: nothing derived from it is kept in registers across evaluations
           // Jres_ -= J res (:273) with J = dx A + dy B summed over the patch: A sdx + B sdy written out in the
           // normalised coordinates u = x/z, v = y/z; signs and fx/2^L are applied once after the reduction
+          // (this is the kernel's own summation, not an operation order of the reference: fused where it can be)
           const double u = X[k].x * zi, v = X[k].y * zi;
-          const double a = u * sdx + v * sdy;
-          accJ[0] += zi * sdx;
-          accJ[1] += zi * sdy;
-          accJ[2] += zi * a;
-          accJ[3] += v * a + sdy;
-          accJ[4] += u * a + sdx;
-          accJ[5] += v * sdx - u * sdy;
+          const double a = __builtin_fma(u, sdx, v * sdy);
+          accJ[0] = __builtin_fma(zi, sdx, accJ[0]);
+          accJ[1] = __builtin_fma(zi, sdy, accJ[1]);
+          accJ[2] = __builtin_fma(zi, a, accJ[2]);
+          accJ[3] += __builtin_fma(v, a, sdy);
+          accJ[4] += __builtin_fma(u, a, sdx);
+          accJ[5] += __builtin_fma(v, sdx, -(u * sdy));
         }
         // H of the tile = its per-level row minus the patches that are outside the current image now (:76, :226-229).
         // The stored row has the patches that were outside at the previous evaluation already taken out; that set
@@ -1211,29 +1294,48 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
 #ifdef SVO_STAMPS
       const long long t1 = __builtin_amdgcn_s_memtime();
 #endif
+      // Wave 0 runs the serial part between the two barriers, alone on the CU, and a lone wave issues one instruction
+      // every ~5 cycles whatever it is: the serial part is as long as its instruction count.  So everything it needs
+      // that is known already -- what the previous solve left behind -- is asked for BEFORE the first barrier (wave 0
+      // is one of the older waves and gets there early), and everything nobody waits for (counters, chi2, the
+      // rollback copy of the pose) is written AFTER the second one.
+#ifdef SVO_V_NOPRELOAD
       __syncthreads();
+#endif
+      double chi2_old = 0.0, nres_old = 0.0, hc_prev = 0.0;
+      double coef[8], inv_row[6], cur[7];
+      int it = 0, stop_old = 0, iters_l = 0, fac_valid = 0;
+      if (wave == 0) {
+#pragma unroll
+#ifdef SVO_V_CURT
+        for (int i = 0; i < 7; ++i) cur[i] = T[i];
+#else
+        for (int i = 0; i < 7; ++i) cur[i] = s_model[i];        // (= T, which lives in scalar registers that are needed elsewhere by now)
+#endif
+        chi2_old = s_chi2; nres_old = s_nres; hc_prev = s_Hc[lane < 21 ? lane : 0];   // H of the previous evaluation
+        it = s_iter; stop_old = s_stop; iters_l = s_iters[level]; fac_valid = s_fac_valid;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) coef[k] = kExpSeries[k * 4 + (lane & 3)];      // this lane's column of the exp series table
+#pragma unroll
+        for (int j = 0; j < 6; ++j) inv_row[j] = s_inv[(lane < 6 ? lane : 0) * 6 + j];   // lanes 0..5: their row of H^-1
+      }
+#ifndef SVO_V_NOPRELOAD
+      __syncthreads();
+#endif
 #ifdef SVO_STAMPS
       const long long t2 = __builtin_amdgcn_s_memtime();
 #endif
+      double v = 0.0;                       // wave 0, lanes 0..28: sums over the waves
+      double x[6] = {0, 0, 0, 0, 0, 0};
+      double new_chi2 = 0.0;
+      bool rollback = false;
       if (wave == 0) {
-        // the solver state lane 0 needs further down: asked for now, together with the wave partials, so that the
-        // serial part below does not pay one LDS round trip per item
-        double cur[7];
+        {
+          double r[NW];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) cur[i] = s_model[i];
-        const double chi2_old = s_chi2;
-        double coef[8];                      // this lane's column of the exp series table
+          for (int w = 0; w < NW; ++w) r[w] = red[w][lane < 29 ? lane : 28];       // all partials asked for at once
 #pragma unroll
-        for (int k = 0; k < 8; ++k) coef[k] = kExpSeries[k * 4 + (lane & 3)];
-        double inv_row[6];                   // lanes 0..5: their row of H^-1 (re-read below if H changed)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) inv_row[j] = s_inv[(lane < 6 ? lane : 0) * 6 + j];
-        const int it = s_iter, stop_old = s_stop, iters_l = s_iters[level];
-        const double nres_old = s_nres;
-        double v = 0.0;
-        if (lane < 29) {
-#pragma unroll
-          for (int w = 0; w < NW; ++w) v += red[w][lane];
+          for (int w = 0; w < NW; ++w) v += r[w];                                  // the waves in fixed order
         }
         // H_ / Jres_ of the last evaluation are reported at the end: carried in a register, or -- by the register-bound
         // shapes, which have the LDS to spare -- kept in LDS
@@ -1242,64 +1344,20 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         // H is the sum of the per-level tile rows minus the patches outside the image at this evaluation: as long as
         // that set does not change it is bit for bit the H of the previous evaluation, and what was derived from it
         // is reused (a deterministic function of H, so the result is the same number)
-        bool h_same = true;
-        if (lane < 21) {
-          h_same = __double_as_longlong(v) == __double_as_longlong(s_Hc[lane]);
-          s_Hc[lane] = v;
-        }
-        const bool reuse = s_fac_valid != 0 && __ballot(!h_same) == 0ull;      // wave-uniform
-        // lanes 21..28 hold Jres, chi2 and the number of measurements: wave-uniform copies, no trip through LDS
+        const bool h_same = lane >= 21 || __double_as_longlong(v) == __double_as_longlong(hc_prev);
+        const bool reuse = fac_valid != 0 && __ballot(!h_same) == 0ull;            // wave-uniform
+        // lanes 21..26 hold Jres: wave-uniform copies, no trip through LDS
         double Jres[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) Jres[i] = readlane_f64(v, 21 + i);
-        const double chi2_sum = readlane_f64(v, 27);
-        const double n_meas_d = readlane_f64(v, 28);
 #ifdef SVO_STAMPS
         const long long q0 = __builtin_amdgcn_s_memtime();
         if (lane == 0) s_stamp[5] += q0 - t2;
 #endif
         if (!reuse) {
-          // H changed: lane 0 factors it (pivoted LDL^T, I/nlls_solver_impl.hpp:35-99 -> Eigen LDLT), then lanes 0..5
-          // each push one unit vector through the substitution -- six right-hand sides in the time of one -- and keep
-          // the columns of H^-1.  Every evaluation after that is a 6x6 matrix-vector product on six lanes instead of a
-          // serial substitution with six divisions.
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          if (lane == 0) {
-            double H[36], m[6][6];
-            int tr[6];
-            int kk = 0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-              for (int j = i; j < 6; ++j) { H[i * 6 + j] = s_Hc[kk]; H[j * 6 + i] = s_Hc[kk]; ++kk; }
-            ldlt6_factor_reg(H, m, tr);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-              s_ftr[i] = tr[i];
-#pragma unroll
-              for (int j = 0; j <= i; ++j) s_fac[i * (i + 1) / 2 + j] = m[i][j];
-            }
-            s_fac_valid = 1;
-          }
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          if (lane < 6) {
-            double m[6][6], e[6], col[6];
-            int tr[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-              tr[i] = __builtin_amdgcn_readfirstlane(s_ftr[i]);
-              e[i] = lane == i ? 1.0 : 0.0;
-#pragma unroll
-              for (int j = 0; j <= i; ++j) m[i][j] = s_fac[i * (i + 1) / 2 + j];
-            }
-            ldlt6_substitute_reg(m, tr, e, col);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) s_inv[lane * 6 + j] = col[j];
-          }
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          // H changed: H^-1 is formed again (cold, out of line)
+          if (lane < 21) s_Hc[lane] = v;
+          fused_refactor_cold(s_Hc, s_fac, s_ftr, &s_fac_valid, s_inv, lane);
 #pragma unroll
           for (int j = 0; j < 6; ++j) inv_row[j] = s_inv[(lane < 6 ? lane : 0) * 6 + j];
         }
@@ -1307,7 +1365,6 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         double xi = inv_row[0] * Jres[0];
 #pragma unroll
         for (int j = 1; j < 6; ++j) xi += inv_row[j] * Jres[j];
-        double x[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) x[i] = readlane_f64(xi, i);
         // the four series of exp(-x) on lanes 0..3 (theta^2 is the same for x and -x), collected wave-uniform
@@ -1318,20 +1375,20 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         const long long q1 = __builtin_amdgcn_s_memtime();
         if (lane == 0) s_stamp[3] += q1 - q0;
 #endif
+        // solve()/update() of S/sparse_img_align.cpp:291-308 inside the loop of I/nlls_solver_impl.hpp:35-99
+        const bool stop_now = stop_old != 0 || x[0] != x[0];                       // NaN -> stop_ (:52-59)
+        bool worse = false;
+        if (prm.early_stop) {                                                      // the reference's exits need chi2 now
+          new_chi2 = (double)((float)readlane_f64(v, 27) / (float)readlane_f64(v, 28));   // (:285)
+          worse = it > 0 && new_chi2 > chi2_old;
+        }
+        rollback = worse || stop_now;                                              // wave-uniform
         if (lane == 0) {
-          // solve()/update() of S/sparse_img_align.cpp:291-308 inside the loop of I/nlls_solver_impl.hpp:35-99
-          // the counts are exact integers (multiples of 16) carried as doubles: no 64-bit integer conversions here
-          const double new_chi2 = (double)((float)chi2_sum / (float)n_meas_d);   // (:285)
-          s_nmeas = n_meas_d;
-          s_nres = nres_old + n_meas_d * 0.0625;
-          s_iters[level] = iters_l + 1;
+          if (rollback) {
 #pragma unroll
-          for (int i = 0; i < 6; ++i) s_x[i] = x[i];
-          const bool stop_now = stop_old != 0 || x[0] != x[0];                   // NaN -> stop_ (:52-59)
-          if (stop_now) s_stop = 1;
-          if ((prm.early_stop && it > 0 && new_chi2 > chi2_old) || stop_now) {
-            for (int i = 0; i < 7; ++i) s_model[i] = s_old[i];                   // rollback (:72)
+            for (int i = 0; i < 7; ++i) s_model[i] = s_old[i];                     // rollback (:72)
             s_done = 1;
+            if (stop_now) s_stop = 1;
           } else {
             double mx[6], dT[7], nm[7];
 #pragma unroll
@@ -1340,32 +1397,52 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
             const long long q2 = __builtin_amdgcn_s_memtime();
 #endif
             if (zt <= 0.25) se3_exp_small_finish(mx, zt, qs_t, pc_t, ps_h, pc_h, dT);
-            else se3_exp(mx, dT);                                                // large angles: the library path
-            se3_mul(cur, dT, nm);                                                // T_new = T_old * exp(-x) (:307)
+            else se3_exp_cold(mx, dT);                                             // large angles: the library path
+            se3_mul(cur, dT, nm);                                                  // T_new = T_old * exp(-x) (:307)
 #ifdef SVO_STAMPS
             const long long q3 = __builtin_amdgcn_s_memtime();
             s_stamp[4] += q3 - q2;
 #endif
 #pragma unroll
-            for (int i = 0; i < 7; ++i) { s_old[i] = cur[i]; s_model[i] = nm[i]; }
-            s_chi2 = new_chi2;
-            if (prm.early_stop) {                                                // :97-98
+            for (int i = 0; i < 7; ++i) s_model[i] = nm[i];
+            bool done = it + 1 >= prm.n_iter;
+            if (prm.early_stop) {                                                  // :97-98
               double mxn = -1;
 #pragma unroll
               for (int i = 0; i < 6; ++i) { double a = fabs(x[i]); if (a > mxn) mxn = a; }
-              if (mxn <= prm.eps) s_done = 1;
+              if (mxn <= prm.eps) done = true;
             }
-            s_iter = it + 1;
-            if (it + 1 >= prm.n_iter) s_done = 1;
-#ifdef SVO_STAMPS
-#endif
+            if (done) s_done = 1;
           }
         }
 #ifdef SVO_STAMPS
         if (lane == 0) s_stamp[8] += __builtin_amdgcn_s_memtime() - t2;
 #endif
       }
+#ifndef SVO_V_NODEFER
       __syncthreads();
+#endif
+      if (wave == 0) {
+        // what only wave 0 itself reads again (and thread 0 at the end): the other waves are already evaluating
+        const double n_meas_d = readlane_f64(v, 28);       // exact integer counts (multiples of 16) carried as doubles
+        if (!prm.early_stop) new_chi2 = (double)((float)readlane_f64(v, 27) / (float)n_meas_d);   // (:285)
+        if (lane == 0) {
+          s_nmeas = n_meas_d;
+          s_nres = nres_old + n_meas_d * 0.0625;
+          s_iters[level] = iters_l + 1;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) s_x[i] = x[i];
+          if (!rollback) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) s_old[i] = cur[i];
+            s_chi2 = new_chi2;
+            s_iter = it + 1;
+          }
+        }
+      }
+#ifdef SVO_V_NODEFER
+      __syncthreads();
+#endif
 #ifdef SVO_STAMPS
       if (threadIdx.x == 64) { const long long t3 = __builtin_amdgcn_s_memtime(); s_stamp[0] += t1 - t0; s_stamp[1] += t2 - t1; s_stamp[2] += t3 - t2; }
       if (lane == 0) { s_wst[wave] += t1 - t0; s_wst[8 + wave] += t2 - t1; }
@@ -1398,6 +1475,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
 #ifdef SVO_STAMPS
       for (int i = 0; i < 16; ++i) s.H[i] = (double)s_wst[i];
       for (int i = 5; i < 10; ++i) s.H[16 + i - 5] = (double)s_stamp[i];
+      s.x[5] = (double)(__builtin_amdgcn_s_memtime() - k_m0) / (double)(__builtin_amdgcn_s_memrealtime() - k_r0) * 0.1;   // GHz over the kernel
       s.x[0] = (double)s_stamp[0]; s.x[1] = (double)s_stamp[1]; s.x[2] = (double)s_stamp[2]; s.x[3] = (double)s_stamp[3]; s.x[4] = (double)s_stamp[4];
 #endif
     }

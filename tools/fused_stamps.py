@@ -11,19 +11,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from android_svo_amd import hip, synth  # noqa: E402
 
-hip.LIB_PATH = os.path.join(ROOT, "build", "libsvo_hip_stamps.so")
+hip.LIB_PATH = os.environ.get("SVO_HIP_STAMPS_LIB") or os.path.join(ROOT, "build", "libsvo_hip_stamps.so")
 ctx = hip.Context(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-fps = [synth.make_frame_pair(seed=12345 + i, n_features=2000) for i in range(4)]
+NS = int(os.environ.get("SVO_STAMPS_SCENES", "4"))
+fps = [synth.make_frame_pair(seed=12345 + i, n_features=2000) for i in range(NS)]
 cam = fps[0].cam
 ref = hip.Pyramid(ctx, cam.width, cam.height, 5, B)
 cur = hip.Pyramid(ctx, cam.width, cam.height, 5, B)
 sia = hip.SparseImgAlign(ctx, B, 2000)
 sia.set_frames(ref, cur)
 for s in range(B):
-    ref.upload(s, fps[s % 4].ref_pyr); cur.upload(s, fps[s % 4].cur_pyr); sia.upload_pair(s, fps[s % 4])
+    ref.upload(s, fps[s % NS].ref_pyr); cur.upload(s, fps[s % NS].cur_pyr); sia.upload_pair(s, fps[s % NS])
 prm = sia.params(early_stop=False)
-for _ in range(2):
+for _ in range(int(os.environ.get("SVO_STAMPS_RUNS", "2"))):
     sia.run(B, prm)
 ctx.sync()
 L = ctx.lib
@@ -35,7 +36,9 @@ rows = []
 for s in range(min(B, 8)):
     L.svo_hip_sia_debug_x(sia.h, s, buf)
     rows.append([buf[0], buf[1], buf[2], buf[3], buf[4]])
+    clk = buf[5]
 rows = np.array(rows) / 150.0
+print("core clock over the kernel (s_memtime / s_memrealtime): %.3f GHz" % clk)
 print("cycles per evaluation: eval+wave-reduce, barrier wait, sum+solve+barrier, of which LDLT, exp+mul")
 print(rows)
 print("per wave: evaluation cycles (waves 0..7), then wait at the first barrier (waves 0..7); frame 0")
@@ -45,3 +48,12 @@ print(np.array(list(buf[14:22])) / 150.0)
 print("wave 0 between the barriers: sum+compare+readlane, (solve), solve->exp, (exp+mul), after exp, whole")
 print(np.array(list(buf[22:26])) / 150.0)
 print("precompute + its barrier, cycles per level (wave 1):", buf[26] / 5.0, " of which interpolation+W store+gradient sums:", buf[23] / 5.0, " H rows:", buf[24] / 5.0)
+if os.environ.get("SVO_STAMPS_COUNT"):
+    vals = []
+    for s in range(B):
+        L.svo_hip_sia_debug_x(sia.h, s, buf)
+        vals.append(buf[24] / 1e6)
+    print("refactorisations per frame pair (stamp[7] / 1e6): mean %.1f min %.1f max %.1f" % (np.mean(vals), np.min(vals), np.max(vals)))
+if os.environ.get("SVO_STAMPS_LEVELS"):
+    L.svo_hip_sia_debug_x(sia.h, 0, buf)
+    print("whole evaluation (eval + barriers + solve) cycles per evaluation by level 0..4 (wave 1, frame 0):", np.array(list(buf[22:27])) / 30.0)
