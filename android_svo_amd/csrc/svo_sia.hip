@@ -675,15 +675,16 @@ SVO_DEV void div2_by(double x, double y, double z, double& qx, double& qy) {
 SVO_DEV LppGeom lpp_project(const double* T, const LeanCam& cam, const double4& X, bool visible, float scale, int cols,
                             int rows, int stride) {
   LppGeom g;
-  g.ok = false; g.w_tl = g.w_tr = g.w_bl = g.w_br = 0.0f; g.off = 0;
-  if (visible) {
+  // (no `if (visible)` around this: a patch that is not visible carries finite coordinates, and a branch costs more
+  // than the work it would skip in the rare wave without a single visible patch)
+  {
     const int border = 3;
     const double xyz_ref[3] = {X.x, X.y, X.z};
     double xyz_cur[3], pxd[2];
     se3_act(T, xyz_ref, xyz_cur);
     double un, vn;
     div2_by(xyz_cur[0], xyz_cur[1], xyz_cur[2], un, vn);
-    if (cam.d == nullptr) {
+    if (__builtin_expect(cam.d == nullptr, 1)) {
       pxd[0] = cam.fx * un + cam.cx;
       pxd[1] = cam.fy * vn + cam.cy;
     } else {
@@ -698,7 +699,7 @@ SVO_DEV LppGeom lpp_project(const double* T, const LeanCam& cam, const double4& 
     const float v_cur = (float)pxd[1] * scale;
     const int u_cur_i = (int)floorf(u_cur);
     const int v_cur_i = (int)floorf(v_cur);
-    g.ok = (u_cur_i >= 0 && v_cur_i >= 0 && u_cur_i - border >= 0 && v_cur_i - border >= 0 &&
+    g.ok = visible && (u_cur_i >= 0 && v_cur_i >= 0 && u_cur_i - border >= 0 && v_cur_i - border >= 0 &&
             u_cur_i < cols - border && v_cur_i < rows - border) && u_cur == u_cur && v_cur == v_cur;       // (no u_cur_i + border: the conversion saturates)
     const float subpix_u = u_cur - u_cur_i;
     const float subpix_v = v_cur - v_cur_i;
@@ -1200,9 +1201,16 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         // correction itself reads memory, and a load inside this loop -- even in a branch that is almost never taken
         // -- makes the compiler drain the loads in flight at every tile.
         const bool out_now = jvalid && !ok;
-        const unsigned long long gone_now = __ballot(out_now);
-        const unsigned long long gone_prev = __ballot((fl[k] & F_GONE) != 0);
-        if (gone_now != gone_prev) {                           // wave-uniform
+        if (!LEAN) {
+          // no branch here (a taken scalar branch costs a wave ~20 cycles, a not-taken one ~10; tools/probes/branch_probe.hip):
+          // the flag is rewritten by every lane and the change goes into a scalar bit
+          const bool was_out = (fl[k] & F_GONE) != 0;
+          gone_changed |= __ballot(out_now != was_out) != 0ull ? 1u << k : 0u;
+          fl[k] = (uint8_t)((fl[k] & ~F_GONE) | (out_now ? F_GONE : 0));
+        }
+        const unsigned long long gone_now = LEAN ? __ballot(out_now) : 0ull;
+        const unsigned long long gone_prev = LEAN ? __ballot((fl[k] & F_GONE) != 0) : 0ull;
+        if (LEAN && gone_now != gone_prev) {                   // wave-uniform
           gone_changed |= 1u << k;
           fl[k] = (uint8_t)((fl[k] & ~F_GONE) | (out_now ? F_GONE : 0));
           if (LEAN) {                                          // register-bound shapes: correct the row right here
