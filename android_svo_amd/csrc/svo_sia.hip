@@ -937,11 +937,15 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       const int v_ref_i = (int)floorf(v_ref);
       const bool valid = have && (fl[k] & F_HASPOINT) != 0 && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i >= cols - border ||
                                                     v_ref_i >= rows - border);
+      // the reference's (float)((1.0 - su) * (1.0 - sv)) in f32 (exact for a position inside the image, see lpp_project),
+      // and HALVED like the weights of the evaluation: every W below is exactly half the reference's interpolated
+      // value -- what the evaluation wants to read -- and a difference of two of them is its 0.5f * (a - b) gradient
       const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
-      pre_w[k][0] = (float)((1.0 - su) * (1.0 - sv));
-      pre_w[k][1] = (float)(su * (1.0 - sv));
-      pre_w[k][2] = (float)((1.0 - su) * sv);
-      pre_w[k][3] = su * sv;
+      const float ou = 1.0f - su, ov = 1.0f - sv;
+      pre_w[k][0] = 0.5f * (ou * ov);
+      pre_w[k][1] = 0.5f * (su * ov);
+      pre_w[k][2] = 0.5f * (ou * sv);
+      pre_w[k][3] = 0.5f * (su * sv);
       pre_off[k] = valid ? (v_ref_i - 3) * stride + (u_ref_i - 3) : 0;   // offset 0: always valid memory
       pre_valid[k] = valid;
       // visible_fts_ is only ever set (:128); the Jacobian block is zero unless recomputed now (:76)
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           for (int c2 = 0; c2 < 6; ++c2)
             W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : interp_at(Fq[k & 1][j], Fq[k & 1][j + 1], c2, w_tl, w_tr, w_bl, w_br);
         if (valid) {
-          // halved (exact), in the order the evaluation reads them: rows 0 and 5 without their corners
+          // in the order the evaluation reads them: rows 0 and 5 without their corners
           float4* dst = Plan::in_lds(k) ? wc + (size_t)((Plan::lds_slot(k) * NW + wave) * 8) * TILE + lane
                         : (k == P_EXTRA && extra_lds) ? wc + (size_t)((CK * NW + wave) * 8) * TILE + lane
                                                       : wmem + ((size_t)b * max_tiles + tile) * 8 * TILE + lane;
@@ -992,7 +996,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int c2 = 0; c2 < 6; ++c2)
-              if (!((j == 0 || j == 5) && (c2 == 0 || c2 == 5))) q[e++] = 0.5f * W[j][c2];
+              if (!((j == 0 || j == 5) && (c2 == 0 || c2 == 5))) q[e++] = W[j][c2];
 #pragma unroll
           for (int c4 = 0; c4 < 8; ++c4) dst[c4 * TILE] = make_float4(q[4 * c4], q[4 * c4 + 1], q[4 * c4 + 2], q[4 * c4 + 3]);
         }
@@ -1000,10 +1004,11 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         for (int y = 0; y < 4; ++y)
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
-            const float dxv = 0.5f * (W[y + 1][x + 2] - W[y + 1][x]);
-            const float dyv = 0.5f * (W[y + 2][x + 1] - W[y][x + 1]);
+            const float dxv = W[y + 1][x + 2] - W[y + 1][x];                       // = 0.5f * (a - b) of the full values
+            const float dyv = W[y + 2][x + 1] - W[y][x + 1];
             const double ddx = (double)dxv, ddy = (double)dyv;
-            sxx += ddx * ddx; sxy += ddx * ddy; syy += ddy * ddy;
+            // (the kernel's own sums: fused)
+            sxx = __builtin_fma(ddx, ddx, sxx); sxy = __builtin_fma(ddx, ddy, sxy); syy = __builtin_fma(ddy, ddy, syy);
           }
       }
 #ifdef SVO_STAMPS
@@ -1015,7 +1020,11 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       {
         double A[6], B[6];
         patch_jacobian_rows(X[k].x, X[k].y, X[k].w, jscale, A, B);
-        // entry e of the row = (i, j) of the upper triangle in row-major order; eight entries per reduction
+        // entry e of the row = (i, j) of the upper triangle in row-major order; eight entries per reduction.
+        // (Entry by entry as sxx (A_i A_j) + sxy (A_i B_j + B_i A_j) + syy (B_i B_j): the cheaper A_i P_j + B_i Q_j with
+        // P = sxx A + sxy B, Q = sxy A + syy B rounds differently, and on a frame whose H is singular -- one patch --
+        // the reference's solve ends in a NaN pose only when the cancellations in its pivots are exact; this form
+        // reproduces that, the factored one returned a finite pose.)
         double mine = 0.0;
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) {
