@@ -157,6 +157,35 @@ def test_patches_leaving_the_image(ctx, sia_mode):
     _free(sia, ref, cur)
 
 
+def test_points_in_the_camera_plane(ctx, sia_mode):
+    """Patches whose point lies (almost) in the plane of the current camera: z_cur of 1e-15 ... 1e-8 m, so the
+    projection is 1e7 ... 1e17 px or infinite.  The float -> int conversion of such a coordinate SATURATES on the
+    device (INT_MAX) where the host's cvttss2si returns INT_MIN; `u + border < cols` then wrapped around and the
+    patch was read thousands of rows outside the image.  Both sides must drop these patches and agree on the rest."""
+    fp = synth.make_frame_pair(seed=83, n_features=700)
+    tz = 0.01
+    fp.T_cur_w_init = synth.se3_mul(np.array([0, 0, -tz, 0, 0, 0, 1.0]), fp.T_ref_w)
+    T_w_ref = synth.se3_inv(fp.T_ref_w)
+    idx = [5, 64, 65, 200, 333, 699]
+    for i, eps in zip(idx, [1e-13, -1e-13, 0.0, 1e-9, 1e-6, 3e-16]):
+        d = tz / fp.f[i, 2] * (1.0 + eps)
+        fp.pos[i] = synth.se3_act(T_w_ref, fp.f[i] * d)
+        z_cur = fp.f[i, 2] * np.linalg.norm(fp.pos[i] - T_w_ref[:3]) - tz
+        assert abs(z_cur) < 2e-8
+    ref, cur, sia = _upload_pair(ctx, [fp])
+    sia.run(1, sia.params(early_stop=False, n_iter=3))
+    r = sia.download(0)
+    o = orc.sparse_img_align(fp, early_stop=False, n_iter=3)
+    assert r.n_precompute_patches == o.n_precompute_patches
+    assert r.n_residual_patches == o.n_residual_patches
+    assert r.n_tracked == o.n_tracked
+    rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
+    assert rot < 1e-9 and trans < 1e-9, (rot, trans)
+    H, Ho = np.array(r.H), np.array(o.H)
+    assert np.abs(H - Ho).max() <= 1e-9 * np.abs(Ho).max()
+    _free(sia, ref, cur)
+
+
 def test_radtan_camera_forward_model(ctx, sia_mode):
     """world2cam with the 5-coefficient radtan model (pinhole_camera.cpp:88-104) inside the residual
     evaluation; fixed work so both sides execute the same evaluations."""
