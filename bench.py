@@ -156,13 +156,17 @@ def pmc_of(path, kernel_prefix):
 
 
 def valu_issue_cycles(c):
-    """VALU issue cycles of one launch from the per-type instruction counters: a wave64 f32 / int / conversion
-    instruction holds its SIMD-32 for 2 cycles, an f64 one for 4, a transcendental for 8 (MI355X_MICROARCH.md,
-    'Per-instruction cycle constants'; fp64 vector peak is half the fp32 one)."""
+    """VALU issue cycles of one launch from the per-type instruction counters: a wave64 f32 / int instruction holds its
+    SIMD-32 for 2 cycles, an f64 one for 4, a transcendental for 8 (MI355X_MICROARCH.md, 'Per-instruction cycle
+    constants'; fp64 vector peak is half the fp32 one).  Conversions (v_cvt_f64_f32, v_cvt_f32_ubyte*, ...) issue at the
+    fp64 rate on this chip -- measured, tools/probes/valu_rate_probe.hip: 1.88 ns against 1.90 ns for v_fma_f64 and
+    1.11 ns for v_add_f32 with two waves per SIMD -- and are counted at 4.  Compares, shifts, min/max and lane reads are
+    in that slower class too but have no counter of their own: they stay at 2, so the sum is still a lower bound."""
     f64 = c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_FMA_F64", 0.0)
     trans = c.get("SQ_INSTS_VALU_TRANS_F64", 0.0) + c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    cvt = c.get("SQ_INSTS_VALU_CVT", 0.0)
     total = c["SQ_INSTS_VALU"]
-    return 2.0 * (total - f64 - trans) + 4.0 * f64 + 8.0 * trans, f64, trans
+    return 2.0 * (total - f64 - trans - cvt) + 4.0 * (f64 + cvt) + 8.0 * trans, f64, trans
 
 
 def with_uploads(torch, ctx, stream, local_rank, sia, ref, fps, n_slots, prm, steps):
@@ -397,8 +401,9 @@ def main():
                         clk = ctr["GRBM_GUI_ACTIVE"] / 8.0 / (ctr["_kernel_avg_us"] * 1e-6) / 1e9
                     roofline["valu"] = {"insts_per_launch": ctr["SQ_INSTS_VALU"], "f64_insts": n_f64, "transcendental_insts": n_trans,
                                         "issue_cycles_per_launch": cyc,
-                                        "rule": "2 cycles per wave64 f32/int/cvt instruction, 4 per f64 add/mul/fma, 8 per transcendental "
-                                                "(conversions to/from f64 counted at 2: a lower bound)",
+                                        "rule": "2 cycles per wave64 f32/int instruction, 4 per f64 add/mul/fma and per conversion (v_cvt_* issue "
+                                                "at the f64 rate: measured, tools/probes/valu_rate_probe.hip), 8 per transcendental; compares, shifts, "
+                                                "min/max and lane reads are in the slower class too but are counted at 2: a lower bound",
                                         "cvt_insts": ctr.get("SQ_INSTS_VALU_CVT"),
                                         "effective_clock_GHz_under_profiler": clk,
                                         "frac_at_that_clock": (cyc / avg_s / 1e9) / (N_SIMD * clk) if clk else None}
