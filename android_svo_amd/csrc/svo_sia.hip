@@ -847,7 +847,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   const bool empty = n <= 0;
   const int tri_i = kTriI[lane < 21 ? lane : 0], tri_j = kTriJ[lane < 21 ? lane : 0];
   // Tile ownership.  Waves w and w+4 share SIMD w&3, and the SIMD's arbiter favours the older one (w < 4): it runs
-  // at the pace of a wave that is alone on its SIMD (one instruction per 4 cycles, whatever the type), the younger
+  // at the pace of a wave that is alone on its SIMD (one instruction per ~5.4 cycles, whatever the type: tools/probes/valu_rate_probe.hip), the younger
   // one gets the issue cycles that are left (measured: 57 % of that pace) and finishes an equal share 40 % later,
   // alone on a half-used SIMD.  The tiles of a SIMD (s, s+4, s+8, ...) are split evenly, the older wave takes the
   // first TPW of them and the younger one the tiles_young that follow; during the first 5/8 of its tiles (to half a tile) the younger
