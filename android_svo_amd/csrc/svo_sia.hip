@@ -619,6 +619,7 @@ constexpr int FUSED_MAX_TILES = 44;               // 2816 patches: 6 tiles on an
 constexpr int FUSED_WC_BYTES = TILE * 128;        // interpolated reference patches of one tile
 constexpr int FUSED_EXTRA_TILES = 3;              // 8-wave shape: at most this many LDS tiles beyond two per wave
 constexpr int FUSED_MAX_TPW = 6;                  // the older wave's share of a SIMD's 11 tiles
+constexpr int FUSED_EXACT_ROW_BELOW = 16;         // frames with fewer patches: H rows entry by entry (fused_tile_row_exact)
 
 struct FusedLevels {
   int cols[SVO_HIP_MAX_LEVELS], rows[SVO_HIP_MAX_LEVELS];
@@ -794,7 +795,13 @@ __device__ __noinline__ void fused_refactor_cold(const double* s_Hc, double* s_f
 // large update angles (theta^2 > 0.25): the library path of SE3::exp
 __device__ __noinline__ void se3_exp_cold(const double* l, double* out) { se3_exp(l, out); }
 
-template <int NW, int TPW, int CK>
+// EXACT_ROWS: the per-tile Hessian rows entry by entry as sxx (A_i A_j) + sxy (A_i B_j + B_i A_j) + syy (B_i B_j), the
+// form the kernel used for every frame until round 2; otherwise factored (see the precompute).  The launcher picks the
+// exact form for a batch that holds a frame with fewer than FUSED_EXACT_ROW_BELOW patches: there H can be rank-deficient
+// (one patch: rank 2), the reference's own solve then wanders off on rounding noise -- in the reference-derived test
+// of a one-patch frame until the patch leaves the image and the pose turns NaN -- and the exact form happens to follow
+// it (tests/test_gpu_parity.py::test_batch_ragged_and_empty) where the factored one returned a finite pose.
+template <int NW, int TPW, int CK, bool EXACT_ROWS>
 __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
     const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
@@ -1018,30 +1025,45 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       // the tile's Hessian row: lane e keeps entry e.  The 21 wave sums go through three transposing reductions
       // (7 long-range exchanges each) instead of 21 butterflies.
       {
-        double A[6], B[6];
-        patch_jacobian_rows(X[k].x, X[k].y, X[k].w, jscale, A, B);
-        // entry e of the row = (i, j) of the upper triangle in row-major order; eight entries per reduction.
-        // (Entry by entry as sxx (A_i A_j) + sxy (A_i B_j + B_i A_j) + syy (B_i B_j): the cheaper A_i P_j + B_i Q_j with
-        // P = sxx A + sxy B, Q = sxy A + syy B rounds differently, and on a frame whose H is singular -- one patch --
-        // the reference's solve ends in a NaN pose only when the cancellations in its pivots are exact; this form
-        // reproduces that, the factored one returned a finite pose.)
+        // J^T J of the patch summed over its pixels = sxx A A^T + sxy (A B^T + B A^T) + syy B B^T.  Factored: entry (i, j)
+        // = A_i P_j + B_i Q_j with P = sxx A + sxy B, Q = sxy A + syy B (A_1 and B_0 are structural zeros), 54 fp64
+        // operations instead of 210; a patch that is not valid at this level contributes nothing: its sums and its
+        // point are replaced before the products.  EXACT_ROWS: entry by entry (see the template parameter).
         double mine = 0.0;
+        {
+          const double gxx = valid ? sxx : 0.0, gxy = valid ? sxy : 0.0, gyy = valid ? syy : 0.0;
+          double A[6], B[6], P[6], Q[6];
+          if (EXACT_ROWS) {
+            patch_jacobian_rows(X[k].x, X[k].y, X[k].w, jscale, A, B);
+          } else {
+            patch_jacobian_rows(valid ? X[k].x : 0.0, valid ? X[k].y : 0.0, valid ? X[k].w : 1.0, jscale, A, B);
+            P[0] = gxx * A[0]; Q[0] = gxy * A[0];
+            P[1] = gxy * B[1]; Q[1] = gyy * B[1];
 #pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) {
-          double h[8];
-#pragma unroll
-          for (int q8 = 0; q8 < 8; ++q8) {
-            const int e = 8 * c3 + q8;
-            h[q8] = 0.0;
-            if (e < 21) {
-              const int i = kTriIc[e], j = kTriJc[e];
-              const double he = sxx * (A[i] * A[j]) + sxy * (A[i] * B[j] + B[i] * A[j]) + syy * (B[i] * B[j]);
-              h[q8] = valid ? he : 0.0;               // a select, not a branch per entry
-            }
+            for (int j = 2; j < 6; ++j) { P[j] = __builtin_fma(gxx, A[j], gxy * B[j]); Q[j] = __builtin_fma(gxy, A[j], gyy * B[j]); }
           }
-          const double r = wave_reduce8(h);                    // lanes 8j..8j+7: total of entry 8*c3 + j
-          const double t = __shfl(r, 8 * (lane & 7), 64);
-          if ((lane >> 3) == c3) mine = t;
+          // entry e of the row = (i, j) of the upper triangle in row-major order; eight entries per reduction
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) {
+            double h[8];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) {
+              const int e = 8 * c3 + q8;
+              h[q8] = 0.0;
+              if (e < 21) {
+                const int i = kTriIc[e], j = kTriJc[e];
+                if (EXACT_ROWS) {
+                  const double he = sxx * (A[i] * A[j]) + sxy * (A[i] * B[j] + B[i] * A[j]) + syy * (B[i] * B[j]);
+                  h[q8] = valid ? he : 0.0;               // a select, not a branch per entry
+                } else {
+                  h[q8] = i == 0 ? A[0] * P[j] : i == 1 ? B[1] * Q[j] : __builtin_fma(A[i], P[j], B[i] * Q[j]);
+                }
+              }
+            }
+            const double r = wave_reduce8(h);                  // lanes 8j..8j+7: total of entry 8*c3 + j
+            const double t = __shfl(r, 8 * (lane & 7), 64);
+            if ((lane >> 3) == c3) mine = t;
+          }
         }
         th_set(k, mine);
         // the untouched row goes to memory: it is only needed again when the set of patches outside the image changes
@@ -1608,11 +1630,11 @@ int fused_tiles_per_wave(const svo_hip_sia* s, int n_slots) {
   return old_share < 1 ? 1 : old_share;
 }
 
-template <int NW, int TPW, int CK>
-int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes, int tiles_young, int n_extra = 0) {
+template <int NW, int TPW, int CK, bool EXACT_ROWS>
+int launch_fused_x(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes, int tiles_young, int n_extra) {
   svo_hip_ctx* ctx = s->ctx;
   // > 64 KiB of dynamic LDS has to be allowed explicitly (per device: set it on every launch, it is cheap)
-  SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<NW, TPW, CK>),
+  SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<NW, TPW, CK, EXACT_ROWS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   FusedLevels lv;
   memset(&lv, 0, sizeof(lv));
@@ -1625,12 +1647,21 @@ int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   fp.early_stop = prm->early_stop; fp.eps = prm->eps;
   hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
-  hipLaunchKernelGGL((sia_fused_kernel<NW, TPW, CK>), dim3(n_slots), dim3(NW * 64), lds_bytes, ctx->stream, s->fc, s->st,
+  hipLaunchKernelGGL((sia_fused_kernel<NW, TPW, CK, EXACT_ROWS>), dim3(n_slots), dim3(NW * 64), lds_bytes, ctx->stream, s->fc, s->st,
                      s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, s->tile_h,
                      s->wmem, s->max_tiles, fp, tiles_young, n_extra);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
+}
+
+// the exact Hessian rows for a batch that holds a frame with a handful of patches (see sia_fused_kernel)
+template <int NW, int TPW, int CK>
+int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes, int tiles_young, int n_extra = 0) {
+  bool tiny = false;
+  for (int i = 0; i < n_slots; ++i) tiny = tiny || (s->h_fc[i].n_feat > 0 && s->h_fc[i].n_feat < FUSED_EXACT_ROW_BELOW);
+  return tiny ? launch_fused_x<NW, TPW, CK, true>(s, n_slots, prm, lds_bytes, tiles_young, n_extra)
+              : launch_fused_x<NW, TPW, CK, false>(s, n_slots, prm, lds_bytes, tiles_young, n_extra);
 }
 
 // LDS tiles (8 KiB) the 8-wave shape can hold beyond ck per wave: what 160 KiB leave next to the kernel's static LDS
@@ -1640,7 +1671,7 @@ int fused_extra_tiles_t() {
   if (cached < 0) {
     hipFuncAttributes at;
     cached = 0;
-    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&sia_fused_kernel<8, TPW, CK>)) == hipSuccess) {
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&sia_fused_kernel<8, TPW, CK, false>)) == hipSuccess) {
       const long free_b = 160L * 1024 - (long)at.sharedSizeBytes - (long)FUSED_WAVES * CK * FUSED_WC_BYTES;
       cached = free_b > 0 ? (int)(free_b / FUSED_WC_BYTES) : 0;
       if (cached > FUSED_EXTRA_TILES) cached = FUSED_EXTRA_TILES;
