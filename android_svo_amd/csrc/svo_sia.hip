@@ -1042,7 +1042,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
 #pragma unroll
             for (int j = 2; j < 6; ++j) { P[j] = __builtin_fma(gxx, A[j], gxy * B[j]); Q[j] = __builtin_fma(gxy, A[j], gyy * B[j]); }
           }
-          // entry e of the row = (i, j) of the upper triangle in row-major order; eight entries per reduction
+          // entry e of the row = (i, j) of the upper triangle in row-major order; eight entries per reduction.  After
+          // reduction c3 the eight lanes 8j..8j+7 all hold the total of entry 8 c3 + j: lane 8j + c3 keeps it, and ONE
+          // lane exchange at the end (instead of one per reduction) brings entry e from lane 8 (e & 7) + (e >> 3).
+          double kept = 0.0;
 #pragma unroll
           for (int c3 = 0; c3 < 3; ++c3) {
             double h[8];
@@ -1061,9 +1064,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
               }
             }
             const double r = wave_reduce8(h);                  // lanes 8j..8j+7: total of entry 8*c3 + j
-            const double t = __shfl(r, 8 * (lane & 7), 64);
-            if ((lane >> 3) == c3) mine = t;
+            if ((lane & 7) == c3) kept = r;
           }
+          mine = __shfl(kept, 8 * (lane & 7) + (lane < 24 ? lane >> 3 : 0), 64);
         }
         th_set(k, mine);
         // the untouched row goes to memory: it is only needed again when the set of patches outside the image changes
