@@ -1341,19 +1341,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       // that is known already -- what the previous solve left behind -- is asked for BEFORE the first barrier (wave 0
       // is one of the older waves and gets there early), and everything nobody waits for (counters, chi2, the
       // rollback copy of the pose) is written AFTER the second one.
-#ifdef SVO_V_NOPRELOAD
-      __syncthreads();
-#endif
       double chi2_old = 0.0, nres_old = 0.0, hc_prev = 0.0;
       double coef[8], inv_row[6], cur[7];
       int it = 0, stop_old = 0, iters_l = 0, fac_valid = 0;
       if (wave == 0) {
 #pragma unroll
-#ifdef SVO_V_CURT
-        for (int i = 0; i < 7; ++i) cur[i] = T[i];
-#else
         for (int i = 0; i < 7; ++i) cur[i] = s_model[i];        // (= T, which lives in scalar registers that are needed elsewhere by now)
-#endif
         chi2_old = s_chi2; nres_old = s_nres; hc_prev = s_Hc[lane < 21 ? lane : 0];   // H of the previous evaluation
         it = s_iter; stop_old = s_stop; iters_l = s_iters[level]; fac_valid = s_fac_valid;
 #pragma unroll
@@ -1361,9 +1354,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
 #pragma unroll
         for (int j = 0; j < 6; ++j) inv_row[j] = s_inv[(lane < 6 ? lane : 0) * 6 + j];   // lanes 0..5: their row of H^-1
       }
-#ifndef SVO_V_NOPRELOAD
       __syncthreads();
-#endif
 #ifdef SVO_STAMPS
       const long long t2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1461,9 +1452,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         if (lane == 0) s_stamp[8] += __builtin_amdgcn_s_memtime() - t2;
 #endif
       }
-#ifndef SVO_V_NODEFER
       __syncthreads();
-#endif
       if (wave == 0) {
         // what only wave 0 itself reads again (and thread 0 at the end): the other waves are already evaluating
         const double n_meas_d = readlane_f64(v, 28);       // exact integer counts (multiples of 16) carried as doubles
@@ -1482,9 +1471,6 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           }
         }
       }
-#ifdef SVO_V_NODEFER
-      __syncthreads();
-#endif
 #ifdef SVO_STAMPS
       if (threadIdx.x == 64) { const long long t3 = __builtin_amdgcn_s_memtime(); s_stamp[0] += t1 - t0; s_stamp[1] += t2 - t1; s_stamp[2] += t3 - t2; }
       if (lane == 0) { s_wst[wave] += t1 - t0; s_wst[8 + wave] += t2 - t1; }
