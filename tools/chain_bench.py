@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Per-frame time of the tracking front end -- SparseImgAlign against the last frame, reprojection of the keyframe's map
+(one match per grid cell), motion-only pose refinement: the chain of tests/tracking_chain.py, i.e. what
+FrameHandlerMono::processFrame runs per image -- through the HIP library's host-buffer entry points (uploads of the two
+pyramids and of the features included, as a drop-in caller pays them) and through the CPU oracle on one host core.
+Diagnostic; not run by the driver.  Prints one JSON line.
+
+    python tools/chain_bench.py [--frames 20] [--min-level 2]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import tracking_chain as tc  # noqa: E402
+from android_svo_amd import hip  # noqa: E402
+
+
+class Timed:
+    """wraps a stages object and accumulates wall time per stage"""
+
+    def __init__(self, inner, sync=None):
+        self.inner, self.sync = inner, sync
+        self.t = {"align": 0.0, "reproject": 0.0, "refine": 0.0}
+        self.calls = 0
+
+    def _run(self, name, *a):
+        t0 = time.perf_counter()
+        r = getattr(self.inner, name)(*a)
+        if self.sync:
+            self.sync()
+        self.t[name] += time.perf_counter() - t0
+        return r
+
+    def align(self, *a):
+        self.calls += 1
+        return self._run("align", *a)
+
+    def reproject(self, *a):
+        return self._run("reproject", *a)
+
+    def refine(self, *a):
+        return self._run("refine", *a)
+
+
+class ResidentStages:
+    """The HIP stages the way the drop-in runs them (include/svo_dropin/svo_hip_bridge.h): the previous frame's pyramid
+    stays on the device and becomes the reference, only level 0 of the new image crosses PCIe (the pyramid is built on
+    the device)."""
+
+    def __init__(self, ctx, seq):
+        from test_gpu_sequence import HipStages
+        self.h = HipStages(ctx, seq)
+        self.seq = seq
+        self.pyr = [self.h.ref, self.h.cur]
+        self.pyr[0].upload_level0_and_build(0, seq["pyrs"][0][0])
+        self.last = 0                                            # index of the pyramid that holds frame k - 1
+
+    def align(self, fp, k, min_level):
+        h = self.h
+        ref, cur = self.pyr[self.last], self.pyr[1 - self.last]
+        if k == 1:                                               # a new run of the chain starts from the keyframe again
+            ref.upload_level0_and_build(0, self.seq["pyrs"][0][0])
+        cur.upload_level0_and_build(0, self.seq["pyrs"][k][0])
+        h.sia.set_frames(ref, cur)
+        h.cur = cur                                              # the reprojection matches against it
+        h.sia.upload_pair(0, fp)
+        h.sia.run(1, h.sia.params(max_level=4, min_level=min_level, n_iter=30, eps=1e-6, early_stop=True))
+        r = h.sia.download(0)
+        self.last = 1 - self.last
+        return np.array(r.T_cur_w), r.n_tracked
+
+    def reproject(self, *a):
+        return self.h.reproject(*a)
+
+    def refine(self, *a):
+        return self.h.refine(*a)
+
+    def destroy(self):
+        self.h.destroy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--min-level", type=int, default=2)     # the shipping default: L4 -> L2
+    args = ap.parse_args()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_sequence import HipStages
+
+    seq = tc.make_sequence(n_frames=args.frames)
+    ctx = hip.Context(0)
+    out = {"what": "per-frame time of SparseImgAlign -> reprojection (one match per cell) -> pose refinement over a %d-frame "
+                   "synthetic sequence (640x480, %d map points, L4-L%d)" % (args.frames, len(seq["px0"]), args.min_level)}
+    for name, make in (("hip", lambda: HipStages(ctx, seq)), ("hip_resident", lambda: ResidentStages(ctx, seq)),
+                       ("cpu_oracle_1_thread", lambda: tc.OracleStages(seq))):
+        inner = make()
+        if name.startswith("hip"):
+            tc.run_chain(seq, inner, args.min_level)          # warm-up (first launches, clocks)
+        st = Timed(inner, ctx.sync if name.startswith("hip") else None)
+        tc.run_chain(seq, st, args.min_level)
+        n = st.calls
+        out[name] = {"frames": n, "ms_per_frame": {k: 1e3 * v / n for k, v in st.t.items()},
+                     "ms_per_frame_total": 1e3 * sum(st.t.values()) / n}
+        if hasattr(inner, "destroy"):
+            inner.destroy()
+    out["speedup"] = out["cpu_oracle_1_thread"]["ms_per_frame_total"] / out["hip_resident"]["ms_per_frame_total"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
