@@ -186,6 +186,24 @@ def test_points_in_the_camera_plane(ctx, sia_mode):
     _free(sia, ref, cur)
 
 
+def test_small_frames_take_the_factored_hessian_rows(ctx, sia_mode):
+    """Frames with 16 ... 64 patches and none smaller: the fused kernel runs its factored per-tile Hessian rows (a batch
+    that holds a frame below 16 patches would select the entry-by-entry instance, test_batch_ragged_and_empty).  Few
+    patches make H poorly conditioned at the coarse levels; every slot must still equal its own oracle run."""
+    fps = [synth.make_frame_pair(seed=140 + i, n_features=n) for i, n in enumerate([16, 17, 20, 33, 48, 64])]
+    ref, cur, sia = _upload_pair(ctx, fps, max_feat=64)
+    sia.run(len(fps), sia.params())
+    res = sia.download_all(len(fps))
+    for i, fp in enumerate(fps):
+        o = orc.sparse_img_align(fp)
+        got, want = np.array(res[i].T_cur_w), np.array(o.T_cur_w)
+        assert not np.isnan(want).any(), i
+        rot, trans = synth.pose_error(got, want)
+        assert rot < 1e-4 and trans < 1e-3, (i, rot, trans)
+        assert res[i].n_tracked == o.n_tracked, i
+    _free(sia, ref, cur)
+
+
 def test_radtan_camera_forward_model(ctx, sia_mode):
     """world2cam with the 5-coefficient radtan model (pinhole_camera.cpp:88-104) inside the residual
     evaluation; fixed work so both sides execute the same evaluations."""
