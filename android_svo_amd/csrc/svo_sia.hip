@@ -651,9 +651,12 @@ struct LeanCam {
 // v_div_fixup for the special operands; the scaling only acts when an exponent is near the end of the range.  Here
 // the refined reciprocal is formed ONCE for both quotients and the same residual correction is applied: for a
 // denominator whose exponent is in the middle 1800 binades these are, operation for operation, the roundings of the
-// expansion (bit-identical quotients for every numerator whose quotient is a normal number; a quotient that is
-// subnormal, overflows or is NaN is outside every image either way).  Any other denominator in the wave takes
-// the two plain divisions.
+// expansion.  Checked on the device against the compiler's divisions (tools/probes/div_probe.hip,
+// profiles/r02_probe_div_probe.txt, 10^9 random quotients per range): bit-identical for |z| in [2^-900, 2^900) and
+// numerators in [2^-960, 2^960) whenever the quotient is a normal number.  A numerator outside that range can cost
+// the last bit (the residual turns subnormal) -- of a quotient below 2^-60 or above 2^60, which projects onto the
+// principal point or outside every image either way, as does a subnormal, infinite or NaN quotient.  Any other
+// denominator in the wave takes the two plain divisions.
 SVO_DEV void div2_by(double x, double y, double z, double& qx, double& qy) {
   const unsigned ez = (unsigned)__double2hiint(z) & 0x7ff00000u;                  // biased exponent << 20
   const bool mid = ez - (123u << 20) < (1800u << 20);                             // 2^-900 <= |z| < 2^900 (no 0, inf, NaN, subnormal)
