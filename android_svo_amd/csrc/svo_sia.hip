@@ -798,6 +798,56 @@ __device__ __noinline__ void fused_refactor_cold(const double* s_Hc, double* s_f
 // large update angles (theta^2 > 0.25): the library path of SE3::exp
 __device__ __noinline__ void se3_exp_cold(const double* l, double* out) { se3_exp(l, out); }
 
+// The Hessian row of a set of patches of one tile: lane e (< 21) returns entry e -- (i, j) of the upper triangle in
+// row-major order -- of the sum, over the lanes with `contributes`, of the patch's J^T J summed over its pixels
+// = sxx A A^T + sxy (A B^T + B A^T) + syy B B^T.  Used for a tile's whole row when the reference patches of a level are
+// formed (contributes = valid) and for the part to take out of it when the set of patches outside the current image has
+// changed (contributes = outside): both with the same arithmetic per patch and the same reduction, so that a tile whose
+// patches are all outside is left with a row of exact zeros.
+// Factored: entry (i, j) = A_i P_j + B_i Q_j with P = sxx A + sxy B, Q = sxy A + syy B (A_1 and B_0 are structural
+// zeros), 54 fp64 operations instead of 210; a lane that does not contribute has its sums and its point replaced
+// before the products.  EXACT_ROWS: entry by entry (see sia_fused_kernel).
+// The 21 wave sums go through three transposing reductions (7 long-range exchanges each) instead of 21 butterflies;
+// after reduction c3 the eight lanes 8j..8j+7 all hold the total of entry 8 c3 + j: lane 8j + c3 keeps it, and ONE lane
+// exchange at the end (instead of one per reduction) brings entry e from lane 8 (e & 7) + (e >> 3).
+template <bool EXACT_ROWS>
+SVO_DEV double fused_tile_row(double x, double y, double z_inv, double jscale, double sxx, double sxy, double syy, bool contributes,
+                              int lane) {
+  const double gxx = contributes ? sxx : 0.0, gxy = contributes ? sxy : 0.0, gyy = contributes ? syy : 0.0;
+  double A[6], B[6], P[6], Q[6];
+  if (EXACT_ROWS) {
+    patch_jacobian_rows(x, y, z_inv, jscale, A, B);
+  } else {
+    patch_jacobian_rows(contributes ? x : 0.0, contributes ? y : 0.0, contributes ? z_inv : 1.0, jscale, A, B);
+    P[0] = gxx * A[0]; Q[0] = gxy * A[0];
+    P[1] = gxy * B[1]; Q[1] = gyy * B[1];
+#pragma unroll
+    for (int j = 2; j < 6; ++j) { P[j] = __builtin_fma(gxx, A[j], gxy * B[j]); Q[j] = __builtin_fma(gxy, A[j], gyy * B[j]); }
+  }
+  double kept = 0.0;
+#pragma unroll
+  for (int c3 = 0; c3 < 3; ++c3) {
+    double h[8];
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) {
+      const int e = 8 * c3 + q8;
+      h[q8] = 0.0;
+      if (e < 21) {
+        const int i = kTriIc[e], j = kTriJc[e];
+        if (EXACT_ROWS) {
+          const double he = sxx * (A[i] * A[j]) + sxy * (A[i] * B[j] + B[i] * A[j]) + syy * (B[i] * B[j]);
+          h[q8] = contributes ? he : 0.0;             // a select, not a branch per entry
+        } else {
+          h[q8] = i == 0 ? A[0] * P[j] : i == 1 ? B[1] * Q[j] : __builtin_fma(A[i], P[j], B[i] * Q[j]);
+        }
+      }
+    }
+    const double r = wave_reduce8(h);                  // lanes 8j..8j+7: total of entry 8*c3 + j
+    if ((lane & 7) == c3) kept = r;
+  }
+  return __shfl(kept, 8 * (lane & 7) + (lane < 24 ? lane >> 3 : 0), 64);
+}
+
 // EXACT_ROWS: the per-tile Hessian rows entry by entry as sxx (A_i A_j) + sxy (A_i B_j + B_i A_j) + syy (B_i B_j), the
 // form the kernel used for every frame until round 2; otherwise factored (see the precompute).  The launcher picks the
 // exact form for a batch that holds a frame with fewer than FUSED_EXACT_ROW_BELOW patches: there H can be rank-deficient
@@ -1025,52 +1075,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       const long long tq1 = __builtin_amdgcn_s_memtime();
 #endif
       if (valid) sxyz[(size_t)b * max_n + i_own] = make_double4(sxx, sxy, syy, 0.0);   // only re-read when a patch leaves the image
-      // the tile's Hessian row: lane e keeps entry e.  The 21 wave sums go through three transposing reductions
-      // (7 long-range exchanges each) instead of 21 butterflies.
+      // the tile's Hessian row: lane e keeps entry e (fused_tile_row)
       {
-        // J^T J of the patch summed over its pixels = sxx A A^T + sxy (A B^T + B A^T) + syy B B^T.  Factored: entry (i, j)
-        // = A_i P_j + B_i Q_j with P = sxx A + sxy B, Q = sxy A + syy B (A_1 and B_0 are structural zeros), 54 fp64
-        // operations instead of 210; a patch that is not valid at this level contributes nothing: its sums and its
-        // point are replaced before the products.  EXACT_ROWS: entry by entry (see the template parameter).
-        double mine = 0.0;
-        {
-          const double gxx = valid ? sxx : 0.0, gxy = valid ? sxy : 0.0, gyy = valid ? syy : 0.0;
-          double A[6], B[6], P[6], Q[6];
-          if (EXACT_ROWS) {
-            patch_jacobian_rows(X[k].x, X[k].y, X[k].w, jscale, A, B);
-          } else {
-            patch_jacobian_rows(valid ? X[k].x : 0.0, valid ? X[k].y : 0.0, valid ? X[k].w : 1.0, jscale, A, B);
-            P[0] = gxx * A[0]; Q[0] = gxy * A[0];
-            P[1] = gxy * B[1]; Q[1] = gyy * B[1];
-#pragma unroll
-            for (int j = 2; j < 6; ++j) { P[j] = __builtin_fma(gxx, A[j], gxy * B[j]); Q[j] = __builtin_fma(gxy, A[j], gyy * B[j]); }
-          }
-          // entry e of the row = (i, j) of the upper triangle in row-major order; eight entries per reduction.  After
-          // reduction c3 the eight lanes 8j..8j+7 all hold the total of entry 8 c3 + j: lane 8j + c3 keeps it, and ONE
-          // lane exchange at the end (instead of one per reduction) brings entry e from lane 8 (e & 7) + (e >> 3).
-          double kept = 0.0;
-#pragma unroll
-          for (int c3 = 0; c3 < 3; ++c3) {
-            double h[8];
-#pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) {
-              const int e = 8 * c3 + q8;
-              h[q8] = 0.0;
-              if (e < 21) {
-                const int i = kTriIc[e], j = kTriJc[e];
-                if (EXACT_ROWS) {
-                  const double he = sxx * (A[i] * A[j]) + sxy * (A[i] * B[j] + B[i] * A[j]) + syy * (B[i] * B[j]);
-                  h[q8] = valid ? he : 0.0;               // a select, not a branch per entry
-                } else {
-                  h[q8] = i == 0 ? A[0] * P[j] : i == 1 ? B[1] * Q[j] : __builtin_fma(A[i], P[j], B[i] * Q[j]);
-                }
-              }
-            }
-            const double r = wave_reduce8(h);                  // lanes 8j..8j+7: total of entry 8*c3 + j
-            if ((lane & 7) == c3) kept = r;
-          }
-          mine = __shfl(kept, 8 * (lane & 7) + (lane < 24 ? lane >> 3 : 0), 64);
-        }
+        const double mine = fused_tile_row<EXACT_ROWS>(X[k].x, X[k].y, X[k].w, jscale, sxx, sxy, syy, valid, lane);
         th_set(k, mine);
         // the untouched row goes to memory: it is only needed again when the set of patches outside the image changes
         if (lane < 21) tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane] = mine;
@@ -1279,35 +1286,23 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       }
 
       __builtin_amdgcn_s_setprio(0);
-      // rows of the tiles whose outside-the-image set changed: one dependent memory access and a 21-entry rank update
-      // per patch, one patch after the other (rare)
+      // rows of the tiles whose outside-the-image set changed: the tile's whole row minus the row of the patches that are
+      // outside now, formed by all of them at once (every lane has its own point, reads its own gradient sums and the
+      // wave reduces: ~350 instructions per tile whatever the number of patches; walking the patches one after the
+      // other -- a dependent load and a rank update each -- cost ~500 cycles per patch, and a coarse level can have 45
+      // of a tile's 64 outside: the slowest of 64 scenes spent 9 % of its time there)
       if (!LEAN && gone_changed) {                             // wave-uniform
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
           if (!((gone_changed >> k) & 1u)) continue;
           const int tile = tile_of(k);
-          const int tile_base = tile * TILE;
+          const int i_own = tile * TILE + lane;
+          const bool gone_lane = (fl[k] & F_GONE) != 0;
           double t = 0.0;
           if (lane < 21) t = tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane];
-          unsigned long long gone = __ballot((fl[k] & F_GONE) != 0);
-          while (gone) {
-            const int src = __ffsll((long long)gone) - 1;
-            gone &= gone - 1;
-            const double gx_ = __shfl(X[k].x, src, 64), gy_ = __shfl(X[k].y, src, 64), gzi = __shfl(X[k].w, src, 64);
-            const double4 G4 = sxyz[(size_t)b * max_n + tile_base + src];
-            const double g_xx = G4.x, g_xy = G4.y, g_yy = G4.z;
-            double A[6], B[6];
-            patch_jacobian_rows(gx_, gy_, gzi, jscale, A, B);
-            double Ai = A[0], Aj = A[0], Bi = B[0], Bj = B[0];
-#pragma unroll
-            for (int kk = 1; kk < 6; ++kk) {
-              if (tri_i == kk) { Ai = A[kk]; Bi = B[kk]; }
-              if (tri_j == kk) { Aj = A[kk]; Bj = B[kk]; }
-            }
-            const double h = g_xx * (Ai * Aj) + g_xy * (Ai * Bj + Bi * Aj) + g_yy * (Bi * Bj);
-            t -= h;
-          }
-          th_set(k, t);
+          const double4 G4 = sxyz[(size_t)b * max_n + (gone_lane ? i_own : 0)];            // (always a valid address)
+          const double out_row = fused_tile_row<EXACT_ROWS>(X[k].x, X[k].y, X[k].w, jscale, G4.x, G4.y, G4.z, gone_lane, lane);
+          th_set(k, t - out_row);
         }
       }
       if (!LEAN) {
@@ -1507,6 +1502,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       for (int i = 0; i < 16; ++i) s.H[i] = (double)s_wst[i];
       for (int i = 5; i < 10; ++i) s.H[16 + i - 5] = (double)s_stamp[i];
       s.x[5] = (double)(__builtin_amdgcn_s_memtime() - k_m0) / (double)(__builtin_amdgcn_s_memrealtime() - k_r0) * 0.1;   // GHz over the kernel
+      s.chi2 = (double)(__builtin_amdgcn_s_memtime() - k_m0);                                                              // cycles of this workgroup
       s.x[0] = (double)s_stamp[0]; s.x[1] = (double)s_stamp[1]; s.x[2] = (double)s_stamp[2]; s.x[3] = (double)s_stamp[3]; s.x[4] = (double)s_stamp[4];
 #endif
     }

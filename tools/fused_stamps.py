@@ -15,11 +15,11 @@ hip.LIB_PATH = os.environ.get("SVO_HIP_STAMPS_LIB") or os.path.join(ROOT, "build
 ctx = hip.Context(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 NS = int(os.environ.get("SVO_STAMPS_SCENES", "4"))
-fps = [synth.make_frame_pair(seed=12345 + i, n_features=2000) for i in range(NS)]
+fps = [synth.make_frame_pair(seed=12345 + i, n_features=int(os.environ.get("SVO_STAMPS_FEATURES", "2000"))) for i in range(NS)]
 cam = fps[0].cam
 ref = hip.Pyramid(ctx, cam.width, cam.height, 5, B)
 cur = hip.Pyramid(ctx, cam.width, cam.height, 5, B)
-sia = hip.SparseImgAlign(ctx, B, 2000)
+sia = hip.SparseImgAlign(ctx, B, int(os.environ.get("SVO_STAMPS_FEATURES", "2000")))
 sia.set_frames(ref, cur)
 for s in range(B):
     ref.upload(s, fps[s % NS].ref_pyr); cur.upload(s, fps[s % NS].cur_pyr); sia.upload_pair(s, fps[s % NS])
@@ -57,3 +57,18 @@ if os.environ.get("SVO_STAMPS_COUNT"):
 if os.environ.get("SVO_STAMPS_LEVELS"):
     L.svo_hip_sia_debug_x(sia.h, 0, buf)
     print("whole evaluation (eval + barriers + solve) cycles per evaluation by level 0..4 (wave 1, frame 0):", np.array(list(buf[22:27])) / 30.0)
+if os.environ.get("SVO_STAMPS_BLOCKS"):
+    cyc = np.array([sia.download(s).chi2 for s in range(B)])
+    per_scene = cyc[:NS]
+    order = np.argsort(per_scene)
+    print("workgroup cycles over the %d scenes: min %.0f  median %.0f  max %.0f   slowest scenes %s" %
+          (NS, per_scene.min(), np.median(per_scene), per_scene.max(), [(int(i), int(per_scene[i])) for i in order[-4:]]))
+if os.environ.get("SVO_STAMPS_COUNTS"):
+    rows = []
+    for s_ in range(NS):
+        r_ = sia.download(s_)
+        rows.append((s_, int(r_.chi2), int(r_.H[30]), int(r_.H[31]), int(r_.H[32])))
+    rows.sort(key=lambda t: t[1])
+    print("scene, workgroup cycles, re-factorisations of H, tile rows corrected, gone patches walked (per frame pair):")
+    for t in rows[:3] + rows[len(rows) // 2:len(rows) // 2 + 1] + rows[-6:]:
+        print("  ", t)
