@@ -890,6 +890,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
 #ifdef SVO_STAMPS
   const long long k_m0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();   // core clock / constant 100 MHz
   __shared__ long long s_stamp[10];
+  __shared__ unsigned s_cnt[4];        // re-factorisations of H, tile rows corrected, patches outside the image at those corrections
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
   __shared__ long long s_wst[16];
   if (threadIdx.x < 16) s_wst[threadIdx.x] = 0;
   if (threadIdx.x == 64) { s_stamp[0] = s_stamp[1] = s_stamp[2] = 0; s_stamp[9] = 0; }
@@ -1298,6 +1300,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           const int tile = tile_of(k);
           const int i_own = tile * TILE + lane;
           const bool gone_lane = (fl[k] & F_GONE) != 0;
+#ifdef SVO_STAMPS
+          if (lane == 0) { atomicAdd(&s_cnt[1], 1u); atomicAdd(&s_cnt[2], (unsigned)__popcll(__ballot(gone_lane))); }
+#endif
           double t = 0.0;
           if (lane < 21) t = tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane];
           const double4 G4 = sxyz[(size_t)b * max_n + (gone_lane ? i_own : 0)];            // (always a valid address)
@@ -1386,6 +1391,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         if (lane == 0) s_stamp[5] += q0 - t2;
 #endif
         if (!reuse) {
+#ifdef SVO_STAMPS
+          if (lane == 0) atomicAdd(&s_cnt[0], 1u);
+#endif
           // H changed: H^-1 is formed again (cold, out of line)
           if (lane < 21) s_Hc[lane] = v;
           fused_refactor_cold(s_Hc, s_fac, s_ftr, &s_fac_valid, s_inv, lane);
@@ -1502,7 +1510,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       for (int i = 0; i < 16; ++i) s.H[i] = (double)s_wst[i];
       for (int i = 5; i < 10; ++i) s.H[16 + i - 5] = (double)s_stamp[i];
       s.x[5] = (double)(__builtin_amdgcn_s_memtime() - k_m0) / (double)(__builtin_amdgcn_s_memrealtime() - k_r0) * 0.1;   // GHz over the kernel
-      s.chi2 = (double)(__builtin_amdgcn_s_memtime() - k_m0);                                                              // cycles of this workgroup
+      s.chi2 = (double)(__builtin_amdgcn_s_memtime() - k_m0);
+      s.H[30] = (double)s_cnt[0]; s.H[31] = (double)s_cnt[1]; s.H[32] = (double)s_cnt[2];                                                              // cycles of this workgroup
       s.x[0] = (double)s_stamp[0]; s.x[1] = (double)s_stamp[1]; s.x[2] = (double)s_stamp[2]; s.x[3] = (double)s_stamp[3]; s.x[4] = (double)s_stamp[4];
 #endif
     }
