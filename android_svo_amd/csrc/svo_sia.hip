@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           const int i_own = tile * TILE + lane;
           const bool gone_lane = (fl[k] & F_GONE) != 0;
 #ifdef SVO_STAMPS
-          if (lane == 0) { atomicAdd(&s_cnt[1], 1u); atomicAdd(&s_cnt[2], (unsigned)__popcll(__ballot(gone_lane))); }
+          { const unsigned n_out = (unsigned)__popcll(__ballot(gone_lane)); if (lane == 0) { atomicAdd(&s_cnt[1], 1u); atomicAdd(&s_cnt[2], n_out); } }
 #endif
           double t = 0.0;
           if (lane < 21) t = tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane];
