@@ -1018,6 +1018,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     for (int j = 0; j < 7; ++j) Fq[0][j] = load_row8(ref_img + pre_off[0] + j * stride);
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
+      // the younger wave of a SIMD is favoured for the first 5/8 of its tiles here as in the evaluation (see tile_of):
+      // without it the older waves sit at the barrier below while the younger ones crawl
+      if (NW == 8 && wave >= 4) { if (8 * k < 5 * my_tiles) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
       // (opaque: the store addresses derived from the tile number are formed here, per level, instead of being
       // hoisted out of the level loop into registers that then spill)
       int tile = tile_of(k);
@@ -1088,6 +1091,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       if (threadIdx.x == 64) { const long long tq2 = __builtin_amdgcn_s_memtime(); s_stamp[6] += tq1 - tq0; s_stamp[7] += tq2 - tq1; }
 #endif
     }
+    if (NW == 8) __builtin_amdgcn_s_setprio(0);
 #ifdef SVO_STAMPS
     const long long tp1 = __builtin_amdgcn_s_memtime();
 #endif
