@@ -72,3 +72,7 @@ if os.environ.get("SVO_STAMPS_COUNTS"):
     print("scene, workgroup cycles, re-factorisations of H, tile rows corrected, gone patches walked (per frame pair):")
     for t in rows[:3] + rows[len(rows) // 2:len(rows) // 2 + 1] + rows[-6:]:
         print("  ", t)
+if os.environ.get("SVO_STAMPS_XCD"):
+    cyc = np.array([sia.download(s).chi2 for s in range(B)])
+    print("mean workgroup cycles by slot %% 8 (workgroups go round the 8 XCDs): %s" % np.round(cyc.reshape(-1, 8).mean(axis=0) / 1e6, 3))
+    print("mean workgroup cycles by scene group of 8 (slot %% 64 // 8): %s" % np.round(cyc.reshape(-1, 64).mean(axis=0).reshape(8, 8).mean(axis=1) / 1e6, 3))
