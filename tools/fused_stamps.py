@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Diagnostic (not part of the product or of bench.py): run the fused SparseImgAlign kernel from a build with
 -DSVO_STAMPS (`make -C android_svo_amd/csrc stamps` -> build/libsvo_hip_stamps.so) and print where wave 1 of each workgroup spends its cycles per
-Gauss-Newton evaluation: evaluation+wave reduction / first barrier wait / sum over the waves + one-lane solve + barrier."""
+Gauss-Newton evaluation: evaluation+wave reduction / first barrier wait / sum over the waves + one-lane solve + barrier.
+
+Environment: SVO_STAMPS_SCENES (distinct synthetic scenes tiled over the batch, default 4; bench.py uses 64),
+SVO_STAMPS_FEATURES (2000), SVO_STAMPS_RUNS (launches before the one that is read: the clock settles after ~100),
+SVO_HIP_STAMPS_LIB (another stamps build), and for more output SVO_STAMPS_BLOCKS=1 (workgroup cycles per scene: the launch
+is as slow as its slowest scene), SVO_STAMPS_COUNTS=1 (per scene: re-factorisations of H, tile rows corrected, patches
+outside the image at those corrections), SVO_STAMPS_XCD=1 (workgroup cycles by XCD)."""
 import os
 import sys
 
