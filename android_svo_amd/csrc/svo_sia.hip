@@ -890,6 +890,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
 #ifdef SVO_STAMPS
   const long long k_m0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();   // core clock / constant 100 MHz
   __shared__ long long s_stamp[10];
+  __shared__ long long s_lev[SVO_HIP_MAX_LEVELS];      // whole evaluations (evaluation + barriers + solve) per level, wave 1
+  if (threadIdx.x < SVO_HIP_MAX_LEVELS) s_lev[threadIdx.x] = 0;
   __shared__ unsigned s_cnt[4];        // re-factorisations of H, tile rows corrected, patches outside the image at those corrections
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
   __shared__ long long s_wst[16];
@@ -1482,7 +1484,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         }
       }
 #ifdef SVO_STAMPS
-      if (threadIdx.x == 64) { const long long t3 = __builtin_amdgcn_s_memtime(); s_stamp[0] += t1 - t0; s_stamp[1] += t2 - t1; s_stamp[2] += t3 - t2; }
+      if (threadIdx.x == 64) { const long long t3 = __builtin_amdgcn_s_memtime(); s_lev[level] += t3 - t0; s_stamp[0] += t1 - t0; s_stamp[1] += t2 - t1; s_stamp[2] += t3 - t2; }
       if (lane == 0) { s_wst[wave] += t1 - t0; s_wst[8 + wave] += t2 - t1; }
 #endif
     }
@@ -1515,7 +1517,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       for (int i = 5; i < 10; ++i) s.H[16 + i - 5] = (double)s_stamp[i];
       s.x[5] = (double)(__builtin_amdgcn_s_memtime() - k_m0) / (double)(__builtin_amdgcn_s_memrealtime() - k_r0) * 0.1;   // GHz over the kernel
       s.chi2 = (double)(__builtin_amdgcn_s_memtime() - k_m0);
-      s.H[30] = (double)s_cnt[0]; s.H[31] = (double)s_cnt[1]; s.H[32] = (double)s_cnt[2];                                                              // cycles of this workgroup
+      s.H[30] = (double)s_cnt[0]; s.H[31] = (double)s_cnt[1]; s.H[32] = (double)s_cnt[2];
+      for (int i = 0; i < 5; ++i) s.H[21 + i] = (double)s_lev[i];                                                              // cycles of this workgroup
       s.x[0] = (double)s_stamp[0]; s.x[1] = (double)s_stamp[1]; s.x[2] = (double)s_stamp[2]; s.x[3] = (double)s_stamp[3]; s.x[4] = (double)s_stamp[4];
 #endif
     }

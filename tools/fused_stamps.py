@@ -7,7 +7,8 @@ Environment: SVO_STAMPS_SCENES (distinct synthetic scenes tiled over the batch, 
 SVO_STAMPS_FEATURES (2000), SVO_STAMPS_RUNS (launches before the one that is read: the clock settles after ~100),
 SVO_HIP_STAMPS_LIB (another stamps build), and for more output SVO_STAMPS_BLOCKS=1 (workgroup cycles per scene: the launch
 is as slow as its slowest scene), SVO_STAMPS_COUNTS=1 (per scene: re-factorisations of H, tile rows corrected, patches
-outside the image at those corrections), SVO_STAMPS_XCD=1 (workgroup cycles by XCD)."""
+outside the image at those corrections), SVO_STAMPS_XCD=1 (workgroup cycles by XCD), SVO_STAMPS_LEVELS=1 (cycles per
+evaluation by pyramid level)."""
 import os
 import sys
 
@@ -61,8 +62,8 @@ if os.environ.get("SVO_STAMPS_COUNT"):
         vals.append(buf[24] / 1e6)
     print("refactorisations per frame pair (stamp[7] / 1e6): mean %.1f min %.1f max %.1f" % (np.mean(vals), np.min(vals), np.max(vals)))
 if os.environ.get("SVO_STAMPS_LEVELS"):
-    L.svo_hip_sia_debug_x(sia.h, 0, buf)
-    print("whole evaluation (eval + barriers + solve) cycles per evaluation by level 0..4 (wave 1, frame 0):", np.array(list(buf[22:27])) / 30.0)
+    print("whole evaluation (eval + barriers + solve) cycles per evaluation by level 0..4 (wave 1, frame 0):",
+          np.array(list(sia.download(0).H[21:26])) / 30.0)
 if os.environ.get("SVO_STAMPS_BLOCKS"):
     cyc = np.array([sia.download(s).chi2 for s in range(B)])
     per_scene = cyc[:NS]
