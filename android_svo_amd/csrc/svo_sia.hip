@@ -313,6 +313,11 @@ __global__ __launch_bounds__(256) void sia_precompute_kernel(
   if (lane < TILE_ROW) tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane] = lane < 21 ? mine : 0.0;
 }
 
+// (defined with the fused kernel below)
+template <bool EXACT_ROWS>
+SVO_DEV double fused_tile_row(double x, double y, double z_inv, double jscale, double sxx, double sxy, double syy, bool contributes,
+                              int lane);
+
 // One computeResiduals(linearize=true) evaluation for every live frame.
 // grid = (chunks, n_slots), block = 256; wave w of chunk c walks tiles c*tpc + w, +4, ...
 // Output: one partial row of RED doubles per block.
@@ -347,7 +352,6 @@ __global__ __launch_bounds__(256) void sia_residual_kernel(
   const uint8_t* img = cur_base + (size_t)b * pyr_bytes + g.cur_off;
   const double jscale = fabs(cam.fx) / (1 << level);
 
-  const int tri_i = kTriI[lane < 21 ? lane : 0], tri_j = kTriJ[lane < 21 ? lane : 0];
   double accH = 0.0;                       // lane e < 21 accumulates H entry e
   double accJ[6] = {0, 0, 0, 0, 0, 0};     // lane-per-patch partial sums of Jres
   double acc_chi = 0.0;
@@ -447,26 +451,16 @@ __global__ __launch_bounds__(256) void sia_residual_kernel(
 #pragma unroll
       for (int k = 0; k < 6; ++k) accJ[k] -= A[k] * sdx + B[k] * sdy;          // Jres_ -= J*res (:273)
     }
-    // H: add the tile's precomputed row (lane e adds entry e), then take out the few linearised
-    // patches that are outside the current image at this evaluation, one at a time (wave-uniform
-    // loop, normally zero trips): H is the sum over the patches visible now, as in the reference.
+    // H: add the tile's precomputed row (lane e adds entry e), then take out the linearised patches that are outside the
+    // current image at this evaluation -- all of them at once (fused_tile_row: every lane its own point and gradient
+    // sums, one wave reduction; walking them one after the other cost ~500 cycles per patch, and a coarse level can
+    // have most of a tile outside): H is the sum over the patches visible now, as in the reference.
     if (lane < 21) accH += tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane];
-    unsigned long long gone = __ballot(jvalid && !ok);
-    while (gone) {
-      const int src = __ffsll((long long)gone) - 1;
-      gone &= gone - 1;
-      const double gx_ = __shfl(X.x, src, 64), gy_ = __shfl(X.y, src, 64), gzi = __shfl(X.w, src, 64);
-      const double4 S4 = sxyz[(size_t)b * max_n + tile_base + 16 * (src & 3) + (src >> 2)];
-      double A[6], B[6];
-      patch_jacobian_rows(gx_, gy_, gzi, jscale, A, B);
-      double Ai = A[0], Aj = A[0], Bi = B[0], Bj = B[0];
-#pragma unroll
-      for (int k = 1; k < 6; ++k) {
-        if (tri_i == k) { Ai = A[k]; Bi = B[k]; }
-        if (tri_j == k) { Aj = A[k]; Bj = B[k]; }
-      }
-      const double h = S4.x * (Ai * Aj) + S4.y * (Ai * Bj + Bi * Aj) + S4.z * (Bi * Bj);
-      if (lane < 21) accH -= h;
+    const bool gone_lane = jvalid && !ok;
+    if (__ballot(gone_lane) != 0ull) {                            // wave-uniform, normally not taken
+      const double4 S4 = sxyz[(size_t)b * max_n + (gone_lane ? tile_base + 16 * (lane & 3) + (lane >> 2) : 0)];   // (always a valid address)
+      const double out_row = fused_tile_row<true>(X.x, X.y, X.w, jscale, S4.x, S4.y, S4.z, gone_lane, lane);
+      if (lane < 21) accH -= out_row;
     }
   }
 
