@@ -54,7 +54,11 @@ Rccl& rccl() {
   const char* names[] = {"librccl.so.1", "librccl.so"};
   for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (r.lib) break; }       // a copy already in the process
   if (!r.lib) for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
-  if (!r.lib) { r.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return r; }
+  if (!r.lib) {
+    const char* e = dlerror();                                 // (one call: dlerror() clears the message it returns)
+    r.err = std::string("librccl not found: ") + (e ? e : "");
+    return r;
+  }
   r.GetUniqueId = (fn_GetUniqueId)dlsym(r.lib, "ncclGetUniqueId");
   r.CommInitRank = (fn_CommInitRank)dlsym(r.lib, "ncclCommInitRank");
   r.CommDestroy = (fn_CommDestroy)dlsym(r.lib, "ncclCommDestroy");
@@ -105,6 +109,8 @@ struct svo_hip_comm {
   size_t shm_bytes = 0, slot_bytes = 0;
   unsigned char* host = nullptr;            // page-locked staging of one slot
   double timeout_s = 60.0;
+  bool failed = false;                      // a barrier timed out: the segment's counters are no longer consistent
+  unsigned long long id = 0;                // unique per communicator object of this process (graph-replay cache key)
 };
 
 namespace {
@@ -129,13 +135,20 @@ bool shm_barrier(svo_hip_comm* c) {
   return true;
 }
 
+// a timed-out barrier leaves `arrived` incremented: the communicator is unusable from then on and says so
+int shm_timeout(svo_hip_comm* c) {
+  c->failed = true;
+  return svo_fail(c->ctx, SVO_HIP_ERR_DEVICE, "svo_hip_comm (shm)", "timed out waiting for the other ranks");
+}
+
 int shm_exchange(svo_hip_comm* c, void* dev, size_t bytes, bool reduce_f64, void* gather_dst_dev) {
   svo_hip_ctx* ctx = c->ctx;
+  if (c->failed) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_comm (shm)", "an earlier exchange timed out: destroy the communicator");
   if (bytes > c->slot_bytes) return svo_fail(ctx, SVO_HIP_ERR_INVALID, "svo_hip_comm (shm)", "message larger than the segment's slot");
   SVO_CHECK_HIP(ctx, hipMemcpyAsync(c->host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
   SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(slot(c, c->rank), c->host, bytes);
-  if (!shm_barrier(c)) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_comm (shm)", "timed out waiting for the other ranks");
+  if (!shm_barrier(c)) return shm_timeout(c);
   if (reduce_f64) {
     const size_t n = bytes / sizeof(double);
     double* acc = reinterpret_cast<double*>(c->host);
@@ -153,11 +166,19 @@ int shm_exchange(svo_hip_comm* c, void* dev, size_t bytes, bool reduce_f64, void
       SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the slot is pageable shared memory: finish before it is reused
     }
   }
-  if (!shm_barrier(c)) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_comm (shm)", "timed out waiting for the other ranks");
+  if (!shm_barrier(c)) return shm_timeout(c);
   return SVO_HIP_OK;
 }
 
+unsigned long long next_comm_id() {
+  static unsigned long long n = 0;
+  return __atomic_add_fetch(&n, 1ull, __ATOMIC_RELAXED);
+}
+
 }  // namespace
+
+unsigned long long svo_comm_id(const svo_hip_comm* c) { return c ? c->id : 0ull; }
+svo_hip_ctx* svo_comm_ctx(const svo_hip_comm* c) { return c ? c->ctx : nullptr; }
 
 // used by svo_sia.hip / svo_depth.hip
 int svo_comm_all_reduce_sum_f64(svo_hip_comm* c, double* dev, size_t count) {
@@ -207,6 +228,7 @@ int svo_hip_comm_create_rccl(svo_hip_ctx* ctx, const void* id128, int rank, int 
   if (rc != 0) return nccl_fail(ctx, "ncclCommInitRank", rc);
   svo_hip_comm* c = new svo_hip_comm;
   c->ctx = ctx; c->rank = rank; c->world = world; c->kind = 0; c->nccl = comm; c->own_nccl = true;
+  c->id = next_comm_id();
   *out = c;
   return SVO_HIP_OK;
 }
@@ -218,6 +240,7 @@ int svo_hip_comm_from_nccl(svo_hip_ctx* ctx, void* nccl_comm, int rank, int worl
   if (!r.lib) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_comm_from_nccl", r.err.c_str());
   svo_hip_comm* c = new svo_hip_comm;
   c->ctx = ctx; c->rank = rank; c->world = world; c->kind = 0; c->nccl = nccl_comm; c->own_nccl = false;
+  c->id = next_comm_id();
   *out = c;
   return SVO_HIP_OK;
 }
@@ -229,48 +252,96 @@ int svo_hip_comm_create_shm(svo_hip_ctx* ctx, const char* name, int rank, int wo
   const size_t total = kShmHeaderBytes + (size_t)world * slot_bytes;
   svo_hip_comm* c = new svo_hip_comm;
   c->ctx = ctx; c->rank = rank; c->world = world; c->kind = 1; c->shm_name = name; c->slot_bytes = slot_bytes; c->shm_bytes = total;
+  c->id = next_comm_id();
+  bool created = false;                                        // rank 0: the name exists and is ours to remove
+  auto unmap = [&]() {
+    if (c->shm) { munmap(c->shm, total); c->shm = nullptr; }
+    if (c->shm_fd >= 0) { close(c->shm_fd); c->shm_fd = -1; }
+  };
   auto fail = [&](const char* what) {
     const int rc = svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_comm_create_shm", what);
-    if (c->shm) munmap(c->shm, total);
-    if (c->shm_fd >= 0) close(c->shm_fd);
+    unmap();
+    if (created) shm_unlink(name);                             // never leave a segment behind that a later run could attach to
+    if (c->host) (void)hipHostFree(c->host);
     delete c;
     return rc;
   };
   const double t0 = now_s();
+  void* hp = nullptr;
+  if (hipHostMalloc(&hp, slot_bytes, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
+  c->host = static_cast<unsigned char*>(hp);
   if (rank == 0) {
     shm_unlink(name);                                          // a stale segment of an earlier run
     c->shm_fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
     if (c->shm_fd < 0) return fail("shm_open (create) failed");
+    created = true;
     if (ftruncate(c->shm_fd, (off_t)total) != 0) return fail("ftruncate failed");
-  } else {
-    for (;;) {                                                 // wait until rank 0 has created and sized it
-      c->shm_fd = shm_open(name, O_RDWR, 0600);
-      struct stat st;
-      if (c->shm_fd >= 0 && fstat(c->shm_fd, &st) == 0 && (size_t)st.st_size >= total) break;
-      if (c->shm_fd >= 0) { close(c->shm_fd); c->shm_fd = -1; }
-      if (now_s() - t0 > c->timeout_s) return fail("timed out waiting for rank 0's segment");
-      usleep(1000);
-    }
-  }
-  void* p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, c->shm_fd, 0);
-  if (p == MAP_FAILED) return fail("mmap failed");
-  c->shm = static_cast<unsigned char*>(p);
-  ShmHeader* h = hdr(c);
-  if (rank == 0) {
+    void* p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, c->shm_fd, 0);
+    if (p == MAP_FAILED) return fail("mmap failed");
+    c->shm = static_cast<unsigned char*>(p);
+    ShmHeader* h = hdr(c);
     h->world = (unsigned)world; h->slot_bytes = slot_bytes; h->arrived = 0; h->generation = 0;
     __atomic_store_n(&h->magic, kShmMagic, __ATOMIC_RELEASE);
-  } else {
+    if (!shm_barrier(c)) return fail("timed out at the first barrier");
+    shm_unlink(name);                                          // everybody has it mapped: the name can go
+    *out = c;
+    return SVO_HIP_OK;
+  }
+  // rank > 0: attach to the segment the name refers to.  The name may still refer to the segment of a crashed earlier
+  // run when this rank gets here first (rank 0 unlinks and recreates it): while waiting, the name is looked up again, and
+  // when it has moved to another inode this rank lets go of the dead one and attaches to the new one.
+  for (;;) {
+    if (now_s() - t0 > c->timeout_s) return fail("timed out waiting for rank 0's segment");
+    c->shm_fd = shm_open(name, O_RDWR, 0600);
+    struct stat st;
+    if (c->shm_fd < 0 || fstat(c->shm_fd, &st) != 0 || (size_t)st.st_size < total) {
+      if (c->shm_fd >= 0) { close(c->shm_fd); c->shm_fd = -1; }
+      usleep(1000);
+      continue;
+    }
+    void* p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, c->shm_fd, 0);
+    if (p == MAP_FAILED) return fail("mmap failed");
+    c->shm = static_cast<unsigned char*>(p);
+    ShmHeader* h = hdr(c);
+    auto name_moved = [&]() -> bool {                          // does the name point at another inode by now?
+      const int fd2 = shm_open(name, O_RDWR, 0600);
+      if (fd2 < 0) return false;                               // (unlinked: either rank 0 is between unlink and create, or all is well)
+      struct stat s2;
+      const bool moved = fstat(fd2, &s2) == 0 && (s2.st_ino != st.st_ino || s2.st_dev != st.st_dev);
+      close(fd2);
+      return moved;
+    };
+    bool restart = false;
     while (__atomic_load_n(&h->magic, __ATOMIC_ACQUIRE) != kShmMagic) {
       if (now_s() - t0 > c->timeout_s) return fail("timed out waiting for rank 0 to initialise the segment");
+      if (name_moved()) { restart = true; break; }
       usleep(1000);
     }
-    if (h->world != (unsigned)world || h->slot_bytes != slot_bytes) return fail("segment geometry differs from this rank's arguments");
+    if (!restart) {
+      if (h->world != (unsigned)world || h->slot_bytes != slot_bytes) {
+        if (!name_moved()) return fail("segment geometry differs from this rank's arguments");
+        restart = true;
+      }
+    }
+    if (!restart) {
+      // first barrier, with the same look-out (a stale segment has its magic set: this is where a rank would sit)
+      const unsigned gen = __atomic_load_n(&h->generation, __ATOMIC_ACQUIRE);
+      if (__atomic_add_fetch(&h->arrived, 1u, __ATOMIC_ACQ_REL) == (unsigned)world) {
+        __atomic_store_n(&h->arrived, 0u, __ATOMIC_RELAXED);
+        __atomic_add_fetch(&h->generation, 1u, __ATOMIC_RELEASE);
+      } else {
+        double t_check = now_s();
+        while (__atomic_load_n(&h->generation, __ATOMIC_ACQUIRE) == gen) {
+          const double t = now_s();
+          if (t - t0 > c->timeout_s) return fail("timed out at the first barrier");
+          if (t - t_check > 0.01) { t_check = t; if (name_moved()) { restart = true; break; } }
+          usleep(20);
+        }
+      }
+    }
+    if (!restart) break;
+    unmap();
   }
-  void* hp = nullptr;
-  if (hipHostMalloc(&hp, slot_bytes, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
-  c->host = static_cast<unsigned char*>(hp);
-  if (!shm_barrier(c)) { (void)hipHostFree(hp); c->host = nullptr; return fail("timed out at the first barrier"); }
-  if (rank == 0) shm_unlink(name);                             // everybody has it mapped: the name can go
   *out = c;
   return SVO_HIP_OK;
 }

@@ -118,5 +118,7 @@ inline svo_dev::Cam svo_make_cam(const svo_hip_camera& c) {
 struct svo_hip_comm;
 int svo_comm_all_reduce_sum_f64(svo_hip_comm* c, double* dev, size_t count);
 int svo_comm_all_gather(svo_hip_comm* c, void* recv_dev, size_t bytes_per_rank);     // rank r's block at recv_dev + r * bytes, in place
+unsigned long long svo_comm_id(const svo_hip_comm* c);        // unique per communicator object (never reused within a process)
+svo_hip_ctx* svo_comm_ctx(const svo_hip_comm* c);
 extern "C" int svo_hip_comm_info(const svo_hip_comm* c, int* rank, int* world, int* kind);
 

@@ -854,7 +854,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
     const double* __restrict__ f, const double* __restrict__ pos, const uint8_t* __restrict__ has_point,
     double4* __restrict__ sxyz, double* __restrict__ tile_h, float4* __restrict__ wmem, int max_tiles, FusedParams prm,
-    int tiles_young, int n_extra) {
+    int tiles_young, int n_extra, const int* __restrict__ slots) {
   using Plan = FusedPlan<TPW, CK>;
   // the LDS left over holds one more tile -- the first one the plan keeps in memory -- for the first n_extra waves
   // (kernels whose waves own five or six tiles are register-bound: for them the extra LDS slot and the deferred
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   if (threadIdx.x == 0) { for (int i = 3; i < 9; ++i) s_stamp[i] = 0; }
 #endif
 
-  const int b = blockIdx.x;
+  const int b = slots ? slots[blockIdx.x] : (int)blockIdx.x;   // a mixed launch hands over the list of its slots (run_fused)
   const FrameConst& c = fc[b];
   LeanCam cam;
   cam.fx = c.cam.fx; cam.fy = c.cam.fy; cam.cx = c.cam.cx; cam.cy = c.cam.cy;
@@ -1545,6 +1545,9 @@ struct svo_hip_sia {
   FrameConst* h_fc = nullptr;
   bool fc_dirty = true;
   int shard_rank = 0, shard_world = 1;
+  // tuning / diagnostic switches of this object (svo_hip_sia_set_option); 0 / -1 = automatic
+  int opt_mode = 0, opt_waves = 0, opt_chunks = 0, opt_extra_lds = -1, opt_old_tiles = 0;
+  int* slot_list = nullptr;          // device [2][batch]: slots of a mixed launch (fused kernel, see run_fused)
   // stepwise state
   svo_hip_sia_params prm{};
   int n_slots = 0, level = -1, chunks = 1;
@@ -1558,7 +1561,20 @@ struct svo_hip_sia {
   // {accumulate, all-reduce, solve_update}), valid for the configuration in graph_key
   bool sharded_graph = false;
   hipGraphExec_t level_graph[SVO_HIP_MAX_LEVELS] = {nullptr};
-  struct { const void* comm; int n_slots, n_iter, early_stop, max_level, min_level, rank, world; double eps; const void *ref, *cur, *reduce; } graph_key = {};
+  struct GraphKey {
+    unsigned long long comm_id = 0;            // svo_comm_id: never reused, unlike the communicator's address
+    int n_slots = 0, n_iter = 0, early_stop = 0, max_level = 0, min_level = 0, rank = 0, world = 0, chunks = 0;
+    double eps = 0.0;
+    const void *ref_base = nullptr, *cur_base = nullptr, *reduce = nullptr;
+    int width = 0, height = 0;
+    size_t pyr_bytes = 0;
+    bool operator==(const GraphKey& o) const {     // field by field: the struct has padding
+      return comm_id == o.comm_id && n_slots == o.n_slots && n_iter == o.n_iter && early_stop == o.early_stop &&
+             max_level == o.max_level && min_level == o.min_level && rank == o.rank && world == o.world && chunks == o.chunks &&
+             eps == o.eps && ref_base == o.ref_base && cur_base == o.cur_base && reduce == o.reduce && width == o.width &&
+             height == o.height && pyr_bytes == o.pyr_bytes;
+    }
+  } graph_key;
 };
 
 namespace {
@@ -1578,11 +1594,10 @@ int dev_alloc(svo_hip_ctx* ctx, T** p, size_t count) {
 
 // blocks per frame for the residual kernel: aim at >= ~1024 blocks (4096 waves) on the chip while
 // giving every wave as many tiles as possible (the per-wave reduction is amortised over them)
-int pick_chunks(int n_slots, int max_n) {
-  const char* env = getenv("SVO_HIP_SIA_CHUNKS");
+int pick_chunks(const svo_hip_sia* s, int n_slots, int max_n) {
   int tiles = (max_n + TILE - 1) / TILE;
   int cap = (tiles + 3) / 4;                 // at least one tile per wave
-  int c = env ? atoi(env) : (1024 + n_slots - 1) / n_slots;
+  int c = s->opt_chunks > 0 ? s->opt_chunks : (1024 + n_slots - 1) / n_slots;
   if (c > cap) c = cap;
   if (c > MAX_CHUNKS) c = MAX_CHUNKS;
   if (c < 1) c = 1;
@@ -1610,26 +1625,11 @@ int flush_fc(svo_hip_sia* s) {
   return SVO_HIP_OK;
 }
 
-// The fused kernel handles frames whose footprints fit in one CU's LDS and that are not patch-sharded.
-int fused_tiles_per_wave(const svo_hip_sia* s, int n_slots) {
-  const char* env = getenv("SVO_HIP_SIA_MODE");
-  if (env && strcmp(env, "stream") == 0) return 0;
-  if (s->shard_world != 1) return 0;
-  int max_n = 0;
-  for (int i = 0; i < n_slots; ++i) max_n = s->h_fc[i].n_feat > max_n ? s->h_fc[i].n_feat : max_n;
-  const int tiles = (max_n + TILE - 1) / TILE;
-  if (tiles > FUSED_MAX_TILES) return 0;
-  // tiles per SIMD, split between its older and its younger wave (see tile_of in the kernel); returns the older share
-  const int per_simd = (tiles + 3) / 4;
-  int old_share = (per_simd + 1) / 2;
-  const char* ovr = getenv("SVO_HIP_SIA_OLD_TILES");                     // diagnostic override
-  if (ovr && atoi(ovr) >= (per_simd + 1) / 2 && atoi(ovr) <= per_simd && atoi(ovr) <= FUSED_MAX_TPW) old_share = atoi(ovr);
-  static_assert(FUSED_MAX_TPW * 2 * 4 >= FUSED_MAX_TILES, "dispatch covers every tile count");
-  return old_share < 1 ? 1 : old_share;
-}
-
+// One launch of the fused kernel over n_launch frame pairs: slots [0, n_launch) when slots_dev is null, else the
+// listed ones.
 template <int NW, int TPW, int CK, bool EXACT_ROWS>
-int launch_fused_x(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes, int tiles_young, int n_extra) {
+int launch_fused_x(svo_hip_sia* s, int n_launch, const int* slots_dev, const svo_hip_sia_params* prm, size_t lds_bytes,
+                   int tiles_young, int n_extra = 0) {
   svo_hip_ctx* ctx = s->ctx;
   // > 64 KiB of dynamic LDS has to be allowed explicitly (per device: set it on every launch, it is cheap)
   SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<NW, TPW, CK, EXACT_ROWS>),
@@ -1643,23 +1643,11 @@ int launch_fused_x(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, s
   FusedParams fp;
   fp.max_level = prm->max_level; fp.min_level = prm->min_level; fp.n_iter = prm->n_iter;
   fp.early_stop = prm->early_stop; fp.eps = prm->eps;
-  hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
-  if (ev) (void)hipEventRecord(ev[0], ctx->stream);
-  hipLaunchKernelGGL((sia_fused_kernel<NW, TPW, CK, EXACT_ROWS>), dim3(n_slots), dim3(NW * 64), lds_bytes, ctx->stream, s->fc, s->st,
+  hipLaunchKernelGGL((sia_fused_kernel<NW, TPW, CK, EXACT_ROWS>), dim3(n_launch), dim3(NW * 64), lds_bytes, ctx->stream, s->fc, s->st,
                      s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, s->tile_h,
-                     s->wmem, s->max_tiles, fp, tiles_young, n_extra);
-  if (ev) (void)hipEventRecord(ev[1], ctx->stream);
+                     s->wmem, s->max_tiles, fp, tiles_young, n_extra, slots_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
-}
-
-// the exact Hessian rows for a batch that holds a frame with a handful of patches (see sia_fused_kernel)
-template <int NW, int TPW, int CK>
-int launch_fused_t(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, size_t lds_bytes, int tiles_young, int n_extra = 0) {
-  bool tiny = false;
-  for (int i = 0; i < n_slots; ++i) tiny = tiny || (s->h_fc[i].n_feat > 0 && s->h_fc[i].n_feat < FUSED_EXACT_ROW_BELOW);
-  return tiny ? launch_fused_x<NW, TPW, CK, true>(s, n_slots, prm, lds_bytes, tiles_young, n_extra)
-              : launch_fused_x<NW, TPW, CK, false>(s, n_slots, prm, lds_bytes, tiles_young, n_extra);
 }
 
 // LDS tiles (8 KiB) the 8-wave shape can hold beyond ck per wave: what 160 KiB leave next to the kernel's static LDS
@@ -1686,7 +1674,74 @@ int fused_extra_tiles(int tpw, int ck) {
   }
 }
 
-int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tpw) {
+// tiles per SIMD of the largest frame of a launch -> the older wave's share of them (see tile_of in the kernel)
+int fused_old_share(const svo_hip_sia* s, int max_n, int* per_simd_out) {
+  const int tiles = max_n > 0 ? (max_n + TILE - 1) / TILE : 1;
+  const int per_simd = (tiles + 3) / 4;
+  int old_share = (per_simd + 1) / 2;
+  const int ovr = s->opt_old_tiles;                                      // diagnostic override
+  if (ovr > 0 && ovr >= (per_simd + 1) / 2 && ovr <= per_simd && ovr <= FUSED_MAX_TPW) old_share = ovr;
+  static_assert(FUSED_MAX_TPW * 2 * 4 >= FUSED_MAX_TILES, "dispatch covers every tile count");
+  *per_simd_out = per_simd;
+  return old_share < 1 ? 1 : old_share;
+}
+
+// The shape of the fused kernel for a launch of n_launch pairs whose largest frame has max_n patches (factored Hessian rows).
+int launch_fused_shape(svo_hip_sia* s, int n_launch, const int* slots_dev, int max_n, const svo_hip_sia_params* prm) {
+  svo_hip_ctx* ctx = s->ctx;
+  int per_simd = 1;
+  const int tpw = fused_old_share(s, max_n, &per_simd);
+  // Two frame pairs per CU (4-wave workgroups) when the launch has at least two pairs for every CU and a wave can hold
+  // a quarter of the tiles: the one-lane solve phase of one pair then overlaps the evaluation of the other.
+  // (measured with 512 pairs per launch: 200 patches 715 k against 444 k frames/s, 500: 549 k / 393 k, 1000: 314 k /
+  // 277 k; at 2000 patches a wave would own 8 tiles and their {x,y,z,1/z} no longer fit in 256 VGPRs: 97 k / 163 k)
+  bool four = n_launch >= 2 * ctx->n_cu && per_simd <= 4;
+  if (s->opt_waves) four = s->opt_waves == 4 && per_simd <= 4;          // diagnostic override: 4 or 8
+  if (four) {
+    const size_t lds4 = (size_t)4 * (per_simd < 2 ? 1 : 2) * FUSED_WC_BYTES;
+    switch (per_simd) {                                                // tiles per wave (3 runs as 4 with an empty slot)
+      case 1: return launch_fused_x<4, 1, 1, false>(s, n_launch, slots_dev, prm, lds4, 0);
+      case 2: return launch_fused_x<4, 2, 2, false>(s, n_launch, slots_dev, prm, lds4, 0);
+      case 3:
+      case 4: return launch_fused_x<4, 4, 2, false>(s, n_launch, slots_dev, prm, lds4, 0);
+      default: break;
+    }
+  }
+  const int ty = per_simd - tpw;             // the younger wave's share of a SIMD's tiles
+  SVO_REQUIRE(ctx, ty >= 0 && ty <= tpw);
+  // two tiles per wave keep their interpolated patches in LDS (8 waves x 2 x 8 KiB), the others in memory
+  const int ck = tpw < 2 ? tpw : 2;
+  int n_extra = tpw > ck ? fused_extra_tiles(tpw, ck) : 0;
+  if (s->opt_extra_lds >= 0) n_extra = tpw > ck ? s->opt_extra_lds : 0;   // diagnostic override
+  if (n_extra < 0 || n_extra > (tpw > ck ? fused_extra_tiles(tpw, ck) : 0)) n_extra = 0;
+  const size_t lds = (size_t)(FUSED_WAVES * ck + n_extra) * FUSED_WC_BYTES;
+  switch (tpw) {                 // tiles of an older wave
+    case 1: return launch_fused_x<8, 1, 1, false>(s, n_launch, slots_dev, prm, lds, ty);
+    case 2: return launch_fused_x<8, 2, 2, false>(s, n_launch, slots_dev, prm, lds, ty);
+    case 3: return launch_fused_x<8, 3, 2, false>(s, n_launch, slots_dev, prm, lds, ty, n_extra);
+    case 4: return launch_fused_x<8, 4, 2, false>(s, n_launch, slots_dev, prm, lds, ty, n_extra);
+    case 5: return launch_fused_x<8, 5, 2, false>(s, n_launch, slots_dev, prm, lds, ty, n_extra);
+    case 6: return launch_fused_x<8, 6, 2, false>(s, n_launch, slots_dev, prm, lds, ty, n_extra);
+    default: break;
+  }
+  return svo_fail(ctx, SVO_HIP_ERR_INVALID, "fused SparseImgAlign", "unsupported tiles-per-wave");
+}
+
+// The fused kernel handles frames of at most FUSED_MAX_TILES tiles that are not patch-sharded.
+bool fused_applies(const svo_hip_sia* s, int n_slots) {
+  if (s->opt_mode == SVO_HIP_SIA_MODE_STREAM) return false;
+  if (s->shard_world != 1) return false;
+  int max_n = 0;
+  for (int i = 0; i < n_slots; ++i) max_n = s->h_fc[i].n_feat > max_n ? s->h_fc[i].n_feat : max_n;
+  return (max_n + TILE - 1) / TILE <= FUSED_MAX_TILES;
+}
+
+// Frames with a handful of patches (fewer than FUSED_EXACT_ROW_BELOW) need the entry-by-entry Hessian rows (EXACT_ROWS,
+// see sia_fused_kernel); that instance spills hundreds of registers, so it only ever runs for those frames: a batch that
+// holds some is split into two launches on the same stream -- the listed tiny slots with the exact instance, every
+// other slot with the shape its own largest frame asks for.  A frame's result therefore does not depend on whether a
+// tiny frame shares its batch (it still depends on the shape, i.e. on the largest frame and the number of pairs).
+int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) {
   svo_hip_ctx* ctx = s->ctx;
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   SVO_REQUIRE(ctx, s->ref && s->cur);
@@ -1696,47 +1751,33 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int tp
   SVO_REQUIRE(ctx, s->ref->pyr_bytes == s->cur->pyr_bytes);
   int rc = flush_fc(s);
   if (rc != SVO_HIP_OK) return rc;
-  int max_n = 0;
-  for (int i = 0; i < n_slots; ++i) max_n = s->h_fc[i].n_feat > max_n ? s->h_fc[i].n_feat : max_n;
-  const int tiles = max_n > 0 ? (max_n + TILE - 1) / TILE : 1;
   s->begun = false;
   s->last_mode = 1;
-  // Two frame pairs per CU (4-wave workgroups) when the launch has at least two pairs for every CU and a wave can hold
-  // a quarter of the tiles: the one-lane solve phase of one pair then overlaps the evaluation of the other.
-  const char* wv = getenv("SVO_HIP_SIA_WAVES");                        // diagnostic override: 4 or 8
-  const int per_simd = (tiles + 3) / 4;
-  // (measured with 512 pairs per launch: 200 patches 715 k against 444 k frames/s, 500: 549 k / 393 k, 1000: 314 k /
-  // 277 k; at 2000 patches a wave would own 8 tiles and their {x,y,z,1/z} no longer fit in 256 VGPRs: 97 k / 163 k)
-  bool four = n_slots >= 2 * ctx->n_cu && per_simd <= 4;
-  if (wv) four = atoi(wv) == 4 && per_simd <= 4;
-  if (four) {
-    const size_t lds4 = (size_t)4 * (per_simd < 2 ? 1 : 2) * FUSED_WC_BYTES;
-    switch (per_simd) {                                                // tiles per wave (3 runs as 4 with an empty slot)
-      case 1: return launch_fused_t<4, 1, 1>(s, n_slots, prm, lds4, 0);
-      case 2: return launch_fused_t<4, 2, 2>(s, n_slots, prm, lds4, 0);
-      case 3:
-      case 4: return launch_fused_t<4, 4, 2>(s, n_slots, prm, lds4, 0);
-      default: break;
+  int n_tiny = 0, max_rest = 0;
+  for (int i = 0; i < n_slots; ++i) {
+    const int n = s->h_fc[i].n_feat;
+    if (n > 0 && n < FUSED_EXACT_ROW_BELOW) ++n_tiny;
+    else if (n > max_rest) max_rest = n;
+  }
+  hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
+  if (ev) (void)hipEventRecord(ev[0], ctx->stream);
+  if (n_tiny == 0) {
+    rc = launch_fused_shape(s, n_slots, nullptr, max_rest, prm);
+  } else {
+    std::vector<int> lists((size_t)2 * s->batch);
+    int n_rest = 0, n_t = 0;
+    for (int i = 0; i < n_slots; ++i) {
+      const int n = s->h_fc[i].n_feat;
+      if (n > 0 && n < FUSED_EXACT_ROW_BELOW) lists[(size_t)s->batch + n_t++] = i; else lists[n_rest++] = i;
     }
+    // (pageable source: staged by the runtime before the call returns)
+    SVO_CHECK_HIP(ctx, hipMemcpyAsync(s->slot_list, lists.data(), sizeof(int) * lists.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (n_rest > 0) rc = launch_fused_shape(s, n_rest, s->slot_list, max_rest, prm);
+    if (rc == SVO_HIP_OK)       // one tile: wave 0 of an 8-wave workgroup owns it
+      rc = launch_fused_x<8, 1, 1, true>(s, n_t, s->slot_list + s->batch, prm, (size_t)FUSED_WAVES * FUSED_WC_BYTES, 0);
   }
-  const int ty = per_simd - tpw;             // the younger wave's share of a SIMD's tiles
-  SVO_REQUIRE(ctx, ty >= 0 && ty <= tpw);
-  // two tiles per wave keep their interpolated patches in LDS (8 waves x 2 x 8 KiB), the others in memory
-  const int ck = tpw < 2 ? tpw : 2;
-  int n_extra = tpw > ck ? fused_extra_tiles(tpw, ck) : 0;
-  { const char* ex = getenv("SVO_HIP_SIA_EXTRA_LDS"); if (ex) n_extra = tpw > ck ? atoi(ex) : 0; }   // diagnostic override
-  if (n_extra < 0 || n_extra > (tpw > ck ? fused_extra_tiles(tpw, ck) : 0)) n_extra = 0;
-  const size_t lds = (size_t)(FUSED_WAVES * ck + n_extra) * FUSED_WC_BYTES;
-  switch (tpw) {                 // tiles of an older wave
-    case 1: return launch_fused_t<8, 1, 1>(s, n_slots, prm, lds, ty);
-    case 2: return launch_fused_t<8, 2, 2>(s, n_slots, prm, lds, ty);
-    case 3: return launch_fused_t<8, 3, 2>(s, n_slots, prm, lds, ty, n_extra);
-    case 4: return launch_fused_t<8, 4, 2>(s, n_slots, prm, lds, ty, n_extra);
-    case 5: return launch_fused_t<8, 5, 2>(s, n_slots, prm, lds, ty, n_extra);
-    case 6: return launch_fused_t<8, 6, 2>(s, n_slots, prm, lds, ty, n_extra);
-    default: break;
-  }
-  return svo_fail(ctx, SVO_HIP_ERR_INVALID, "fused SparseImgAlign", "unsupported tiles-per-wave");
+  if (ev) (void)hipEventRecord(ev[1], ctx->stream);
+  return rc;
 }
 
 }  // namespace
@@ -1764,6 +1805,7 @@ int svo_hip_sia_create(svo_hip_ctx* ctx, int batch, int max_features, svo_hip_si
   A(dev_alloc(ctx, &s->partial, (size_t)batch * MAX_CHUNKS * RED));
   A(dev_alloc(ctx, &s->reduce_own, (size_t)batch * RED));
   A(dev_alloc(ctx, &s->n_pre_count, batch));
+  A(dev_alloc(ctx, &s->slot_list, (size_t)2 * batch));
   s->h_fc = new (std::nothrow) FrameConst[batch];
   if (rc != SVO_HIP_OK || !s->h_fc) { svo_hip_sia_destroy(s); return rc != SVO_HIP_OK ? rc : SVO_HIP_ERR_NOMEM; }
   memset(s->h_fc, 0, sizeof(FrameConst) * batch);
@@ -1785,7 +1827,7 @@ int svo_hip_sia_destroy(svo_hip_sia* s) {
   (void)hipStreamSynchronize(ctx->stream);
   drop_level_graphs(s);
   void* ptrs[] = {s->fc, s->st, s->px, s->f, s->pos, s->has_point, s->visible, s->ref_cache, s->dxc, s->dyc,
-                  s->sxyz, s->xyz4, s->tile_h, s->wmem, s->partial, s->reduce_own, s->n_pre_count};
+                  s->sxyz, s->xyz4, s->tile_h, s->wmem, s->partial, s->reduce_own, s->n_pre_count, s->slot_list};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev_res) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_pre) (void)hipEventDestroy(e);
@@ -1865,7 +1907,7 @@ int svo_hip_sia_begin(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm
   int rc = flush_fc(s);
   if (rc != SVO_HIP_OK) return rc;
   s->prm = *prm; s->n_slots = n_slots; s->level = -1; s->begun = true;
-  s->chunks = pick_chunks(n_slots, s->max_n);
+  s->chunks = pick_chunks(s, n_slots, s->max_n);
   SVO_CHECK_HIP(ctx, hipMemsetAsync(s->visible, 0, (size_t)n_slots * s->max_n, ctx->stream));
   SVO_CHECK_HIP(ctx, hipMemsetAsync(s->n_pre_count, 0, sizeof(unsigned) * n_slots, ctx->stream));
   hipLaunchKernelGGL(sia_begin_kernel, dim3((n_slots + 63) / 64), dim3(64), 0, ctx->stream, s->fc, s->st, n_slots);
@@ -1959,10 +2001,9 @@ int svo_hip_sia_finish(svo_hip_sia* s) {
 
 int svo_hip_sia_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) {
   if (!s || !prm) return SVO_HIP_ERR_INVALID;
-  if (n_slots > 0 && n_slots <= s->batch) {
-    const int tpw = fused_tiles_per_wave(s, n_slots);
-    if (tpw > 0) return run_fused(s, n_slots, prm, tpw);
-  }
+  if (s->shard_world != 1)     // (svo_hip_sia_run_sharded / the step-wise entry points are the sharded forms)
+    return svo_fail(s->ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_run", "a patch shard is set on this solver: the whole solve needs the all-reduce of svo_hip_sia_run_sharded");
+  if (n_slots > 0 && n_slots <= s->batch && fused_applies(s, n_slots)) return run_fused(s, n_slots, prm);
   s->last_mode = 0;
   int rc = svo_hip_sia_begin(s, n_slots, prm);
   if (rc != SVO_HIP_OK) return rc;
@@ -1994,14 +2035,9 @@ static int sharded_level(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, const 
   return SVO_HIP_OK;
 }
 
-int svo_hip_sia_run_sharded(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, const svo_hip_sia_params* prm) {
-  if (!s || !comm || !prm) return SVO_HIP_ERR_INVALID;
+static int run_sharded_levels(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, const svo_hip_sia_params* prm, int rank, int world, int kind) {
   svo_hip_ctx* ctx = s->ctx;
-  int rank = 0, world = 1, kind = 0;
-  svo_hip_comm_info(comm, &rank, &world, &kind);
-  int rc = svo_hip_sia_set_shard(s, rank, world);
-  if (rc != SVO_HIP_OK) return rc;
-  rc = svo_hip_sia_begin(s, n_slots, prm);
+  int rc = svo_hip_sia_begin(s, n_slots, prm);
   if (rc != SVO_HIP_OK) return rc;
   // Graph replay (opt-in, RCCL transport only: the host-staged transport blocks the host and cannot be captured): the
   // launch sequence of a level does not depend on the data -- finished frames are skipped inside the kernels -- so it
@@ -2009,9 +2045,15 @@ int svo_hip_sia_run_sharded(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, con
   // per Gauss-Newton step), not device time.
   const bool graph = s->sharded_graph && kind == 0 && !s->profiling;
   if (graph) {
-    const decltype(s->graph_key) key = {comm, n_slots, prm->n_iter, prm->early_stop, prm->max_level, prm->min_level, rank, world, prm->eps,
-                                        s->ref, s->cur, s->reduce};
-    if (memcmp(&key, &s->graph_key, sizeof(key)) != 0) { drop_level_graphs(s); s->graph_key = key; }
+    // everything the captured nodes have baked in: the communicator (by its never-reused id, not its address), the
+    // launch geometry, the buffers and the pyramids
+    svo_hip_sia::GraphKey key;
+    key.comm_id = svo_comm_id(comm);
+    key.n_slots = n_slots; key.n_iter = prm->n_iter; key.early_stop = prm->early_stop; key.max_level = prm->max_level;
+    key.min_level = prm->min_level; key.rank = rank; key.world = world; key.chunks = s->chunks; key.eps = prm->eps;
+    key.ref_base = s->ref->base; key.cur_base = s->cur->base; key.reduce = s->reduce;
+    key.width = s->ref->width; key.height = s->ref->height; key.pyr_bytes = s->ref->pyr_bytes;
+    if (!(key == s->graph_key)) { drop_level_graphs(s); s->graph_key = key; }
   }
   for (int level = prm->max_level; level >= prm->min_level; --level) {
     if (!graph) {
@@ -2035,6 +2077,36 @@ int svo_hip_sia_run_sharded(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, con
     SVO_CHECK_HIP(ctx, hipGraphLaunch(s->level_graph[level], ctx->stream));
   }
   return svo_hip_sia_finish(s);
+}
+
+int svo_hip_sia_run_sharded(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, const svo_hip_sia_params* prm) {
+  if (!s || !comm || !prm) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = s->ctx;
+  // the collective is enqueued on the communicator's stream, the kernels on the solver's: they must be the same one
+  SVO_REQUIRE(ctx, svo_comm_ctx(comm) == s->ctx);
+  int rank = 0, world = 1, kind = 0;
+  svo_hip_comm_info(comm, &rank, &world, &kind);
+  // the shard of this call only: whatever svo_hip_sia_set_shard left on the object is back in place afterwards, on the
+  // error paths too (a later svo_hip_sia_run must not see a shard it never asked for)
+  const int old_rank = s->shard_rank, old_world = s->shard_world;
+  int rc = svo_hip_sia_set_shard(s, rank, world);
+  if (rc == SVO_HIP_OK) rc = run_sharded_levels(s, comm, n_slots, prm, rank, world, kind);
+  s->shard_rank = old_rank; s->shard_world = old_world;
+  return rc;
+}
+
+int svo_hip_sia_set_option(svo_hip_sia* s, int option, int value) {
+  if (!s) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = s->ctx;
+  switch (option) {
+    case SVO_HIP_SIA_OPT_MODE: SVO_REQUIRE(ctx, value == SVO_HIP_SIA_MODE_AUTO || value == SVO_HIP_SIA_MODE_STREAM); s->opt_mode = value; break;
+    case SVO_HIP_SIA_OPT_WAVES: SVO_REQUIRE(ctx, value == 0 || value == 4 || value == 8); s->opt_waves = value; break;
+    case SVO_HIP_SIA_OPT_CHUNKS: SVO_REQUIRE(ctx, value >= 0 && value <= MAX_CHUNKS); s->opt_chunks = value; break;
+    case SVO_HIP_SIA_OPT_EXTRA_LDS: SVO_REQUIRE(ctx, value >= -1 && value <= FUSED_EXTRA_TILES); s->opt_extra_lds = value; break;
+    case SVO_HIP_SIA_OPT_OLD_TILES: SVO_REQUIRE(ctx, value >= 0 && value <= FUSED_MAX_TPW); s->opt_old_tiles = value; break;
+    default: return svo_fail(ctx, SVO_HIP_ERR_INVALID, "svo_hip_sia_set_option", "unknown option");
+  }
+  return SVO_HIP_OK;
 }
 
 int svo_hip_sia_set_sharded_graph(svo_hip_sia* s, int enable) {
@@ -2142,7 +2214,7 @@ int svo_hip_sia_download_caches(svo_hip_sia* s, int slot, float* ref_patch, floa
   // the per-pixel caches exist only in the streaming implementation: after a fused run they would be stale
   if (s->last_mode == 1)
     return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_download_caches",
-                    "the last run used the fused kernel, which keeps no per-pixel caches in memory (use the step-wise entry points or SVO_HIP_SIA_MODE=stream)");
+                    "the last run used the fused kernel, which keeps no per-pixel caches in memory (use the step-wise entry points or SVO_HIP_SIA_OPT_MODE = SVO_HIP_SIA_MODE_STREAM)");
   const size_t o = (size_t)slot * s->max_n;
   const int n = s->h_fc[slot].n_feat;
   int rc = SVO_HIP_OK;

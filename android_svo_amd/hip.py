@@ -19,6 +19,13 @@ REDUCE_DOUBLES = 32
 
 SEED_BEHIND, SEED_NOT_IN_FRAME, SEED_NO_MATCH, SEED_UPDATED, SEED_CONVERGED, SEED_NAN = range(6)
 
+# svo_hip_sia_set_option (per solver object; the library itself reads no environment variable)
+SIA_OPT_MODE, SIA_OPT_WAVES, SIA_OPT_CHUNKS, SIA_OPT_EXTRA_LDS, SIA_OPT_OLD_TILES = range(5)
+SIA_MODE_AUTO, SIA_MODE_STREAM = 0, 1
+# options every SparseImgAlign object created from now on starts with: {option: value}.  Test fixtures and A/B scripts
+# set this (a Python-side default, applied per object through the C-ABI).
+SIA_DEFAULT_OPTIONS: dict = {}
+
 
 class SvoHipError(RuntimeError):
     pass
@@ -202,6 +209,15 @@ class SparseImgAlign:
         self.ctx, self.batch, self.max_features = ctx, batch, max_features
         self.h = C.c_void_p()
         ctx.check(ctx.lib.svo_hip_sia_create(ctx.h, batch, max_features, C.byref(self.h)), "sia_create")
+        for opt, val in SIA_DEFAULT_OPTIONS.items():
+            self.set_option(opt, val)
+
+    def set_option(self, option: int, value: int):
+        self.ctx.check(self.ctx.lib.svo_hip_sia_set_option(self.h, int(option), int(value)), "sia_set_option")
+
+    def set_mode(self, stream: bool):
+        """svo_hip_sia_run: True = always the streaming kernels, False = automatic (the fused kernel where it applies)"""
+        self.set_option(SIA_OPT_MODE, SIA_MODE_STREAM if stream else SIA_MODE_AUTO)
 
     def set_frames(self, ref: Pyramid, cur: Pyramid):
         self.ref, self.cur = ref, cur
@@ -465,7 +481,7 @@ class SeedBatch:
 
     def free(self):
         for d in (self.px, self.f, self.level, self.a, self.b, self.mu, self.z_range, self.sigma2, self.status, self.z,
-                  self.xyz, self.n_zmssd, self.n_align, self.px_cur, self.search_level):
+                  self.xyz, self.n_zmssd, self.n_align, self.px_cur, self.search_level) + tuple(getattr(self, "_blocks", ())):
             d.free()
 
 
@@ -504,6 +520,7 @@ def pack_seed_state(sb: "SeedBatch"):
         getattr(sb, name).free()
         setattr(sb, name, DeviceView(ctx, block.ptr + 4 * n * k, (n,), np.float32))
     pristine = ctx.to_device(host)
+    sb._blocks = (block, pristine)        # freed with the batch
     return block, pristine
 
 

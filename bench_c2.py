@@ -33,6 +33,73 @@ def timed(ctx, fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+def measure_align2d(ctx, patches=5000, steps=20, warmup=3):
+    """feature_alignment::align2D over `patches` 8x8 patches resident in HBM (BASELINE config C2, first half).  Returns the
+    result dict and the case (for the CPU leg)."""
+    ac = seedsynth.make_align_case(n=patches)
+    pyr = hip.Pyramid(ctx, ac.cam.width, ac.cam.height, 5, 1)
+    pyr.upload(0, ac.cur_pyr)
+    d_pwb = ctx.to_device(ac.pwb)
+    d_px0 = ctx.to_device(ac.px_init)
+    d_px = ctx.empty(ac.px_init.shape, np.float64)
+    d_conv = ctx.empty((patches,), np.uint8)
+    d_it = ctx.empty((patches,), np.int32)
+
+    def run_align():
+        # restore the initial estimates (device to device) then refine
+        ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(d_px.ptr), C.c_void_p(d_px0.ptr), C.c_size_t(d_px.nbytes)), "d2d")
+        ctx.check(ctx.lib.svo_hip_align2d_batch_dev(ctx.h, pyr.h, 0, 0, patches, C.c_void_p(d_pwb.ptr), None, 10,
+                                                    C.c_void_p(d_px.ptr), C.c_void_p(d_conv.ptr), C.c_void_p(d_it.ptr)), "align2d")
+    t_align = timed(ctx, run_align, steps, warmup)
+    iters = d_it.download()
+    alg_align = float(np.sum(197 + 81 * iters))
+    res = {"patches": patches, "patches_per_s": patches / t_align, "us_per_batch": t_align * 1e6,
+           "converged": int(d_conv.download().sum()), "mean_iters": float(iters.mean()),
+           "algorithmic_bytes": alg_align, "algorithmic_GBps": alg_align / t_align / 1e9,
+           "frac_hbm": alg_align / t_align / 1e9 / HBM_PEAK_GBS}
+    for d in (d_pwb, d_px0, d_px, d_conv, d_it):
+        d.free()
+    pyr.destroy()
+    return res, ac
+
+
+def measure_depth_filter(ctx, seeds=100000, steps=20, warmup=3, width=640, height=480, sigma_scale=None, compact=False):
+    """One DepthFilter::updateSeeds pass over `seeds` seeds resident in HBM (BASELINE config C2, second half; with
+    width=1280, height=720, seeds=1000000, compact=True the one-GPU form of config C4: the pass plus the on-device packing
+    of the converged records, i.e. everything but the exchange).  Returns (result dict, case, SeedBatch, pyramids)."""
+    sc = seedsynth.make_seed_case(n_seeds=seeds, seed=9, width=width, height=height)
+    kf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
+    cf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
+    kf.upload(0, sc.ref_pyr)
+    cf.upload(0, sc.cur_pyr)
+    sigma2 = sc.sigma2 if sigma_scale is None else (sc.sigma2 * np.float32(sigma_scale)).astype(np.float32)
+    sb = hip.SeedBatch(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, sigma2)
+    state, state0 = hip.pack_seed_state(sb)          # a | b | mu | sigma2 in one block: one copy restores all seeds
+    rec = cnt = None
+    if compact:
+        rec, cnt = ctx.empty((seeds, 6), np.float64), ctx.empty((1,), np.int32)
+
+    def run_df():
+        # same seed state every step (one 16 B/seed device-to-device copy), then the pass
+        ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(state.ptr), C.c_void_p(state0.ptr), C.c_size_t(state.nbytes)), "d2d")
+        hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb)
+        if compact:
+            ctx.check(ctx.lib.svo_hip_seed_compact_converged_dev(ctx.h, seeds, C.c_longlong(0), C.c_void_p(sb.status.ptr), C.c_void_p(sb.mu.ptr),
+                                                                 C.c_void_p(sb.sigma2.ptr), C.c_void_p(sb.xyz.ptr), C.c_void_p(rec.ptr),
+                                                                 C.c_void_p(cnt.ptr)), "seed_compact_converged")
+    t_df = timed(ctx, run_df, steps, warmup)
+    nz, na, st = sb.n_zmssd.download(), sb.n_align.download(), sb.status.download()
+    alg_df = float(np.sum(44 + 56 + 100 + 64 * nz.astype(np.int64) + 81 * na.astype(np.int64)))
+    res = {"seeds": seeds, "image": "%dx%d" % (width, height), "seeds_per_s": seeds / t_df, "us_per_frame": t_df * 1e6,
+           "status_counts": np.bincount(st, minlength=6).tolist(), "mean_zmssd": float(nz.mean()),
+           "mean_align_iters": float(na.mean()), "algorithmic_bytes": alg_df,
+           "algorithmic_GBps": alg_df / t_df / 1e9, "frac_hbm": alg_df / t_df / 1e9 / HBM_PEAK_GBS}
+    if compact:
+        res["converged_records_packed"] = int(cnt.download()[0])
+        rec.free(); cnt.free()
+    return res, sc, sb, (kf, cf)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--patches", type=int, default=5000)
@@ -47,48 +114,10 @@ def main():
     out = {"config": {"workload": "C2: align2D x %d patches + DepthFilter update x %d seeds, 640x480" % (args.patches, args.seeds)}}
 
     # ---------------- align2D ----------------
-    ac = seedsynth.make_align_case(n=args.patches)
-    pyr = hip.Pyramid(ctx, ac.cam.width, ac.cam.height, 5, 1)
-    pyr.upload(0, ac.cur_pyr)
-    d_pwb = ctx.to_device(ac.pwb)
-    d_px0 = ctx.to_device(ac.px_init)
-    d_px = ctx.empty(ac.px_init.shape, np.float64)
-    d_conv = ctx.empty((args.patches,), np.uint8)
-    d_it = ctx.empty((args.patches,), np.int32)
-
-    def run_align():
-        # restore the initial estimates (device to device) then refine
-        ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(d_px.ptr), C.c_void_p(d_px0.ptr), C.c_size_t(d_px.nbytes)), "d2d")
-        ctx.check(ctx.lib.svo_hip_align2d_batch_dev(ctx.h, pyr.h, 0, 0, args.patches, C.c_void_p(d_pwb.ptr), None, 10,
-                                                    C.c_void_p(d_px.ptr), C.c_void_p(d_conv.ptr), C.c_void_p(d_it.ptr)), "align2d")
-    t_align = timed(ctx, run_align, args.steps, args.warmup)
-    iters = d_it.download()
-    alg_align = float(np.sum(197 + 81 * iters))
-    out["align2d"] = {"patches_per_s": args.patches / t_align, "us_per_batch": t_align * 1e6,
-                      "converged": int(d_conv.download().sum()), "mean_iters": float(iters.mean()),
-                      "algorithmic_bytes": alg_align, "algorithmic_GBps": alg_align / t_align / 1e9,
-                      "frac_hbm": alg_align / t_align / 1e9 / HBM_PEAK_GBS}
+    out["align2d"], ac = measure_align2d(ctx, args.patches, args.steps, args.warmup)
 
     # ---------------- depth filter ----------------
-    sc = seedsynth.make_seed_case(n_seeds=args.seeds, seed=9)
-    kf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
-    cf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
-    kf.upload(0, sc.ref_pyr)
-    cf.upload(0, sc.cur_pyr)
-    sb = hip.SeedBatch(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, sc.sigma2)
-    state, state0 = hip.pack_seed_state(sb)          # a | b | mu | sigma2 in one block: one copy restores all seeds
-
-    def run_df():
-        # same seed state every step (one 16 B/seed device-to-device copy), then the pass
-        ctx.check(ctx.lib.svo_hip_copy_d2d(ctx.h, C.c_void_p(state.ptr), C.c_void_p(state0.ptr), C.c_size_t(state.nbytes)), "d2d")
-        hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb)
-    t_df = timed(ctx, run_df, args.steps, args.warmup)
-    nz, na, st = sb.n_zmssd.download(), sb.n_align.download(), sb.status.download()
-    alg_df = float(np.sum(44 + 56 + 100 + 64 * nz.astype(np.int64) + 81 * na.astype(np.int64)))
-    out["depth_filter"] = {"seeds_per_s": args.seeds / t_df, "us_per_frame": t_df * 1e6,
-                           "status_counts": np.bincount(st, minlength=6).tolist(), "mean_zmssd": float(nz.mean()),
-                           "mean_align_iters": float(na.mean()), "algorithmic_bytes": alg_df,
-                           "algorithmic_GBps": alg_df / t_df / 1e9, "frac_hbm": alg_df / t_df / 1e9 / HBM_PEAK_GBS}
+    out["depth_filter"], sc, sb, (kf, cf) = measure_depth_filter(ctx, args.seeds, args.steps, args.warmup)
 
     # pure Bayes update (44 B/seed)
     n = args.seeds

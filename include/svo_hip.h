@@ -143,7 +143,9 @@ int svo_hip_sia_upload_features(svo_hip_sia* sia, int slot, int n, const double*
 int svo_hip_sia_upload_poses(svo_hip_sia* sia, int slot, const svo_hip_camera* cam,
                              const double T_ref_w[7], const double T_cur_w_init[7]);
 /* Only patches [n*rank/world, n*(rank+1)/world) of every frame are evaluated by this process;
- * the per-frame sums must then be all-reduced across ranks between accumulate and solve_update. */
+ * the per-frame sums must then be all-reduced across ranks between accumulate and solve_update (step-wise entry
+ * points).  svo_hip_sia_run returns SVO_HIP_ERR_STATE while world != 1: a whole solve over one shard without the
+ * exchange would be a different problem. */
 int svo_hip_sia_set_shard(svo_hip_sia* sia, int rank, int world);
 
 /* ---- multi-GPU exchange: the reference has none; these entries let the C++ host shard the path ----
@@ -167,7 +169,9 @@ int svo_hip_comm_info(const svo_hip_comm* comm, int* rank, int* world, int* kind
  * rank evaluates patches [n*rank/world, n*(rank+1)/world) of every slot, ONE all-reduce of n_slots x
  * SVO_HIP_REDUCE_DOUBLES doubles per Gauss-Newton step on the context stream, then the identical solve on every rank.
  * Every rank must hold the same features, poses and pyramids and call this with the same arguments; all ranks end
- * with the same result (svo_hip_sia_download). */
+ * with the same result (svo_hip_sia_download).  comm must have been created on the solver's context (one stream for
+ * kernels and collective).  The shard is in force for this call only: a shard set with svo_hip_sia_set_shard is back
+ * in place when it returns. */
 int svo_hip_sia_run_sharded(svo_hip_sia* sia, svo_hip_comm* comm, int n_slots, const svo_hip_sia_params* prm);
 /* Opt-in: replay the per-level launch sequence of svo_hip_sia_run_sharded (level_begin + n_iter x {accumulate,
  * all-reduce, solve_update}) from one HIP graph per pyramid level, captured at the first call of a configuration (RCCL
@@ -194,12 +198,26 @@ int svo_hip_sia_finish(svo_hip_sia* sia);
 int svo_hip_sia_reduce_buffer(svo_hip_sia* sia, void** dev_ptr, size_t* n_doubles);
 /* use a caller-owned device buffer instead (e.g. a torch tensor that RCCL all-reduces in place) */
 int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
+/* Tuning / diagnostic switches of ONE solver object (the library reads no environment variable and keeps no
+ * process-wide switch: two host threads with two solvers do not see each other's settings).  0 = automatic unless
+ * stated otherwise. */
+#define SVO_HIP_SIA_OPT_MODE 0          /* SVO_HIP_SIA_MODE_AUTO, or SVO_HIP_SIA_MODE_STREAM: svo_hip_sia_run always uses the streaming kernels */
+#define SVO_HIP_SIA_OPT_WAVES 1         /* fused kernel: waves per frame pair, 0 (automatic), 4 or 8 */
+#define SVO_HIP_SIA_OPT_CHUNKS 2        /* streaming residual kernel: workgroups per frame, 0 (automatic) .. 64 */
+#define SVO_HIP_SIA_OPT_EXTRA_LDS 3     /* fused kernel: waves with a third tile in LDS, -1 (automatic) .. 3 */
+#define SVO_HIP_SIA_OPT_OLD_TILES 4     /* fused kernel: tiles of the older wave of a SIMD, 0 (automatic) .. 6 */
+#define SVO_HIP_SIA_MODE_AUTO 0
+#define SVO_HIP_SIA_MODE_STREAM 1
+int svo_hip_sia_set_option(svo_hip_sia* sia, int option, int value);
+
 /* Which implementation the last svo_hip_sia_run used: 1 = the fused kernel (one workgroup per frame pair,
  * interpolated reference patches in LDS / L2-resident memory, whole coarse-to-fine loop in one launch; chosen
  * when every frame has at most 2816 features and no patch shard is set; launches with at least two frame pairs
  * per compute unit and at most 1024 features per frame use its 4-wave shape, two pairs per compute unit),
  * 0 = the streaming kernels (one launch per Gauss-Newton evaluation; always used by the step-wise entry
- * points).  SVO_HIP_SIA_MODE=stream forces 0. */
+ * points).  svo_hip_sia_set_option(SVO_HIP_SIA_OPT_MODE, SVO_HIP_SIA_MODE_STREAM) forces 0.  A batch that holds
+ * frames with fewer than 16 patches runs as two launches (those frames with the entry-by-entry Hessian rows a
+ * rank-deficient system needs, the others as if the tiny frames were not there). */
 int svo_hip_sia_last_run_mode(svo_hip_sia* sia, int* mode);
 /* Optional timing of the two heavy kernels with HIP events recorded on the context stream around
  * each launch (precompute: one per level; residual: one per Gauss-Newton evaluation; in fused mode the single
@@ -210,7 +228,7 @@ int svo_hip_sia_set_profiling(svo_hip_sia* sia, int enable);
 int svo_hip_sia_get_profile(svo_hip_sia* sia, double* residual_ms, uint64_t* residual_launches,
                             double* precompute_ms, uint64_t* precompute_launches);
 /* cached reference patches / per-patch Jacobian records of one slot, for kernel-level tests (filled by the
- * streaming kernels, i.e. after the step-wise entry points or a run with SVO_HIP_SIA_MODE=stream):
+ * streaming kernels, i.e. after the step-wise entry points or a run in SVO_HIP_SIA_MODE_STREAM):
  * ref_patch[n][16] f32, dx[n][16] f32, dy[n][16] f32, visible[n] u8 (any may be NULL).  Returns SVO_HIP_ERR_STATE when
  * the last svo_hip_sia_run used the fused kernel (it keeps no per-pixel caches in memory). */
 int svo_hip_sia_download_caches(svo_hip_sia* sia, int slot, float* ref_patch, float* dx, float* dy,

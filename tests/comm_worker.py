@@ -55,6 +55,9 @@ def main():
             res[tag + "_n"] = np.array([x.n_tracked for x in r])
             res[tag + "_H"] = np.array([list(x.H) for x in r])
             res[tag + "_iters"] = np.array([list(x.iters)[:5] for x in r])
+            # the shard was in force for the sharded call only: a plain run on the same object is the whole problem again
+            sia.run(len(fps), prm)
+            res[tag + "_T_plain"] = np.array([list(x.T_cur_w) for x in sia.download_all(len(fps))])
         np.savez(out, **res)
     else:
         sc = seedsynth.make_seed_case(n_seeds=6000, seed=13)

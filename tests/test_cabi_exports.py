@@ -55,3 +55,29 @@ def test_product_package_never_imports_the_oracle():
                     not re.search(r"^\s*(from|import)\s+oracle|#include\s+\".*oracle", src, flags=re.M), fn
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
                 assert "svo_oracle" not in src, fn
+
+
+def test_missing_librccl_is_an_error_code_not_a_crash(tmp_path):
+    """A deployment without a loadable librccl (the single-GPU case the header promises "needs no RCCL at all"):
+    svo_hip_comm_unique_id must return SVO_HIP_ERR_DEVICE.  The library is hidden from a child process by a preloaded
+    dlopen that fails for every name containing "rccl"; the child calls the entry point twice (the failure is cached)."""
+    import subprocess
+    import sys
+    shim_c = tmp_path / "hide_rccl.c"
+    shim_c.write_text(
+        '#define _GNU_SOURCE\n#include <dlfcn.h>\n#include <string.h>\n'
+        'void* dlopen(const char* name, int flags) {\n'
+        '  static void* (*real)(const char*, int);\n'
+        '  if (!real) real = (void* (*)(const char*, int))dlsym(RTLD_NEXT, "dlopen");\n'
+        '  if (name && strstr(name, "rccl")) return 0;   /* and no dlerror() text: the worst case for the caller */\n'
+        '  return real(name, flags);\n}\n')
+    shim = tmp_path / "hide_rccl.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", str(shim_c), "-o", str(shim), "-ldl"])
+    code = ("import ctypes as C\n"
+            "lib = C.CDLL(%r)\n"
+            "buf = C.create_string_buffer(128)\n"
+            "print(lib.svo_hip_comm_unique_id(buf), lib.svo_hip_comm_unique_id(buf))\n" % hip.LIB_PATH)
+    env = dict(os.environ, LD_PRELOAD=str(shim))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-500:])
+    assert r.stdout.split() == ["-2", "-2"], r.stdout

@@ -47,6 +47,9 @@ def _check_sia(results):
             np.testing.assert_array_equal(r[tag + "_H"], results[0][tag + "_H"])
             np.testing.assert_array_equal(r[tag + "_iters"], results[0][tag + "_iters"])
         for s, fp in enumerate(fps):
+            # svo_hip_sia_run on the same object afterwards: no shard left behind (whole frames, frame-parallel kernel)
+            rot, trans = synth.pose_error(results[0][tag + "_T_plain"][s], results[0][tag + "_T"][s])
+            assert rot < 2e-5 and trans < 5e-5, (tag, s, rot, trans)
             o = orc.sparse_img_align(fp, n_iter=n_iter, early_stop=es)
             rot, trans = synth.pose_error(results[0][tag + "_T"][s], np.array(o.T_cur_w))
             assert rot < 1e-4 and trans < 1e-3, (tag, s, rot, trans)             # north_star tolerance

@@ -28,16 +28,15 @@ def sia_mode(request):
     """svo_hip_sia_run has two implementations (one fused launch per run / one launch per Gauss-Newton
     evaluation), and the fused kernel two shapes (8 waves per frame pair; 4 waves, two pairs per CU, which large
     launches of small frames get -- forced here); every run()-level parity test is executed against all three."""
-    old = os.environ.get("SVO_HIP_SIA_MODE")
-    os.environ["SVO_HIP_SIA_MODE"] = "fused" if request.param == "fused4" else request.param
+    old = dict(hip.SIA_DEFAULT_OPTIONS)
+    hip.SIA_DEFAULT_OPTIONS.clear()
+    if request.param == "stream":
+        hip.SIA_DEFAULT_OPTIONS[hip.SIA_OPT_MODE] = hip.SIA_MODE_STREAM
     if request.param == "fused4":
-        os.environ["SVO_HIP_SIA_WAVES"] = "4"
+        hip.SIA_DEFAULT_OPTIONS[hip.SIA_OPT_WAVES] = 4
     yield "fused" if request.param == "fused4" else request.param
-    os.environ.pop("SVO_HIP_SIA_WAVES", None)
-    if old is None:
-        os.environ.pop("SVO_HIP_SIA_MODE", None)
-    else:
-        os.environ["SVO_HIP_SIA_MODE"] = old
+    hip.SIA_DEFAULT_OPTIONS.clear()
+    hip.SIA_DEFAULT_OPTIONS.update(old)
 
 
 def _upload_pair(ctx, fps, max_feat=None):
@@ -250,6 +249,58 @@ def test_batch_ragged_and_empty(ctx, sia_mode):
     _free(sia, ref, cur)
 
 
+def test_tiny_frame_in_a_batch_does_not_change_the_other_frames(ctx):
+    """A frame with fewer than 16 patches needs the entry-by-entry Hessian rows (a rank-deficient system); svo_hip_sia_run
+    launches that kernel instance for those slots only.  The largest frame of the batch must come out bit for bit as when
+    it is solved alone (same kernel shape either way), the other frames within the tolerance of their oracle runs, and
+    the tiny frame must still follow its own oracle run."""
+    specs = [(1200, 0), (5, 0), (700, 3), (0, 0), (12, 0)]
+    fps = [synth.make_frame_pair(seed=610 + i, n_features=max(n, 1), null_point_every=k) for i, (n, k) in enumerate(specs)]
+    ref, cur, sia = _upload_pair(ctx, fps, max_feat=1200)
+    empty = synth.FramePair(fps[0].cam, fps[3].ref_pyr, fps[3].cur_pyr, np.zeros((0, 2)), np.zeros((0, 3)), np.zeros((0, 3)),
+                            np.zeros(0, dtype=np.uint8), fps[3].T_ref_w, fps[3].T_cur_w_true, fps[3].T_cur_w_init)
+    sia.upload_pair(3, empty)
+    for early in (True, False):
+        prm = sia.params(early_stop=early, n_iter=30 if early else 8)
+        sia.run(len(fps), prm)
+        assert sia.last_run_mode() == 1
+        res = sia.download_all(len(fps))
+        ref1, cur1, sia1 = _upload_pair(ctx, [fps[0]], max_feat=1200)
+        sia1.run(1, prm)
+        alone = sia1.download(0)
+        _free(sia1, ref1, cur1)
+        np.testing.assert_array_equal(np.array(res[0].T_cur_w), np.array(alone.T_cur_w))
+        np.testing.assert_array_equal(np.array(res[0].H), np.array(alone.H))
+        assert list(res[0].iters) == list(alone.iters)
+        for i in (0, 1, 2, 4):
+            o = orc.sparse_img_align(fps[i], early_stop=early, n_iter=prm.n_iter)
+            got, want = np.array(res[i].T_cur_w), np.array(o.T_cur_w)
+            if np.isnan(want).any():
+                assert np.isnan(got).any(), i
+                continue
+            rot, trans = synth.pose_error(got, want)
+            assert rot < 1e-4 and trans < 1e-3, (i, early, rot, trans)
+            assert res[i].n_tracked == o.n_tracked, i
+        assert res[3].n_tracked == 0
+        np.testing.assert_array_equal(np.array(res[3].T_cur_w), fps[3].T_cur_w_init)
+    _free(sia, ref, cur)
+
+
+def test_run_with_a_shard_set_is_a_state_error(ctx):
+    """svo_hip_sia_run over one patch shard without the exchange would silently solve another problem: it is refused."""
+    fp = synth.make_frame_pair(seed=52, n_features=300)
+    ref, cur, sia = _upload_pair(ctx, [fp])
+    sia.set_shard(1, 2)
+    with pytest.raises(hip.SvoHipError):
+        sia.run(1, sia.params())
+    sia.set_shard(0, 1)
+    sia.run(1, sia.params())
+    o = orc.sparse_img_align(fp)
+    rot, trans = synth.pose_error(np.array(sia.download(0).T_cur_w), np.array(o.T_cur_w))
+    assert rot < 1e-4 and trans < 1e-3
+    _free(sia, ref, cur)
+
+
 def test_stepwise_equals_run_and_sharded_sum(ctx):
     """The step-wise entry points reproduce the streaming run() bit for bit and the fused run() to
     summation-order noise, and two patch shards whose reduce rows are added (what the all-reduce does
@@ -257,13 +308,13 @@ def test_stepwise_equals_run_and_sharded_sum(ctx):
     fp = synth.make_frame_pair(seed=51, n_features=700)
     ref, cur, sia = _upload_pair(ctx, [fp])
     prm = sia.params()
-    os.environ["SVO_HIP_SIA_MODE"] = "fused"
+    sia.set_mode(stream=False)
     sia.run(1, prm)
     fused = sia.download(0)
-    os.environ["SVO_HIP_SIA_MODE"] = "stream"
+    sia.set_mode(stream=True)
     sia.run(1, prm)
     whole = sia.download(0)
-    os.environ.pop("SVO_HIP_SIA_MODE")
+    sia.set_mode(stream=False)
     rot, trans = synth.pose_error(np.array(fused.T_cur_w), np.array(whole.T_cur_w))
     assert rot < 1e-6 and trans < 1e-6
     sia.begin(1, prm)
@@ -476,8 +527,7 @@ def test_large_launch_of_small_frames_picks_two_pairs_per_cu(ctx):
     """C0-sized frames (200 patches) in a launch with more than two pairs per compute unit: svo_hip_sia_run chooses
     the 4-wave shape of the fused kernel by itself (no environment override); every slot agrees with the oracle run of
     its scene, replicas and repeated runs agree bit for bit."""
-    os.environ.pop("SVO_HIP_SIA_WAVES", None)
-    os.environ.pop("SVO_HIP_SIA_MODE", None)
+    assert not hip.SIA_DEFAULT_OPTIONS
     fps = [synth.make_frame_pair(seed=777 + i, n_features=200, width=320, height=240) for i in range(6)]
     B = 528
     ref, cur, sia = _upload_pair(ctx, [fps[i % 6] for i in range(B)])

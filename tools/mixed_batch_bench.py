@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""A 256-pair C1 batch (2000 patches each, fixed work) against the same batch with ONE frame replaced by a 5-patch frame:
+svo_hip_sia_run launches the entry-by-entry Hessian-row instance for that slot only (run_fused in svo_sia.hip), so the
+mixed batch must run within a few per cent of the pure one.  Diagnostic; prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from android_svo_amd import hip, synth  # noqa: E402
+
+
+def main():
+    B, N, steps = 256, 2000, 20
+    ctx = hip.Context(0)
+    fps = [synth.make_frame_pair(seed=12345 + i, n_features=N) for i in range(16)]
+    tiny = synth.make_frame_pair(seed=999, n_features=5)
+    cam = fps[0].cam
+    ref = hip.Pyramid(ctx, cam.width, cam.height, 5, B)
+    cur = hip.Pyramid(ctx, cam.width, cam.height, 5, B)
+    sia = hip.SparseImgAlign(ctx, B, N)
+    sia.set_frames(ref, cur)
+    for s in range(B):
+        fp = fps[s % len(fps)]
+        ref.upload(s, fp.ref_pyr); cur.upload(s, fp.cur_pyr); sia.upload_pair(s, fp)
+    prm = sia.params(early_stop=False)
+
+    def timed():
+        for _ in range(3):
+            sia.run(B, prm)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sia.run(B, prm)
+        ctx.sync()
+        return (time.perf_counter() - t0) / steps * 1e3
+    pure = timed()
+    ref.upload(100, tiny.ref_pyr); cur.upload(100, tiny.cur_pyr); sia.upload_pair(100, tiny)
+    mixed = timed()
+    print(json.dumps({"what": "256 x C1 frame pairs, fixed work; slot 100 replaced by a 5-patch frame", "pure_ms_per_launch": pure,
+                      "mixed_ms_per_step": mixed, "ratio": mixed / pure}))
+
+
+if __name__ == "__main__":
+    main()

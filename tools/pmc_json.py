@@ -1,9 +1,19 @@
 #!/usr/bin/env python3
 """Turn the text written by tools/pmc_pass.sh (per-kernel means of rocprofv3 --pmc counters) into JSON.
 Usage: tools/pmc_json.py in.txt out.json "<command the passes profiled>" """
+import hashlib
 import json
+import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the sources the profiled kernels are compiled from: bench.py refuses a profile whose hashes differ from the tree's
+PROFILED_SOURCES = ("android_svo_amd/csrc/svo_sia.hip", "android_svo_amd/csrc/svo_device_math.h", "android_svo_amd/csrc/Makefile")
+
+
+def source_sha256():
+    return {os.path.basename(f): hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest() for f in PROFILED_SOURCES}
 
 
 def main():
@@ -21,7 +31,7 @@ def main():
             cur = line.strip()
             kernels.setdefault(cur, {})
     json.dump({"command": cmd, "unit": "counter value per dispatch (mean over the dispatches of the pass)",
-               "kernels": kernels}, open(dst, "w"), indent=1)
+               "source_sha256": source_sha256(), "kernels": kernels}, open(dst, "w"), indent=1)
     print(dst, {k: len(v) - 1 for k, v in kernels.items()})
 
 
