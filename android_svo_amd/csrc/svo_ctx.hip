@@ -40,6 +40,23 @@ __global__ void half_sample_kernel(const uint8_t* __restrict__ in, int w, int h,
 
 }  // namespace
 
+int svo_ctx_fork(svo_hip_ctx* ctx) {
+  if (!ctx->aux_stream) {
+    SVO_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    SVO_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    SVO_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  SVO_CHECK_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  SVO_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+  return SVO_HIP_OK;
+}
+
+int svo_ctx_join(svo_hip_ctx* ctx) {
+  SVO_CHECK_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
+  SVO_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  return SVO_HIP_OK;
+}
+
 extern "C" {
 
 const char* svo_hip_version(void) { return "svo_hip 0.1 (gfx950)"; }
@@ -77,6 +94,9 @@ int svo_hip_ctx_create(svo_hip_ctx** out, int device, void* stream) {
 int svo_hip_ctx_destroy(svo_hip_ctx* ctx) {
   if (!ctx) return SVO_HIP_ERR_INVALID;
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->staging) (void)hipFree(ctx->staging);
   if (ctx->host_staging) (void)hipHostFree(ctx->host_staging);

@@ -20,6 +20,9 @@ struct svo_hip_ctx {
   size_t staging_bytes = 0;
   void* host_staging = nullptr;     // grow-only page-locked host mirror of it: one transfer each way per call
   size_t host_staging_bytes = 0;
+  // side stream + fork / join events (created on first use): small launches that may overlap the main one
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   char err[512] = {0};
 };
 
@@ -103,6 +106,11 @@ inline int svo_ctx_host_staging(svo_hip_ctx* ctx, size_t need, char** out) {
   *out = static_cast<char*>(ctx->host_staging);
   return SVO_HIP_OK;
 }
+
+// side stream of the context (svo_ctx.hip): work enqueued between svo_ctx_fork and svo_ctx_join on ctx->aux_stream starts
+// after everything already on the context stream and is complete before anything enqueued on it after the join
+int svo_ctx_fork(svo_hip_ctx* ctx);
+int svo_ctx_join(svo_hip_ctx* ctx);
 
 inline svo_dev::Cam svo_make_cam(const svo_hip_camera& c) {
   svo_dev::Cam d;

@@ -341,3 +341,79 @@ def flatten_cells(case, cells):
         off[c + 1] = off[c] + len(r)
     ids = np.concatenate([r for r in cells]) if off[-1] else np.zeros(0, dtype=np.int64)
     return off, ids.astype(np.int64)
+
+
+def make_map_case(seed: int = 31, width: int = 320, height: int = 240, n_kf: int = 14, n_points: int = 1400, n_candidates: int = 150,
+                  cell_size: int = 20, edgelet_frac: float = 0.04, kf_step: float = 0.16):
+    """A small svo::Map as index tables (what Reprojector::reprojectMap walks, S/reprojector.cpp:72-168): n_kf keyframes along
+    a trajectory over a textured plane -- more than the ten the reprojector uses, some of them far from the current frame
+    -- map points with one to several observations (Point::obs_ order: newest keyframe first, as addFrameRef pushes to
+    the front), keyframe feature lists in a shuffled order, point candidates (one observation, in no feature list), a few
+    deleted points that are still referenced, counters close to the deletion / promotion thresholds, a few edgelets.
+    Observation o lies in keyframe obs_kf[o] and belongs to point obs_point[o]; the observations of a point are stored
+    contiguously (pt_obs_offset)."""
+    rng = np.random.default_rng(seed)
+    cam = Camera(width, height, 250.0 * width / 320, 250.0 * width / 320, width / 2 - 0.5, height / 2 - 0.5)
+    scene = PlaneScene(seed=seed, depth=2.0, tilt=(0.08, -0.05))
+    kf_poses = []
+    for k in range(n_kf):
+        # a sideways trajectory: the far keyframes no longer see what the current frame sees
+        t = np.array([kf_step * (k - n_kf // 2), 0.03 * np.sin(k), 0.02 * k]) + rng.uniform(-0.02, 0.02, 3)
+        kf_poses.append(se3_from_twist(t, rng.uniform(-0.03, 0.03, 3)))
+    T_cur_w = se3_mul(se3_from_twist(rng.uniform(-0.03, 0.03, 3), rng.uniform(-0.015, 0.015, 3)), kf_poses[n_kf // 2 + 1])
+    kf_pyr = [build_pyramid(scene.render(cam, T)) for T in kf_poses]
+    cur_pyr = build_pyramid(scene.render(cam, T_cur_w))
+    n_all = n_points + n_candidates
+    home = rng.integers(0, n_kf, n_all)
+    px_home = np.stack([rng.uniform(8, width - 8, n_all), rng.uniform(8, height - 8, n_all)], axis=1)
+    pos = np.zeros((n_all, 3))
+    for k in range(n_kf):
+        m = home == k
+        if m.any():
+            pos[m] = scene.intersect(cam, kf_poses[k], px_home[m, 0], px_home[m, 1])
+    pos[:n_points] += rng.normal(0, 0.004, (n_points, 3))                       # map points are not exactly on the surface
+    ptype = rng.choice([TYPE_UNKNOWN, TYPE_UNKNOWN, TYPE_GOOD, TYPE_GOOD, TYPE_DELETED], n_all, p=[0.3, 0.3, 0.19, 0.19, 0.02]).astype(np.int32)
+    ptype[n_points:] = TYPE_CANDIDATE
+    n_failed = np.where(ptype == TYPE_UNKNOWN, rng.integers(12, 17, n_all), rng.integers(24, 32, n_all)).astype(np.int32)
+    n_succ = rng.integers(8, 12, n_all).astype(np.int32)
+    obs_point, obs_kf, obs_px, obs_level = [], [], [], []
+    pt_obs_offset = [0]
+    for p in range(n_all):
+        kfs_p = [int(home[p])]
+        if p < n_points:
+            for k in range(n_kf):
+                if k != home[p] and abs(k - home[p]) <= 3 and rng.uniform() < 0.45:
+                    kfs_p.append(k)
+        for k in sorted(kfs_p, reverse=True):                                   # obs_.push_front: newest first
+            if k == home[p]:
+                px = px_home[p]
+            else:
+                Xc = se3_act(kf_poses[k], pos[p])
+                px = np.array([cam.fx * Xc[0] / Xc[2] + cam.cx, cam.fy * Xc[1] / Xc[2] + cam.cy]) + rng.uniform(-0.3, 0.3, 2)
+                if not (4 <= px[0] < width - 4 and 4 <= px[1] < height - 4):
+                    continue
+            obs_point.append(p); obs_kf.append(k); obs_px.append(px); obs_level.append(int(rng.choice([0, 0, 1, 2])))
+        pt_obs_offset.append(len(obs_point))
+    obs_point, obs_kf = np.array(obs_point, np.int32), np.array(obs_kf, np.int32)
+    obs_px, obs_level = np.array(obs_px), np.array(obs_level, np.int32)
+    obs_f = np.ascontiguousarray(cam2world(cam, obs_px))
+    obs_edgelet = (rng.uniform(size=len(obs_point)) < edgelet_frac).astype(np.uint8)
+    ang = rng.uniform(0, 2 * np.pi, len(obs_point))
+    obs_grad = np.stack([np.cos(ang), np.sin(ang)], axis=1)
+    obs_grad[obs_edgelet == 0] = [1.0, 0.0]
+    # keyframe feature lists (fts_ order): the observations that lie in the keyframe, shuffled; candidates' features are in none
+    kf_ftr_offset, kf_ftr_obs = [0], []
+    for k in range(n_kf):
+        o = np.where((obs_kf == k) & (obs_point < n_points))[0]
+        rng.shuffle(o)
+        kf_ftr_obs.extend(o.tolist())
+        kf_ftr_offset.append(len(kf_ftr_obs))
+    kf_ftr_obs = np.array(kf_ftr_obs, np.int32)
+    cand_point = np.arange(n_points, n_all, dtype=np.int32)
+    rng.shuffle(cand_point)
+    cand_obs = np.array([pt_obs_offset[p] for p in cand_point], np.int32)
+    return dict(cam=cam, cell_size=cell_size, kf_pyr=kf_pyr, cur_pyr=cur_pyr, T_kf_w=np.stack(kf_poses), T_cur_w=T_cur_w, n_kf=n_kf,
+                n_points=n_all, pt_pos=pos, pt_type=ptype, pt_n_failed=n_failed, pt_n_succeeded=n_succ,
+                pt_obs_offset=np.array(pt_obs_offset, np.int32), obs_point=obs_point, obs_kf=obs_kf, obs_px=obs_px, obs_f=obs_f,
+                obs_level=obs_level, obs_edgelet=obs_edgelet, obs_grad=obs_grad, kf_ftr_offset=np.array(kf_ftr_offset, np.int32),
+                kf_ftr_obs=kf_ftr_obs, kf_ftr_point=obs_point[kf_ftr_obs].astype(np.int32), cand_point=cand_point, cand_obs=cand_obs)

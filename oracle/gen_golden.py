@@ -397,6 +397,29 @@ def gen_reproject_ref():
     np.savez_compressed(os.path.join(OUT, "reproject_ref.npz"), **out)
 
 
+MAP_REF_CASES = (("near", dict(seed=31), 1200), ("cap", dict(seed=31), 40), ("wide", dict(seed=32, n_kf=9, n_points=900, n_candidates=60, cell_size=25, kf_step=0.55), 1200))
+
+
+def gen_reproject_map_ref():
+    """The WHOLE Reprojector::reprojectMap executed by the reference's own compiled code on a real svo::Map with keyframes,
+    multi-observation points and point candidates (oracle/ref/ref_objects.cpp: ref_reproject_map): close-keyframe
+    selection and ordering, the projection into grid cells, the candidate loop, the cell loop with its bookkeeping.
+    Stored: the key points Frame::setKeyPoints chose (an input of the restatement) and every output."""
+    out = {}
+    for tag, kw, max_fts in MAP_REF_CASES:
+        cs = synth.make_map_case(**kw)
+        r = refpy.reproject_map(cs, max_fts=max_fts)
+        out[tag + "_crc"] = np.array([crc(cs["cur_pyr"][0]), crc(cs["obs_px"]), crc(cs["pt_pos"]), crc(cs["kf_ftr_obs"])], dtype=np.uint64)
+        out[tag + "_n"] = np.array([r["n_matches"], r["n_trials"]], dtype=np.int64)
+        for k in ("kf_key_point", "type", "n_failed", "n_succeeded", "unlinked", "overlap_kf", "overlap_count", "feat_point", "feat_px",
+                  "feat_level", "feat_type", "feat_grad"):
+            out[tag + "_" + k] = r[k]
+        n_del_loop = int(((r["unlinked"] == 1) & (cs["pt_type"] != synth.TYPE_CANDIDATE)).sum())
+        print("reproject_map_ref", tag, r["n_matches"], r["n_trials"], "overlap", list(r["overlap_kf"]), "deleted in the cell loop", n_del_loop,
+              "candidates deleted", int(((r["unlinked"] == 1) & (cs["pt_type"] == synth.TYPE_CANDIDATE)).sum()), "edgelet features", int((r["feat_type"] == 1).sum()))
+    np.savez_compressed(os.path.join(OUT, "reproject_map_ref.npz"), **out)
+
+
 CAMERA_REF_CASES = (
     # name, width, height, fx, fy, cx, cy, (k1, k2, p1, p2, k3)
     ("pinhole_vga", 640, 480, 500.0, 500.0, 319.5, 239.5, (0.0, 0.0, 0.0, 0.0, 0.0)),
@@ -450,6 +473,10 @@ def main():
         assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
         gen_camera_ref()
         return
+    if "--map-only" in sys.argv:
+        assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
+        gen_reproject_map_ref()
+        return
     assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(OUT, exist_ok=True)
     if not any(a in sys.argv for a in ("--objects-only", "--refine-only", "--shitomasi-only", "--reproject-only")):
@@ -462,6 +489,7 @@ def main():
     if "--reproject-only" not in sys.argv:
         gen_shitomasi_ref()
     gen_reproject_ref()
+    gen_reproject_map_ref()
     gen_camera_ref()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))

@@ -385,3 +385,54 @@ def is_in_frame(cam, obs, boundary, level=-1):
     return np.array([lib().svo_orc_is_in_frame(C.byref(c), int(o[0]), int(o[1]), int(boundary), int(level)) for o in obs],
                     dtype=np.uint8)
 
+
+
+# ---- Reprojector::reprojectMap on a flattened svo::Map (svo_orc_reproject_map) ----
+class OrcMap(C.Structure):
+    _fields_ = [("n_kf", C.c_int), ("T_kf_w", C.POINTER(C.c_double)), ("kf_key_point", C.POINTER(C.c_int)),
+                ("kf_ftr_offset", C.POINTER(C.c_int)), ("kf_ftr_point", C.POINTER(C.c_int)), ("n_points", C.c_int),
+                ("pt_pos", C.POINTER(C.c_double)), ("pt_type", C.POINTER(C.c_int)), ("pt_n_failed", C.POINTER(C.c_int)),
+                ("pt_n_succeeded", C.POINTER(C.c_int)), ("pt_obs_offset", C.POINTER(C.c_int)), ("obs_kf", C.POINTER(C.c_int)),
+                ("obs_px", C.POINTER(C.c_double)), ("obs_f", C.POINTER(C.c_double)), ("obs_level", C.POINTER(C.c_int)),
+                ("obs_edgelet", C.POINTER(C.c_uint8)), ("obs_grad", C.POINTER(C.c_double)), ("n_candidates", C.c_int),
+                ("cand_point", C.POINTER(C.c_int))]
+
+
+def reproject_map(cs, kf_key_point, T_cur_w=None, max_fts=1200, max_n_kfs=10, n_pyr_levels=3, align_max_iter=10, state=None):
+    """cs: a map case (android_svo_amd.synth.make_map_case layout); kf_key_point [n_kf][5] = the keyframes' key points
+    (point indices, -1 for none).  state (optional): dict with pt_type / pt_n_failed / pt_n_succeeded / unlinked arrays
+    that are updated in place (a sequence of frames over one map); default: copies of the case's arrays."""
+    cam = camera(cs["cam"])
+    n_kf, n_pts = cs["n_kf"], cs["n_points"]
+    kp = (C.POINTER(C.POINTER(C.c_uint8)) * n_kf)()
+    keep = []
+    for k in range(n_kf):
+        pp = pyr_ptrs(cs["kf_pyr"][k])
+        keep.append(pp)
+        kp[k] = C.cast(pp, C.POINTER(C.POINTER(C.c_uint8)))
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    if state is None:
+        state = {"pt_type": i32(cs["pt_type"]).copy(), "pt_n_failed": i32(cs["pt_n_failed"]).copy(),
+                 "pt_n_succeeded": i32(cs["pt_n_succeeded"]).copy(), "unlinked": np.zeros(n_pts, np.uint8)}
+    a = dict(Tk=f64(cs["T_kf_w"]), key=i32(kf_key_point), ko=i32(cs["kf_ftr_offset"]), kfp=i32(cs["kf_ftr_point"]), pos=f64(cs["pt_pos"]),
+             oo=i32(cs["pt_obs_offset"]), ok=i32(cs["obs_kf"]), opx=f64(cs["obs_px"]), of=f64(cs["obs_f"]), ol=i32(cs["obs_level"]),
+             oe=np.ascontiguousarray(cs["obs_edgelet"], dtype=np.uint8), og=f64(cs["obs_grad"]), cp=i32(cs["cand_point"]))
+    I, DD, U = C.c_int, C.c_double, C.c_uint8
+    m = OrcMap(n_kf, _p(a["Tk"], DD), _p(a["key"], I), _p(a["ko"], I), _p(a["kfp"], I), n_pts, _p(a["pos"], DD), _p(state["pt_type"], I),
+               _p(state["pt_n_failed"], I), _p(state["pt_n_succeeded"], I), _p(a["oo"], I), _p(a["ok"], I), _p(a["opx"], DD), _p(a["of"], DD),
+               _p(a["ol"], I), _p(a["oe"], U), _p(a["og"], DD), len(a["cp"]), _p(a["cp"], I))
+    Tc = f64(cs["T_cur_w"] if T_cur_w is None else T_cur_w)
+    cw, ch, g = cs["cam"].width, cs["cam"].height, cs["cell_size"]
+    n_cells = (-(-cw // g)) * (-(-ch // g))
+    n_ov, ov_kf, ov_cnt = C.c_int(0), np.zeros(max(max_n_kfs, 1), np.int32), np.zeros(max(max_n_kfs, 1), np.int32)
+    nf = C.c_int(0)
+    fpx, fl, fp, fe, fg = np.zeros((n_cells, 2)), np.zeros(n_cells, np.int32), np.zeros(n_cells, np.int32), np.zeros(n_cells, np.uint8), np.zeros((n_cells, 2))
+    nm, nt = C.c_size_t(0), C.c_size_t(0)
+    cur = pyr_ptrs(cs["cur_pyr"] if "cur_pyr_override" not in cs else cs["cur_pyr_override"])
+    lib().svo_orc_reproject_map(C.byref(cam), C.byref(m), kp, cur, _p(Tc, DD), I(g), I(max_fts), I(max_n_kfs), I(n_pyr_levels),
+                                I(align_max_iter), _p(state["unlinked"], U), C.byref(n_ov), _p(ov_kf, I), _p(ov_cnt, I), C.byref(nf),
+                                _p(fpx, DD), _p(fl, I), _p(fp, I), _p(fe, U), _p(fg, DD), C.byref(nm), C.byref(nt))
+    k = nf.value
+    return {"type": state["pt_type"], "n_failed": state["pt_n_failed"], "n_succeeded": state["pt_n_succeeded"], "unlinked": state["unlinked"],
+            "overlap_kf": ov_kf[:n_ov.value], "overlap_count": ov_cnt[:n_ov.value], "feat_point": fp[:k], "feat_px": fpx[:k],
+            "feat_level": fl[:k], "feat_type": fe[:k].astype(np.int32), "feat_grad": fg[:k], "n_matches": nm.value, "n_trials": nt.value}

@@ -107,6 +107,8 @@ struct HandFrame {
 
 }  // namespace
 
+static bool pt_obs_nonempty(const svo::Point* p) { return !p->obs_.empty(); }
+
 extern "C" {
 
 // The reference's SparseImgAlign on one frame pair (see the file header for what is hand-laid).
@@ -357,6 +359,114 @@ int ref_reproject_cells(int width, int height, double fx, double fy, double cx, 
   // tear down: points that were not deleted are ours, deleted ones sit in the map's trash (freed by ~Map)
   for (int i = 0; i < n; ++i) if (pts[i]->type_ != svo::Point::TYPE_DELETED) delete pts[i];
   delete rp;
+  delete map;
+  for (HandFrame* k : kfs) delete k;
+  return nf;
+}
+
+// The whole Reprojector::reprojectMap (reprojector.cpp:72-168) on a real svo::Map: keyframes with their feature lists
+// and key points (chosen by the reference's own Frame::setKeyPoints), map points with several observations, point
+// candidates.  Everything that runs is the reference's compiled code: Map::getCloseKeyframes, Frame::isVisible, the
+// list sort, reprojectPoint, the candidate loop, reprojectCell with cell.sort / Point::getCloseViewObs /
+// Matcher::findMatchDirect / Map::safeDeletePoint / MapPointCandidates::deleteCandidatePoint.
+// Inputs (index tables): observation o lies in keyframe obs_kf[o] and belongs to point obs_point[o]; the observations of a
+// point are appended to its obs_ list in ascending o; keyframe k's fts_ holds the features kf_ftr_obs[kf_ftr_offset[k] ..
+// kf_ftr_offset[k+1]) (observation indices) in that order; candidate c is point cand_point[c] with its single
+// observation cand_obs[c] (a feature that is in no fts_ list).
+// Outputs: kf_key_point [n_kf][5] (point index or -1) as the reference chose them BEFORE the call; per point type / counters
+// after the call and whether it is still referenced by its features; the frame's new features; overlap_kfs.
+int ref_reproject_map(int width, int height, double fx, double fy, double cx, double cy, int n_levels, int grid_size, int max_fts,
+                      int n_pyr_levels, int n_kf, const uint8_t* const* const* kf_pyr, const double* T_kf_w,
+                      const uint8_t* const* cur_pyr, const double* T_cur_w, int n_points, const double* pt_pos, const int* pt_type,
+                      const int* pt_n_failed, const int* pt_n_succeeded, int n_obs, const int* obs_point, const int* obs_kf,
+                      const double* obs_px, const double* obs_f, const int* obs_level, const uint8_t* obs_edgelet,
+                      const double* obs_grad, const int* kf_ftr_offset, const int* kf_ftr_obs, int n_candidates,
+                      const int* cand_point, const int* cand_obs,
+                      int* kf_key_point, int* type_out, int* n_failed_out, int* n_succeeded_out, uint8_t* unlinked_out,
+                      int* n_overlap, int* overlap_kf, int* overlap_count, int* feat_point, double* feat_px, int* feat_level,
+                      int* feat_type, double* feat_grad, size_t* n_matches, size_t* n_trials) {
+  svo::Config::gridSize() = (size_t)grid_size;
+  svo::Config::maxFts() = (size_t)max_fts;
+  svo::Config::nPyrLevels() = (size_t)n_pyr_levels;
+  HarnessPinhole cam(width, height, fx, fy, cx, cy);
+  std::vector<HandFrame*> kfs;
+  for (int k = 0; k < n_kf; ++k) {
+    kfs.push_back(new HandFrame(&cam, kf_pyr[k], width, height, n_levels, T_kf_w + 7 * k));
+    kfs.back()->f->is_keyframe_ = true;
+  }
+  HandFrame cur(&cam, cur_pyr, width, height, n_levels, T_cur_w);
+  svo::FramePtr frame = cur.ptr();
+  std::vector<svo::Point*> pts((size_t)n_points);
+  for (int p = 0; p < n_points; ++p) {
+    pts[p] = new svo::Point(Eigen::Vector3d(pt_pos[3 * p], pt_pos[3 * p + 1], pt_pos[3 * p + 2]));
+    pts[p]->type_ = (svo::Point::PointType)pt_type[p];
+    pts[p]->n_failed_reproj_ = pt_n_failed[p];
+    pts[p]->n_succeeded_reproj_ = pt_n_succeeded[p];
+  }
+  std::vector<svo::Feature*> obs((size_t)n_obs);
+  for (int o = 0; o < n_obs; ++o) {
+    svo::Feature* ftr = new svo::Feature(kfs[obs_kf[o]]->f, Eigen::Vector2d(obs_px[2 * o], obs_px[2 * o + 1]),
+                                         Eigen::Vector3d(obs_f[3 * o], obs_f[3 * o + 1], obs_f[3 * o + 2]), obs_level[o]);
+    if (obs_edgelet && obs_edgelet[o]) { ftr->type = svo::Feature::EDGELET; ftr->grad = Eigen::Vector2d(obs_grad[2 * o], obs_grad[2 * o + 1]); }
+    ftr->point = pts[obs_point[o]];
+    pts[obs_point[o]]->obs_.push_back(ftr);
+    pts[obs_point[o]]->n_obs_++;
+    obs[o] = ftr;
+  }
+  std::vector<char> in_fts((size_t)n_obs, 0);
+  for (int k = 0; k < n_kf; ++k) {
+    for (int j = kf_ftr_offset[k]; j < kf_ftr_offset[k + 1]; ++j) { kfs[k]->f->fts_.push_back(obs[kf_ftr_obs[j]]); in_fts[kf_ftr_obs[j]] = 1; }
+    kfs[k]->f->setKeyPoints();                                       // the reference's own choice (frame.cpp:79-133)
+  }
+  for (int k = 0; k < n_kf; ++k)
+    for (int j = 0; j < 5; ++j) {
+      kf_key_point[5 * k + j] = -1;
+      svo::Feature* kp = kfs[k]->f->key_pts_[j];
+      if (kp != nullptr)
+        for (int p = 0; p < n_points; ++p) if (pts[p] == kp->point) kf_key_point[5 * k + j] = p;
+    }
+  svo::Map* map = new svo::Map();
+  for (int k = 0; k < n_kf; ++k) map->addKeyframe(kfs[k]->ptr());
+  for (int c = 0; c < n_candidates; ++c)                               // (newCandidatePoint would reset the type: push the pair as it does)
+    map->point_candidates_.candidates_.push_back(svo::MapPointCandidates::PointCandidate(pts[cand_point[c]], obs[cand_obs[c]]));
+  svo::Reprojector* rp = new svo::Reprojector(&cam, *map);
+  std::vector<std::pair<svo::FramePtr, std::size_t> > overlap;
+  rp->reprojectMap(frame, overlap);
+  *n_matches = rp->n_matches_;
+  *n_trials = rp->n_trials_;
+  *n_overlap = (int)overlap.size();
+  for (size_t i = 0; i < overlap.size(); ++i) {
+    overlap_kf[i] = -1;
+    for (int k = 0; k < n_kf; ++k) if (overlap[i].first.get() == kfs[k]->f) overlap_kf[i] = k;
+    overlap_count[i] = (int)overlap[i].second;
+  }
+  std::vector<char> is_cand((size_t)n_points, 0), cand_left((size_t)n_points, 0);
+  for (int c = 0; c < n_candidates; ++c) is_cand[cand_point[c]] = 1;
+  for (auto& pc : map->point_candidates_.candidates_)
+    for (int p = 0; p < n_points; ++p) if (pts[p] == pc.first) cand_left[p] = 1;
+  for (int p = 0; p < n_points; ++p) {
+    type_out[p] = (int)pts[p]->type_;
+    n_failed_out[p] = pts[p]->n_failed_reproj_;
+    n_succeeded_out[p] = pts[p]->n_succeeded_reproj_;
+    // cut loose: a map point whose observation list was cleared (safeDeletePoint), a candidate that left candidates_
+    unlinked_out[p] = is_cand[p] ? (cand_left[p] ? 0 : 1) : ((pt_obs_nonempty(pts[p]) ? 0 : 1));
+  }
+  int nf = 0;
+  for (svo::Feature* ftr : cur.f->fts_) {
+    int idx = -1;
+    for (int p = 0; p < n_points; ++p) if (pts[p] == ftr->point) idx = p;
+    feat_point[nf] = idx;
+    feat_px[2 * nf] = ftr->px[0]; feat_px[2 * nf + 1] = ftr->px[1];
+    feat_level[nf] = ftr->level;
+    feat_type[nf] = (int)ftr->type;
+    feat_grad[2 * nf] = ftr->grad[0]; feat_grad[2 * nf + 1] = ftr->grad[1];
+    ++nf;
+  }
+  // tear down.  Candidate points and their features belong to the map (MapPointCandidates::reset / its trash delete them);
+  // deleted map points sit in the map's trash; the other points are ours; keyframe features die with their HandFrame.
+  delete rp;
+  for (int p = 0; p < n_points; ++p)
+    if (!is_cand[p] && pts[p]->type_ != svo::Point::TYPE_DELETED) delete pts[p];
   delete map;
   for (HandFrame* k : kfs) delete k;
   return nf;

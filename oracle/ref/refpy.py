@@ -335,3 +335,40 @@ def camera_is_in_frame(width, height, obs, boundary, level):
                                  C.c_int(level), _p(plain, C.c_uint8), _p(lev, C.c_uint8))
     return plain, lev
 
+
+
+# ---- the whole Reprojector::reprojectMap on a real svo::Map (ref_objects.cpp: ref_reproject_map) ----
+def reproject_map(cs, max_fts=1200, n_pyr_levels=3):
+    """cs: a case of android_svo_amd.synth.make_map_case.  Returns the reference's outputs, incl. the key points its own
+    Frame::setKeyPoints chose for every keyframe (an input of the oracle / HIP forms of the call)."""
+    cam, n_kf, n_pts, n_obs = cs["cam"], cs["n_kf"], cs["n_points"], len(cs["obs_point"])
+    kp = (C.POINTER(C.POINTER(C.c_uint8)) * n_kf)()
+    keep = []
+    for k in range(n_kf):
+        pp = orc.pyr_ptrs(cs["kf_pyr"][k])
+        keep.append(pp)
+        kp[k] = C.cast(pp, C.POINTER(C.POINTER(C.c_uint8)))
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+    I, U = C.c_int, C.c_uint8
+    n_cells = (-(-cam.width // cs["cell_size"])) * (-(-cam.height // cs["cell_size"]))
+    ins = dict(Tk=f64(cs["T_kf_w"]), Tc=f64(cs["T_cur_w"]), pos=f64(cs["pt_pos"]), ty=i32(cs["pt_type"]), nf=i32(cs["pt_n_failed"]),
+               ns=i32(cs["pt_n_succeeded"]), op=i32(cs["obs_point"]), ok=i32(cs["obs_kf"]), opx=f64(cs["obs_px"]), of=f64(cs["obs_f"]),
+               ol=i32(cs["obs_level"]), oe=u8(cs["obs_edgelet"]), og=f64(cs["obs_grad"]), ko=i32(cs["kf_ftr_offset"]), kb=i32(cs["kf_ftr_obs"]),
+               cp=i32(cs["cand_point"]), co=i32(cs["cand_obs"]))
+    key = np.zeros((n_kf, 5), np.int32)
+    ty_o, nf_o, ns_o, un_o = np.zeros(n_pts, np.int32), np.zeros(n_pts, np.int32), np.zeros(n_pts, np.int32), np.zeros(n_pts, np.uint8)
+    n_ov, ov_kf, ov_cnt = C.c_int(0), np.zeros(max(n_kf, 1), np.int32), np.zeros(max(n_kf, 1), np.int32)
+    fp, fpx, fl, ft, fg = np.zeros(n_cells, np.int32), np.zeros((n_cells, 2)), np.zeros(n_cells, np.int32), np.zeros(n_cells, np.int32), np.zeros((n_cells, 2))
+    nm, nt = C.c_size_t(0), C.c_size_t(0)
+    k = lib().ref_reproject_map(*_cam_args(cam), I(len(cs["cur_pyr"])), I(cs["cell_size"]), I(max_fts), I(n_pyr_levels), I(n_kf), kp,
+                                _p(ins["Tk"], D), orc.pyr_ptrs(cs["cur_pyr"]), _p(ins["Tc"], D), I(n_pts), _p(ins["pos"], D), _p(ins["ty"], I),
+                                _p(ins["nf"], I), _p(ins["ns"], I), I(n_obs), _p(ins["op"], I), _p(ins["ok"], I), _p(ins["opx"], D),
+                                _p(ins["of"], D), _p(ins["ol"], I), _p(ins["oe"], U), _p(ins["og"], D), _p(ins["ko"], I), _p(ins["kb"], I),
+                                I(len(ins["cp"])), _p(ins["cp"], I), _p(ins["co"], I),
+                                _p(key, I), _p(ty_o, I), _p(nf_o, I), _p(ns_o, I), _p(un_o, U), C.byref(n_ov), _p(ov_kf, I), _p(ov_cnt, I),
+                                _p(fp, I), _p(fpx, D), _p(fl, I), _p(ft, I), _p(fg, D), C.byref(nm), C.byref(nt))
+    assert k >= 0
+    return {"kf_key_point": key, "type": ty_o, "n_failed": nf_o, "n_succeeded": ns_o, "unlinked": un_o,
+            "overlap_kf": ov_kf[:n_ov.value], "overlap_count": ov_cnt[:n_ov.value], "feat_point": fp[:k], "feat_px": fpx[:k],
+            "feat_level": fl[:k], "feat_type": ft[:k], "feat_grad": fg[:k], "n_matches": nm.value, "n_trials": nt.value}

@@ -1678,3 +1678,202 @@ int svo_orc_reproject_cells(const svo_orc_camera* cam, int n_kf, const uint8_t* 
   *n_trials_out = n_trials;
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Reprojector::reprojectMap on a flattened svo::Map (S/reprojector.cpp:72-168 with reprojectPoint :246-259,
+ * reprojectCell :180-241, Map::getCloseKeyframes S/map.cpp:109-131, Frame::isVisible S/frame.cpp:162-172,
+ * Point::getCloseViewObs S/point.cpp:101-125, Matcher::findMatchDirect S/matcher.cpp:156-202).
+ * The pointer graph is given as index tables (svo_orc_map); what the reference changes on its objects is changed in
+ * the tables: pt_type / pt_n_failed / pt_n_succeeded in place, pt_unlinked[p] = 1 for a point that went through
+ * Map::safeDeletePoint (its keyframe features now have point == NULL) or whose candidate was erased.
+ * New features of the frame are returned in creation order. */
+/* ------------------------------------------------------------------------ */
+
+/* S/frame.cpp:162-172 */
+static int frame_is_visible(const svo_orc_camera* cam, const double T_f_w[7], const double xyz_w[3]) {
+  double xyz_f[3], px[2];
+  svo_orc_se3_act(T_f_w, xyz_w, xyz_f);
+  if (xyz_f[2] < 0.0) return 0;
+  svo_orc_world2cam(cam, xyz_f, px);
+  return px[0] >= 0.0 && px[1] >= 0.0 && px[0] < cam->width && px[1] < cam->height;
+}
+
+/* S/point.cpp:101-125: index of the observation with the closest view (first maximum of the cosine above 0; the
+ * first observation when none is above 0); returns whether its cosine reaches 0.5 */
+static int point_close_view_obs(const svo_orc_map* m, int p, const double framepos[3], int* obs_out) {
+  const double* pos = m->pt_pos + 3 * (size_t)p;
+  double od[3] = {framepos[0] - pos[0], framepos[1] - pos[1], framepos[2] - pos[2]};
+  {
+    const double n2 = od[0] * od[0] + od[1] * od[1] + od[2] * od[2];
+    if (n2 > 0.0) { const double nn = sqrt(n2); od[0] = od[0] / nn; od[1] = od[1] / nn; od[2] = od[2] / nn; }
+  }
+  int min_it = m->pt_obs_offset[p];
+  double min_cos_angle = 0;
+  for (int o = m->pt_obs_offset[p]; o < m->pt_obs_offset[p + 1]; ++o) {
+    double Tinv[7];
+    svo_orc_se3_inverse(m->T_kf_w + 7 * (size_t)m->obs_kf[o], Tinv);          /* (*it)->frame->pos() */
+    double d[3] = {Tinv[0] - pos[0], Tinv[1] - pos[1], Tinv[2] - pos[2]};
+    const double n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    if (n2 > 0.0) { const double nn = sqrt(n2); d[0] = d[0] / nn; d[1] = d[1] / nn; d[2] = d[2] / nn; }
+    const double cos_angle = od[0] * d[0] + od[1] * d[1] + od[2] * d[2];
+    if (cos_angle > min_cos_angle) { min_cos_angle = cos_angle; min_it = o; }
+  }
+  *obs_out = min_it;
+  return !(min_cos_angle < 0.5);
+}
+
+typedef struct { int point; double px[2]; int seq; } orc_cand;
+
+static int orc_cand_cmp(const void* a, const void* b) {          /* cell.sort(pointQualityComparator): stable, by type descending */
+  const orc_cand* x = (const orc_cand*)a; const orc_cand* y = (const orc_cand*)b;
+  return x->seq < y->seq ? -1 : (x->seq > y->seq ? 1 : 0);
+}
+
+int svo_orc_reproject_map(const svo_orc_camera* cam, svo_orc_map* m, const uint8_t* const* const* kf_pyr,
+                          const uint8_t* const* cur_pyr, const double T_cur_w[7], int grid_size, int max_fts, int max_n_kfs,
+                          int n_pyr_levels, int align_max_iter, uint8_t* pt_unlinked, int* n_overlap_out, int* overlap_kf,
+                          int* overlap_count, int* n_feat_out, double* feat_px, int* feat_level, int* feat_point,
+                          uint8_t* feat_edgelet, double* feat_grad, size_t* n_matches_out, size_t* n_trials_out) {
+  const int cols = (int)ceil((double)cam->width / grid_size), rows = (int)ceil((double)cam->height / grid_size);   /* :46-47 */
+  const int n_cells = cols * rows;
+  /* ---- Map::getCloseKeyframes (map.cpp:109-131), then close_kfs.sort by distance (:82-83; std::list::sort is stable) */
+  int* close = (int*)malloc(sizeof(int) * (size_t)(m->n_kf > 0 ? m->n_kf : 1));
+  double* dist = (double*)malloc(sizeof(double) * (size_t)(m->n_kf > 0 ? m->n_kf : 1));
+  int n_close = 0;
+  for (int k = 0; k < m->n_kf; ++k) {
+    for (int j = 0; j < 5; ++j) {
+      const int p = m->kf_key_point[5 * k + j];
+      if (p < 0) continue;
+      if (frame_is_visible(cam, T_cur_w, m->pt_pos + 3 * (size_t)p)) {
+        const double* tk = m->T_kf_w + 7 * (size_t)k;
+        const double dx = T_cur_w[0] - tk[0], dy = T_cur_w[1] - tk[1], dz = T_cur_w[2] - tk[2];
+        close[n_close] = k;
+        dist[n_close] = sqrt(dx * dx + dy * dy + dz * dz);
+        ++n_close;
+        break;
+      }
+    }
+  }
+  for (int i = 1; i < n_close; ++i) {                                   /* stable insertion sort */
+    const int ck = close[i]; const double cd = dist[i];
+    int j = i - 1;
+    while (j >= 0 && cd < dist[j]) { close[j + 1] = close[j]; dist[j + 1] = dist[j]; --j; }
+    close[j + 1] = ck; dist[j + 1] = cd;
+  }
+  /* ---- candidates per cell, in push_back order */
+  size_t cap = (size_t)m->n_candidates + 1;
+  for (int i = 0; i < n_close && i < max_n_kfs; ++i) cap += (size_t)(m->kf_ftr_offset[close[i] + 1] - m->kf_ftr_offset[close[i]]);
+  orc_cand* cand = (orc_cand*)malloc(sizeof(orc_cand) * cap);
+  int* cand_cell = (int*)malloc(sizeof(int) * cap);
+  int n_cand = 0;
+  uint8_t* projected = (uint8_t*)calloc((size_t)(m->n_points > 0 ? m->n_points : 1), 1);   /* last_projected_kf_id_ == frame->id_ */
+  int n_overlap = 0;
+  for (int i = 0; i < n_close && i < max_n_kfs; ++i) {                   /* :88-114 */
+    const int k = close[i];
+    overlap_kf[n_overlap] = k; overlap_count[n_overlap] = 0;
+    for (int j = m->kf_ftr_offset[k]; j < m->kf_ftr_offset[k + 1]; ++j) {
+      const int p = m->kf_ftr_point[j];
+      if (p < 0 || pt_unlinked[p]) continue;                             /* (*it_ftr)->point == NULL */
+      if (projected[p]) continue;
+      projected[p] = 1;
+      double xyz_f[3], px[2];                                            /* reprojectPoint (:246-259) */
+      svo_orc_se3_act(T_cur_w, m->pt_pos + 3 * (size_t)p, xyz_f);
+      svo_orc_world2cam(cam, xyz_f, px);
+      if (svo_orc_is_in_frame(cam, (int)px[0], (int)px[1], 8, -1)) {
+        cand_cell[n_cand] = (int)(px[1] / grid_size) * cols + (int)(px[0] / grid_size);
+        cand[n_cand].point = p; cand[n_cand].px[0] = px[0]; cand[n_cand].px[1] = px[1];
+        ++n_cand;
+        overlap_count[n_overlap]++;
+      }
+    }
+    ++n_overlap;
+  }
+  *n_overlap_out = n_overlap;
+  for (int c = 0; c < m->n_candidates; ++c) {                            /* :118-138 */
+    const int p = m->cand_point[c];
+    if (p < 0 || pt_unlinked[p]) continue;                               /* erased from candidates_ earlier */
+    double xyz_f[3], px[2];
+    svo_orc_se3_act(T_cur_w, m->pt_pos + 3 * (size_t)p, xyz_f);
+    svo_orc_world2cam(cam, xyz_f, px);
+    if (svo_orc_is_in_frame(cam, (int)px[0], (int)px[1], 8, -1)) {
+      cand_cell[n_cand] = (int)(px[1] / grid_size) * cols + (int)(px[0] / grid_size);
+      cand[n_cand].point = p; cand[n_cand].px[0] = px[0]; cand[n_cand].px[1] = px[1];
+      ++n_cand;
+    } else {
+      m->pt_n_failed[p] += 3;
+      if (m->pt_n_failed[p] > 30) { m->pt_type[p] = 0 /* TYPE_DELETED */; pt_unlinked[p] = 1; }   /* deleteCandidate + erase */
+    }
+  }
+  /* ---- the cell loop (:149-166) */
+  double T_cur_inv[7];
+  svo_orc_se3_inverse(T_cur_w, T_cur_inv);                               /* cur_frame.pos() */
+  size_t n_matches = 0, n_trials = 0;
+  int n_feat = 0;
+  orc_cand* cell = (orc_cand*)malloc(sizeof(orc_cand) * (size_t)(n_cand > 0 ? n_cand : 1));
+  for (int c = 0; c < n_cells; ++c) {
+    /* the cell's list in push_back order, then cell.sort(pointQualityComparator) (:183): stable, higher type first */
+    int nc = 0;
+    for (int t = 3; t >= 0; --t)
+      for (int i = 0; i < n_cand; ++i)
+        if (cand_cell[i] == c && m->pt_type[cand[i].point] == t) { cell[nc] = cand[i]; cell[nc].seq = nc; ++nc; }
+    qsort(cell, (size_t)nc, sizeof(orc_cand), orc_cand_cmp);             /* (already ordered: keeps the intent explicit) */
+    int found = 0;
+    for (int i = 0; i < nc && !found; ++i) {
+      ++n_trials;
+      const int p = cell[i].point;
+      if (m->pt_type[p] == 0) continue;                                  /* TYPE_DELETED (:190-194) */
+      int o = -1;
+      int ok = point_close_view_obs(m, p, T_cur_inv, &o);
+      double px_cur[2] = {cell[i].px[0], cell[i].px[1]};
+      int sl = 0;
+      double A[4] = {0, 0, 0, 0};
+      if (ok) {
+        const int k = m->obs_kf[o];
+        const double g[2] = {m->obs_grad ? m->obs_grad[2 * (size_t)o] : 1.0, m->obs_grad ? m->obs_grad[2 * (size_t)o + 1] : 0.0};
+        const int edge = m->obs_edgelet ? m->obs_edgelet[o] : 0;
+        ok = svo_orc_find_match_direct(cam, kf_pyr[k], cur_pyr, m->T_kf_w + 7 * (size_t)k, T_cur_w, m->obs_px + 2 * (size_t)o,
+                                       m->obs_f + 3 * (size_t)o, m->obs_level[o], m->pt_pos + 3 * (size_t)p, edge, g, n_pyr_levels,
+                                       align_max_iter, px_cur, &sl);
+        if (ok && edge) {                                                /* A_cur_ref_ of the successful call, for the new feature's grad */
+          double T_ref_inv[7], T_cur_ref[7];
+          svo_orc_se3_inverse(m->T_kf_w + 7 * (size_t)k, T_ref_inv);
+          svo_orc_se3_mul(T_cur_w, T_ref_inv, T_cur_ref);
+          const double* pp = m->pt_pos + 3 * (size_t)p;
+          const double dx = T_ref_inv[0] - pp[0], dy = T_ref_inv[1] - pp[1], dz = T_ref_inv[2] - pp[2];
+          svo_orc_get_warp_matrix_affine(cam, cam, m->obs_px + 2 * (size_t)o, m->obs_f + 3 * (size_t)o, sqrt(dx * dx + dy * dy + dz * dz),
+                                         T_cur_ref, m->obs_level[o], A);
+        }
+      }
+      if (!ok) {                                                         /* :202-209 */
+        m->pt_n_failed[p]++;
+        if (m->pt_type[p] == 2 /* UNKNOWN */ && m->pt_n_failed[p] > 15) { m->pt_type[p] = 0; pt_unlinked[p] = 1; }    /* safeDeletePoint */
+        if (m->pt_type[p] == 1 /* CANDIDATE */ && m->pt_n_failed[p] > 30) { m->pt_type[p] = 0; pt_unlinked[p] = 1; }  /* deleteCandidatePoint */
+        continue;
+      }
+      m->pt_n_succeeded[p]++;                                            /* :211-214 */
+      if (m->pt_type[p] == 2 && m->pt_n_succeeded[p] > 10) m->pt_type[p] = 3;
+      feat_px[2 * n_feat] = px_cur[0]; feat_px[2 * n_feat + 1] = px_cur[1];   /* new Feature(frame, it->px, search_level_) (:217) */
+      feat_level[n_feat] = sl;
+      feat_point[n_feat] = p;
+      feat_edgelet[n_feat] = 0;
+      feat_grad[2 * n_feat] = 1.0; feat_grad[2 * n_feat + 1] = 0.0;
+      if (m->obs_edgelet && m->obs_edgelet[o]) {                         /* :224-229 */
+        double g0 = A[0] * m->obs_grad[2 * (size_t)o] + A[1] * m->obs_grad[2 * (size_t)o + 1];
+        double g1 = A[2] * m->obs_grad[2 * (size_t)o] + A[3] * m->obs_grad[2 * (size_t)o + 1];
+        const double n2 = g0 * g0 + g1 * g1;
+        if (n2 > 0.0) { const double nn = sqrt(n2); g0 = g0 / nn; g1 = g1 / nn; }
+        feat_edgelet[n_feat] = 1;
+        feat_grad[2 * n_feat] = g0; feat_grad[2 * n_feat + 1] = g1;
+      }
+      ++n_feat;
+      found = 1;
+    }
+    if (found) ++n_matches;
+    if (n_matches > (size_t)max_fts) break;                              /* :164-165 */
+  }
+  *n_feat_out = n_feat;
+  *n_matches_out = n_matches;
+  *n_trials_out = n_trials;
+  free(cell); free(projected); free(cand_cell); free(cand); free(dist); free(close);
+  return 0;
+}

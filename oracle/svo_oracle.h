@@ -272,6 +272,42 @@ int svo_orc_reproject_cells(const svo_orc_camera* cam, int n_kf, const uint8_t* 
                             double* px_cur /*in/out*/, int max_fts, int n_pyr_levels, int align_max_iter, uint8_t* tried,
                             uint8_t* matched, int* search_level, int* cell_winner, size_t* n_matches, size_t* n_trials);
 
+/* ---- Reprojector::reprojectMap on a flattened svo::Map (reprojector.cpp:72-259, map.cpp:109-131, point.cpp:101-125,
+ *      matcher.cpp:156-202).  Index tables instead of the pointer graph: keyframes in Map::keyframes_ order, the features
+ *      of each keyframe that have a point in fts_ order, the observations of each point in Point::obs_ order (each
+ *      names the keyframe it lies in), the candidate points in MapPointCandidates::candidates_ order.  Point types are
+ *      Point::PointType values (0 deleted, 1 candidate, 2 unknown, 3 good). */
+typedef struct {
+  int n_kf;
+  const double* T_kf_w;          /* [n_kf][7] */
+  const int* kf_key_point;       /* [n_kf][5]: point of key_pts_[j], -1 for NULL */
+  const int* kf_ftr_offset;      /* [n_kf + 1] */
+  const int* kf_ftr_point;       /* point index per keyframe feature (-1: no point) */
+  int n_points;
+  const double* pt_pos;          /* [n_points][3] */
+  int* pt_type;                  /* in/out */
+  int* pt_n_failed;              /* in/out */
+  int* pt_n_succeeded;           /* in/out */
+  const int* pt_obs_offset;      /* [n_points + 1] */
+  const int* obs_kf;             /* keyframe index of every observation */
+  const double* obs_px;          /* [..][2] */
+  const double* obs_f;           /* [..][3] */
+  const int* obs_level;
+  const uint8_t* obs_edgelet;    /* may be NULL */
+  const double* obs_grad;        /* [..][2], may be NULL */
+  int n_candidates;
+  const int* cand_point;
+} svo_orc_map;
+
+/* pt_unlinked [n_points] in/out: points whose references were cut (safeDeletePoint / deleted candidates).  overlap_kf /
+ * overlap_count [max_n_kfs]: the reference's overlap_kfs.  feat_* [number of grid cells]: the features added to the
+ * frame, in creation order. */
+int svo_orc_reproject_map(const svo_orc_camera* cam, svo_orc_map* m, const uint8_t* const* const* kf_pyr,
+                          const uint8_t* const* cur_pyr, const double T_cur_w[7], int grid_size, int max_fts, int max_n_kfs,
+                          int n_pyr_levels, int align_max_iter, uint8_t* pt_unlinked, int* n_overlap_out, int* overlap_kf,
+                          int* overlap_count, int* n_feat_out, double* feat_px, int* feat_level, int* feat_point,
+                          uint8_t* feat_edgelet, double* feat_grad, size_t* n_matches_out, size_t* n_trials_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,49 @@
+"""The whole Reprojector::reprojectMap (S/reprojector.cpp:72-259: Map::getCloseKeyframes, the distance sort, the projection
+of the closest keyframes' points and of the point candidates into grid cells, the cell loop with Point::getCloseViewObs,
+Matcher::findMatchDirect and the point bookkeeping): the C restatement on index tables against the reference's own compiled
+code run on a real svo::Map (tests/golden/reproject_map_ref.npz, made by oracle/gen_golden.py --map-only through
+oracle/ref/ref_objects.cpp: ref_reproject_map)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from android_svo_amd import synth
+from oracle import orc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reproject_map_ref.npz")
+# (tag, generator arguments, Config::maxFts()) -- the same table as oracle/gen_golden.py: MAP_REF_CASES
+CASES = (("near", dict(seed=31), 1200), ("cap", dict(seed=31), 40),
+         ("wide", dict(seed=32, n_kf=9, n_points=900, n_candidates=60, cell_size=25, kf_step=0.55), 1200))
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def check_map_result(g, tag, res):
+    """every output of the call against the reference fixture: integers equal, pixels and gradients bitwise"""
+    assert [int(res["n_matches"]), int(res["n_trials"])] == [int(v) for v in g[tag + "_n"]]
+    for k in ("overlap_kf", "overlap_count", "feat_point", "feat_level", "feat_type", "type", "n_failed", "n_succeeded", "unlinked"):
+        np.testing.assert_array_equal(np.asarray(res[k]).astype(np.int64), g[tag + "_" + k].astype(np.int64), err_msg=tag + " " + k)
+    assert np.asarray(res["feat_px"], dtype=np.float64).tobytes() == g[tag + "_feat_px"].tobytes(), tag
+    assert np.asarray(res["feat_grad"], dtype=np.float64).tobytes() == g[tag + "_feat_grad"].tobytes(), tag
+
+
+@pytest.mark.parametrize("tag,kw,max_fts", CASES, ids=[c[0] for c in CASES])
+def test_reproject_map_against_reference_fixture(tag, kw, max_fts):
+    g = np.load(GOLD)
+    cs = synth.make_map_case(**kw)
+    assert [crc(cs["cur_pyr"][0]), crc(cs["obs_px"]), crc(cs["pt_pos"]), crc(cs["kf_ftr_obs"])] == [int(v) for v in g[tag + "_crc"]], \
+        "the generator no longer reproduces the inputs the fixture was recorded on"
+    res = orc.reproject_map(cs, g[tag + "_kf_key_point"], max_fts=max_fts)
+    check_map_result(g, tag, res)
+    # the case exercises what it is meant to: a cap on the keyframes or keyframes out of view, deletions, candidates
+    assert len(res["overlap_kf"]) == min(10, cs["n_kf"]) or tag == "wide"
+    if tag == "wide":
+        assert len(res["overlap_kf"]) < cs["n_kf"]                      # some keyframes do not see the frame at all
+    assert ((res["unlinked"] == 1) & (cs["pt_type"] != synth.TYPE_CANDIDATE)).sum() >= 1      # Map::safeDeletePoint in the cell loop
+    assert ((res["unlinked"] == 1) & (cs["pt_type"] == synth.TYPE_CANDIDATE)).sum() >= 1      # candidates deleted out of view
+    if tag == "cap":
+        assert int(res["n_matches"]) == max_fts + 1                     # the loop stops once n_matches EXCEEDS maxFts (:164-165)
