@@ -214,28 +214,7 @@ __global__ void camera_batch_kernel(Cam cam, int n, const double* __restrict__ x
 }
 
 // ---- matcher pieces ---------------------------------------------------------------------------
-// S/matcher.cpp:36-60 (A row-major)
-SVO_DEV void get_warp_matrix_affine(const Cam& cam, const double* px_ref, const double* f_ref, double depth_ref,
-                                    const double* T_cur_ref, int level_ref, double* A) {
-  const int halfpatch_size = 5;
-  const double xyz_ref[3] = {f_ref[0] * depth_ref, f_ref[1] * depth_ref, f_ref[2] * depth_ref};
-  double du[3], dv[3];
-  const double off = (double)halfpatch_size * (1 << level_ref);
-  cam2world(cam, px_ref[0] + off, px_ref[1] + 0.0 * (1 << level_ref), du);
-  cam2world(cam, px_ref[0] + 0.0 * (1 << level_ref), px_ref[1] + off, dv);
-  const double su = xyz_ref[2] / du[2];
-  du[0] *= su; du[1] *= su; du[2] *= su;
-  const double sv = xyz_ref[2] / dv[2];
-  dv[0] *= sv; dv[1] *= sv; dv[2] *= sv;
-  double p[3], px_cur[2], px_du[2], px_dv[2];
-  se3_act(T_cur_ref, xyz_ref, p); world2cam(cam, p, px_cur);
-  se3_act(T_cur_ref, du, p);      world2cam(cam, p, px_du);
-  se3_act(T_cur_ref, dv, p);      world2cam(cam, p, px_dv);
-  A[0] = (px_du[0] - px_cur[0]) / halfpatch_size;
-  A[2] = (px_du[1] - px_cur[1]) / halfpatch_size;
-  A[1] = (px_dv[0] - px_cur[0]) / halfpatch_size;
-  A[3] = (px_dv[1] - px_cur[1]) / halfpatch_size;
-}
+// (get_warp_matrix_affine: svo_device_math.h)
 
 // S/matcher.cpp:123-136
 SVO_DEV bool depth_from_triangulation(const double* T_search_ref, const double* f_ref, const double* f_cur,
@@ -935,16 +914,25 @@ __global__ __launch_bounds__(256) void md_geometry_kernel(
     MdFrame fr, int n, const double* __restrict__ T_ref_w /*[n_kf][7]*/, const int32_t* __restrict__ kf_slot,
     const double* __restrict__ px_ref, const double* __restrict__ f_ref, const int32_t* __restrict__ level,
     const double* __restrict__ pt_pos, const uint8_t* __restrict__ edgelet, const double* __restrict__ grad,
-    const double* __restrict__ px_cur, SeedRec* __restrict__ recs) {
+    const double* __restrict__ px_cur, SeedRec* __restrict__ recs, const double* __restrict__ T_cur_w_dev,
+    const int* __restrict__ n_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const Cam cam = fr.cam;
   SeedRec rc;
-  rc.uv0[0] = px_cur[2 * (size_t)i]; rc.uv0[1] = px_cur[2 * (size_t)i + 1];
+  rc.uv0[0] = rc.uv0[1] = 0.0;
   rc.step[0] = rc.step[1] = 0.0;
   rc.a00 = rc.a01 = rc.a10 = rc.a11 = rc.prx = rc.pry = 0.0f; rc.z_inv_min = 0.0f;
   rc.n_steps = 0; rc.search_level = 0; rc.path = -1; rc.status = 0; rc.warp_nan = 0;
-  rc.matched = 0; rc.n_zmssd = 0; rc.n_align = 0;
+  rc.matched = 0; rc.n_zmssd = 0; rc.n_align = 0; rc.pad = 0;
+  // tracking chain (svo_track.hip): the item count and the frame pose come from earlier kernels of the same stream;
+  // the launch covers the capacity and the items past the count become records no later stage touches
+  if (n_dev && i >= *n_dev) { recs[i] = rc; return; }
+  if (T_cur_w_dev) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) fr.T_cur_w[k] = T_cur_w_dev[k];
+  }
+  rc.uv0[0] = px_cur[2 * (size_t)i]; rc.uv0[1] = px_cur[2 * (size_t)i + 1];
   const int slot = kf_slot[i];
   rc.pad = slot;
   const int level_ref = level[i];
@@ -1344,14 +1332,18 @@ int svo_hip_epipolar_match_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* re
   return SVO_HIP_OK;
 }
 
-int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, int cur_slot,
-                                   const svo_hip_camera* cam, int n_kf, const double* T_ref_w_dev,
-                                   const double T_cur_w[7], int n, const int32_t* kf_slot_dev, const double* px_ref_dev,
-                                   const double* f_ref_dev, const int32_t* level_ref_dev, const double* pt_pos_dev,
-                                   const uint8_t* edgelet_dev, const double* grad_dev, int n_pyr_levels,
-                                   int align_max_iter, double* px_cur_dev, uint8_t* success_dev,
-                                   int32_t* search_level_dev) {
-  if (!ctx || !ref || !cur || !cam || !T_cur_w) return SVO_HIP_ERR_INVALID;
+}  // extern "C"
+
+// svo_hip_match_direct_batch_dev with, optionally, the pose of the current frame and the number of items left on the
+// device by earlier kernels of the stream (T_cur_w_dev / n_dev non-null: the tracking chain of svo_track.hip; n is then
+// the capacity the launches cover)
+int svo_match_direct_internal(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, int cur_slot,
+                              const svo_hip_camera* cam, int n_kf, const double* T_ref_w_dev, const double* T_cur_w,
+                              const double* T_cur_w_dev, int n, const int* n_dev, const int32_t* kf_slot_dev,
+                              const double* px_ref_dev, const double* f_ref_dev, const int32_t* level_ref_dev,
+                              const double* pt_pos_dev, const uint8_t* edgelet_dev, const double* grad_dev, int n_pyr_levels,
+                              int align_max_iter, double* px_cur_dev, uint8_t* success_dev, int32_t* search_level_dev) {
+  if (!ctx || !ref || !cur || !cam || (!T_cur_w && !T_cur_w_dev)) return SVO_HIP_ERR_INVALID;
   SVO_REQUIRE(ctx, cur_slot >= 0 && cur_slot < cur->batch && n_kf >= 1 && n_kf <= ref->batch);
   SVO_REQUIRE(ctx, ref->width == cam->width && ref->height == cam->height && cur->width == cam->width && cur->height == cam->height);
   SVO_REQUIRE(ctx, n_pyr_levels >= 1 && n_pyr_levels <= ref->n_levels && n_pyr_levels <= cur->n_levels && align_max_iter >= 0);
@@ -1368,7 +1360,8 @@ int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref,
   }
   MdFrame mf;
   mf.cam = svo_make_cam(*cam);
-  memcpy(mf.T_cur_w, T_cur_w, sizeof(double) * 7);
+  if (T_cur_w) memcpy(mf.T_cur_w, T_cur_w, sizeof(double) * 7);
+  else memset(mf.T_cur_w, 0, sizeof(double) * 7);
   mf.n_pyr_levels = n_pyr_levels;
   mf.n_kf = n_kf; mf.n_ref_levels = ref->n_levels;
   DfFrame fr;
@@ -1378,7 +1371,7 @@ int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref,
   for (int l = 0; l < cur->n_levels; ++l) fr.cur_level_off[l] = cur->level_offset[l];
   fr.n_pyr_levels = n_pyr_levels; fr.align_max_iter = align_max_iter; fr.keep_px_on_failure = 1;
   hipLaunchKernelGGL(md_geometry_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, mf, n, T_ref_w_dev, kf_slot_dev,
-                     px_ref_dev, f_ref_dev, level_ref_dev, pt_pos_dev, edgelet_dev, grad_dev, px_cur_dev, recs);
+                     px_ref_dev, f_ref_dev, level_ref_dev, pt_pos_dev, edgelet_dev, grad_dev, px_cur_dev, recs, T_cur_w_dev, n_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref->base, ref->pyr_bytes,
                      cur->base + (size_t)cur_slot * cur->pyr_bytes, n, level_ref_dev, recs, pwb_t, n_pad);
@@ -1395,6 +1388,21 @@ int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref,
                      search_level_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
+}
+
+extern "C" {
+
+int svo_hip_match_direct_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, int cur_slot,
+                                   const svo_hip_camera* cam, int n_kf, const double* T_ref_w_dev,
+                                   const double T_cur_w[7], int n, const int32_t* kf_slot_dev, const double* px_ref_dev,
+                                   const double* f_ref_dev, const int32_t* level_ref_dev, const double* pt_pos_dev,
+                                   const uint8_t* edgelet_dev, const double* grad_dev, int n_pyr_levels,
+                                   int align_max_iter, double* px_cur_dev, uint8_t* success_dev,
+                                   int32_t* search_level_dev) {
+  if (!T_cur_w) return SVO_HIP_ERR_INVALID;
+  return svo_match_direct_internal(ctx, ref, cur, cur_slot, cam, n_kf, T_ref_w_dev, T_cur_w, nullptr, n, nullptr, kf_slot_dev, px_ref_dev,
+                                   f_ref_dev, level_ref_dev, pt_pos_dev, edgelet_dev, grad_dev, n_pyr_levels, align_max_iter, px_cur_dev,
+                                   success_dev, search_level_dev);
 }
 
 // host-buffer convenience form: copies the SoA arrays in, runs, copies the results out, synchronises

@@ -272,6 +272,30 @@ SVO_DEV bool is_in_frame_level(const Cam& c, int ox, int oy, int boundary, int l
          oy < c.height / (1 << level) - boundary;
 }
 
+// S/matcher.cpp:36-60 (A row-major)
+SVO_DEV void get_warp_matrix_affine(const Cam& cam, const double* px_ref, const double* f_ref, double depth_ref,
+                                    const double* T_cur_ref, int level_ref, double* A) {
+  const int halfpatch_size = 5;
+  const double xyz_ref[3] = {f_ref[0] * depth_ref, f_ref[1] * depth_ref, f_ref[2] * depth_ref};
+  double du[3], dv[3];
+  const double off = (double)halfpatch_size * (1 << level_ref);
+  cam2world(cam, px_ref[0] + off, px_ref[1] + 0.0 * (1 << level_ref), du);
+  cam2world(cam, px_ref[0] + 0.0 * (1 << level_ref), px_ref[1] + off, dv);
+  const double su = xyz_ref[2] / du[2];
+  du[0] *= su; du[1] *= su; du[2] *= su;
+  const double sv = xyz_ref[2] / dv[2];
+  dv[0] *= sv; dv[1] *= sv; dv[2] *= sv;
+  double p[3], px_cur[2], px_du[2], px_dv[2];
+  se3_act(T_cur_ref, xyz_ref, p); world2cam(cam, p, px_cur);
+  se3_act(T_cur_ref, du, p);      world2cam(cam, p, px_du);
+  se3_act(T_cur_ref, dv, p);      world2cam(cam, p, px_dv);
+  A[0] = (px_du[0] - px_cur[0]) / halfpatch_size;
+  A[2] = (px_du[1] - px_cur[1]) / halfpatch_size;
+  A[1] = (px_dv[0] - px_cur[0]) / halfpatch_size;
+  A[3] = (px_dv[1] - px_cur[1]) / halfpatch_size;
+}
+
+
 // I/frame.h:110-132, 2x6 row-major
 SVO_DEV void jacobian_xyz2uv(const double* p, double* J) {
   const double x = p[0], y = p[1];

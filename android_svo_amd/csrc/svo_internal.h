@@ -121,6 +121,57 @@ inline svo_dev::Cam svo_make_cam(const svo_hip_camera& c) {
   return d;
 }
 
+// ---- SparseImgAlign solver records shared between svo_sia.hip and svo_track.hip
+namespace svo_dev {
+// per-frame constants
+struct FrameConst {
+  Cam cam;
+  double T_ref_w[7];
+  double T_cur_w_init[7];
+  double ref_pos[3];
+  int n_feat;
+  int pad;
+};
+
+// per-frame Gauss-Newton state (I/nlls_solver.h:51-60,96-111)
+struct FrameState {
+  double model[7];        // T_cur_from_ref
+  double old_model[7];
+  double chi2;            // chi2_
+  double H[36];
+  double Jres[6];
+  double x[6];
+  unsigned long long n_meas;
+  unsigned long long n_pre, n_res;
+  int stop;               // stop_ (persists across levels)
+  int iter;               // iter_ of the current level
+  int level_done;         // the level's GN loop has exited
+  int empty;              // ref frame has no features: run() returns 0 and leaves the pose alone (:55-59)
+  int iters[SVO_HIP_MAX_LEVELS];
+  double T_cur_w[7];      // result
+};
+}  // namespace svo_dev
+
+// internal entries of svo_sia.hip for the device-resident tracking chain (svo_track.hip): slot 0 of the solver is filled
+// by a kernel from device arrays -- the previous frame's features (pixel, bearing, map point index or -1) and the point
+// table -- with ref_frame->T_f_w_ = cur_frame->T_f_w_ = *T_last_w_dev (frame_handler_mono.cpp:175); n_feat_host is the
+// feature count the host knows from the previous frame's result (it chooses the kernel shape; the kernel itself reads
+// the count the device wrote).  The solve leaves its result in the device record svo_sia_state_dev returns.
+struct svo_hip_sia;
+int svo_sia_prepare_from_device(svo_hip_sia* s, const svo_hip_camera* cam, int n_feat_host, const int* n_feat_dev,
+                                const double* T_last_w_dev, const double* px_dev, const double* f_dev, const int32_t* point_dev,
+                                const double* pt_pos_dev);
+const svo_dev::FrameState* svo_sia_state_dev(const svo_hip_sia* s);
+
+// svo_depth.hip: Matcher::findMatchDirect over n items (svo_hip_match_direct_batch_dev) with, optionally, the current
+// frame's pose and the item count read from device memory
+int svo_match_direct_internal(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, int cur_slot,
+                              const svo_hip_camera* cam, int n_kf, const double* T_ref_w_dev, const double* T_cur_w,
+                              const double* T_cur_w_dev, int n, const int* n_dev, const int32_t* kf_slot_dev,
+                              const double* px_ref_dev, const double* f_ref_dev, const int32_t* level_ref_dev,
+                              const double* pt_pos_dev, const uint8_t* edgelet_dev, const double* grad_dev, int n_pyr_levels,
+                              int align_max_iter, double* px_cur_dev, uint8_t* success_dev, int32_t* search_level_dev);
+
 // ---- multi-GPU exchange (svo_comm.hip): RCCL over xGMI, or a host-staged shared-memory transport for bring-up / tests.
 // Both all-reduce in place on the communicator's context stream and give every rank bitwise the same result.
 struct svo_hip_comm;

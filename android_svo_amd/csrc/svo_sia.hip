@@ -56,34 +56,7 @@ constexpr uint8_t F_JVALID = 2;                 // jacobian_cache_ column block 
 constexpr uint8_t F_GONE = 4;
 constexpr uint8_t F_HASPOINT = 8;              // fused kernel: the feature has a map point (sticky)                   // fused kernel: outside the current image at the previous evaluation
 
-// per-frame constants
-struct FrameConst {
-  Cam cam;
-  double T_ref_w[7];
-  double T_cur_w_init[7];
-  double ref_pos[3];
-  int n_feat;
-  int pad;
-};
-
-// per-frame Gauss-Newton state (I/nlls_solver.h:51-60,96-111)
-struct FrameState {
-  double model[7];        // T_cur_from_ref
-  double old_model[7];
-  double chi2;            // chi2_
-  double H[36];
-  double Jres[6];
-  double x[6];
-  unsigned long long n_meas;
-  unsigned long long n_pre, n_res;
-  int stop;               // stop_ (persists across levels)
-  int iter;               // iter_ of the current level
-  int level_done;         // the level's GN loop has exited
-  int empty;              // ref frame has no features: run() returns 0 and leaves the pose alone (:55-59)
-  int iters[SVO_HIP_MAX_LEVELS];
-  double T_cur_w[7];      // result
-};
-
+// (FrameConst, FrameState: svo_internal.h -- the tracking chain of svo_track.hip writes the one and reads the other on the device)
 struct LevelGeom {
   int cols, rows;
   size_t ref_off, cur_off;   // byte offset of the level inside a pyramid
@@ -1520,6 +1493,37 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   }
 }
 
+// Tracking chain (svo_track.hip): slot 0 of a solver filled from device arrays -- the previous frame's features and the
+// point table -- so that SparseImgAlign::run(last_frame, new_frame) with new_frame->T_f_w_ = last_frame->T_f_w_
+// (frame_handler_mono.cpp:175,186-188) starts without a host round trip.  One workgroup.
+__global__ __launch_bounds__(256) void sia_gather_kernel(FrameConst* __restrict__ fc, Cam cam, const int* __restrict__ n_feat_dev, int max_n,
+                                                         const double* __restrict__ T_last_w, const double* __restrict__ px_in,
+                                                         const double* __restrict__ f_in, const int32_t* __restrict__ point_in,
+                                                         const double* __restrict__ pt_pos, double* __restrict__ px, double* __restrict__ f,
+                                                         double* __restrict__ pos, uint8_t* __restrict__ has_point) {
+  int n = *n_feat_dev;
+  if (n > max_n) n = max_n;
+  if (threadIdx.x == 0) {
+    FrameConst c;
+    c.cam = cam;
+    double Tinv[7];
+    se3_inverse(T_last_w, Tinv);                                     // Frame::pos() (I/frame.h:105)
+    for (int i = 0; i < 7; ++i) { c.T_ref_w[i] = T_last_w[i]; c.T_cur_w_init[i] = T_last_w[i]; }
+    c.ref_pos[0] = Tinv[0]; c.ref_pos[1] = Tinv[1]; c.ref_pos[2] = Tinv[2];
+    c.n_feat = n; c.pad = 0;
+    fc[0] = c;
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int p = point_in[i];
+    px[2 * i] = px_in[2 * i]; px[2 * i + 1] = px_in[2 * i + 1];
+    f[3 * i] = f_in[3 * i]; f[3 * i + 1] = f_in[3 * i + 1]; f[3 * i + 2] = f_in[3 * i + 2];
+    has_point[i] = p >= 0 ? 1 : 0;                                   // point == NULL features are skipped (sparse_img_align.cpp:118)
+    pos[3 * i] = p >= 0 ? pt_pos[3 * (size_t)p] : 0.0;
+    pos[3 * i + 1] = p >= 0 ? pt_pos[3 * (size_t)p + 1] : 0.0;
+    pos[3 * i + 2] = p >= 0 ? pt_pos[3 * (size_t)p + 2] : 1.0;
+  }
+}
+
 }  // namespace
 
 struct svo_hip_sia {
@@ -1790,6 +1794,24 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) {
 }
 
 }  // namespace
+
+int svo_sia_prepare_from_device(svo_hip_sia* s, const svo_hip_camera* cam, int n_feat_host, const int* n_feat_dev,
+                                const double* T_last_w_dev, const double* px_dev, const double* f_dev, const int32_t* point_dev,
+                                const double* pt_pos_dev) {
+  if (!s || !cam) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = s->ctx;
+  SVO_REQUIRE(ctx, n_feat_host >= 0 && n_feat_host <= s->max_n && n_feat_dev && T_last_w_dev && px_dev && f_dev && point_dev && pt_pos_dev);
+  hipLaunchKernelGGL(sia_gather_kernel, dim3(1), dim3(256), 0, ctx->stream, s->fc, svo_make_cam(*cam), n_feat_dev, s->max_n, T_last_w_dev,
+                     px_dev, f_dev, point_dev, pt_pos_dev, s->px, s->f, s->pos, s->has_point);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  // the host mirror only steers the launch (kernel shape by the feature count); the device record is authoritative
+  s->h_fc[0].n_feat = n_feat_host;
+  s->h_fc[0].cam = svo_make_cam(*cam);
+  s->fc_dirty = false;
+  return SVO_HIP_OK;
+}
+
+const svo_dev::FrameState* svo_sia_state_dev(const svo_hip_sia* s) { return s ? s->st : nullptr; }
 
 extern "C" {
 

@@ -1,0 +1,844 @@
+// svo_track.hip -- one tracked frame of FrameHandlerMono::processFrame (S/frame_handler_mono.cpp:171-229) as ONE chain of
+// kernels on ONE stream with ONE synchronisation at the end:
+//
+//   new_frame->T_f_w_ = last_frame->T_f_w_                                   (:175)
+//   SparseImgAlign(kltMaxLevel, kltMinLevel, 30, GaussNewton).run(last, new)  (:186-188)   svo_sia.hip, fused kernel
+//   Reprojector::reprojectMap(new_frame, overlap_kfs)                         (:203)       trk_plan_kernel -> Matcher::findMatchDirect
+//                                                                                          batch (svo_depth.hip) -> trk_replay_kernel
+//   pose_optimizer::optimizeGaussNewton(...)                                  (:226-229)   svo_refine.hip
+//   last_frame_ = new_frame_                                                  (frame_handler_mono.cpp:91)   trk_finish_kernel
+//
+// What stays on the device between the stages: the pose SparseImgAlign leaves (read by the reprojection and by the pose
+// refinement straight from the solver's record), the candidates of every grid cell, the matches, and -- across frames --
+// the new frame's pyramid and features, which are the next call's reference frame.  The map the reprojector walks
+// (keyframe poses / pyramids / feature lists / key points, points with their observation lists, point candidates) is a
+// set of index tables the host uploads when the map changes (keyframe rate); the counters the reprojector keeps on the
+// points (n_failed_reproj_, n_succeeded_reproj_, type promotions) are advanced on the device and returned with every
+// frame.  A point the reprojector deletes changes the pointer graph (Map::safeDeletePoint clears feature references and
+// re-selects key points): the device marks it unlinked, reports map_changed and the host uploads the map again.
+//
+// The two serial policies of the reference are kept by construction, not approximated:
+//   * cell lists are formed in the reference's push_back order (closest keyframe first, each keyframe's fts_ order, a
+//     point only once: last_projected_kf_id_, then the point candidates) and stably ordered by point type
+//     (cell.sort(pointQualityComparator)) -- every item gets its sequence number and a rank inside its cell;
+//   * all candidates are matched in one batch, then "first success per cell wins, stop once n_matches exceeds maxFts" is
+//     replayed over the results (Matcher::findMatchDirect is a pure function of its candidate).
+#include <climits>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "svo_internal.h"
+
+using namespace svo_dev;
+
+namespace {
+
+constexpr int TRK_THREADS = 1024;
+constexpr int TRK_MAX_SEL = 16;            // >= Reprojector::Options::max_n_kfs
+constexpr int TYPE_DELETED = 0, TYPE_CANDIDATE = 1, TYPE_UNKNOWN = 2, TYPE_GOOD = 3;   // Point::PointType (I/point.h:33-38)
+
+// the map as index tables (device pointers)
+struct TrkMap {
+  int n_kf, n_points, n_candidates;
+  const double* T_kf_w;          // [n_kf][7]
+  const int* kf_slot;            // [n_kf] pyramid slot
+  const int* kf_key_point;       // [n_kf][5]
+  const int* kf_ftr_offset;      // [n_kf + 1]
+  const int* kf_ftr_point;
+  const double* pt_pos;          // [n_points][3]
+  int* pt_type;
+  int* pt_n_failed;
+  int* pt_n_succeeded;
+  uint8_t* pt_unlinked;
+  const int* pt_obs_offset;      // [n_points + 1]
+  const int* obs_kf;
+  const double* obs_px;
+  const double* obs_f;
+  const int* obs_level;
+  const uint8_t* obs_edgelet;
+  const double* obs_grad;
+  const int* cand_point;
+};
+
+// scratch and outputs of the planning kernel; cap = capacity of the candidate arrays
+struct TrkPlan {
+  int cap, n_cells, grid_cols, grid_size, max_n_kfs;
+  int* kf_close;                 // [n_kf]
+  double* kf_dist;               // [n_kf]
+  int* first_seq;                // [n_points]
+  int* item_point;               // [cap] kept items in arrival order
+  double* item_px;               // [cap][2]
+  int* item_cell;                // [cap]
+  unsigned long long* item_key;  // [cap]
+  int* seg;                      // [cap]
+  int* cell_count;               // [n_cells + 1]
+  int* cell_fill;                // [n_cells]
+  // outputs (the candidates of every cell in trial order)
+  int* counters;                 // [8]: 0 n_cand, 1 overflow, 2 map_changed, 3 n_overlap, 4 n_features, 5 n_pose_opt, 6.. n_trials (64 bit)
+  int* cell_offset;              // [n_cells + 1]
+  int* overlap_kf;               // [TRK_MAX_SEL]
+  int* overlap_count;            // [TRK_MAX_SEL]
+  int* cand_point;               // [cap]
+  int* cand_obs;                 // [cap] (-1: Point::getCloseViewObs failed)
+  int* cand_kf_slot;             // [cap] pyramid slot of the reference feature, -1 = do not match
+  double* cand_px_ref;           // [cap][2]
+  double* cand_f_ref;            // [cap][3]
+  int* cand_level_ref;           // [cap]
+  double* cand_pt_pos;           // [cap][3]
+  uint8_t* cand_edgelet;         // [cap]
+  double* cand_grad;             // [cap][2]
+  double* cand_px_cur;           // [cap][2] in: the projection, out: the refined pixel
+  uint8_t* cand_deleted;         // [cap]
+};
+
+// the new frame's features (what Reprojector::reprojectCell adds to frame->fts_, in creation order) + pose-refinement inputs
+struct TrkFeat {
+  int cap;
+  double* px;        // [cap][2]
+  double* f;         // [cap][3]
+  double* pos;       // [cap][3]
+  int* level;        // [cap]
+  int* point;        // [cap]
+  uint8_t* edgelet;  // [cap]
+  double* grad;      // [cap][2]
+  uint8_t* has_point;   // [cap] in/out of the pose refinement
+};
+
+// the last frame (reference of the next SparseImgAlign)
+struct TrkLast {
+  int* n;            // [1]
+  double* T_f_w;     // [7]
+  double* px;        // [cap][2]
+  double* f;         // [cap][3]
+  int* point;        // [cap]
+};
+
+// Frame::isVisible (S/frame.cpp:162-172)
+SVO_DEV bool frame_is_visible(const Cam& cam, const double* T_f_w, const double* xyz_w) {
+  double xyz_f[3], px[2];
+  se3_act(T_f_w, xyz_w, xyz_f);
+  if (xyz_f[2] < 0.0) return false;
+  world2cam(cam, xyz_f, px);
+  return px[0] >= 0.0 && px[1] >= 0.0 && px[0] < cam.width && px[1] < cam.height;
+}
+
+// v.normalize() of Eigen 3.4: divide by the norm when the squared norm is positive
+SVO_DEV void normalize3(double* v) {
+  const double n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  if (n2 > 0.0) { const double nn = sqrt(n2); v[0] = v[0] / nn; v[1] = v[1] / nn; v[2] = v[2] / nn; }
+}
+
+// Point::getCloseViewObs (S/point.cpp:101-125): the observation whose viewing direction is closest to the frame's (first
+// maximum of the cosine above zero, else the first observation); false when the angle exceeds 60 degrees
+SVO_DEV bool close_view_obs(const TrkMap& m, int p, const double* framepos, int* obs_out) {
+  const double* pos = m.pt_pos + 3 * (size_t)p;
+  double od[3] = {framepos[0] - pos[0], framepos[1] - pos[1], framepos[2] - pos[2]};
+  normalize3(od);
+  int min_it = m.pt_obs_offset[p];
+  double min_cos_angle = 0;
+  for (int o = m.pt_obs_offset[p]; o < m.pt_obs_offset[p + 1]; ++o) {
+    double Tinv[7];
+    se3_inverse(m.T_kf_w + 7 * (size_t)m.obs_kf[o], Tinv);                 // (*it)->frame->pos()
+    double d[3] = {Tinv[0] - pos[0], Tinv[1] - pos[1], Tinv[2] - pos[2]};
+    normalize3(d);
+    const double cos_angle = od[0] * d[0] + od[1] * d[1] + od[2] * d[2];
+    if (cos_angle > min_cos_angle) { min_cos_angle = cos_angle; min_it = o; }
+  }
+  *obs_out = min_it;
+  return !(min_cos_angle < 0.5);
+}
+
+// exclusive scan of v[0..n) in place by one workgroup, total -> v[n]; s_part: blockDim.x ints of LDS
+SVO_DEV void block_exclusive_scan(int* v, int n, int* s_part) {
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int chunk = (n + nt - 1) / nt;
+  const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += v[i];
+  s_part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < nt; d <<= 1) {                      // Hillis-Steele over the thread sums
+    const int add = t >= d ? s_part[t - d] : 0;
+    __syncthreads();
+    s_part[t] += add;
+    __syncthreads();
+  }
+  int run = s_part[t] - sum;                              // exclusive prefix of this thread's chunk
+  for (int i = lo; i < hi; ++i) { const int c = v[i]; v[i] = run; run += c; }
+  if (t == nt - 1) v[n] = s_part[t];
+  __syncthreads();
+}
+
+// ---- Reprojector::reprojectMap up to the cell loop (S/reprojector.cpp:72-146) + the per-candidate choice of the reference
+// feature (Point::getCloseViewObs, the first statement of Matcher::findMatchDirect).  One workgroup.
+__global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan pl, Cam cam, const FrameState* __restrict__ sia_state) {
+  __shared__ int s_part[TRK_THREADS];
+  __shared__ int s_sel[TRK_MAX_SEL], s_seq_base[TRK_MAX_SEL + 1];
+  __shared__ int s_n_close, s_n_sel, s_n_kept, s_overflow, s_changed;
+  __shared__ int s_overlap[TRK_MAX_SEL];
+  __shared__ double s_T[7], s_framepos[3];
+  const int t = threadIdx.x, nt = blockDim.x;
+  if (t < 7) s_T[t] = sia_state->T_cur_w[t];
+  if (t == 0) { s_n_close = 0; s_n_kept = 0; s_overflow = 0; s_changed = 0; }
+  if (t < TRK_MAX_SEL) { s_sel[t] = -1; s_overlap[t] = 0; }
+  __syncthreads();
+  double T[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) T[k] = s_T[k];
+  if (t == 0) {
+    double Tinv[7];
+    se3_inverse(T, Tinv);                                                  // cur_frame.pos()
+    s_framepos[0] = Tinv[0]; s_framepos[1] = Tinv[1]; s_framepos[2] = Tinv[2];
+  }
+  // ---- Map::getCloseKeyframes (S/map.cpp:109-131): keyframes one of whose key points is visible in the frame
+  for (int k = t; k < m.n_kf; k += nt) {
+    bool close = false;
+    for (int j = 0; j < 5 && !close; ++j) {
+      const int p = m.kf_key_point[5 * k + j];
+      if (p >= 0) close = frame_is_visible(cam, T, m.pt_pos + 3 * (size_t)p);
+    }
+    const double* tk = m.T_kf_w + 7 * (size_t)k;
+    const double dx = T[0] - tk[0], dy = T[1] - tk[1], dz = T[2] - tk[2];
+    pl.kf_close[k] = close ? 1 : 0;
+    pl.kf_dist[k] = sqrt(dx * dx + dy * dy + dz * dz);                     // (translation_vec difference).norm()
+    if (close) atomicAdd(&s_n_close, 1);
+  }
+  for (int p = t; p < m.n_points; p += nt) pl.first_seq[p] = INT_MAX;
+  for (int c = t; c <= pl.n_cells; c += nt) pl.cell_count[c] = 0;
+  for (int c = t; c < pl.n_cells; c += nt) pl.cell_fill[c] = 0;
+  __syncthreads();
+  // ---- close_kfs.sort by distance (stable: std::list::sort), the first max_n_kfs of them (:82-88)
+  for (int k = t; k < m.n_kf; k += nt) {
+    if (!pl.kf_close[k]) continue;
+    const double dk = pl.kf_dist[k];
+    int rank = 0;
+    for (int j = 0; j < m.n_kf; ++j)
+      if (pl.kf_close[j] && (pl.kf_dist[j] < dk || (!(dk < pl.kf_dist[j]) && j < k))) ++rank;
+    if (rank < pl.max_n_kfs) s_sel[rank] = k;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const int n_sel = s_n_close < pl.max_n_kfs ? s_n_close : pl.max_n_kfs;
+    s_n_sel = n_sel;
+    int base = 0;
+    for (int r = 0; r < n_sel; ++r) { s_seq_base[r] = base; base += m.kf_ftr_offset[s_sel[r] + 1] - m.kf_ftr_offset[s_sel[r]]; }
+    s_seq_base[n_sel] = base;
+  }
+  __syncthreads();
+  const int n_sel = s_n_sel;
+  const int m_kf = s_seq_base[n_sel];
+  const int m_all = m_kf + m.n_candidates;
+  // ---- a point is projected once: the first keyframe feature that refers to it (last_projected_kf_id_, :103-106)
+  for (int q = t; q < m_kf; q += nt) {
+    int r = 0;
+    while (r + 1 < n_sel && q >= s_seq_base[r + 1]) ++r;
+    const int p = m.kf_ftr_point[m.kf_ftr_offset[s_sel[r]] + (q - s_seq_base[r])];
+    if (p >= 0 && !m.pt_unlinked[p]) atomicMin(&pl.first_seq[p], q);
+  }
+  __syncthreads();
+  // ---- reprojectPoint (:246-259) for the keyframe points and the point candidates (:118-138)
+  for (int q = t; q < m_all; q += nt) {
+    int p, r = -1;
+    if (q < m_kf) {
+      r = 0;
+      while (r + 1 < n_sel && q >= s_seq_base[r + 1]) ++r;
+      p = m.kf_ftr_point[m.kf_ftr_offset[s_sel[r]] + (q - s_seq_base[r])];
+      if (p < 0 || m.pt_unlinked[p] || pl.first_seq[p] != q) continue;
+    } else {
+      p = m.cand_point[q - m_kf];
+      if (p < 0 || m.pt_unlinked[p]) continue;
+    }
+    double xyz_f[3], px[2];
+    se3_act(T, m.pt_pos + 3 * (size_t)p, xyz_f);
+    world2cam(cam, xyz_f, px);                                             // frame->w2c(point->pos_)
+    const int ix = (int)px[0], iy = (int)px[1];                            // px.cast<int>()
+    const bool in = px[0] == px[0] && px[1] == px[1] && ix >= 8 && ix < cam.width - 8 && iy >= 8 && iy < cam.height - 8;   // isInFrame(., 8)
+    if (in) {
+      const int cell = (int)(px[1] / pl.grid_size) * pl.grid_cols + (int)(px[0] / pl.grid_size);
+      const int idx = atomicAdd(&s_n_kept, 1);
+      if (idx < pl.cap) {
+        pl.item_point[idx] = p;
+        pl.item_px[2 * idx] = px[0]; pl.item_px[2 * idx + 1] = px[1];
+        pl.item_cell[idx] = cell;
+        pl.item_key[idx] = ((unsigned long long)(3 - m.pt_type[p]) << 32) | (unsigned)q;   // cell.sort: higher type first, stable
+        atomicAdd(&pl.cell_count[cell], 1);
+      } else {
+        s_overflow = 1;
+      }
+      if (r >= 0) atomicAdd(&s_overlap[r], 1);                             // overlap_kfs.back().second++ (:112-113)
+    } else if (q >= m_kf) {
+      // a candidate that is not in the frame (:126-135); the point sits in no cell, nobody else touches it
+      const int nf = m.pt_n_failed[p] + 3;
+      m.pt_n_failed[p] = nf;
+      if (nf > 30) { m.pt_type[p] = TYPE_DELETED; m.pt_unlinked[p] = 1; s_changed = 1; }    // deleteCandidate + erase
+    }
+  }
+  __syncthreads();
+  const int n_kept = s_n_kept < pl.cap ? s_n_kept : pl.cap;
+  // ---- cell segments
+  block_exclusive_scan(pl.cell_count, pl.n_cells, s_part);                 // cell_count[c] = start of cell c, [n_cells] = total
+  for (int c = t; c <= pl.n_cells; c += nt) pl.cell_offset[c] = pl.cell_count[c];
+  for (int i = t; i < n_kept; i += nt) {
+    const int c = pl.item_cell[i];
+    pl.seg[pl.cell_count[c] + atomicAdd(&pl.cell_fill[c], 1)] = i;
+  }
+  __syncthreads();
+  // ---- trial order inside the cell, and the reference feature of every candidate
+  const double framepos[3] = {s_framepos[0], s_framepos[1], s_framepos[2]};
+  for (int s = t; s < n_kept; s += nt) {
+    const int i = pl.seg[s];
+    const int c = pl.item_cell[i];
+    const unsigned long long key = pl.item_key[i];
+    int rank = 0;
+    for (int j = pl.cell_count[c]; j < pl.cell_count[c + 1]; ++j) rank += pl.item_key[pl.seg[j]] < key ? 1 : 0;
+    const int o = pl.cell_count[c] + rank;
+    const int p = pl.item_point[i];
+    const bool deleted = m.pt_type[p] == TYPE_DELETED;
+    int obs = -1;
+    bool view_ok = false;
+    if (!deleted && m.pt_obs_offset[p + 1] > m.pt_obs_offset[p]) view_ok = close_view_obs(m, p, framepos, &obs);
+    pl.cand_point[o] = p;
+    pl.cand_obs[o] = view_ok ? obs : -1;
+    pl.cand_deleted[o] = deleted ? 1 : 0;
+    pl.cand_px_cur[2 * o] = pl.item_px[2 * i]; pl.cand_px_cur[2 * o + 1] = pl.item_px[2 * i + 1];
+    pl.cand_pt_pos[3 * o] = m.pt_pos[3 * (size_t)p]; pl.cand_pt_pos[3 * o + 1] = m.pt_pos[3 * (size_t)p + 1]; pl.cand_pt_pos[3 * o + 2] = m.pt_pos[3 * (size_t)p + 2];
+    if (view_ok) {
+      pl.cand_kf_slot[o] = m.kf_slot[m.obs_kf[obs]];
+      pl.cand_px_ref[2 * o] = m.obs_px[2 * (size_t)obs]; pl.cand_px_ref[2 * o + 1] = m.obs_px[2 * (size_t)obs + 1];
+      pl.cand_f_ref[3 * o] = m.obs_f[3 * (size_t)obs]; pl.cand_f_ref[3 * o + 1] = m.obs_f[3 * (size_t)obs + 1]; pl.cand_f_ref[3 * o + 2] = m.obs_f[3 * (size_t)obs + 2];
+      pl.cand_level_ref[o] = m.obs_level[obs];
+      pl.cand_edgelet[o] = m.obs_edgelet[obs];
+      pl.cand_grad[2 * o] = m.obs_grad[2 * (size_t)obs]; pl.cand_grad[2 * o + 1] = m.obs_grad[2 * (size_t)obs + 1];
+    } else {
+      pl.cand_kf_slot[o] = -1;                                             // rejected by the matcher's range test: no work, no success
+      pl.cand_px_ref[2 * o] = pl.cand_px_ref[2 * o + 1] = 0.0;
+      pl.cand_f_ref[3 * o] = pl.cand_f_ref[3 * o + 1] = 0.0; pl.cand_f_ref[3 * o + 2] = 1.0;
+      pl.cand_level_ref[o] = 0;
+      pl.cand_edgelet[o] = 0;
+      pl.cand_grad[2 * o] = 1.0; pl.cand_grad[2 * o + 1] = 0.0;
+    }
+  }
+  if (t == 0) {
+    pl.counters[0] = n_kept;
+    pl.counters[1] = s_overflow;
+    pl.counters[2] = s_changed;
+    pl.counters[3] = n_sel;
+  }
+  if (t < TRK_MAX_SEL) { pl.overlap_kf[t] = t < n_sel ? s_sel[t] : -1; pl.overlap_count[t] = t < n_sel ? s_overlap[t] : 0; }
+}
+
+// ---- the cell loop of Reprojector::reprojectMap (S/reprojector.cpp:149-166) with reprojectCell (:180-241) replayed over
+// the batch results: per cell the first successful candidate wins, the loop stops after the cell that takes n_matches
+// beyond max_fts; point bookkeeping (:202-215), the frame's new features (:217-231) and the inputs of the pose refinement.
+__global__ __launch_bounds__(TRK_THREADS) void trk_replay_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, Cam cam, const FrameState* __restrict__ sia_state,
+                                                                 const uint8_t* __restrict__ success, const int* __restrict__ search_level,
+                                                                 int* __restrict__ cell_winner, int* __restrict__ cell_cum, int max_fts,
+                                                                 int quality_min_fts) {
+  __shared__ int s_part[TRK_THREADS];
+  __shared__ int s_cut, s_changed;
+  __shared__ unsigned long long s_trials;
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int n_cells = pl.n_cells;
+  if (t == 0) { s_cut = n_cells - 1; s_changed = pl.counters[2]; s_trials = 0ull; }
+  // first success per cell
+  for (int c = t; c < n_cells; c += nt) {
+    int w = -1;
+    for (int i = pl.cell_offset[c]; i < pl.cell_offset[c + 1] && w < 0; ++i)
+      if (!pl.cand_deleted[i] && success[i]) w = i;
+    cell_winner[c] = w;
+    cell_cum[c] = w >= 0 ? 1 : 0;
+  }
+  __syncthreads();
+  block_exclusive_scan(cell_cum, n_cells, s_part);                          // cell_cum[c] = matches before cell c
+  for (int c = t; c < n_cells; c += nt)
+    if (cell_cum[c] + (cell_winner[c] >= 0 ? 1 : 0) > max_fts) atomicMin(&s_cut, c);     // n_matches_ > maxFts after this cell (:164-165)
+  __syncthreads();
+  const int cut = s_cut;
+  double T[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) T[k] = sia_state->T_cur_w[k];
+  unsigned long long my_trials = 0ull;
+  for (int c = t; c <= cut && c < n_cells; c += nt) {
+    const int w = cell_winner[c];
+    const int end = w >= 0 ? w + 1 : pl.cell_offset[c + 1];
+    for (int i = pl.cell_offset[c]; i < end; ++i) {
+      ++my_trials;                                                          // ++n_trials_ (:188)
+      if (pl.cand_deleted[i]) continue;                                     // TYPE_DELETED: erased from the cell (:190-194)
+      const int p = pl.cand_point[i];
+      if (i != w) {                                                         // :202-209
+        const int nf = m.pt_n_failed[p] + 1;
+        m.pt_n_failed[p] = nf;
+        const int ty = m.pt_type[p];
+        if ((ty == TYPE_UNKNOWN && nf > 15) || (ty == TYPE_CANDIDATE && nf > 30)) {   // safeDeletePoint / deleteCandidatePoint
+          m.pt_type[p] = TYPE_DELETED; m.pt_unlinked[p] = 1; s_changed = 1;
+        }
+        continue;
+      }
+      const int ns = m.pt_n_succeeded[p] + 1;                               // :211-214
+      m.pt_n_succeeded[p] = ns;
+      if (m.pt_type[p] == TYPE_UNKNOWN && ns > 10) m.pt_type[p] = TYPE_GOOD;
+      const int fi = cell_cum[c];                                           // creation order = cell order
+      if (fi < ft.cap) {
+        const double u = pl.cand_px_cur[2 * i], v = pl.cand_px_cur[2 * i + 1];
+        ft.px[2 * fi] = u; ft.px[2 * fi + 1] = v;
+        double fv[3];
+        cam2world(cam, u, v, fv);                                           // Feature(frame, px, level): f = cam2world(px) (I/feature.h:43-51)
+        ft.f[3 * fi] = fv[0]; ft.f[3 * fi + 1] = fv[1]; ft.f[3 * fi + 2] = fv[2];
+        ft.pos[3 * fi] = pl.cand_pt_pos[3 * i]; ft.pos[3 * fi + 1] = pl.cand_pt_pos[3 * i + 1]; ft.pos[3 * fi + 2] = pl.cand_pt_pos[3 * i + 2];
+        ft.level[fi] = search_level[i];
+        ft.point[fi] = p;
+        ft.has_point[fi] = 1;
+        double g0 = 1.0, g1 = 0.0;
+        const bool edge = pl.cand_edgelet[i] != 0;
+        if (edge) {                                                         // grad = (A_cur_ref_ * ref_ftr_->grad).normalized() (:224-229)
+          const int obs = pl.cand_obs[i];
+          const double* Tr = m.T_kf_w + 7 * (size_t)m.obs_kf[obs];
+          double T_ref_inv[7], T_cur_ref[7], A[4];
+          se3_inverse(Tr, T_ref_inv);
+          se3_mul(T, T_ref_inv, T_cur_ref);
+          const double dx = T_ref_inv[0] - pl.cand_pt_pos[3 * i], dy = T_ref_inv[1] - pl.cand_pt_pos[3 * i + 1], dz = T_ref_inv[2] - pl.cand_pt_pos[3 * i + 2];
+          get_warp_matrix_affine(cam, pl.cand_px_ref + 2 * i, pl.cand_f_ref + 3 * i, sqrt(dx * dx + dy * dy + dz * dz), T_cur_ref, pl.cand_level_ref[i], A);
+          g0 = A[0] * pl.cand_grad[2 * i] + A[1] * pl.cand_grad[2 * i + 1];
+          g1 = A[2] * pl.cand_grad[2 * i] + A[3] * pl.cand_grad[2 * i + 1];
+          const double n2 = g0 * g0 + g1 * g1;
+          if (n2 > 0.0) { const double nn = sqrt(n2); g0 = g0 / nn; g1 = g1 / nn; }
+        }
+        ft.edgelet[fi] = edge ? 1 : 0;
+        ft.grad[2 * fi] = g0; ft.grad[2 * fi + 1] = g1;
+      }
+    }
+  }
+  if (my_trials) atomicAdd(&s_trials, my_trials);
+  __syncthreads();
+  if (t == 0) {
+    const int last = cut < n_cells ? cut : n_cells - 1;
+    int n_matches = n_cells > 0 ? cell_cum[last] + (cell_winner[last] >= 0 ? 1 : 0) : 0;
+    const int n_feat = n_matches < ft.cap ? n_matches : ft.cap;
+    pl.counters[2] = s_changed;
+    pl.counters[4] = n_feat;
+    // processFrame returns before the pose refinement when the reprojector matched too few points (:208-215)
+    pl.counters[5] = n_matches < quality_min_fts ? 0 : n_feat;
+    pl.counters[6] = (int)(s_trials & 0xffffffffull);
+    pl.counters[7] = n_matches;
+  }
+}
+
+// ---- last_frame_ = new_frame_ (frame_handler_mono.cpp:91) and the result block.  One workgroup.
+__global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, TrkLast last, const FrameState* __restrict__ sia_state,
+                                                         const svo_hip_pose_opt_result* __restrict__ po, svo_hip_track_result* __restrict__ res,
+                                                         double* __restrict__ out_px, double* __restrict__ out_f, int* __restrict__ out_level,
+                                                         int* __restrict__ out_point, uint8_t* __restrict__ out_edgelet, double* __restrict__ out_grad,
+                                                         int* __restrict__ out_pt_type, int* __restrict__ out_pt_failed, int* __restrict__ out_pt_succeeded) {
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int n_feat = pl.counters[4];
+  const int n_po = pl.counters[5];
+  const bool refined = n_po > 0 && po->ran != 0;
+  if (t == 0) {
+    svo_hip_track_result r;
+    for (int i = 0; i < 7; ++i) r.T_f_w_sia[i] = sia_state->T_cur_w[i];
+    r.sia_n_tracked = sia_state->n_meas / 16;
+    for (int i = 0; i < SVO_HIP_MAX_LEVELS; ++i) r.sia_iters[i] = sia_state->iters[i];
+    r.sia_stop = sia_state->stop;
+    r.n_features = n_feat;
+    r.n_matches = (uint64_t)pl.counters[7];
+    r.n_trials = (uint64_t)(unsigned)pl.counters[6];
+    r.n_overlap = pl.counters[3];
+    r.map_changed = pl.counters[2];
+    for (int i = 0; i < 16; ++i) { r.overlap_kf[i] = i < TRK_MAX_SEL ? pl.overlap_kf[i] : -1; r.overlap_count[i] = i < TRK_MAX_SEL ? pl.overlap_count[i] : 0; }
+    r.n_candidates = pl.counters[0];
+    r.items_overflow = pl.counters[1];
+    r.pose = *po;
+    if (!refined) {                        // the reference did not reach / did not run the refinement: nothing of it is valid
+      memset(&r.pose, 0, sizeof(r.pose));
+      for (int i = 0; i < 7; ++i) r.pose.T_f_w[i] = sia_state->T_cur_w[i];
+    }
+    // new_frame_->T_f_w_ when processFrame hands the frame over: the refined pose, or -- too few matches (:211) -- the last frame's
+    for (int i = 0; i < 7; ++i) r.T_f_w[i] = n_po > 0 ? r.pose.T_f_w[i] : last.T_f_w[i];
+    *res = r;
+  }
+  __syncthreads();
+  for (int i = t; i < n_feat; i += nt) {
+    const int p = ft.has_point[i] ? ft.point[i] : -1;                       // pose_optimizer.cpp:154-157: (*it)->point = NULL
+    out_px[2 * i] = ft.px[2 * i]; out_px[2 * i + 1] = ft.px[2 * i + 1];
+    out_f[3 * i] = ft.f[3 * i]; out_f[3 * i + 1] = ft.f[3 * i + 1]; out_f[3 * i + 2] = ft.f[3 * i + 2];
+    out_level[i] = ft.level[i];
+    out_point[i] = p;
+    out_edgelet[i] = ft.edgelet[i];
+    out_grad[2 * i] = ft.grad[2 * i]; out_grad[2 * i + 1] = ft.grad[2 * i + 1];
+    last.px[2 * i] = ft.px[2 * i]; last.px[2 * i + 1] = ft.px[2 * i + 1];
+    last.f[3 * i] = ft.f[3 * i]; last.f[3 * i + 1] = ft.f[3 * i + 1]; last.f[3 * i + 2] = ft.f[3 * i + 2];
+    last.point[i] = p;
+  }
+  for (int p = t; p < m.n_points; p += nt) {
+    out_pt_type[p] = m.pt_type[p]; out_pt_failed[p] = m.pt_n_failed[p]; out_pt_succeeded[p] = m.pt_n_succeeded[p];
+  }
+  __syncthreads();
+  if (t == 0) {
+    *last.n = n_feat;
+    for (int i = 0; i < 7; ++i) last.T_f_w[i] = res->T_f_w[i];
+  }
+}
+
+template <typename T>
+int trk_alloc(svo_hip_ctx* ctx, T** p, size_t count) {
+  void* d = nullptr;
+  const int rc = svo_hip_malloc(ctx, &d, (count ? count : 1) * sizeof(T));
+  *p = (T*)d;
+  return rc;
+}
+
+}  // namespace
+
+struct svo_hip_tracker {
+  svo_hip_ctx* ctx = nullptr;
+  svo_hip_camera cam{};
+  svo_hip_tracker_config cfg{};
+  int n_cells = 0, grid_cols = 0, grid_rows = 0;
+  svo_hip_pyramid* kf_pyr = nullptr;        // max_keyframes slots
+  svo_hip_pyramid* frame_pyr[2] = {nullptr, nullptr};
+  int last_idx = 0;                         // frame_pyr[last_idx] holds the last frame
+  svo_hip_sia* sia = nullptr;
+  // map tables
+  double *T_kf_w = nullptr, *T_slot_w = nullptr, *pt_pos = nullptr, *obs_px = nullptr, *obs_f = nullptr, *obs_grad = nullptr;
+  int *kf_slot = nullptr, *kf_key_point = nullptr, *kf_ftr_offset = nullptr, *kf_ftr_point = nullptr, *pt_type = nullptr, *pt_n_failed = nullptr,
+      *pt_n_succeeded = nullptr, *pt_obs_offset = nullptr, *obs_kf = nullptr, *obs_level = nullptr, *cand_point = nullptr;
+  uint8_t *pt_unlinked = nullptr, *obs_edgelet = nullptr;
+  int n_kf = 0, n_points = 0, n_candidates = 0;
+  bool have_map = false, map_stale = false, have_last = false;
+  int last_n_host = 0;
+  // plan / replay scratch
+  TrkPlan pl{};
+  TrkFeat ft{};
+  TrkLast last{};
+  uint8_t* success = nullptr;
+  int *search_level = nullptr, *cell_winner = nullptr, *cell_cum = nullptr, *n_po_dev = nullptr;
+  svo_hip_pose_opt_result* po = nullptr;
+  // result block: [svo_hip_track_result][px][f][level][point][edgelet][grad][pt_type][pt_failed][pt_succeeded]
+  char* res_dev = nullptr;
+  char* res_host = nullptr;                 // page-locked
+  size_t o_px = 0, o_f = 0, o_level = 0, o_point = 0, o_edge = 0, o_grad = 0, o_pt = 0, res_bytes = 0;
+  // page-locked staging: one frame image, the map tables
+  uint8_t* img_host = nullptr;
+  char* map_host = nullptr;
+  size_t map_host_bytes = 0;
+  std::vector<void*> dev_allocs;
+};
+
+namespace {
+
+TrkMap make_map(const svo_hip_tracker* t) {
+  TrkMap m;
+  m.n_kf = t->n_kf; m.n_points = t->n_points; m.n_candidates = t->n_candidates;
+  m.T_kf_w = t->T_kf_w; m.kf_slot = t->kf_slot; m.kf_key_point = t->kf_key_point; m.kf_ftr_offset = t->kf_ftr_offset;
+  m.kf_ftr_point = t->kf_ftr_point; m.pt_pos = t->pt_pos; m.pt_type = t->pt_type; m.pt_n_failed = t->pt_n_failed;
+  m.pt_n_succeeded = t->pt_n_succeeded; m.pt_unlinked = t->pt_unlinked; m.pt_obs_offset = t->pt_obs_offset; m.obs_kf = t->obs_kf;
+  m.obs_px = t->obs_px; m.obs_f = t->obs_f; m.obs_level = t->obs_level; m.obs_edgelet = t->obs_edgelet; m.obs_grad = t->obs_grad;
+  m.cand_point = t->cand_point;
+  return m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int svo_hip_tracker_default_config(svo_hip_tracker_config* c) {
+  if (!c) return SVO_HIP_ERR_INVALID;
+  memset(c, 0, sizeof(*c));
+  c->max_keyframes = 64; c->max_points = 1 << 16; c->max_obs = 1 << 18; c->max_kf_features = 1 << 17; c->max_candidates = 1 << 14;
+  c->max_items = 1 << 14; c->max_frame_features = 2048;
+  c->n_levels = 5;                 // max(Config::nPyrLevels(), Config::kltMaxLevel() + 1) (frame.cpp:63)
+  c->klt_max_level = 4; c->klt_min_level = 2; c->sia_n_iter = 30; c->sia_eps = 1e-6;       // config.cpp:62-63, frame_handler_mono.cpp:186-187
+  c->grid_size = 20; c->max_fts = 1200; c->quality_min_fts = 40;                            // config.cpp:61,82,83
+  c->reproj_max_n_kfs = 10;        // Reprojector::Options::max_n_kfs (I/reprojector.h:41)
+  c->n_pyr_levels = 3; c->align_max_iter = 10;                                              // config.cpp:59, I/matcher.h:86
+  c->pose_optim_thresh = 2.0; c->pose_optim_num_iter = 10;                                  // config.cpp:66-67
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_destroy(svo_hip_tracker* t) {
+  if (!t) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = t->ctx;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (t->sia) svo_hip_sia_destroy(t->sia);
+  if (t->kf_pyr) svo_hip_pyramid_destroy(t->kf_pyr);
+  for (int i = 0; i < 2; ++i) if (t->frame_pyr[i]) svo_hip_pyramid_destroy(t->frame_pyr[i]);
+  for (void* p : t->dev_allocs) if (p) (void)hipFree(p);
+  if (t->res_host) (void)hipHostFree(t->res_host);
+  if (t->img_host) (void)hipHostFree(t->img_host);
+  if (t->map_host) (void)hipHostFree(t->map_host);
+  delete t;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const svo_hip_tracker_config* cfg, svo_hip_tracker** out) {
+  if (!ctx || !cam || !cfg || !out) return SVO_HIP_ERR_INVALID;
+  *out = nullptr;
+  SVO_REQUIRE(ctx, cfg->max_keyframes >= 1 && cfg->max_points >= 1 && cfg->max_obs >= 1 && cfg->max_kf_features >= 1 && cfg->max_candidates >= 0);
+  SVO_REQUIRE(ctx, cfg->max_items >= 1 && cfg->max_frame_features >= 1 && cfg->max_frame_features <= 2816);
+  SVO_REQUIRE(ctx, cfg->n_levels >= 1 && cfg->n_levels <= SVO_HIP_MAX_LEVELS && cfg->klt_max_level < cfg->n_levels && cfg->klt_min_level >= 0 &&
+                       cfg->klt_min_level <= cfg->klt_max_level && cfg->sia_n_iter >= 0);
+  SVO_REQUIRE(ctx, cfg->grid_size >= 1 && cfg->max_fts >= 0 && cfg->reproj_max_n_kfs >= 1 && cfg->reproj_max_n_kfs <= TRK_MAX_SEL);
+  SVO_REQUIRE(ctx, cfg->n_pyr_levels >= 1 && cfg->n_pyr_levels <= cfg->n_levels && cfg->align_max_iter >= 0 && cfg->pose_optim_num_iter >= 0);
+  SVO_REQUIRE(ctx, cam->width > 16 && cam->height > 16);
+  svo_hip_tracker* t = new (std::nothrow) svo_hip_tracker();
+  if (!t) return SVO_HIP_ERR_NOMEM;
+  t->ctx = ctx; t->cam = *cam; t->cfg = *cfg;
+  t->grid_cols = (cam->width + cfg->grid_size - 1) / cfg->grid_size;        // ceil(width / cell_size) (reprojector.cpp:46-47)
+  t->grid_rows = (cam->height + cfg->grid_size - 1) / cfg->grid_size;
+  t->n_cells = t->grid_cols * t->grid_rows;
+  int rc = SVO_HIP_OK;
+  auto A = [&](int r) { if (rc == SVO_HIP_OK) rc = r; };
+  auto D = [&](auto** p, size_t count) {
+    if (rc != SVO_HIP_OK) return;
+    rc = trk_alloc(ctx, p, count);
+    if (rc == SVO_HIP_OK) t->dev_allocs.push_back((void*)*p);
+  };
+  A(svo_hip_pyramid_create(ctx, cam->width, cam->height, cfg->n_levels, cfg->max_keyframes, &t->kf_pyr));
+  for (int i = 0; i < 2; ++i) A(svo_hip_pyramid_create(ctx, cam->width, cam->height, cfg->n_levels, 1, &t->frame_pyr[i]));
+  A(svo_hip_sia_create(ctx, 1, cfg->max_frame_features, &t->sia));
+  const size_t K = cfg->max_keyframes, P = cfg->max_points, O = cfg->max_obs, F = cfg->max_kf_features, CN = cfg->max_candidates > 0 ? cfg->max_candidates : 1;
+  D(&t->T_kf_w, K * 7); D(&t->T_slot_w, K * 7); D(&t->kf_slot, K); D(&t->kf_key_point, K * 5); D(&t->kf_ftr_offset, K + 1); D(&t->kf_ftr_point, F);
+  D(&t->pt_pos, P * 3); D(&t->pt_type, P); D(&t->pt_n_failed, P); D(&t->pt_n_succeeded, P); D(&t->pt_unlinked, P); D(&t->pt_obs_offset, P + 1);
+  D(&t->obs_kf, O); D(&t->obs_px, O * 2); D(&t->obs_f, O * 3); D(&t->obs_level, O); D(&t->obs_edgelet, O); D(&t->obs_grad, O * 2); D(&t->cand_point, CN);
+  TrkPlan& pl = t->pl;
+  const size_t C = cfg->max_items, NC = t->n_cells;
+  pl.cap = cfg->max_items; pl.n_cells = t->n_cells; pl.grid_cols = t->grid_cols; pl.grid_size = cfg->grid_size; pl.max_n_kfs = cfg->reproj_max_n_kfs;
+  D(&pl.kf_close, K); D(&pl.kf_dist, K); D(&pl.first_seq, P); D(&pl.item_point, C); D(&pl.item_px, C * 2); D(&pl.item_cell, C); D(&pl.item_key, C);
+  D(&pl.seg, C); D(&pl.cell_count, NC + 1); D(&pl.cell_fill, NC); D(&pl.counters, 8); D(&pl.cell_offset, NC + 1); D(&pl.overlap_kf, TRK_MAX_SEL);
+  D(&pl.overlap_count, TRK_MAX_SEL); D(&pl.cand_point, C); D(&pl.cand_obs, C); D(&pl.cand_kf_slot, C); D(&pl.cand_px_ref, C * 2); D(&pl.cand_f_ref, C * 3);
+  D(&pl.cand_level_ref, C); D(&pl.cand_pt_pos, C * 3); D(&pl.cand_edgelet, C); D(&pl.cand_grad, C * 2); D(&pl.cand_px_cur, C * 2); D(&pl.cand_deleted, C);
+  D(&t->success, C); D(&t->search_level, C); D(&t->cell_winner, NC + 1); D(&t->cell_cum, NC + 1); D(&t->po, 1);
+  const size_t NF = cfg->max_frame_features;
+  TrkFeat& ft = t->ft;
+  ft.cap = cfg->max_frame_features;
+  D(&ft.px, NF * 2); D(&ft.f, NF * 3); D(&ft.pos, NF * 3); D(&ft.level, NF); D(&ft.point, NF); D(&ft.edgelet, NF); D(&ft.grad, NF * 2); D(&ft.has_point, NF);
+  D(&t->last.n, 1); D(&t->last.T_f_w, 7); D(&t->last.px, NF * 2); D(&t->last.f, NF * 3); D(&t->last.point, NF);
+  // result block
+  auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  t->o_px = al(sizeof(svo_hip_track_result)); t->o_f = al(t->o_px + NF * 16); t->o_level = al(t->o_f + NF * 24); t->o_point = al(t->o_level + NF * 4);
+  t->o_edge = al(t->o_point + NF * 4); t->o_grad = al(t->o_edge + NF); t->o_pt = al(t->o_grad + NF * 16); t->res_bytes = al(t->o_pt + P * 12);
+  D(&t->res_dev, t->res_bytes);
+  if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->res_host, t->res_bytes, hipHostMallocDefault) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
+  if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->img_host, (size_t)cam->width * cam->height, hipHostMallocDefault) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
+  t->map_host_bytes = K * (56 + 4 + 20 + 4) + 8 + F * 4 + P * (24 + 12 + 4) + 8 + O * (4 + 16 + 24 + 4 + 1 + 16) + CN * 4 + 1024;
+  if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->map_host, t->map_host_bytes, hipHostMallocDefault) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
+  if (rc != SVO_HIP_OK) { svo_hip_tracker_destroy(t); return rc; }
+  (void)hipMemsetAsync(t->last.n, 0, sizeof(int), ctx->stream);
+  *out = t;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_upload_keyframe(svo_hip_tracker* t, int slot, const uint8_t* level0) {
+  if (!t || !level0) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(t->ctx, slot >= 0 && slot < t->cfg.max_keyframes);
+  return svo_hip_pyramid_upload_level0_and_build(t->kf_pyr, slot, level0);
+}
+
+int svo_hip_tracker_keyframe_from_last_frame(svo_hip_tracker* t, int slot) {
+  if (!t) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = t->ctx;
+  SVO_REQUIRE(ctx, slot >= 0 && slot < t->cfg.max_keyframes);
+  if (!t->have_last) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_keyframe_from_last_frame", "no frame has been tracked or set yet");
+  const svo_hip_pyramid* src = t->frame_pyr[t->last_idx];
+  return svo_hip_copy_d2d(ctx, t->kf_pyr->base + (size_t)slot * t->kf_pyr->pyr_bytes, src->base, src->pyr_bytes);
+}
+
+int svo_hip_tracker_set_map(svo_hip_tracker* t, const svo_hip_tracker_map* mp) {
+  if (!t || !mp) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = t->ctx;
+  const svo_hip_tracker_config& c = t->cfg;
+  SVO_REQUIRE(ctx, mp->n_kf >= 0 && mp->n_kf <= c.max_keyframes && mp->n_points >= 0 && mp->n_points <= c.max_points);
+  SVO_REQUIRE(ctx, mp->n_candidates >= 0 && mp->n_candidates <= c.max_candidates);
+  SVO_REQUIRE(ctx, mp->n_kf == 0 || (mp->kf_slot && mp->T_kf_w && mp->kf_key_point && mp->kf_ftr_offset));
+  SVO_REQUIRE(ctx, mp->n_points == 0 || (mp->pt_pos && mp->pt_type && mp->pt_n_failed && mp->pt_n_succeeded && mp->pt_obs_offset));
+  SVO_REQUIRE(ctx, mp->n_candidates == 0 || mp->cand_point);
+  const int n_ftr = mp->n_kf > 0 ? mp->kf_ftr_offset[mp->n_kf] : 0;
+  const int n_obs = mp->n_points > 0 ? mp->pt_obs_offset[mp->n_points] : 0;
+  SVO_REQUIRE(ctx, n_ftr >= 0 && n_ftr <= c.max_kf_features && n_obs >= 0 && n_obs <= c.max_obs);
+  SVO_REQUIRE(ctx, n_ftr == 0 || mp->kf_ftr_point);
+  SVO_REQUIRE(ctx, n_obs == 0 || (mp->obs_kf && mp->obs_px && mp->obs_f && mp->obs_level));
+  // every index the kernels follow is checked here, once, on the host
+  for (int k = 0; k < mp->n_kf; ++k) {
+    SVO_REQUIRE(ctx, mp->kf_slot[k] >= 0 && mp->kf_slot[k] < c.max_keyframes && mp->kf_ftr_offset[k] <= mp->kf_ftr_offset[k + 1] && mp->kf_ftr_offset[k] >= 0);
+    for (int j = 0; j < 5; ++j) SVO_REQUIRE(ctx, mp->kf_key_point[5 * k + j] >= -1 && mp->kf_key_point[5 * k + j] < mp->n_points);
+  }
+  for (int j = 0; j < n_ftr; ++j) SVO_REQUIRE(ctx, mp->kf_ftr_point[j] >= -1 && mp->kf_ftr_point[j] < mp->n_points);
+  for (int p = 0; p < mp->n_points; ++p) SVO_REQUIRE(ctx, mp->pt_obs_offset[p] >= 0 && mp->pt_obs_offset[p] <= mp->pt_obs_offset[p + 1] && mp->pt_type[p] >= 0 && mp->pt_type[p] <= 3);
+  for (int o = 0; o < n_obs; ++o) SVO_REQUIRE(ctx, mp->obs_kf[o] >= 0 && mp->obs_kf[o] < mp->n_kf && mp->obs_level[o] >= 0 && mp->obs_level[o] < c.n_levels);
+  for (int i = 0; i < mp->n_candidates; ++i) SVO_REQUIRE(ctx, mp->cand_point[i] >= -1 && mp->cand_point[i] < mp->n_points);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  // the staging area may still feed the copies of the previous upload
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  char* hs = t->map_host;
+  size_t off = 0;
+  hipError_t e = hipSuccess;
+  auto put = [&](void* dst, const void* src, size_t bytes) {
+    if (!bytes || e != hipSuccess) return;
+    off = (off + 15) & ~(size_t)15;
+    memcpy(hs + off, src, bytes);
+    e = hipMemcpyAsync(dst, hs + off, bytes, hipMemcpyHostToDevice, ctx->stream);
+    off += bytes;
+  };
+  const size_t K = mp->n_kf, P = mp->n_points;
+  put(t->T_kf_w, mp->T_kf_w, K * 56); put(t->kf_slot, mp->kf_slot, K * 4); put(t->kf_key_point, mp->kf_key_point, K * 20);
+  if (K) put(t->kf_ftr_offset, mp->kf_ftr_offset, (K + 1) * 4);
+  put(t->kf_ftr_point, mp->kf_ftr_point, (size_t)n_ftr * 4);
+  put(t->pt_pos, mp->pt_pos, P * 24); put(t->pt_type, mp->pt_type, P * 4); put(t->pt_n_failed, mp->pt_n_failed, P * 4);
+  put(t->pt_n_succeeded, mp->pt_n_succeeded, P * 4);
+  if (P) put(t->pt_obs_offset, mp->pt_obs_offset, (P + 1) * 4);
+  put(t->obs_kf, mp->obs_kf, (size_t)n_obs * 4); put(t->obs_px, mp->obs_px, (size_t)n_obs * 16); put(t->obs_f, mp->obs_f, (size_t)n_obs * 24);
+  put(t->obs_level, mp->obs_level, (size_t)n_obs * 4);
+  put(t->cand_point, mp->cand_point, (size_t)mp->n_candidates * 4);
+  // T_slot_w: the keyframe poses indexed by pyramid slot (what the matcher's batch indexes)
+  {
+    off = (off + 15) & ~(size_t)15;
+    double* ts = reinterpret_cast<double*>(hs + off);
+    memset(ts, 0, (size_t)c.max_keyframes * 56);
+    for (int s = 0; s < c.max_keyframes; ++s) ts[7 * s + 6] = 1.0;
+    for (int k = 0; k < mp->n_kf; ++k) memcpy(ts + 7 * (size_t)mp->kf_slot[k], mp->T_kf_w + 7 * (size_t)k, 56);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->T_slot_w, ts, (size_t)c.max_keyframes * 56, hipMemcpyHostToDevice, ctx->stream);
+    off += (size_t)c.max_keyframes * 56;
+  }
+  if (n_obs) {
+    off = (off + 15) & ~(size_t)15;
+    uint8_t* ed = reinterpret_cast<uint8_t*>(hs + off);
+    if (mp->obs_edgelet) memcpy(ed, mp->obs_edgelet, (size_t)n_obs); else memset(ed, 0, (size_t)n_obs);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->obs_edgelet, ed, (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream);
+    off += (size_t)n_obs;
+    off = (off + 15) & ~(size_t)15;
+    double* gr = reinterpret_cast<double*>(hs + off);
+    if (mp->obs_grad) memcpy(gr, mp->obs_grad, (size_t)n_obs * 16);
+    else for (int o = 0; o < n_obs; ++o) { gr[2 * o] = 1.0; gr[2 * o + 1] = 0.0; }
+    if (e == hipSuccess) e = hipMemcpyAsync(t->obs_grad, gr, (size_t)n_obs * 16, hipMemcpyHostToDevice, ctx->stream);
+    off += (size_t)n_obs * 16;
+  }
+  if (e == hipSuccess && P) e = hipMemsetAsync(t->pt_unlinked, 0, P, ctx->stream);
+  if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_tracker_set_map", hipGetErrorString(e));
+  if (off > t->map_host_bytes) return svo_fail(ctx, SVO_HIP_ERR_NOMEM, "svo_hip_tracker_set_map", "staging area too small");
+  t->n_kf = mp->n_kf; t->n_points = mp->n_points; t->n_candidates = mp->n_candidates;
+  t->have_map = true; t->map_stale = false;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_update_point_positions(svo_hip_tracker* t, int n, const int32_t* point, const double* pos) {
+  if (!t) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = t->ctx;
+  SVO_REQUIRE(ctx, n >= 0 && (n == 0 || (point && pos)));
+  if (!t->have_map) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_update_point_positions", "no map has been set");
+  for (int i = 0; i < n; ++i) {
+    SVO_REQUIRE(ctx, point[i] >= 0 && point[i] < t->n_points);
+    SVO_CHECK_HIP(ctx, hipMemcpyAsync(t->pt_pos + 3 * (size_t)point[i], pos + 3 * (size_t)i, 24, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_set_last_frame(svo_hip_tracker* t, const uint8_t* level0, int kf_slot, const double T_f_w[7], int n, const double* px,
+                                   const double* f, const int32_t* point) {
+  if (!t || !T_f_w) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = t->ctx;
+  SVO_REQUIRE(ctx, n >= 0 && n <= t->cfg.max_frame_features && (n == 0 || (px && f && point)));
+  SVO_REQUIRE(ctx, level0 || (kf_slot >= 0 && kf_slot < t->cfg.max_keyframes));
+  svo_hip_pyramid* dst = t->frame_pyr[t->last_idx];
+  int rc;
+  if (level0) rc = svo_hip_pyramid_upload_level0_and_build(dst, 0, level0);
+  else rc = svo_hip_copy_d2d(ctx, dst->base, t->kf_pyr->base + (size_t)kf_slot * t->kf_pyr->pyr_bytes, dst->pyr_bytes);
+  if (rc != SVO_HIP_OK) return rc;
+  const int32_t n32 = n;
+  SVO_CHECK_HIP(ctx, hipMemcpyAsync(t->last.n, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
+  SVO_CHECK_HIP(ctx, hipMemcpyAsync(t->last.T_f_w, T_f_w, 56, hipMemcpyHostToDevice, ctx->stream));
+  if (n > 0) {
+    SVO_CHECK_HIP(ctx, hipMemcpyAsync(t->last.px, px, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    SVO_CHECK_HIP(ctx, hipMemcpyAsync(t->last.f, f, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    SVO_CHECK_HIP(ctx, hipMemcpyAsync(t->last.point, point, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  t->last_n_host = n;
+  t->have_last = true;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_track_result* result, double* feat_px, double* feat_f,
+                          int32_t* feat_level, int32_t* feat_point, uint8_t* feat_edgelet, double* feat_grad, int32_t* pt_type,
+                          int32_t* pt_n_failed, int32_t* pt_n_succeeded) {
+  if (!t || !level0 || !result) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = t->ctx;
+  const svo_hip_tracker_config& c = t->cfg;
+  if (!t->have_map || !t->have_last)
+    return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_track", "svo_hip_tracker_set_map and svo_hip_tracker_set_last_frame come first");
+  if (t->map_stale)
+    return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_track",
+                    "the last frame deleted map points (map_changed): apply that to the map and call svo_hip_tracker_set_map again");
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t l0 = (size_t)t->cam.width * t->cam.height;
+  svo_hip_pyramid* ref = t->frame_pyr[t->last_idx];
+  svo_hip_pyramid* cur = t->frame_pyr[1 - t->last_idx];
+  // ---- new Frame(cam, img, t): the image crosses the link once, from page-locked memory; the pyramid is built on the device
+  memcpy(t->img_host, level0, l0);
+  int rc = svo_hip_pyramid_upload_level0_and_build(cur, 0, t->img_host);
+  if (rc != SVO_HIP_OK) return rc;
+  // ---- SparseImgAlign(kltMaxLevel, kltMinLevel, 30, GaussNewton, false, false).run(last_frame_, new_frame_)
+  rc = svo_hip_sia_set_frames(t->sia, ref, cur);
+  if (rc != SVO_HIP_OK) return rc;
+  rc = svo_sia_prepare_from_device(t->sia, &t->cam, t->last_n_host, t->last.n, t->last.T_f_w, t->last.px, t->last.f, t->last.point, t->pt_pos);
+  if (rc != SVO_HIP_OK) return rc;
+  svo_hip_sia_params sp;
+  sp.max_level = c.klt_max_level; sp.min_level = c.klt_min_level; sp.n_iter = c.sia_n_iter; sp.eps = c.sia_eps; sp.early_stop = 1;
+  rc = svo_hip_sia_run(t->sia, 1, &sp);
+  if (rc != SVO_HIP_OK) return rc;
+  const FrameState* st = svo_sia_state_dev(t->sia);
+  // ---- Reprojector::reprojectMap
+  const TrkMap m = make_map(t);
+  const Cam cam = svo_make_cam(t->cam);
+  hipLaunchKernelGGL(trk_plan_kernel, dim3(1), dim3(TRK_THREADS), 0, ctx->stream, m, t->pl, cam, st);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  rc = svo_match_direct_internal(ctx, t->kf_pyr, cur, 0, &t->cam, c.max_keyframes, t->T_slot_w, nullptr, st->T_cur_w, t->pl.cap, t->pl.counters,
+                                 t->pl.cand_kf_slot, t->pl.cand_px_ref, t->pl.cand_f_ref, t->pl.cand_level_ref, t->pl.cand_pt_pos, t->pl.cand_edgelet,
+                                 t->pl.cand_grad, c.n_pyr_levels, c.align_max_iter, t->pl.cand_px_cur, t->success, t->search_level);
+  if (rc != SVO_HIP_OK) return rc;
+  hipLaunchKernelGGL(trk_replay_kernel, dim3(1), dim3(TRK_THREADS), 0, ctx->stream, m, t->pl, t->ft, cam, st, t->success, t->search_level,
+                     t->cell_winner, t->cell_cum, c.max_fts, c.quality_min_fts);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  // ---- pose_optimizer::optimizeGaussNewton(poseOptimThresh, poseOptimNumIter, ...) on the matched features, from the aligned pose
+  rc = svo_hip_pose_optimize_batch_dev(ctx, 1, c.max_frame_features, t->pl.counters + 5, st->T_cur_w, t->ft.f, t->ft.pos, t->ft.level, t->ft.has_point,
+                                       fabs(t->cam.fx), c.pose_optim_thresh, c.pose_optim_num_iter, t->po);
+  if (rc != SVO_HIP_OK) return rc;
+  // ---- hand-over + result
+  char* rd = t->res_dev;
+  hipLaunchKernelGGL(trk_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, m, t->pl, t->ft, t->last, st, t->po,
+                     reinterpret_cast<svo_hip_track_result*>(rd), reinterpret_cast<double*>(rd + t->o_px), reinterpret_cast<double*>(rd + t->o_f),
+                     reinterpret_cast<int*>(rd + t->o_level), reinterpret_cast<int*>(rd + t->o_point), reinterpret_cast<uint8_t*>(rd + t->o_edge),
+                     reinterpret_cast<double*>(rd + t->o_grad), reinterpret_cast<int*>(rd + t->o_pt), reinterpret_cast<int*>(rd + t->o_pt) + t->n_points,
+                     reinterpret_cast<int*>(rd + t->o_pt) + 2 * (size_t)t->n_points);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  const size_t used = t->o_pt + (size_t)t->n_points * 12;
+  SVO_CHECK_HIP(ctx, hipMemcpyAsync(t->res_host, rd, used, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));                    // the one synchronisation of the frame
+  const char* rh = t->res_host;
+  memcpy(result, rh, sizeof(*result));
+  const size_t nf = (size_t)(result->n_features > 0 ? result->n_features : 0);
+  if (feat_px) memcpy(feat_px, rh + t->o_px, nf * 16);
+  if (feat_f) memcpy(feat_f, rh + t->o_f, nf * 24);
+  if (feat_level) memcpy(feat_level, rh + t->o_level, nf * 4);
+  if (feat_point) memcpy(feat_point, rh + t->o_point, nf * 4);
+  if (feat_edgelet) memcpy(feat_edgelet, rh + t->o_edge, nf);
+  if (feat_grad) memcpy(feat_grad, rh + t->o_grad, nf * 16);
+  const size_t np4 = (size_t)t->n_points * 4;
+  if (pt_type) memcpy(pt_type, rh + t->o_pt, np4);
+  if (pt_n_failed) memcpy(pt_n_failed, rh + t->o_pt + np4, np4);
+  if (pt_n_succeeded) memcpy(pt_n_succeeded, rh + t->o_pt + 2 * np4, np4);
+  t->last_idx = 1 - t->last_idx;            // the new frame's pyramid is the next call's reference
+  t->last_n_host = result->n_features;
+  if (result->map_changed) t->map_stale = true;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_info(const svo_hip_tracker* t, int* n_cells, int* grid_cols, int* grid_rows, svo_hip_pyramid** keyframe_pyramids) {
+  if (!t) return SVO_HIP_ERR_INVALID;
+  if (n_cells) *n_cells = t->n_cells;
+  if (grid_cols) *grid_cols = t->grid_cols;
+  if (grid_rows) *grid_rows = t->grid_rows;
+  if (keyframe_pyramids) *keyframe_pyramids = t->kf_pyr;
+  return SVO_HIP_OK;
+}
+
+}  // extern "C"

@@ -703,3 +703,119 @@ def reproject_cells(ctx: Context, ref: Pyramid, cur: Pyramid, cur_slot: int, cam
         _ptr(matched, C.c_uint8), _ptr(sl, C.c_int32), _ptr(win, C.c_int32), C.byref(nm), C.byref(nt)), "reproject_cells")
     return {"tried": tried[:n], "matched": matched[:n], "search_level": sl[:n], "cell_winner": win[:n_cells], "px_cur": pc,
             "n_matches": nm.value, "n_trials": nt.value}
+
+
+# ---- one tracked frame on one stream (svo_hip_tracker_*: FrameHandlerMono::processFrame up to the pose refinement) -----
+class CTrackerConfig(C.Structure):
+    _fields_ = [("max_keyframes", C.c_int), ("max_points", C.c_int), ("max_obs", C.c_int), ("max_kf_features", C.c_int),
+                ("max_candidates", C.c_int), ("max_items", C.c_int), ("max_frame_features", C.c_int), ("n_levels", C.c_int),
+                ("klt_max_level", C.c_int), ("klt_min_level", C.c_int), ("sia_n_iter", C.c_int), ("sia_eps", C.c_double),
+                ("grid_size", C.c_int), ("max_fts", C.c_int), ("quality_min_fts", C.c_int), ("reproj_max_n_kfs", C.c_int),
+                ("n_pyr_levels", C.c_int), ("align_max_iter", C.c_int), ("pose_optim_thresh", C.c_double),
+                ("pose_optim_num_iter", C.c_int)]
+
+
+class CTrackerMap(C.Structure):
+    _fields_ = [("n_kf", C.c_int), ("kf_slot", C.POINTER(C.c_int32)), ("T_kf_w", C.POINTER(C.c_double)),
+                ("kf_key_point", C.POINTER(C.c_int32)), ("kf_ftr_offset", C.POINTER(C.c_int32)), ("kf_ftr_point", C.POINTER(C.c_int32)),
+                ("n_points", C.c_int), ("pt_pos", C.POINTER(C.c_double)), ("pt_type", C.POINTER(C.c_int32)),
+                ("pt_n_failed", C.POINTER(C.c_int32)), ("pt_n_succeeded", C.POINTER(C.c_int32)), ("pt_obs_offset", C.POINTER(C.c_int32)),
+                ("obs_kf", C.POINTER(C.c_int32)), ("obs_px", C.POINTER(C.c_double)), ("obs_f", C.POINTER(C.c_double)),
+                ("obs_level", C.POINTER(C.c_int32)), ("obs_edgelet", C.POINTER(C.c_uint8)), ("obs_grad", C.POINTER(C.c_double)),
+                ("n_candidates", C.c_int), ("cand_point", C.POINTER(C.c_int32))]
+
+
+class CTrackResult(C.Structure):
+    _fields_ = [("T_f_w", C.c_double * 7), ("T_f_w_sia", C.c_double * 7), ("sia_n_tracked", C.c_uint64),
+                ("sia_iters", C.c_int32 * MAX_LEVELS), ("sia_stop", C.c_int32), ("n_features", C.c_int32), ("n_matches", C.c_uint64),
+                ("n_trials", C.c_uint64), ("n_overlap", C.c_int32), ("map_changed", C.c_int32), ("overlap_kf", C.c_int32 * 16),
+                ("overlap_count", C.c_int32 * 16), ("n_candidates", C.c_int32), ("items_overflow", C.c_int32), ("pose", CPoseOptResult)]
+
+
+class Tracker:
+    """svo_hip_tracker: SparseImgAlign -> Reprojector::reprojectMap -> pose_optimizer on one stream, one synchronisation per
+    frame, the frame's matches handed over to the next call on the device."""
+
+    def __init__(self, ctx: Context, cam, **overrides):
+        self.ctx, self.cam = ctx, cam
+        self.cfg = CTrackerConfig()
+        ctx.check(ctx.lib.svo_hip_tracker_default_config(C.byref(self.cfg)), "tracker_default_config")
+        for k, v in overrides.items():
+            assert hasattr(self.cfg, k), k
+            setattr(self.cfg, k, v)
+        self.ccam = make_camera(cam)
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.svo_hip_tracker_create(ctx.h, C.byref(self.ccam), C.byref(self.cfg), C.byref(self.h)), "tracker_create")
+        nc, gc, gr = C.c_int(), C.c_int(), C.c_int()
+        ctx.check(ctx.lib.svo_hip_tracker_info(self.h, C.byref(nc), C.byref(gc), C.byref(gr), None), "tracker_info")
+        self.n_cells, self.grid_cols, self.grid_rows = nc.value, gc.value, gr.value
+        self.n_points = 0
+
+    def upload_keyframe(self, slot: int, img: np.ndarray):
+        im = np.ascontiguousarray(img, dtype=np.uint8)
+        assert im.shape == (self.cam.height, self.cam.width)
+        self.ctx.check(self.ctx.lib.svo_hip_tracker_upload_keyframe(self.h, slot, _ptr(im, C.c_uint8)), "tracker_upload_keyframe")
+        self.ctx.sync()
+
+    def keyframe_from_last_frame(self, slot: int):
+        self.ctx.check(self.ctx.lib.svo_hip_tracker_keyframe_from_last_frame(self.h, slot), "tracker_keyframe_from_last_frame")
+
+    def set_map(self, mp: dict):
+        """mp: the index tables of android_svo_amd.synth.make_map_case (plus kf_slot, kf_key_point)"""
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        a = dict(ks=i32(mp["kf_slot"]), Tk=_f64(mp["T_kf_w"]), key=i32(mp["kf_key_point"]), ko=i32(mp["kf_ftr_offset"]), kp=i32(mp["kf_ftr_point"]),
+                 pos=_f64(mp["pt_pos"]), ty=i32(mp["pt_type"]), nf=i32(mp["pt_n_failed"]), ns=i32(mp["pt_n_succeeded"]), oo=i32(mp["pt_obs_offset"]),
+                 ok=i32(mp["obs_kf"]), opx=_f64(mp["obs_px"]), of=_f64(mp["obs_f"]), ol=i32(mp["obs_level"]), cp=i32(mp["cand_point"]))
+        ed = np.ascontiguousarray(mp["obs_edgelet"], dtype=np.uint8) if mp.get("obs_edgelet") is not None else None
+        gr = _f64(mp["obs_grad"]) if mp.get("obs_grad") is not None else None
+        I, D = C.c_int32, C.c_double
+        m = CTrackerMap(len(a["ks"]), _ptr(a["ks"], I), _ptr(a["Tk"], D), _ptr(a["key"], I), _ptr(a["ko"], I), _ptr(a["kp"], I), len(a["ty"]),
+                        _ptr(a["pos"], D), _ptr(a["ty"], I), _ptr(a["nf"], I), _ptr(a["ns"], I), _ptr(a["oo"], I), _ptr(a["ok"], I), _ptr(a["opx"], D),
+                        _ptr(a["of"], D), _ptr(a["ol"], I), None if ed is None else _ptr(ed, C.c_uint8), None if gr is None else _ptr(gr, D),
+                        len(a["cp"]), _ptr(a["cp"], I))
+        self.ctx.check(self.ctx.lib.svo_hip_tracker_set_map(self.h, C.byref(m)), "tracker_set_map")
+        self.ctx.sync()
+        self.n_points = len(a["ty"])
+
+    def update_point_positions(self, point, pos):
+        pt, pp = np.ascontiguousarray(point, dtype=np.int32), _f64(pos)
+        self.ctx.check(self.ctx.lib.svo_hip_tracker_update_point_positions(self.h, len(pt), _ptr(pt, C.c_int32), _ptr(pp, C.c_double)),
+                       "tracker_update_point_positions")
+        self.ctx.sync()
+
+    def set_last_frame(self, T_f_w, px, f, point, img: Optional[np.ndarray] = None, kf_slot: int = -1):
+        T, p, ff = _f64(T_f_w), _f64(px), _f64(f)
+        pt = np.ascontiguousarray(point, dtype=np.int32)
+        im = None if img is None else np.ascontiguousarray(img, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.svo_hip_tracker_set_last_frame(self.h, None if im is None else _ptr(im, C.c_uint8), kf_slot, _ptr(T, C.c_double),
+                                                                   len(pt), _ptr(p, C.c_double), _ptr(ff, C.c_double), _ptr(pt, C.c_int32)),
+                       "tracker_set_last_frame")
+        self.ctx.sync()
+
+    def track(self, img: np.ndarray, want_points: bool = True) -> dict:
+        im = np.ascontiguousarray(img, dtype=np.uint8)
+        assert im.shape == (self.cam.height, self.cam.width)
+        nf = self.cfg.max_frame_features
+        if not hasattr(self, "_out") or len(self._out["pt_type"]) != max(self.n_points, 1):
+            self._out = dict(px=np.zeros((nf, 2)), f=np.zeros((nf, 3)), level=np.zeros(nf, np.int32), point=np.zeros(nf, np.int32),
+                             edgelet=np.zeros(nf, np.uint8), grad=np.zeros((nf, 2)), pt_type=np.zeros(max(self.n_points, 1), np.int32),
+                             pt_n_failed=np.zeros(max(self.n_points, 1), np.int32), pt_n_succeeded=np.zeros(max(self.n_points, 1), np.int32))
+        o = self._out
+        res = CTrackResult()
+        I, D = C.c_int32, C.c_double
+        self.ctx.check(self.ctx.lib.svo_hip_tracker_track(
+            self.h, _ptr(im, C.c_uint8), C.byref(res), _ptr(o["px"], D), _ptr(o["f"], D), _ptr(o["level"], I), _ptr(o["point"], I),
+            _ptr(o["edgelet"], C.c_uint8), _ptr(o["grad"], D), _ptr(o["pt_type"], I) if want_points else None,
+            _ptr(o["pt_n_failed"], I) if want_points else None, _ptr(o["pt_n_succeeded"], I) if want_points else None), "tracker_track")
+        n = res.n_features
+        return {"result": res, "T_f_w": np.array(res.T_f_w), "T_f_w_sia": np.array(res.T_f_w_sia), "n_matches": int(res.n_matches),
+                "n_trials": int(res.n_trials), "feat_px": o["px"][:n].copy(), "feat_f": o["f"][:n].copy(), "feat_level": o["level"][:n].copy(),
+                "feat_point": o["point"][:n].copy(), "feat_type": o["edgelet"][:n].astype(np.int32), "feat_grad": o["grad"][:n].copy(),
+                "overlap_kf": np.array(res.overlap_kf[:res.n_overlap]), "overlap_count": np.array(res.overlap_count[:res.n_overlap]),
+                "type": o["pt_type"][:self.n_points].copy(), "n_failed": o["pt_n_failed"][:self.n_points].copy(),
+                "n_succeeded": o["pt_n_succeeded"][:self.n_points].copy(), "map_changed": int(res.map_changed)}
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.svo_hip_tracker_destroy(self.h)
+            self.h = C.c_void_p()

@@ -417,3 +417,23 @@ def make_map_case(seed: int = 31, width: int = 320, height: int = 240, n_kf: int
                 pt_obs_offset=np.array(pt_obs_offset, np.int32), obs_point=obs_point, obs_kf=obs_kf, obs_px=obs_px, obs_f=obs_f,
                 obs_level=obs_level, obs_edgelet=obs_edgelet, obs_grad=obs_grad, kf_ftr_offset=np.array(kf_ftr_offset, np.int32),
                 kf_ftr_obs=kf_ftr_obs, kf_ftr_point=obs_point[kf_ftr_obs].astype(np.int32), cand_point=cand_point, cand_obs=cand_obs)
+
+
+def key_points(cam: Camera, px: np.ndarray, has_point: np.ndarray) -> np.ndarray:
+    """Frame::setKeyPoints on an empty key_pts_ (S/frame.cpp:79-133): the indices of the five key features of a frame among
+    its features in fts_ order -- closest to the centre, and the most "cornerward" one of each quadrant with the reference's
+    own (quirky) quadrant tests and products -- or -1.  Host bookkeeping: the tracker's map upload wants the POINT of
+    each key feature."""
+    cu, cv = cam.width // 2, cam.height // 2
+    key = [-1] * 5
+    for i in range(len(px)):
+        if not has_point[i]:
+            continue
+        x, y = px[i]
+        if key[0] < 0 or max(abs(x - cu), abs(y - cv)) < max(abs(px[key[0]][0] - cu), abs(px[key[0]][1] - cv)):
+            key[0] = i
+        prod = (x - cu) * (y - cv)
+        for slot, cond in ((1, x >= cu and y >= cv), (2, x >= cu and y < cv), (3, x < cv and y < cv), (4, x < cv and y >= cv)):
+            if cond and (key[slot] < 0 or prod > (px[key[slot]][0] - cu) * (px[key[slot]][1] - cv)):
+                key[slot] = i
+    return np.array(key, dtype=np.int32)

@@ -409,6 +409,114 @@ int svo_hip_point_optimize_batch_dev(svo_hip_ctx* ctx, int n_points, int n_iter,
 int svo_hip_point_optimize_batch(svo_hip_ctx* ctx, int n_points, int n_iter, double* pos, const int32_t* obs_offset,
                                  const double* obs_T_f_w, const double* obs_f, int32_t* iters);
 
+/* ---- one tracked frame on one stream: FrameHandlerMono::processFrame up to the pose refinement ------------------
+ *      (frame_handler_mono.cpp:171-229; SURVEY 8f-1 / f-2 / f-4 chained behind a-1)
+ *   new_frame->T_f_w_ = last_frame->T_f_w_ (:175) -> SparseImgAlign(kltMaxLevel, kltMinLevel, 30).run(last, new) (:186-188)
+ *   -> Reprojector::reprojectMap(new_frame, overlap_kfs) (:203; reprojector.cpp:72-259 with Map::getCloseKeyframes,
+ *   Point::getCloseViewObs, Matcher::findMatchDirect) -> pose_optimizer::optimizeGaussNewton (:226-229) -> last_frame_ =
+ *   new_frame_ (:91), enqueued as one chain of kernels with ONE synchronisation at the end: the pose SparseImgAlign leaves is
+ *   read by the later stages on the device, the frame's matches become the next call's reference features without
+ *   leaving it, and only level 0 of the new image crosses the link (from page-locked staging).
+ * The map the reprojector walks is a set of index tables uploaded when the map changes (svo_hip_tracker_set_map);
+ * keyframe pyramids live in a batch owned by the tracker.  The counters the reprojector keeps on the points are advanced
+ * on the device and returned with every frame; when it DELETES a point (reprojector.cpp:126-133,202-209) the pointer
+ * graph changes (Map::safeDeletePoint clears feature references and re-selects key points): the result says map_changed
+ * and the next svo_hip_tracker_track is refused until the host has uploaded the map again.
+ * Host code keeps what it keeps in the reference: keyframe selection, Map / Point / Feature objects, optimizeStructure
+ * (svo_hip_point_optimize_batch + svo_hip_tracker_update_point_positions), relocalisation (svo_hip_tracker_set_last_frame). */
+typedef struct svo_hip_tracker svo_hip_tracker;
+
+typedef struct {
+  /* capacities */
+  int max_keyframes, max_points, max_obs, max_kf_features, max_candidates;
+  int max_items;               /* candidates over all grid cells of one frame */
+  int max_frame_features;      /* features of one frame (<= 2816) */
+  int n_levels;                /* pyramid levels of a frame: max(Config::nPyrLevels(), Config::kltMaxLevel() + 1) (frame.cpp:63) */
+  /* the values processFrame reads from svo::Config / the objects' Options */
+  int klt_max_level, klt_min_level, sia_n_iter;    /* config.cpp:62-63; frame_handler_mono.cpp:186-187 */
+  double sia_eps;                                  /* sparse_img_align.cpp:40 */
+  int grid_size, max_fts, quality_min_fts;         /* Config::gridSize(), maxFts(), qualityMinFts() */
+  int reproj_max_n_kfs;                            /* Reprojector::Options::max_n_kfs (<= 16) */
+  int n_pyr_levels, align_max_iter;                /* Config::nPyrLevels(), Matcher::Options::align_max_iter */
+  double pose_optim_thresh;                        /* Config::poseOptimThresh() */
+  int pose_optim_num_iter;                         /* Config::poseOptimNumIter() */
+} svo_hip_tracker_config;
+
+/* the reference's defaults (config.cpp:56-84) and roomy capacities */
+int svo_hip_tracker_default_config(svo_hip_tracker_config* cfg);
+
+/* svo::Map as index tables (host arrays, copied in).  Keyframes in Map::keyframes_ order; kf_slot[k] = slot of keyframe
+ * k's pyramid in the tracker's keyframe batch; kf_key_point[k][5] = point index of Frame::key_pts_[j]->point or -1;
+ * kf_ftr_point = the point of every keyframe feature that has one, keyframe by keyframe in fts_ order
+ * ([kf_ftr_offset[k], kf_ftr_offset[k+1])).  Points: Point::pos_, type_ (0 deleted, 1 candidate, 2 unknown, 3 good),
+ * n_failed_reproj_, n_succeeded_reproj_, and their observations in Point::obs_ order ([pt_obs_offset[p],
+ * pt_obs_offset[p+1])): keyframe INDEX the feature lies in, Feature::px / f / level, EDGELET flag and grad (both may be
+ * NULL: corners).  cand_point: the points of MapPointCandidates::candidates_ in list order (their single observation is
+ * the seed's feature). */
+typedef struct {
+  int n_kf;
+  const int32_t* kf_slot;
+  const double* T_kf_w;
+  const int32_t* kf_key_point;
+  const int32_t* kf_ftr_offset;
+  const int32_t* kf_ftr_point;
+  int n_points;
+  const double* pt_pos;
+  const int32_t* pt_type;
+  const int32_t* pt_n_failed;
+  const int32_t* pt_n_succeeded;
+  const int32_t* pt_obs_offset;
+  const int32_t* obs_kf;
+  const double* obs_px;
+  const double* obs_f;
+  const int32_t* obs_level;
+  const uint8_t* obs_edgelet;
+  const double* obs_grad;
+  int n_candidates;
+  const int32_t* cand_point;
+} svo_hip_tracker_map;
+
+typedef struct {
+  double T_f_w[7];              /* new_frame_->T_f_w_ as processFrame leaves it for last_frame_: the refined pose; the LAST
+                                   frame's pose when the reprojector matched fewer than quality_min_fts points (:208-215) */
+  double T_f_w_sia[7];          /* ... after SparseImgAlign::run (:188) */
+  uint64_t sia_n_tracked;       /* img_align_n_tracked */
+  int32_t sia_iters[SVO_HIP_MAX_LEVELS];
+  int32_t sia_stop;
+  int32_t n_features;           /* new_frame_->fts_.size(): features the reprojector added, in creation order */
+  uint64_t n_matches, n_trials; /* reprojector_.n_matches_, n_trials_ */
+  int32_t n_overlap;            /* overlap_kfs_.size() */
+  int32_t map_changed;          /* 1: a point or candidate was deleted; apply it on the host and call svo_hip_tracker_set_map */
+  int32_t overlap_kf[16];       /* overlap_kfs_[i].first as keyframe index */
+  int32_t overlap_count[16];    /* overlap_kfs_[i].second */
+  int32_t n_candidates;         /* candidates in all cells */
+  int32_t items_overflow;       /* 1: more than max_items candidates (the excess was dropped: raise max_items) */
+  svo_hip_pose_opt_result pose; /* sfba_*: ran == 0 when the refinement was not reached */
+} svo_hip_track_result;
+
+int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const svo_hip_tracker_config* cfg, svo_hip_tracker** out);
+int svo_hip_tracker_destroy(svo_hip_tracker* trk);
+/* grid geometry (Reprojector::initializeGrid, reprojector.cpp:44-55) and the keyframe pyramid batch (borrowed) */
+int svo_hip_tracker_info(const svo_hip_tracker* trk, int* n_cells, int* grid_cols, int* grid_rows, svo_hip_pyramid** keyframe_pyramids);
+/* keyframe images: level 0 from the host (pyramid built on the device), or the pyramid of the last tracked frame
+ * (FrameHandlerMono: new_frame_->setKeyframe(); map_.addKeyframe(new_frame_), :284-330) */
+int svo_hip_tracker_upload_keyframe(svo_hip_tracker* trk, int slot, const uint8_t* level0);
+int svo_hip_tracker_keyframe_from_last_frame(svo_hip_tracker* trk, int slot);
+int svo_hip_tracker_set_map(svo_hip_tracker* trk, const svo_hip_tracker_map* map);
+/* Point::pos_ of n points after FrameHandlerBase::optimizeStructure (frame_handler_base.cpp:190-210) */
+int svo_hip_tracker_update_point_positions(svo_hip_tracker* trk, int n, const int32_t* point, const double* pos);
+/* last_frame_ from the host (after initialisation / relocalisation): its image (level0, or NULL = the keyframe pyramid in
+ * kf_slot), pose and features: px[n][2], f[n][3], point[n] (index or -1) */
+int svo_hip_tracker_set_last_frame(svo_hip_tracker* trk, const uint8_t* level0, int kf_slot, const double T_f_w[7], int n,
+                                   const double* px, const double* f, const int32_t* point);
+/* One frame.  Outputs (host, any may be NULL except result): the new frame's features in creation order -- px[n][2],
+ * f[n][3], level[n], point[n] (-1 where the pose refinement dropped the observation, pose_optimizer.cpp:154-157),
+ * edgelet[n], grad[n][2], capacity max_frame_features -- and the point counters after the frame (capacity n_points of
+ * the map).  Synchronises once. */
+int svo_hip_tracker_track(svo_hip_tracker* trk, const uint8_t* level0, svo_hip_track_result* result, double* feat_px,
+                          double* feat_f, int32_t* feat_level, int32_t* feat_point, uint8_t* feat_edgelet, double* feat_grad,
+                          int32_t* pt_type, int32_t* pt_n_failed, int32_t* pt_n_succeeded);
+
 /* The 6x6 pivoted LDL^T solve both Gauss-Newton solvers use (x = H.ldlt().solve(b), Eigen 3.4 semantics incl. the
  * pseudo-inverse of D), n systems from host buffers: exposed so that the parity tests can show it is bit-identical
  * to Eigen's result. */

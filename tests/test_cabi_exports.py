@@ -33,6 +33,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(hip.CSiaParams) == 32
     assert C.sizeof(hip.CSiaResult) == 7 * 8 + 8 + 36 * 8 + 8 + 4 + 8 * 4 + 4 + 16
     assert C.sizeof(hip.CDfParams) == 24
+    assert C.sizeof(hip.CTrackerConfig) == 96 and C.sizeof(hip.CTrackerMap) == 160
+    assert C.sizeof(hip.CTrackResult) == 14 * 8 + 8 + 8 * 4 + 2 * 4 + 2 * 8 + 2 * 4 + 32 * 4 + 2 * 4 + C.sizeof(hip.CPoseOptResult)
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -1,0 +1,113 @@
+"""svo_hip_tracker_track: one frame of FrameHandlerMono::processFrame (S/frame_handler_mono.cpp:171-229) as one chain of
+kernels on one stream -- SparseImgAlign against the last frame, Reprojector::reprojectMap with Map::getCloseKeyframes /
+Point::getCloseViewObs / Matcher::findMatchDirect, pose_optimizer::optimizeGaussNewton, hand-over of the frame.
+
+  * the reprojection stage against the reference's own compiled Reprojector::reprojectMap on a real svo::Map
+    (tests/golden/reproject_map_ref.npz): every integer equal, pixels and gradients bitwise;
+  * the 20-frame tracking sequence of tests/test_gpu_sequence.py through the new entry: equal matches in every cell and
+    frame as the oracle composition AND as the stage-by-stage chain, poses within 1e-6 (north_star: 1e-4 rad / 1e-3 m)."""
+import os
+
+import numpy as np
+import pytest
+
+import tracking_chain as tc
+from test_oracle_reproject_map import CASES, GOLD, check_map_result
+from android_svo_amd import hip, synth
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def _tracker_for(ctx, cs, key, **cfg):
+    trk = hip.Tracker(ctx, cs["cam"], max_keyframes=max(cs["n_kf"], 1), grid_size=cs["cell_size"], **cfg)
+    for k in range(cs["n_kf"]):
+        trk.upload_keyframe(k, cs["kf_pyr"][k][0])
+    trk.set_map(dict(cs, kf_slot=np.arange(cs["n_kf"], dtype=np.int32), kf_key_point=key))
+    return trk
+
+
+@pytest.mark.parametrize("tag,kw,max_fts", CASES, ids=[c[0] for c in CASES])
+def test_reprojection_stage_against_reference_fixture(ctx, tag, kw, max_fts):
+    g = np.load(GOLD)
+    cs = synth.make_map_case(**kw)
+    trk = _tracker_for(ctx, cs, g[tag + "_kf_key_point"], max_fts=max_fts, quality_min_fts=20)
+    # a last frame without features: SparseImgAlign::run returns at once (:55-59) and the new frame keeps the pose it was
+    # given -- exactly the pose the fixture was recorded at
+    trk.set_last_frame(cs["T_cur_w"], np.zeros((0, 2)), np.zeros((0, 3)), np.zeros(0, np.int32), img=cs["cur_pyr"][0])
+    r = trk.track(cs["cur_pyr"][0])
+    np.testing.assert_array_equal(r["T_f_w_sia"], cs["T_cur_w"])
+    assert r["result"].items_overflow == 0
+    # the features as the reprojector made them: before the pose refinement drops observations
+    po, hp = orc.pose_optimize(abs(cs["cam"].fx), cs["T_cur_w"], orc.cam2world(cs["cam"], g[tag + "_feat_px"]), cs["pt_pos"][g[tag + "_feat_point"]],
+                               g[tag + "_feat_level"], np.ones(len(g[tag + "_feat_point"]), np.uint8))
+    dropped = r["feat_point"] < 0
+    np.testing.assert_array_equal(dropped, ~hp.astype(bool))
+    res = dict(r, feat_point=np.where(dropped, g[tag + "_feat_point"], r["feat_point"]),
+               unlinked=((r["type"] == synth.TYPE_DELETED) & (cs["pt_type"] != synth.TYPE_DELETED)).astype(np.uint8))
+    check_map_result(g, tag, res)
+    assert r["map_changed"] == 1                                            # every case deletes points
+    np.testing.assert_array_equal(r["feat_f"], orc.cam2world(cs["cam"], g[tag + "_feat_px"]))      # Feature(frame, px, level): f = cam2world(px)
+    # the pose refinement on those features, from the aligned pose
+    rot, trans = synth.pose_error(r["T_f_w"], np.array(po.T_f_w))
+    assert rot < 1e-9 and trans < 1e-9, (rot, trans)
+    assert r["result"].pose.num_obs == po.num_obs
+    # the tracker now refuses the next frame until the map has been uploaded again
+    with pytest.raises(hip.SvoHipError):
+        trk.track(cs["cur_pyr"][0])
+    trk.destroy()
+
+
+@pytest.mark.parametrize("min_level", [2, 0], ids=["L4-L2_shipping_default", "L4-L0"])
+def test_twenty_frame_sequence_through_the_tracker(ctx, min_level):
+    seq = tc.make_sequence(n_frames=20)
+    mp = tc.sequence_map(seq)
+    cam = seq["cam"]
+    # ---- HIP: the whole-frame entry
+    trk = hip.Tracker(ctx, cam, max_keyframes=2, max_points=1024, max_obs=1024, max_kf_features=1024, max_candidates=16, max_items=1024,
+                      max_frame_features=1024, grid_size=tc.CELL, max_fts=tc.MAX_FTS, klt_min_level=min_level)
+    trk.upload_keyframe(0, seq["pyrs"][0][0])
+    trk.set_map(mp)
+    n = len(seq["px0"])
+    trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)
+
+    def hip_track(k, last):
+        r = trk.track(seq["pyrs"][k][0])
+        assert r["map_changed"] == 0
+        return r
+    g_poses, g_n, g_win, g_px = tc.run_tracker_chain(seq, hip_track, min_level)
+    trk.destroy()
+    # ---- oracle composition of the same frame function
+    state = {"pt_type": mp["pt_type"].copy(), "pt_n_failed": mp["pt_n_failed"].copy(), "pt_n_succeeded": mp["pt_n_succeeded"].copy(),
+             "unlinked": np.zeros(n, np.uint8)}
+
+    def orc_track(k, last):
+        return tc.oracle_track_frame(orc, mp, state, last, seq["pyrs"][k - 1], seq["pyrs"][k], min_level)
+    c_poses, c_n, c_win, c_px = tc.run_tracker_chain(seq, orc_track, min_level)
+    # ---- the stage-by-stage oracle chain of tests/test_gpu_sequence.py (host-side projection and bucketing)
+    s_poses, s_n, s_win = tc.run_chain(seq, tc.OracleStages(seq), min_level)
+    truth = seq["truth"][1:]
+    diff = np.array([synth.pose_error(a, b) for a, b in zip(g_poses, c_poses)])
+    assert (diff[:, 0] < 1e-4).all() and (diff[:, 1] < 1e-3).all(), diff        # north_star tolerance at every frame
+    for a, b in zip(g_win, c_win):                                              # every integer decision equal
+        np.testing.assert_array_equal(a, b)
+    assert g_n == c_n
+    # the stage-by-stage chain has no point types: it agrees until the first points are promoted to TYPE_GOOD (more than ten
+    # successful reprojections, reprojector.cpp:212-214) and move to the front of their cells
+    for a, s in list(zip(c_win, s_win))[:10]:
+        np.testing.assert_array_equal(np.sort(a), np.sort(s))
+    assert c_n[:10] == s_n[:10]
+    assert diff[:5].max() < 1e-12, diff[:5]
+    assert diff.max() < 1e-6, diff.max(axis=0)
+    for a, b in list(zip(c_poses, s_poses))[:10]:                               # ... and is the same computation until then
+        rot, trans = synth.pose_error(a, b)
+        assert rot < 1e-12 and trans < 1e-12
+    err_gpu = np.array([synth.pose_error(a, t) for a, t in zip(g_poses, truth)])
+    assert err_gpu[:, 0].max() < 2e-3 and err_gpu[:, 1].max() < 5e-3, err_gpu.max(axis=0)

@@ -104,3 +104,60 @@ class OracleStages:
     def refine(self, T_sia, f, pos, level, hp):
         r, hp_out = self.orc.pose_optimize(abs(self.seq["cam"].fx), T_sia, f, pos, level, hp)
         return np.array(r.T_f_w), hp_out
+
+
+# ---- the same chain through the whole-frame entry (svo_hip_tracker_track) and its oracle composition ---------------------
+def sequence_map(seq):
+    """The map of make_sequence as the index tables the tracker / orc.reproject_map take: ONE keyframe (frame 0) whose
+    features are the map points in map order, one observation per point, no candidates."""
+    cam, px0, f0, pos = seq["cam"], seq["px0"], seq["f0"], seq["pos"]
+    n = len(px0)
+    key_ftr = synth.key_points(cam, px0, np.ones(n, bool))
+    return dict(cam=cam, cell_size=CELL, n_kf=1, n_points=n, kf_pyr=[seq["pyrs"][0]], kf_slot=np.zeros(1, np.int32), T_kf_w=seq["T0"][None, :].copy(),
+                kf_key_point=key_ftr[None, :].copy(),          # feature index == point index here
+                kf_ftr_offset=np.array([0, n], np.int32), kf_ftr_point=np.arange(n, dtype=np.int32), pt_pos=pos.copy(),
+                pt_type=np.full(n, synth.TYPE_UNKNOWN, np.int32), pt_n_failed=np.zeros(n, np.int32), pt_n_succeeded=np.zeros(n, np.int32),
+                pt_obs_offset=np.arange(n + 1, dtype=np.int32), obs_kf=np.zeros(n, np.int32), obs_px=px0.copy(), obs_f=f0.copy(),
+                obs_level=np.zeros(n, np.int32), obs_edgelet=np.zeros(n, np.uint8), obs_grad=np.tile([1.0, 0.0], (n, 1)),
+                cand_point=np.zeros(0, np.int32))
+
+
+def oracle_track_frame(orc, mp, state, last, last_pyr, cur_pyr, min_level, max_fts=MAX_FTS, quality_min_fts=40):
+    """One frame of FrameHandlerMono::processFrame (:175-229) composed from the oracle's pieces; `last` = dict(T, px, f,
+    point) of the previous frame, `state` = the map's point counters (updated in place).  Returns the same dict layout
+    as hip.Tracker.track."""
+    cam = mp["cam"]
+    pt = last["point"]
+    pos = np.where(pt[:, None] >= 0, mp["pt_pos"][np.maximum(pt, 0)], np.array([0.0, 0.0, 1.0]))
+    fp = synth.FramePair(cam, last_pyr, cur_pyr, last["px"], last["f"], pos, (pt >= 0).astype(np.uint8), last["T"], last["T"], last["T"])
+    o = orc.sparse_img_align(fp, max_level=4, min_level=min_level, n_iter=30, early_stop=True)
+    T_sia = np.array(o.T_cur_w)
+    cs = dict(mp, cur_pyr=cur_pyr)
+    r = orc.reproject_map(cs, mp["kf_key_point"], T_cur_w=T_sia, max_fts=max_fts, state=state)
+    f_m = orc.cam2world(cam, r["feat_px"]) if len(r["feat_px"]) else np.zeros((0, 3))
+    out = dict(r, T_f_w_sia=T_sia, feat_f=f_m, sia_n_tracked=o.n_tracked)
+    if r["n_matches"] < quality_min_fts:
+        out["T_f_w"] = np.array(last["T"])
+        return out
+    po, hp = orc.pose_optimize(abs(cam.fx), T_sia, f_m, mp["pt_pos"][r["feat_point"]], r["feat_level"], np.ones(len(f_m), np.uint8))
+    out["T_f_w"] = np.array(po.T_f_w)
+    out["feat_point"] = np.where(hp.astype(bool), r["feat_point"], -1).astype(np.int32)
+    out["pose"] = po
+    return out
+
+
+def run_tracker_chain(seq, track, min_level):
+    """track(k, last) -> result dict (hip.Tracker.track layout) for frame k; the chain feeds on its own outputs."""
+    last = dict(T=seq["T0"].copy(), px=seq["px0"].copy(), f=seq["f0"].copy(), point=np.arange(len(seq["px0"]), dtype=np.int32))
+    poses, n_matches, winners, feats = [], [], [], []
+    for k in range(1, len(seq["truth"])):
+        r = track(k, last)
+        assert r["n_matches"] >= 50                                        # Config::qualityMinFts()
+        keep = r["feat_point"] >= 0
+        assert keep.sum() >= 20                                            # sfba_n_edges_final (:231)
+        last = dict(T=r["T_f_w"].copy(), px=r["feat_px"], f=r["feat_f"], point=r["feat_point"])
+        poses.append(r["T_f_w"].copy())
+        n_matches.append(int(r["n_matches"]))
+        winners.append(r["feat_point"][keep])
+        feats.append(r["feat_px"].copy())
+    return poses, n_matches, winners, feats

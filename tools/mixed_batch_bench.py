@@ -25,9 +25,10 @@ def main():
     for s in range(B):
         fp = fps[s % len(fps)]
         ref.upload(s, fp.ref_pyr); cur.upload(s, fp.cur_pyr); sia.upload_pair(s, fp)
-    prm = sia.params(early_stop=False)
+    out = {"what": "256 x C1 frame pairs (2000 patches); slot 100 replaced by a frame with few patches: svo_hip_sia_run launches the "
+                   "entry-by-entry Hessian-row instance for that slot only, on the context's side stream"}
 
-    def timed():
+    def timed(prm):
         for _ in range(3):
             sia.run(B, prm)
         ctx.sync()
@@ -36,11 +37,15 @@ def main():
             sia.run(B, prm)
         ctx.sync()
         return (time.perf_counter() - t0) / steps * 1e3
-    pure = timed()
-    ref.upload(100, tiny.ref_pyr); cur.upload(100, tiny.cur_pyr); sia.upload_pair(100, tiny)
-    mixed = timed()
-    print(json.dumps({"what": "256 x C1 frame pairs, fixed work; slot 100 replaced by a 5-patch frame", "pure_ms_per_launch": pure,
-                      "mixed_ms_per_step": mixed, "ratio": mixed / pure}))
+    prms = {"fixed_work": sia.params(early_stop=False), "reference_exits": sia.params(early_stop=True)}
+    pure = {k: timed(p) for k, p in prms.items()}
+    for n_tiny in (12, 5):
+        tiny = synth.make_frame_pair(seed=999, n_features=n_tiny)
+        ref.upload(100, tiny.ref_pyr); cur.upload(100, tiny.cur_pyr); sia.upload_pair(100, tiny)
+        for k, p in prms.items():
+            mixed = timed(p)
+            out["%s_tiny%d" % (k, n_tiny)] = {"pure_ms": pure[k], "mixed_ms": mixed, "ratio": mixed / pure[k]}
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
