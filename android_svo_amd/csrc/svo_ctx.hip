@@ -38,22 +38,72 @@ __global__ void half_sample_kernel(const uint8_t* __restrict__ in, int w, int h,
   }
 }
 
-}  // namespace
-
-int svo_ctx_fork(svo_hip_ctx* ctx) {
-  if (!ctx->aux_stream) {
-    SVO_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-    SVO_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    SVO_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+// All coarser levels of one pyramid in ONE launch (the per-level kernels above cost a dependent launch each, ~4.5 us, which is
+// what a single tracked frame pays: svo_track.hip).  A workgroup takes a 64 x 16 tile of level 0 and halves it in LDS:
+// 32x8 -> 16x4 -> 8x2 -> 4x1, every level with the same truncating 2x2 mean of the level before (vk::halfSample scalar /
+// NEON form), so the bytes are those of the level-by-level build.  Needs width % 64 == 0, height % 16 == 0 and at most
+// five levels; other shapes take the per-level kernels.
+__global__ __launch_bounds__(256) void pyramid_tile_kernel(uint8_t* __restrict__ base, int w, int h, int n_levels, size_t o1, size_t o2,
+                                                           size_t o3, size_t o4, size_t slot_stride) {
+  __shared__ uint8_t l1[8][32], l2[4][16], l3[2][8];
+  base += (size_t)blockIdx.z * slot_stride;
+  const int t = threadIdx.x;
+  const int tx = blockIdx.x, ty = blockIdx.y;
+  {
+    const int x = t & 31, y = t >> 5;                       // one level-1 pixel per thread
+    const uint8_t* p = base + (size_t)(16 * ty + 2 * y) * w + 64 * tx + 2 * x;
+    const unsigned a = *reinterpret_cast<const unsigned short*>(p), b = *reinterpret_cast<const unsigned short*>(p + w);
+    const uint8_t v = (uint8_t)(((a & 0xff) + (a >> 8) + (b & 0xff) + (b >> 8)) >> 2);
+    l1[y][x] = v;
+    base[o1 + (size_t)(8 * ty + y) * (w >> 1) + 32 * tx + x] = v;
   }
-  SVO_CHECK_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-  SVO_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-  return SVO_HIP_OK;
+  if (n_levels <= 2) return;
+  __syncthreads();
+  if (t < 64) {
+    const int x = t & 15, y = t >> 4;
+    const uint8_t v = (uint8_t)(((unsigned)l1[2 * y][2 * x] + l1[2 * y][2 * x + 1] + l1[2 * y + 1][2 * x] + l1[2 * y + 1][2 * x + 1]) >> 2);
+    l2[y][x] = v;
+    base[o2 + (size_t)(4 * ty + y) * (w >> 2) + 16 * tx + x] = v;
+  }
+  if (n_levels <= 3) return;
+  __syncthreads();
+  if (t < 16) {
+    const int x = t & 7, y = t >> 3;
+    const uint8_t v = (uint8_t)(((unsigned)l2[2 * y][2 * x] + l2[2 * y][2 * x + 1] + l2[2 * y + 1][2 * x] + l2[2 * y + 1][2 * x + 1]) >> 2);
+    l3[y][x] = v;
+    base[o3 + (size_t)(2 * ty + y) * (w >> 3) + 8 * tx + x] = v;
+  }
+  if (n_levels <= 4) return;
+  __syncthreads();
+  if (t < 4) {
+    const uint8_t v = (uint8_t)(((unsigned)l3[0][2 * t] + l3[0][2 * t + 1] + l3[1][2 * t] + l3[1][2 * t + 1]) >> 2);
+    base[o4 + (size_t)ty * (w >> 4) + 4 * tx + t] = v;
+  }
 }
 
-int svo_ctx_join(svo_hip_ctx* ctx) {
-  SVO_CHECK_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
-  SVO_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+}  // namespace
+
+// levels 1.. of n_slots pyramids starting at first_slot, from their level 0 (already in place), on the context stream
+int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots) {
+  svo_hip_ctx* ctx = pyr->ctx;
+  uint8_t* base = pyr->base + (size_t)first_slot * pyr->pyr_bytes;
+  if (pyr->n_levels < 2) return SVO_HIP_OK;
+  if (pyr->width % 64 == 0 && pyr->height % 16 == 0 && pyr->n_levels <= 5) {
+    const size_t o1 = pyr->level_offset[1], o2 = pyr->n_levels > 2 ? pyr->level_offset[2] : 0, o3 = pyr->n_levels > 3 ? pyr->level_offset[3] : 0,
+                 o4 = pyr->n_levels > 4 ? pyr->level_offset[4] : 0;
+    hipLaunchKernelGGL(pyramid_tile_kernel, dim3(pyr->width / 64, pyr->height / 16, n_slots), dim3(256), 0, ctx->stream, base, pyr->width, pyr->height,
+                       pyr->n_levels, o1, o2, o3, o4, pyr->pyr_bytes);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+    return SVO_HIP_OK;
+  }
+  for (int l = 1; l < pyr->n_levels; ++l) {
+    const int w = pyr->width >> (l - 1), h = pyr->height >> (l - 1);
+    const int ow = w >> 1, oh = h >> 1;
+    dim3 block(64), grid(((ow + 3) / 4 + 63) / 64, oh, n_slots);
+    hipLaunchKernelGGL(half_sample_kernel, grid, block, 0, ctx->stream, base + pyr->level_offset[l - 1], w, h,
+                       base + pyr->level_offset[l], pyr->pyr_bytes);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+  }
   return SVO_HIP_OK;
 }
 
@@ -94,9 +144,6 @@ int svo_hip_ctx_create(svo_hip_ctx** out, int device, void* stream) {
 int svo_hip_ctx_destroy(svo_hip_ctx* ctx) {
   if (!ctx) return SVO_HIP_ERR_INVALID;
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
-  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->staging) (void)hipFree(ctx->staging);
   if (ctx->host_staging) (void)hipHostFree(ctx->host_staging);
@@ -247,15 +294,7 @@ int svo_hip_pyramid_upload_level0_and_build(svo_hip_pyramid* pyr, int slot, cons
   SVO_REQUIRE(ctx, slot >= 0 && slot < pyr->batch);
   uint8_t* base = pyr->base + (size_t)slot * pyr->pyr_bytes;
   SVO_CHECK_HIP(ctx, hipMemcpyAsync(base, level0, (size_t)pyr->width * pyr->height, hipMemcpyHostToDevice, ctx->stream));
-  for (int l = 1; l < pyr->n_levels; ++l) {
-    const int w = pyr->width >> (l - 1), h = pyr->height >> (l - 1);
-    const int ow = w >> 1, oh = h >> 1;
-    dim3 block(64), grid(((ow + 3) / 4 + 63) / 64, oh);
-    hipLaunchKernelGGL(half_sample_kernel, grid, block, 0, ctx->stream, base + pyr->level_offset[l - 1], w, h,
-                       base + pyr->level_offset[l]);
-    SVO_CHECK_HIP(ctx, hipGetLastError());
-  }
-  return SVO_HIP_OK;
+  return svo_pyramid_build_levels(pyr, slot, 1);
 }
 
 int svo_hip_pyramid_upload_level0_batch_and_build(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* level0_packed) {
@@ -266,15 +305,7 @@ int svo_hip_pyramid_upload_level0_batch_and_build(svo_hip_pyramid* pyr, int firs
   const size_t l0 = (size_t)pyr->width * pyr->height;
   // n_slots level-0 images, back to back on the host, into their slots (one strided transfer)
   SVO_CHECK_HIP(ctx, hipMemcpy2DAsync(base, pyr->pyr_bytes, level0_packed, l0, l0, (size_t)n_slots, hipMemcpyHostToDevice, ctx->stream));
-  for (int l = 1; l < pyr->n_levels; ++l) {
-    const int w = pyr->width >> (l - 1), h = pyr->height >> (l - 1);
-    const int ow = w >> 1, oh = h >> 1;
-    dim3 block(64), grid(((ow + 3) / 4 + 63) / 64, oh, n_slots);
-    hipLaunchKernelGGL(half_sample_kernel, grid, block, 0, ctx->stream, base + pyr->level_offset[l - 1], w, h,
-                       base + pyr->level_offset[l], pyr->pyr_bytes);
-    SVO_CHECK_HIP(ctx, hipGetLastError());
-  }
-  return SVO_HIP_OK;
+  return svo_pyramid_build_levels(pyr, first_slot, n_slots);
 }
 
 int svo_hip_pyramid_download_level(svo_hip_pyramid* pyr, int slot, int level, uint8_t* out_host) {

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "svo_internal.h"
+#include "svo_match_device.h"
 
 using namespace svo_dev;
 
@@ -280,21 +281,7 @@ SVO_DEV int zmssd_8x8(const uint8_t* __restrict__ p, int stride, const uint32_t*
 // F  thread per seed : triangulation, computeTau, updateSeed, convergence                     -> seed arrays
 // The fp64 geometry of a seed runs once (64 seeds per wave instruction) instead of on every lane of
 // the seed's wave; only the pixel work is wave-per-seed.
-struct SeedRec {                 // 96 B, one per seed of the batch (device scratch owned by the context)
-  double uv0[2];                 // path 1: B - step (epipolar abscissa of step 0); path 0: px midpoint (level 0)
-  double step[2];                // path 1: epi_dir / n_steps; after stage S: px_cur (level 0) of the match
-  float a00, a01, a10, a11;      // inverse affine warp (A_cur_ref^-1 cast to f32)
-  float prx, pry;                // ref px on its pyramid level
-  float z_inv_min;               // for the NaN test of depth_filter.cpp:333
-  int n_steps;                   // epi_length / 0.7 (before the ++ of matcher.cpp:297)
-  int search_level;
-  int path;                      // 0 direct align, 1 epipolar search, 2 no search (too long), -1 seed not live
-  int status;                    // pre-status for non-live seeds
-  int warp_nan;
-  int matched;                   // stage S: align2D converged
-  int n_zmssd, n_align;
-  int pad;
-};
+// (SeedRec: svo_match_device.h)
 
 // EXPLICIT_DEPTH = false: the per-seed body of DepthFilter::updateSeeds (visibility test, depth interval from mu/sigma2);
 // EXPLICIT_DEPTH = true: Matcher::findEpipolarMatchDirect as a caller would use it directly, with d_estimate / d_min /
@@ -468,7 +455,9 @@ constexpr int SEEDS_PER_BLOCK = 16;
 
 __global__ __launch_bounds__(256, 7) void df_search_kernel(
     DfFrame fr, const uint8_t* __restrict__ ref_base, size_t ref_pyr_bytes, const uint8_t* __restrict__ cur_pyr, int n,
-    const int32_t* __restrict__ level, SeedRec* __restrict__ recs, uint32_t* __restrict__ pwb_t, int n_pad) {
+    const int32_t* __restrict__ level, SeedRec* __restrict__ recs, uint32_t* __restrict__ pwb_t, int n_pad,
+    const int* __restrict__ n_dev = nullptr) {
+  if (n_dev) { const int nd = *n_dev; n = nd < n ? nd : n; }       // item count left by an earlier kernel of the stream (svo_track.hip)
   __shared__ __attribute__((aligned(16))) uint8_t s_pwb[SEEDS_PER_BLOCK][112];
   __shared__ __attribute__((aligned(16))) uint32_t s_patch[SEEDS_PER_BLOCK][16];
   __shared__ double s_px[SEEDS_PER_BLOCK][2];
@@ -766,7 +755,9 @@ __global__ __launch_bounds__(256, 7) void df_search_kernel(
 // findMatchDirect with align1D (matcher.cpp:183-191; the depth filter never produces them).
 template <bool ONE_D>
 __global__ __launch_bounds__(ALIGN_BLOCK) void df_align_kernel(DfFrame fr, const uint8_t* __restrict__ cur_pyr, int n, int n_pad,
-                                                               const uint32_t* __restrict__ pwb_t, SeedRec* __restrict__ recs) {
+                                                               const uint32_t* __restrict__ pwb_t, SeedRec* __restrict__ recs,
+                                                               const int* __restrict__ n_dev = nullptr) {
+  if (n_dev) { const int nd = *n_dev; n = nd < n ? nd : n; }
   const int i = blockIdx.x * ALIGN_PATCHES + (threadIdx.x >> 2);
   const int q = threadIdx.x & 3;
   const bool have = i < n;
@@ -902,13 +893,7 @@ __global__ __launch_bounds__(256) void epi_finalize_kernel(
 }
 
 // ---- Matcher::findMatchDirect over n (map point, reference feature) pairs (S/matcher.cpp:156-202) ----
-struct MdFrame {
-  Cam cam;
-  double T_cur_w[7];
-  int n_pyr_levels;
-  int n_kf, n_ref_levels;      // valid ranges of the caller's kf_slot / level values
-};
-
+// (MdFrame, md_geometry_item: svo_match_device.h)
 // thread per item: frame test, depth, affine warp, search level -> SeedRec (path 0 = align2D, 3 = align1D)
 __global__ __launch_bounds__(256) void md_geometry_kernel(
     MdFrame fr, int n, const double* __restrict__ T_ref_w /*[n_kf][7]*/, const int32_t* __restrict__ kf_slot,
@@ -918,64 +903,16 @@ __global__ __launch_bounds__(256) void md_geometry_kernel(
     const int* __restrict__ n_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const Cam cam = fr.cam;
-  SeedRec rc;
-  rc.uv0[0] = rc.uv0[1] = 0.0;
-  rc.step[0] = rc.step[1] = 0.0;
-  rc.a00 = rc.a01 = rc.a10 = rc.a11 = rc.prx = rc.pry = 0.0f; rc.z_inv_min = 0.0f;
-  rc.n_steps = 0; rc.search_level = 0; rc.path = -1; rc.status = 0; rc.warp_nan = 0;
-  rc.matched = 0; rc.n_zmssd = 0; rc.n_align = 0; rc.pad = 0;
-  // tracking chain (svo_track.hip): the item count and the frame pose come from earlier kernels of the same stream;
-  // the launch covers the capacity and the items past the count become records no later stage touches
-  if (n_dev && i >= *n_dev) { recs[i] = rc; return; }
+  // the item count and the frame pose may come from earlier kernels of the same stream; the launch then covers the
+  // capacity and the items past the count become records no later stage touches
+  if (n_dev && i >= *n_dev) { recs[i] = md_dead_record(); return; }
   if (T_cur_w_dev) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) fr.T_cur_w[k] = T_cur_w_dev[k];
   }
-  rc.uv0[0] = px_cur[2 * (size_t)i]; rc.uv0[1] = px_cur[2 * (size_t)i + 1];
-  const int slot = kf_slot[i];
-  rc.pad = slot;
-  const int level_ref = level[i];
-  const double pr[2] = {px_ref[2 * (size_t)i], px_ref[2 * (size_t)i + 1]};
-  const double fi[3] = {f_ref[3 * (size_t)i], f_ref[3 * (size_t)i + 1], f_ref[3 * (size_t)i + 2]};
-  // isInFrame(px.cast<int>()/(1<<level), halfpatch_size_+2, level) (:164-166)
-  // a slot or level outside the pyramids the caller handed over is rejected like a failed frame test (never indexed)
-  const bool in_range = slot >= 0 && slot < fr.n_kf && level_ref >= 0 && level_ref < fr.n_ref_levels;
-  const int ox = in_range ? (int)pr[0] / (1 << level_ref) : -1, oy = in_range ? (int)pr[1] / (1 << level_ref) : -1;
-  if (in_range && is_in_frame_level(cam, ox, oy, 6, level_ref)) {
-    const double* Tr = T_ref_w + 7 * (size_t)slot;
-    double T_ref_inv[7], T_cur_ref[7];
-    se3_inverse(Tr, T_ref_inv);
-    se3_mul(fr.T_cur_w, T_ref_inv, T_cur_ref);
-    const double dx = T_ref_inv[0] - pt_pos[3 * (size_t)i], dy = T_ref_inv[1] - pt_pos[3 * (size_t)i + 1],
-                 dz = T_ref_inv[2] - pt_pos[3 * (size_t)i + 2];
-    const double depth = sqrt(dx * dx + dy * dy + dz * dz);
-    double Acr[4];
-    get_warp_matrix_affine(cam, pr, fi, depth, T_cur_ref, level_ref, Acr);
-    int search_level = 0;
-    {
-      double D = Acr[0] * Acr[3] - Acr[2] * Acr[1];
-      while (D > 3.0 && search_level < fr.n_pyr_levels - 1) { search_level += 1; D *= 0.25; }
-    }
-    rc.search_level = search_level;
-    const double det = Acr[0] * Acr[3] - Acr[2] * Acr[1];
-    const double invdet = 1.0 / det;
-    rc.a00 = (float)(Acr[3] * invdet); rc.a01 = (float)(-Acr[1] * invdet);
-    rc.a10 = (float)(-Acr[2] * invdet); rc.a11 = (float)(Acr[0] * invdet);
-    rc.warp_nan = rc.a00 != rc.a00;
-    rc.prx = (float)pr[0] / (1 << level_ref);
-    rc.pry = (float)pr[1] / (1 << level_ref);
-    rc.path = 0;
-    if (edgelet && edgelet[i]) {
-      double d0 = Acr[0] * grad[2 * (size_t)i] + Acr[1] * grad[2 * (size_t)i + 1];
-      double d1 = Acr[2] * grad[2 * (size_t)i] + Acr[3] * grad[2 * (size_t)i + 1];
-      const double n2 = d0 * d0 + d1 * d1;
-      if (n2 > 0.0) { const double nn = sqrt(n2); d0 = d0 / nn; d1 = d1 / nn; }
-      rc.step[0] = (double)(float)d0; rc.step[1] = (double)(float)d1;
-      rc.path = 3;
-    }
-  }
-  recs[i] = rc;
+  const double g[2] = {grad ? grad[2 * (size_t)i] : 1.0, grad ? grad[2 * (size_t)i + 1] : 0.0};
+  recs[i] = md_geometry_item(fr, T_ref_w, kf_slot[i], level[i], px_ref + 2 * (size_t)i, f_ref + 3 * (size_t)i, pt_pos + 3 * (size_t)i,
+                             edgelet && edgelet[i], g, px_cur + 2 * (size_t)i);
 }
 
 __global__ void md_finalize_kernel(int n, const SeedRec* __restrict__ recs, double* __restrict__ px_cur,
@@ -1333,6 +1270,38 @@ int svo_hip_epipolar_match_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* re
 }
 
 }  // extern "C"
+
+// The middle stages of the findMatchDirect pipeline for callers that form the records themselves (svo_track.hip): scratch
+// for n_cap records + word-transposed patches, then warp / align2D (/ align1D) over records [0, min(n_cap, *n_dev)).
+int svo_match_scratch(svo_hip_ctx* ctx, int n_cap, svo_dev::SeedRec** recs, uint32_t** pwb_t, int* n_pad) {
+  return df_scratch(ctx, n_cap, recs, pwb_t, n_pad);
+}
+
+int svo_match_stages(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                     int n_cap, const int* n_dev, const int32_t* level_ref_dev, svo_dev::SeedRec* recs, uint32_t* pwb_t, int n_pad,
+                     int n_pyr_levels, int align_max_iter, bool edgelets) {
+  if (!ctx || !ref || !cur || !cam || !recs || !pwb_t || !level_ref_dev) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n_cap > 0 && cur_slot >= 0 && cur_slot < cur->batch);
+  DfFrame fr;
+  memset(&fr, 0, sizeof(fr));
+  fr.cam = svo_make_cam(*cam);
+  for (int l = 0; l < ref->n_levels; ++l) fr.ref_level_off[l] = ref->level_offset[l];
+  for (int l = 0; l < cur->n_levels; ++l) fr.cur_level_off[l] = cur->level_offset[l];
+  fr.n_pyr_levels = n_pyr_levels; fr.align_max_iter = align_max_iter; fr.keep_px_on_failure = 1;
+  const uint8_t* cur_img = cur->base + (size_t)cur_slot * cur->pyr_bytes;
+  hipLaunchKernelGGL(df_search_kernel, dim3((n_cap + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref->base, ref->pyr_bytes,
+                     cur_img, n_cap, level_ref_dev, recs, pwb_t, n_pad, n_dev);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(df_align_kernel<false>, dim3((n_cap + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr, cur_img, n_cap, n_pad,
+                     pwb_t, recs, n_dev);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  if (edgelets) {
+    hipLaunchKernelGGL(df_align_kernel<true>, dim3((n_cap + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr, cur_img, n_cap,
+                       n_pad, pwb_t, recs, n_dev);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+  }
+  return SVO_HIP_OK;
+}
 
 // svo_hip_match_direct_batch_dev with, optionally, the pose of the current frame and the number of items left on the
 // device by earlier kernels of the stream (T_cur_w_dev / n_dev non-null: the tracking chain of svo_track.hip; n is then

@@ -20,9 +20,6 @@ struct svo_hip_ctx {
   size_t staging_bytes = 0;
   void* host_staging = nullptr;     // grow-only page-locked host mirror of it: one transfer each way per call
   size_t host_staging_bytes = 0;
-  // side stream + fork / join events (created on first use): small launches that may overlap the main one
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   char err[512] = {0};
 };
 
@@ -107,10 +104,7 @@ inline int svo_ctx_host_staging(svo_hip_ctx* ctx, size_t need, char** out) {
   return SVO_HIP_OK;
 }
 
-// side stream of the context (svo_ctx.hip): work enqueued between svo_ctx_fork and svo_ctx_join on ctx->aux_stream starts
-// after everything already on the context stream and is complete before anything enqueued on it after the join
-int svo_ctx_fork(svo_hip_ctx* ctx);
-int svo_ctx_join(svo_hip_ctx* ctx);
+int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots);    // levels 1.. from level 0 (svo_ctx.hip)
 
 inline svo_dev::Cam svo_make_cam(const svo_hip_camera& c) {
   svo_dev::Cam d;
@@ -162,6 +156,8 @@ int svo_sia_prepare_from_device(svo_hip_sia* s, const svo_hip_camera* cam, int n
                                 const double* T_last_w_dev, const double* px_dev, const double* f_dev, const int32_t* point_dev,
                                 const double* pt_pos_dev);
 const svo_dev::FrameState* svo_sia_state_dev(const svo_hip_sia* s);
+int svo_sia_slot0_arrays(svo_hip_sia* s, svo_dev::FrameConst** fc, double** px, double** f, double** pos, uint8_t** has_point, int* max_n);
+int svo_sia_note_device_slot0(svo_hip_sia* s, const svo_hip_camera* cam, int n_feat_host);
 
 // svo_depth.hip: Matcher::findMatchDirect over n items (svo_hip_match_direct_batch_dev) with, optionally, the current
 // frame's pose and the item count read from device memory
@@ -171,6 +167,12 @@ int svo_match_direct_internal(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, cons
                               const double* px_ref_dev, const double* f_ref_dev, const int32_t* level_ref_dev,
                               const double* pt_pos_dev, const uint8_t* edgelet_dev, const double* grad_dev, int n_pyr_levels,
                               int align_max_iter, double* px_cur_dev, uint8_t* success_dev, int32_t* search_level_dev);
+
+namespace svo_dev { struct SeedRec; }
+int svo_match_scratch(svo_hip_ctx* ctx, int n_cap, svo_dev::SeedRec** recs, uint32_t** pwb_t, int* n_pad);
+int svo_match_stages(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                     int n_cap, const int* n_dev, const int32_t* level_ref_dev, svo_dev::SeedRec* recs, uint32_t* pwb_t, int n_pad,
+                     int n_pyr_levels, int align_max_iter, bool edgelets);
 
 // ---- multi-GPU exchange (svo_comm.hip): RCCL over xGMI, or a host-staged shared-memory transport for bring-up / tests.
 // Both all-reduce in place on the communicator's context stream and give every rank bitwise the same result.

@@ -95,6 +95,27 @@ __device__ KeyT block_radix_select(unsigned k, ForEachKey for_each_key, int* his
   return *s_prefix;
 }
 
+// The same k-th smallest key for a frame with at most one observation per thread (n <= blockDim.x: what a tracked frame
+// has -- a few hundred matches): the keys go to LDS once and every thread ranks its own key against all of them
+// (ties by thread index); one pass and two barriers instead of four or eight histogram passes of three barriers each.
+// has_key / key: this thread's key (a thread without one passes has_key = false).  s_keys: blockDim.x entries.
+__device__ unsigned long long block_rank_select(unsigned k, bool has_key, unsigned long long key, int n, unsigned long long* s_keys,
+                                                unsigned long long* s_out) {
+  const unsigned long long none = ~0ull;                   // above every key (bit patterns of non-negative numbers)
+  s_keys[threadIdx.x] = has_key ? key : none;
+  __syncthreads();
+  if (has_key) {
+    unsigned rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const unsigned long long o = s_keys[j];
+      rank += (o < key || (o == key && j < (int)threadIdx.x)) ? 1u : 0u;
+    }
+    if (rank == k) *s_out = key;
+  }
+  __syncthreads();
+  return *s_out;
+}
+
 // Matrix<double,6,6>::inverse() = partialPivLu().inverse() (Eigen LU/PartialPivLU.h:379-425): one thread
 SVO_DEV void inverse6(const double* Ain, double* out) {
   constexpr int N = 6;
@@ -133,6 +154,8 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
     double reproj_thresh, int n_iter, float* __restrict__ err_ws, double* __restrict__ sq_init_ws,
     double* __restrict__ sq_final_ws, PoseOptOut* __restrict__ out) {
   __shared__ int hist[256];
+  __shared__ unsigned long long s_keys[PR_THREADS];
+  __shared__ unsigned long long s_sel;
   __shared__ unsigned s_k;
   __shared__ unsigned s_pref32;
   __shared__ unsigned long long s_pref64;
@@ -223,7 +246,10 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
     }
     return;
   }
-  const unsigned med_bits = block_radix_select<unsigned>(
+  const bool small = n <= PR_THREADS;                        // block-uniform: one observation per thread at most
+  const unsigned med_bits = small
+      ? (unsigned)block_rank_select(n_obs / 2, ch[0], (unsigned long long)__float_as_uint(cerr[0]), n, s_keys, &s_sel)
+      : block_radix_select<unsigned>(
       n_obs / 2, [&](auto&& emit) {
 #pragma unroll
         for (int j = 0; j < PR_CACHED; ++j) if (ch[j]) emit(__float_as_uint(cerr[j]));
@@ -335,14 +361,16 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
   const unsigned n_deleted = s_count;
   // the observations of the init/final vectors are those that had a point when the function was entered:
   // sq_final >= 0 marks them (has_point was just cleared for the outliers)
-  const unsigned long long mi = block_radix_select<unsigned long long>(
+  const unsigned long long mi = small ? block_rank_select(n_obs / 2, ch0[0], (unsigned long long)__double_as_longlong(csqi[0]), n, s_keys, &s_sel)
+                                      : block_radix_select<unsigned long long>(
       n_obs / 2, [&](auto&& emit) {
 #pragma unroll
         for (int j = 0; j < PR_CACHED; ++j) if (ch0[j]) emit((unsigned long long)__double_as_longlong(csqi[j]));
         for (int i = threadIdx.x + PR_THREADS * PR_CACHED; i < n; i += PR_THREADS)
           if (sq_final[i] >= 0.0) emit((unsigned long long)__double_as_longlong(sq_init[i]));
       }, hist, &s_pref64, &s_k);
-  const unsigned long long mf = block_radix_select<unsigned long long>(
+  const unsigned long long mf = small ? block_rank_select(n_obs / 2, ch0[0], (unsigned long long)__double_as_longlong(csqf[0]), n, s_keys, &s_sel)
+                                      : block_radix_select<unsigned long long>(
       n_obs / 2, [&](auto&& emit) {
 #pragma unroll
         for (int j = 0; j < PR_CACHED; ++j) if (ch0[j]) emit((unsigned long long)__double_as_longlong(csqf[j]));

@@ -778,8 +778,8 @@ __device__ __noinline__ void se3_exp_cold(const double* l, double* out) { se3_ex
 // after reduction c3 the eight lanes 8j..8j+7 all hold the total of entry 8 c3 + j: lane 8j + c3 keeps it, and ONE lane
 // exchange at the end (instead of one per reduction) brings entry e from lane 8 (e & 7) + (e >> 3).
 template <bool EXACT_ROWS>
-SVO_DEV double fused_tile_row(double x, double y, double z_inv, double jscale, double sxx, double sxy, double syy, bool contributes,
-                              int lane) {
+SVO_DEV double fused_tile_row_body(double x, double y, double z_inv, double jscale, double sxx, double sxy, double syy, bool contributes,
+                                   int lane) {
   const double gxx = contributes ? sxx : 0.0, gxy = contributes ? sxy : 0.0, gyy = contributes ? syy : 0.0;
   double A[6], B[6], P[6], Q[6];
   if (EXACT_ROWS) {
@@ -815,19 +815,37 @@ SVO_DEV double fused_tile_row(double x, double y, double z_inv, double jscale, d
   return __shfl(kept, 8 * (lane & 7) + (lane < 24 ? lane >> 3 : 0), 64);
 }
 
-// EXACT_ROWS: the per-tile Hessian rows entry by entry as sxx (A_i A_j) + sxy (A_i B_j + B_i A_j) + syy (B_i B_j), the
-// form the kernel used for every frame until round 2; otherwise factored (see the precompute).  The launcher picks the
-// exact form for a batch that holds a frame with fewer than FUSED_EXACT_ROW_BELOW patches: there H can be rank-deficient
-// (one patch: rank 2), the reference's own solve then wanders off on rounding noise -- in the reference-derived test
-// of a one-patch frame until the patch leaves the image and the pose turns NaN -- and the exact form happens to follow
-// it (tests/test_gpu_parity.py::test_batch_ragged_and_empty) where the factored one returned a finite pose.
+// The entry-by-entry form runs once per level and tile (and on the rare corrections), for the handful of frames with
+// fewer than FUSED_EXACT_ROW_BELOW patches: out of line, so that its ~250 live fp64 values do not shape the register
+// allocation of the evaluation loop (inlined, the <8,1,1,true> instance spilled 30 VGPRs inside that loop and ran three
+// times slower per evaluation than <8,1,1,false>: 1.58 ms for ONE 5-patch frame in fixed-work mode).
+__device__ __noinline__ double fused_tile_row_exact(double x, double y, double z_inv, double jscale, double sxx, double sxy, double syy,
+                                                    bool contributes, int lane) {
+  return fused_tile_row_body<true>(x, y, z_inv, jscale, sxx, sxy, syy, contributes, lane);
+}
+
+template <bool EXACT_ROWS>
+SVO_DEV double fused_tile_row(double x, double y, double z_inv, double jscale, double sxx, double sxy, double syy, bool contributes,
+                              int lane) {
+  if (EXACT_ROWS) return fused_tile_row_exact(x, y, z_inv, jscale, sxx, sxy, syy, contributes, lane);
+  return fused_tile_row_body<false>(x, y, z_inv, jscale, sxx, sxy, syy, contributes, lane);
+}
+
+// EXACT_ROWS: workgroups whose frame has fewer than FUSED_EXACT_ROW_BELOW patches form the per-tile Hessian rows entry
+// by entry as sxx (A_i A_j) + sxy (A_i B_j + B_i A_j) + syy (B_i B_j) -- the form the kernel used for every frame until
+// round 2 -- instead of factored (see fused_tile_row_body).  There H can be rank-deficient (one patch: rank 2), the
+// reference's own solve then wanders off on rounding noise -- in the reference-derived test of a one-patch frame until
+// the patch leaves the image and the pose turns NaN -- and the exact form happens to follow it
+// (tests/test_gpu_parity.py::test_batch_ragged_and_empty) where the factored one returned a finite pose.  The launcher
+// picks the EXACT_ROWS instance of a shape for a batch that holds such a frame; every other frame of that batch still
+// takes the factored rows, so its result does not depend on the company it is launched in.
 template <int NW, int TPW, int CK, bool EXACT_ROWS>
 __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
     const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
     const double* __restrict__ f, const double* __restrict__ pos, const uint8_t* __restrict__ has_point,
     double4* __restrict__ sxyz, double* __restrict__ tile_h, float4* __restrict__ wmem, int max_tiles, FusedParams prm,
-    int tiles_young, int n_extra, const int* __restrict__ slots) {
+    int tiles_young, int n_extra) {
   using Plan = FusedPlan<TPW, CK>;
   // the LDS left over holds one more tile -- the first one the plan keeps in memory -- for the first n_extra waves
   // (kernels whose waves own five or six tiles are register-bound: for them the extra LDS slot and the deferred
@@ -867,12 +885,16 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   if (threadIdx.x == 0) { for (int i = 3; i < 9; ++i) s_stamp[i] = 0; }
 #endif
 
-  const int b = slots ? slots[blockIdx.x] : (int)blockIdx.x;   // a mixed launch hands over the list of its slots (run_fused)
+  const int b = blockIdx.x;
   const FrameConst& c = fc[b];
   LeanCam cam;
   cam.fx = c.cam.fx; cam.fy = c.cam.fy; cam.cx = c.cam.cx; cam.cy = c.cam.cy;
   cam.d = c.cam.distortion ? c.cam.d : nullptr;
   const int n = c.n_feat;
+  // block-uniform: a frame with a handful of patches takes the entry-by-entry Hessian rows (out of line: fused_tile_row_exact).
+  // Only the instances launched for a batch that holds such a frame carry the branch (EXACT_ROWS): it costs the evaluation
+  // loop registers -- 36 instead of 20 spilled VGPRs in <8,4,2>, -1.4 % fixed work, -3 % with the reference's exits.
+  const bool exact_rows = EXACT_ROWS && n < FUSED_EXACT_ROW_BELOW;
   const int n_tiles = (n + TILE - 1) / TILE;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPRs
   const bool empty = n <= 0;
@@ -1051,7 +1073,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       if (valid) sxyz[(size_t)b * max_n + i_own] = make_double4(sxx, sxy, syy, 0.0);   // only re-read when a patch leaves the image
       // the tile's Hessian row: lane e keeps entry e (fused_tile_row)
       {
-        const double mine = fused_tile_row<EXACT_ROWS>(X[k].x, X[k].y, X[k].w, jscale, sxx, sxy, syy, valid, lane);
+        const double mine = exact_rows ? fused_tile_row_exact(X[k].x, X[k].y, X[k].w, jscale, sxx, sxy, syy, valid, lane)
+                                       : fused_tile_row_body<false>(X[k].x, X[k].y, X[k].w, jscale, sxx, sxy, syy, valid, lane);
         th_set(k, mine);
         // the untouched row goes to memory: it is only needed again when the set of patches outside the image changes
         if (lane < 21) tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane] = mine;
@@ -1279,7 +1302,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           double t = 0.0;
           if (lane < 21) t = tile_h[((size_t)b * max_tiles + tile) * TILE_ROW + lane];
           const double4 G4 = sxyz[(size_t)b * max_n + (gone_lane ? i_own : 0)];            // (always a valid address)
-          const double out_row = fused_tile_row<EXACT_ROWS>(X[k].x, X[k].y, X[k].w, jscale, G4.x, G4.y, G4.z, gone_lane, lane);
+          const double out_row = exact_rows ? fused_tile_row_exact(X[k].x, X[k].y, X[k].w, jscale, G4.x, G4.y, G4.z, gone_lane, lane)
+                                            : fused_tile_row_body<false>(X[k].x, X[k].y, X[k].w, jscale, G4.x, G4.y, G4.z, gone_lane, lane);
           th_set(k, t - out_row);
         }
       }
@@ -1551,7 +1575,6 @@ struct svo_hip_sia {
   int shard_rank = 0, shard_world = 1;
   // tuning / diagnostic switches of this object (svo_hip_sia_set_option); 0 / -1 = automatic
   int opt_mode = 0, opt_waves = 0, opt_chunks = 0, opt_extra_lds = -1, opt_old_tiles = 0;
-  int* slot_list = nullptr;          // device [2][batch]: slots of a mixed launch (fused kernel, see run_fused)
   // stepwise state
   svo_hip_sia_params prm{};
   int n_slots = 0, level = -1, chunks = 1;
@@ -1629,13 +1652,10 @@ int flush_fc(svo_hip_sia* s) {
   return SVO_HIP_OK;
 }
 
-// One launch of the fused kernel over n_launch frame pairs: slots [0, n_launch) when slots_dev is null, else the
-// listed ones.
+// One launch of the fused kernel over slots [0, n_launch).
 template <int NW, int TPW, int CK, bool EXACT_ROWS>
-int launch_fused_x(svo_hip_sia* s, int n_launch, const int* slots_dev, const svo_hip_sia_params* prm, size_t lds_bytes,
-                   int tiles_young, int n_extra = 0, hipStream_t stream = nullptr) {
+int launch_fused_x(svo_hip_sia* s, int n_launch, const svo_hip_sia_params* prm, size_t lds_bytes, int tiles_young, int n_extra = 0) {
   svo_hip_ctx* ctx = s->ctx;
-  if (!stream) stream = ctx->stream;
   // > 64 KiB of dynamic LDS has to be allowed explicitly (per device: set it on every launch, it is cheap)
   SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<NW, TPW, CK, EXACT_ROWS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1648,9 +1668,9 @@ int launch_fused_x(svo_hip_sia* s, int n_launch, const int* slots_dev, const svo
   FusedParams fp;
   fp.max_level = prm->max_level; fp.min_level = prm->min_level; fp.n_iter = prm->n_iter;
   fp.early_stop = prm->early_stop; fp.eps = prm->eps;
-  hipLaunchKernelGGL((sia_fused_kernel<NW, TPW, CK, EXACT_ROWS>), dim3(n_launch), dim3(NW * 64), lds_bytes, stream, s->fc, s->st,
+  hipLaunchKernelGGL((sia_fused_kernel<NW, TPW, CK, EXACT_ROWS>), dim3(n_launch), dim3(NW * 64), lds_bytes, ctx->stream, s->fc, s->st,
                      s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, s->tile_h,
-                     s->wmem, s->max_tiles, fp, tiles_young, n_extra, slots_dev);
+                     s->wmem, s->max_tiles, fp, tiles_young, n_extra);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
 }
@@ -1691,8 +1711,9 @@ int fused_old_share(const svo_hip_sia* s, int max_n, int* per_simd_out) {
   return old_share < 1 ? 1 : old_share;
 }
 
-// The shape of the fused kernel for a launch of n_launch pairs whose largest frame has max_n patches (factored Hessian rows).
-int launch_fused_shape(svo_hip_sia* s, int n_launch, const int* slots_dev, int max_n, const svo_hip_sia_params* prm) {
+// The shape of the fused kernel for a launch of n_launch pairs whose largest frame has max_n patches.
+template <bool EXACT_ROWS>
+int launch_fused_shape(svo_hip_sia* s, int n_launch, int max_n, const svo_hip_sia_params* prm) {
   svo_hip_ctx* ctx = s->ctx;
   int per_simd = 1;
   const int tpw = fused_old_share(s, max_n, &per_simd);
@@ -1705,10 +1726,10 @@ int launch_fused_shape(svo_hip_sia* s, int n_launch, const int* slots_dev, int m
   if (four) {
     const size_t lds4 = (size_t)4 * (per_simd < 2 ? 1 : 2) * FUSED_WC_BYTES;
     switch (per_simd) {                                                // tiles per wave (3 runs as 4 with an empty slot)
-      case 1: return launch_fused_x<4, 1, 1, false>(s, n_launch, slots_dev, prm, lds4, 0);
-      case 2: return launch_fused_x<4, 2, 2, false>(s, n_launch, slots_dev, prm, lds4, 0);
+      case 1: return launch_fused_x<4, 1, 1, EXACT_ROWS>(s, n_launch, prm, lds4, 0);
+      case 2: return launch_fused_x<4, 2, 2, EXACT_ROWS>(s, n_launch, prm, lds4, 0);
       case 3:
-      case 4: return launch_fused_x<4, 4, 2, false>(s, n_launch, slots_dev, prm, lds4, 0);
+      case 4: return launch_fused_x<4, 4, 2, EXACT_ROWS>(s, n_launch, prm, lds4, 0);
       default: break;
     }
   }
@@ -1721,12 +1742,12 @@ int launch_fused_shape(svo_hip_sia* s, int n_launch, const int* slots_dev, int m
   if (n_extra < 0 || n_extra > (tpw > ck ? fused_extra_tiles(tpw, ck) : 0)) n_extra = 0;
   const size_t lds = (size_t)(FUSED_WAVES * ck + n_extra) * FUSED_WC_BYTES;
   switch (tpw) {                 // tiles of an older wave
-    case 1: return launch_fused_x<8, 1, 1, false>(s, n_launch, slots_dev, prm, lds, ty);
-    case 2: return launch_fused_x<8, 2, 2, false>(s, n_launch, slots_dev, prm, lds, ty);
-    case 3: return launch_fused_x<8, 3, 2, false>(s, n_launch, slots_dev, prm, lds, ty, n_extra);
-    case 4: return launch_fused_x<8, 4, 2, false>(s, n_launch, slots_dev, prm, lds, ty, n_extra);
-    case 5: return launch_fused_x<8, 5, 2, false>(s, n_launch, slots_dev, prm, lds, ty, n_extra);
-    case 6: return launch_fused_x<8, 6, 2, false>(s, n_launch, slots_dev, prm, lds, ty, n_extra);
+    case 1: return launch_fused_x<8, 1, 1, EXACT_ROWS>(s, n_launch, prm, lds, ty);
+    case 2: return launch_fused_x<8, 2, 2, EXACT_ROWS>(s, n_launch, prm, lds, ty);
+    case 3: return launch_fused_x<8, 3, 2, EXACT_ROWS>(s, n_launch, prm, lds, ty, n_extra);
+    case 4: return launch_fused_x<8, 4, 2, EXACT_ROWS>(s, n_launch, prm, lds, ty, n_extra);
+    case 5: return launch_fused_x<8, 5, 2, EXACT_ROWS>(s, n_launch, prm, lds, ty, n_extra);
+    case 6: return launch_fused_x<8, 6, 2, EXACT_ROWS>(s, n_launch, prm, lds, ty, n_extra);
     default: break;
   }
   return svo_fail(ctx, SVO_HIP_ERR_INVALID, "fused SparseImgAlign", "unsupported tiles-per-wave");
@@ -1741,11 +1762,14 @@ bool fused_applies(const svo_hip_sia* s, int n_slots) {
   return (max_n + TILE - 1) / TILE <= FUSED_MAX_TILES;
 }
 
-// Frames with a handful of patches (fewer than FUSED_EXACT_ROW_BELOW) need the entry-by-entry Hessian rows (EXACT_ROWS,
-// see sia_fused_kernel); that instance spills hundreds of registers, so it only ever runs for those frames: a batch that
-// holds some is split into two launches on the same stream -- the listed tiny slots with the exact instance, every
-// other slot with the shape its own largest frame asks for.  A frame's result therefore does not depend on whether a
-// tiny frame shares its batch (it still depends on the shape, i.e. on the largest frame and the number of pairs).
+// A batch that holds a frame with a handful of patches (fewer than FUSED_EXACT_ROW_BELOW) is launched with the instance
+// whose workgroups choose the form of their Hessian rows by their own patch count (EXACT_ROWS, see sia_fused_kernel);
+// every other batch with the instance that has no such branch.  (Two alternatives were measured on 256 C1 pairs of which
+// one has 5 or 12 patches -- tools/mixed_batch_bench.py: the whole batch in the all-exact instance of round 2, which spills
+// 469 VGPRs; and a second launch for the tiny slots on a side stream, which overlaps the main launch but runs 3.5 times
+// slower beside it than alone -- 1.58 ms against 0.45 ms, two different kernels evicting each other from the
+// instruction cache their CUs share -- and so made the step 31-37 % longer.  The per-workgroup branch costs a mixed
+// batch 1.4 % in fixed-work mode and 3 % with the reference's exits, and a pure batch nothing.)
 int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) {
   svo_hip_ctx* ctx = s->ctx;
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
@@ -1758,37 +1782,16 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) {
   if (rc != SVO_HIP_OK) return rc;
   s->begun = false;
   s->last_mode = 1;
-  int n_tiny = 0, max_rest = 0;
+  bool tiny = false;
+  int max_n = 0;
   for (int i = 0; i < n_slots; ++i) {
     const int n = s->h_fc[i].n_feat;
-    if (n > 0 && n < FUSED_EXACT_ROW_BELOW) ++n_tiny;
-    else if (n > max_rest) max_rest = n;
+    tiny = tiny || (n > 0 && n < FUSED_EXACT_ROW_BELOW);
+    if (n > max_n) max_n = n;
   }
   hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
-  if (n_tiny == 0) {
-    rc = launch_fused_shape(s, n_slots, nullptr, max_rest, prm);
-  } else {
-    std::vector<int> lists((size_t)2 * s->batch);
-    int n_rest = 0, n_t = 0;
-    for (int i = 0; i < n_slots; ++i) {
-      const int n = s->h_fc[i].n_feat;
-      if (n > 0 && n < FUSED_EXACT_ROW_BELOW) lists[(size_t)s->batch + n_t++] = i; else lists[n_rest++] = i;
-    }
-    // (pageable source: staged by the runtime before the call returns)
-    SVO_CHECK_HIP(ctx, hipMemcpyAsync(s->slot_list, lists.data(), sizeof(int) * lists.size(), hipMemcpyHostToDevice, ctx->stream));
-    // the tiny frames on the context's side stream, so that their launch -- one workgroup each, a third of a full
-    // frame's time in fixed-work mode -- runs beside the main one instead of after it (measured, 256 C1 pairs of which
-    // one has 5 patches: 1.66 ms in sequence against 1.25 ms for the pure batch)
-    rc = svo_ctx_fork(ctx);
-    if (rc == SVO_HIP_OK) {
-      // one tile: wave 0 of an 8-wave workgroup owns it
-      rc = launch_fused_x<8, 1, 1, true>(s, n_t, s->slot_list + s->batch, prm, (size_t)FUSED_WAVES * FUSED_WC_BYTES, 0, 0, ctx->aux_stream);
-      if (rc == SVO_HIP_OK && n_rest > 0) rc = launch_fused_shape(s, n_rest, s->slot_list, max_rest, prm);
-      const int rj = svo_ctx_join(ctx);        // (also after a failed launch: the side stream must not be left forked)
-      if (rc == SVO_HIP_OK) rc = rj;
-    }
-  }
+  rc = tiny ? launch_fused_shape<true>(s, n_slots, max_n, prm) : launch_fused_shape<false>(s, n_slots, max_n, prm);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   return rc;
 }
@@ -1813,6 +1816,23 @@ int svo_sia_prepare_from_device(svo_hip_sia* s, const svo_hip_camera* cam, int n
 
 const svo_dev::FrameState* svo_sia_state_dev(const svo_hip_sia* s) { return s ? s->st : nullptr; }
 
+// slot 0's input arrays, for a caller whose own kernel fills them (the hand-over kernel of svo_track.hip writes the next
+// frame's reference features there directly); svo_sia_note_device_slot0 then tells the host mirror what the device holds
+int svo_sia_slot0_arrays(svo_hip_sia* s, svo_dev::FrameConst** fc, double** px, double** f, double** pos, uint8_t** has_point, int* max_n) {
+  if (!s) return SVO_HIP_ERR_INVALID;
+  *fc = s->fc; *px = s->px; *f = s->f; *pos = s->pos; *has_point = s->has_point; *max_n = s->max_n;
+  return SVO_HIP_OK;
+}
+
+int svo_sia_note_device_slot0(svo_hip_sia* s, const svo_hip_camera* cam, int n_feat_host) {
+  if (!s || !cam) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(s->ctx, n_feat_host >= 0 && n_feat_host <= s->max_n);
+  s->h_fc[0].n_feat = n_feat_host;
+  s->h_fc[0].cam = svo_make_cam(*cam);
+  s->fc_dirty = false;
+  return SVO_HIP_OK;
+}
+
 extern "C" {
 
 int svo_hip_sia_create(svo_hip_ctx* ctx, int batch, int max_features, svo_hip_sia** out) {
@@ -1836,7 +1856,6 @@ int svo_hip_sia_create(svo_hip_ctx* ctx, int batch, int max_features, svo_hip_si
   A(dev_alloc(ctx, &s->partial, (size_t)batch * MAX_CHUNKS * RED));
   A(dev_alloc(ctx, &s->reduce_own, (size_t)batch * RED));
   A(dev_alloc(ctx, &s->n_pre_count, batch));
-  A(dev_alloc(ctx, &s->slot_list, (size_t)2 * batch));
   s->h_fc = new (std::nothrow) FrameConst[batch];
   if (rc != SVO_HIP_OK || !s->h_fc) { svo_hip_sia_destroy(s); return rc != SVO_HIP_OK ? rc : SVO_HIP_ERR_NOMEM; }
   memset(s->h_fc, 0, sizeof(FrameConst) * batch);
@@ -1858,7 +1877,7 @@ int svo_hip_sia_destroy(svo_hip_sia* s) {
   (void)hipStreamSynchronize(ctx->stream);
   drop_level_graphs(s);
   void* ptrs[] = {s->fc, s->st, s->px, s->f, s->pos, s->has_point, s->visible, s->ref_cache, s->dxc, s->dyc,
-                  s->sxyz, s->xyz4, s->tile_h, s->wmem, s->partial, s->reduce_own, s->n_pre_count, s->slot_list};
+                  s->sxyz, s->xyz4, s->tile_h, s->wmem, s->partial, s->reduce_own, s->n_pre_count};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev_res) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_pre) (void)hipEventDestroy(e);

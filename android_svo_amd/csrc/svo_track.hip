@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "svo_internal.h"
+#include "svo_match_device.h"
 
 using namespace svo_dev;
 
@@ -81,14 +82,7 @@ struct TrkPlan {
   int* overlap_count;            // [TRK_MAX_SEL]
   int* cand_point;               // [cap]
   int* cand_obs;                 // [cap] (-1: Point::getCloseViewObs failed)
-  int* cand_kf_slot;             // [cap] pyramid slot of the reference feature, -1 = do not match
-  double* cand_px_ref;           // [cap][2]
-  double* cand_f_ref;            // [cap][3]
-  int* cand_level_ref;           // [cap]
-  double* cand_pt_pos;           // [cap][3]
-  uint8_t* cand_edgelet;         // [cap]
-  double* cand_grad;             // [cap][2]
-  double* cand_px_cur;           // [cap][2] in: the projection, out: the refined pixel
+  int* cand_level_ref;           // [cap] pyramid level of the reference feature (read by the warp stage)
   uint8_t* cand_deleted;         // [cap]
 };
 
@@ -112,6 +106,11 @@ struct TrkLast {
   double* px;        // [cap][2]
   double* f;         // [cap][3]
   int* point;        // [cap]
+  // slot 0 of the SparseImgAlign solver: the hand-over kernel writes the next solve's inputs there directly
+  FrameConst* sia_fc;
+  double *sia_px, *sia_f, *sia_pos;
+  uint8_t* sia_has_point;
+  int sia_max_n;
 };
 
 // Frame::isVisible (S/frame.cpp:162-172)
@@ -172,7 +171,9 @@ SVO_DEV void block_exclusive_scan(int* v, int n, int* s_part) {
 
 // ---- Reprojector::reprojectMap up to the cell loop (S/reprojector.cpp:72-146) + the per-candidate choice of the reference
 // feature (Point::getCloseViewObs, the first statement of Matcher::findMatchDirect).  One workgroup.
-__global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan pl, Cam cam, const FrameState* __restrict__ sia_state) {
+__global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan pl, MdFrame mf, const double* __restrict__ T_slot_w,
+                                                               SeedRec* __restrict__ recs, const FrameState* __restrict__ sia_state) {
+  const Cam cam = mf.cam;
   __shared__ int s_part[TRK_THREADS];
   __shared__ int s_sel[TRK_MAX_SEL], s_seq_base[TRK_MAX_SEL + 1];
   __shared__ int s_n_close, s_n_sel, s_n_kept, s_overflow, s_changed;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan
   __syncthreads();
   double T[7];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) T[k] = s_T[k];
+  for (int k = 0; k < 7; ++k) { T[k] = s_T[k]; mf.T_cur_w[k] = s_T[k]; }
   if (t == 0) {
     double Tinv[7];
     se3_inverse(T, Tinv);                                                  // cur_frame.pos()
@@ -301,22 +302,19 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan
     pl.cand_point[o] = p;
     pl.cand_obs[o] = view_ok ? obs : -1;
     pl.cand_deleted[o] = deleted ? 1 : 0;
-    pl.cand_px_cur[2 * o] = pl.item_px[2 * i]; pl.cand_px_cur[2 * o + 1] = pl.item_px[2 * i + 1];
-    pl.cand_pt_pos[3 * o] = m.pt_pos[3 * (size_t)p]; pl.cand_pt_pos[3 * o + 1] = m.pt_pos[3 * (size_t)p + 1]; pl.cand_pt_pos[3 * o + 2] = m.pt_pos[3 * (size_t)p + 2];
+    // the matcher's record of the candidate (Matcher::findMatchDirect up to the warp, svo_match_device.h): formed here,
+    // read by the warp / alignment stages and by the replay
+    const double pxc[2] = {pl.item_px[2 * i], pl.item_px[2 * i + 1]};
     if (view_ok) {
-      pl.cand_kf_slot[o] = m.kf_slot[m.obs_kf[obs]];
-      pl.cand_px_ref[2 * o] = m.obs_px[2 * (size_t)obs]; pl.cand_px_ref[2 * o + 1] = m.obs_px[2 * (size_t)obs + 1];
-      pl.cand_f_ref[3 * o] = m.obs_f[3 * (size_t)obs]; pl.cand_f_ref[3 * o + 1] = m.obs_f[3 * (size_t)obs + 1]; pl.cand_f_ref[3 * o + 2] = m.obs_f[3 * (size_t)obs + 2];
       pl.cand_level_ref[o] = m.obs_level[obs];
-      pl.cand_edgelet[o] = m.obs_edgelet[obs];
-      pl.cand_grad[2 * o] = m.obs_grad[2 * (size_t)obs]; pl.cand_grad[2 * o + 1] = m.obs_grad[2 * (size_t)obs + 1];
+      recs[o] = md_geometry_item(mf, T_slot_w, m.kf_slot[m.obs_kf[obs]], m.obs_level[obs], m.obs_px + 2 * (size_t)obs, m.obs_f + 3 * (size_t)obs,
+                                 m.pt_pos + 3 * (size_t)p, m.obs_edgelet[obs] != 0, m.obs_grad + 2 * (size_t)obs, pxc);
     } else {
-      pl.cand_kf_slot[o] = -1;                                             // rejected by the matcher's range test: no work, no success
-      pl.cand_px_ref[2 * o] = pl.cand_px_ref[2 * o + 1] = 0.0;
-      pl.cand_f_ref[3 * o] = pl.cand_f_ref[3 * o + 1] = 0.0; pl.cand_f_ref[3 * o + 2] = 1.0;
+      // a deleted point is erased from its cell (:190-194), a point without a close view fails the match at once (matcher.cpp:161-162)
       pl.cand_level_ref[o] = 0;
-      pl.cand_edgelet[o] = 0;
-      pl.cand_grad[2 * o] = 1.0; pl.cand_grad[2 * o + 1] = 0.0;
+      SeedRec rc = md_dead_record();
+      rc.uv0[0] = pxc[0]; rc.uv0[1] = pxc[1];
+      recs[o] = rc;
     }
   }
   if (t == 0) {
@@ -332,9 +330,8 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan
 // the batch results: per cell the first successful candidate wins, the loop stops after the cell that takes n_matches
 // beyond max_fts; point bookkeeping (:202-215), the frame's new features (:217-231) and the inputs of the pose refinement.
 __global__ __launch_bounds__(TRK_THREADS) void trk_replay_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, Cam cam, const FrameState* __restrict__ sia_state,
-                                                                 const uint8_t* __restrict__ success, const int* __restrict__ search_level,
-                                                                 int* __restrict__ cell_winner, int* __restrict__ cell_cum, int max_fts,
-                                                                 int quality_min_fts) {
+                                                                 const SeedRec* __restrict__ recs, int* __restrict__ cell_winner,
+                                                                 int* __restrict__ cell_cum, int max_fts, int quality_min_fts) {
   __shared__ int s_part[TRK_THREADS];
   __shared__ int s_cut, s_changed;
   __shared__ unsigned long long s_trials;
@@ -345,7 +342,7 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_replay_kernel(TrkMap m, TrkPl
   for (int c = t; c < n_cells; c += nt) {
     int w = -1;
     for (int i = pl.cell_offset[c]; i < pl.cell_offset[c + 1] && w < 0; ++i)
-      if (!pl.cand_deleted[i] && success[i]) w = i;
+      if (!pl.cand_deleted[i] && recs[i].path >= 0 && recs[i].matched) w = i;      // findMatchDirect returned true
     cell_winner[c] = w;
     cell_cum[c] = w >= 0 ? 1 : 0;
   }
@@ -380,27 +377,30 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_replay_kernel(TrkMap m, TrkPl
       if (m.pt_type[p] == TYPE_UNKNOWN && ns > 10) m.pt_type[p] = TYPE_GOOD;
       const int fi = cell_cum[c];                                           // creation order = cell order
       if (fi < ft.cap) {
-        const double u = pl.cand_px_cur[2 * i], v = pl.cand_px_cur[2 * i + 1];
+        const SeedRec& rc = recs[i];
+        const double u = rc.step[0], v = rc.step[1];                        // px_cur = px_scaled * (1 << search_level_) (matcher.cpp:200)
+        const double* pp = m.pt_pos + 3 * (size_t)p;
         ft.px[2 * fi] = u; ft.px[2 * fi + 1] = v;
         double fv[3];
         cam2world(cam, u, v, fv);                                           // Feature(frame, px, level): f = cam2world(px) (I/feature.h:43-51)
         ft.f[3 * fi] = fv[0]; ft.f[3 * fi + 1] = fv[1]; ft.f[3 * fi + 2] = fv[2];
-        ft.pos[3 * fi] = pl.cand_pt_pos[3 * i]; ft.pos[3 * fi + 1] = pl.cand_pt_pos[3 * i + 1]; ft.pos[3 * fi + 2] = pl.cand_pt_pos[3 * i + 2];
-        ft.level[fi] = search_level[i];
+        ft.pos[3 * fi] = pp[0]; ft.pos[3 * fi + 1] = pp[1]; ft.pos[3 * fi + 2] = pp[2];
+        ft.level[fi] = rc.search_level;
         ft.point[fi] = p;
         ft.has_point[fi] = 1;
         double g0 = 1.0, g1 = 0.0;
-        const bool edge = pl.cand_edgelet[i] != 0;
+        const int obs = pl.cand_obs[i];
+        const bool edge = m.obs_edgelet[obs] != 0;
         if (edge) {                                                         // grad = (A_cur_ref_ * ref_ftr_->grad).normalized() (:224-229)
-          const int obs = pl.cand_obs[i];
           const double* Tr = m.T_kf_w + 7 * (size_t)m.obs_kf[obs];
           double T_ref_inv[7], T_cur_ref[7], A[4];
           se3_inverse(Tr, T_ref_inv);
           se3_mul(T, T_ref_inv, T_cur_ref);
-          const double dx = T_ref_inv[0] - pl.cand_pt_pos[3 * i], dy = T_ref_inv[1] - pl.cand_pt_pos[3 * i + 1], dz = T_ref_inv[2] - pl.cand_pt_pos[3 * i + 2];
-          get_warp_matrix_affine(cam, pl.cand_px_ref + 2 * i, pl.cand_f_ref + 3 * i, sqrt(dx * dx + dy * dy + dz * dz), T_cur_ref, pl.cand_level_ref[i], A);
-          g0 = A[0] * pl.cand_grad[2 * i] + A[1] * pl.cand_grad[2 * i + 1];
-          g1 = A[2] * pl.cand_grad[2 * i] + A[3] * pl.cand_grad[2 * i + 1];
+          const double dx = T_ref_inv[0] - pp[0], dy = T_ref_inv[1] - pp[1], dz = T_ref_inv[2] - pp[2];
+          get_warp_matrix_affine(cam, m.obs_px + 2 * (size_t)obs, m.obs_f + 3 * (size_t)obs, sqrt(dx * dx + dy * dy + dz * dz), T_cur_ref, m.obs_level[obs], A);
+          const double gr0 = m.obs_grad[2 * (size_t)obs], gr1 = m.obs_grad[2 * (size_t)obs + 1];
+          g0 = A[0] * gr0 + A[1] * gr1;
+          g1 = A[2] * gr0 + A[3] * gr1;
           const double n2 = g0 * g0 + g1 * g1;
           if (n2 > 0.0) { const double nn = sqrt(n2); g0 = g0 / nn; g1 = g1 / nn; }
         }
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_replay_kernel(TrkMap m, TrkPl
 }
 
 // ---- last_frame_ = new_frame_ (frame_handler_mono.cpp:91) and the result block.  One workgroup.
-__global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, TrkLast last, const FrameState* __restrict__ sia_state,
+__global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, TrkLast last, Cam cam, const FrameState* __restrict__ sia_state,
                                                          const svo_hip_pose_opt_result* __restrict__ po, svo_hip_track_result* __restrict__ res,
                                                          double* __restrict__ out_px, double* __restrict__ out_f, int* __restrict__ out_level,
                                                          int* __restrict__ out_point, uint8_t* __restrict__ out_edgelet, double* __restrict__ out_grad,
@@ -469,6 +469,12 @@ __global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, T
     last.px[2 * i] = ft.px[2 * i]; last.px[2 * i + 1] = ft.px[2 * i + 1];
     last.f[3 * i] = ft.f[3 * i]; last.f[3 * i + 1] = ft.f[3 * i + 1]; last.f[3 * i + 2] = ft.f[3 * i + 2];
     last.point[i] = p;
+    if (i < last.sia_max_n) {          // the next SparseImgAlign::run walks this frame's features (sparse_img_align.cpp:116-118)
+      last.sia_px[2 * i] = ft.px[2 * i]; last.sia_px[2 * i + 1] = ft.px[2 * i + 1];
+      last.sia_f[3 * i] = ft.f[3 * i]; last.sia_f[3 * i + 1] = ft.f[3 * i + 1]; last.sia_f[3 * i + 2] = ft.f[3 * i + 2];
+      last.sia_pos[3 * i] = ft.pos[3 * i]; last.sia_pos[3 * i + 1] = ft.pos[3 * i + 1]; last.sia_pos[3 * i + 2] = ft.pos[3 * i + 2];
+      last.sia_has_point[i] = p >= 0 ? 1 : 0;
+    }
   }
   for (int p = t; p < m.n_points; p += nt) {
     out_pt_type[p] = m.pt_type[p]; out_pt_failed[p] = m.pt_n_failed[p]; out_pt_succeeded[p] = m.pt_n_succeeded[p];
@@ -476,7 +482,14 @@ __global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, T
   __syncthreads();
   if (t == 0) {
     *last.n = n_feat;
-    for (int i = 0; i < 7; ++i) last.T_f_w[i] = res->T_f_w[i];
+    FrameConst c;
+    c.cam = cam;
+    for (int i = 0; i < 7; ++i) { const double v = res->T_f_w[i]; last.T_f_w[i] = v; c.T_ref_w[i] = v; c.T_cur_w_init[i] = v; }   // :175
+    double Tinv[7];
+    se3_inverse(c.T_ref_w, Tinv);                                            // Frame::pos()
+    c.ref_pos[0] = Tinv[0]; c.ref_pos[1] = Tinv[1]; c.ref_pos[2] = Tinv[2];
+    c.n_feat = n_feat < last.sia_max_n ? n_feat : last.sia_max_n; c.pad = 0;
+    last.sia_fc[0] = c;
   }
 }
 
@@ -511,8 +524,9 @@ struct svo_hip_tracker {
   TrkPlan pl{};
   TrkFeat ft{};
   TrkLast last{};
-  uint8_t* success = nullptr;
-  int *search_level = nullptr, *cell_winner = nullptr, *cell_cum = nullptr, *n_po_dev = nullptr;
+  int *cell_winner = nullptr, *cell_cum = nullptr;
+  bool need_gather = true;                  // the solver's slot 0 does not hold the last frame yet (a host upload came in between)
+  bool any_edgelet = false;                 // the map holds EDGELET reference features (align1D stage needed)
   svo_hip_pose_opt_result* po = nullptr;
   // result block: [svo_hip_track_result][px][f][level][point][edgelet][grad][pt_type][pt_failed][pt_succeeded]
   char* res_dev = nullptr;
@@ -606,9 +620,8 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
   pl.cap = cfg->max_items; pl.n_cells = t->n_cells; pl.grid_cols = t->grid_cols; pl.grid_size = cfg->grid_size; pl.max_n_kfs = cfg->reproj_max_n_kfs;
   D(&pl.kf_close, K); D(&pl.kf_dist, K); D(&pl.first_seq, P); D(&pl.item_point, C); D(&pl.item_px, C * 2); D(&pl.item_cell, C); D(&pl.item_key, C);
   D(&pl.seg, C); D(&pl.cell_count, NC + 1); D(&pl.cell_fill, NC); D(&pl.counters, 8); D(&pl.cell_offset, NC + 1); D(&pl.overlap_kf, TRK_MAX_SEL);
-  D(&pl.overlap_count, TRK_MAX_SEL); D(&pl.cand_point, C); D(&pl.cand_obs, C); D(&pl.cand_kf_slot, C); D(&pl.cand_px_ref, C * 2); D(&pl.cand_f_ref, C * 3);
-  D(&pl.cand_level_ref, C); D(&pl.cand_pt_pos, C * 3); D(&pl.cand_edgelet, C); D(&pl.cand_grad, C * 2); D(&pl.cand_px_cur, C * 2); D(&pl.cand_deleted, C);
-  D(&t->success, C); D(&t->search_level, C); D(&t->cell_winner, NC + 1); D(&t->cell_cum, NC + 1); D(&t->po, 1);
+  D(&pl.overlap_count, TRK_MAX_SEL); D(&pl.cand_point, C); D(&pl.cand_obs, C); D(&pl.cand_level_ref, C); D(&pl.cand_deleted, C);
+  D(&t->cell_winner, NC + 1); D(&t->cell_cum, NC + 1); D(&t->po, 1);
   const size_t NF = cfg->max_frame_features;
   TrkFeat& ft = t->ft;
   ft.cap = cfg->max_frame_features;
@@ -625,6 +638,7 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
   if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->map_host, t->map_host_bytes, hipHostMallocDefault) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
   if (rc != SVO_HIP_OK) { svo_hip_tracker_destroy(t); return rc; }
   (void)hipMemsetAsync(t->last.n, 0, sizeof(int), ctx->stream);
+  svo_sia_slot0_arrays(t->sia, &t->last.sia_fc, &t->last.sia_px, &t->last.sia_f, &t->last.sia_pos, &t->last.sia_has_point, &t->last.sia_max_n);
   *out = t;
   return SVO_HIP_OK;
 }
@@ -717,7 +731,10 @@ int svo_hip_tracker_set_map(svo_hip_tracker* t, const svo_hip_tracker_map* mp) {
   if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_tracker_set_map", hipGetErrorString(e));
   if (off > t->map_host_bytes) return svo_fail(ctx, SVO_HIP_ERR_NOMEM, "svo_hip_tracker_set_map", "staging area too small");
   t->n_kf = mp->n_kf; t->n_points = mp->n_points; t->n_candidates = mp->n_candidates;
+  t->any_edgelet = false;
+  if (mp->obs_edgelet) for (int o = 0; o < n_obs && !t->any_edgelet; ++o) t->any_edgelet = mp->obs_edgelet[o] != 0;
   t->have_map = true; t->map_stale = false;
+  t->need_gather = true;                    // point positions may have changed
   return SVO_HIP_OK;
 }
 
@@ -730,6 +747,7 @@ int svo_hip_tracker_update_point_positions(svo_hip_tracker* t, int n, const int3
     SVO_REQUIRE(ctx, point[i] >= 0 && point[i] < t->n_points);
     SVO_CHECK_HIP(ctx, hipMemcpyAsync(t->pt_pos + 3 * (size_t)point[i], pos + 3 * (size_t)i, 24, hipMemcpyHostToDevice, ctx->stream));
   }
+  t->need_gather = true;
   return SVO_HIP_OK;
 }
 
@@ -754,6 +772,7 @@ int svo_hip_tracker_set_last_frame(svo_hip_tracker* t, const uint8_t* level0, in
   }
   t->last_n_host = n;
   t->have_last = true;
+  t->need_gather = true;
   return SVO_HIP_OK;
 }
 
@@ -779,7 +798,10 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   // ---- SparseImgAlign(kltMaxLevel, kltMinLevel, 30, GaussNewton, false, false).run(last_frame_, new_frame_)
   rc = svo_hip_sia_set_frames(t->sia, ref, cur);
   if (rc != SVO_HIP_OK) return rc;
-  rc = svo_sia_prepare_from_device(t->sia, &t->cam, t->last_n_host, t->last.n, t->last.T_f_w, t->last.px, t->last.f, t->last.point, t->pt_pos);
+  // the previous call's hand-over kernel has written the solver's inputs already, unless the host changed the last frame,
+  // the map or point positions since
+  if (t->need_gather) rc = svo_sia_prepare_from_device(t->sia, &t->cam, t->last_n_host, t->last.n, t->last.T_f_w, t->last.px, t->last.f, t->last.point, t->pt_pos);
+  else rc = svo_sia_note_device_slot0(t->sia, &t->cam, t->last_n_host);
   if (rc != SVO_HIP_OK) return rc;
   svo_hip_sia_params sp;
   sp.max_level = c.klt_max_level; sp.min_level = c.klt_min_level; sp.n_iter = c.sia_n_iter; sp.eps = c.sia_eps; sp.early_stop = 1;
@@ -789,14 +811,22 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   // ---- Reprojector::reprojectMap
   const TrkMap m = make_map(t);
   const Cam cam = svo_make_cam(t->cam);
-  hipLaunchKernelGGL(trk_plan_kernel, dim3(1), dim3(TRK_THREADS), 0, ctx->stream, m, t->pl, cam, st);
-  SVO_CHECK_HIP(ctx, hipGetLastError());
-  rc = svo_match_direct_internal(ctx, t->kf_pyr, cur, 0, &t->cam, c.max_keyframes, t->T_slot_w, nullptr, st->T_cur_w, t->pl.cap, t->pl.counters,
-                                 t->pl.cand_kf_slot, t->pl.cand_px_ref, t->pl.cand_f_ref, t->pl.cand_level_ref, t->pl.cand_pt_pos, t->pl.cand_edgelet,
-                                 t->pl.cand_grad, c.n_pyr_levels, c.align_max_iter, t->pl.cand_px_cur, t->success, t->search_level);
+  SeedRec* recs = nullptr;
+  uint32_t* pwb_t = nullptr;
+  int n_pad = 0;
+  rc = svo_match_scratch(ctx, t->pl.cap, &recs, &pwb_t, &n_pad);
   if (rc != SVO_HIP_OK) return rc;
-  hipLaunchKernelGGL(trk_replay_kernel, dim3(1), dim3(TRK_THREADS), 0, ctx->stream, m, t->pl, t->ft, cam, st, t->success, t->search_level,
-                     t->cell_winner, t->cell_cum, c.max_fts, c.quality_min_fts);
+  MdFrame mf;
+  memset(&mf, 0, sizeof(mf));
+  mf.cam = cam; mf.n_pyr_levels = c.n_pyr_levels; mf.n_kf = c.max_keyframes; mf.n_ref_levels = c.n_levels;
+  hipLaunchKernelGGL(trk_plan_kernel, dim3(1), dim3(TRK_THREADS), 0, ctx->stream, m, t->pl, mf, t->T_slot_w, recs, st);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  // warp + align2D (+ align1D when the map holds edgelets) over the candidates
+  rc = svo_match_stages(ctx, t->kf_pyr, cur, 0, &t->cam, t->pl.cap, t->pl.counters, t->pl.cand_level_ref, recs, pwb_t, n_pad, c.n_pyr_levels,
+                        c.align_max_iter, t->any_edgelet);
+  if (rc != SVO_HIP_OK) return rc;
+  hipLaunchKernelGGL(trk_replay_kernel, dim3(1), dim3(TRK_THREADS), 0, ctx->stream, m, t->pl, t->ft, cam, st, recs, t->cell_winner, t->cell_cum,
+                     c.max_fts, c.quality_min_fts);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   // ---- pose_optimizer::optimizeGaussNewton(poseOptimThresh, poseOptimNumIter, ...) on the matched features, from the aligned pose
   rc = svo_hip_pose_optimize_batch_dev(ctx, 1, c.max_frame_features, t->pl.counters + 5, st->T_cur_w, t->ft.f, t->ft.pos, t->ft.level, t->ft.has_point,
@@ -804,7 +834,7 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   if (rc != SVO_HIP_OK) return rc;
   // ---- hand-over + result
   char* rd = t->res_dev;
-  hipLaunchKernelGGL(trk_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, m, t->pl, t->ft, t->last, st, t->po,
+  hipLaunchKernelGGL(trk_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, m, t->pl, t->ft, t->last, cam, st, t->po,
                      reinterpret_cast<svo_hip_track_result*>(rd), reinterpret_cast<double*>(rd + t->o_px), reinterpret_cast<double*>(rd + t->o_f),
                      reinterpret_cast<int*>(rd + t->o_level), reinterpret_cast<int*>(rd + t->o_point), reinterpret_cast<uint8_t*>(rd + t->o_edge),
                      reinterpret_cast<double*>(rd + t->o_grad), reinterpret_cast<int*>(rd + t->o_pt), reinterpret_cast<int*>(rd + t->o_pt) + t->n_points,
@@ -828,6 +858,7 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   if (pt_n_succeeded) memcpy(pt_n_succeeded, rh + t->o_pt + 2 * np4, np4);
   t->last_idx = 1 - t->last_idx;            // the new frame's pyramid is the next call's reference
   t->last_n_host = result->n_features;
+  t->need_gather = false;
   if (result->map_changed) t->map_stale = true;
   return SVO_HIP_OK;
 }

@@ -215,9 +215,10 @@ int svo_hip_sia_set_option(svo_hip_sia* sia, int option, int value);
  * when every frame has at most 2816 features and no patch shard is set; launches with at least two frame pairs
  * per compute unit and at most 1024 features per frame use its 4-wave shape, two pairs per compute unit),
  * 0 = the streaming kernels (one launch per Gauss-Newton evaluation; always used by the step-wise entry
- * points).  svo_hip_sia_set_option(SVO_HIP_SIA_OPT_MODE, SVO_HIP_SIA_MODE_STREAM) forces 0.  A batch that holds
- * frames with fewer than 16 patches runs as two launches (those frames with the entry-by-entry Hessian rows a
- * rank-deficient system needs, the others as if the tiny frames were not there). */
+ * points).  svo_hip_sia_set_option(SVO_HIP_SIA_OPT_MODE, SVO_HIP_SIA_MODE_STREAM) forces 0.  In a batch that holds
+ * frames with fewer than 16 patches those frames take the entry-by-entry Hessian rows a rank-deficient system needs
+ * (chosen per workgroup); the other frames' results are bit for bit what they are without such company.  A frame's
+ * result does depend on the kernel shape, i.e. on the largest frame of the batch and on the number of pairs. */
 int svo_hip_sia_last_run_mode(svo_hip_sia* sia, int* mode);
 /* Optional timing of the two heavy kernels with HIP events recorded on the context stream around
  * each launch (precompute: one per level; residual: one per Gauss-Newton evaluation; in fused mode the single

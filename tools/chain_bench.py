@@ -85,11 +85,48 @@ class ResidentStages:
         self.h.destroy()
 
 
+def tracker_leg(ctx, seq, min_level, repeats=3):
+    """The same frames through svo_hip_tracker_track: the whole chain of a frame enqueued on one stream with the aligned
+    pose, the candidates and the matches staying on the device, level 0 of the new image from page-locked staging, one
+    synchronisation per frame.  Timed around the C call (the wall time a C++ caller sees)."""
+    import ctypes as C
+    mp = tc.sequence_map(seq)
+    n = len(seq["px0"])
+    trk = hip.Tracker(ctx, seq["cam"], max_keyframes=2, max_points=1024, max_obs=1024, max_kf_features=1024, max_candidates=16, max_items=1024,
+                      max_frame_features=1024, grid_size=tc.CELL, max_fts=tc.MAX_FTS, klt_min_level=min_level)
+    trk.upload_keyframe(0, seq["pyrs"][0][0])
+    imgs = [np.ascontiguousarray(p[0]) for p in seq["pyrs"]]
+    res = hip.CTrackResult()
+    times = []
+    for rep in range(repeats + 1):
+        trk.set_map(mp)                                             # fresh point counters: every pass tracks the same sequence
+        trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)
+        ctx.sync()
+        for k in range(1, len(imgs)):
+            t0 = time.perf_counter()
+            rc = ctx.lib.svo_hip_tracker_track(trk.h, imgs[k].ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(res), None, None, None, None, None,
+                                               None, None, None, None)
+            dt = time.perf_counter() - t0
+            ctx.check(rc, "tracker_track")
+            assert res.n_matches >= 50 and res.map_changed == 0
+            if rep > 0:
+                times.append(dt)
+    trk.destroy()
+    t = np.array(times) * 1e3
+    return {"frames": len(t), "ms_per_frame_total": float(t.mean()), "ms_per_frame_median": float(np.median(t)), "ms_per_frame_min": float(t.min()),
+            "what": "svo_hip_tracker_track: image upload + pyramid + SparseImgAlign + reprojectMap + pose refinement + hand-over + result download, one sync"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--min-level", type=int, default=2)     # the shipping default: L4 -> L2
+    ap.add_argument("--tracker-only", action="store_true")
     args = ap.parse_args()
+    if args.tracker_only:
+        seq = tc.make_sequence(n_frames=args.frames)
+        print(json.dumps({"hip_tracker": tracker_leg(hip.Context(0), seq, args.min_level)}))
+        return
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_gpu_sequence import HipStages
 
@@ -109,7 +146,9 @@ def main():
                      "ms_per_frame_total": 1e3 * sum(st.t.values()) / n}
         if hasattr(inner, "destroy"):
             inner.destroy()
+    out["hip_tracker"] = tracker_leg(ctx, seq, args.min_level)
     out["speedup"] = out["cpu_oracle_1_thread"]["ms_per_frame_total"] / out["hip_resident"]["ms_per_frame_total"]
+    out["speedup_tracker"] = out["cpu_oracle_1_thread"]["ms_per_frame_total"] / out["hip_tracker"]["ms_per_frame_total"]
     print(json.dumps(out))
 
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""A 256-pair C1 batch (2000 patches each, fixed work) against the same batch with ONE frame replaced by a 5-patch frame:
-svo_hip_sia_run launches the entry-by-entry Hessian-row instance for that slot only (run_fused in svo_sia.hip), so the
-mixed batch must run within a few per cent of the pure one.  Diagnostic; prints one JSON line."""
+"""A 256-pair C1 batch (2000 patches each) against the same batch with ONE frame replaced by a frame of 12 or 5 patches:
+svo_hip_sia_run launches the instance whose workgroups pick the entry-by-entry Hessian rows by their own patch count
+(run_fused in svo_sia.hip), so the mixed batch must run within a few per cent of the pure one.  Diagnostic; prints one
+JSON line."""
 import json
 import os
 import sys
@@ -26,7 +27,7 @@ def main():
         fp = fps[s % len(fps)]
         ref.upload(s, fp.ref_pyr); cur.upload(s, fp.cur_pyr); sia.upload_pair(s, fp)
     out = {"what": "256 x C1 frame pairs (2000 patches); slot 100 replaced by a frame with few patches: svo_hip_sia_run launches the "
-                   "entry-by-entry Hessian-row instance for that slot only, on the context's side stream"}
+                   "instance whose workgroups choose the entry-by-entry Hessian rows by their own patch count"}
 
     def timed(prm):
         for _ in range(3):
