@@ -43,16 +43,27 @@ __global__ void half_sample_kernel(const uint8_t* __restrict__ in, int w, int h,
 // 32x8 -> 16x4 -> 8x2 -> 4x1, every level with the same truncating 2x2 mean of the level before (vk::halfSample scalar /
 // NEON form), so the bytes are those of the level-by-level build.  Needs width % 64 == 0, height % 16 == 0 and at most
 // five levels; other shapes take the per-level kernels.
+// src0 != null: level 0 is read from there (page-locked host memory mapped into the device: the image crosses the link
+// inside this kernel, 16 bytes per lane, and is written to the pyramid's level 0 on the way -- no separate copy, no
+// dependent launch behind it) instead of from the pyramid.
 __global__ __launch_bounds__(256) void pyramid_tile_kernel(uint8_t* __restrict__ base, int w, int h, int n_levels, size_t o1, size_t o2,
-                                                           size_t o3, size_t o4, size_t slot_stride) {
+                                                           size_t o3, size_t o4, size_t slot_stride, const uint8_t* __restrict__ src0) {
+  __shared__ __attribute__((aligned(16))) uint8_t l0[16][64];
   __shared__ uint8_t l1[8][32], l2[4][16], l3[2][8];
   base += (size_t)blockIdx.z * slot_stride;
   const int t = threadIdx.x;
   const int tx = blockIdx.x, ty = blockIdx.y;
+  if (t < 64) {                                             // the 64 x 16 tile of level 0: 16 bytes per thread
+    const int r = t >> 2, c16 = (t & 3) * 16;
+    const size_t off = (size_t)(16 * ty + r) * w + 64 * tx + c16;
+    const uint4 v = *reinterpret_cast<const uint4*>((src0 ? src0 : base) + off);
+    *reinterpret_cast<uint4*>(&l0[r][c16]) = v;
+    if (src0) *reinterpret_cast<uint4*>(base + off) = v;
+  }
+  __syncthreads();
   {
     const int x = t & 31, y = t >> 5;                       // one level-1 pixel per thread
-    const uint8_t* p = base + (size_t)(16 * ty + 2 * y) * w + 64 * tx + 2 * x;
-    const unsigned a = *reinterpret_cast<const unsigned short*>(p), b = *reinterpret_cast<const unsigned short*>(p + w);
+    const unsigned a = *reinterpret_cast<const unsigned short*>(&l0[2 * y][2 * x]), b = *reinterpret_cast<const unsigned short*>(&l0[2 * y + 1][2 * x]);
     const uint8_t v = (uint8_t)(((a & 0xff) + (a >> 8) + (b & 0xff) + (b >> 8)) >> 2);
     l1[y][x] = v;
     base[o1 + (size_t)(8 * ty + y) * (w >> 1) + 32 * tx + x] = v;
@@ -84,15 +95,21 @@ __global__ __launch_bounds__(256) void pyramid_tile_kernel(uint8_t* __restrict__
 }  // namespace
 
 // levels 1.. of n_slots pyramids starting at first_slot, from their level 0 (already in place), on the context stream
-int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots) {
+// (level0_mapped: device address of a page-locked host image to take level 0 from -- one slot only; null: level 0 is in place)
+int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* level0_mapped) {
   svo_hip_ctx* ctx = pyr->ctx;
   uint8_t* base = pyr->base + (size_t)first_slot * pyr->pyr_bytes;
+  const bool tiled = pyr->width % 64 == 0 && pyr->height % 16 == 0 && pyr->n_levels <= 5 && pyr->n_levels >= 2 && (pyr->pyr_bytes % 16) == 0;
+  if (level0_mapped && !tiled) {       // shapes the tile kernel does not take: an ordinary copy first
+    SVO_CHECK_HIP(ctx, hipMemcpyAsync(base, level0_mapped, (size_t)pyr->width * pyr->height, hipMemcpyDefault, ctx->stream));
+    level0_mapped = nullptr;
+  }
   if (pyr->n_levels < 2) return SVO_HIP_OK;
-  if (pyr->width % 64 == 0 && pyr->height % 16 == 0 && pyr->n_levels <= 5) {
+  if (tiled) {
     const size_t o1 = pyr->level_offset[1], o2 = pyr->n_levels > 2 ? pyr->level_offset[2] : 0, o3 = pyr->n_levels > 3 ? pyr->level_offset[3] : 0,
                  o4 = pyr->n_levels > 4 ? pyr->level_offset[4] : 0;
     hipLaunchKernelGGL(pyramid_tile_kernel, dim3(pyr->width / 64, pyr->height / 16, n_slots), dim3(256), 0, ctx->stream, base, pyr->width, pyr->height,
-                       pyr->n_levels, o1, o2, o3, o4, pyr->pyr_bytes);
+                       pyr->n_levels, o1, o2, o3, o4, pyr->pyr_bytes, level0_mapped);
     SVO_CHECK_HIP(ctx, hipGetLastError());
     return SVO_HIP_OK;
   }
@@ -294,7 +311,7 @@ int svo_hip_pyramid_upload_level0_and_build(svo_hip_pyramid* pyr, int slot, cons
   SVO_REQUIRE(ctx, slot >= 0 && slot < pyr->batch);
   uint8_t* base = pyr->base + (size_t)slot * pyr->pyr_bytes;
   SVO_CHECK_HIP(ctx, hipMemcpyAsync(base, level0, (size_t)pyr->width * pyr->height, hipMemcpyHostToDevice, ctx->stream));
-  return svo_pyramid_build_levels(pyr, slot, 1);
+  return svo_pyramid_build_levels(pyr, slot, 1, nullptr);
 }
 
 int svo_hip_pyramid_upload_level0_batch_and_build(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* level0_packed) {
@@ -305,7 +322,7 @@ int svo_hip_pyramid_upload_level0_batch_and_build(svo_hip_pyramid* pyr, int firs
   const size_t l0 = (size_t)pyr->width * pyr->height;
   // n_slots level-0 images, back to back on the host, into their slots (one strided transfer)
   SVO_CHECK_HIP(ctx, hipMemcpy2DAsync(base, pyr->pyr_bytes, level0_packed, l0, l0, (size_t)n_slots, hipMemcpyHostToDevice, ctx->stream));
-  return svo_pyramid_build_levels(pyr, first_slot, n_slots);
+  return svo_pyramid_build_levels(pyr, first_slot, n_slots, nullptr);
 }
 
 int svo_hip_pyramid_download_level(svo_hip_pyramid* pyr, int slot, int level, uint8_t* out_host) {

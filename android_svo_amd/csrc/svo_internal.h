@@ -104,7 +104,7 @@ inline int svo_ctx_host_staging(svo_hip_ctx* ctx, size_t need, char** out) {
   return SVO_HIP_OK;
 }
 
-int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots);    // levels 1.. from level 0 (svo_ctx.hip)
+int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* level0_mapped);    // levels 1.. from level 0 (svo_ctx.hip)
 
 inline svo_dev::Cam svo_make_cam(const svo_hip_camera& c) {
   svo_dev::Cam d;

@@ -429,7 +429,9 @@ __global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, T
                                                          const svo_hip_pose_opt_result* __restrict__ po, svo_hip_track_result* __restrict__ res,
                                                          double* __restrict__ out_px, double* __restrict__ out_f, int* __restrict__ out_level,
                                                          int* __restrict__ out_point, uint8_t* __restrict__ out_edgelet, double* __restrict__ out_grad,
-                                                         int* __restrict__ out_pt_type, int* __restrict__ out_pt_failed, int* __restrict__ out_pt_succeeded) {
+                                                         int* __restrict__ out_pt_type, int* __restrict__ out_pt_failed, int* __restrict__ out_pt_succeeded,
+                                                         unsigned long long* __restrict__ done_flag, unsigned long long seq) {
+  __shared__ double s_Tnew[7];
   const int t = threadIdx.x, nt = blockDim.x;
   const int n_feat = pl.counters[4];
   const int n_po = pl.counters[5];
@@ -454,8 +456,8 @@ __global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, T
       for (int i = 0; i < 7; ++i) r.pose.T_f_w[i] = sia_state->T_cur_w[i];
     }
     // new_frame_->T_f_w_ when processFrame hands the frame over: the refined pose, or -- too few matches (:211) -- the last frame's
-    for (int i = 0; i < 7; ++i) r.T_f_w[i] = n_po > 0 ? r.pose.T_f_w[i] : last.T_f_w[i];
-    *res = r;
+    for (int i = 0; i < 7; ++i) { r.T_f_w[i] = n_po > 0 ? r.pose.T_f_w[i] : last.T_f_w[i]; s_Tnew[i] = r.T_f_w[i]; }
+    *res = r;                              // (res lies in host memory: written, never read back here)
   }
   __syncthreads();
   for (int i = t; i < n_feat; i += nt) {
@@ -484,13 +486,18 @@ __global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, T
     *last.n = n_feat;
     FrameConst c;
     c.cam = cam;
-    for (int i = 0; i < 7; ++i) { const double v = res->T_f_w[i]; last.T_f_w[i] = v; c.T_ref_w[i] = v; c.T_cur_w_init[i] = v; }   // :175
+    for (int i = 0; i < 7; ++i) { const double v = s_Tnew[i]; last.T_f_w[i] = v; c.T_ref_w[i] = v; c.T_cur_w_init[i] = v; }   // :175
     double Tinv[7];
     se3_inverse(c.T_ref_w, Tinv);                                            // Frame::pos()
     c.ref_pos[0] = Tinv[0]; c.ref_pos[1] = Tinv[1]; c.ref_pos[2] = Tinv[2];
     c.n_feat = n_feat < last.sia_max_n ? n_feat : last.sia_max_n; c.pad = 0;
     last.sia_fc[0] = c;
   }
+  // the result block lies in page-locked host memory: once every thread's stores have left for the host, the frame's
+  // sequence number goes after them and the waiting host thread reads the block
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <typename T>
@@ -529,8 +536,11 @@ struct svo_hip_tracker {
   bool any_edgelet = false;                 // the map holds EDGELET reference features (align1D stage needed)
   svo_hip_pose_opt_result* po = nullptr;
   // result block: [svo_hip_track_result][px][f][level][point][edgelet][grad][pt_type][pt_failed][pt_succeeded]
-  char* res_dev = nullptr;
-  char* res_host = nullptr;                 // page-locked
+  char* res_dev = nullptr;                  // device address of res_host
+  char* res_host = nullptr;                 // page-locked, mapped into the device: the hand-over kernel writes it directly
+  unsigned long long seq = 0;               // frames tracked: the kernel stores it behind the block (o_flag) when the block is complete
+  size_t o_flag = 0;
+  uint8_t* img_dev = nullptr;               // device address of img_host
   size_t o_px = 0, o_f = 0, o_level = 0, o_point = 0, o_edge = 0, o_grad = 0, o_pt = 0, res_bytes = 0;
   // page-locked staging: one frame image, the map tables
   uint8_t* img_host = nullptr;
@@ -630,10 +640,13 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
   // result block
   auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
   t->o_px = al(sizeof(svo_hip_track_result)); t->o_f = al(t->o_px + NF * 16); t->o_level = al(t->o_f + NF * 24); t->o_point = al(t->o_level + NF * 4);
-  t->o_edge = al(t->o_point + NF * 4); t->o_grad = al(t->o_edge + NF); t->o_pt = al(t->o_grad + NF * 16); t->res_bytes = al(t->o_pt + P * 12);
-  D(&t->res_dev, t->res_bytes);
-  if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->res_host, t->res_bytes, hipHostMallocDefault) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
-  if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->img_host, (size_t)cam->width * cam->height, hipHostMallocDefault) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
+  t->o_edge = al(t->o_point + NF * 4); t->o_grad = al(t->o_edge + NF); t->o_pt = al(t->o_grad + NF * 16); t->o_flag = al(t->o_pt + P * 12);
+  t->res_bytes = t->o_flag + 64;
+  if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->res_host, t->res_bytes, hipHostMallocMapped) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
+  if (rc == SVO_HIP_OK && hipHostGetDevicePointer((void**)&t->res_dev, t->res_host, 0) != hipSuccess) rc = SVO_HIP_ERR_DEVICE;
+  if (rc == SVO_HIP_OK) memset(t->res_host, 0, t->res_bytes);
+  if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->img_host, (size_t)cam->width * cam->height + 64, hipHostMallocMapped) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
+  if (rc == SVO_HIP_OK && hipHostGetDevicePointer((void**)&t->img_dev, t->img_host, 0) != hipSuccess) rc = SVO_HIP_ERR_DEVICE;
   t->map_host_bytes = K * (56 + 4 + 20 + 4) + 8 + F * 4 + P * (24 + 12 + 4) + 8 + O * (4 + 16 + 24 + 4 + 1 + 16) + CN * 4 + 1024;
   if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->map_host, t->map_host_bytes, hipHostMallocDefault) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
   if (rc != SVO_HIP_OK) { svo_hip_tracker_destroy(t); return rc; }
@@ -793,7 +806,7 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   svo_hip_pyramid* cur = t->frame_pyr[1 - t->last_idx];
   // ---- new Frame(cam, img, t): the image crosses the link once, from page-locked memory; the pyramid is built on the device
   memcpy(t->img_host, level0, l0);
-  int rc = svo_hip_pyramid_upload_level0_and_build(cur, 0, t->img_host);
+  int rc = svo_pyramid_build_levels(cur, 0, 1, t->img_dev);
   if (rc != SVO_HIP_OK) return rc;
   // ---- SparseImgAlign(kltMaxLevel, kltMinLevel, 30, GaussNewton, false, false).run(last_frame_, new_frame_)
   rc = svo_hip_sia_set_frames(t->sia, ref, cur);
@@ -832,17 +845,28 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   rc = svo_hip_pose_optimize_batch_dev(ctx, 1, c.max_frame_features, t->pl.counters + 5, st->T_cur_w, t->ft.f, t->ft.pos, t->ft.level, t->ft.has_point,
                                        fabs(t->cam.fx), c.pose_optim_thresh, c.pose_optim_num_iter, t->po);
   if (rc != SVO_HIP_OK) return rc;
-  // ---- hand-over + result
+  // ---- hand-over + result: written straight into the page-locked block, the frame's sequence number last
   char* rd = t->res_dev;
+  const unsigned long long seq = ++t->seq;
   hipLaunchKernelGGL(trk_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, m, t->pl, t->ft, t->last, cam, st, t->po,
                      reinterpret_cast<svo_hip_track_result*>(rd), reinterpret_cast<double*>(rd + t->o_px), reinterpret_cast<double*>(rd + t->o_f),
                      reinterpret_cast<int*>(rd + t->o_level), reinterpret_cast<int*>(rd + t->o_point), reinterpret_cast<uint8_t*>(rd + t->o_edge),
                      reinterpret_cast<double*>(rd + t->o_grad), reinterpret_cast<int*>(rd + t->o_pt), reinterpret_cast<int*>(rd + t->o_pt) + t->n_points,
-                     reinterpret_cast<int*>(rd + t->o_pt) + 2 * (size_t)t->n_points);
+                     reinterpret_cast<int*>(rd + t->o_pt) + 2 * (size_t)t->n_points, reinterpret_cast<unsigned long long*>(rd + t->o_flag), seq);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  const size_t used = t->o_pt + (size_t)t->n_points * 12;
-  SVO_CHECK_HIP(ctx, hipMemcpyAsync(t->res_host, rd, used, hipMemcpyDeviceToHost, ctx->stream));
-  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));                    // the one synchronisation of the frame
+  // the one synchronisation of the frame: wait for the sequence number (a spin on host memory: no driver call on the way
+  // back), with the stream's own synchronisation as the fall-back and the error check
+  {
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(t->res_host + t->o_flag);
+    bool seen = false;
+    for (long spins = 0; spins < 4000000L; ++spins) {                      // a few hundred milliseconds at most
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+      __builtin_ia32_pause();
+    }
+    if (!seen) SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+      return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_tracker_track", "the frame's kernels did not complete");
+  }
   const char* rh = t->res_host;
   memcpy(result, rh, sizeof(*result));
   const size_t nf = (size_t)(result->n_features > 0 ? result->n_features : 0);

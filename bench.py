@@ -387,6 +387,15 @@ def main():
         latency_ms = (time.perf_counter() - t1) / 20 * 1e3
         sia1.destroy()
 
+    # ---- one camera, one frame at a time: the whole per-frame chain through svo_hip_tracker_track (outside the timed region)
+    chain = None
+    if rank == 0 and not allreduce and world == 1 and not args.no_secondary and not args.early_stop and args.width == 640:
+        for d_ in ("tools", "tests"):
+            if os.path.join(ROOT, d_) not in sys.path:
+                sys.path.insert(0, os.path.join(ROOT, d_))
+        import chain_bench
+        chain = chain_bench.single_stream_chain(ctx)
+
     # ---- parity check (outside the timed region): EVERY distinct scene against the CPU oracle, every replica bitwise
     res = sia.download(0)
     results = sia.download_all(n_slots)
@@ -612,6 +621,8 @@ def main():
             "pose_err_vs_ground_truth": dict(zip(("rot_rad", "trans_m"), synth.pose_error(np.array(res.T_cur_w), fps[0].T_cur_w_true))),
             "gn_evaluations_per_frame": int(evals),
             "single_pair_latency_ms_early_stop": latency_ms,
+            "single_stream_chain_ms": chain["L4_L2_shipping_default"]["ms_per_frame"] if chain else None,
+            "single_stream_chain": chain,
             "algorithmic_bytes_per_frame": int(bytes_frame),
             "whole_solve_algorithmic_GBps": bytes_frame * value / 1e9,
             "roofline": roofline,

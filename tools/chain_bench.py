@@ -85,6 +85,62 @@ class ResidentStages:
         self.h.destroy()
 
 
+def oracle_tracker_leg(seq, min_level):
+    """The same frame function composed from the CPU oracle's pieces (tests/tracking_chain.py: oracle_track_frame) on one
+    host thread: per-frame time and the poses, for the parity figure of the tracker leg."""
+    from oracle import orc
+    mp = tc.sequence_map(seq)
+    n = len(seq["px0"])
+    state = {"pt_type": mp["pt_type"].copy(), "pt_n_failed": mp["pt_n_failed"].copy(), "pt_n_succeeded": mp["pt_n_succeeded"].copy(),
+             "unlinked": np.zeros(n, np.uint8)}
+    times = []
+
+    def track(k, last):
+        t0 = time.perf_counter()
+        r = tc.oracle_track_frame(orc, mp, state, last, seq["pyrs"][k - 1], seq["pyrs"][k], min_level)
+        times.append(time.perf_counter() - t0)
+        return r
+    poses, n_matches, winners, _ = tc.run_tracker_chain(seq, track, min_level)
+    return {"frames": len(times), "ms_per_frame_total": float(np.mean(times) * 1e3)}, poses, winners
+
+
+def tracker_poses(ctx, seq, min_level):
+    """poses and matched points of the sequence through svo_hip_tracker_track (for the parity figure)"""
+    mp = tc.sequence_map(seq)
+    n = len(seq["px0"])
+    trk = hip.Tracker(ctx, seq["cam"], max_keyframes=2, max_points=1024, max_obs=1024, max_kf_features=1024, max_candidates=16, max_items=1024,
+                      max_frame_features=1024, grid_size=tc.CELL, max_fts=tc.MAX_FTS, klt_min_level=min_level)
+    trk.upload_keyframe(0, seq["pyrs"][0][0])
+    trk.set_map(mp)
+    trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)
+    poses, _, winners, _ = tc.run_tracker_chain(seq, lambda k, last: trk.track(seq["pyrs"][k][0]), min_level)
+    trk.destroy()
+    return poses, winners
+
+
+def single_stream_chain(ctx, n_frames=20):
+    """What bench.py reports as the single-stream figure: per-frame wall time of svo_hip_tracker_track over the synthetic
+    tracking sequence at the shipping pyramid range (L4-L2) and at L4-L0, next to the CPU oracle's composition of the same
+    frame function on one host thread, with the largest pose difference between the two chains."""
+    seq = tc.make_sequence(n_frames=n_frames)
+    out = {"what": "one camera, one frame at a time: image in -> SparseImgAlign vs the last frame -> Reprojector::reprojectMap (one match per grid "
+                   "cell of %d map points) -> pose refinement -> pose + features out (svo_hip_tracker_track, one stream, one synchronisation); "
+                   "640x480, %d frames" % (len(seq["px0"]), n_frames - 1)}
+    for tag, min_level in (("L4_L2_shipping_default", 2), ("L4_L0", 0)):
+        leg = tracker_leg(ctx, seq, min_level)
+        cpu, c_poses, c_win = oracle_tracker_leg(seq, min_level)
+        g_poses, g_win = tracker_poses(ctx, seq, min_level)
+        from android_svo_amd import synth
+        diff = np.array([synth.pose_error(a, b) for a, b in zip(g_poses, c_poses)])
+        same = all(np.array_equal(a, b) for a, b in zip(g_win, c_win))
+        assert diff[:, 0].max() < 1e-4 and diff[:, 1].max() < 1e-3 and same, "tracking chain parity violated"
+        out[tag] = {"ms_per_frame": leg["ms_per_frame_total"], "ms_per_frame_median": leg["ms_per_frame_median"], "ms_per_frame_min": leg["ms_per_frame_min"],
+                    "cpu_oracle_1_thread_ms_per_frame": cpu["ms_per_frame_total"], "speedup_vs_1_thread": cpu["ms_per_frame_total"] / leg["ms_per_frame_total"],
+                    "max_pose_diff_vs_cpu_chain": {"rot_rad": float(diff[:, 0].max()), "trans_m": float(diff[:, 1].max())},
+                    "matched_points_equal_in_every_frame": bool(same)}
+    return out
+
+
 def tracker_leg(ctx, seq, min_level, repeats=3):
     """The same frames through svo_hip_tracker_track: the whole chain of a frame enqueued on one stream with the aligned
     pose, the candidates and the matches staying on the device, level 0 of the new image from page-locked staging, one
