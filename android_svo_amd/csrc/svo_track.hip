@@ -500,6 +500,14 @@ __global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, T
   if (t == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Point::pos_ of n points after the host optimised them: one staged block in, one launch
+__global__ void trk_scatter_positions_kernel(int n, const int* __restrict__ idx, const double* __restrict__ pos, double* __restrict__ pt_pos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t p = (size_t)idx[i];
+  pt_pos[3 * p] = pos[3 * i]; pt_pos[3 * p + 1] = pos[3 * i + 1]; pt_pos[3 * p + 2] = pos[3 * i + 2];
+}
+
 template <typename T>
 int trk_alloc(svo_hip_ctx* ctx, T** p, size_t count) {
   void* d = nullptr;
@@ -756,11 +764,23 @@ int svo_hip_tracker_update_point_positions(svo_hip_tracker* t, int n, const int3
   svo_hip_ctx* ctx = t->ctx;
   SVO_REQUIRE(ctx, n >= 0 && (n == 0 || (point && pos)));
   if (!t->have_map) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_update_point_positions", "no map has been set");
-  for (int i = 0; i < n; ++i) {
-    SVO_REQUIRE(ctx, point[i] >= 0 && point[i] < t->n_points);
-    SVO_CHECK_HIP(ctx, hipMemcpyAsync(t->pt_pos + 3 * (size_t)point[i], pos + 3 * (size_t)i, 24, hipMemcpyHostToDevice, ctx->stream));
-  }
-  t->need_gather = true;
+  if (n == 0) return SVO_HIP_OK;
+  for (int i = 0; i < n; ++i) SVO_REQUIRE(ctx, point[i] >= 0 && point[i] < t->n_points);
+  // [pos n x 3 doubles][index n ints] gathered in page-locked memory: one transfer, one scatter launch
+  const size_t o_idx = (size_t)n * 24, bytes = o_idx + (size_t)n * 4;
+  char* d = nullptr;
+  char* hs = nullptr;
+  int rc = svo_ctx_staging(ctx, bytes, &d);
+  if (rc == SVO_HIP_OK) rc = svo_ctx_host_staging(ctx, bytes, &hs);
+  if (rc != SVO_HIP_OK) return rc;
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the staging area may still feed an earlier transfer
+  memcpy(hs, pos, (size_t)n * 24);
+  memcpy(hs + o_idx, point, (size_t)n * 4);
+  SVO_CHECK_HIP(ctx, hipMemcpyAsync(d, hs, bytes, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(trk_scatter_positions_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, reinterpret_cast<const int*>(d + o_idx),
+                     reinterpret_cast<const double*>(d), t->pt_pos);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  t->need_gather = true;                    // the solver's copy of the last frame's point positions is stale
   return SVO_HIP_OK;
 }
 

@@ -58,6 +58,21 @@ class FrameTracker {
   /// the map changed behind the tracker's back (keyframe added / removed, points optimised or deleted, candidates added):
   /// flatten it again before the next frame.  processFrame calls this after map_.addKeyframe, optimizeStructure etc.
   void mapChanged() { map_dirty_ = true; }
+  /// FrameHandlerBase::optimizeStructure moved points of `frame` (frame_handler_base.cpp:190-210): push their positions
+  /// (the tables keep their indices, nothing else of the map changed)
+  bool pointsOptimised(const Frame& frame) {
+    if (!trk_ || map_dirty_) return trk_ != NULL;              // a full upload is pending anyway
+    std::vector<int32_t> idx;
+    std::vector<double> pos;
+    for (Features::const_iterator it = frame.fts_.begin(); it != frame.fts_.end(); ++it) {
+      if ((*it)->point == NULL) continue;
+      std::map<const Point*, int>::const_iterator pi = index_of_point_.find((*it)->point);
+      if (pi == index_of_point_.end()) continue;
+      idx.push_back(pi->second);
+      pos.push_back((*it)->point->pos_[0]); pos.push_back((*it)->point->pos_[1]); pos.push_back((*it)->point->pos_[2]);
+    }
+    return svo_hip_tracker_update_point_positions(trk_, (int)idx.size(), idx.data(), pos.data()) == SVO_HIP_OK;
+  }
   /// last_frame_ was set by somebody else (initialisation, relocalisation)
   void lastFrameChanged() { have_last_ = false; }
 

@@ -111,3 +111,39 @@ def test_twenty_frame_sequence_through_the_tracker(ctx, min_level):
         assert rot < 1e-12 and trans < 1e-12
     err_gpu = np.array([synth.pose_error(a, t) for a, t in zip(g_poses, truth)])
     assert err_gpu[:, 0].max() < 2e-3 and err_gpu[:, 1].max() < 5e-3, err_gpu.max(axis=0)
+
+
+def test_update_point_positions_equals_a_fresh_map(ctx):
+    """FrameHandlerBase::optimizeStructure moves a few points between two frames: pushing the new positions with
+    svo_hip_tracker_update_point_positions must give bit for bit what a fresh upload of the whole map gives (the last
+    frame's reference features read the positions through the point table)."""
+    seq = tc.make_sequence(n_frames=4)
+    mp = tc.sequence_map(seq)
+    n = len(seq["px0"])
+    rng = np.random.default_rng(5)
+    moved = np.sort(rng.choice(n, 20, replace=False)).astype(np.int32)
+    pos2 = mp["pt_pos"].copy()
+    pos2[moved] += rng.normal(0, 0.01, (len(moved), 3))
+    outs = []
+    for mode in ("fresh", "update"):
+        trk = hip.Tracker(ctx, seq["cam"], max_keyframes=2, max_points=1024, max_obs=1024, max_kf_features=1024, max_candidates=16,
+                          max_items=1024, max_frame_features=1024, grid_size=tc.CELL, max_fts=tc.MAX_FTS)
+        trk.upload_keyframe(0, seq["pyrs"][0][0])
+        trk.set_map(mp)
+        trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)
+        r1 = trk.track(seq["pyrs"][1][0])
+        if mode == "fresh":
+            # the host's view after frame 1: counters advanced, positions moved -> a whole new upload, then the last frame again
+            trk.set_map(dict(mp, pt_pos=pos2, pt_type=r1["type"], pt_n_failed=r1["n_failed"], pt_n_succeeded=r1["n_succeeded"]))
+            trk.set_last_frame(r1["T_f_w"], r1["feat_px"], r1["feat_f"], r1["feat_point"], img=seq["pyrs"][1][0])
+        else:
+            trk.update_point_positions(moved, pos2[moved])
+        r2 = trk.track(seq["pyrs"][2][0])
+        outs.append(r2)
+        trk.destroy()
+    a, b = outs
+    np.testing.assert_array_equal(a["T_f_w_sia"], b["T_f_w_sia"])
+    np.testing.assert_array_equal(a["T_f_w"], b["T_f_w"])
+    np.testing.assert_array_equal(a["feat_point"], b["feat_point"])
+    assert a["feat_px"].tobytes() == b["feat_px"].tobytes()
+    assert a["n_matches"] == b["n_matches"] and a["n_trials"] == b["n_trials"]
