@@ -288,28 +288,149 @@ __global__ __launch_bounds__(256) void sia_precompute_kernel(
 
 // (defined with the fused kernel below)
 template <bool EXACT_ROWS>
-SVO_DEV double fused_tile_row(double x, double y, double z_inv, double jscale, double sxx, double sxy, double syy, bool contributes,
-                              int lane);
+SVO_DEV double fused_tile_row_body(double x, double y, double z_inv, double jscale, double sxx, double sxy, double syy, bool contributes,
+                                   int lane);
+
+// One Gauss-Newton control step of one frame from its sums r[0..28] (21 H, 6 Jres, chi2, n_meas):
+// I/nlls_solver_impl.hpp:35-99 with solve()/update() of S/sparse_img_align.cpp:291-308.  One thread.
+SVO_DEV void gn_control_step(FrameState& s, const double* r, int level, int n_iter, double eps, int early_stop) {
+  double H[36], Jres[6], x[6];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) { H[i * 6 + j] = r[k]; H[j * 6 + i] = r[k]; ++k; }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Jres[i] = r[21 + i];
+  const double chi2_sum = r[27];
+  const unsigned long long n_meas = (unsigned long long)(r[28] + 0.5);
+  // computeResiduals returns float chi2 / size_t n_meas evaluated in float (:285)
+  const double new_chi2 = (double)((float)chi2_sum / (float)n_meas);
+#pragma unroll
+  for (int i = 0; i < 36; ++i) s.H[i] = H[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) s.Jres[i] = Jres[i];
+  s.n_meas = n_meas;
+  s.n_res += n_meas / 16;
+  s.iters[level] += 1;
+
+  ldlt6_solve_reg(H, Jres, x);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) s.x[i] = x[i];
+  if (x[0] != x[0]) s.stop = 1;                               // NaN -> stop_ (:52-59)
+  const int iter = s.iter;
+  if ((early_stop && iter > 0 && new_chi2 > s.chi2) || s.stop) {
+    for (int i = 0; i < 7; ++i) s.model[i] = s.old_model[i];  // rollback (:72)
+    s.level_done = 1;
+    return;
+  }
+  double mx[6], dT[7], nm[7], cur[7];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) mx[i] = -x[i];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) cur[i] = s.model[i];
+  se3_exp(mx, dT);
+  se3_mul(cur, dT, nm);                                       // T_new = T_old * exp(-x) (:307)
+#pragma unroll
+  for (int i = 0; i < 7; ++i) { s.old_model[i] = cur[i]; s.model[i] = nm[i]; }
+  s.chi2 = new_chi2;
+  double mxn = -1;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { double a = fabs(x[i]); if (a > mxn) mxn = a; }
+  int done = 0;
+  if (early_stop && mxn <= eps) done = 1;                     // :97-98
+  s.iter = iter + 1;
+  if (iter + 1 >= n_iter) done = 1;
+  if (done) s.level_done = 1;
+}
+
+// The control step at the head of an evaluation launch (see sia_residual_kernel), called by the first wave of the block
+// and kept out of line: the 6x6 solve must not shape the register allocation of the streaming loop (inlined it took the
+// kernel from 127 to 165 VGPRs and the state copy into 640 B of scratch per lane).  The state is stepped in LDS.
+__device__ __noinline__ void head_control_step(const FrameState* in, FrameState* out, const double* partial_rows, int chunks, int level, int n_iter,
+                                               double eps, int early_stop, double* s_model, int* s_level_done) {
+  __shared__ FrameState s_state;
+  __shared__ double s_r[RED];
+  const int lane = threadIdx.x;
+  {
+    // 64 lanes copy the record and the sums in (8-byte words)
+    static_assert(sizeof(FrameState) % 8 == 0, "FrameState is copied as 8-byte words");
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(in);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&s_state);
+    for (int i = lane; i < (int)(sizeof(FrameState) / 8); i += 64) dst[i] = src[i];
+    if (lane < RED) {                 // the frame's sums: its block partials in block order (as sia_solve_kernel<true> adds them)
+      double v = 0.0;
+      for (int c = 0; c < chunks; ++c) v += partial_rows[(size_t)c * RED + lane];
+      s_r[lane] = v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane == 0) {
+    if (!s_state.level_done) gn_control_step(s_state, s_r, level, n_iter, eps, early_stop);
+    for (int k = 0; k < 7; ++k) s_model[k] = s_state.model[k];
+    *s_level_done = s_state.level_done;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (out) {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&s_state);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out);
+    for (int i = lane; i < (int)(sizeof(FrameState) / 8); i += 64) dst[i] = src[i];
+  }
+}
+
+// what the FUSED_STEP instance of sia_residual_kernel does at its head (pending == null: nothing)
+struct SiaStepFusion {
+  const double* pending;         // block partials of the previous evaluation, all-reduced over the ranks: take its control step
+  FrameState* st_out;            // ... and write the stepped state here (block 0 of the frame)
+  int n_iter, early_stop;
+  double eps;
+};
 
 // One computeResiduals(linearize=true) evaluation for every live frame.
 // grid = (chunks, n_slots), block = 256; wave w of chunk c walks tiles c*tpc + w, +4, ...
 // Output: one partial row of RED doubles per block.
+// FUSED_STEP: the instance svo_hip_sia_run_sharded launches (control step of the previous evaluation at the head); the
+// plain instance -- svo_hip_sia_run's streaming path, the HBM-bound Jacobian pass, and the step-wise entry points --
+// carries none of that code (the out-of-line head costs the kernel a wave of occupancy).
+template <bool FUSED_STEP>
 __global__ __launch_bounds__(256) void sia_residual_kernel(
     const FrameConst* __restrict__ fc, const FrameState* __restrict__ st, const uint8_t* __restrict__ cur_base,
     size_t pyr_bytes, LevelGeom g, int level, int max_n, int max_tiles, int chunks, Shard sh,
     const float4* __restrict__ ref_cache, const float4* __restrict__ dxc, const float4* __restrict__ dyc,
     const double4* __restrict__ sxyz, const double4* __restrict__ xyz4, const double* __restrict__ tile_h,
-    const uint8_t* __restrict__ flags, double* __restrict__ partial) {
+    const uint8_t* __restrict__ flags, double* __restrict__ partial, SiaStepFusion fu) {
   const int b = blockIdx.y;
   const int chunk = blockIdx.x;
-  const FrameState& s = st[b];
   double* out_row = partial + ((size_t)b * chunks + chunk) * RED;
-  if (s.level_done) return;          // this frame's GN loop already exited at this level
+  __shared__ double s_model[7];
+  __shared__ int s_level_done;
+  // Patch-sharded solve (svo_hip_sia_run_sharded): the control step of the PREVIOUS evaluation -- its sums have been
+  // all-reduced into fu.pending since -- is taken at the head of this launch by every block of the frame (identical
+  // inputs, identical result), and block 0 writes the stepped state to the other state buffer, which nobody reads
+  // during this launch.  One launch per Gauss-Newton step instead of three.
+  if (FUSED_STEP && fu.pending) {
+    if (threadIdx.x < 64) head_control_step(st + b, chunk == 0 ? fu.st_out + b : nullptr, fu.pending + (size_t)b * chunks * RED, chunks, level, fu.n_iter,
+                                            fu.eps, fu.early_stop, s_model, &s_level_done);
+  }
+  const bool stepped = FUSED_STEP && fu.pending;             // block-uniform
+  if (stepped) __syncthreads();
+  const int level_done = stepped ? s_level_done : st[b].level_done;
+  if (level_done) {                  // this frame's GN loop already exited at this level: it contributes zeros to the exchange
+    if (FUSED_STEP && threadIdx.x < RED) out_row[threadIdx.x] = 0.0;
+    return;
+  }
   const FrameConst& c = fc[b];
   const Cam cam = c.cam;
-  double T[7];
+  double T[7];                       // block-uniform: scalar registers (a scalar load, or the stepped model out of LDS)
 #pragma unroll
-  for (int k = 0; k < 7; ++k) T[k] = s.model[k];
+  for (int k = 0; k < 7; ++k) {
+    const double v = stepped ? s_model[k] : st[b].model[k];
+    T[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  }
 
   int lo, hi;
   shard_range(c.n_feat, sh, &lo, &hi);
@@ -432,7 +553,7 @@ __global__ __launch_bounds__(256) void sia_residual_kernel(
     const bool gone_lane = jvalid && !ok;
     if (__ballot(gone_lane) != 0ull) {                            // wave-uniform, normally not taken
       const double4 S4 = sxyz[(size_t)b * max_n + (gone_lane ? tile_base + 16 * (lane & 3) + (lane >> 2) : 0)];   // (always a valid address)
-      const double out_row = fused_tile_row<true>(X.x, X.y, X.w, jscale, S4.x, S4.y, S4.z, gone_lane, lane);
+      const double out_row = fused_tile_row_body<true>(X.x, X.y, X.w, jscale, S4.x, S4.y, S4.z, gone_lane, lane);   // (inlined here: 127 VGPRs either way)
       if (lane < 21) accH -= out_row;
     }
   }
@@ -457,8 +578,8 @@ __global__ __launch_bounds__(256) void sia_residual_kernel(
     out_row[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// Sum the block partials of each frame in fixed order -> reduce buffer [n_slots][RED]
-// (only needed when the sums leave the device loop, i.e. for the all-reduce path).
+// Sum the block partials of each frame in fixed order -> reduce buffer [n_slots][RED] (the step-wise entry points: what a
+// caller exchanges between svo_hip_sia_accumulate and svo_hip_sia_solve_update).
 __global__ void sia_sum_partials_kernel(const FrameState* __restrict__ st, const double* __restrict__ partial,
                                         int chunks, double* __restrict__ reduce, int n_slots) {
   const int b = blockIdx.x;
@@ -471,20 +592,21 @@ __global__ void sia_sum_partials_kernel(const FrameState* __restrict__ st, const
   reduce[(size_t)b * RED + t] = v;
 }
 
-// One Gauss-Newton control step per frame, one wave per frame: lanes 0..28 gather the
-// frame's sums (from the block partials, or from the all-reduced buffer), lane 0 runs
-// I/nlls_solver_impl.hpp:35-99 with solve()/update() of S/sparse_img_align.cpp:291-308.
+// One Gauss-Newton control step per frame, one wave per frame: lanes 0..28 gather the frame's sums (from the block
+// partials, or from the all-reduced buffer), lane 0 runs gn_control_step.  st_out != st: the state is read from st and
+// the stepped state written to st_out (the end-of-level step of the sharded solve, which brings the state back to its
+// home buffer); frames that are done are copied through.
 template <bool FROM_PARTIALS>
-__global__ __launch_bounds__(64) void sia_solve_kernel(FrameState* __restrict__ st, const double* __restrict__ src,
+__global__ __launch_bounds__(64) void sia_solve_kernel(const FrameState* __restrict__ st, FrameState* __restrict__ st_out, const double* __restrict__ src,
                                                        int chunks, int n_slots, int level, int n_iter, double eps,
                                                        int early_stop) {
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   if (b >= n_slots) return;
-  FrameState& s = st[b];
-  if (s.level_done) return;
+  const bool done = st[b].level_done != 0;
+  if (done && st_out == st) return;
   __shared__ double r[RED];
-  if (lane < RED) {
+  if (!done && lane < RED) {
     double v = 0.0;
     if (FROM_PARTIALS) {
       const double* p = src + (size_t)b * chunks * RED + lane;
@@ -496,56 +618,10 @@ __global__ __launch_bounds__(64) void sia_solve_kernel(FrameState* __restrict__ 
   }
   __syncthreads();
   if (lane != 0) return;
-  double H[36], Jres[6], x[6];
-  {
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = i; j < 6; ++j) { H[i * 6 + j] = r[k]; H[j * 6 + i] = r[k]; ++k; }
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) Jres[i] = r[21 + i];
-  const double chi2_sum = r[27];
-  const unsigned long long n_meas = (unsigned long long)(r[28] + 0.5);
-  // computeResiduals returns float chi2 / size_t n_meas evaluated in float (:285)
-  const double new_chi2 = (double)((float)chi2_sum / (float)n_meas);
-#pragma unroll
-  for (int i = 0; i < 36; ++i) s.H[i] = H[i];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) s.Jres[i] = Jres[i];
-  s.n_meas = n_meas;
-  s.n_res += n_meas / 16;
-  s.iters[level] += 1;
-
-  ldlt6_solve_reg(H, Jres, x);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) s.x[i] = x[i];
-  if (x[0] != x[0]) s.stop = 1;                               // NaN -> stop_ (:52-59)
-  const int iter = s.iter;
-  if ((early_stop && iter > 0 && new_chi2 > s.chi2) || s.stop) {
-    for (int i = 0; i < 7; ++i) s.model[i] = s.old_model[i];  // rollback (:72)
-    s.level_done = 1;
-    return;
-  }
-  double mx[6], dT[7], nm[7], cur[7];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) mx[i] = -x[i];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) cur[i] = s.model[i];
-  se3_exp(mx, dT);
-  se3_mul(cur, dT, nm);                                       // T_new = T_old * exp(-x) (:307)
-#pragma unroll
-  for (int i = 0; i < 7; ++i) { s.old_model[i] = cur[i]; s.model[i] = nm[i]; }
-  s.chi2 = new_chi2;
-  double mxn = -1;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { double a = fabs(x[i]); if (a > mxn) mxn = a; }
-  int done = 0;
-  if (early_stop && mxn <= eps) done = 1;                     // :97-98
-  s.iter = iter + 1;
-  if (iter + 1 >= n_iter) done = 1;
-  if (done) s.level_done = 1;
+  if (st_out == st) { gn_control_step(st_out[b], r, level, n_iter, eps, early_stop); return; }
+  FrameState loc = st[b];
+  if (!done) gn_control_step(loc, r, level, n_iter, eps, early_stop);
+  st_out[b] = loc;
 }
 
 __global__ void sia_finish_kernel(const FrameConst* __restrict__ fc, FrameState* __restrict__ st,
@@ -1557,7 +1633,8 @@ struct svo_hip_sia {
   const svo_hip_pyramid* cur = nullptr;
   // device buffers
   FrameConst* fc = nullptr;
-  FrameState* st = nullptr;
+  FrameState* st = nullptr;                 // the frames' Gauss-Newton state (home buffer: results are read from here)
+  FrameState* st_alt = nullptr;             // second buffer of the sharded solve (see sharded_level)
   double *px = nullptr, *f = nullptr, *pos = nullptr;
   uint8_t *has_point = nullptr, *visible = nullptr;
   float4 *ref_cache = nullptr, *dxc = nullptr, *dyc = nullptr;   // [batch][max_n][4 rows] x float4
@@ -1845,7 +1922,7 @@ int svo_hip_sia_create(svo_hip_ctx* ctx, int batch, int max_features, svo_hip_si
   const size_t bn = (size_t)batch * max_features;
   int rc = SVO_HIP_OK;
   auto A = [&](int r) { if (rc == SVO_HIP_OK) rc = r; };
-  A(dev_alloc(ctx, &s->fc, batch)); A(dev_alloc(ctx, &s->st, batch));
+  A(dev_alloc(ctx, &s->fc, batch)); A(dev_alloc(ctx, &s->st, batch)); A(dev_alloc(ctx, &s->st_alt, batch));
   A(dev_alloc(ctx, &s->px, bn * 2)); A(dev_alloc(ctx, &s->f, bn * 3)); A(dev_alloc(ctx, &s->pos, bn * 3));
   A(dev_alloc(ctx, &s->has_point, bn)); A(dev_alloc(ctx, &s->visible, bn));
   s->max_tiles = (max_features + TILE - 1) / TILE + 1;
@@ -1867,6 +1944,7 @@ int svo_hip_sia_create(svo_hip_ctx* ctx, int batch, int max_features, svo_hip_si
   (void)hipMemsetAsync(s->sxyz, 0, bn * sizeof(double4), ctx->stream);
   (void)hipMemsetAsync(s->xyz4, 0, bn * sizeof(double4), ctx->stream);
   (void)hipMemsetAsync(s->st, 0, sizeof(FrameState) * batch, ctx->stream);
+  (void)hipMemsetAsync(s->st_alt, 0, sizeof(FrameState) * batch, ctx->stream);
   *out = s;
   return SVO_HIP_OK;
 }
@@ -1876,7 +1954,7 @@ int svo_hip_sia_destroy(svo_hip_sia* s) {
   svo_hip_ctx* ctx = s->ctx;
   (void)hipStreamSynchronize(ctx->stream);
   drop_level_graphs(s);
-  void* ptrs[] = {s->fc, s->st, s->px, s->f, s->pos, s->has_point, s->visible, s->ref_cache, s->dxc, s->dyc,
+  void* ptrs[] = {s->st_alt, s->fc, s->st, s->px, s->f, s->pos, s->has_point, s->visible, s->ref_cache, s->dxc, s->dyc,
                   s->sxyz, s->xyz4, s->tile_h, s->wmem, s->partial, s->reduce_own, s->n_pre_count};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev_res) (void)hipEventDestroy(e);
@@ -1989,7 +2067,9 @@ int svo_hip_sia_level_begin(svo_hip_sia* s, int level) {
   return SVO_HIP_OK;
 }
 
-static int launch_residual(svo_hip_sia* s) {
+// One evaluation.  st_in / st_out: the control step of the previous evaluation, whose block partials have been all-reduced
+// in place since, is taken at the head of the launch (state read from st_in, stepped state written to st_out).
+static int launch_residual(svo_hip_sia* s, const FrameState* st_in = nullptr, FrameState* st_out = nullptr) {
   svo_hip_ctx* ctx = s->ctx;
   const int level = s->level;
   LevelGeom g;
@@ -1999,21 +2079,32 @@ static int launch_residual(svo_hip_sia* s) {
   hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
   const Shard sh = {s->shard_rank, s->shard_world};
-  hipLaunchKernelGGL(sia_residual_kernel, grid, block, 0, ctx->stream, s->fc, s->st, s->cur->base, s->cur->pyr_bytes,
-                     g, level, s->max_n, s->max_tiles, s->chunks, sh, s->ref_cache, s->dxc, s->dyc, s->sxyz, s->xyz4,
-                     s->tile_h, s->visible, s->partial);
+  SiaStepFusion fu;
+  memset(&fu, 0, sizeof(fu));
+  if (st_out) { fu.pending = s->partial; fu.st_out = st_out; fu.n_iter = s->prm.n_iter; fu.early_stop = s->prm.early_stop; fu.eps = s->prm.eps; }
+  if (st_in)
+    hipLaunchKernelGGL(sia_residual_kernel<true>, grid, block, 0, ctx->stream, s->fc, st_in, s->cur->base, s->cur->pyr_bytes,
+                       g, level, s->max_n, s->max_tiles, s->chunks, sh, s->ref_cache, s->dxc, s->dyc, s->sxyz, s->xyz4,
+                       s->tile_h, s->visible, s->partial, fu);
+  else
+    hipLaunchKernelGGL(sia_residual_kernel<false>, grid, block, 0, ctx->stream, s->fc, s->st, s->cur->base, s->cur->pyr_bytes,
+                       g, level, s->max_n, s->max_tiles, s->chunks, sh, s->ref_cache, s->dxc, s->dyc, s->sxyz, s->xyz4,
+                       s->tile_h, s->visible, s->partial, fu);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
 }
 
-static int launch_solve(svo_hip_sia* s, bool from_partials) {
+// the control step as a launch of its own: from the block partials (single device) or from the reduce buffer; the state is
+// stepped in place in the home buffer unless st_in names the buffer it currently lives in
+static int launch_solve(svo_hip_sia* s, bool from_partials, const FrameState* st_in = nullptr) {
   svo_hip_ctx* ctx = s->ctx;
+  const FrameState* in = st_in ? st_in : s->st;
   if (from_partials)
-    hipLaunchKernelGGL(sia_solve_kernel<true>, dim3(s->n_slots), dim3(64), 0, ctx->stream, s->st, s->partial, s->chunks,
+    hipLaunchKernelGGL(sia_solve_kernel<true>, dim3(s->n_slots), dim3(64), 0, ctx->stream, in, s->st, s->partial, s->chunks,
                        s->n_slots, s->level, s->prm.n_iter, s->prm.eps, s->prm.early_stop);
   else
-    hipLaunchKernelGGL(sia_solve_kernel<false>, dim3(s->n_slots), dim3(64), 0, ctx->stream, s->st, s->reduce, s->chunks,
+    hipLaunchKernelGGL(sia_solve_kernel<false>, dim3(s->n_slots), dim3(64), 0, ctx->stream, in, s->st, s->reduce, s->chunks,
                        s->n_slots, s->level, s->prm.n_iter, s->prm.eps, s->prm.early_stop);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
@@ -2077,11 +2168,26 @@ int svo_hip_sia_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) 
 static int sharded_level(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, const svo_hip_sia_params* prm, int level) {
   int rc = svo_hip_sia_level_begin(s, level);
   if (rc != SVO_HIP_OK) return rc;
+  // Per Gauss-Newton step ONE launch and ONE collective.  What the ranks exchange is the evaluation kernel's own output,
+  // the block partials (n_slots x chunks rows of 32 doubles, all-reduced in place: at these sizes the collective is
+  // latency, not bandwidth), and the control step of an evaluation is taken at the HEAD of the next launch: every block
+  // of a frame adds the frame's rows in block order and redoes the 6x6 solve on identical numbers, block 0 writes the
+  // stepped state to the buffer nobody reads during the launch, and the two state buffers change roles.  Nothing is
+  // passed between blocks inside a launch (forming the frame rows in the kernel's tail needed device-scope fences
+  // between blocks on different XCDs -- whose L2s are not coherent -- and cost more than the launch it saved).  The step
+  // of the level's last evaluation is a launch of its own and brings the state back to the home buffer.
+  // The exchange adds the ranks first and the blocks second; the step-wise entry points (block rows summed, then
+  // exchanged) round differently in the last bits.  Every rank still ends with the same bits.
+  const FrameState* in = s->st;
+  FrameState* out = s->st_alt;
+  const size_t n_exchange = (size_t)n_slots * s->chunks * SVO_HIP_REDUCE_DOUBLES;
   for (int it = 0; it < prm->n_iter; ++it) {
-    if ((rc = svo_hip_sia_accumulate(s)) != SVO_HIP_OK) return rc;
-    if ((rc = svo_comm_all_reduce_sum_f64(comm, s->reduce, (size_t)n_slots * SVO_HIP_REDUCE_DOUBLES)) != SVO_HIP_OK) return rc;
-    if ((rc = svo_hip_sia_solve_update(s)) != SVO_HIP_OK) return rc;
+    rc = launch_residual(s, in, it == 0 ? nullptr : out);
+    if (it > 0) { const FrameState* t = in; in = out; out = const_cast<FrameState*>(t); }
+    if (rc != SVO_HIP_OK) return rc;
+    if ((rc = svo_comm_all_reduce_sum_f64(comm, s->partial, n_exchange)) != SVO_HIP_OK) return rc;
   }
+  if (prm->n_iter > 0 && (rc = launch_solve(s, true, in)) != SVO_HIP_OK) return rc;
   return SVO_HIP_OK;
 }
 
