@@ -907,6 +907,29 @@ SVO_DEV double fused_tile_row(double x, double y, double z_inv, double jscale, d
   return fused_tile_row_body<false>(x, y, z_inv, jscale, sxx, sxy, syy, contributes, lane);
 }
 
+// Reference patch of the fused kernel, shared with the kernel that dumps it for the parity test (sia_fused_patch_dump_kernel):
+// the reference's (float)((1.0 - su) * (1.0 - sv)) etc. in f32 (exact for a position inside the image, see lpp_project),
+// HALVED like the weights of the evaluation: every W is exactly half the reference's interpolated value -- what the
+// evaluation wants to read -- and a difference of two of them is its 0.5f * (a - b) gradient.
+SVO_DEV void fused_ref_weights(float u_ref, float v_ref, int u_ref_i, int v_ref_i, float* w) {
+  const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
+  const float ou = 1.0f - su, ov = 1.0f - sv;
+  w[0] = 0.5f * (ou * ov);
+  w[1] = 0.5f * (su * ov);
+  w[2] = 0.5f * (ou * sv);
+  w[3] = 0.5f * (su * sv);
+}
+
+// the 32 interpolated values of a patch (6 x 6 without the corners) from its seven 8-byte footprint rows.  (The fused
+// kernel keeps this two-line loop inline: called as a function there, the same code spilled 43 instead of 20 VGPRs.)
+SVO_DEV void fused_interp_W(const uint2* F, float w_tl, float w_tr, float w_bl, float w_br, float (*W)[6]) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int c2 = 0; c2 < 6; ++c2)
+      W[j][c2] = ((j == 0 || j == 5) && (c2 == 0 || c2 == 5)) ? 0.0f : interp_at(F[j], F[j + 1], c2, w_tl, w_tr, w_bl, w_br);
+}
+
 // EXACT_ROWS: workgroups whose frame has fewer than FUSED_EXACT_ROW_BELOW patches form the per-tile Hessian rows entry
 // by entry as sxx (A_i A_j) + sxy (A_i B_j + B_i A_j) + syy (B_i B_j) -- the form the kernel used for every frame until
 // round 2 -- instead of factored (see fused_tile_row_body).  There H can be rank-deficient (one patch: rank 2), the
@@ -1066,15 +1089,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
       const int v_ref_i = (int)floorf(v_ref);
       const bool valid = have && (fl[k] & F_HASPOINT) != 0 && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i >= cols - border ||
                                                     v_ref_i >= rows - border);
-      // the reference's (float)((1.0 - su) * (1.0 - sv)) in f32 (exact for a position inside the image, see lpp_project),
-      // and HALVED like the weights of the evaluation: every W below is exactly half the reference's interpolated
-      // value -- what the evaluation wants to read -- and a difference of two of them is its 0.5f * (a - b) gradient
-      const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
-      const float ou = 1.0f - su, ov = 1.0f - sv;
-      pre_w[k][0] = 0.5f * (ou * ov);
-      pre_w[k][1] = 0.5f * (su * ov);
-      pre_w[k][2] = 0.5f * (ou * sv);
-      pre_w[k][3] = 0.5f * (su * sv);
+      fused_ref_weights(u_ref, v_ref, u_ref_i, v_ref_i, pre_w[k]);
       pre_off[k] = valid ? (v_ref_i - 3) * stride + (u_ref_i - 3) : 0;   // offset 0: always valid memory
       pre_valid[k] = valid;
       // visible_fts_ is only ever set (:128); the Jacobian block is zero unless recomputed now (:76)
@@ -1590,6 +1605,47 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
 #endif
     }
     for (int i = 0; i < SVO_HIP_MAX_LEVELS; ++i) s.iters[i] = s_iters[i];
+  }
+}
+
+// Parity test support: the reference patches exactly as sia_fused_kernel forms them at `level` (same feature position in
+// f32, same weights, same interpolation: the two device functions above), written in the layout of the streaming kernels'
+// caches -- reference value = 2 W (exact), dx / dy = differences of W -- so that svo_hip_sia_download_caches hands them to
+// the test.  One thread per patch.
+__global__ __launch_bounds__(256) void sia_fused_patch_dump_kernel(const FrameConst* __restrict__ fc, int slot, const uint8_t* __restrict__ ref_base,
+                                                                   size_t pyr_bytes, LevelGeom g, int level, int max_n, const double* __restrict__ px,
+                                                                   const uint8_t* __restrict__ has_point, float4* __restrict__ ref_cache,
+                                                                   float4* __restrict__ dxc, float4* __restrict__ dyc, uint8_t* __restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= fc[slot].n_feat) return;
+  const size_t fo = (size_t)slot * max_n + i;
+  const int border = 3, stride = g.cols;
+  const float scale = 1.0f / (1 << level);
+  const float u_ref = (float)px[2 * fo] * scale, v_ref = (float)px[2 * fo + 1] * scale;
+  const int u_ref_i = (int)floorf(u_ref), v_ref_i = (int)floorf(v_ref);
+  const bool valid = has_point[fo] != 0 && !(u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i >= g.cols - border || v_ref_i >= g.rows - border);
+  flags[fo] = valid ? 1 : 0;
+  if (!valid) return;
+  float w[4];
+  fused_ref_weights(u_ref, v_ref, u_ref_i, v_ref_i, w);
+  const uint8_t* img = ref_base + (size_t)slot * pyr_bytes + g.ref_off + (v_ref_i - 3) * stride + (u_ref_i - 3);
+  uint2 F[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) F[j] = load_row8(img + j * stride);
+  float W[6][6];
+  fused_interp_W(F, w[0], w[1], w[2], w[3], W);
+#pragma unroll
+  for (int y = 0; y < 4; ++y) {
+    float v[4], dx[4], dy[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      v[x] = 2.0f * W[y + 1][x + 1];
+      dx[x] = W[y + 1][x + 2] - W[y + 1][x];
+      dy[x] = W[y + 2][x + 1] - W[y][x + 1];
+    }
+    ref_cache[fo * 4 + y] = make_float4(v[0], v[1], v[2], v[3]);
+    dxc[fo * 4 + y] = make_float4(dx[0], dx[1], dx[2], dx[3]);
+    dyc[fo * 4 + y] = make_float4(dy[0], dy[1], dy[2], dy[3]);
   }
 }
 
@@ -2360,6 +2416,28 @@ int svo_hip_sia_download_all(svo_hip_sia* s, int n_slots, svo_hip_sia_result* ou
   if (rc == SVO_HIP_OK)
     for (int i = 0; i < n_slots; ++i) fill_result(h[i], out + i);
   delete[] h;
+  return rc;
+}
+
+int svo_hip_sia_download_fused_patches(svo_hip_sia* s, int slot, int level, float* ref_patch, float* dx, float* dy, uint8_t* valid) {
+  if (!s) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = s->ctx;
+  SVO_REQUIRE(ctx, slot >= 0 && slot < s->batch && s->ref && level >= 0 && level < s->ref->n_levels);
+  int rc = flush_fc(s);
+  if (rc != SVO_HIP_OK) return rc;
+  const int n = s->h_fc[slot].n_feat;
+  if (n <= 0) return SVO_HIP_OK;
+  LevelGeom g;
+  g.cols = s->ref->width >> level; g.rows = s->ref->height >> level;
+  g.ref_off = s->ref->level_offset[level]; g.cur_off = 0;
+  hipLaunchKernelGGL(sia_fused_patch_dump_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, s->fc, slot, s->ref->base, s->ref->pyr_bytes, g,
+                     level, s->max_n, s->px, s->has_point, s->ref_cache, s->dxc, s->dyc, s->visible);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  const size_t o = (size_t)slot * s->max_n;
+  if (ref_patch && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, ref_patch, s->ref_cache + o * 4, sizeof(float) * 16 * n);
+  if (dx && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, dx, s->dxc + o * 4, sizeof(float) * 16 * n);
+  if (dy && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, dy, s->dyc + o * 4, sizeof(float) * 16 * n);
+  if (valid && rc == SVO_HIP_OK) rc = svo_hip_memcpy_d2h(ctx, valid, s->visible + o, (size_t)n);
   return rc;
 }
 

@@ -297,6 +297,16 @@ class SparseImgAlign:
                                                                 _ptr(dy, C.c_float), _ptr(vis, C.c_uint8)), "sia_download_caches")
         return ref, dx, dy, vis
 
+    def download_fused_patches(self, slot: int, n: int, level: int):
+        """reference patches as the fused kernel forms them at `level`: (ref[n][16], dx[n][16], dy[n][16], valid[n])"""
+        ref = np.zeros((n, 16), dtype=np.float32)
+        dx = np.zeros((n, 16), dtype=np.float32)
+        dy = np.zeros((n, 16), dtype=np.float32)
+        valid = np.zeros(n, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.svo_hip_sia_download_fused_patches(self.h, slot, level, _ptr(ref, C.c_float), _ptr(dx, C.c_float),
+                                                                       _ptr(dy, C.c_float), _ptr(valid, C.c_uint8)), "sia_download_fused_patches")
+        return ref, dx, dy, valid
+
     def destroy(self):
         if self.h:
             self.ctx.lib.svo_hip_sia_destroy(self.h)

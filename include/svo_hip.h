@@ -234,6 +234,13 @@ int svo_hip_sia_get_profile(svo_hip_sia* sia, double* residual_ms, uint64_t* res
  * the last svo_hip_sia_run used the fused kernel (it keeps no per-pixel caches in memory). */
 int svo_hip_sia_download_caches(svo_hip_sia* sia, int slot, float* ref_patch, float* dx, float* dy,
                                 uint8_t* visible);
+/* The same quantities as the FUSED kernel forms them at one pyramid level (it keeps them in LDS / L2-resident memory as
+ * 32 interpolated values per patch and never writes per-pixel caches): recomputed by a kernel that shares the fused
+ * kernel's device functions for the feature position, the weights and the interpolation, for kernel-level tests against
+ * precomputeReferencePatches (sparse_img_align.cpp:144-175).  valid[n]: patches inside the level image with a point;
+ * rows of other patches are not written.  Overwrites the streaming kernels' cache arrays of the slot. */
+int svo_hip_sia_download_fused_patches(svo_hip_sia* sia, int slot, int level, float* ref_patch, float* dx, float* dy,
+                                       uint8_t* valid);
 
 /* ---- feature_alignment::align2D (I/feature_alignment.h:40-47, feature_alignment.cpp:154-282) */
 /* n independent 8x8 patches refined on level `level` of cur->slot: ref_patch_with_border

@@ -87,6 +87,36 @@ def test_precompute_caches_bit_exact(ctx):
     _free(sia, ref, cur)
 
 
+@pytest.mark.parametrize("level", [0, 2, 4])
+def test_fused_kernel_reference_patches_bit_exact(ctx, level):
+    """The FUSED kernel never writes per-pixel caches: it keeps 32 interpolated values per patch (halved weights) in LDS /
+    L2-resident memory and takes reference value, dx and dy as differences of them.  svo_hip_sia_download_fused_patches
+    recomputes them with the fused kernel's own device functions (f32 feature position, halved weights, interpolation):
+    the reference values must equal the reference's ref_patch_cache_ (oracle, pinned by sia_ref.npz) bit for bit, and dx /
+    dy the streaming kernels' arrays (whose Jacobian cache is pinned bit-exact), at the finest, a middle and the
+    coarsest level, border patches and point-less features included."""
+    fp = synth.make_frame_pair(seed=23, n_features=400, null_point_every=9, border=6)
+    ref, cur, sia = _upload_pair(ctx, [fp])
+    n = len(fp.px)
+    prm = sia.params(max_level=level, min_level=level, n_iter=1)
+    sia.begin(1, prm)
+    sia.level_begin(level)
+    sia.accumulate()
+    sia.solve_update()
+    sia.finish()
+    s_ref, s_dx, s_dy, s_vis = sia.download_caches(0, n)
+    f_ref, f_dx, f_dy, f_valid = sia.download_fused_patches(0, n, level)
+    T_cfr = synth.se3_mul(fp.T_cur_w_init, synth.se3_inv(fp.T_ref_w))
+    _, _, cache, _, ovis = orc.sia_single_eval(fp, level, T_cfr, want_caches=True)
+    np.testing.assert_array_equal(f_valid, ovis)                  # valid at this level == visible_fts_ after this level alone
+    v = f_valid == 1
+    assert 10 < v.sum() and (~v).sum() >= (fp.has_point == 0).sum()
+    assert f_ref[v].tobytes() == cache[v].astype(np.float32).tobytes()
+    assert f_dx[v].tobytes() == s_dx[v].tobytes() and f_dy[v].tobytes() == s_dy[v].tobytes()
+    assert f_ref[v].tobytes() == s_ref[v].tobytes()
+    _free(sia, ref, cur)
+
+
 @pytest.mark.parametrize("n,seed", [(200, 12345), (2000, 12346), (1200, 12347)])
 def test_sparse_img_align_pose_parity(ctx, sia_mode, n, seed):
     """Configs C0 / C1-shape, reference semantics (early stop), L4-L0 and the shipping L4-L2."""

@@ -15,17 +15,29 @@ CELL = 30           # Config::gridSize()
 MAX_FTS = 120       # Config::maxFts()
 
 
-def make_sequence(n_frames=20, n_map=600):
+def make_sequence(n_frames=20, n_map=600, orbit=False):
+    """orbit: instead of moving on, the camera walks the first 20 poses of the path back and forth (0 .. 19 .. 0 .. 19 ...), so
+    that a sequence of any length keeps the keyframe's map in view."""
     rng = np.random.default_rng(2024)
     cam = synth.Camera.default()
     scene = synth.PlaneScene(seed=77, depth=2.2, tilt=(0.06, -0.04))
     T0 = synth.se3_from_twist([0.01, -0.02, 0.0], [0.004, -0.003, 0.002])
     step_t, step_r = np.array([0.012, 0.004, -0.003]), np.array([0.0015, -0.0025, 0.002])
     truth = [T0]
-    for _ in range(1, n_frames):
+    for _ in range(1, min(n_frames, 20) if orbit else n_frames):
         wob = rng.uniform(-0.002, 0.002, 3)
         truth.append(synth.se3_mul(synth.se3_from_twist(step_t + wob, step_r + 0.2 * wob), truth[-1]))
-    pyrs = [synth.build_pyramid(scene.render(cam, T)) for T in truth]
+    if orbit:
+        path = truth
+        idx = []
+        for k in range(n_frames):
+            r = k % 38
+            idx.append(r if r <= 19 else 38 - r)
+        base = [synth.build_pyramid(scene.render(cam, T)) for T in path]
+        truth = [path[j] for j in idx]
+        pyrs = [base[j] for j in idx]
+    if not orbit:
+        pyrs = [synth.build_pyramid(scene.render(cam, T)) for T in truth]
     px0 = synth.grid_features(cam, n_map, rng)           # the map: points seen in keyframe 0
     f0 = synth.cam2world(cam, px0)
     pos = scene.intersect(cam, T0, px0[:, 0], px0[:, 1])
@@ -146,14 +158,17 @@ def oracle_track_frame(orc, mp, state, last, last_pyr, cur_pyr, min_level, max_f
     return out
 
 
-def run_tracker_chain(seq, track, min_level):
-    """track(k, last) -> result dict (hip.Tracker.track layout) for frame k; the chain feeds on its own outputs."""
+def run_tracker_chain(seq, track, min_level, stop_when_lost=False):
+    """track(k, last) -> result dict (hip.Tracker.track layout) for frame k; the chain feeds on its own outputs.
+    stop_when_lost: end the chain (instead of failing) at the frame processFrame would report RESULT_FAILURE for."""
     last = dict(T=seq["T0"].copy(), px=seq["px0"].copy(), f=seq["f0"].copy(), point=np.arange(len(seq["px0"]), dtype=np.int32))
     poses, n_matches, winners, feats = [], [], [], []
     for k in range(1, len(seq["truth"])):
         r = track(k, last)
-        assert r["n_matches"] >= 50                                        # Config::qualityMinFts()
         keep = r["feat_point"] >= 0
+        if stop_when_lost and (r["n_matches"] < 50 or keep.sum() < 20):
+            break
+        assert r["n_matches"] >= 50                                        # Config::qualityMinFts()
         assert keep.sum() >= 20                                            # sfba_n_edges_final (:231)
         last = dict(T=r["T_f_w"].copy(), px=r["feat_px"], f=r["feat_f"], point=r["feat_point"])
         poses.append(r["T_f_w"].copy())

@@ -85,7 +85,7 @@ class ResidentStages:
         self.h.destroy()
 
 
-def oracle_tracker_leg(seq, min_level):
+def oracle_tracker_leg(seq, min_level, max_fts=None, stop_when_lost=False):
     """The same frame function composed from the CPU oracle's pieces (tests/tracking_chain.py: oracle_track_frame) on one
     host thread: per-frame time and the poses, for the parity figure of the tracker leg."""
     from oracle import orc
@@ -97,23 +97,23 @@ def oracle_tracker_leg(seq, min_level):
 
     def track(k, last):
         t0 = time.perf_counter()
-        r = tc.oracle_track_frame(orc, mp, state, last, seq["pyrs"][k - 1], seq["pyrs"][k], min_level)
+        r = tc.oracle_track_frame(orc, mp, state, last, seq["pyrs"][k - 1], seq["pyrs"][k], min_level, max_fts=max_fts or tc.MAX_FTS)
         times.append(time.perf_counter() - t0)
         return r
-    poses, n_matches, winners, _ = tc.run_tracker_chain(seq, track, min_level)
+    poses, n_matches, winners, _ = tc.run_tracker_chain(seq, track, min_level, stop_when_lost=stop_when_lost)
     return {"frames": len(times), "ms_per_frame_total": float(np.mean(times) * 1e3)}, poses, winners
 
 
-def tracker_poses(ctx, seq, min_level):
+def tracker_poses(ctx, seq, min_level, max_fts=None, stop_when_lost=False):
     """poses and matched points of the sequence through svo_hip_tracker_track (for the parity figure)"""
     mp = tc.sequence_map(seq)
     n = len(seq["px0"])
     trk = hip.Tracker(ctx, seq["cam"], max_keyframes=2, max_points=1024, max_obs=1024, max_kf_features=1024, max_candidates=16, max_items=1024,
-                      max_frame_features=1024, grid_size=tc.CELL, max_fts=tc.MAX_FTS, klt_min_level=min_level)
+                      max_frame_features=1024, grid_size=tc.CELL, max_fts=max_fts or tc.MAX_FTS, klt_min_level=min_level)
     trk.upload_keyframe(0, seq["pyrs"][0][0])
     trk.set_map(mp)
     trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)
-    poses, _, winners, _ = tc.run_tracker_chain(seq, lambda k, last: trk.track(seq["pyrs"][k][0]), min_level)
+    poses, _, winners, _ = tc.run_tracker_chain(seq, lambda k, last: trk.track(seq["pyrs"][k][0]), min_level, stop_when_lost=stop_when_lost)
     trk.destroy()
     return poses, winners
 
