@@ -39,56 +39,66 @@ __global__ void half_sample_kernel(const uint8_t* __restrict__ in, int w, int h,
 }
 
 // All coarser levels of one pyramid in ONE launch (the per-level kernels above cost a dependent launch each, ~4.5 us, which is
-// what a single tracked frame pays: svo_track.hip).  A workgroup takes a 64 x 16 tile of level 0 and halves it in LDS:
-// 32x8 -> 16x4 -> 8x2 -> 4x1, every level with the same truncating 2x2 mean of the level before (vk::halfSample scalar /
-// NEON form), so the bytes are those of the level-by-level build.  Needs width % 64 == 0, height % 16 == 0 and at most
-// five levels; other shapes take the per-level kernels.
+// what a single tracked frame pays: svo_track.hip).  A workgroup takes a full-width strip of 16 rows of level 0 and halves
+// it in LDS -- w/2 x 8 -> w/4 x 4 -> w/8 x 2 -> w/16 x 1 -- every level with the same truncating 2x2 mean of the level
+// before (vk::halfSample scalar / NEON form), so the bytes are those of the level-by-level build.  Needs width % 16 == 0,
+// width <= PYR_STRIP_MAX_W, height % 16 == 0 and at most five levels; other shapes take the per-level kernels.
 // src0 != null: level 0 is read from there (page-locked host memory mapped into the device: the image crosses the link
-// inside this kernel, 16 bytes per lane, and is written to the pyramid's level 0 on the way -- no separate copy, no
-// dependent launch behind it) instead of from the pyramid.
-__global__ __launch_bounds__(256) void pyramid_tile_kernel(uint8_t* __restrict__ base, int w, int h, int n_levels, size_t o1, size_t o2,
-                                                           size_t o3, size_t o4, size_t slot_stride, const uint8_t* __restrict__ src0) {
-  __shared__ __attribute__((aligned(16))) uint8_t l0[16][64];
-  __shared__ uint8_t l1[8][32], l2[4][16], l3[2][8];
+// inside this kernel and is written to the pyramid's level 0 on the way -- no separate copy, no dependent launch behind
+// it).  The strip is read row by row, 16 bytes per lane, consecutive lanes consecutive addresses: whole rows per request
+// (64 x 16 tiles, i.e. 64-byte requests, read the image at a third of the link rate).
+constexpr int PYR_STRIP_MAX_W = 2048;
+__global__ __launch_bounds__(256) void pyramid_strip_kernel(uint8_t* __restrict__ base, int w, int h, int n_levels, size_t o1, size_t o2,
+                                                            size_t o3, size_t o4, size_t slot_stride, const uint8_t* __restrict__ src0) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint8_t* l0 = lds;                      // [16][w]
+  uint8_t* l1 = l0 + 16 * w;              // [8][w/2]
+  uint8_t* l2 = l1 + 4 * w;               // [4][w/4]
+  uint8_t* l3 = l2 + w;                   // [2][w/8]
   base += (size_t)blockIdx.z * slot_stride;
-  const int t = threadIdx.x;
-  const int tx = blockIdx.x, ty = blockIdx.y;
-  if (t < 64) {                                             // the 64 x 16 tile of level 0: 16 bytes per thread
-    const int r = t >> 2, c16 = (t & 3) * 16;
-    const size_t off = (size_t)(16 * ty + r) * w + 64 * tx + c16;
-    const uint4 v = *reinterpret_cast<const uint4*>((src0 ? src0 : base) + off);
-    *reinterpret_cast<uint4*>(&l0[r][c16]) = v;
-    if (src0) *reinterpret_cast<uint4*>(base + off) = v;
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int ty = blockIdx.x;
+  {
+    const size_t off = (size_t)(16 * ty) * w;                // the strip is contiguous in level 0
+    const uint4* s4 = reinterpret_cast<const uint4*>((src0 ? src0 : base) + off);
+    uint4* d4 = reinterpret_cast<uint4*>(base + off);
+    uint4* l4 = reinterpret_cast<uint4*>(l0);
+    for (int i = t; i < w; i += nt) {                        // 16 * w bytes = w uint4
+      const uint4 v = s4[i];
+      l4[i] = v;
+      if (src0) d4[i] = v;
+    }
   }
   __syncthreads();
-  {
-    const int x = t & 31, y = t >> 5;                       // one level-1 pixel per thread
-    const unsigned a = *reinterpret_cast<const unsigned short*>(&l0[2 * y][2 * x]), b = *reinterpret_cast<const unsigned short*>(&l0[2 * y + 1][2 * x]);
+  const int w1 = w >> 1, w2 = w >> 2, w3 = w >> 3, w4 = w >> 4;
+  for (int i = t; i < 8 * w1; i += nt) {
+    const int y = i / w1, x = i - y * w1;
+    const unsigned a = *reinterpret_cast<const unsigned short*>(l0 + (2 * y) * w + 2 * x), b = *reinterpret_cast<const unsigned short*>(l0 + (2 * y + 1) * w + 2 * x);
     const uint8_t v = (uint8_t)(((a & 0xff) + (a >> 8) + (b & 0xff) + (b >> 8)) >> 2);
-    l1[y][x] = v;
-    base[o1 + (size_t)(8 * ty + y) * (w >> 1) + 32 * tx + x] = v;
+    l1[y * w1 + x] = v;
+    base[o1 + (size_t)(8 * ty + y) * w1 + x] = v;
   }
   if (n_levels <= 2) return;
   __syncthreads();
-  if (t < 64) {
-    const int x = t & 15, y = t >> 4;
-    const uint8_t v = (uint8_t)(((unsigned)l1[2 * y][2 * x] + l1[2 * y][2 * x + 1] + l1[2 * y + 1][2 * x] + l1[2 * y + 1][2 * x + 1]) >> 2);
-    l2[y][x] = v;
-    base[o2 + (size_t)(4 * ty + y) * (w >> 2) + 16 * tx + x] = v;
+  for (int i = t; i < 4 * w2; i += nt) {
+    const int y = i / w2, x = i - y * w2;
+    const uint8_t v = (uint8_t)(((unsigned)l1[(2 * y) * w1 + 2 * x] + l1[(2 * y) * w1 + 2 * x + 1] + l1[(2 * y + 1) * w1 + 2 * x] + l1[(2 * y + 1) * w1 + 2 * x + 1]) >> 2);
+    l2[y * w2 + x] = v;
+    base[o2 + (size_t)(4 * ty + y) * w2 + x] = v;
   }
   if (n_levels <= 3) return;
   __syncthreads();
-  if (t < 16) {
-    const int x = t & 7, y = t >> 3;
-    const uint8_t v = (uint8_t)(((unsigned)l2[2 * y][2 * x] + l2[2 * y][2 * x + 1] + l2[2 * y + 1][2 * x] + l2[2 * y + 1][2 * x + 1]) >> 2);
-    l3[y][x] = v;
-    base[o3 + (size_t)(2 * ty + y) * (w >> 3) + 8 * tx + x] = v;
+  for (int i = t; i < 2 * w3; i += nt) {
+    const int y = i / w3, x = i - y * w3;
+    const uint8_t v = (uint8_t)(((unsigned)l2[(2 * y) * w2 + 2 * x] + l2[(2 * y) * w2 + 2 * x + 1] + l2[(2 * y + 1) * w2 + 2 * x] + l2[(2 * y + 1) * w2 + 2 * x + 1]) >> 2);
+    l3[y * w3 + x] = v;
+    base[o3 + (size_t)(2 * ty + y) * w3 + x] = v;
   }
   if (n_levels <= 4) return;
   __syncthreads();
-  if (t < 4) {
-    const uint8_t v = (uint8_t)(((unsigned)l3[0][2 * t] + l3[0][2 * t + 1] + l3[1][2 * t] + l3[1][2 * t + 1]) >> 2);
-    base[o4 + (size_t)ty * (w >> 4) + 4 * tx + t] = v;
+  for (int x = t; x < w4; x += nt) {
+    const uint8_t v = (uint8_t)(((unsigned)l3[2 * x] + l3[2 * x + 1] + l3[w3 + 2 * x] + l3[w3 + 2 * x + 1]) >> 2);
+    base[o4 + (size_t)ty * w4 + x] = v;
   }
 }
 
@@ -99,7 +109,8 @@ __global__ __launch_bounds__(256) void pyramid_tile_kernel(uint8_t* __restrict__
 int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* level0_mapped) {
   svo_hip_ctx* ctx = pyr->ctx;
   uint8_t* base = pyr->base + (size_t)first_slot * pyr->pyr_bytes;
-  const bool tiled = pyr->width % 64 == 0 && pyr->height % 16 == 0 && pyr->n_levels <= 5 && pyr->n_levels >= 2 && (pyr->pyr_bytes % 16) == 0;
+  const bool tiled = pyr->width % 16 == 0 && pyr->width <= PYR_STRIP_MAX_W && pyr->height % 16 == 0 && pyr->n_levels <= 5 && pyr->n_levels >= 2 &&
+                     (pyr->pyr_bytes % 16) == 0;
   if (level0_mapped && !tiled) {       // shapes the tile kernel does not take: an ordinary copy first
     SVO_CHECK_HIP(ctx, hipMemcpyAsync(base, level0_mapped, (size_t)pyr->width * pyr->height, hipMemcpyDefault, ctx->stream));
     level0_mapped = nullptr;
@@ -108,7 +119,8 @@ int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots, 
   if (tiled) {
     const size_t o1 = pyr->level_offset[1], o2 = pyr->n_levels > 2 ? pyr->level_offset[2] : 0, o3 = pyr->n_levels > 3 ? pyr->level_offset[3] : 0,
                  o4 = pyr->n_levels > 4 ? pyr->level_offset[4] : 0;
-    hipLaunchKernelGGL(pyramid_tile_kernel, dim3(pyr->width / 64, pyr->height / 16, n_slots), dim3(256), 0, ctx->stream, base, pyr->width, pyr->height,
+    const size_t lds = (size_t)16 * pyr->width + 4 * pyr->width + pyr->width + pyr->width / 4 + 64;
+    hipLaunchKernelGGL(pyramid_strip_kernel, dim3(pyr->height / 16, 1, n_slots), dim3(256), lds, ctx->stream, base, pyr->width, pyr->height,
                        pyr->n_levels, o1, o2, o3, o4, pyr->pyr_bytes, level0_mapped);
     SVO_CHECK_HIP(ctx, hipGetLastError());
     return SVO_HIP_OK;

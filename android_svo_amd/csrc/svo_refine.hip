@@ -117,7 +117,7 @@ __device__ unsigned long long block_rank_select(unsigned k, bool has_key, unsign
 }
 
 // Matrix<double,6,6>::inverse() = partialPivLu().inverse() (Eigen LU/PartialPivLU.h:379-425): one thread
-SVO_DEV void inverse6(const double* Ain, double* out) {
+SVO_DEV void inverse6(const double* Ain, double* out, int col = -1) {
   constexpr int N = 6;
   double lu[N][N];
   int piv[N];
@@ -134,7 +134,10 @@ SVO_DEV void inverse6(const double* Ain, double* out) {
     for (int i = k + 1; i < N; ++i)
       for (int j = k + 1; j < N; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
   }
+  // column `col` of the inverse (the columns are independent substitutions: six lanes take one each -- same arithmetic
+  // per column as the serial loop over the columns, a seventh of its time behind the shared factorisation)
   for (int c = 0; c < N; ++c) {
+    if (col >= 0 && c != col) continue;
     double d[N];
     for (int i = 0; i < N; ++i) d[i] = (i == c) ? 1.0 : 0.0;
     for (int k = 0; k < N; ++k) if (piv[k] != k) { const double t = d[k]; d[k] = d[piv[k]]; d[piv[k]] = t; }
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
   __shared__ unsigned s_pref32;
   __shared__ unsigned long long s_pref64;
   __shared__ double red[PR_WAVES][32];
+  __shared__ double s_S[28];
   __shared__ double s_T[7], s_Told[7];
   __shared__ double s_A[36];
   __shared__ double s_chi2, s_scale;
@@ -304,9 +308,16 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
       if ((lane & 7) == 0 && 8 * g + (lane >> 3) < 28) red[wave][8 * g + (lane >> 3)] = t;
     }
     __syncthreads();
+    if (threadIdx.x < 28) {                                  // the waves in fixed order, one sum per lane
+      double v = 0.0;
+      for (int w = 0; w < PR_WAVES; ++w) v += red[w][threadIdx.x];
+      s_S[threadIdx.x] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (threadIdx.x == 0) {
       double S[28];
-      for (int k = 0; k < 28; ++k) { double v = 0.0; for (int w = 0; w < PR_WAVES; ++w) v += red[w][k]; S[k] = v; }
+      for (int k = 0; k < 28; ++k) S[k] = s_S[k];
       double A[36], bb[6], dT[6];
       int kk = 0;
       for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { A[r * 6 + c] = S[kk]; A[c * 6 + r] = S[kk]; ++kk; }
@@ -334,12 +345,12 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
   }
 
   // ---- covariance (:141), outlier test (:144-159), medians (:161-166)
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 6) {                                     // one column of Cov_ per lane
     double As[36];
     const double em2 = em * em;                              // pow(em, 2)
     for (int k = 0; k < 36; ++k) As[k] = s_A[k] * em2;
-    inverse6(As, o.Cov);
-    s_count = 0;
+    inverse6(As, o.Cov, (int)threadIdx.x);
+    if (threadIdx.x == 0) s_count = 0;
   }
   __syncthreads();
   {

@@ -148,25 +148,31 @@ SVO_DEV bool close_view_obs(const TrkMap& m, int p, const double* framepos, int*
   return !(min_cos_angle < 0.5);
 }
 
-// exclusive scan of v[0..n) in place by one workgroup, total -> v[n]; s_part: blockDim.x ints of LDS
+// exclusive scan of v[0..n) in place by one workgroup, total -> v[n]; s_part: blockDim.x ints of LDS (64 used).
+// Thread t owns a contiguous chunk; the thread sums are scanned inside each wave with lane shifts and across the waves
+// through LDS: two barriers (a log-step scan over all 1024 threads took twenty).
 SVO_DEV void block_exclusive_scan(int* v, int n, int* s_part) {
   const int t = threadIdx.x, nt = blockDim.x;
+  const int lane = t & 63, wave = t >> 6, n_waves = nt >> 6;
   const int chunk = (n + nt - 1) / nt;
   const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
   int sum = 0;
   for (int i = lo; i < hi; ++i) sum += v[i];
-  s_part[t] = sum;
-  __syncthreads();
-  for (int d = 1; d < nt; d <<= 1) {                      // Hillis-Steele over the thread sums
-    const int add = t >= d ? s_part[t - d] : 0;
-    __syncthreads();
-    s_part[t] += add;
-    __syncthreads();
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
   }
-  int run = s_part[t] - sum;                              // exclusive prefix of this thread's chunk
-  for (int i = lo; i < hi; ++i) { const int c = v[i]; v[i] = run; run += c; }
-  if (t == nt - 1) v[n] = s_part[t];
+  if (lane == 63) s_part[wave] = incl;
   __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += s_part[w];
+  int run = before + incl - sum;                          // exclusive prefix of this thread's chunk
+  for (int i = lo; i < hi; ++i) { const int c = v[i]; v[i] = run; run += c; }
+  if (t == nt - 1) v[n] = before + incl;
+  __syncthreads();
+  (void)n_waves;
 }
 
 // ---- Reprojector::reprojectMap up to the cell loop (S/reprojector.cpp:72-146) + the per-candidate choice of the reference
