@@ -63,6 +63,9 @@ def parse_args():
     ap.add_argument("--early-stop", action="store_true", help="reference GN exits instead of fixed work")
     ap.add_argument("--graph", action="store_true",
                     help="--mode allreduce: svo_hip_sia_set_sharded_graph (one HIP graph per level inside the library); --mode allreduce-torch: torch graphs")
+    ap.add_argument("--stream-mode", action="store_true",
+                    help="time the streaming implementation (one launch per Gauss-Newton evaluation) instead of the fused kernel: the run the PMC "
+                         "passes of the Jacobian pass profile (tools/pmc_stream.sh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames-per-thread", type=int, default=16)
     ap.add_argument("--latency-probe", action="store_true",
@@ -311,6 +314,8 @@ def main():
     cur = hip.Pyramid(ctx, cam.width, cam.height, 5, n_slots)
     sia = hip.SparseImgAlign(ctx, n_slots, n_feat)
     sia.set_frames(ref, cur)
+    if args.stream_mode:
+        sia.set_mode(stream=True)
     if allreduce:
         # every rank holds every frame of the global batch (same seeds on all ranks), evaluates its patch shard
         fps = [synth.make_frame_pair(seed=12345 + i, n_features=n_feat, width=args.width, height=args.height) for i in range(args.distinct)]
