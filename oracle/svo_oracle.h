@@ -16,7 +16,10 @@
  *     caches bit-exact, iteration counts equal), feature_alignment::align2D/align1D,
  *     ZMSSD, warp::getWarpMatrixAffine/getBestSearchLevel/warpAffine,
  *     depthFromTriangulation, Matcher::findEpipolarMatchDirect and
- *     Matcher::findMatchDirect end to end, vk::interpolateMat_8u, vk::halfSample.
+ *     Matcher::findMatchDirect end to end, vk::interpolateMat_8u, vk::halfSample,
+ *     the whole Reprojector::reprojectMap on a real svo::Map (close keyframes, cell lists,
+ *     Point::getCloseViewObs, point bookkeeping; tests/golden/reproject_map_ref.npz),
+ *     vk::PinholeCamera::world2cam / cam2world / isInFrame, Point::optimize, shiTomasiScore.
  *   pinned by the known-answer vector recorded in SURVEY.md 8(a-9):
  *     Seed ctor + DepthFilter::updateSeed.
  *   PARITY UNPINNED (restated from source text only; depth_filter.cpp needs the

@@ -146,7 +146,8 @@ def oracle_track_frame(orc, mp, state, last, last_pyr, cur_pyr, min_level, max_f
     T_sia = np.array(o.T_cur_w)
     cs = dict(mp, cur_pyr=cur_pyr)
     r = orc.reproject_map(cs, mp["kf_key_point"], T_cur_w=T_sia, max_fts=max_fts, state=state)
-    f_m = orc.cam2world(cam, r["feat_px"]) if len(r["feat_px"]) else np.zeros((0, 3))
+    # Feature(frame, px, level): f = cam2world(px).  (synth.cam2world is the vectorised form of the oracle's: equal bit for bit)
+    f_m = synth.cam2world(cam, r["feat_px"]) if len(r["feat_px"]) else np.zeros((0, 3))
     out = dict(r, T_f_w_sia=T_sia, feat_f=f_m, sia_n_tracked=o.n_tracked)
     if r["n_matches"] < quality_min_fts:
         out["T_f_w"] = np.array(last["T"])
