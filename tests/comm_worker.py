@@ -20,9 +20,11 @@ def main():
         comm = hip.Comm(ctx, rank, world, kind="shm", name=token, slot_bytes=8 << 20)
     else:
         comm = hip.Comm(ctx, rank, world, kind="rccl", unique_id=open(token, "rb").read())
-    if what == "sia_c3":
-        # BASELINE config C3's shape: 1280x720 pairs with 2000 patches, patch-sharded, short fixed iteration budget
-        fps = [synth.make_frame_pair(seed=3300 + i, n_features=2000, width=1280, height=720) for i in range(2)]
+    if what in ("sia_c3", "sia_c3_full"):
+        # BASELINE config C3's shape: 1280x720 pairs with 2000 patches, patch-sharded; "sia_c3": two pairs, short fixed
+        # iteration budget; "sia_c3_full": the configuration's 8 concurrent pairs x 5 levels x 30 evaluations
+        n_pairs, n_it = (8, 30) if what == "sia_c3_full" else (2, 4)
+        fps = [synth.make_frame_pair(seed=3300 + i, n_features=2000, width=1280, height=720) for i in range(n_pairs)]
         cam = fps[0].cam
         ref = hip.Pyramid(ctx, cam.width, cam.height, 5, len(fps))
         cur = hip.Pyramid(ctx, cam.width, cam.height, 5, len(fps))
@@ -30,7 +32,7 @@ def main():
         sia.set_frames(ref, cur)
         for s, fp in enumerate(fps):
             ref.upload(s, fp.ref_pyr); cur.upload(s, fp.cur_pyr); sia.upload_pair(s, fp)
-        prm = sia.params(max_level=4, min_level=0, n_iter=4, eps=1e-6, early_stop=False)
+        prm = sia.params(max_level=4, min_level=0, n_iter=n_it, eps=1e-6, early_stop=False)
         hip.sia_run_sharded(sia, comm, len(fps), prm)
         r = sia.download_all(len(fps))
         np.savez(out, T=np.array([list(x.T_cur_w) for x in r]), n=np.array([x.n_tracked for x in r]), H=np.array([list(x.H) for x in r]))
