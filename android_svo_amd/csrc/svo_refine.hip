@@ -95,61 +95,139 @@ __device__ KeyT block_radix_select(unsigned k, ForEachKey for_each_key, int* his
   return *s_prefix;
 }
 
-// The same k-th smallest key for a frame with at most one observation per thread (n <= blockDim.x: what a tracked frame
-// has -- a few hundred matches): the keys go to LDS once and every thread ranks its own key against all of them
-// (ties by thread index); one pass and two barriers instead of four or eight histogram passes of three barriers each.
-// has_key / key: this thread's key (a thread without one passes has_key = false).  s_keys: blockDim.x entries.
-__device__ unsigned long long block_rank_select(unsigned k, bool has_key, unsigned long long key, int n, unsigned long long* s_keys,
-                                                unsigned long long* s_out) {
+// The same k-th smallest key for a frame with at most one observation per thread (n <= PR_THREADS: what a tracked frame
+// has -- a few hundred matches), for NS key sets at once (same k, same threads holding keys): the keys go to LDS and
+// every key is ranked against all of them -- it is the answer when (number of keys below it) <= k < (number of keys not
+// above it); equal keys all qualify and carry the same value.  A frame of <= 128 (<= 64) keys splits the scan of a key
+// over 2 (4) threads, the LDS reads are issued eight keys ahead of their use: two barriers and ~2 k cycles instead of
+// four or eight histogram passes of three barriers each.
+// has_key / key[NS]: this thread's keys (a thread without one passes has_key = false).
+template <int NS>
+__device__ void block_rank_select(unsigned k, bool has_key, const unsigned long long* key, int n,
+                                  unsigned long long (*s_keys)[PR_THREADS], unsigned (*s_cnt)[PR_THREADS],
+                                  unsigned long long* s_out, unsigned long long* out) {
   const unsigned long long none = ~0ull;                   // above every key (bit patterns of non-negative numbers)
-  s_keys[threadIdx.x] = has_key ? key : none;
-  __syncthreads();
-  if (has_key) {
-    unsigned rank = 0;
-    for (int j = 0; j < n; ++j) {
-      const unsigned long long o = s_keys[j];
-      rank += (o < key || (o == key && j < (int)threadIdx.x)) ? 1u : 0u;
-    }
-    if (rank == k) *s_out = key;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    s_keys[s][t] = has_key ? key[s] : none;
+    s_cnt[2 * s][t] = 0; s_cnt[2 * s + 1][t] = 0;
   }
   __syncthreads();
-  return *s_out;
+  const int P = n <= PR_THREADS / 4 ? 4 : (n <= PR_THREADS / 2 ? 2 : 1);
+  const int per = PR_THREADS / P;
+  const int ki = t & (per - 1), part = t / per;
+  const int n8 = (n + 7) & ~7;
+  const int chunk = ((n8 / P) + 7) & ~7;
+  const int j0 = part * chunk, j1 = (j0 + chunk < n8) ? j0 + chunk : n8;
+  unsigned long long mine[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) mine[s] = s_keys[s][ki];
+  if (ki < n) {
+    unsigned lt[NS], le[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { lt[s] = 0; le[s] = 0; }
+    for (int j = j0; j < j1; j += 8) {
+      ulonglong2 o[NS][4];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[s][e] = *reinterpret_cast<const ulonglong2*>(&s_keys[s][j + 2 * e]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lt[s] += (o[s][e].x < mine[s] ? 1u : 0u) + (o[s][e].y < mine[s] ? 1u : 0u);
+          le[s] += (o[s][e].x <= mine[s] ? 1u : 0u) + (o[s][e].y <= mine[s] ? 1u : 0u);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { atomicAdd(&s_cnt[2 * s][ki], lt[s]); atomicAdd(&s_cnt[2 * s + 1][ki], le[s]); }
+  }
+  __syncthreads();
+  if (part == 0 && ki < n) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (mine[s] != none && s_cnt[2 * s][ki] <= k && k < s_cnt[2 * s + 1][ki]) s_out[s] = mine[s];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NS; ++s) out[s] = s_out[s];
 }
 
-// Matrix<double,6,6>::inverse() = partialPivLu().inverse() (Eigen LU/PartialPivLU.h:379-425): one thread
-SVO_DEV void inverse6(const double* Ain, double* out, int col = -1) {
+// Matrix<double,6,6>::inverse() = partialPivLu().inverse() (Eigen LU/PartialPivLU.h:379-425), column `col` of it:
+// the columns are independent substitutions behind a shared factorisation, so six lanes of a wave take one each (all of
+// them factor the same matrix -- the pivots are wave-uniform and read with readfirstlane, which keeps every index static
+// and the matrix in registers).  Same arithmetic per column as the serial loop over the columns.
+SVO_DEV void inverse6_column(const double* Ain, int col, double* d) {
   constexpr int N = 6;
   double lu[N][N];
   int piv[N];
-  for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) lu[i][j] = Ain[i * N + j];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) lu[i][j] = Ain[i * N + j];
+#pragma unroll
   for (int k = 0; k < N; ++k) {
     int big = k;
     double best = fabs(lu[k][k]);
-    for (int i = k + 1; i < N; ++i) if (fabs(lu[i][k]) > best) { best = fabs(lu[i][k]); big = i; }
+#pragma unroll
+    for (int i = k + 1; i < N; ++i)
+      if (fabs(lu[i][k]) > best) { best = fabs(lu[i][k]); big = i; }
+    big = __builtin_amdgcn_readfirstlane(big);
     piv[k] = big;
     if (best != 0.0) {
-      if (big != k) for (int j = 0; j < N; ++j) { const double t = lu[k][j]; lu[k][j] = lu[big][j]; lu[big][j] = t; }
+#pragma unroll
+      for (int c = k + 1; c < N; ++c) {
+        if (big == c) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) { const double t = lu[k][j]; lu[k][j] = lu[c][j]; lu[c][j] = t; }
+        }
+      }
+#pragma unroll
       for (int i = k + 1; i < N; ++i) lu[i][k] /= lu[k][k];
     }
+#pragma unroll
     for (int i = k + 1; i < N; ++i)
+#pragma unroll
       for (int j = k + 1; j < N; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
   }
-  // column `col` of the inverse (the columns are independent substitutions: six lanes take one each -- same arithmetic
-  // per column as the serial loop over the columns, a seventh of its time behind the shared factorisation)
-  for (int c = 0; c < N; ++c) {
-    if (col >= 0 && c != col) continue;
-    double d[N];
-    for (int i = 0; i < N; ++i) d[i] = (i == c) ? 1.0 : 0.0;
-    for (int k = 0; k < N; ++k) if (piv[k] != k) { const double t = d[k]; d[k] = d[piv[k]]; d[piv[k]] = t; }
-    for (int i = 0; i < N; ++i) { double s = d[i]; for (int j = 0; j < i; ++j) s -= lu[i][j] * d[j]; d[i] = s; }
-    for (int i = N - 1; i >= 0; --i) {
-      double s = d[i];
-      for (int j = i + 1; j < N; ++j) s -= lu[i][j] * d[j];
-      d[i] = s / lu[i][i];
-    }
-    for (int i = 0; i < N; ++i) out[i * N + c] = d[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) d[i] = (i == col) ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int c = k + 1; c < N; ++c)
+      if (piv[k] == c) { const double t = d[k]; d[k] = d[c]; d[c] = t; }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double acc = d[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) acc -= lu[i][j] * d[j];
+    d[i] = acc;
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    double acc = d[i];
+#pragma unroll
+    for (int j = i + 1; j < N; ++j) acc -= lu[i][j] * d[j];
+    d[i] = acc / lu[i][i];
   }
 }
+
+// se3_exp_series_table (svo_device_math.h), [step][column]
+__device__ __constant__ double kExpSeries[32] = {
+    0.0,         0.0,         1.0 / 272.0, 0.0,
+    1.0 / 272.0, 1.0 / 240.0, 1.0 / 210.0, 1.0 / 240.0,
+    1.0 / 210.0, 1.0 / 182.0, 1.0 / 156.0, 1.0 / 182.0,
+    1.0 / 156.0, 1.0 / 132.0, 1.0 / 110.0, 1.0 / 132.0,
+    1.0 / 110.0, 1.0 / 90.0,  1.0 / 72.0,  1.0 / 90.0,
+    1.0 / 72.0,  1.0 / 56.0,  1.0 / 42.0,  1.0 / 56.0,
+    1.0 / 42.0,  1.0 / 30.0,  1.0 / 20.0,  1.0 / 30.0,
+    1.0 / 20.0,  1.0 / 12.0,  1.0 / 6.0,   1.0 / 12.0};
+// large update angles (theta^2 > 0.25): the library path of SE3::exp
+__device__ __noinline__ void se3_exp_cold(const double* l, double* out) { se3_exp(l, out); }
 
 __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
     int max_n, const int* __restrict__ n_feat, const double* __restrict__ T_in, const double* __restrict__ f,
@@ -157,15 +235,16 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
     double reproj_thresh, int n_iter, float* __restrict__ err_ws, double* __restrict__ sq_init_ws,
     double* __restrict__ sq_final_ws, PoseOptOut* __restrict__ out) {
   __shared__ int hist[256];
-  __shared__ unsigned long long s_keys[PR_THREADS];
-  __shared__ unsigned long long s_sel;
+  __shared__ __attribute__((aligned(16))) unsigned long long s_keys[2][PR_THREADS];
+  __shared__ unsigned s_cnt[4][PR_THREADS];
+  __shared__ unsigned long long s_sel[2];
+  __shared__ double s_Ac[36], s_cov[36];
   __shared__ unsigned s_k;
   __shared__ unsigned s_pref32;
   __shared__ unsigned long long s_pref64;
   __shared__ double red[PR_WAVES][32];
-  __shared__ double s_S[28];
+  __shared__ double s_S[32];
   __shared__ double s_T[7], s_Told[7];
-  __shared__ double s_A[36];
   __shared__ double s_chi2, s_scale;
   __shared__ int s_done, s_iters;
   __shared__ unsigned s_count;
@@ -217,7 +296,6 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
 
   if (threadIdx.x == 0) {
     for (int i = 0; i < 7; ++i) { s_T[i] = T_in[7 * b + i]; s_Told[i] = s_T[i]; }            // :45
-    for (int i = 0; i < 36; ++i) s_A[i] = 0.0;
     s_chi2 = 0.0; s_done = 0; s_iters = 0; s_count = 0;
   }
   if (lane >= 28 && lane < 32) red[wave][lane] = 0.0;
@@ -251,8 +329,13 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
     return;
   }
   const bool small = n <= PR_THREADS;                        // block-uniform: one observation per thread at most
+  unsigned long long med_small = 0;
+  if (small) {
+    const unsigned long long key = (unsigned long long)__float_as_uint(cerr[0]);
+    block_rank_select<1>(n_obs / 2, ch[0], &key, n, s_keys, s_cnt, s_sel, &med_small);
+  }
   const unsigned med_bits = small
-      ? (unsigned)block_rank_select(n_obs / 2, ch[0], (unsigned long long)__float_as_uint(cerr[0]), n, s_keys, &s_sel)
+      ? (unsigned)med_small
       : block_radix_select<unsigned>(
       n_obs / 2, [&](auto&& emit) {
 #pragma unroll
@@ -260,8 +343,36 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
         for (int i = threadIdx.x + PR_THREADS * PR_CACHED; i < n; i += PR_THREADS) if (hb[i]) emit(__float_as_uint(err[i]));
       }, hist, &s_pref32, &s_k);
   const double estimated_scale = (double)(1.48f * __uint_as_float(med_bits));                  // MADScaleEstimator
-  if (threadIdx.x == 0) s_scale = estimated_scale;
+  if (threadIdx.x == 0) { s_scale = estimated_scale; s_count = 0; }
   __syncthreads();
+
+  int tri_r = 0, tri_c = 0;                                  // lane < 21: its entry of the upper triangle, row-major
+  {
+    int kk = lane < 21 ? lane : 0;
+    while (kk >= 6 - tri_r) { kk -= 6 - tri_r; ++tri_r; }
+    tri_c = tri_r + kk;
+  }
+  // Cov_ = (A em^2)^-1 (:141) of the step's A, on six lanes of the last wave while wave 0 solves the step (the waves
+  // without the solve wait at the barrier anyway): what the last step leaves in s_cov is reported.
+  auto covariance_of = [&](bool from_partials) {
+    if (lane < 21) {
+      double v = 0.0;
+      if (from_partials)
+        for (int w = 0; w < PR_WAVES; ++w) v += red[w][lane];
+      s_Ac[tri_r * 6 + tri_c] = v; s_Ac[tri_c * 6 + tri_r] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < 6) {
+      double As[36], col[6];
+      const double em2 = em * em;                            // pow(em, 2)
+#pragma unroll
+      for (int k = 0; k < 36; ++k) As[k] = s_Ac[k] * em2;
+      inverse6_column(As, lane, col);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) s_cov[i * 6 + lane] = col[i];
+    }
+  };
 
   // ---- robust Gauss-Newton (:70-138)
   for (int iter = 0; iter < n_iter; ++iter) {
@@ -307,52 +418,70 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
       const double t = wave_reduce8(v8);
       if ((lane & 7) == 0 && 8 * g + (lane >> 3) < 28) red[wave][8 * g + (lane >> 3)] = t;
     }
-    __syncthreads();
-    if (threadIdx.x < 28) {                                  // the waves in fixed order, one sum per lane
-      double v = 0.0;
-      for (int w = 0; w < PR_WAVES; ++w) v += red[w][threadIdx.x];
-      s_S[threadIdx.x] = v;
+    // wave 0 asks for what the step needs and is known already before the barrier (it runs the serial part alone)
+    double coef[8], Tc[7];
+    double chi2_old = 0.0;
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) coef[k] = kExpSeries[k * 4 + (lane & 3)];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) Tc[i] = s_T[i];
+      chi2_old = s_chi2;
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (threadIdx.x == 0) {
-      double S[28];
-      for (int k = 0; k < 28; ++k) S[k] = s_S[k];
-      double A[36], bb[6], dT[6];
-      int kk = 0;
-      for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { A[r * 6 + c] = S[kk]; A[c * 6 + r] = S[kk]; ++kk; }
-      for (int r = 0; r < 6; ++r) bb[r] = S[21 + r];
-      const double new_chi2 = S[27];
-      for (int k = 0; k < 36; ++k) s_A[k] = A[k];
-      ldlt6_solve_reg(A, bb, dT);
-      s_iters = iter + 1;
-      if ((iter > 0 && new_chi2 > s_chi2 * 1.2) || dT[0] != dT[0]) {                           // :106-116
-        for (int i = 0; i < 7; ++i) s_T[i] = s_Told[i];
-        s_done = 1;
-      } else {
-        double E[7], Tn[7], Tc[7];
-        for (int i = 0; i < 7; ++i) Tc[i] = s_T[i];
-        se3_exp(dT, E);
-        se3_mul(E, Tc, Tn);                                                                     // exp(dT) * T_f_w (:120)
-        for (int i = 0; i < 7; ++i) { s_Told[i] = Tc[i]; s_T[i] = Tn[i]; }
-        s_chi2 = new_chi2;
-        double mx = -1;
-        for (int k = 0; k < 6; ++k) { const double a = fabs(dT[k]); if (a > mx) mx = a; }
-        if (mx <= 0.0000000001) s_done = 1;                                                     // EPS
+    __syncthreads();
+    if (wave == PR_WAVES - 1) covariance_of(true);
+    if (wave == 0) {
+      double v = 0.0;                                          // the waves in fixed order, one sum per lane
+      if (lane < 28)
+        for (int w = 0; w < PR_WAVES; ++w) v += red[w][lane];
+      s_S[lane < 28 ? lane : 28] = v;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      double dT0[6] = {0, 0, 0, 0, 0, 0};
+      if (lane == 0) {
+        double S[27];
+        for (int k = 0; k < 27; ++k) S[k] = s_S[k];
+        double A[36], bb[6];
+        int kk = 0;
+        for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { A[r * 6 + c] = S[kk]; A[c * 6 + r] = S[kk]; ++kk; }
+        for (int r = 0; r < 6; ++r) bb[r] = S[21 + r];
+        ldlt6_solve_reg(A, bb, dT0);
+      }
+      double dT[6];                                            // wave-uniform copies
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dT[k] = readlane_f64(dT0[k], 0);
+      const double new_chi2 = readlane_f64(v, 27);
+      // the four series of SE3::exp on lanes 0..3 (svo_device_math.h)
+      const double zt = dT[3] * dT[3] + dT[4] * dT[4] + dT[5] * dT[5];
+      const double ser = se3_exp_series_lane(coef, (lane & 2) ? 0.25 * zt : zt);
+      const double qs_t = readlane_f64(ser, 0), pc_t = readlane_f64(ser, 1), ps_h = readlane_f64(ser, 2), pc_h = readlane_f64(ser, 3);
+      if (lane == 0) {
+        s_iters = iter + 1;
+        if ((iter > 0 && new_chi2 > chi2_old * 1.2) || dT[0] != dT[0]) {                         // :106-116
+          for (int i = 0; i < 7; ++i) s_T[i] = s_Told[i];
+          s_done = 1;
+        } else {
+          double E[7], Tn[7];
+          if (zt <= 0.25) se3_exp_small_finish(dT, zt, qs_t, pc_t, ps_h, pc_h, E);
+          else se3_exp_cold(dT, E);
+          se3_mul(E, Tc, Tn);                                                                     // exp(dT) * T_f_w (:120)
+          for (int i = 0; i < 7; ++i) { s_Told[i] = Tc[i]; s_T[i] = Tn[i]; }
+          s_chi2 = new_chi2;
+          double mx = -1;
+          for (int k = 0; k < 6; ++k) { const double a = fabs(dT[k]); if (a > mx) mx = a; }
+          if (mx <= 0.0000000001) s_done = 1;                                                     // EPS
+        }
       }
     }
     __syncthreads();
   }
 
   // ---- covariance (:141), outlier test (:144-159), medians (:161-166)
-  if (threadIdx.x < 6) {                                     // one column of Cov_ per lane
-    double As[36];
-    const double em2 = em * em;                              // pow(em, 2)
-    for (int k = 0; k < 36; ++k) As[k] = s_A[k] * em2;
-    inverse6(As, o.Cov, (int)threadIdx.x);
-    if (threadIdx.x == 0) s_count = 0;
+  if (n_iter <= 0) {                                         // no step ran: the inverse of the zero matrix, as there
+    if (wave == PR_WAVES - 1) covariance_of(false);
+    __syncthreads();
   }
-  __syncthreads();
+  if (threadIdx.x < 36) o.Cov[threadIdx.x] = s_cov[threadIdx.x];
   {
     double T[7];
     for (int i = 0; i < 7; ++i) T[i] = s_T[i];
@@ -368,26 +497,32 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
     });
     if (deleted) atomicAdd(&s_count, deleted);
   }
-  __syncthreads();
-  const unsigned n_deleted = s_count;
   // the observations of the init/final vectors are those that had a point when the function was entered:
   // sq_final >= 0 marks them (has_point was just cleared for the outliers)
-  const unsigned long long mi = small ? block_rank_select(n_obs / 2, ch0[0], (unsigned long long)__double_as_longlong(csqi[0]), n, s_keys, &s_sel)
-                                      : block_radix_select<unsigned long long>(
-      n_obs / 2, [&](auto&& emit) {
+  unsigned long long mi = 0, mf = 0;
+  if (small) {                                               // both medians in one ranking pass (its barriers cover s_count)
+    const unsigned long long keys[2] = {(unsigned long long)__double_as_longlong(csqi[0]), (unsigned long long)__double_as_longlong(csqf[0])};
+    unsigned long long med[2];
+    block_rank_select<2>(n_obs / 2, ch0[0], keys, n, s_keys, s_cnt, s_sel, med);
+    mi = med[0]; mf = med[1];
+  } else {
+    __syncthreads();
+    mi = block_radix_select<unsigned long long>(
+        n_obs / 2, [&](auto&& emit) {
 #pragma unroll
-        for (int j = 0; j < PR_CACHED; ++j) if (ch0[j]) emit((unsigned long long)__double_as_longlong(csqi[j]));
-        for (int i = threadIdx.x + PR_THREADS * PR_CACHED; i < n; i += PR_THREADS)
-          if (sq_final[i] >= 0.0) emit((unsigned long long)__double_as_longlong(sq_init[i]));
-      }, hist, &s_pref64, &s_k);
-  const unsigned long long mf = small ? block_rank_select(n_obs / 2, ch0[0], (unsigned long long)__double_as_longlong(csqf[0]), n, s_keys, &s_sel)
-                                      : block_radix_select<unsigned long long>(
-      n_obs / 2, [&](auto&& emit) {
+          for (int j = 0; j < PR_CACHED; ++j) if (ch0[j]) emit((unsigned long long)__double_as_longlong(csqi[j]));
+          for (int i = threadIdx.x + PR_THREADS * PR_CACHED; i < n; i += PR_THREADS)
+            if (sq_final[i] >= 0.0) emit((unsigned long long)__double_as_longlong(sq_init[i]));
+        }, hist, &s_pref64, &s_k);
+    mf = block_radix_select<unsigned long long>(
+        n_obs / 2, [&](auto&& emit) {
 #pragma unroll
-        for (int j = 0; j < PR_CACHED; ++j) if (ch0[j]) emit((unsigned long long)__double_as_longlong(csqf[j]));
-        for (int i = threadIdx.x + PR_THREADS * PR_CACHED; i < n; i += PR_THREADS)
-          if (sq_final[i] >= 0.0) emit((unsigned long long)__double_as_longlong(sq_final[i]));
-      }, hist, &s_pref64, &s_k);
+          for (int j = 0; j < PR_CACHED; ++j) if (ch0[j]) emit((unsigned long long)__double_as_longlong(csqf[j]));
+          for (int i = threadIdx.x + PR_THREADS * PR_CACHED; i < n; i += PR_THREADS)
+            if (sq_final[i] >= 0.0) emit((unsigned long long)__double_as_longlong(sq_final[i]));
+        }, hist, &s_pref64, &s_k);
+  }
+  const unsigned n_deleted = s_count;
   if (threadIdx.x == 0) {
     o.ran = 1;
     o.n_iter_done = s_iters;

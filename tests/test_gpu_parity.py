@@ -937,6 +937,8 @@ def test_ldlt6_device_is_bit_identical_to_eigen(ctx, golden):
     Hs, bs = [], []
     for t in range(500):
         M = rng.normal(size=(int(rng.integers(2, 40)), 6)) * rng.uniform(0.01, 100, 6)
+        if t % 7 == 0:                                         # a transposition at nearly every step
+            M = M[:, rng.permutation(6)] * np.array([1e4, 1e4, 1e4, 1.0, 1.0, 1.0])[rng.permutation(6)]
         Hs.append((M.T @ M).reshape(36)); bs.append(rng.normal(size=6))
     Hs, bs = np.array(Hs), np.array(bs)
     x = hip.ldlt6_solve_batch(ctx, Hs, bs)
