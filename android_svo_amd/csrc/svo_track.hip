@@ -4,9 +4,9 @@
 //   new_frame->T_f_w_ = last_frame->T_f_w_                                   (:175)
 //   SparseImgAlign(kltMaxLevel, kltMinLevel, 30, GaussNewton).run(last, new)  (:186-188)   svo_sia.hip, fused kernel
 //   Reprojector::reprojectMap(new_frame, overlap_kfs)                         (:203)       trk_plan_kernel -> Matcher::findMatchDirect
-//                                                                                          batch (svo_depth.hip) -> trk_replay_kernel
-//   pose_optimizer::optimizeGaussNewton(...)                                  (:226-229)   svo_refine.hip
-//   last_frame_ = new_frame_                                                  (frame_handler_mono.cpp:91)   trk_finish_kernel
+//                                                                                          batch (svo_depth.hip) -> trk_tail_kernel
+//   pose_optimizer::optimizeGaussNewton(...)                                  (:226-229)   trk_tail_kernel (svo_pose_refine.h)
+//   last_frame_ = new_frame_                                                  (frame_handler_mono.cpp:91)   trk_tail_kernel
 //
 // What stays on the device between the stages: the pose SparseImgAlign leaves (read by the reprojection and by the pose
 // refinement straight from the solver's record), the candidates of every grid cell, the matches, and -- across frames --
@@ -30,12 +30,14 @@
 
 #include "svo_internal.h"
 #include "svo_match_device.h"
+#include "svo_pose_refine.h"
 
 using namespace svo_dev;
 
 namespace {
 
 constexpr int TRK_THREADS = 1024;
+constexpr int TRK_TAIL_THREADS = svo_pose::PR_THREADS;      // the tail kernel's workgroup is the pose refinement's
 constexpr int TRK_MAX_SEL = 16;            // >= Reprojector::Options::max_n_kfs
 constexpr int TYPE_DELETED = 0, TYPE_CANDIDATE = 1, TYPE_UNKNOWN = 2, TYPE_GOOD = 3;   // Point::PointType (I/point.h:33-38)
 
@@ -335,10 +337,10 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan
 // ---- the cell loop of Reprojector::reprojectMap (S/reprojector.cpp:149-166) with reprojectCell (:180-241) replayed over
 // the batch results: per cell the first successful candidate wins, the loop stops after the cell that takes n_matches
 // beyond max_fts; point bookkeeping (:202-215), the frame's new features (:217-231) and the inputs of the pose refinement.
-__global__ __launch_bounds__(TRK_THREADS) void trk_replay_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, Cam cam, const FrameState* __restrict__ sia_state,
-                                                                 const SeedRec* __restrict__ recs, int* __restrict__ cell_winner,
-                                                                 int* __restrict__ cell_cum, int max_fts, int quality_min_fts) {
-  __shared__ int s_part[TRK_THREADS];
+SVO_DEV void trk_replay_block(const TrkMap& m, const TrkPlan& pl, const TrkFeat& ft, const Cam& cam, const FrameState* __restrict__ sia_state,
+                              const SeedRec* __restrict__ recs, int* __restrict__ cell_winner,
+                              int* __restrict__ cell_cum, int max_fts, int quality_min_fts) {
+  __shared__ int s_part[TRK_TAIL_THREADS];
   __shared__ int s_cut, s_changed;
   __shared__ unsigned long long s_trials;
   const int t = threadIdx.x, nt = blockDim.x;
@@ -430,13 +432,25 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_replay_kernel(TrkMap m, TrkPl
   }
 }
 
-// ---- last_frame_ = new_frame_ (frame_handler_mono.cpp:91) and the result block.  One workgroup.
-__global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, TrkLast last, Cam cam, const FrameState* __restrict__ sia_state,
-                                                         const svo_hip_pose_opt_result* __restrict__ po, svo_hip_track_result* __restrict__ res,
-                                                         double* __restrict__ out_px, double* __restrict__ out_f, int* __restrict__ out_level,
-                                                         int* __restrict__ out_point, uint8_t* __restrict__ out_edgelet, double* __restrict__ out_grad,
-                                                         int* __restrict__ out_pt_type, int* __restrict__ out_pt_failed, int* __restrict__ out_pt_succeeded,
-                                                         unsigned long long* __restrict__ done_flag, unsigned long long seq) {
+// where the result block of a frame goes (page-locked host memory mapped into the device)
+struct TrkOut {
+  svo_hip_track_result* res;
+  double *px, *f, *grad;
+  int *level, *point, *pt_type, *pt_failed, *pt_succeeded;
+  uint8_t* edgelet;
+  unsigned long long* done_flag;
+  unsigned long long seq;
+};
+
+// ---- last_frame_ = new_frame_ (frame_handler_mono.cpp:91) and the result block
+SVO_DEV void trk_finish_block(const TrkMap& m, const TrkPlan& pl, const TrkFeat& ft, const TrkLast& last, const Cam& cam, const FrameState* __restrict__ sia_state,
+                              const svo_hip_pose_opt_result* __restrict__ po, const TrkOut& out) {
+  svo_hip_track_result* __restrict__ res = out.res;
+  double* __restrict__ out_px = out.px; double* __restrict__ out_f = out.f; int* __restrict__ out_level = out.level;
+  int* __restrict__ out_point = out.point; uint8_t* __restrict__ out_edgelet = out.edgelet; double* __restrict__ out_grad = out.grad;
+  int* __restrict__ out_pt_type = out.pt_type; int* __restrict__ out_pt_failed = out.pt_failed; int* __restrict__ out_pt_succeeded = out.pt_succeeded;
+  unsigned long long* __restrict__ done_flag = out.done_flag;
+  const unsigned long long seq = out.seq;
   __shared__ double s_Tnew[7];
   const int t = threadIdx.x, nt = blockDim.x;
   const int n_feat = pl.counters[4];
@@ -506,6 +520,30 @@ __global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, T
   if (t == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// what the pose refinement of the frame takes besides the frame's features
+struct TrkPose {
+  int max_n, n_iter;
+  double em, reproj_thresh;
+  float* err_ws;
+  double *sq_init_ws, *sq_final_ws;
+  svo_hip_pose_opt_result* po;
+};
+
+// ---- everything of a tracked frame behind the matching stages, in one launch of one workgroup: the cell loop of the
+// reprojector, pose_optimizer::optimizeGaussNewton from the aligned pose (frame_handler_mono.cpp:218-226) and the
+// hand-over with the result block.  Three launches of one workgroup each cost a tracked frame ~8 us of dispatch.
+__global__ __launch_bounds__(TRK_TAIL_THREADS) void trk_tail_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, TrkLast last, Cam cam,
+                                                                    const FrameState* __restrict__ sia_state, const SeedRec* __restrict__ recs,
+                                                                    int* __restrict__ cell_winner, int* __restrict__ cell_cum, int max_fts,
+                                                                    int quality_min_fts, TrkPose pose, TrkOut out) {
+  trk_replay_block(m, pl, ft, cam, sia_state, recs, cell_winner, cell_cum, max_fts, quality_min_fts);
+  __syncthreads();                                                          // (one workgroup, one L1: the frame's features and counters[5] are visible)
+  svo_pose::pose_refine_block(0, pose.max_n, pl.counters + 5, sia_state->T_cur_w, ft.f, ft.pos, ft.level, ft.has_point, pose.em, pose.reproj_thresh,
+                              pose.n_iter, pose.err_ws, pose.sq_init_ws, pose.sq_final_ws, reinterpret_cast<svo_pose::PoseOptOut*>(pose.po));
+  __syncthreads();
+  trk_finish_block(m, pl, ft, last, cam, sia_state, pose.po, out);
+}
+
 // Point::pos_ of n points after the host optimised them: one staged block in, one launch
 __global__ void trk_scatter_positions_kernel(int n, const int* __restrict__ idx, const double* __restrict__ pos, double* __restrict__ pt_pos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -549,6 +587,8 @@ struct svo_hip_tracker {
   bool need_gather = true;                  // the solver's slot 0 does not hold the last frame yet (a host upload came in between)
   bool any_edgelet = false;                 // the map holds EDGELET reference features (align1D stage needed)
   svo_hip_pose_opt_result* po = nullptr;
+  float* po_err_ws = nullptr;               // pose refinement workspace (used beyond 2048 features only)
+  double *po_sq_init_ws = nullptr, *po_sq_final_ws = nullptr;
   // result block: [svo_hip_track_result][px][f][level][point][edgelet][grad][pt_type][pt_failed][pt_succeeded]
   char* res_dev = nullptr;                  // device address of res_host
   char* res_host = nullptr;                 // page-locked, mapped into the device: the hand-over kernel writes it directly
@@ -646,6 +686,7 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
   D(&pl.seg, C); D(&pl.cell_count, NC + 1); D(&pl.cell_fill, NC); D(&pl.counters, 8); D(&pl.cell_offset, NC + 1); D(&pl.overlap_kf, TRK_MAX_SEL);
   D(&pl.overlap_count, TRK_MAX_SEL); D(&pl.cand_point, C); D(&pl.cand_obs, C); D(&pl.cand_level_ref, C); D(&pl.cand_deleted, C);
   D(&t->cell_winner, NC + 1); D(&t->cell_cum, NC + 1); D(&t->po, 1);
+  D(&t->po_err_ws, (size_t)cfg->max_frame_features); D(&t->po_sq_init_ws, (size_t)cfg->max_frame_features); D(&t->po_sq_final_ws, (size_t)cfg->max_frame_features);
   const size_t NF = cfg->max_frame_features;
   TrkFeat& ft = t->ft;
   ft.cap = cfg->max_frame_features;
@@ -864,21 +905,23 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   rc = svo_match_stages(ctx, t->kf_pyr, cur, 0, &t->cam, t->pl.cap, t->pl.counters, t->pl.cand_level_ref, recs, pwb_t, n_pad, c.n_pyr_levels,
                         c.align_max_iter, t->any_edgelet);
   if (rc != SVO_HIP_OK) return rc;
-  hipLaunchKernelGGL(trk_replay_kernel, dim3(1), dim3(TRK_THREADS), 0, ctx->stream, m, t->pl, t->ft, cam, st, recs, t->cell_winner, t->cell_cum,
-                     c.max_fts, c.quality_min_fts);
-  SVO_CHECK_HIP(ctx, hipGetLastError());
-  // ---- pose_optimizer::optimizeGaussNewton(poseOptimThresh, poseOptimNumIter, ...) on the matched features, from the aligned pose
-  rc = svo_hip_pose_optimize_batch_dev(ctx, 1, c.max_frame_features, t->pl.counters + 5, st->T_cur_w, t->ft.f, t->ft.pos, t->ft.level, t->ft.has_point,
-                                       fabs(t->cam.fx), c.pose_optim_thresh, c.pose_optim_num_iter, t->po);
-  if (rc != SVO_HIP_OK) return rc;
-  // ---- hand-over + result: written straight into the page-locked block, the frame's sequence number last
+  // ---- the cell loop of the reprojector, pose_optimizer::optimizeGaussNewton(poseOptimThresh, poseOptimNumIter, ...) on the
+  // matched features from the aligned pose, and hand-over + result (written straight into the page-locked block, the
+  // frame's sequence number last): one launch
   char* rd = t->res_dev;
   const unsigned long long seq = ++t->seq;
-  hipLaunchKernelGGL(trk_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, m, t->pl, t->ft, t->last, cam, st, t->po,
-                     reinterpret_cast<svo_hip_track_result*>(rd), reinterpret_cast<double*>(rd + t->o_px), reinterpret_cast<double*>(rd + t->o_f),
-                     reinterpret_cast<int*>(rd + t->o_level), reinterpret_cast<int*>(rd + t->o_point), reinterpret_cast<uint8_t*>(rd + t->o_edge),
-                     reinterpret_cast<double*>(rd + t->o_grad), reinterpret_cast<int*>(rd + t->o_pt), reinterpret_cast<int*>(rd + t->o_pt) + t->n_points,
-                     reinterpret_cast<int*>(rd + t->o_pt) + 2 * (size_t)t->n_points, reinterpret_cast<unsigned long long*>(rd + t->o_flag), seq);
+  TrkPose pose;
+  pose.max_n = c.max_frame_features; pose.n_iter = c.pose_optim_num_iter; pose.em = fabs(t->cam.fx); pose.reproj_thresh = c.pose_optim_thresh;
+  pose.err_ws = t->po_err_ws; pose.sq_init_ws = t->po_sq_init_ws; pose.sq_final_ws = t->po_sq_final_ws; pose.po = t->po;
+  TrkOut out;
+  out.res = reinterpret_cast<svo_hip_track_result*>(rd);
+  out.px = reinterpret_cast<double*>(rd + t->o_px); out.f = reinterpret_cast<double*>(rd + t->o_f); out.grad = reinterpret_cast<double*>(rd + t->o_grad);
+  out.level = reinterpret_cast<int*>(rd + t->o_level); out.point = reinterpret_cast<int*>(rd + t->o_point);
+  out.pt_type = reinterpret_cast<int*>(rd + t->o_pt); out.pt_failed = out.pt_type + t->n_points; out.pt_succeeded = out.pt_type + 2 * (size_t)t->n_points;
+  out.edgelet = reinterpret_cast<uint8_t*>(rd + t->o_edge);
+  out.done_flag = reinterpret_cast<unsigned long long*>(rd + t->o_flag); out.seq = seq;
+  hipLaunchKernelGGL(trk_tail_kernel, dim3(1), dim3(TRK_TAIL_THREADS), 0, ctx->stream, m, t->pl, t->ft, t->last, cam, st, recs, t->cell_winner, t->cell_cum,
+                     c.max_fts, c.quality_min_fts, pose, out);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   // the one synchronisation of the frame: wait for the sequence number (a spin on host memory: no driver call on the way
   // back), with the stream's own synchronisation as the fall-back and the error check
