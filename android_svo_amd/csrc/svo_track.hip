@@ -4,9 +4,9 @@
 //   new_frame->T_f_w_ = last_frame->T_f_w_                                   (:175)
 //   SparseImgAlign(kltMaxLevel, kltMinLevel, 30, GaussNewton).run(last, new)  (:186-188)   svo_sia.hip, fused kernel
 //   Reprojector::reprojectMap(new_frame, overlap_kfs)                         (:203)       trk_plan_kernel -> Matcher::findMatchDirect
-//                                                                                          batch (svo_depth.hip) -> trk_tail_kernel
-//   pose_optimizer::optimizeGaussNewton(...)                                  (:226-229)   trk_tail_kernel (svo_pose_refine.h)
-//   last_frame_ = new_frame_                                                  (frame_handler_mono.cpp:91)   trk_tail_kernel
+//                                                                                          batch (svo_depth.hip) -> trk_replay_kernel
+//   pose_optimizer::optimizeGaussNewton(...)                                  (:226-229)   svo_refine.hip
+//   last_frame_ = new_frame_                                                  (frame_handler_mono.cpp:91)   trk_finish_kernel
 //
 // What stays on the device between the stages: the pose SparseImgAlign leaves (read by the reprojection and by the pose
 // refinement straight from the solver's record), the candidates of every grid cell, the matches, and -- across frames --
@@ -30,15 +30,16 @@
 
 #include "svo_internal.h"
 #include "svo_match_device.h"
-#include "svo_pose_refine.h"
 
 using namespace svo_dev;
 
 namespace {
 
 constexpr int TRK_THREADS = 1024;
-constexpr int TRK_TAIL_THREADS = svo_pose::PR_THREADS;      // the tail kernel's workgroup is the pose refinement's
 constexpr int TRK_MAX_SEL = 16;            // >= Reprojector::Options::max_n_kfs
+constexpr int TRK_LDS_KF = 256;            // keyframes of the map (svo_hip_tracker_config::max_keyframes <= this): per-keyframe scratch in LDS
+constexpr int TRK_LDS_ITEMS = 2048;        // a frame with at most this many candidates keeps their per-cell sort keys in LDS
+constexpr int TRK_LDS_CELLS = 2048;        // a grid with at most this many cells keeps the cell counters in LDS
 constexpr int TYPE_DELETED = 0, TYPE_CANDIDATE = 1, TYPE_UNKNOWN = 2, TYPE_GOOD = 3;   // Point::PointType (I/point.h:33-38)
 
 // the map as index tables (device pointers)
@@ -67,14 +68,13 @@ struct TrkMap {
 // scratch and outputs of the planning kernel; cap = capacity of the candidate arrays
 struct TrkPlan {
   int cap, n_cells, grid_cols, grid_size, max_n_kfs;
-  int* kf_close;                 // [n_kf]
-  double* kf_dist;               // [n_kf]
   int* first_seq;                // [n_points]
   int* item_point;               // [cap] kept items in arrival order
   double* item_px;               // [cap][2]
   int* item_cell;                // [cap]
   unsigned long long* item_key;  // [cap]
   int* seg;                      // [cap]
+  unsigned long long* seg_key;   // [cap] item_key in segment order (frames beyond TRK_LDS_ITEMS candidates)
   int* cell_count;               // [n_cells + 1]
   int* cell_fill;                // [n_cells]
   // outputs (the candidates of every cell in trial order)
@@ -132,19 +132,25 @@ SVO_DEV void normalize3(double* v) {
 
 // Point::getCloseViewObs (S/point.cpp:101-125): the observation whose viewing direction is closest to the frame's (first
 // maximum of the cosine above zero, else the first observation); false when the angle exceeds 60 degrees
-SVO_DEV bool close_view_obs(const TrkMap& m, int p, const double* framepos, int* obs_out) {
+SVO_DEV bool close_view_obs(const TrkMap& m, int p, const double* framepos, const double (*kf_pos)[3], int* obs_out) {
   const double* pos = m.pt_pos + 3 * (size_t)p;
   double od[3] = {framepos[0] - pos[0], framepos[1] - pos[1], framepos[2] - pos[2]};
   normalize3(od);
-  int min_it = m.pt_obs_offset[p];
+  const int o0 = m.pt_obs_offset[p], o1 = m.pt_obs_offset[p + 1];
+  int min_it = o0;
   double min_cos_angle = 0;
-  for (int o = m.pt_obs_offset[p]; o < m.pt_obs_offset[p + 1]; ++o) {
-    double Tinv[7];
-    se3_inverse(m.T_kf_w + 7 * (size_t)m.obs_kf[o], Tinv);                 // (*it)->frame->pos()
-    double d[3] = {Tinv[0] - pos[0], Tinv[1] - pos[1], Tinv[2] - pos[2]};
-    normalize3(d);
-    const double cos_angle = od[0] * d[0] + od[1] * d[1] + od[2] * d[2];
-    if (cos_angle > min_cos_angle) { min_cos_angle = cos_angle; min_it = o; }
+  for (int ob = o0; ob < o1; ob += 4) {                                      // the keyframe indices of four observations at once
+    int kf[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) kf[e] = ob + e < o1 ? m.obs_kf[ob + e] : -1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (kf[e] < 0) continue;
+      double d[3] = {kf_pos[kf[e]][0] - pos[0], kf_pos[kf[e]][1] - pos[1], kf_pos[kf[e]][2] - pos[2]};   // (*it)->frame->pos() - pos_
+      normalize3(d);
+      const double cos_angle = od[0] * d[0] + od[1] * d[1] + od[2] * d[2];
+      if (cos_angle > min_cos_angle) { min_cos_angle = cos_angle; min_it = ob + e; }
+    }
   }
   *obs_out = min_it;
   return !(min_cos_angle < 0.5);
@@ -183,11 +189,19 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan
                                                                SeedRec* __restrict__ recs, const FrameState* __restrict__ sia_state) {
   const Cam cam = mf.cam;
   __shared__ int s_part[TRK_THREADS];
-  __shared__ int s_sel[TRK_MAX_SEL], s_seq_base[TRK_MAX_SEL + 1];
+  __shared__ int s_sel[TRK_MAX_SEL], s_seq_base[TRK_MAX_SEL + 1], s_ftr_off[TRK_MAX_SEL], s_ftr_cnt[TRK_MAX_SEL];
   __shared__ int s_n_close, s_n_sel, s_n_kept, s_overflow, s_changed;
   __shared__ int s_overlap[TRK_MAX_SEL];
   __shared__ double s_T[7], s_framepos[3];
+  // per-keyframe scratch, and -- for frames and grids that fit (block-uniform choice) -- the cell counters and the sort keys
+  // in segment order: what one phase writes and the next one reads costs an LDS access instead of a trip to L2
+  __shared__ int s_kf_close[TRK_LDS_KF];
+  __shared__ double s_kf_dist[TRK_LDS_KF], s_kf_pos[TRK_LDS_KF][3];
+  __shared__ int s_cell_count[TRK_LDS_CELLS + 1], s_cell_fill[TRK_LDS_CELLS];
+  __shared__ unsigned long long s_seg_key[TRK_LDS_ITEMS];
   const int t = threadIdx.x, nt = blockDim.x;
+  int* const cell_count = pl.n_cells <= TRK_LDS_CELLS ? s_cell_count : pl.cell_count;
+  int* const cell_fill = pl.n_cells <= TRK_LDS_CELLS ? s_cell_fill : pl.cell_fill;
   if (t < 7) s_T[t] = sia_state->T_cur_w[t];
   if (t == 0) { s_n_close = 0; s_n_kept = 0; s_overflow = 0; s_changed = 0; }
   if (t < TRK_MAX_SEL) { s_sel[t] = -1; s_overlap[t] = 0; }
@@ -202,36 +216,52 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan
   }
   // ---- Map::getCloseKeyframes (S/map.cpp:109-131): keyframes one of whose key points is visible in the frame
   for (int k = t; k < m.n_kf; k += nt) {
+    int kp[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) kp[j] = m.kf_key_point[5 * k + j];
     bool close = false;
-    for (int j = 0; j < 5 && !close; ++j) {
-      const int p = m.kf_key_point[5 * k + j];
-      if (p >= 0) close = frame_is_visible(cam, T, m.pt_pos + 3 * (size_t)p);
-    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (!close && kp[j] >= 0) close = frame_is_visible(cam, T, m.pt_pos + 3 * (size_t)kp[j]);
     const double* tk = m.T_kf_w + 7 * (size_t)k;
-    const double dx = T[0] - tk[0], dy = T[1] - tk[1], dz = T[2] - tk[2];
-    pl.kf_close[k] = close ? 1 : 0;
-    pl.kf_dist[k] = sqrt(dx * dx + dy * dy + dz * dz);                     // (translation_vec difference).norm()
+    double Tk[7], Tinv[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) Tk[i] = tk[i];
+    const double dx = T[0] - Tk[0], dy = T[1] - Tk[1], dz = T[2] - Tk[2];
+    s_kf_close[k] = close ? 1 : 0;
+    s_kf_dist[k] = sqrt(dx * dx + dy * dy + dz * dz);                      // (translation_vec difference).norm()
+    se3_inverse(Tk, Tinv);                                                 // Frame::pos() of the keyframe (Point::getCloseViewObs)
+    s_kf_pos[k][0] = Tinv[0]; s_kf_pos[k][1] = Tinv[1]; s_kf_pos[k][2] = Tinv[2];
     if (close) atomicAdd(&s_n_close, 1);
   }
   for (int p = t; p < m.n_points; p += nt) pl.first_seq[p] = INT_MAX;
-  for (int c = t; c <= pl.n_cells; c += nt) pl.cell_count[c] = 0;
-  for (int c = t; c < pl.n_cells; c += nt) pl.cell_fill[c] = 0;
+  for (int c = t; c <= pl.n_cells; c += nt) cell_count[c] = 0;
+  for (int c = t; c < pl.n_cells; c += nt) cell_fill[c] = 0;
   __syncthreads();
   // ---- close_kfs.sort by distance (stable: std::list::sort), the first max_n_kfs of them (:82-88)
   for (int k = t; k < m.n_kf; k += nt) {
-    if (!pl.kf_close[k]) continue;
-    const double dk = pl.kf_dist[k];
+    if (!s_kf_close[k]) continue;
+    const double dk = s_kf_dist[k];
     int rank = 0;
     for (int j = 0; j < m.n_kf; ++j)
-      if (pl.kf_close[j] && (pl.kf_dist[j] < dk || (!(dk < pl.kf_dist[j]) && j < k))) ++rank;
+      if (s_kf_close[j] && (s_kf_dist[j] < dk || (!(dk < s_kf_dist[j]) && j < k))) ++rank;
     if (rank < pl.max_n_kfs) s_sel[rank] = k;
+  }
+  __syncthreads();
+  if (t < TRK_MAX_SEL) {                                                    // the selected keyframes' feature ranges, all at once
+    const int n_sel = s_n_close < pl.max_n_kfs ? s_n_close : pl.max_n_kfs;
+    if (t < n_sel) {
+      const int off = m.kf_ftr_offset[s_sel[t]];
+      s_ftr_off[t] = off;
+      s_ftr_cnt[t] = m.kf_ftr_offset[s_sel[t] + 1] - off;
+    }
   }
   __syncthreads();
   if (t == 0) {
     const int n_sel = s_n_close < pl.max_n_kfs ? s_n_close : pl.max_n_kfs;
     s_n_sel = n_sel;
     int base = 0;
-    for (int r = 0; r < n_sel; ++r) { s_seq_base[r] = base; base += m.kf_ftr_offset[s_sel[r] + 1] - m.kf_ftr_offset[s_sel[r]]; }
+    for (int r = 0; r < n_sel; ++r) { s_seq_base[r] = base; base += s_ftr_cnt[r]; }
     s_seq_base[n_sel] = base;
   }
   __syncthreads();
@@ -242,7 +272,7 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan
   for (int q = t; q < m_kf; q += nt) {
     int r = 0;
     while (r + 1 < n_sel && q >= s_seq_base[r + 1]) ++r;
-    const int p = m.kf_ftr_point[m.kf_ftr_offset[s_sel[r]] + (q - s_seq_base[r])];
+    const int p = m.kf_ftr_point[s_ftr_off[r] + (q - s_seq_base[r])];
     if (p >= 0 && !m.pt_unlinked[p]) atomicMin(&pl.first_seq[p], q);
   }
   __syncthreads();
@@ -252,12 +282,15 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan
     if (q < m_kf) {
       r = 0;
       while (r + 1 < n_sel && q >= s_seq_base[r + 1]) ++r;
-      p = m.kf_ftr_point[m.kf_ftr_offset[s_sel[r]] + (q - s_seq_base[r])];
-      if (p < 0 || m.pt_unlinked[p] || pl.first_seq[p] != q) continue;
+      p = m.kf_ftr_point[s_ftr_off[r] + (q - s_seq_base[r])];
+      if (p < 0) continue;
+      const int fs = pl.first_seq[p];                                        // (asked for together with the flag)
+      if (m.pt_unlinked[p] || fs != q) continue;
     } else {
       p = m.cand_point[q - m_kf];
       if (p < 0 || m.pt_unlinked[p]) continue;
     }
+    const int ptype = m.pt_type[p];                                          // (in flight during the projection)
     double xyz_f[3], px[2];
     se3_act(T, m.pt_pos + 3 * (size_t)p, xyz_f);
     world2cam(cam, xyz_f, px);                                             // frame->w2c(point->pos_)
@@ -270,8 +303,8 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan
         pl.item_point[idx] = p;
         pl.item_px[2 * idx] = px[0]; pl.item_px[2 * idx + 1] = px[1];
         pl.item_cell[idx] = cell;
-        pl.item_key[idx] = ((unsigned long long)(3 - m.pt_type[p]) << 32) | (unsigned)q;   // cell.sort: higher type first, stable
-        atomicAdd(&pl.cell_count[cell], 1);
+        pl.item_key[idx] = ((unsigned long long)(3 - ptype) << 32) | (unsigned)q;   // cell.sort: higher type first, stable
+        atomicAdd(&cell_count[cell], 1);
       } else {
         s_overflow = 1;
       }
@@ -285,34 +318,39 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan
   }
   __syncthreads();
   const int n_kept = s_n_kept < pl.cap ? s_n_kept : pl.cap;
+  unsigned long long* const seg_key = n_kept <= TRK_LDS_ITEMS ? s_seg_key : pl.seg_key;
   // ---- cell segments
-  block_exclusive_scan(pl.cell_count, pl.n_cells, s_part);                 // cell_count[c] = start of cell c, [n_cells] = total
-  for (int c = t; c <= pl.n_cells; c += nt) pl.cell_offset[c] = pl.cell_count[c];
+  block_exclusive_scan(cell_count, pl.n_cells, s_part);                    // cell_count[c] = start of cell c, [n_cells] = total
+  for (int c = t; c <= pl.n_cells; c += nt) pl.cell_offset[c] = cell_count[c];
   for (int i = t; i < n_kept; i += nt) {
     const int c = pl.item_cell[i];
-    pl.seg[pl.cell_count[c] + atomicAdd(&pl.cell_fill[c], 1)] = i;
+    const unsigned long long key = pl.item_key[i];
+    const int at = cell_count[c] + atomicAdd(&cell_fill[c], 1);
+    pl.seg[at] = i;
+    seg_key[at] = key;
   }
   __syncthreads();
   // ---- trial order inside the cell, and the reference feature of every candidate
   const double framepos[3] = {s_framepos[0], s_framepos[1], s_framepos[2]};
   for (int s = t; s < n_kept; s += nt) {
     const int i = pl.seg[s];
+    const unsigned long long key = seg_key[s];
     const int c = pl.item_cell[i];
-    const unsigned long long key = pl.item_key[i];
-    int rank = 0;
-    for (int j = pl.cell_count[c]; j < pl.cell_count[c + 1]; ++j) rank += pl.item_key[pl.seg[j]] < key ? 1 : 0;
-    const int o = pl.cell_count[c] + rank;
     const int p = pl.item_point[i];
+    const double pxc[2] = {pl.item_px[2 * i], pl.item_px[2 * i + 1]};
+    const int c0 = cell_count[c], c1 = cell_count[c + 1];
+    int rank = 0;
+    for (int j = c0; j < c1; ++j) rank += seg_key[j] < key ? 1 : 0;
+    const int o = c0 + rank;
     const bool deleted = m.pt_type[p] == TYPE_DELETED;
     int obs = -1;
     bool view_ok = false;
-    if (!deleted && m.pt_obs_offset[p + 1] > m.pt_obs_offset[p]) view_ok = close_view_obs(m, p, framepos, &obs);
+    if (!deleted && m.pt_obs_offset[p + 1] > m.pt_obs_offset[p]) view_ok = close_view_obs(m, p, framepos, s_kf_pos, &obs);
     pl.cand_point[o] = p;
     pl.cand_obs[o] = view_ok ? obs : -1;
     pl.cand_deleted[o] = deleted ? 1 : 0;
     // the matcher's record of the candidate (Matcher::findMatchDirect up to the warp, svo_match_device.h): formed here,
     // read by the warp / alignment stages and by the replay
-    const double pxc[2] = {pl.item_px[2 * i], pl.item_px[2 * i + 1]};
     if (view_ok) {
       pl.cand_level_ref[o] = m.obs_level[obs];
       recs[o] = md_geometry_item(mf, T_slot_w, m.kf_slot[m.obs_kf[obs]], m.obs_level[obs], m.obs_px + 2 * (size_t)obs, m.obs_f + 3 * (size_t)obs,
@@ -337,10 +375,10 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan
 // ---- the cell loop of Reprojector::reprojectMap (S/reprojector.cpp:149-166) with reprojectCell (:180-241) replayed over
 // the batch results: per cell the first successful candidate wins, the loop stops after the cell that takes n_matches
 // beyond max_fts; point bookkeeping (:202-215), the frame's new features (:217-231) and the inputs of the pose refinement.
-SVO_DEV void trk_replay_block(const TrkMap& m, const TrkPlan& pl, const TrkFeat& ft, const Cam& cam, const FrameState* __restrict__ sia_state,
-                              const SeedRec* __restrict__ recs, int* __restrict__ cell_winner,
-                              int* __restrict__ cell_cum, int max_fts, int quality_min_fts) {
-  __shared__ int s_part[TRK_TAIL_THREADS];
+__global__ __launch_bounds__(TRK_THREADS) void trk_replay_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, Cam cam, const FrameState* __restrict__ sia_state,
+                                                                 const SeedRec* __restrict__ recs, int* __restrict__ cell_winner,
+                                                                 int* __restrict__ cell_cum, int max_fts, int quality_min_fts) {
+  __shared__ int s_part[TRK_THREADS];
   __shared__ int s_cut, s_changed;
   __shared__ unsigned long long s_trials;
   const int t = threadIdx.x, nt = blockDim.x;
@@ -432,25 +470,13 @@ SVO_DEV void trk_replay_block(const TrkMap& m, const TrkPlan& pl, const TrkFeat&
   }
 }
 
-// where the result block of a frame goes (page-locked host memory mapped into the device)
-struct TrkOut {
-  svo_hip_track_result* res;
-  double *px, *f, *grad;
-  int *level, *point, *pt_type, *pt_failed, *pt_succeeded;
-  uint8_t* edgelet;
-  unsigned long long* done_flag;
-  unsigned long long seq;
-};
-
-// ---- last_frame_ = new_frame_ (frame_handler_mono.cpp:91) and the result block
-SVO_DEV void trk_finish_block(const TrkMap& m, const TrkPlan& pl, const TrkFeat& ft, const TrkLast& last, const Cam& cam, const FrameState* __restrict__ sia_state,
-                              const svo_hip_pose_opt_result* __restrict__ po, const TrkOut& out) {
-  svo_hip_track_result* __restrict__ res = out.res;
-  double* __restrict__ out_px = out.px; double* __restrict__ out_f = out.f; int* __restrict__ out_level = out.level;
-  int* __restrict__ out_point = out.point; uint8_t* __restrict__ out_edgelet = out.edgelet; double* __restrict__ out_grad = out.grad;
-  int* __restrict__ out_pt_type = out.pt_type; int* __restrict__ out_pt_failed = out.pt_failed; int* __restrict__ out_pt_succeeded = out.pt_succeeded;
-  unsigned long long* __restrict__ done_flag = out.done_flag;
-  const unsigned long long seq = out.seq;
+// ---- last_frame_ = new_frame_ (frame_handler_mono.cpp:91) and the result block.  One workgroup.
+__global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, TrkLast last, Cam cam, const FrameState* __restrict__ sia_state,
+                                                         const svo_hip_pose_opt_result* __restrict__ po, svo_hip_track_result* __restrict__ res,
+                                                         double* __restrict__ out_px, double* __restrict__ out_f, int* __restrict__ out_level,
+                                                         int* __restrict__ out_point, uint8_t* __restrict__ out_edgelet, double* __restrict__ out_grad,
+                                                         int* __restrict__ out_pt_type, int* __restrict__ out_pt_failed, int* __restrict__ out_pt_succeeded,
+                                                         unsigned long long* __restrict__ done_flag, unsigned long long seq) {
   __shared__ double s_Tnew[7];
   const int t = threadIdx.x, nt = blockDim.x;
   const int n_feat = pl.counters[4];
@@ -520,30 +546,6 @@ SVO_DEV void trk_finish_block(const TrkMap& m, const TrkPlan& pl, const TrkFeat&
   if (t == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// what the pose refinement of the frame takes besides the frame's features
-struct TrkPose {
-  int max_n, n_iter;
-  double em, reproj_thresh;
-  float* err_ws;
-  double *sq_init_ws, *sq_final_ws;
-  svo_hip_pose_opt_result* po;
-};
-
-// ---- everything of a tracked frame behind the matching stages, in one launch of one workgroup: the cell loop of the
-// reprojector, pose_optimizer::optimizeGaussNewton from the aligned pose (frame_handler_mono.cpp:218-226) and the
-// hand-over with the result block.  Three launches of one workgroup each cost a tracked frame ~8 us of dispatch.
-__global__ __launch_bounds__(TRK_TAIL_THREADS) void trk_tail_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, TrkLast last, Cam cam,
-                                                                    const FrameState* __restrict__ sia_state, const SeedRec* __restrict__ recs,
-                                                                    int* __restrict__ cell_winner, int* __restrict__ cell_cum, int max_fts,
-                                                                    int quality_min_fts, TrkPose pose, TrkOut out) {
-  trk_replay_block(m, pl, ft, cam, sia_state, recs, cell_winner, cell_cum, max_fts, quality_min_fts);
-  __syncthreads();                                                          // (one workgroup, one L1: the frame's features and counters[5] are visible)
-  svo_pose::pose_refine_block(0, pose.max_n, pl.counters + 5, sia_state->T_cur_w, ft.f, ft.pos, ft.level, ft.has_point, pose.em, pose.reproj_thresh,
-                              pose.n_iter, pose.err_ws, pose.sq_init_ws, pose.sq_final_ws, reinterpret_cast<svo_pose::PoseOptOut*>(pose.po));
-  __syncthreads();
-  trk_finish_block(m, pl, ft, last, cam, sia_state, pose.po, out);
-}
-
 // Point::pos_ of n points after the host optimised them: one staged block in, one launch
 __global__ void trk_scatter_positions_kernel(int n, const int* __restrict__ idx, const double* __restrict__ pos, double* __restrict__ pt_pos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -587,8 +589,6 @@ struct svo_hip_tracker {
   bool need_gather = true;                  // the solver's slot 0 does not hold the last frame yet (a host upload came in between)
   bool any_edgelet = false;                 // the map holds EDGELET reference features (align1D stage needed)
   svo_hip_pose_opt_result* po = nullptr;
-  float* po_err_ws = nullptr;               // pose refinement workspace (used beyond 2048 features only)
-  double *po_sq_init_ws = nullptr, *po_sq_final_ws = nullptr;
   // result block: [svo_hip_track_result][px][f][level][point][edgelet][grad][pt_type][pt_failed][pt_succeeded]
   char* res_dev = nullptr;                  // device address of res_host
   char* res_host = nullptr;                 // page-locked, mapped into the device: the hand-over kernel writes it directly
@@ -652,6 +652,7 @@ int svo_hip_tracker_destroy(svo_hip_tracker* t) {
 int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const svo_hip_tracker_config* cfg, svo_hip_tracker** out) {
   if (!ctx || !cam || !cfg || !out) return SVO_HIP_ERR_INVALID;
   *out = nullptr;
+  SVO_REQUIRE(ctx, cfg->max_keyframes <= TRK_LDS_KF);
   SVO_REQUIRE(ctx, cfg->max_keyframes >= 1 && cfg->max_points >= 1 && cfg->max_obs >= 1 && cfg->max_kf_features >= 1 && cfg->max_candidates >= 0);
   SVO_REQUIRE(ctx, cfg->max_items >= 1 && cfg->max_frame_features >= 1 && cfg->max_frame_features <= 2816);
   SVO_REQUIRE(ctx, cfg->n_levels >= 1 && cfg->n_levels <= SVO_HIP_MAX_LEVELS && cfg->klt_max_level < cfg->n_levels && cfg->klt_min_level >= 0 &&
@@ -682,11 +683,10 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
   TrkPlan& pl = t->pl;
   const size_t C = cfg->max_items, NC = t->n_cells;
   pl.cap = cfg->max_items; pl.n_cells = t->n_cells; pl.grid_cols = t->grid_cols; pl.grid_size = cfg->grid_size; pl.max_n_kfs = cfg->reproj_max_n_kfs;
-  D(&pl.kf_close, K); D(&pl.kf_dist, K); D(&pl.first_seq, P); D(&pl.item_point, C); D(&pl.item_px, C * 2); D(&pl.item_cell, C); D(&pl.item_key, C);
-  D(&pl.seg, C); D(&pl.cell_count, NC + 1); D(&pl.cell_fill, NC); D(&pl.counters, 8); D(&pl.cell_offset, NC + 1); D(&pl.overlap_kf, TRK_MAX_SEL);
+  D(&pl.first_seq, P); D(&pl.item_point, C); D(&pl.item_px, C * 2); D(&pl.item_cell, C); D(&pl.item_key, C);
+  D(&pl.seg, C); D(&pl.seg_key, C); D(&pl.cell_count, NC + 1); D(&pl.cell_fill, NC); D(&pl.counters, 8); D(&pl.cell_offset, NC + 1); D(&pl.overlap_kf, TRK_MAX_SEL);
   D(&pl.overlap_count, TRK_MAX_SEL); D(&pl.cand_point, C); D(&pl.cand_obs, C); D(&pl.cand_level_ref, C); D(&pl.cand_deleted, C);
   D(&t->cell_winner, NC + 1); D(&t->cell_cum, NC + 1); D(&t->po, 1);
-  D(&t->po_err_ws, (size_t)cfg->max_frame_features); D(&t->po_sq_init_ws, (size_t)cfg->max_frame_features); D(&t->po_sq_final_ws, (size_t)cfg->max_frame_features);
   const size_t NF = cfg->max_frame_features;
   TrkFeat& ft = t->ft;
   ft.cap = cfg->max_frame_features;
@@ -905,23 +905,21 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   rc = svo_match_stages(ctx, t->kf_pyr, cur, 0, &t->cam, t->pl.cap, t->pl.counters, t->pl.cand_level_ref, recs, pwb_t, n_pad, c.n_pyr_levels,
                         c.align_max_iter, t->any_edgelet);
   if (rc != SVO_HIP_OK) return rc;
-  // ---- the cell loop of the reprojector, pose_optimizer::optimizeGaussNewton(poseOptimThresh, poseOptimNumIter, ...) on the
-  // matched features from the aligned pose, and hand-over + result (written straight into the page-locked block, the
-  // frame's sequence number last): one launch
+  hipLaunchKernelGGL(trk_replay_kernel, dim3(1), dim3(TRK_THREADS), 0, ctx->stream, m, t->pl, t->ft, cam, st, recs, t->cell_winner, t->cell_cum,
+                     c.max_fts, c.quality_min_fts);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  // ---- pose_optimizer::optimizeGaussNewton(poseOptimThresh, poseOptimNumIter, ...) on the matched features, from the aligned pose
+  rc = svo_hip_pose_optimize_batch_dev(ctx, 1, c.max_frame_features, t->pl.counters + 5, st->T_cur_w, t->ft.f, t->ft.pos, t->ft.level, t->ft.has_point,
+                                       fabs(t->cam.fx), c.pose_optim_thresh, c.pose_optim_num_iter, t->po);
+  if (rc != SVO_HIP_OK) return rc;
+  // ---- hand-over + result: written straight into the page-locked block, the frame's sequence number last
   char* rd = t->res_dev;
   const unsigned long long seq = ++t->seq;
-  TrkPose pose;
-  pose.max_n = c.max_frame_features; pose.n_iter = c.pose_optim_num_iter; pose.em = fabs(t->cam.fx); pose.reproj_thresh = c.pose_optim_thresh;
-  pose.err_ws = t->po_err_ws; pose.sq_init_ws = t->po_sq_init_ws; pose.sq_final_ws = t->po_sq_final_ws; pose.po = t->po;
-  TrkOut out;
-  out.res = reinterpret_cast<svo_hip_track_result*>(rd);
-  out.px = reinterpret_cast<double*>(rd + t->o_px); out.f = reinterpret_cast<double*>(rd + t->o_f); out.grad = reinterpret_cast<double*>(rd + t->o_grad);
-  out.level = reinterpret_cast<int*>(rd + t->o_level); out.point = reinterpret_cast<int*>(rd + t->o_point);
-  out.pt_type = reinterpret_cast<int*>(rd + t->o_pt); out.pt_failed = out.pt_type + t->n_points; out.pt_succeeded = out.pt_type + 2 * (size_t)t->n_points;
-  out.edgelet = reinterpret_cast<uint8_t*>(rd + t->o_edge);
-  out.done_flag = reinterpret_cast<unsigned long long*>(rd + t->o_flag); out.seq = seq;
-  hipLaunchKernelGGL(trk_tail_kernel, dim3(1), dim3(TRK_TAIL_THREADS), 0, ctx->stream, m, t->pl, t->ft, t->last, cam, st, recs, t->cell_winner, t->cell_cum,
-                     c.max_fts, c.quality_min_fts, pose, out);
+  hipLaunchKernelGGL(trk_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, m, t->pl, t->ft, t->last, cam, st, t->po,
+                     reinterpret_cast<svo_hip_track_result*>(rd), reinterpret_cast<double*>(rd + t->o_px), reinterpret_cast<double*>(rd + t->o_f),
+                     reinterpret_cast<int*>(rd + t->o_level), reinterpret_cast<int*>(rd + t->o_point), reinterpret_cast<uint8_t*>(rd + t->o_edge),
+                     reinterpret_cast<double*>(rd + t->o_grad), reinterpret_cast<int*>(rd + t->o_pt), reinterpret_cast<int*>(rd + t->o_pt) + t->n_points,
+                     reinterpret_cast<int*>(rd + t->o_pt) + 2 * (size_t)t->n_points, reinterpret_cast<unsigned long long*>(rd + t->o_flag), seq);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   // the one synchronisation of the frame: wait for the sequence number (a spin on host memory: no driver call on the way
   // back), with the stream's own synchronisation as the fall-back and the error check

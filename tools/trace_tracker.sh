@@ -12,8 +12,8 @@ python3 - "$csv" > $root/gpurun_out/${tag}_tracker_trace.txt <<'PY'
 import csv, sys, collections
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-# the last 19 frames: find the last occurrences of trk_tail_kernel
-ends=[i for i,r in enumerate(rows) if 'trk_tail_kernel' in r['Kernel_Name']]
+# the last 19 frames: find the last occurrences of trk_finish_kernel
+ends=[i for i,r in enumerate(rows) if 'trk_finish_kernel' in r['Kernel_Name']]
 lo=ends[-2]+1; hi=ends[-1]+1
 t0=int(rows[lo]['Start_Timestamp'])
 print("one frame, kernels in order (start us, duration us):")
