@@ -663,6 +663,8 @@ constexpr int FUSED_WC_BYTES = TILE * 128;        // interpolated reference patc
 constexpr int FUSED_EXTRA_TILES = 3;              // 8-wave shape: at most this many LDS tiles beyond two per wave
 constexpr int FUSED_MAX_TPW = 6;                  // the older wave's share of a SIMD's 11 tiles
 constexpr int FUSED_EXACT_ROW_BELOW = 16;         // frames with fewer patches: H rows entry by entry (fused_tile_row_exact)
+// instances of a kernel shape: the plain one, the one whose workgroups may take the exact rows, the fast arithmetic
+constexpr int FUSED_PLAIN = 0, FUSED_EXACT_ROWS = 1, FUSED_FAST = 2;
 
 struct FusedLevels {
   int cols[SVO_HIP_MAX_LEVELS], rows[SVO_HIP_MAX_LEVELS];
@@ -674,6 +676,11 @@ struct FusedParams { int max_level, min_level, n_iter, early_stop; double eps; }
 // interpolated value at footprint row pair (R, Rn) and byte column k, with the reference's operation order
 SVO_DEV float interp_at(uint2 R, uint2 Rn, int k, float a_tl, float a_tr, float a_bl, float a_br) {
   return a_tl * byte_f(R, k) + a_tr * byte_f(R, k + 1) + a_bl * byte_f(Rn, k) + a_br * byte_f(Rn, k + 1);
+}
+// the same sum contracted as a compiler with -ffp-contract=on forms it (a product, then three fused multiply-adds: 4
+// operations instead of 7): SVO_HIP_SIA_ARITH_FAST only
+SVO_DEV float interp_at_contracted(uint2 R, uint2 Rn, int k, float a_tl, float a_tr, float a_bl, float a_br) {
+  return __builtin_fmaf(a_br, byte_f(Rn, k + 1), __builtin_fmaf(a_bl, byte_f(Rn, k), __builtin_fmaf(a_tl, byte_f(R, k), a_tr * byte_f(R, k + 1))));
 }
 
 struct LppGeom {
@@ -938,7 +945,7 @@ SVO_DEV void fused_interp_W(const uint2* F, float w_tl, float w_tr, float w_bl, 
 // (tests/test_gpu_parity.py::test_batch_ragged_and_empty) where the factored one returned a finite pose.  The launcher
 // picks the EXACT_ROWS instance of a shape for a batch that holds such a frame; every other frame of that batch still
 // takes the factored rows, so its result does not depend on the company it is launched in.
-template <int NW, int TPW, int CK, bool EXACT_ROWS>
+template <int NW, int TPW, int CK, int VARIANT>
 __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
     const FrameConst* __restrict__ fc, FrameState* __restrict__ st, const uint8_t* __restrict__ ref_base,
     const uint8_t* __restrict__ cur_base, size_t pyr_bytes, FusedLevels lv, int max_n, const double* __restrict__ px,
@@ -993,6 +1000,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   // block-uniform: a frame with a handful of patches takes the entry-by-entry Hessian rows (out of line: fused_tile_row_exact).
   // Only the instances launched for a batch that holds such a frame carry the branch (EXACT_ROWS): it costs the evaluation
   // loop registers -- 36 instead of 20 spilled VGPRs in <8,4,2>, -1.4 % fixed work, -3 % with the reference's exits.
+  constexpr bool EXACT_ROWS = VARIANT == FUSED_EXACT_ROWS;
+  constexpr bool FAST = VARIANT == FUSED_FAST;
   const bool exact_rows = EXACT_ROWS && n < FUSED_EXACT_ROW_BELOW;
   const int n_tiles = (n + TILE - 1) / TILE;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPRs
@@ -1274,6 +1283,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
         // ---- residuals (:238-279): the lane walks the 16 pixels of its own patch; no cross-lane traffic at all.
         // ref value / dx / dy of every pixel are differences of the 32 interpolated values formed once per level.
         double sdx = 0.0, sdy = 0.0;
+        float sdxf = 0.0f, sdyf = 0.0f;
         float chi = 0.0f;
         {
           uint2 Cr[5];
@@ -1300,6 +1310,16 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
               const float refv = W[y + 1][x + 1];                                  // half the reference value
               const float dxv = W[y + 1][x + 2] - W[y + 1][x];                     // = 0.5f * (a - b) of the full values
               const float dyv = W[y + 2][x + 1] - W[y][x + 1];
+              if (FAST) {
+                // SVO_HIP_SIA_ARITH_FAST: contracted interpolation, the patch's chi2 and gradient moments summed in f32
+                // (16 terms; the f64 form spends three conversions and two f64 operations per pixel on them)
+                const float inten = interp_at_contracted(Cr[y], Cr[y + 1], x, g.w_tl, g.w_tr, g.w_bl, g.w_br);
+                const float res = inten - refv;
+                chi = __builtin_fmaf(res, res, chi);
+                sdxf = __builtin_fmaf(dxv, res, sdxf);
+                sdyf = __builtin_fmaf(dyv, res, sdyf);
+                continue;
+              }
               const float inten = interp_at(Cr[y], Cr[y + 1], x, g.w_tl, g.w_tr, g.w_bl, g.w_br);
               const float res = inten - refv;                                      // half the residual
               chi += res * res;
@@ -1311,6 +1331,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           }
         }
         // ---- normal equations
+        if (FAST) { sdx = (double)sdxf; sdy = (double)sdyf; }
         const bool lin = ok && jvalid;
         if (ok) { acc_chi += (double)chi; acc_n += 16; }
         if (lin) {
@@ -1707,7 +1728,7 @@ struct svo_hip_sia {
   bool fc_dirty = true;
   int shard_rank = 0, shard_world = 1;
   // tuning / diagnostic switches of this object (svo_hip_sia_set_option); 0 / -1 = automatic
-  int opt_mode = 0, opt_waves = 0, opt_chunks = 0, opt_extra_lds = -1, opt_old_tiles = 0;
+  int opt_mode = 0, opt_waves = 0, opt_chunks = 0, opt_extra_lds = -1, opt_old_tiles = 0, opt_arith = SVO_HIP_SIA_ARITH_EXACT;
   // stepwise state
   svo_hip_sia_params prm{};
   int n_slots = 0, level = -1, chunks = 1;
@@ -1786,11 +1807,11 @@ int flush_fc(svo_hip_sia* s) {
 }
 
 // One launch of the fused kernel over slots [0, n_launch).
-template <int NW, int TPW, int CK, bool EXACT_ROWS>
+template <int NW, int TPW, int CK, int VARIANT>
 int launch_fused_x(svo_hip_sia* s, int n_launch, const svo_hip_sia_params* prm, size_t lds_bytes, int tiles_young, int n_extra = 0) {
   svo_hip_ctx* ctx = s->ctx;
   // > 64 KiB of dynamic LDS has to be allowed explicitly (per device: set it on every launch, it is cheap)
-  SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<NW, TPW, CK, EXACT_ROWS>),
+  SVO_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sia_fused_kernel<NW, TPW, CK, VARIANT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   FusedLevels lv;
   memset(&lv, 0, sizeof(lv));
@@ -1801,7 +1822,7 @@ int launch_fused_x(svo_hip_sia* s, int n_launch, const svo_hip_sia_params* prm, 
   FusedParams fp;
   fp.max_level = prm->max_level; fp.min_level = prm->min_level; fp.n_iter = prm->n_iter;
   fp.early_stop = prm->early_stop; fp.eps = prm->eps;
-  hipLaunchKernelGGL((sia_fused_kernel<NW, TPW, CK, EXACT_ROWS>), dim3(n_launch), dim3(NW * 64), lds_bytes, ctx->stream, s->fc, s->st,
+  hipLaunchKernelGGL((sia_fused_kernel<NW, TPW, CK, VARIANT>), dim3(n_launch), dim3(NW * 64), lds_bytes, ctx->stream, s->fc, s->st,
                      s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, s->tile_h,
                      s->wmem, s->max_tiles, fp, tiles_young, n_extra);
   SVO_CHECK_HIP(ctx, hipGetLastError());
@@ -1815,7 +1836,7 @@ int fused_extra_tiles_t() {
   if (cached < 0) {
     hipFuncAttributes at;
     cached = 0;
-    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&sia_fused_kernel<8, TPW, CK, false>)) == hipSuccess) {
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&sia_fused_kernel<8, TPW, CK, FUSED_PLAIN>)) == hipSuccess) {
       const long free_b = 160L * 1024 - (long)at.sharedSizeBytes - (long)FUSED_WAVES * CK * FUSED_WC_BYTES;
       cached = free_b > 0 ? (int)(free_b / FUSED_WC_BYTES) : 0;
       if (cached > FUSED_EXTRA_TILES) cached = FUSED_EXTRA_TILES;
@@ -1845,7 +1866,7 @@ int fused_old_share(const svo_hip_sia* s, int max_n, int* per_simd_out) {
 }
 
 // The shape of the fused kernel for a launch of n_launch pairs whose largest frame has max_n patches.
-template <bool EXACT_ROWS>
+template <int VARIANT>
 int launch_fused_shape(svo_hip_sia* s, int n_launch, int max_n, const svo_hip_sia_params* prm) {
   svo_hip_ctx* ctx = s->ctx;
   int per_simd = 1;
@@ -1859,10 +1880,10 @@ int launch_fused_shape(svo_hip_sia* s, int n_launch, int max_n, const svo_hip_si
   if (four) {
     const size_t lds4 = (size_t)4 * (per_simd < 2 ? 1 : 2) * FUSED_WC_BYTES;
     switch (per_simd) {                                                // tiles per wave (3 runs as 4 with an empty slot)
-      case 1: return launch_fused_x<4, 1, 1, EXACT_ROWS>(s, n_launch, prm, lds4, 0);
-      case 2: return launch_fused_x<4, 2, 2, EXACT_ROWS>(s, n_launch, prm, lds4, 0);
+      case 1: return launch_fused_x<4, 1, 1, VARIANT>(s, n_launch, prm, lds4, 0);
+      case 2: return launch_fused_x<4, 2, 2, VARIANT>(s, n_launch, prm, lds4, 0);
       case 3:
-      case 4: return launch_fused_x<4, 4, 2, EXACT_ROWS>(s, n_launch, prm, lds4, 0);
+      case 4: return launch_fused_x<4, 4, 2, VARIANT>(s, n_launch, prm, lds4, 0);
       default: break;
     }
   }
@@ -1875,12 +1896,12 @@ int launch_fused_shape(svo_hip_sia* s, int n_launch, int max_n, const svo_hip_si
   if (n_extra < 0 || n_extra > (tpw > ck ? fused_extra_tiles(tpw, ck) : 0)) n_extra = 0;
   const size_t lds = (size_t)(FUSED_WAVES * ck + n_extra) * FUSED_WC_BYTES;
   switch (tpw) {                 // tiles of an older wave
-    case 1: return launch_fused_x<8, 1, 1, EXACT_ROWS>(s, n_launch, prm, lds, ty);
-    case 2: return launch_fused_x<8, 2, 2, EXACT_ROWS>(s, n_launch, prm, lds, ty);
-    case 3: return launch_fused_x<8, 3, 2, EXACT_ROWS>(s, n_launch, prm, lds, ty, n_extra);
-    case 4: return launch_fused_x<8, 4, 2, EXACT_ROWS>(s, n_launch, prm, lds, ty, n_extra);
-    case 5: return launch_fused_x<8, 5, 2, EXACT_ROWS>(s, n_launch, prm, lds, ty, n_extra);
-    case 6: return launch_fused_x<8, 6, 2, EXACT_ROWS>(s, n_launch, prm, lds, ty, n_extra);
+    case 1: return launch_fused_x<8, 1, 1, VARIANT>(s, n_launch, prm, lds, ty);
+    case 2: return launch_fused_x<8, 2, 2, VARIANT>(s, n_launch, prm, lds, ty);
+    case 3: return launch_fused_x<8, 3, 2, VARIANT>(s, n_launch, prm, lds, ty, n_extra);
+    case 4: return launch_fused_x<8, 4, 2, VARIANT>(s, n_launch, prm, lds, ty, n_extra);
+    case 5: return launch_fused_x<8, 5, 2, VARIANT>(s, n_launch, prm, lds, ty, n_extra);
+    case 6: return launch_fused_x<8, 6, 2, VARIANT>(s, n_launch, prm, lds, ty, n_extra);
     default: break;
   }
   return svo_fail(ctx, SVO_HIP_ERR_INVALID, "fused SparseImgAlign", "unsupported tiles-per-wave");
@@ -1924,7 +1945,10 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) {
   }
   hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
-  rc = tiny ? launch_fused_shape<true>(s, n_slots, max_n, prm) : launch_fused_shape<false>(s, n_slots, max_n, prm);
+  // (the fast arithmetic is an option of the plain instance: a batch with a tiny frame runs in the reference's arithmetic)
+  rc = tiny ? launch_fused_shape<FUSED_EXACT_ROWS>(s, n_slots, max_n, prm)
+            : (s->opt_arith == SVO_HIP_SIA_ARITH_FAST ? launch_fused_shape<FUSED_FAST>(s, n_slots, max_n, prm)
+                                                      : launch_fused_shape<FUSED_PLAIN>(s, n_slots, max_n, prm));
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   return rc;
 }
@@ -2316,6 +2340,7 @@ int svo_hip_sia_set_option(svo_hip_sia* s, int option, int value) {
     case SVO_HIP_SIA_OPT_CHUNKS: SVO_REQUIRE(ctx, value >= 0 && value <= MAX_CHUNKS); s->opt_chunks = value; break;
     case SVO_HIP_SIA_OPT_EXTRA_LDS: SVO_REQUIRE(ctx, value >= -1 && value <= FUSED_EXTRA_TILES); s->opt_extra_lds = value; break;
     case SVO_HIP_SIA_OPT_OLD_TILES: SVO_REQUIRE(ctx, value >= 0 && value <= FUSED_MAX_TPW); s->opt_old_tiles = value; break;
+    case SVO_HIP_SIA_OPT_ARITH: SVO_REQUIRE(ctx, value == SVO_HIP_SIA_ARITH_EXACT || value == SVO_HIP_SIA_ARITH_FAST); s->opt_arith = value; break;
     default: return svo_fail(ctx, SVO_HIP_ERR_INVALID, "svo_hip_sia_set_option", "unknown option");
   }
   return SVO_HIP_OK;

@@ -521,6 +521,7 @@ def main():
 
         # ---- secondary measurements, outside the timed region (rank 0, one GPU, default workload)
         early = None
+        fast = None
         jac = None
         upl = None
         if not allreduce and world == 1 and not args.no_secondary and not args.early_stop:
@@ -544,6 +545,30 @@ def main():
                      "pose_err_vs_cpu_ref": {"rot_rad": rot_es, "trans_m": trans_es},
                      "pose_err_vs_ground_truth": dict(zip(("rot_rad", "trans_m"), synth.pose_error(np.array(r_es.T_cur_w), fps[0].T_cur_w_true)))}
             assert rot_es < 1e-4 and trans_es < 1e-3, "early-stop pose parity violated: %g rad %g m" % (rot_es, trans_es)
+            # (1b) the same batch, fixed work, with the opt-in fast arithmetic of the fused kernel (SVO_HIP_SIA_ARITH_FAST:
+            # contracted interpolation, f32 sums over a patch's 16 pixels), every distinct scene against the CPU oracle
+            sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_FAST)
+            try:
+                for _ in range(2):
+                    sia.run(n_slots, prm)
+                ctx.sync()
+                fa_steps = max(5, min(args.steps, 20))
+                t1 = time.perf_counter()
+                for _ in range(fa_steps):
+                    sia.run(n_slots, prm)
+                ctx.sync()
+                dt_fa = time.perf_counter() - t1
+                r_fa = sia.download_all(n_slots)
+            finally:
+                sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_EXACT)
+            fa_err = np.array([synth.pose_error(np.array(r_fa[i].T_cur_w), np.array(oracle_res[i].T_cur_w)) for i in range(n_scenes)])
+            fast = {"what": "the timed workload with svo_hip_sia_set_option(SVO_HIP_SIA_OPT_ARITH, SVO_HIP_SIA_ARITH_FAST): opt-in, not the "
+                            "reference's arithmetic (`value` above is the exact flavour)",
+                    "value": n_slots * fa_steps / dt_fa, "unit": "frames/s", "steps": fa_steps, "ms_per_step": dt_fa / fa_steps * 1e3,
+                    "pose_err_vs_cpu_ref": {"scenes_checked": int(n_scenes), "max_rot_rad_over_scenes": float(fa_err[:, 0].max()),
+                                            "max_trans_m_over_scenes": float(fa_err[:, 1].max()), "tolerance": "1e-4 rad / 1e-3 m",
+                                            "n_tracked_equal_in_every_scene": bool(all(int(r_fa[i].n_tracked) == int(oracle_res[i].n_tracked) for i in range(n_scenes)))}}
+            assert fa_err[:, 0].max() < 1e-4 and fa_err[:, 1].max() < 1e-3, "fast-arithmetic pose parity violated: %s" % fa_err.max(axis=0)
             # (2) the streaming implementation of the Jacobian / residual pass: the HBM-bound form (north_star: >= 50 % of the HBM roofline)
             sia.set_mode(stream=True)           # an option of this solver object (svo_hip_sia_set_option), not a process-wide switch
             try:
@@ -634,6 +659,7 @@ def main():
             "cpu_baseline": cpu,
             "roofline_jacobian_pass": jac,
             "reference_semantics": early,
+            "fast_arithmetic": fast,
             "with_image_uploads": upl,
             "c2": c2,
             "c4_one_gpu": c4,

@@ -206,8 +206,18 @@ int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
 #define SVO_HIP_SIA_OPT_CHUNKS 2        /* streaming residual kernel: workgroups per frame, 0 (automatic) .. 64 */
 #define SVO_HIP_SIA_OPT_EXTRA_LDS 3     /* fused kernel: waves with a third tile in LDS, -1 (automatic) .. 3 */
 #define SVO_HIP_SIA_OPT_OLD_TILES 4     /* fused kernel: tiles of the older wave of a SIMD, 0 (automatic) .. 6 */
+#define SVO_HIP_SIA_OPT_ARITH 5         /* fused kernel: SVO_HIP_SIA_ARITH_EXACT (default) or SVO_HIP_SIA_ARITH_FAST */
 #define SVO_HIP_SIA_MODE_AUTO 0
 #define SVO_HIP_SIA_MODE_STREAM 1
+/* EXACT: the reference's arithmetic statement by statement -- uncontracted f32 interpolation, residual products and
+ * Jacobian moments in f64 (sparse_img_align.cpp:238-279): poses agree with the CPU path to ~1e-13.
+ * FAST: the bilinear sum contracted (one product + three fused multiply-adds), a patch's chi2 and its two gradient
+ * moments summed in f32 over its 16 pixels; everything else (projection, pixel choice, normal equations, solve) unchanged.
+ * Poses then agree with the CPU path to ~1e-8 rad / 1e-8 m on the test scenes (tests assert 1e-6; north_star allows
+ * 1e-4 rad / 1e-3 m) and the solve runs ~10 % faster.  Applies to the fused kernel; a batch with a frame of fewer than 16
+ * patches and the streaming / sharded paths always use EXACT. */
+#define SVO_HIP_SIA_ARITH_EXACT 0
+#define SVO_HIP_SIA_ARITH_FAST 1
 int svo_hip_sia_set_option(svo_hip_sia* sia, int option, int value);
 
 /* Which implementation the last svo_hip_sia_run used: 1 = the fused kernel (one workgroup per frame pair,

@@ -851,6 +851,57 @@ def test_sparse_img_align_against_reference_run(ctx, sia_mode, golden, case):
     _free(sia, ref, cur)
 
 
+@pytest.mark.parametrize("case", _ref_cases(), ids=[c[0] for c in _ref_cases()])
+def test_fast_arithmetic_against_reference_run(ctx, golden, case):
+    """SVO_HIP_SIA_ARITH_FAST (contracted interpolation, f32 sums over a patch's 16 pixels: opt-in, fused kernel) against
+    SparseImgAlign::run executed by the reference's own code: within the north-star tolerance always, within 1e-6 of the
+    reference where the evaluation sequence is the same (observed 1e-8), counters exact."""
+    from oracle import gen_golden
+    name, kw, max_level, min_level, n_iter = case
+    g = golden("sia_ref.npz")
+    fp = gen_golden.make_sia_case(kw)
+    ref, cur, sia = _upload_pair(ctx, [fp], max_feat=max(len(fp.px), 1))
+    sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_FAST)
+    prm = sia.params(max_level=max_level, min_level=min_level, n_iter=n_iter, eps=1e-6, early_stop=True)
+    sia.run(1, prm)
+    assert sia.last_run_mode() == 1
+    r = sia.download(0)
+    rot, trans = synth.pose_error(np.array(r.T_cur_w), g[name + "_T"])
+    assert rot < 1e-4 and trans < 1e-3, (rot, trans)            # north_star tolerance
+    assert int(r.stop) == int(g[name + "_stop"])
+    if len(fp.px):
+        same_iters = all(r.iters[l] == int(g[name + "_iter"][l]) + 1 for l in range(min_level, max_level + 1))
+        if same_iters:
+            assert r.n_tracked == int(g[name + "_n_tracked"])
+            assert rot < 1e-6 and trans < 1e-6, (rot, trans)
+            H = np.array(r.H)
+            assert np.abs(H - g[name + "_H"]).max() <= 1e-6 * np.abs(g[name + "_H"]).max()   # H does not depend on the residuals
+    _free(sia, ref, cur)
+
+
+def test_fast_arithmetic_close_to_exact_on_the_bench_scene(ctx):
+    """The two arithmetic flavours of the fused kernel on bench-sized frames (2000 patches, L4..L0, fixed 30 evaluations
+    per level): same patches tracked, poses within 1e-6 of each other (observed 1e-8), and both within the north-star
+    tolerance of the oracle."""
+    fps = [synth.make_frame_pair(seed=4100 + i, n_features=2000) for i in range(3)]
+    poses = {}
+    for arith in (hip.SIA_ARITH_EXACT, hip.SIA_ARITH_FAST):
+        ref, cur, sia = _upload_pair(ctx, fps)
+        sia.set_option(hip.SIA_OPT_ARITH, arith)
+        sia.run(len(fps), sia.params(early_stop=False))
+        assert sia.last_run_mode() == 1
+        poses[arith] = [(np.array(sia.download(i).T_cur_w), sia.download(i).n_tracked) for i in range(len(fps))]
+        _free(sia, ref, cur)
+    for i, fp in enumerate(fps):
+        (Te, ne), (Tf, nf) = poses[hip.SIA_ARITH_EXACT][i], poses[hip.SIA_ARITH_FAST][i]
+        assert ne == nf
+        rot, trans = synth.pose_error(Tf, Te)
+        assert rot < 1e-6 and trans < 1e-6, (rot, trans)
+        o = orc.sparse_img_align(fp, early_stop=False)
+        rot, trans = synth.pose_error(Tf, o.T_cur_w)
+        assert rot < 1e-4 and trans < 1e-3, (rot, trans)
+
+
 def test_find_epipolar_match_direct_against_reference_fixture(ctx, golden):
     """svo_hip_epipolar_match_batch_dev against Matcher::findEpipolarMatchDirect executed by the reference's own code on
     real frames (epi_ref.npz: 600 seeds, four kinds of depth interval, 21 failures): the return value, the search level
