@@ -2,6 +2,8 @@
 // the DepthFilter protocol synchronously, then again with its worker thread while the main thread keeps
 // aligning frames (two host threads, two svo_hip contexts, as in the reference: SURVEY 8b "Threading").
 // Usage: svo_host_demo <case_dir> <out_dir>      (inputs written by tests/test_gpu_host_cpp.py)
+//        svo_host_demo <case_dir> <out_dir> track   the tracking chain: svo::FrameTracker (hip_bridge::FrameTrackerT on this
+//                                                   file's data model) over a map built as an object graph from index tables
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -53,9 +55,149 @@ static void dump_filter(DepthFilter& df, const std::map<Feature*, int>& index, c
   write_bin(out + "/" + tag + "_conv.bin", conv);
 }
 
+// ---- svo::FrameTracker over a svo::Map: the object graph (frames, features, points with their observation lists,
+// point candidates) is built from the index tables the test wrote, the frames are tracked one after the other (each
+// tracked frame is the next one's last frame), and what the tracker left on the objects is written out as tables again.
+static int track_demo(const std::string& dir, const std::string& out) {
+  const std::vector<double> m = read_bin<double>(dir + "/track_manifest.bin");
+  PinholeCamera cam{(int)m[0], (int)m[1], m[2], m[3], m[4], m[5]};
+  const int n_kf = (int)m[6], n_points = (int)m[7], n_obs = (int)m[8], n_cand = (int)m[10], n_frames = (int)m[11];
+  const auto kf_pose = read_bin<double>(dir + "/kf_pose.bin"), pt_pos = read_bin<double>(dir + "/pt_pos.bin");
+  const auto pt_type = read_bin<int32_t>(dir + "/pt_type.bin"), pt_failed = read_bin<int32_t>(dir + "/pt_n_failed.bin"),
+             pt_succ = read_bin<int32_t>(dir + "/pt_n_succeeded.bin"), pt_obs_offset = read_bin<int32_t>(dir + "/pt_obs_offset.bin"),
+             obs_point = read_bin<int32_t>(dir + "/obs_point.bin"), obs_kf = read_bin<int32_t>(dir + "/obs_kf.bin"),
+             obs_level = read_bin<int32_t>(dir + "/obs_level.bin"), kf_ftr_offset = read_bin<int32_t>(dir + "/kf_ftr_offset.bin"),
+             kf_ftr_obs = read_bin<int32_t>(dir + "/kf_ftr_obs.bin"), cand_obs = read_bin<int32_t>(dir + "/cand_obs.bin");
+  const auto obs_px = read_bin<double>(dir + "/obs_px.bin"), obs_f = read_bin<double>(dir + "/obs_f.bin"), obs_grad = read_bin<double>(dir + "/obs_grad.bin");
+  const auto obs_edgelet = read_bin<uint8_t>(dir + "/obs_edgelet.bin");
+  if ((int)obs_point.size() != n_obs || (int)pt_type.size() != n_points || (int)cand_obs.size() != n_cand) throw std::runtime_error("track case: table sizes");
+
+  Map map;
+  std::vector<std::unique_ptr<Point>> points;
+  std::map<const Point*, int> index_of_point;
+  for (int p = 0; p < n_points; ++p) {
+    points.emplace_back(new Point(Vector3d{{pt_pos[3 * p], pt_pos[3 * p + 1], pt_pos[3 * p + 2]}}));
+    points.back()->type_ = (Point::PointType)pt_type[p];
+    points.back()->n_failed_reproj_ = pt_failed[p];
+    points.back()->n_succeeded_reproj_ = pt_succ[p];
+    index_of_point[points.back().get()] = p;
+  }
+  std::vector<FramePtr> kfs;
+  for (int k = 0; k < n_kf; ++k) {
+    std::vector<std::vector<uint8_t>> pyr;
+    pyr.push_back(read_bin<uint8_t>(dir + "/kf_" + std::to_string(k) + "_img.bin"));
+    kfs.push_back(std::make_shared<Frame>(&cam, std::move(pyr)));
+    kfs.back()->T_f_w_ = SE3(&kf_pose[7 * (size_t)k]);
+  }
+  std::vector<Feature*> feature_of_obs((size_t)n_obs, nullptr);
+  auto make_obs_feature = [&](int o) {
+    Feature* ftr = new Feature(kfs[obs_kf[o]].get(), Vector2d{{obs_px[2 * o], obs_px[2 * o + 1]}},
+                               Vector3d{{obs_f[3 * o], obs_f[3 * o + 1], obs_f[3 * o + 2]}}, obs_level[o]);
+    if (obs_edgelet[o]) { ftr->type = Feature::EDGELET; ftr->grad = Vector2d{{obs_grad[2 * o], obs_grad[2 * o + 1]}}; }
+    ftr->point = points[obs_point[o]].get();
+    feature_of_obs[o] = ftr;
+    return ftr;
+  };
+  for (int k = 0; k < n_kf; ++k)                                               // Frame::fts_ in the keyframe's own order
+    for (int j = kf_ftr_offset[k]; j < kf_ftr_offset[k + 1]; ++j) kfs[k]->addFeature(make_obs_feature(kf_ftr_obs[j]));
+  for (int c = 0; c < n_cand; ++c) {                                           // candidates: one feature each, in no fts_
+    Feature* ftr = make_obs_feature(cand_obs[c]);
+    map.point_candidates_.candidates_.push_back(MapPointCandidates::PointCandidate(ftr->point, ftr));
+  }
+  for (int p = 0; p < n_points; ++p)                                           // Point::obs_ in table order
+    for (int o = pt_obs_offset[p]; o < pt_obs_offset[p + 1]; ++o)
+      if (feature_of_obs[o]) points[p]->obs_.push_back(feature_of_obs[o]);
+  for (int k = 0; k < n_kf; ++k) { kfs[k]->setKeyframe(); map.addKeyframe(kfs[k]); }
+  auto key_table = [&]() {
+    std::vector<int32_t> key;
+    for (int k = 0; k < n_kf; ++k)
+      for (int j = 0; j < 5; ++j) { const Feature* kp = kfs[k]->key_pts_[j]; key.push_back(kp && kp->point ? index_of_point.at(kp->point) : -1); }
+    return key;
+  };
+  write_bin(out + "/track_key_before.bin", key_table());
+
+  svo_hip_tracker_config cfg;
+  svo_hip_tracker_default_config(&cfg);
+  cfg.max_keyframes = n_kf > 1 ? n_kf : 1; cfg.grid_size = (int)m[12]; cfg.max_fts = (int)m[13]; cfg.quality_min_fts = (int)m[14];
+  cfg.klt_min_level = (int)m[15]; cfg.max_frame_features = (int)m[16];
+  FrameTracker tracker(cam, cfg);
+  if (!tracker.ok()) throw std::runtime_error("svo::FrameTracker: no device tracker");
+
+  // the last frame: a keyframe of the map, or a frame of its own without features (SparseImgAlign::run then returns at once)
+  const int last_kf = (int)m[17];
+  FramePtr last;
+  if (last_kf >= 0) {
+    last = kfs[last_kf];
+  } else {
+    std::vector<std::vector<uint8_t>> pyr;
+    pyr.push_back(read_bin<uint8_t>(dir + "/last_img.bin"));
+    last = std::make_shared<Frame>(&cam, std::move(pyr));
+    last->T_f_w_ = SE3(read_bin<double>(dir + "/last_pose.bin").data());
+  }
+  std::vector<double> poses, stats, overlap;
+  for (int k = 0; k < n_frames; ++k) {
+    std::vector<std::vector<uint8_t>> pyr;
+    pyr.push_back(read_bin<uint8_t>(dir + "/trk_frame_" + std::to_string(k) + ".bin"));
+    FramePtr cur = std::make_shared<Frame>(&cam, std::move(pyr));
+    std::vector<std::pair<FramePtr, size_t>> overlap_kfs;
+    FrameTracker::Outcome oc;
+    if (!tracker.track(last, cur, map, overlap_kfs, oc)) throw std::runtime_error("svo::FrameTracker::track failed at frame " + std::to_string(k));
+    poses.insert(poses.end(), cur->T_f_w_.p, cur->T_f_w_.p + 7);
+    stats.insert(stats.end(), {(double)cur->fts_.size(), (double)oc.repr_n_matches, (double)oc.repr_n_trials, (double)oc.img_align_n_tracked,
+                               oc.pose_optimised ? 1.0 : 0.0, (double)oc.sfba_n_edges_final, oc.sfba_error_init, oc.sfba_error_final, (double)overlap_kfs.size()});
+    std::vector<double> fpx, fgrad;
+    std::vector<int32_t> flevel, fpoint;
+    std::vector<uint8_t> fedge;
+    for (const Feature* ftr : cur->fts_) {
+      fpx.push_back(ftr->px[0]); fpx.push_back(ftr->px[1]);
+      fgrad.push_back(ftr->grad[0]); fgrad.push_back(ftr->grad[1]);
+      flevel.push_back(ftr->level);
+      fpoint.push_back(ftr->point ? index_of_point.at(ftr->point) : -1);
+      fedge.push_back(ftr->type == Feature::EDGELET ? 1 : 0);
+    }
+    const std::string tag = out + "/track_feat_" + std::to_string(k);
+    write_bin(tag + "_px.bin", fpx); write_bin(tag + "_grad.bin", fgrad); write_bin(tag + "_level.bin", flevel);
+    write_bin(tag + "_point.bin", fpoint); write_bin(tag + "_edgelet.bin", fedge);
+    if (k == 0)
+      for (const auto& ov : overlap_kfs) {
+        int idx = -1;
+        for (int j = 0; j < n_kf; ++j) if (kfs[j] == ov.first) idx = j;
+        overlap.push_back((double)idx); overlap.push_back((double)ov.second);
+      }
+    if (k == 0) {                                                              // the map's points as the first frame left them
+      std::vector<int32_t> st;
+      for (int p = 0; p < n_points; ++p) { st.push_back((int32_t)points[p]->type_); st.push_back(points[p]->n_failed_reproj_); st.push_back(points[p]->n_succeeded_reproj_); }
+      write_bin(out + "/track_points_after_first.bin", st);
+      write_bin(out + "/track_key_after_first.bin", key_table());
+      std::vector<int32_t> linked;                                             // features that still refer to their point, per observation
+      for (int o = 0; o < n_obs; ++o) {
+        // (a deleted candidate's feature is gone: its observation counts as unlinked)
+        bool cand_alive = true;
+        if (points[obs_point[o]]->type_ == Point::TYPE_DELETED && pt_type[obs_point[o]] == (int)Point::TYPE_CANDIDATE) cand_alive = false;
+        linked.push_back(cand_alive && feature_of_obs[o] && feature_of_obs[o]->point != nullptr ? 1 : 0);
+      }
+      write_bin(out + "/track_obs_linked_after_first.bin", linked);
+    }
+    last = cur;
+  }
+  write_bin(out + "/track_poses.bin", poses);
+  write_bin(out + "/track_stats.bin", stats);
+  write_bin(out + "/track_overlap_first.bin", overlap);
+  std::printf("svo_host_demo track OK\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 3) { std::fprintf(stderr, "usage: %s case_dir out_dir\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s case_dir out_dir [track]\n", argv[0]); return 2; }
   const std::string dir = argv[1], out = argv[2];
+  if (argc > 3 && std::string(argv[3]) == "track") {
+    try {
+      return track_demo(dir, out);
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "svo_host_demo FAILED: %s\n", e.what());
+      return 1;
+    }
+  }
   try {
     const std::vector<double> m = read_bin<double>(dir + "/manifest.bin");   // w h fx fy cx cy n_levels n_frames
     Case c;

@@ -6,10 +6,16 @@
 // reference's real headers are include/svo_dropin/ (compile-checked only); this file is
 // their executable counterpart.  DepthFilter::updateSeeds is NOT a second copy: both sides instantiate
 // hip_bridge::updateSeedsBatched (include/svo_dropin/depth_filter_batch.h) with a small Host policy, so the
-// batching / ordering / halt logic the GPU tests exercise is the code the drop-in ships.  Host logic here:
+// batching / ordering / halt logic the GPU tests exercise is the code the drop-in ships.  The same holds for the tracking
+// chain: svo::FrameTracker here and in include/svo_dropin/frame_tracker_hip.h are both hip_bridge::FrameTrackerT
+// (frame_tracker_batch.h) -- the flattening of svo::Map's pointer graph into the tracker's index tables and the write-back
+// of a frame's outcome (features, counters, Map::safeDeletePoint) run on the GPU from this file's Map / Frame / Point.
+// Host logic here:
 //   * SparseImgAlign::run       S/sparse_img_align.cpp:51-92   (flatten fts_, upload, run, read back)
 //   * DepthFilter protocol      S/depth_filter.cpp:47-229,237-357 (thread, 3-deep frame queue, keyframe
 //                               hand-off with the halt flag, std::list<Seed>, age-out, convergence callback)
+//   * Map / Frame bookkeeping   S/map.cpp:78-99,256-304 (safeDeletePoint, deleteCandidatePoint), S/frame.cpp:67-165
+//                               (setKeyframe, addFeature, setKeyPoints / checkKeyPoints / removeKeyPoint)
 // Host threads: the tracking thread and the depth-filter thread each own a svo_hip_ctx (one stream each).
 #ifndef SVO_HOST_H_
 #define SVO_HOST_H_
@@ -31,6 +37,7 @@
 
 #include "svo_hip.h"
 #include "svo_dropin/depth_filter_batch.h"
+#include "svo_dropin/frame_tracker_batch.h"
 
 namespace svo {
 
@@ -78,14 +85,20 @@ struct PinholeCamera {            // distortion-free vk::PinholeCamera
 
 struct Feature;
 struct Point {                                      // I/point.h: position + the features that observe it
+  enum PointType { TYPE_DELETED, TYPE_CANDIDATE, TYPE_UNKNOWN, TYPE_GOOD };      // I/point.h:33-38
   Vector3d pos_;
   std::list<Feature*> obs_;
+  PointType type_ = TYPE_UNKNOWN;
+  int n_failed_reproj_ = 0, n_succeeded_reproj_ = 0;                             // the reprojector's counters (I/point.h:49-50)
   explicit Point(const Vector3d& p) : pos_(p) {}
   Point(const Vector3d& p, Feature* ftr) : pos_(p) { obs_.push_front(ftr); }     // S/point.cpp:39-48
 };
 struct Frame;
 struct Feature {
+  enum FeatureType { CORNER, EDGELET };                                          // I/feature.h:26-29
+  FeatureType type = CORNER;
   Frame* frame; Vector2d px; Vector3d f; int level; Point* point;
+  Vector2d grad{{1.0, 0.0}};                                                     // edgelets: direction of the gradient, normalised
   Feature(Frame* fr, const Vector2d& px_, const Vector3d& f_, int lvl) : frame(fr), px(px_), f(f_), level(lvl), point(nullptr) {}
 };
 
@@ -96,11 +109,41 @@ struct Frame {
   SE3 T_f_w_;
   std::vector<std::vector<uint8_t>> img_pyr_;      // level l: (w>>l) x (h>>l), stride == cols
   std::list<Feature*> fts_;
+  std::vector<Feature*> key_pts_ = std::vector<Feature*>(5, nullptr);   // five features spread over the image: the keyframe's overlap test
+  std::array<double, 36> Cov_{};                   // covariance of the refined pose (pose_optimizer.cpp:141)
   bool is_keyframe_ = false;
   Frame(const PinholeCamera* cam, std::vector<std::vector<uint8_t>> pyr) : id_(frame_counter_++), cam_(cam), img_pyr_(std::move(pyr)) {}
   ~Frame() { for (Feature* f : fts_) delete f; }
   bool isKeyframe() const { return is_keyframe_; }
-  void setKeyframe() { is_keyframe_ = true; }
+  void setKeyframe() { is_keyframe_ = true; setKeyPoints(); }                    // S/frame.cpp:67-71
+  void addFeature(Feature* ftr) { fts_.push_back(ftr); }                         // :75-78
+
+  /// S/frame.cpp:83-92: key features whose point is gone are dropped, then every feature with a point competes again
+  void setKeyPoints() {
+    for (Feature*& k : key_pts_) if (k != nullptr && k->point == nullptr) k = nullptr;
+    for (Feature* ftr : fts_) if (ftr->point != nullptr) checkKeyPoints(ftr);
+  }
+  /// :98-149.  Slot 0: the feature closest to the image centre (max norm).  Slots 1..4: per quadrant the feature with the
+  /// largest product (x - cu)(y - cv); the two left quadrants test x against cv, not cu, as the reference does (:133,142).
+  void checkKeyPoints(Feature* ftr) {
+    const int cu = cam_->width / 2, cv = cam_->height / 2;
+    const double x = ftr->px[0], y = ftr->px[1];
+    auto off_centre = [&](const Feature* g) { return std::max(std::fabs(g->px[0] - cu), std::fabs(g->px[1] - cv)); };
+    auto product = [&](const Feature* g) { return (g->px[0] - cu) * (g->px[1] - cv); };
+    if (key_pts_[0] == nullptr || off_centre(ftr) < off_centre(key_pts_[0])) key_pts_[0] = ftr;
+    const bool in_quadrant[4] = {x >= cu && y >= cv, x >= cu && y < cv, x < cv && y < cv, x < cv && y >= cv};
+    for (int q = 0; q < 4; ++q) {
+      if (!in_quadrant[q]) continue;
+      Feature*& slot = key_pts_[1 + q];
+      if (slot == nullptr || product(ftr) > product(slot)) slot = ftr;
+    }
+  }
+  /// :154-165
+  void removeKeyPoint(Feature* ftr) {
+    bool found = false;
+    for (Feature*& k : key_pts_) if (k == ftr) { k = nullptr; found = true; }
+    if (found) setKeyPoints();
+  }
 };
 inline int Frame::frame_counter_ = 0;
 typedef std::shared_ptr<Frame> FramePtr;
@@ -134,6 +177,76 @@ class PyramidCache {
   svo_hip_ctx* ctx_; svo_hip_pyramid* pyr_ = nullptr; int capacity_, next_ = 0; std::vector<int> ids_;
 };
 }  // namespace hip_bridge
+
+/// I/map.h:34-66, S/map.cpp:256-304: converged seeds that no keyframe holds yet
+struct MapPointCandidates {
+  typedef std::pair<Point*, Feature*> PointCandidate;
+  typedef std::list<PointCandidate> PointCandidateList;
+  std::mutex mut_;
+  PointCandidateList candidates_;
+  std::list<Point*> trash_points_;
+  ~MapPointCandidates() {
+    for (PointCandidate& c : candidates_) delete c.second;
+  }
+  bool deleteCandidatePoint(Point* point) {                                      // S/map.cpp:256-269, :297-304
+    std::unique_lock<std::mutex> lock(mut_);
+    for (auto it = candidates_.begin(); it != candidates_.end(); ++it) {
+      if (it->first != point) continue;
+      delete it->second;                           // the candidate's only feature
+      it->first->type_ = Point::TYPE_DELETED;
+      trash_points_.push_back(it->first);
+      candidates_.erase(it);
+      return true;
+    }
+    return false;
+  }
+};
+
+/// I/map.h:69-130: keyframes + the candidates; points are owned through the features that refer to them
+struct Map {
+  std::list<FramePtr> keyframes_;
+  std::list<Point*> trash_points_;
+  MapPointCandidates point_candidates_;
+  void addKeyframe(FramePtr kf) { keyframes_.push_back(kf); }                    // S/map.cpp:96-99
+  void deletePoint(Point* pt) { pt->type_ = Point::TYPE_DELETED; trash_points_.push_back(pt); }   // :90-94
+  /// :78-88: every observation lets go of the point (a keyframe that loses a key feature picks its key features again)
+  void safeDeletePoint(Point* pt) {
+    for (Feature* ftr : pt->obs_) { ftr->point = nullptr; ftr->frame->removeKeyPoint(ftr); }
+    pt->obs_.clear();
+    deletePoint(pt);
+  }
+};
+
+/// Host policy of hip_bridge::FrameTrackerT on this file's data model (the drop-in instantiates the same template on the
+/// reference's types: include/svo_dropin/frame_tracker_hip.h)
+struct HostTrackerPolicy {
+  typedef svo::Frame Frame;
+  typedef svo::FramePtr FramePtr;
+  typedef svo::Feature Feature;
+  typedef svo::Point Point;
+  typedef svo::Map Map;
+  typedef std::list<svo::Feature*> FeatureList;
+  typedef MapPointCandidates::PointCandidateList CandidateList;
+  static void pose7(const Frame& fr, double T[7]) { std::memcpy(T, fr.T_f_w_.p, sizeof(double) * 7); }
+  static void setPose(Frame& fr, const double T[7]) { fr.T_f_w_ = SE3(T); }
+  static const uint8_t* level0(const Frame& fr, int* stride, int* cols, int* rows) {
+    *stride = fr.cam_->width; *cols = fr.cam_->width; *rows = fr.cam_->height;
+    return fr.img_pyr_[0].data();
+  }
+  static Feature* makeFeature(Frame* fr, const double px[2], const double f[3], int level) {
+    return new Feature(fr, Vector2d{{px[0], px[1]}}, Vector3d{{f[0], f[1], f[2]}}, level);
+  }
+  static void setEdgelet(Feature& ftr, const double g[2]) { ftr.type = Feature::EDGELET; ftr.grad = Vector2d{{g[0], g[1]}}; }
+  static bool isEdgelet(const Feature& ftr) { return ftr.type == Feature::EDGELET; }
+  static void setCov(Frame& fr, const double cov[36]) { std::memcpy(fr.Cov_.data(), cov, sizeof(double) * 36); }
+};
+
+/// The first half of FrameHandlerMono::processFrame (frame_handler_mono.cpp:171-229) in one device call per frame: the
+/// executable twin of include/svo_dropin/frame_tracker_hip.h.  cfg: svo_hip_tracker_default_config + the caller's values.
+class FrameTracker : public hip_bridge::FrameTrackerT<HostTrackerPolicy> {
+ public:
+  FrameTracker(const PinholeCamera& cam, const svo_hip_tracker_config& cfg) : hip_bridge::FrameTrackerT<HostTrackerPolicy>(cam.toC(), cfg) {}
+};
 
 /// I/sparse_img_align.h:33-79
 class SparseImgAlign {

@@ -3,19 +3,16 @@
 // (svo_hip_tracker_track: one stream, one synchronisation; the aligned pose, the candidates and the matches never leave
 // the device between the stages, the frame's matches are the next call's reference features).
 //
-// What this header does is the host side the reference keeps: it flattens the pointer graph of svo::Map into the index
-// tables the tracker walks (when the map has changed), hands the new image over, and applies the outcome to the
-// reference's own objects with the reference's own functions -- new_frame_->T_f_w_, frame->addFeature(new Feature(...)),
-// the points' reprojection counters and types, Map::safeDeletePoint / MapPointCandidates::deleteCandidatePoint for the
-// points the reprojector gave up on, overlap_kfs_ -- so that everything behind the call (structure optimisation,
-// keyframe selection, depth filter, map maintenance) runs unchanged on the same data it would have had.
+// The host logic -- flattening svo::Map into the tracker's index tables, applying a frame's outcome to the reference's own
+// objects with the reference's own functions -- is hip_bridge::FrameTrackerT (frame_tracker_batch.h); this header
+// instantiates it on the reference's types.  The same template runs on the GPU against the self-contained twins of those
+// types (android_svo_amd/host/svo_host.h, tests/test_gpu_host_cpp.py).
 // INTEGRATION.md shows the edit of processFrame; `make -C oracle dropin-check` compiles this file against the
 // reference's headers.
 #ifndef SVO_FRAME_TRACKER_HIP_H_
 #define SVO_FRAME_TRACKER_HIP_H_
 
-#include <map>
-#include <vector>
+#include <algorithm>
 
 #include <svo/config.h>
 #include <svo/feature.h>
@@ -23,23 +20,40 @@
 #include <svo/map.h>
 #include <svo/point.h>
 
+#include "frame_tracker_batch.h"
 #include "svo_hip_bridge.h"
 
 namespace svo {
 namespace hip_bridge {
 
-class FrameTracker {
- public:
-  struct Outcome {
-    size_t img_align_n_tracked;      // SparseImgAlign::run (:188)
-    size_t repr_n_matches, repr_n_trials;       // reprojector_.n_matches_ / n_trials_ (:206-207)
-    bool pose_optimised;             // false: fewer than Config::qualityMinFts() matches, processFrame returns RESULT_FAILURE (:208-215)
-    size_t sfba_n_edges_final;       // pose_optimizer's num_obs (:226-229)
-    double sfba_thresh, sfba_error_init, sfba_error_final;
-  };
-
-  explicit FrameTracker(vk::AbstractCamera* cam, int max_keyframes = 256)
-      : ctx_(0), trk_(NULL), cam_(cam), map_dirty_(true), have_last_(false), next_slot_(0) {
+/// Host policy of FrameTrackerT on the reference's data model
+struct SvoTrackerHost {
+  typedef svo::Frame Frame;
+  typedef svo::FramePtr FramePtr;
+  typedef svo::Feature Feature;
+  typedef svo::Point Point;
+  typedef svo::Map Map;
+  typedef svo::Features FeatureList;
+  typedef svo::MapPointCandidates::PointCandidateList CandidateList;
+  static void pose7(const Frame& fr, double T[7]) { toPose7(fr.T_f_w_, T); }
+  static void setPose(Frame& fr, const double T[7]) { fr.T_f_w_ = fromPose7(T); }
+  static const uint8_t* level0(const Frame& fr, int* stride, int* cols, int* rows) {
+    const cv::Mat& img = fr.img_pyr_[0];
+    *stride = (int)img.step.p[0]; *cols = img.cols; *rows = img.rows;
+    return img.data;
+  }
+  static Feature* makeFeature(Frame* fr, const double px[2], const double f[3], int level) {
+    return new Feature(fr, Vector2d(px[0], px[1]), Vector3d(f[0], f[1], f[2]), level);
+  }
+  static void setEdgelet(Feature& ftr, const double g[2]) { ftr.type = Feature::EDGELET; ftr.grad = Vector2d(g[0], g[1]); }
+  static bool isEdgelet(const Feature& ftr) { return ftr.type == Feature::EDGELET; }
+  static void setCov(Frame& fr, const double cov[36]) {
+    Matrix<double, 6, 6> c;
+    for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) c(a, b) = cov[6 * a + b];
+    fr.Cov_ = c;
+  }
+  /// svo_hip_tracker_config from svo::Config (the values processFrame's stages read)
+  static svo_hip_tracker_config config(int max_keyframes) {
     svo_hip_tracker_config cfg;
     svo_hip_tracker_default_config(&cfg);
     cfg.max_keyframes = max_keyframes;
@@ -48,212 +62,14 @@ class FrameTracker {
     cfg.grid_size = (int)Config::gridSize(); cfg.max_fts = (int)Config::maxFts(); cfg.quality_min_fts = (int)Config::qualityMinFts();
     cfg.n_pyr_levels = (int)Config::nPyrLevels();
     cfg.pose_optim_thresh = Config::poseOptimThresh(); cfg.pose_optim_num_iter = (int)Config::poseOptimNumIter();
-    const svo_hip_camera c = toCamera(cam);
-    if (ctx_.ok() && svo_hip_tracker_create(ctx_.get(), &c, &cfg, &trk_) != SVO_HIP_OK) trk_ = NULL;
-    cfg_ = cfg;
+    return cfg;
   }
-  ~FrameTracker() { if (trk_) svo_hip_tracker_destroy(trk_); }
-  bool ok() const { return trk_ != NULL; }
+};
 
-  /// the map changed behind the tracker's back (keyframe added / removed, points optimised or deleted, candidates added):
-  /// flatten it again before the next frame.  processFrame calls this after map_.addKeyframe, optimizeStructure etc.
-  void mapChanged() { map_dirty_ = true; }
-  /// FrameHandlerBase::optimizeStructure moved points of `frame` (frame_handler_base.cpp:190-210): push their positions
-  /// (the tables keep their indices, nothing else of the map changed)
-  bool pointsOptimised(const Frame& frame) {
-    if (!trk_ || map_dirty_) return trk_ != NULL;              // a full upload is pending anyway
-    std::vector<int32_t> idx;
-    std::vector<double> pos;
-    for (Features::const_iterator it = frame.fts_.begin(); it != frame.fts_.end(); ++it) {
-      if ((*it)->point == NULL) continue;
-      std::map<const Point*, int>::const_iterator pi = index_of_point_.find((*it)->point);
-      if (pi == index_of_point_.end()) continue;
-      idx.push_back(pi->second);
-      pos.push_back((*it)->point->pos_[0]); pos.push_back((*it)->point->pos_[1]); pos.push_back((*it)->point->pos_[2]);
-    }
-    return svo_hip_tracker_update_point_positions(trk_, (int)idx.size(), idx.data(), pos.data()) == SVO_HIP_OK;
-  }
-  /// last_frame_ was set by somebody else (initialisation, relocalisation)
-  void lastFrameChanged() { have_last_ = false; }
-
-  /// new_frame->T_f_w_ = last_frame->T_f_w_; SparseImgAlign::run; Reprojector::reprojectMap; pose_optimizer::optimizeGaussNewton.
-  /// Returns false on a device error (the caller treats the frame as a tracking failure).
-  bool track(const FramePtr& last_frame, const FramePtr& new_frame, Map& map,
-             std::vector<std::pair<FramePtr, size_t> >& overlap_kfs, Outcome& out) {
-    if (!trk_) return false;
-    if (map_dirty_ && !uploadMap(map)) return false;
-    if (!have_last_ && !uploadLastFrame(*last_frame)) return false;
-    const cv::Mat& img = new_frame->img_pyr_[0];
-    std::vector<uint8_t> packed;
-    const uint8_t* level0 = img.data;
-    if ((int)img.step.p[0] != img.cols) {                    // the kernels assume stride == cols
-      packed.resize((size_t)img.rows * img.cols);
-      for (int y = 0; y < img.rows; ++y) memcpy(&packed[(size_t)y * img.cols], img.data + (size_t)y * img.step.p[0], img.cols);
-      level0 = packed.data();
-    }
-    const size_t cap = (size_t)cfg_.max_frame_features, np = points_.size();
-    f_px_.resize(cap * 2); f_f_.resize(cap * 3); f_level_.resize(cap); f_point_.resize(cap); f_edge_.resize(cap); f_grad_.resize(cap * 2);
-    p_type_.resize(np + 1); p_failed_.resize(np + 1); p_succ_.resize(np + 1);
-    svo_hip_track_result r;
-    if (svo_hip_tracker_track(trk_, level0, &r, f_px_.data(), f_f_.data(), f_level_.data(), f_point_.data(), f_edge_.data(), f_grad_.data(),
-                              p_type_.data(), p_failed_.data(), p_succ_.data()) != SVO_HIP_OK)
-      return false;
-    // ---- what processFrame would have found on its objects after the three stages
-    new_frame->T_f_w_ = fromPose7(r.T_f_w);
-    for (int i = 0; i < r.n_features; ++i) {                 // Reprojector::reprojectCell :217-231
-      Feature* ftr = new Feature(new_frame.get(), Vector2d(f_px_[2 * i], f_px_[2 * i + 1]),
-                                 Vector3d(f_f_[3 * i], f_f_[3 * i + 1], f_f_[3 * i + 2]), f_level_[i]);
-      ftr->point = f_point_[i] >= 0 ? points_[f_point_[i]] : NULL;       // NULL: dropped by the pose refinement (pose_optimizer.cpp:154-157)
-      if (f_edge_[i]) { ftr->type = Feature::EDGELET; ftr->grad = Vector2d(f_grad_[2 * i], f_grad_[2 * i + 1]); }
-      new_frame->addFeature(ftr);
-    }
-    overlap_kfs.clear();
-    for (int i = 0; i < r.n_overlap; ++i) overlap_kfs.push_back(std::make_pair(keyframes_[r.overlap_kf[i]], (size_t)r.overlap_count[i]));
-    // point bookkeeping (:126-133, :202-215): counters and promotions as numbers, deletions through the map's own functions
-    for (size_t p = 0; p < np; ++p) {
-      Point* pt = points_[p];
-      const bool deleted_now = p_type_[p] == (int)Point::TYPE_DELETED && pt->type_ != Point::TYPE_DELETED;
-      pt->n_failed_reproj_ = p_failed_[p];
-      pt->n_succeeded_reproj_ = p_succ_[p];
-      if (!deleted_now) { pt->type_ = (Point::PointType)p_type_[p]; continue; }
-      if (pt->type_ == Point::TYPE_CANDIDATE) map.point_candidates_.deleteCandidatePoint(pt);
-      else map.safeDeletePoint(pt);
-    }
-    if (r.map_changed) map_dirty_ = true;                    // feature references and key points changed with the deletions
-    out.img_align_n_tracked = (size_t)r.sia_n_tracked;
-    out.repr_n_matches = (size_t)r.n_matches; out.repr_n_trials = (size_t)r.n_trials;
-    out.pose_optimised = r.pose.ran != 0;
-    out.sfba_n_edges_final = (size_t)r.pose.num_obs;
-    out.sfba_thresh = r.pose.estimated_scale; out.sfba_error_init = r.pose.error_init; out.sfba_error_final = r.pose.error_final;
-    if (r.pose.ran) {
-      Matrix<double, 6, 6> cov;
-      for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) cov(a, b) = r.pose.Cov[6 * a + b];
-      new_frame->Cov_ = cov;
-    }
-    have_last_ = true;                                       // the device handed the frame over to itself
-    return true;
-  }
-
-  /// new_frame_->setKeyframe(); map_.addKeyframe(new_frame_) (:284-330): keep the frame's pyramid on the device as a keyframe
-  bool lastFrameBecameKeyframe(const Frame& frame) {
-    const int slot = next_slot_++ % cfg_.max_keyframes;
-    slot_of_frame_[frame.id_] = slot;
-    map_dirty_ = true;
-    return svo_hip_tracker_keyframe_from_last_frame(trk_, slot) == SVO_HIP_OK;
-  }
-
- private:
-  bool uploadLastFrame(const Frame& last) {
-    std::vector<double> px, f;
-    std::vector<int32_t> pt;
-    for (Features::const_iterator it = last.fts_.begin(); it != last.fts_.end(); ++it) {
-      px.push_back((*it)->px[0]); px.push_back((*it)->px[1]);
-      f.push_back((*it)->f[0]); f.push_back((*it)->f[1]); f.push_back((*it)->f[2]);
-      std::map<const Point*, int>::const_iterator pi = index_of_point_.find((*it)->point);
-      pt.push_back((*it)->point && pi != index_of_point_.end() ? pi->second : -1);
-    }
-    double T[7];
-    toPose7(last.T_f_w_, T);
-    std::map<int, int>::const_iterator si = slot_of_frame_.find(last.id_);
-    const cv::Mat& img = last.img_pyr_[0];
-    const bool from_slot = si != slot_of_frame_.end();
-    if (!from_slot && (int)img.step.p[0] != img.cols) return false;
-    if (svo_hip_tracker_set_last_frame(trk_, from_slot ? NULL : img.data, from_slot ? si->second : -1, T, (int)pt.size(), px.data(), f.data(),
-                                       pt.data()) != SVO_HIP_OK)
-      return false;
-    have_last_ = true;
-    return true;
-  }
-
-  /// svo::Map -> index tables (Map::keyframes_ order, fts_ order, Point::obs_ order, candidates_ order)
-  bool uploadMap(Map& map) {
-    keyframes_.assign(map.keyframes_.begin(), map.keyframes_.end());
-    points_.clear(); index_of_point_.clear();
-    std::map<int, int> index_of_frame;
-    std::vector<int32_t> kf_slot, key, ftr_off(1, 0), ftr_pt, ty, nf, ns, obs_off(1, 0), obs_kf, obs_level, cand;
-    std::vector<double> T, pos, obs_px, obs_f, obs_grad;
-    std::vector<uint8_t> obs_edge;
-    struct Local {
-      static int pointIndex(Point* p, std::vector<Point*>& pts, std::map<const Point*, int>& idx) {
-        std::map<const Point*, int>::iterator it = idx.find(p);
-        if (it != idx.end()) return it->second;
-        const int i = (int)pts.size();
-        pts.push_back(p); idx[p] = i;
-        return i;
-      }
-    };
-    for (size_t k = 0; k < keyframes_.size(); ++k) {
-      const Frame& kf = *keyframes_[k];
-      index_of_frame[kf.id_] = (int)k;
-      std::map<int, int>::const_iterator si = slot_of_frame_.find(kf.id_);
-      if (si == slot_of_frame_.end()) {                      // a keyframe the device has not seen (initialisation): upload its image
-        const cv::Mat& img = kf.img_pyr_[0];
-        if ((int)img.step.p[0] != img.cols) return false;
-        const int slot = next_slot_++ % cfg_.max_keyframes;
-        if (svo_hip_tracker_upload_keyframe(trk_, slot, img.data) != SVO_HIP_OK) return false;
-        slot_of_frame_[kf.id_] = slot;
-        si = slot_of_frame_.find(kf.id_);
-      }
-      kf_slot.push_back(si->second);
-      double Tk[7];
-      toPose7(kf.T_f_w_, Tk);
-      T.insert(T.end(), Tk, Tk + 7);
-      for (Features::const_iterator it = kf.fts_.begin(); it != kf.fts_.end(); ++it)
-        if ((*it)->point != NULL) ftr_pt.push_back(Local::pointIndex((*it)->point, points_, index_of_point_));
-      ftr_off.push_back((int32_t)ftr_pt.size());
-      for (size_t j = 0; j < 5; ++j) {
-        const Feature* kp = j < kf.key_pts_.size() ? kf.key_pts_[j] : NULL;
-        key.push_back(kp && kp->point ? Local::pointIndex(kp->point, points_, index_of_point_) : -1);
-      }
-    }
-    {
-      std::unique_lock<std::mutex> lock(map.point_candidates_.mut_);
-      for (MapPointCandidates::PointCandidateList::iterator it = map.point_candidates_.candidates_.begin();
-           it != map.point_candidates_.candidates_.end(); ++it)
-        cand.push_back(Local::pointIndex(it->first, points_, index_of_point_));
-    }
-    for (size_t p = 0; p < points_.size(); ++p) {
-      const Point* pt = points_[p];
-      pos.push_back(pt->pos_[0]); pos.push_back(pt->pos_[1]); pos.push_back(pt->pos_[2]);
-      ty.push_back((int)pt->type_); nf.push_back(pt->n_failed_reproj_); ns.push_back(pt->n_succeeded_reproj_);
-      for (std::list<Feature*>::const_iterator it = pt->obs_.begin(); it != pt->obs_.end(); ++it) {
-        std::map<int, int>::const_iterator fi = index_of_frame.find((*it)->frame->id_);
-        if (fi == index_of_frame.end()) continue;            // an observation in a frame that is not (yet / any more) a keyframe of the map
-        obs_kf.push_back(fi->second);
-        obs_px.push_back((*it)->px[0]); obs_px.push_back((*it)->px[1]);
-        obs_f.push_back((*it)->f[0]); obs_f.push_back((*it)->f[1]); obs_f.push_back((*it)->f[2]);
-        obs_level.push_back((*it)->level);
-        obs_edge.push_back((*it)->type == Feature::EDGELET ? 1 : 0);
-        obs_grad.push_back((*it)->grad[0]); obs_grad.push_back((*it)->grad[1]);
-      }
-      obs_off.push_back((int32_t)obs_kf.size());
-    }
-    svo_hip_tracker_map m;
-    m.n_kf = (int)keyframes_.size(); m.kf_slot = kf_slot.data(); m.T_kf_w = T.data(); m.kf_key_point = key.data();
-    m.kf_ftr_offset = ftr_off.data(); m.kf_ftr_point = ftr_pt.data();
-    m.n_points = (int)points_.size(); m.pt_pos = pos.data(); m.pt_type = ty.data(); m.pt_n_failed = nf.data(); m.pt_n_succeeded = ns.data();
-    m.pt_obs_offset = obs_off.data(); m.obs_kf = obs_kf.data(); m.obs_px = obs_px.data(); m.obs_f = obs_f.data(); m.obs_level = obs_level.data();
-    m.obs_edgelet = obs_edge.data(); m.obs_grad = obs_grad.data();
-    m.n_candidates = (int)cand.size(); m.cand_point = cand.data();
-    if (svo_hip_tracker_set_map(trk_, &m) != SVO_HIP_OK) return false;
-    map_dirty_ = false;
-    have_last_ = false;                                      // point indices changed: the last frame's features refer to them
-    return true;
-  }
-
-  Context ctx_;
-  svo_hip_tracker* trk_;
-  svo_hip_tracker_config cfg_;
-  vk::AbstractCamera* cam_;
-  bool map_dirty_, have_last_;
-  int next_slot_;
-  std::vector<FramePtr> keyframes_;
-  std::vector<Point*> points_;
-  std::map<const Point*, int> index_of_point_;
-  std::map<int, int> slot_of_frame_;                         // Frame::id_ -> keyframe pyramid slot
-  std::vector<double> f_px_, f_f_, f_grad_;
-  std::vector<int32_t> f_level_, f_point_, p_type_, p_failed_, p_succ_;
-  std::vector<uint8_t> f_edge_;
+class FrameTracker : public FrameTrackerT<SvoTrackerHost> {
+ public:
+  explicit FrameTracker(vk::AbstractCamera* cam, int max_keyframes = 256)
+      : FrameTrackerT<SvoTrackerHost>(toCamera(cam), SvoTrackerHost::config(max_keyframes)) {}
 };
 
 }  // namespace hip_bridge

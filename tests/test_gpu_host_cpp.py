@@ -146,3 +146,137 @@ def test_cpp_host_layer_end_to_end(tmp_path):
     np.testing.assert_array_equal(np.fromfile(out / "sync_seeds.bin"), np.fromfile(out / "sync_small_seeds.bin"))
     np.testing.assert_array_equal(np.fromfile(out / "sync_conv.bin"), np.fromfile(out / "sync_small_conv.bin"))
     assert summary[0] >= 1                                     # the main thread really aligned frames meanwhile
+
+
+# ---- svo::FrameTracker (hip_bridge::FrameTrackerT, the template the drop-in instantiates on the reference's types) run on
+# ---- the GPU over a svo::Map built as an object graph
+def _write_track_case(case, cs, frames, cfg, last_kf=-1, last_img=None, last_pose=None):
+    cam = cs["cam"]
+    n_kf, n_points = int(cs["n_kf"]), int(cs["n_points"])
+    _write(case / "track_manifest.bin",
+           [cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, n_kf, n_points, len(cs["obs_point"]), len(cs["kf_ftr_obs"]), len(cs["cand_obs"]),
+            len(frames), cfg["grid_size"], cfg["max_fts"], cfg["quality_min_fts"], cfg["klt_min_level"], cfg["max_frame_features"], last_kf], np.float64)
+    for k in range(n_kf):
+        _write(case / ("kf_%d_img.bin" % k), cs["kf_pyr"][k][0], np.uint8)
+    _write(case / "kf_pose.bin", cs["T_kf_w"], np.float64)
+    for name, dt in (("pt_pos", np.float64), ("pt_type", np.int32), ("pt_n_failed", np.int32), ("pt_n_succeeded", np.int32), ("pt_obs_offset", np.int32),
+                     ("obs_point", np.int32), ("obs_kf", np.int32), ("obs_px", np.float64), ("obs_f", np.float64), ("obs_level", np.int32),
+                     ("obs_edgelet", np.uint8), ("obs_grad", np.float64), ("kf_ftr_offset", np.int32), ("kf_ftr_obs", np.int32), ("cand_obs", np.int32)):
+        _write(case / (name + ".bin"), cs[name], dt)
+    for k, img in enumerate(frames):
+        _write(case / ("trk_frame_%d.bin" % k), img, np.uint8)
+    if last_kf < 0:
+        _write(case / "last_img.bin", last_img, np.uint8)
+        _write(case / "last_pose.bin", last_pose, np.float64)
+
+
+def _run_track_demo(case, out):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([DEMO, str(case), str(out), "track"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    return lambda name, dt: np.fromfile(out / name, dtype=dt)
+
+
+def test_cpp_frame_tracker_twenty_frame_sequence(tmp_path):
+    """The tracking sequence of tests/test_gpu_tracker.py through the C++ host twin: a svo::Map with one keyframe whose
+    features hold the map points, svo::FrameTracker::track frame after frame (each tracked svo::Frame, with the svo::Feature
+    objects the tracker added to it, is the next call's last frame).  Poses, features and match counts of every frame are
+    those of the Python-driven svo_hip_tracker chain -- bit for bit: both sides hand the C-ABI the same tables."""
+    import tracking_chain as tc
+    from android_svo_amd import hip
+    assert os.path.exists(DEMO)
+    case, out = tmp_path / "case", tmp_path / "out"
+    case.mkdir(); out.mkdir()
+    seq = tc.make_sequence(n_frames=20)
+    mp = tc.sequence_map(seq)
+    n = len(seq["px0"])
+    cs = dict(mp, obs_point=np.arange(n, dtype=np.int32), kf_ftr_obs=np.arange(n, dtype=np.int32), cand_obs=np.zeros(0, np.int32))
+    cfg = dict(grid_size=tc.CELL, max_fts=tc.MAX_FTS, quality_min_fts=40, klt_min_level=2, max_frame_features=1024)
+    _write_track_case(case, cs, [seq["pyrs"][k][0] for k in range(1, 20)], cfg, last_kf=0)
+    rd = _run_track_demo(case, out)
+    np.testing.assert_array_equal(rd("track_key_before.bin", np.int32).reshape(1, 5), mp["kf_key_point"])       # Frame::setKeyPoints of the twin
+    ctx = hip.Context(0)
+    trk = hip.Tracker(ctx, seq["cam"], max_keyframes=2, grid_size=tc.CELL, max_fts=tc.MAX_FTS, klt_min_level=2, max_frame_features=1024)
+    trk.upload_keyframe(0, seq["pyrs"][0][0])
+    trk.set_map(mp)
+    trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)
+    poses = rd("track_poses.bin", np.float64).reshape(-1, 7)
+    stats = rd("track_stats.bin", np.float64).reshape(-1, 9)
+    assert len(poses) == 19
+    for k in range(1, 20):
+        r = trk.track(seq["pyrs"][k][0])
+        np.testing.assert_array_equal(poses[k - 1], r["T_f_w"])
+        assert stats[k - 1, 0] == len(r["feat_px"]) and stats[k - 1, 1] == r["n_matches"] and stats[k - 1, 2] == r["n_trials"]
+        assert stats[k - 1, 3] == int(r["result"].sia_n_tracked) and stats[k - 1, 4] == 1 and stats[k - 1, 5] == int(r["result"].pose.num_obs)
+        np.testing.assert_array_equal(rd("track_feat_%d_px.bin" % (k - 1), np.float64).reshape(-1, 2), r["feat_px"])
+        np.testing.assert_array_equal(rd("track_feat_%d_point.bin" % (k - 1), np.int32), r["feat_point"])
+        np.testing.assert_array_equal(rd("track_feat_%d_level.bin" % (k - 1), np.int32), r["feat_level"])
+    err = np.array([synth.pose_error(a, t) for a, t in zip(poses, seq["truth"][1:])])
+    assert err[:, 0].max() < 2e-3 and err[:, 1].max() < 5e-3
+    trk.destroy(); ctx.close()
+
+
+def test_cpp_frame_tracker_on_a_map_with_deletions(tmp_path):
+    """svo::FrameTracker on the 14-keyframe map of the reprojection fixture (tests/golden/reproject_map_ref.npz, recorded from
+    the reference's own compiled Reprojector::reprojectMap on a real svo::Map): the twin flattens its object graph (keyframe
+    feature lists, observation lists, point candidates, key points) into the tracker's tables, and applies the outcome --
+    matches, counters, type promotions, and the deletions through Map::safeDeletePoint / deleteCandidatePoint -- to its
+    objects.  Everything the fixture holds must come out equal; then the map is flattened again (it changed) and a second
+    frame is tracked against it."""
+    from test_oracle_reproject_map import CASES, GOLD
+    assert os.path.exists(DEMO)
+    case, out = tmp_path / "case", tmp_path / "out"
+    case.mkdir(); out.mkdir()
+    tag, kw, max_fts = CASES[0]
+    g = np.load(GOLD)
+    cs = synth.make_map_case(**kw)
+    cfg = dict(grid_size=cs["cell_size"], max_fts=max_fts, quality_min_fts=20, klt_min_level=2, max_frame_features=2048)
+    # the second frame: the same scene a small step further (make_map_case's own scene; the same image twice would make the
+    # alignment's update exactly zero, for which SE3::exp returns a NaN translation -- in the reference too)
+    scene = synth.PlaneScene(seed=kw.get("seed", 31), depth=2.0, tilt=(0.08, -0.05))
+    T2 = synth.se3_mul(synth.se3_from_twist([0.012, -0.006, 0.004], [0.002, -0.003, 0.001]), cs["T_cur_w"])
+    img2 = scene.render(cs["cam"], T2)
+    _write_track_case(case, cs, [cs["cur_pyr"][0], img2], cfg, last_kf=-1, last_img=cs["cur_pyr"][0], last_pose=cs["T_cur_w"])
+    rd = _run_track_demo(case, out)
+    n_kf, n_points = cs["n_kf"], cs["n_points"]
+    # Frame::setKeyPoints of the twin == the reference's (the fixture's key points)
+    np.testing.assert_array_equal(rd("track_key_before.bin", np.int32).reshape(n_kf, 5), g[tag + "_kf_key_point"])
+    stats = rd("track_stats.bin", np.float64).reshape(-1, 9)
+    assert [int(stats[0, 1]), int(stats[0, 2])] == [int(v) for v in g[tag + "_n"]]
+    # the features Reprojector::reprojectCell created, in creation order (the pose refinement may have dropped some points)
+    np.testing.assert_array_equal(rd("track_feat_0_px.bin", np.float64).reshape(-1, 2).view(np.uint64), g[tag + "_feat_px"].view(np.uint64))
+    np.testing.assert_array_equal(rd("track_feat_0_level.bin", np.int32), g[tag + "_feat_level"])
+    fp = rd("track_feat_0_point.bin", np.int32)
+    assert ((fp == g[tag + "_feat_point"]) | (fp == -1)).all() and (fp >= 0).sum() >= 0.8 * len(fp)
+    np.testing.assert_array_equal(rd("track_feat_0_edgelet.bin", np.uint8), g[tag + "_feat_type"].astype(np.uint8))
+    assert rd("track_feat_0_grad.bin", np.float64).tobytes() == g[tag + "_feat_grad"].tobytes()
+    # the map's points as the first frame left them: counters, promotions, deletions
+    st = rd("track_points_after_first.bin", np.int32).reshape(n_points, 3)
+    np.testing.assert_array_equal(st[:, 0], g[tag + "_type"])
+    np.testing.assert_array_equal(st[:, 1], g[tag + "_n_failed"])
+    np.testing.assert_array_equal(st[:, 2], g[tag + "_n_succeeded"])
+    deleted_now = (st[:, 0] == synth.TYPE_DELETED) & (cs["pt_type"] != synth.TYPE_DELETED)
+    assert deleted_now.sum() > 0
+    np.testing.assert_array_equal(deleted_now.astype(np.uint8), g[tag + "_unlinked"].astype(np.uint8))
+    # safeDeletePoint: every observation of a deleted point let go of it, all others still refer to theirs
+    linked = rd("track_obs_linked_after_first.bin", np.int32)
+    np.testing.assert_array_equal(linked == 0, deleted_now[cs["obs_point"]])
+    # overlap keyframes of the first frame (:110-113)
+    ov = rd("track_overlap_first.bin", np.float64).reshape(-1, 2).astype(np.int64)
+    np.testing.assert_array_equal(ov[:, 0], g[tag + "_overlap_kf"][:len(ov)])
+    np.testing.assert_array_equal(ov[:, 1], g[tag + "_overlap_count"][:len(ov)])
+    # removeKeyPoint / setKeyPoints after the deletions: no key feature refers to a deleted point, and a keyframe that lost one
+    # chose again among its remaining features
+    key_after = rd("track_key_after_first.bin", np.int32).reshape(n_kf, 5)
+    assert not deleted_now[key_after[key_after >= 0]].any()
+    for k in range(n_kf):
+        o = cs["kf_ftr_obs"][cs["kf_ftr_offset"][k]:cs["kf_ftr_offset"][k + 1]]
+        alive = ~deleted_now[cs["obs_point"][o]]
+        expect = synth.key_points(cs["cam"], cs["obs_px"][o], alive)
+        if (key_after[k] != g[tag + "_kf_key_point"][k]).any():                 # the keyframe lost a key feature: all five were chosen again
+            np.testing.assert_array_equal(key_after[k], np.where(expect >= 0, cs["obs_point"][o][np.maximum(expect, 0)], -1))
+    # the second frame: tracked against the re-flattened map from the first one's features
+    assert stats[1, 4] == 1 and stats[1, 1] >= 0.8 * stats[0, 1] and stats[1, 3] > 0.5 * stats[0, 0], stats
+    poses = rd("track_poses.bin", np.float64).reshape(-1, 7)
+    rot, trans = synth.pose_error(poses[1], T2)
+    assert rot < 3e-3 and trans < 1e-2, (rot, trans)                            # the second frame's true pose
