@@ -147,3 +147,53 @@ def test_update_point_positions_equals_a_fresh_map(ctx):
     np.testing.assert_array_equal(a["feat_point"], b["feat_point"])
     assert a["feat_px"].tobytes() == b["feat_px"].tobytes()
     assert a["n_matches"] == b["n_matches"] and a["n_trials"] == b["n_trials"]
+
+
+def _key_points_of(cs):
+    """Frame::setKeyPoints of every keyframe of a map case, as point indices (synth.key_points == the reference's on all
+    keyframes of the fixture cases)"""
+    key = np.full((cs["n_kf"], 5), -1, np.int32)
+    for k in range(cs["n_kf"]):
+        o = cs["kf_ftr_obs"][cs["kf_ftr_offset"][k]:cs["kf_ftr_offset"][k + 1]]
+        e = synth.key_points(cs["cam"], cs["obs_px"][o], np.ones(len(o), bool))
+        key[k] = np.where(e >= 0, cs["obs_point"][o][np.maximum(e, 0)], -1)
+    return key
+
+
+@pytest.mark.parametrize("tag,kw,max_fts", [
+    ("many_cells", dict(seed=41, cell_size=4), 1200),                            # 80 x 60 = 4800 cells: cell counters in global memory
+    ("many_candidates", dict(seed=42, n_points=6000, n_candidates=400, cell_size=10), 1200),   # > 2048 candidates in the frame: sort keys in global memory
+    ("both", dict(seed=43, n_points=6000, n_candidates=300, cell_size=5, edgelet_frac=0.1), 300),
+    ("few", dict(seed=44, n_kf=3, n_points=120, n_candidates=10, cell_size=40), 1200)])
+def test_reprojection_stage_beyond_and_below_the_lds_limits(ctx, tag, kw, max_fts):
+    """The planning kernel keeps its cell counters and per-cell sort keys in LDS for grids of <= 2048 cells and frames of
+    <= 2048 candidates, in global memory beyond: maps on either side of both limits against the oracle's
+    Reprojector::reprojectMap (itself pinned by the reference's own compiled code, tests/test_oracle_reproject_map.py) --
+    every integer equal, pixels and gradients bitwise."""
+    cs = synth.make_map_case(**kw)
+    key = _key_points_of(cs)
+    ro = orc.reproject_map(cs, key, max_fts=max_fts)
+    trk = _tracker_for(ctx, cs, key, max_fts=max_fts, quality_min_fts=20, max_frame_features=2816)
+    n_cells = trk.n_cells
+    trk.set_last_frame(cs["T_cur_w"], np.zeros((0, 2)), np.zeros((0, 3)), np.zeros(0, np.int32), img=cs["cur_pyr"][0])
+    r = trk.track(cs["cur_pyr"][0])
+    n_cand = int(r["result"].n_candidates)
+    if tag in ("many_cells", "both"):
+        assert n_cells > 2048
+    if tag in ("many_candidates", "both"):
+        assert n_cand > 2048
+    if tag == "few":
+        assert n_cells <= 2048 and n_cand <= 2048
+    assert r["result"].items_overflow == 0
+    assert [int(r["n_matches"]), int(r["n_trials"])] == [int(ro["n_matches"]), int(ro["n_trials"])]
+    np.testing.assert_array_equal(r["overlap_kf"], ro["overlap_kf"])
+    np.testing.assert_array_equal(r["overlap_count"], ro["overlap_count"])
+    dropped = r["feat_point"] < 0                                                # by the pose refinement, after the reprojector
+    np.testing.assert_array_equal(np.where(dropped, ro["feat_point"], r["feat_point"]), ro["feat_point"])
+    np.testing.assert_array_equal(r["feat_level"], ro["feat_level"])
+    np.testing.assert_array_equal(r["feat_type"], ro["feat_type"])
+    assert np.asarray(r["feat_px"], dtype=np.float64).tobytes() == np.asarray(ro["feat_px"], dtype=np.float64).tobytes()
+    assert np.asarray(r["feat_grad"], dtype=np.float64).tobytes() == np.asarray(ro["feat_grad"], dtype=np.float64).tobytes()
+    for k in ("type", "n_failed", "n_succeeded"):
+        np.testing.assert_array_equal(r[k], ro[k], err_msg=k)
+    trk.destroy()
