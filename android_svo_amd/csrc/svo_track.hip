@@ -581,6 +581,8 @@ struct svo_hip_tracker {
   int n_kf = 0, n_points = 0, n_candidates = 0;
   bool have_map = false, map_stale = false, have_last = false;
   int last_n_host = 0;
+  int last_max_point = -1;                  // largest map point index the last frame's features refer to (set_last_frame input)
+  bool last_from_track = false;             // ... or: the last frame is the previous call's new frame, its features are in the result block
   // plan / replay scratch
   TrkPlan pl{};
   TrkFeat ft{};
@@ -702,7 +704,9 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
   if (rc == SVO_HIP_OK) memset(t->res_host, 0, t->res_bytes);
   if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->img_host, (size_t)cam->width * cam->height + 64, hipHostMallocMapped) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
   if (rc == SVO_HIP_OK && hipHostGetDevicePointer((void**)&t->img_dev, t->img_host, 0) != hipSuccess) rc = SVO_HIP_ERR_DEVICE;
-  t->map_host_bytes = K * (56 + 4 + 20 + 4) + 8 + F * 4 + P * (24 + 12 + 4) + 8 + O * (4 + 16 + 24 + 4 + 1 + 16) + CN * 4 + 1024;
+  // staging area of svo_hip_tracker_set_map: every table at its capacity (T_kf_w and T_slot_w: two pose tables), 16 bytes of
+  // alignment slack per table
+  t->map_host_bytes = K * (56 + 56 + 4 + 20 + 4) + 8 + F * 4 + P * (24 + 12 + 4) + 8 + O * (4 + 16 + 24 + 4 + 1 + 16) + CN * 4 + 32 * 16;
   if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->map_host, t->map_host_bytes, hipHostMallocDefault) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
   if (rc != SVO_HIP_OK) { svo_hip_tracker_destroy(t); return rc; }
   (void)hipMemsetAsync(t->last.n, 0, sizeof(int), ctx->stream);
@@ -740,6 +744,17 @@ int svo_hip_tracker_set_map(svo_hip_tracker* t, const svo_hip_tracker_map* mp) {
   SVO_REQUIRE(ctx, n_ftr >= 0 && n_ftr <= c.max_kf_features && n_obs >= 0 && n_obs <= c.max_obs);
   SVO_REQUIRE(ctx, n_ftr == 0 || mp->kf_ftr_point);
   SVO_REQUIRE(ctx, n_obs == 0 || (mp->obs_kf && mp->obs_px && mp->obs_f && mp->obs_level));
+  if (t->have_last) {
+    // the last frame's features keep referring to map points by index: a map with fewer points than the largest of them
+    // needs svo_hip_tracker_set_last_frame again (the result block still holds the features of a tracked frame)
+    int max_point = t->last_max_point;
+    if (t->last_from_track) {
+      const int32_t* fp = reinterpret_cast<const int32_t*>(t->res_host + t->o_point);
+      max_point = -1;
+      for (int i = 0; i < t->last_n_host; ++i) if (fp[i] > max_point) max_point = fp[i];
+    }
+    if (max_point >= mp->n_points) t->have_last = false;     // svo_hip_tracker_track will ask for svo_hip_tracker_set_last_frame
+  }
   // every index the kernels follow is checked here, once, on the host
   for (int k = 0; k < mp->n_kf; ++k) {
     SVO_REQUIRE(ctx, mp->kf_slot[k] >= 0 && mp->kf_slot[k] < c.max_keyframes && mp->kf_ftr_offset[k] <= mp->kf_ftr_offset[k + 1] && mp->kf_ftr_offset[k] >= 0);
@@ -749,6 +764,13 @@ int svo_hip_tracker_set_map(svo_hip_tracker* t, const svo_hip_tracker_map* mp) {
   for (int p = 0; p < mp->n_points; ++p) SVO_REQUIRE(ctx, mp->pt_obs_offset[p] >= 0 && mp->pt_obs_offset[p] <= mp->pt_obs_offset[p + 1] && mp->pt_type[p] >= 0 && mp->pt_type[p] <= 3);
   for (int o = 0; o < n_obs; ++o) SVO_REQUIRE(ctx, mp->obs_kf[o] >= 0 && mp->obs_kf[o] < mp->n_kf && mp->obs_level[o] >= 0 && mp->obs_level[o] < c.n_levels);
   for (int i = 0; i < mp->n_candidates; ++i) SVO_REQUIRE(ctx, mp->cand_point[i] >= -1 && mp->cand_point[i] < mp->n_points);
+  {
+    // what the tables below take in the staging area (each starts on a 16-byte boundary): checked before anything is written
+    const size_t K_ = (size_t)mp->n_kf, P_ = (size_t)mp->n_points, O_ = (size_t)n_obs;
+    const size_t need = K_ * (56 + 4 + 20) + (K_ + 1) * 4 + (size_t)n_ftr * 4 + P_ * (24 + 12) + (P_ + 1) * 4 + O_ * (4 + 16 + 24 + 4 + 1 + 16) +
+                        (size_t)mp->n_candidates * 4 + (size_t)c.max_keyframes * 56 + 32 * 16;
+    if (need > t->map_host_bytes) return svo_fail(ctx, SVO_HIP_ERR_NOMEM, "svo_hip_tracker_set_map", "staging area too small");
+  }
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   // the staging area may still feed the copies of the previous upload
   SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -797,7 +819,6 @@ int svo_hip_tracker_set_map(svo_hip_tracker* t, const svo_hip_tracker_map* mp) {
   }
   if (e == hipSuccess && P) e = hipMemsetAsync(t->pt_unlinked, 0, P, ctx->stream);
   if (e != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_tracker_set_map", hipGetErrorString(e));
-  if (off > t->map_host_bytes) return svo_fail(ctx, SVO_HIP_ERR_NOMEM, "svo_hip_tracker_set_map", "staging area too small");
   t->n_kf = mp->n_kf; t->n_points = mp->n_points; t->n_candidates = mp->n_candidates;
   t->any_edgelet = false;
   if (mp->obs_edgelet) for (int o = 0; o < n_obs && !t->any_edgelet; ++o) t->any_edgelet = mp->obs_edgelet[o] != 0;
@@ -837,6 +858,11 @@ int svo_hip_tracker_set_last_frame(svo_hip_tracker* t, const uint8_t* level0, in
   svo_hip_ctx* ctx = t->ctx;
   SVO_REQUIRE(ctx, n >= 0 && n <= t->cfg.max_frame_features && (n == 0 || (px && f && point)));
   SVO_REQUIRE(ctx, level0 || (kf_slot >= 0 && kf_slot < t->cfg.max_keyframes));
+  int max_point = -1;
+  for (int i = 0; i < n; ++i) {                               // the alignment reads pt_pos[point]: every index is checked here
+    SVO_REQUIRE(ctx, point[i] >= -1 && point[i] < (t->have_map ? t->n_points : 0));
+    if (point[i] > max_point) max_point = point[i];
+  }
   svo_hip_pyramid* dst = t->frame_pyr[t->last_idx];
   int rc;
   if (level0) rc = svo_hip_pyramid_upload_level0_and_build(dst, 0, level0);
@@ -851,6 +877,8 @@ int svo_hip_tracker_set_last_frame(svo_hip_tracker* t, const uint8_t* level0, in
     SVO_CHECK_HIP(ctx, hipMemcpyAsync(t->last.point, point, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   }
   t->last_n_host = n;
+  t->last_max_point = max_point;
+  t->last_from_track = false;
   t->have_last = true;
   t->need_gather = true;
   return SVO_HIP_OK;
@@ -949,6 +977,7 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   if (pt_n_succeeded) memcpy(pt_n_succeeded, rh + t->o_pt + 2 * np4, np4);
   t->last_idx = 1 - t->last_idx;            // the new frame's pyramid is the next call's reference
   t->last_n_host = result->n_features;
+  t->last_from_track = true;
   t->need_gather = false;
   if (result->map_changed) t->map_stale = true;
   return SVO_HIP_OK;

@@ -520,6 +520,9 @@ int svo_hip_tracker_info(const svo_hip_tracker* trk, int* n_cells, int* grid_col
  * (FrameHandlerMono: new_frame_->setKeyframe(); map_.addKeyframe(new_frame_), :284-330) */
 int svo_hip_tracker_upload_keyframe(svo_hip_tracker* trk, int slot, const uint8_t* level0);
 int svo_hip_tracker_keyframe_from_last_frame(svo_hip_tracker* trk, int slot);
+/* The map as index tables (every index is checked here, on the host).  The last frame's features refer to map points by index: a
+ * map with the same point numbering may be set between two tracked frames; if the new map has fewer points than the largest
+ * index the last frame uses, the last frame is forgotten and svo_hip_tracker_set_last_frame has to follow. */
 int svo_hip_tracker_set_map(svo_hip_tracker* trk, const svo_hip_tracker_map* map);
 /* Point::pos_ of n points after FrameHandlerBase::optimizeStructure (frame_handler_base.cpp:190-210) */
 int svo_hip_tracker_update_point_positions(svo_hip_tracker* trk, int n, const int32_t* point, const double* pos);

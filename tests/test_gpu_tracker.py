@@ -197,3 +197,35 @@ def test_reprojection_stage_beyond_and_below_the_lds_limits(ctx, tag, kw, max_ft
     for k in ("type", "n_failed", "n_succeeded"):
         np.testing.assert_array_equal(r[k], ro[k], err_msg=k)
     trk.destroy()
+
+
+def test_last_frame_indices_are_checked_against_the_map(ctx):
+    """The alignment reads pt_pos[point] of the last frame's features: svo_hip_tracker_set_last_frame refuses an index beyond the
+    map, and a smaller map set afterwards makes the tracker ask for the last frame again instead of reading past its tables."""
+    seq = tc.make_sequence(n_frames=3)
+    mp = tc.sequence_map(seq)
+    n = len(seq["px0"])
+    trk = hip.Tracker(ctx, seq["cam"], max_keyframes=2, grid_size=tc.CELL, max_fts=tc.MAX_FTS, max_frame_features=1024)
+    trk.upload_keyframe(0, seq["pyrs"][0][0])
+    trk.set_map(mp)
+    bad = np.arange(n, dtype=np.int32); bad[5] = n
+    with pytest.raises(hip.SvoHipError):
+        trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], bad, kf_slot=0)
+    trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)
+    r = trk.track(seq["pyrs"][1][0])
+    assert r["n_matches"] > 50
+    # a map with half the points: the tracked frame's features refer to points that no longer exist
+    h = n // 12                                                                   # (the first frame matches points of the top rows: low indices)
+    small = dict(mp, n_points=h, kf_ftr_offset=np.array([0, h], np.int32), kf_ftr_point=np.arange(h, dtype=np.int32), pt_pos=mp["pt_pos"][:h],
+                 pt_type=mp["pt_type"][:h], pt_n_failed=mp["pt_n_failed"][:h], pt_n_succeeded=mp["pt_n_succeeded"][:h],
+                 pt_obs_offset=np.arange(h + 1, dtype=np.int32), obs_kf=mp["obs_kf"][:h], obs_px=mp["obs_px"][:h], obs_f=mp["obs_f"][:h],
+                 obs_level=mp["obs_level"][:h], obs_edgelet=mp["obs_edgelet"][:h], obs_grad=mp["obs_grad"][:h],
+                 kf_key_point=synth.key_points(seq["cam"], mp["obs_px"][:h], np.ones(h, bool))[None, :])
+    trk.set_map(small)
+    with pytest.raises(hip.SvoHipError):
+        trk.track(seq["pyrs"][2][0])                                              # "set_last_frame comes first"
+    keep = r["feat_point"] < h
+    trk.set_last_frame(r["T_f_w"], r["feat_px"][keep], r["feat_f"][keep], np.where(r["feat_point"][keep] >= 0, r["feat_point"][keep], -1), img=seq["pyrs"][1][0])
+    r2 = trk.track(seq["pyrs"][2][0])
+    assert r2["n_matches"] > 5
+    trk.destroy()
