@@ -164,7 +164,8 @@ def _key_points_of(cs):
     ("many_cells", dict(seed=41, cell_size=4), 1200),                            # 80 x 60 = 4800 cells: cell counters in global memory
     ("many_candidates", dict(seed=42, n_points=6000, n_candidates=400, cell_size=10), 1200),   # > 2048 candidates in the frame: sort keys in global memory
     ("both", dict(seed=43, n_points=6000, n_candidates=300, cell_size=5, edgelet_frac=0.1), 300),
-    ("few", dict(seed=44, n_kf=3, n_points=120, n_candidates=10, cell_size=40), 1200)])
+    ("few", dict(seed=44, n_kf=3, n_points=120, n_candidates=10, cell_size=40), 1200),
+    ("exact_capacity", dict(seed=45, n_kf=5, n_points=300, n_candidates=25, cell_size=30), 1200)])        # every table of the tracker exactly full
 def test_reprojection_stage_beyond_and_below_the_lds_limits(ctx, tag, kw, max_fts):
     """The planning kernel keeps its cell counters and per-cell sort keys in LDS for grids of <= 2048 cells and frames of
     <= 2048 candidates, in global memory beyond: maps on either side of both limits against the oracle's
@@ -173,7 +174,10 @@ def test_reprojection_stage_beyond_and_below_the_lds_limits(ctx, tag, kw, max_ft
     cs = synth.make_map_case(**kw)
     key = _key_points_of(cs)
     ro = orc.reproject_map(cs, key, max_fts=max_fts)
-    trk = _tracker_for(ctx, cs, key, max_fts=max_fts, quality_min_fts=20, max_frame_features=2816)
+    caps = {}
+    if tag == "exact_capacity":
+        caps = dict(max_points=cs["n_points"], max_obs=len(cs["obs_kf"]), max_kf_features=len(cs["kf_ftr_point"]), max_candidates=len(cs["cand_point"]))
+    trk = _tracker_for(ctx, cs, key, max_fts=max_fts, quality_min_fts=20, max_frame_features=2816, **caps)
     n_cells = trk.n_cells
     trk.set_last_frame(cs["T_cur_w"], np.zeros((0, 2)), np.zeros((0, 3)), np.zeros(0, np.int32), img=cs["cur_pyr"][0])
     r = trk.track(cs["cur_pyr"][0])
@@ -182,7 +186,7 @@ def test_reprojection_stage_beyond_and_below_the_lds_limits(ctx, tag, kw, max_ft
         assert n_cells > 2048
     if tag in ("many_candidates", "both"):
         assert n_cand > 2048
-    if tag == "few":
+    if tag in ("few", "exact_capacity"):
         assert n_cells <= 2048 and n_cand <= 2048
     assert r["result"].items_overflow == 0
     assert [int(r["n_matches"]), int(r["n_trials"])] == [int(ro["n_matches"]), int(ro["n_trials"])]
