@@ -15,7 +15,8 @@
 // set of index tables the host uploads when the map changes (keyframe rate); the counters the reprojector keeps on the
 // points (n_failed_reproj_, n_succeeded_reproj_, type promotions) are advanced on the device and returned with every
 // frame.  A point the reprojector deletes changes the pointer graph (Map::safeDeletePoint clears feature references and
-// re-selects key points): the device marks it unlinked, reports map_changed and the host uploads the map again.
+// re-selects key points): the device marks it unlinked, the keyframes that lost a key feature choose again before the next
+// frame (trk_rekey_kernel), and map_changed tells the host to apply the same deletions to its own objects -- no new upload.
 //
 // The two serial policies of the reference are kept by construction, not approximated:
 //   * cell lists are formed in the reference's push_back order (closest keyframe first, each keyframe's fts_ order, a
@@ -470,6 +471,80 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_replay_kernel(TrkMap m, TrkPl
   }
 }
 
+// ---- Frame::removeKeyPoint / setKeyPoints (S/frame.cpp:83-165) for the keyframes that lost a key feature to a point the
+// reprojector deleted in the previous frame (Map::safeDeletePoint, S/map.cpp:78-88): one workgroup per keyframe.
+// A keyframe none of whose key features lost its point keeps its key features untouched, as in the reference (they are
+// incumbents of the frame's history, not necessarily what a fresh selection would give).  In a keyframe that lost one,
+// every slot is contested again by every feature that still has a point, in fts_ order with strict improvement: the
+// incumbent stays on a tie, otherwise the first feature that reaches the best value wins.  A feature's pixel is the
+// observation of its point in this keyframe.
+__global__ __launch_bounds__(256) void trk_rekey_kernel(TrkMap m, int* __restrict__ kf_key_point, Cam cam) {
+  const int k = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  __shared__ int s_found, s_inc[5], s_best_idx[5][256];
+  __shared__ double s_inc_val[5], s_best_val[5][256];
+  const int cu = cam.width / 2, cv = cam.height / 2;
+  // pixel of point p's observation in keyframe k (false: none)
+  auto px_in_kf = [&](int p, double* x, double* y) {
+    for (int o = m.pt_obs_offset[p]; o < m.pt_obs_offset[p + 1]; ++o)
+      if (m.obs_kf[o] == k) { *x = m.obs_px[2 * (size_t)o]; *y = m.obs_px[2 * (size_t)o + 1]; return true; }
+    return false;
+  };
+  // value of a feature for slot j (0: distance from the centre, smaller is better; 1..4: the quadrant products, larger is
+  // better, -inf outside the quadrant -- the two left quadrants test x against cv as the reference does, S/frame.cpp:133,142)
+  auto slot_value = [&](int j, double x, double y) {
+    if (j == 0) return fmax(fabs(x - cu), fabs(y - cv));
+    const bool in = j == 1 ? (x >= cu && y >= cv) : j == 2 ? (x >= cu && y < cv) : j == 3 ? (x < cv && y < cv) : (x < cv && y >= cv);
+    return in ? (x - cu) * (y - cv) : -HUGE_VAL;
+  };
+  if (t == 0) s_found = 0;
+  __syncthreads();
+  if (t < 5) {
+    int p = kf_key_point[5 * k + t];
+    if (p >= 0 && m.pt_unlinked[p]) { p = -1; atomicOr(&s_found, 1); }       // the key feature's point is gone (:85-88, :157-162)
+    double x = 0, y = 0;
+    const bool has = p >= 0 && px_in_kf(p, &x, &y);
+    s_inc[t] = has ? p : -1;
+    s_inc_val[t] = has ? slot_value(t, x, y) : 0.0;
+  }
+  __syncthreads();
+  if (!s_found) return;                                                        // block-uniform
+  double best[5];
+  int best_j[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) { best[j] = j == 0 ? HUGE_VAL : -HUGE_VAL; best_j[j] = INT_MAX; }
+  const int f0 = m.kf_ftr_offset[k], f1 = m.kf_ftr_offset[k + 1];
+  for (int i = f0 + t; i < f1; i += nt) {                                      // ascending per thread: the first best index is kept
+    const int p = m.kf_ftr_point[i];
+    if (p < 0 || m.pt_unlinked[p]) continue;                                   // ftr->point == NULL
+    double x, y;
+    if (!px_in_kf(p, &x, &y)) continue;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const double v = slot_value(j, x, y);
+      const bool better = j == 0 ? v < best[j] : v > best[j];
+      if (better) { best[j] = v; best_j[j] = i; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) { s_best_val[j][t] = best[j]; s_best_idx[j][t] = best_j[j]; }
+  __syncthreads();
+  if (t < 5) {
+    double bv = t == 0 ? HUGE_VAL : -HUGE_VAL;
+    int bi = INT_MAX;
+    for (int q = 0; q < nt; ++q) {                                             // best value, lowest feature index on ties
+      const double v = s_best_val[t][q];
+      const int i = s_best_idx[t][q];
+      if (i == INT_MAX) continue;
+      const bool better = t == 0 ? v < bv : v > bv;
+      if (better || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+    int winner = s_inc[t];
+    const bool challenger = bi != INT_MAX && (t == 0 || bv > -HUGE_VAL);       // (a feature outside the quadrant is no contender)
+    if (challenger && (winner < 0 || (t == 0 ? bv < s_inc_val[t] : bv > s_inc_val[t]))) winner = m.kf_ftr_point[bi];
+    kf_key_point[5 * k + t] = winner;
+  }
+}
+
 // ---- last_frame_ = new_frame_ (frame_handler_mono.cpp:91) and the result block.  One workgroup.
 __global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, TrkLast last, Cam cam, const FrameState* __restrict__ sia_state,
                                                          const svo_hip_pose_opt_result* __restrict__ po, svo_hip_track_result* __restrict__ res,
@@ -579,7 +654,8 @@ struct svo_hip_tracker {
       *pt_n_succeeded = nullptr, *pt_obs_offset = nullptr, *obs_kf = nullptr, *obs_level = nullptr, *cand_point = nullptr;
   uint8_t *pt_unlinked = nullptr, *obs_edgelet = nullptr;
   int n_kf = 0, n_points = 0, n_candidates = 0;
-  bool have_map = false, map_stale = false, have_last = false;
+  bool have_map = false, have_last = false;
+  bool rekey_pending = false;               // the last frame deleted points: keyframes that lost a key feature choose again before the next frame
   int last_n_host = 0;
   int last_max_point = -1;                  // largest map point index the last frame's features refer to (set_last_frame input)
   bool last_from_track = false;             // ... or: the last frame is the previous call's new frame, its features are in the result block
@@ -822,7 +898,7 @@ int svo_hip_tracker_set_map(svo_hip_tracker* t, const svo_hip_tracker_map* mp) {
   t->n_kf = mp->n_kf; t->n_points = mp->n_points; t->n_candidates = mp->n_candidates;
   t->any_edgelet = false;
   if (mp->obs_edgelet) for (int o = 0; o < n_obs && !t->any_edgelet; ++o) t->any_edgelet = mp->obs_edgelet[o] != 0;
-  t->have_map = true; t->map_stale = false;
+  t->have_map = true; t->rekey_pending = false;
   t->need_gather = true;                    // point positions may have changed
   return SVO_HIP_OK;
 }
@@ -892,9 +968,6 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   const svo_hip_tracker_config& c = t->cfg;
   if (!t->have_map || !t->have_last)
     return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_track", "svo_hip_tracker_set_map and svo_hip_tracker_set_last_frame come first");
-  if (t->map_stale)
-    return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_track",
-                    "the last frame deleted map points (map_changed): apply that to the map and call svo_hip_tracker_set_map again");
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   const size_t l0 = (size_t)t->cam.width * t->cam.height;
   svo_hip_pyramid* ref = t->frame_pyr[t->last_idx];
@@ -919,6 +992,11 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   // ---- Reprojector::reprojectMap
   const TrkMap m = make_map(t);
   const Cam cam = svo_make_cam(t->cam);
+  if (t->rekey_pending && t->n_kf > 0) {    // Map::safeDeletePoint of the previous frame: Frame::removeKeyPoint on the keyframes
+    hipLaunchKernelGGL(trk_rekey_kernel, dim3(t->n_kf), dim3(256), 0, ctx->stream, m, t->kf_key_point, cam);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+  }
+  t->rekey_pending = false;
   SeedRec* recs = nullptr;
   uint32_t* pwb_t = nullptr;
   int n_pad = 0;
@@ -979,7 +1057,24 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   t->last_n_host = result->n_features;
   t->last_from_track = true;
   t->need_gather = false;
-  if (result->map_changed) t->map_stale = true;
+  if (result->map_changed) t->rekey_pending = true;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_download_key_points(svo_hip_tracker* t, int32_t* kf_key_point) {
+  if (!t || !kf_key_point) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = t->ctx;
+  if (!t->have_map) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_download_key_points", "no map has been set");
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  if (t->rekey_pending && t->n_kf > 0) {
+    hipLaunchKernelGGL(trk_rekey_kernel, dim3(t->n_kf), dim3(256), 0, ctx->stream, make_map(t), t->kf_key_point, svo_make_cam(t->cam));
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+  }
+  t->rekey_pending = false;
+  if (t->n_kf > 0) {
+    SVO_CHECK_HIP(ctx, hipMemcpyAsync(kf_key_point, t->kf_key_point, (size_t)t->n_kf * 5 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return SVO_HIP_OK;
 }
 

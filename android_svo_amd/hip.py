@@ -771,6 +771,13 @@ class Tracker:
     def keyframe_from_last_frame(self, slot: int):
         self.ctx.check(self.ctx.lib.svo_hip_tracker_keyframe_from_last_frame(self.h, slot), "tracker_keyframe_from_last_frame")
 
+    def download_key_points(self, n_kf: int) -> np.ndarray:
+        """[n_kf][5] point indices of the keyframes' key features as the device holds them (after the re-selections that follow
+        deletions)"""
+        out = np.full((max(n_kf, 1), 5), -1, dtype=np.int32)
+        self.ctx.check(self.ctx.lib.svo_hip_tracker_download_key_points(self.h, _ptr(out, C.c_int32)), "tracker_download_key_points")
+        return out[:n_kf]
+
     def set_map(self, mp: dict):
         """mp: the index tables of android_svo_amd.synth.make_map_case (plus kf_slot, kf_key_point)"""
         i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)

@@ -129,14 +129,20 @@ class FrameTrackerT {
     // point bookkeeping (:126-133, :202-215): counters and promotions as numbers, deletions through the map's own functions
     for (size_t p = 0; p < np; ++p) {
       Point* pt = points_[p];
+      if (pt == NULL) continue;                              // deleted in an earlier frame: the object is the map's trash, or gone
       const bool deleted_now = p_type_[p] == (int)Point::TYPE_DELETED && pt->type_ != Point::TYPE_DELETED;
       pt->n_failed_reproj_ = p_failed_[p];
       pt->n_succeeded_reproj_ = p_succ_[p];
       if (!deleted_now) { pt->type_ = (typename Point::PointType)p_type_[p]; continue; }
       if (pt->type_ == Point::TYPE_CANDIDATE) map.point_candidates_.deleteCandidatePoint(pt);
       else map.safeDeletePoint(pt);
+      // the point now belongs to the map's trash (freed by Map::emptyTrash): this table forgets the object, the index stays
+      // taken (the device tables keep the dead entry until the map is flattened again)
+      index_of_point_.erase(pt);
+      points_[p] = NULL;
     }
-    if (r.map_changed) map_dirty_ = true;                    // feature references and key points changed with the deletions
+    // (r.map_changed: the device tables followed the deletions themselves -- points unlinked, key points chosen again with
+    // Frame::removeKeyPoint's rule -- so the map is not flattened again for them; index_of_point_ stays valid)
     out.img_align_n_tracked = (size_t)r.sia_n_tracked;
     out.repr_n_matches = (size_t)r.n_matches; out.repr_n_trials = (size_t)r.n_trials;
     out.pose_optimised = r.pose.ran != 0;

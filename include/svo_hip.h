@@ -438,8 +438,10 @@ int svo_hip_point_optimize_batch(svo_hip_ctx* ctx, int n_points, int n_iter, dou
  * The map the reprojector walks is a set of index tables uploaded when the map changes (svo_hip_tracker_set_map);
  * keyframe pyramids live in a batch owned by the tracker.  The counters the reprojector keeps on the points are advanced
  * on the device and returned with every frame; when it DELETES a point (reprojector.cpp:126-133,202-209) the pointer
- * graph changes (Map::safeDeletePoint clears feature references and re-selects key points): the result says map_changed
- * and the next svo_hip_tracker_track is refused until the host has uploaded the map again.
+ * graph changes (Map::safeDeletePoint, S/map.cpp:78-88: every observation lets go of the point, a keyframe that loses a key
+ * feature chooses its key features again, Frame::removeKeyPoint): the device tables follow -- the point is unlinked there and
+ * the affected keyframes re-select before the next frame with the reference's rule -- and the result says map_changed so that
+ * the host applies the same deletions to its own objects; a new upload of the map is NOT needed for that.
  * Host code keeps what it keeps in the reference: keyframe selection, Map / Point / Feature objects, optimizeStructure
  * (svo_hip_point_optimize_batch + svo_hip_tracker_update_point_positions), relocalisation (svo_hip_tracker_set_last_frame). */
 typedef struct svo_hip_tracker svo_hip_tracker;
@@ -504,7 +506,8 @@ typedef struct {
   int32_t n_features;           /* new_frame_->fts_.size(): features the reprojector added, in creation order */
   uint64_t n_matches, n_trials; /* reprojector_.n_matches_, n_trials_ */
   int32_t n_overlap;            /* overlap_kfs_.size() */
-  int32_t map_changed;          /* 1: a point or candidate was deleted; apply it on the host and call svo_hip_tracker_set_map */
+  int32_t map_changed;          /* 1: a point or candidate was deleted (its type is TYPE_DELETED in pt_type): apply Map::safeDeletePoint /
+                                   deleteCandidatePoint to the host's objects; the device tables have followed already */
   int32_t overlap_kf[16];       /* overlap_kfs_[i].first as keyframe index */
   int32_t overlap_count[16];    /* overlap_kfs_[i].second */
   int32_t n_candidates;         /* candidates in all cells */
@@ -524,6 +527,9 @@ int svo_hip_tracker_keyframe_from_last_frame(svo_hip_tracker* trk, int slot);
  * map with the same point numbering may be set between two tracked frames; if the new map has fewer points than the largest
  * index the last frame uses, the last frame is forgotten and svo_hip_tracker_set_last_frame has to follow. */
 int svo_hip_tracker_set_map(svo_hip_tracker* trk, const svo_hip_tracker_map* map);
+/* the keyframes' key points as the device holds them ([n_kf][5] point indices, -1 = none): what was uploaded, advanced by the
+ * re-selections that followed deletions (parity tests) */
+int svo_hip_tracker_download_key_points(svo_hip_tracker* trk, int32_t* kf_key_point);
 /* Point::pos_ of n points after FrameHandlerBase::optimizeStructure (frame_handler_base.cpp:190-210) */
 int svo_hip_tracker_update_point_positions(svo_hip_tracker* trk, int n, const int32_t* point, const double* pos);
 /* last_frame_ from the host (after initialisation / relocalisation): its image (level0, or NULL = the keyframe pyramid in

@@ -59,9 +59,7 @@ def test_reprojection_stage_against_reference_fixture(ctx, tag, kw, max_fts):
     rot, trans = synth.pose_error(r["T_f_w"], np.array(po.T_f_w))
     assert rot < 1e-9 and trans < 1e-9, (rot, trans)
     assert r["result"].pose.num_obs == po.num_obs
-    # the tracker now refuses the next frame until the map has been uploaded again
-    with pytest.raises(hip.SvoHipError):
-        trk.track(cs["cur_pyr"][0])
+    # (what follows a frame with deletions: test_tracker_follows_deletions_on_the_device)
     trk.destroy()
 
 
@@ -233,3 +231,110 @@ def test_last_frame_indices_are_checked_against_the_map(ctx):
     r2 = trk.track(seq["pyrs"][2][0])
     assert r2["n_matches"] > 5
     trk.destroy()
+
+
+def _rekey_expected(cs, key, deleted):
+    """Frame::removeKeyPoint / setKeyPoints (S/frame.cpp:83-165) on every keyframe after Map::safeDeletePoint of the points in
+    `deleted`: a keyframe none of whose key features lost its point is left alone; in the others every slot is contested
+    again by every feature that still has a point, in fts_ order, an incumbent staying unless strictly beaten."""
+    cam = cs["cam"]
+    cu, cv = cam.width // 2, cam.height // 2
+    out = key.copy()
+    for k in range(cs["n_kf"]):
+        o = cs["kf_ftr_obs"][cs["kf_ftr_offset"][k]:cs["kf_ftr_offset"][k + 1]]
+        px_of = {int(cs["obs_point"][oo]): cs["obs_px"][oo] for oo in np.where(cs["obs_kf"] == k)[0]}
+        cur = [int(p) for p in key[k]]
+        found = False
+        for j in range(5):
+            if cur[j] >= 0 and deleted[cur[j]]:
+                cur[j] = -1
+                found = True
+        if not found:
+            continue
+
+        def value(j, x, y):
+            if j == 0:
+                return -max(abs(x - cu), abs(y - cv))                          # smaller distance = better: negated
+            cond = (x >= cu and y >= cv, x >= cu and y < cv, x < cv and y < cv, x < cv and y >= cv)[j - 1]
+            return (x - cu) * (y - cv) if cond else None
+        for oo in o:
+            p = int(cs["obs_point"][oo])
+            if deleted[p]:
+                continue
+            x, y = cs["obs_px"][oo]
+            for j in range(5):
+                v = value(j, x, y)
+                if v is None:
+                    continue
+                if cur[j] < 0:
+                    cur[j] = p
+                else:
+                    xi, yi = px_of[cur[j]]
+                    vi = -max(abs(xi - cu), abs(yi - cv)) if j == 0 else (xi - cu) * (yi - cv)
+                    if v > vi:
+                        cur[j] = p
+        out[k] = cur
+    return out
+
+
+def test_tracker_follows_deletions_on_the_device(ctx):
+    """A frame that deletes map points (Map::safeDeletePoint / deleteCandidatePoint in the reprojector) does not need the map
+    uploaded again: the points are unlinked in the device tables and the keyframes that lost a key feature choose their key
+    features again with Frame::removeKeyPoint's rule (incumbents of untouched keyframes and slots stay, even non-optimal
+    ones).  The next frame tracked straight on equals the next frame tracked after applying the deletions to the host
+    tables and uploading them -- every integer, pixels bitwise."""
+    tag, kw, max_fts = CASES[0]
+    g = np.load(GOLD)
+    cs = synth.make_map_case(**kw)
+    rng = np.random.default_rng(5)
+    key = g[tag + "_kf_key_point"].copy()
+    deleted0 = g[tag + "_unlinked"].astype(bool)                                 # what the frame deletes with the fixture's key points
+    # Incumbents a fresh selection would not pick: in the even keyframes the centre slot holds some other live feature's point
+    # (must survive untouched), in the odd ones a point the frame is going to delete (the keyframe must choose again).
+    for k in range(cs["n_kf"]):
+        o = cs["kf_ftr_obs"][cs["kf_ftr_offset"][k]:cs["kf_ftr_offset"][k + 1]]
+        pts = cs["obs_point"][o]
+        pool = [int(p) for p in pts if (deleted0[p] if k % 2 else (not deleted0[p] and cs["pt_type"][p] != synth.TYPE_DELETED))]
+        if pool:
+            key[k, 0] = pool[int(rng.integers(len(pool)))]
+    scene = synth.PlaneScene(seed=kw.get("seed", 31), depth=2.0, tilt=(0.08, -0.05))
+    T2 = synth.se3_mul(synth.se3_from_twist([0.012, -0.006, 0.004], [0.002, -0.003, 0.001]), cs["T_cur_w"])
+    img2 = scene.render(cs["cam"], T2)
+
+    def first_frame():
+        trk = _tracker_for(ctx, cs, key, max_fts=max_fts, quality_min_fts=20)
+        trk.set_last_frame(cs["T_cur_w"], np.zeros((0, 2)), np.zeros((0, 3)), np.zeros(0, np.int32), img=cs["cur_pyr"][0])
+        return trk, trk.track(cs["cur_pyr"][0])
+    # ---- A: straight on
+    trk, r1 = first_frame()
+    assert r1["map_changed"] == 1
+    deleted = (r1["type"] == synth.TYPE_DELETED) & (cs["pt_type"] != synth.TYPE_DELETED)      # (other key points, other close keyframes: not the fixture's set)
+    key_dev = trk.download_key_points(cs["n_kf"])
+    expect = _rekey_expected(cs, key, deleted)
+    np.testing.assert_array_equal(key_dev, expect)
+    lost = np.array([deleted[key[k][key[k] >= 0]].any() for k in range(cs["n_kf"])])
+    assert lost.sum() >= 2 and (~lost).sum() >= 2                                  # some keyframes chose again ...
+    np.testing.assert_array_equal(expect[~lost], key[~lost])                       # ... the others kept their (partly non-optimal) incumbents
+    assert (expect[lost] != key[lost]).any()
+    ra = trk.track(img2)
+    trk.destroy()
+    # ---- B: the deletions applied to the host tables, the map uploaded again, the last frame handed over by the host
+    trk, r1b = first_frame()
+    np.testing.assert_array_equal(r1b["T_f_w"], r1["T_f_w"])
+    kfp = cs["kf_ftr_point"].copy()
+    kfp[deleted[kfp]] = -1
+    cs2 = dict(cs, pt_type=r1b["type"], pt_n_failed=r1b["n_failed"], pt_n_succeeded=r1b["n_succeeded"], kf_ftr_point=kfp,
+               cand_point=np.array([p for p in cs["cand_point"] if not deleted[p]], np.int32))
+    trk.set_map(dict(cs2, kf_slot=np.arange(cs["n_kf"], dtype=np.int32), kf_key_point=expect))
+    trk.set_last_frame(r1b["T_f_w"], r1b["feat_px"], r1b["feat_f"], r1b["feat_point"], img=cs["cur_pyr"][0])
+    rb = trk.track(img2)
+    trk.destroy()
+    assert ra["n_matches"] > 100
+    for k in ("n_matches", "n_trials"):
+        assert int(ra[k]) == int(rb[k]), k
+    for k in ("overlap_kf", "overlap_count", "feat_point", "feat_level", "feat_type", "type", "n_failed", "n_succeeded"):
+        np.testing.assert_array_equal(ra[k], rb[k], err_msg=k)
+    assert ra["feat_px"].tobytes() == rb["feat_px"].tobytes() and ra["feat_grad"].tobytes() == rb["feat_grad"].tobytes()
+    np.testing.assert_array_equal(ra["T_f_w"], rb["T_f_w"])
+    rot, trans = synth.pose_error(ra["T_f_w"], T2)
+    assert rot < 3e-3 and trans < 1e-2
