@@ -12,6 +12,7 @@
 // two medians of the squared errors (radix selection on the f64 bit pattern).  Sums over observations are taken
 // in a fixed tree order instead of the reference's list order: results agree to rounding, run to run bit-equal.
 #include "svo_internal.h"
+#include "svo_point_refine.h"
 
 namespace {
 
@@ -535,63 +536,17 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
   }
 }
 
-// Point::jacobian_xyz2uv (I/point.h:83-97): -[1/z 0 -x/z^2; 0 1/z -y/z^2] * R_f_w, inner sums (a0 + a1) + a2
-SVO_DEV void point_jacobian(const double* p, const double* R, double* J) {
-  const double z_inv = 1.0 / p[2];
-  const double z_inv_sq = z_inv * z_inv;
-  const double j[6] = {-(z_inv), -(0.0), -(-p[0] * z_inv_sq), -(0.0), -(z_inv), -(-p[1] * z_inv_sq)};
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      J[r * 3 + c] = (j[r * 3 + 0] * R[0 * 3 + c] + j[r * 3 + 1] * R[1 * 3 + c]) + j[r * 3 + 2] * R[2 * 3 + c];
-}
-
-// Point::optimize (S/point.cpp:130-192): thread per map point, observations in CSR form, list order kept
+// Point::optimize (S/point.cpp:130-192): thread per map point, observations in CSR form, list order kept (svo_point_refine.h)
 __global__ void point_refine_kernel(int n_points, int n_iter, double* __restrict__ pos, const int* __restrict__ obs_offset,
                                     const double* __restrict__ obs_T, const double* __restrict__ obs_f,
                                     int* __restrict__ iters_out) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_points) return;
   double P[3] = {pos[3 * p], pos[3 * p + 1], pos[3 * p + 2]};
-  double old_point[3] = {P[0], P[1], P[2]};
-  double chi2 = 0.0;
-  int done = 0;
-  const int o0 = obs_offset[p], o1 = obs_offset[p + 1];
-  for (int i = 0; i < n_iter; ++i) {
-    double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
-    double new_chi2 = 0.0;
-    for (int k = o0; k < o1; ++k) {
-      double T[7], q[3], R[9], J[6];
-      for (int t = 0; t < 7; ++t) T[t] = obs_T[7 * k + t];
-      const double fx = obs_f[3 * k], fy = obs_f[3 * k + 1], fz = obs_f[3 * k + 2];
-      se3_act(T, P, q);
-      se3_rotation_matrix(T, R);
-      point_jacobian(q, R, J);
-      const double e0 = fx / fz - q[0] / q[2];
-      const double e1 = fy / fz - q[1] / q[2];
-      new_chi2 += e0 * e0 + e1 * e1;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) A[r * 3 + c] += J[r] * J[c] + J[3 + r] * J[3 + c];
-        bb[r] -= J[r] * e0 + J[3 + r] * e1;
-      }
-    }
-    double dp[3];
-    ldlt_solve<3>(A, bb, dp);
-    done = i + 1;
-    if ((i > 0 && new_chi2 > chi2) || dp[0] != dp[0]) {
-      P[0] = old_point[0]; P[1] = old_point[1]; P[2] = old_point[2];
-      break;
-    }
-    old_point[0] = P[0]; old_point[1] = P[1]; old_point[2] = P[2];
-    P[0] += dp[0]; P[1] += dp[1]; P[2] += dp[2];
-    chi2 = new_chi2;
-    double mx = -1;
-    for (int k = 0; k < 3; ++k) { const double a = fabs(dp[k]); if (a > mx) mx = a; }
-    if (mx <= 0.0000000001) break;
-  }
+  const int done = point_refine_one(P, obs_offset[p], obs_offset[p + 1], n_iter, [&](int k, double* T, double* fo) {
+    for (int t = 0; t < 7; ++t) T[t] = obs_T[7 * k + t];
+    fo[0] = obs_f[3 * k]; fo[1] = obs_f[3 * k + 1]; fo[2] = obs_f[3 * k + 2];
+  });
   pos[3 * p] = P[0]; pos[3 * p + 1] = P[1]; pos[3 * p + 2] = P[2];
   if (iters_out) iters_out[p] = done;
 }

@@ -31,6 +31,7 @@
 
 #include "svo_internal.h"
 #include "svo_match_device.h"
+#include "svo_point_refine.h"
 
 using namespace svo_dev;
 
@@ -38,6 +39,7 @@ namespace {
 
 constexpr int TRK_THREADS = 1024;
 constexpr int TRK_MAX_SEL = 16;            // >= Reprojector::Options::max_n_kfs
+constexpr int TRK_MAX_STRUCT = 64;         // points per structure-optimisation call (Config::structureOptimMaxPts() = 20)
 constexpr int TRK_LDS_KF = 256;            // keyframes of the map (svo_hip_tracker_config::max_keyframes <= this): per-keyframe scratch in LDS
 constexpr int TRK_LDS_ITEMS = 2048;        // a frame with at most this many candidates keeps their per-cell sort keys in LDS
 constexpr int TRK_LDS_CELLS = 2048;        // a grid with at most this many cells keeps the cell counters in LDS
@@ -545,6 +547,40 @@ __global__ __launch_bounds__(256) void trk_rekey_kernel(TrkMap m, int* __restric
   }
 }
 
+// ---- FrameHandlerBase::optimizeStructure (S/frame_handler_base.cpp:190-210) on the points the host selected: Point::optimize
+// of each of them over its observations as the map tables hold them (keyframe pose + bearing, Point::obs_ order), the new
+// positions written into the point table, into the solver's copy of the last frame's points (the next SparseImgAlign::run reads
+// point->pos_) and into the page-locked result block.  One workgroup.
+struct TrkStructSel { int n; int point[TRK_MAX_STRUCT]; };
+__global__ __launch_bounds__(256) void trk_structure_kernel(TrkMap m, double* __restrict__ pt_pos, TrkLast last, TrkStructSel sel, int n_iter,
+                                                            double* __restrict__ out_pos, int* __restrict__ out_iters,
+                                                            unsigned long long* __restrict__ done_flag, unsigned long long seq) {
+  __shared__ double s_new[TRK_MAX_STRUCT][3];
+  const int t = threadIdx.x, nt = blockDim.x;
+  if (t < sel.n) {
+    const int p = sel.point[t];
+    double P[3] = {pt_pos[3 * (size_t)p], pt_pos[3 * (size_t)p + 1], pt_pos[3 * (size_t)p + 2]};
+    const int done = point_refine_one(P, m.pt_obs_offset[p], m.pt_obs_offset[p + 1], n_iter, [&](int o, double* T, double* fo) {
+      const double* tk = m.T_kf_w + 7 * (size_t)m.obs_kf[o];
+      for (int i = 0; i < 7; ++i) T[i] = tk[i];
+      fo[0] = m.obs_f[3 * (size_t)o]; fo[1] = m.obs_f[3 * (size_t)o + 1]; fo[2] = m.obs_f[3 * (size_t)o + 2];
+    });
+    for (int i = 0; i < 3; ++i) { pt_pos[3 * (size_t)p + i] = P[i]; s_new[t][i] = P[i]; out_pos[3 * t + i] = P[i]; }
+    out_iters[t] = done;
+  }
+  __syncthreads();
+  const int n_last = *last.n < last.sia_max_n ? *last.n : last.sia_max_n;
+  for (int j = t; j < n_last; j += nt) {
+    const int p = last.point[j];
+    if (p < 0) continue;
+    for (int i = 0; i < sel.n; ++i)
+      if (sel.point[i] == p) { last.sia_pos[3 * j] = s_new[i][0]; last.sia_pos[3 * j + 1] = s_new[i][1]; last.sia_pos[3 * j + 2] = s_new[i][2]; }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- last_frame_ = new_frame_ (frame_handler_mono.cpp:91) and the result block.  One workgroup.
 __global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, TrkLast last, Cam cam, const FrameState* __restrict__ sia_state,
                                                          const svo_hip_pose_opt_result* __restrict__ po, svo_hip_track_result* __restrict__ res,
@@ -673,6 +709,9 @@ struct svo_hip_tracker {
   unsigned long long seq = 0;               // frames tracked: the kernel stores it behind the block (o_flag) when the block is complete
   size_t o_flag = 0;
   uint8_t* img_dev = nullptr;               // device address of img_host
+  char* st_host = nullptr;                  // page-locked result of svo_hip_tracker_optimize_structure: [pos 64 x 3][iters 64][flag]
+  char* st_dev = nullptr;
+  unsigned long long st_seq = 0;
   size_t o_px = 0, o_f = 0, o_level = 0, o_point = 0, o_edge = 0, o_grad = 0, o_pt = 0, res_bytes = 0;
   // page-locked staging: one frame image, the map tables
   uint8_t* img_host = nullptr;
@@ -722,6 +761,7 @@ int svo_hip_tracker_destroy(svo_hip_tracker* t) {
   for (void* p : t->dev_allocs) if (p) (void)hipFree(p);
   if (t->res_host) (void)hipHostFree(t->res_host);
   if (t->img_host) (void)hipHostFree(t->img_host);
+  if (t->st_host) (void)hipHostFree(t->st_host);
   if (t->map_host) (void)hipHostFree(t->map_host);
   delete t;
   return SVO_HIP_OK;
@@ -780,6 +820,10 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
   if (rc == SVO_HIP_OK) memset(t->res_host, 0, t->res_bytes);
   if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->img_host, (size_t)cam->width * cam->height + 64, hipHostMallocMapped) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
   if (rc == SVO_HIP_OK && hipHostGetDevicePointer((void**)&t->img_dev, t->img_host, 0) != hipSuccess) rc = SVO_HIP_ERR_DEVICE;
+  const size_t st_bytes = TRK_MAX_STRUCT * (24 + 4) + 64;
+  if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->st_host, st_bytes, hipHostMallocMapped) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
+  if (rc == SVO_HIP_OK) memset(t->st_host, 0, st_bytes);
+  if (rc == SVO_HIP_OK && hipHostGetDevicePointer((void**)&t->st_dev, t->st_host, 0) != hipSuccess) rc = SVO_HIP_ERR_DEVICE;
   // staging area of svo_hip_tracker_set_map: every table at its capacity (T_kf_w and T_slot_w: two pose tables), 16 bytes of
   // alignment slack per table
   t->map_host_bytes = K * (56 + 56 + 4 + 20 + 4) + 8 + F * 4 + P * (24 + 12 + 4) + 8 + O * (4 + 16 + 24 + 4 + 1 + 16) + CN * 4 + 32 * 16;
@@ -925,6 +969,44 @@ int svo_hip_tracker_update_point_positions(svo_hip_tracker* t, int n, const int3
                      reinterpret_cast<const double*>(d), t->pt_pos);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   t->need_gather = true;                    // the solver's copy of the last frame's point positions is stale
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_optimize_structure(svo_hip_tracker* t, int n, const int32_t* point, int n_iter, double* pos_out, int32_t* iters_out) {
+  if (!t) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = t->ctx;
+  SVO_REQUIRE(ctx, n >= 0 && n <= TRK_MAX_STRUCT && n_iter >= 0 && (n == 0 || (point && pos_out)));
+  if (!t->have_map) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_optimize_structure", "no map has been set");
+  if (n == 0) return SVO_HIP_OK;
+  TrkStructSel sel;
+  memset(&sel, 0, sizeof(sel));
+  sel.n = n;
+  for (int i = 0; i < n; ++i) {
+    SVO_REQUIRE(ctx, point[i] >= 0 && point[i] < t->n_points);
+    for (int j = 0; j < i; ++j) SVO_REQUIRE(ctx, point[j] != point[i]);         // a point is optimised once per call
+    sel.point[i] = point[i];
+  }
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t o_it = TRK_MAX_STRUCT * 24, o_flag = o_it + TRK_MAX_STRUCT * 4;
+  const unsigned long long seq = ++t->st_seq;
+  hipLaunchKernelGGL(trk_structure_kernel, dim3(1), dim3(256), 0, ctx->stream, make_map(t), t->pt_pos, t->last, sel, n_iter,
+                     reinterpret_cast<double*>(t->st_dev), reinterpret_cast<int*>(t->st_dev + o_it),
+                     reinterpret_cast<unsigned long long*>(t->st_dev + o_flag), seq);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  {
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(t->st_host + o_flag);
+    bool seen = false;
+    for (long spins = 0; spins < 4000000L; ++spins) {
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+      __builtin_ia32_pause();
+    }
+    if (!seen) SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+      return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_tracker_optimize_structure", "the kernel did not complete");
+  }
+  memcpy(pos_out, t->st_host, (size_t)n * 24);
+  if (iters_out) memcpy(iters_out, t->st_host + o_it, (size_t)n * 4);
+  // (the point table and the solver's copy of the last frame's points were updated by the kernel: nothing to gather)
   return SVO_HIP_OK;
 }
 

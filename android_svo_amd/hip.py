@@ -771,6 +771,15 @@ class Tracker:
     def keyframe_from_last_frame(self, slot: int):
         self.ctx.check(self.ctx.lib.svo_hip_tracker_keyframe_from_last_frame(self.h, slot), "tracker_keyframe_from_last_frame")
 
+    def optimize_structure(self, point, n_iter: int = 5):
+        """FrameHandlerBase::optimizeStructure on the given points over the observations the map tables hold.
+        Returns (pos [n,3], iters [n])."""
+        pt = np.ascontiguousarray(point, dtype=np.int32)
+        pos, it = np.zeros((max(len(pt), 1), 3)), np.zeros(max(len(pt), 1), np.int32)
+        self.ctx.check(self.ctx.lib.svo_hip_tracker_optimize_structure(self.h, len(pt), _ptr(pt, C.c_int32), int(n_iter), _ptr(pos, C.c_double),
+                                                                       _ptr(it, C.c_int32)), "tracker_optimize_structure")
+        return pos[:len(pt)], it[:len(pt)]
+
     def download_key_points(self, n_kf: int) -> np.ndarray:
         """[n_kf][5] point indices of the keyframes' key features as the device holds them (after the re-selections that follow
         deletions)"""

@@ -164,6 +164,16 @@ static int track_demo(const std::string& dir, const std::string& out) {
         for (int j = 0; j < n_kf; ++j) if (kfs[j] == ov.first) idx = j;
         overlap.push_back((double)idx); overlap.push_back((double)ov.second);
       }
+    if (k == 0 && m.size() > 18 && m[18] > 0) {
+      // FrameHandlerBase::optimizeStructure(new_frame, 20, 5) as processFrame calls it behind the pose refinement (:242-244)
+      std::vector<const Point*> had;
+      for (const Feature* ftr : cur->fts_) if (ftr->point) had.push_back(ftr->point);
+      if (!tracker.optimiseStructure(cur, map, (size_t)m[18], 5)) throw std::runtime_error("svo::FrameTracker::optimiseStructure failed");
+      std::vector<double> so;                                                  // point index, x, y, z of every point that was optimised
+      for (int p = 0; p < n_points; ++p)
+        if (points[p]->last_structure_optim_ == cur->id_) so.insert(so.end(), {(double)p, points[p]->pos_[0], points[p]->pos_[1], points[p]->pos_[2]});
+      write_bin(out + "/track_structure_first.bin", so);
+    }
     if (k == 0) {                                                              // the map's points as the first frame left them
       std::vector<int32_t> st;
       for (int p = 0; p < n_points; ++p) { st.push_back((int32_t)points[p]->type_); st.push_back(points[p]->n_failed_reproj_); st.push_back(points[p]->n_succeeded_reproj_); }

@@ -90,6 +90,7 @@ struct Point {                                      // I/point.h: position + the
   std::list<Feature*> obs_;
   PointType type_ = TYPE_UNKNOWN;
   int n_failed_reproj_ = 0, n_succeeded_reproj_ = 0;                             // the reprojector's counters (I/point.h:49-50)
+  int last_structure_optim_ = 0;                                                 // id of the frame that optimised it last (:51)
   explicit Point(const Vector3d& p) : pos_(p) {}
   Point(const Vector3d& p, Feature* ftr) : pos_(p) { obs_.push_front(ftr); }     // S/point.cpp:39-48
 };

@@ -24,7 +24,9 @@
 #ifndef SVO_FRAME_TRACKER_BATCH_H_
 #define SVO_FRAME_TRACKER_BATCH_H_
 
+#include <algorithm>
 #include <cstring>
+#include <deque>
 #include <list>
 #include <map>
 #include <mutex>
@@ -153,6 +155,44 @@ class FrameTrackerT {
     return true;
   }
 
+  /// FrameHandlerBase::optimizeStructure(frame, max_n_pts, max_iter) (S/frame_handler_base.cpp:190-210) with Point::optimize on
+  /// the device over the observations the map tables hold: the selection is the reference's own (std::nth_element by
+  /// Point::last_structure_optim_ over the frame's points in fts_ order -- whatever the host's standard library makes of
+  /// ties, as on the CPU path); the new positions are written to Point::pos_ and stay in the device tables.
+  /// Points the tables do not know (created after the last upload) make the map flatten again first.
+  bool optimiseStructure(const FramePtr& frame, Map& map, size_t max_n_pts, int max_iter) {
+    if (!trk_) return false;
+    std::deque<Point*> pts;
+    bool unknown = false;
+    for (typename Host::FeatureList::iterator it = frame->fts_.begin(); it != frame->fts_.end(); ++it)
+      if ((*it)->point != NULL) {
+        pts.push_back((*it)->point);
+        if (index_of_point_.find((*it)->point) == index_of_point_.end()) unknown = true;
+      }
+    if ((map_dirty_ || unknown) && !uploadMap(map)) return false;
+    max_n_pts = std::min(max_n_pts, pts.size());
+    if (max_n_pts > 64) max_n_pts = 64;                      // one device call (Config::structureOptimMaxPts() is 20)
+    if (max_n_pts == 0) return true;
+    std::nth_element(pts.begin(), pts.begin() + max_n_pts, pts.end(), LastOptimLess());
+    std::vector<int32_t> idx;
+    std::vector<Point*> chosen;
+    for (size_t i = 0; i < max_n_pts; ++i) {
+      typename std::map<const Point*, int>::const_iterator pi = index_of_point_.find(pts[i]);
+      if (pi == index_of_point_.end()) continue;             // (a point no keyframe or candidate list holds: nothing to optimise it with)
+      bool twice = false;
+      for (size_t j = 0; j < chosen.size(); ++j) twice = twice || chosen[j] == pts[i];
+      if (twice) continue;
+      idx.push_back(pi->second); chosen.push_back(pts[i]);
+    }
+    std::vector<double> pos(idx.size() * 3 + 3);
+    if (!idx.empty() && svo_hip_tracker_optimize_structure(trk_, (int)idx.size(), idx.data(), max_iter, pos.data(), NULL) != SVO_HIP_OK) return false;
+    for (size_t i = 0; i < chosen.size(); ++i) {
+      chosen[i]->pos_[0] = pos[3 * i]; chosen[i]->pos_[1] = pos[3 * i + 1]; chosen[i]->pos_[2] = pos[3 * i + 2];
+    }
+    for (size_t i = 0; i < max_n_pts; ++i) pts[i]->last_structure_optim_ = frame->id_;          // :208
+    return true;
+  }
+
   /// new_frame_->setKeyframe(); map_.addKeyframe(new_frame_) (:284-330): keep the frame's pyramid on the device as a keyframe
   bool lastFrameBecameKeyframe(const Frame& frame) {
     const int slot = next_slot_++ % cfg_.max_keyframes;
@@ -162,6 +202,9 @@ class FrameTrackerT {
   }
 
  private:
+  struct LastOptimLess {                                   // ptLastOptimComparator (frame_handler_base.cpp:181-184)
+    bool operator()(const Point* a, const Point* b) const { return a->last_structure_optim_ < b->last_structure_optim_; }
+  };
   bool uploadLastFrame(const Frame& last) {
     std::vector<double> px, f;
     std::vector<int32_t> pt;

@@ -532,6 +532,13 @@ int svo_hip_tracker_set_map(svo_hip_tracker* trk, const svo_hip_tracker_map* map
 int svo_hip_tracker_download_key_points(svo_hip_tracker* trk, int32_t* kf_key_point);
 /* Point::pos_ of n points after FrameHandlerBase::optimizeStructure (frame_handler_base.cpp:190-210) */
 int svo_hip_tracker_update_point_positions(svo_hip_tracker* trk, int n, const int32_t* point, const double* pos);
+/* FrameHandlerBase::optimizeStructure (frame_handler_base.cpp:190-210) without the observations leaving the device: the host
+ * selects the points as the reference does (std::nth_element by Point::last_structure_optim_) and passes their indices
+ * (n <= 64, no duplicates); Point::optimize(n_iter) runs on each over the observations the map tables hold (keyframe pose +
+ * bearing in Point::obs_ order), and the new positions go into the device's point table, into the solver's copy of the last
+ * frame's points and to pos_out[n][3] (iters_out[n]: iterations taken, may be NULL).  One launch, one synchronisation;
+ * replaces svo_hip_point_optimize_batch + svo_hip_tracker_update_point_positions between two tracked frames. */
+int svo_hip_tracker_optimize_structure(svo_hip_tracker* trk, int n, const int32_t* point, int n_iter, double* pos_out, int32_t* iters_out);
 /* last_frame_ from the host (after initialisation / relocalisation): its image (level0, or NULL = the keyframe pyramid in
  * kf_slot), pose and features: px[n][2], f[n][3], point[n] (index or -1) */
 int svo_hip_tracker_set_last_frame(svo_hip_tracker* trk, const uint8_t* level0, int kf_slot, const double T_f_w[7], int n,

@@ -155,7 +155,8 @@ def _write_track_case(case, cs, frames, cfg, last_kf=-1, last_img=None, last_pos
     n_kf, n_points = int(cs["n_kf"]), int(cs["n_points"])
     _write(case / "track_manifest.bin",
            [cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, n_kf, n_points, len(cs["obs_point"]), len(cs["kf_ftr_obs"]), len(cs["cand_obs"]),
-            len(frames), cfg["grid_size"], cfg["max_fts"], cfg["quality_min_fts"], cfg["klt_min_level"], cfg["max_frame_features"], last_kf], np.float64)
+            len(frames), cfg["grid_size"], cfg["max_fts"], cfg["quality_min_fts"], cfg["klt_min_level"], cfg["max_frame_features"], last_kf,
+            cfg.get("structure_optim_max_pts", 0)], np.float64)
     for k in range(n_kf):
         _write(case / ("kf_%d_img.bin" % k), cs["kf_pyr"][k][0], np.uint8)
     _write(case / "kf_pose.bin", cs["T_kf_w"], np.float64)
@@ -230,7 +231,7 @@ def test_cpp_frame_tracker_on_a_map_with_deletions(tmp_path):
     tag, kw, max_fts = CASES[0]
     g = np.load(GOLD)
     cs = synth.make_map_case(**kw)
-    cfg = dict(grid_size=cs["cell_size"], max_fts=max_fts, quality_min_fts=20, klt_min_level=2, max_frame_features=2048)
+    cfg = dict(grid_size=cs["cell_size"], max_fts=max_fts, quality_min_fts=20, klt_min_level=2, max_frame_features=2048, structure_optim_max_pts=20)
     # the second frame: the same scene a small step further (make_map_case's own scene; the same image twice would make the
     # alignment's update exactly zero, for which SE3::exp returns a NaN translation -- in the reference too)
     scene = synth.PlaneScene(seed=kw.get("seed", 31), depth=2.0, tilt=(0.08, -0.05))
@@ -275,7 +276,22 @@ def test_cpp_frame_tracker_on_a_map_with_deletions(tmp_path):
         expect = synth.key_points(cs["cam"], cs["obs_px"][o], alive)
         if (key_after[k] != g[tag + "_kf_key_point"][k]).any():                 # the keyframe lost a key feature: all five were chosen again
             np.testing.assert_array_equal(key_after[k], np.where(expect >= 0, cs["obs_point"][o][np.maximum(expect, 0)], -1))
-    # the second frame: tracked against the re-flattened map from the first one's features
+    # FrameHandlerBase::optimizeStructure(new_frame, 20, 5) behind the first frame: twenty of the frame's points (the reference's own
+    # std::nth_element picks them), each equal to Point::optimize over its observations in the tables, bit for bit
+    from android_svo_amd import hip
+    so = rd("track_structure_first.bin", np.float64).reshape(-1, 4)
+    sel = so[:, 0].astype(np.int64)
+    assert len(sel) == 20 and len(set(sel.tolist())) == 20 and set(sel.tolist()) <= set(fp[fp >= 0].tolist())
+    off, oT, of = [0], [], []
+    for p in sel:
+        for o in range(cs["pt_obs_offset"][p], cs["pt_obs_offset"][p + 1]):
+            oT.append(cs["T_kf_w"][cs["obs_kf"][o]]); of.append(cs["obs_f"][o])
+        off.append(len(oT))
+    ctx = hip.Context(0)
+    pos_ref, _ = hip.point_optimize_batch(ctx, cs["pt_pos"][sel], np.array(off, np.int32), np.array(oT), np.array(of), n_iter=5)
+    ctx.close()
+    assert np.ascontiguousarray(so[:, 1:]).tobytes() == pos_ref.tobytes()
+    # the second frame: tracked straight on (the device tables followed the deletions and the new positions)
     assert stats[1, 4] == 1 and stats[1, 1] >= 0.8 * stats[0, 1] and stats[1, 3] > 0.5 * stats[0, 0], stats
     poses = rd("track_poses.bin", np.float64).reshape(-1, 7)
     rot, trans = synth.pose_error(poses[1], T2)

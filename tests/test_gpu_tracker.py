@@ -338,3 +338,52 @@ def test_tracker_follows_deletions_on_the_device(ctx):
     np.testing.assert_array_equal(ra["T_f_w"], rb["T_f_w"])
     rot, trans = synth.pose_error(ra["T_f_w"], T2)
     assert rot < 3e-3 and trans < 1e-2
+
+
+def test_structure_optimisation_on_the_device_tables(ctx):
+    """svo_hip_tracker_optimize_structure (FrameHandlerBase::optimizeStructure without the observations leaving the device):
+    the positions equal Point::optimize over the same observations through svo_hip_point_optimize_batch (itself bit-identical
+    to the reference's compiled point.cpp) bit for bit, and the next frame tracked after it equals the next frame tracked
+    after svo_hip_tracker_update_point_positions with those positions -- poses and features bitwise."""
+    tag, kw, max_fts = CASES[0]
+    g = np.load(GOLD)
+    cs = synth.make_map_case(**kw)
+    key = g[tag + "_kf_key_point"]
+    scene = synth.PlaneScene(seed=kw.get("seed", 31), depth=2.0, tilt=(0.08, -0.05))
+    T2 = synth.se3_mul(synth.se3_from_twist([0.012, -0.006, 0.004], [0.002, -0.003, 0.001]), cs["T_cur_w"])
+    img2 = scene.render(cs["cam"], T2)
+
+    def first_frame():
+        trk = _tracker_for(ctx, cs, key, max_fts=max_fts, quality_min_fts=20)
+        trk.set_last_frame(cs["T_cur_w"], np.zeros((0, 2)), np.zeros((0, 3)), np.zeros(0, np.int32), img=cs["cur_pyr"][0])
+        return trk, trk.track(cs["cur_pyr"][0])
+    trk, r1 = first_frame()
+    # the points of the new frame's features with at least two observations, the first twenty (Config::structureOptimMaxPts())
+    n_obs = np.diff(cs["pt_obs_offset"])
+    sel = [int(p) for p in r1["feat_point"] if p >= 0 and n_obs[p] >= 2][:20]
+    assert len(sel) == 20
+    pos_dev, it_dev = trk.optimize_structure(sel, n_iter=5)
+    # the same through the batch entry point: observations in CSR form from the tables
+    off, oT, of = [0], [], []
+    for p in sel:
+        for o in range(cs["pt_obs_offset"][p], cs["pt_obs_offset"][p + 1]):
+            oT.append(cs["T_kf_w"][cs["obs_kf"][o]]); of.append(cs["obs_f"][o])
+        off.append(len(oT))
+    pos_ref, it_ref = hip.point_optimize_batch(ctx, cs["pt_pos"][sel], np.array(off, np.int32), np.array(oT), np.array(of), n_iter=5)
+    assert pos_dev.tobytes() == pos_ref.tobytes()
+    np.testing.assert_array_equal(it_dev, it_ref)
+    assert np.abs(pos_dev - cs["pt_pos"][sel]).max() > 1e-6                        # the points moved (the map's points carry noise)
+    with pytest.raises(hip.SvoHipError):
+        trk.optimize_structure([sel[0], sel[0]])
+    ra = trk.track(img2)
+    trk.destroy()
+    # ---- the reference path: positions pushed from the host
+    trk, r1b = first_frame()
+    trk.update_point_positions(sel, pos_ref)
+    rb = trk.track(img2)
+    trk.destroy()
+    np.testing.assert_array_equal(ra["T_f_w_sia"], rb["T_f_w_sia"])
+    np.testing.assert_array_equal(ra["T_f_w"], rb["T_f_w"])
+    np.testing.assert_array_equal(ra["feat_point"], rb["feat_point"])
+    assert ra["feat_px"].tobytes() == rb["feat_px"].tobytes()
+    assert int(ra["n_matches"]) == int(rb["n_matches"]) > 100
