@@ -375,6 +375,23 @@ int ref_reproject_cells(int width, int height, double fx, double fy, double cx, 
 // observation cand_obs[c] (a feature that is in no fts_ list).
 // Outputs: kf_key_point [n_kf][5] (point index or -1) as the reference chose them BEFORE the call; per point type / counters
 // after the call and whether it is still referenced by its features; the frame's new features; overlap_kfs.
+// ref_reproject_map_keys: the same with the keyframes' key features under the caller's control -- key_override [n_kf][5]: -2 keeps
+// what Frame::setKeyPoints chose, -1 empties the slot, a point index puts that point's feature in this keyframe there (an
+// incumbent of the frame's history that a fresh selection would not necessarily pick) -- and the key points AFTER the call in
+// kf_key_after [n_kf][5]: what Map::safeDeletePoint -> Frame::removeKeyPoint -> setKeyPoints (S/map.cpp:78-88,
+// S/frame.cpp:83-165) left, executed by the reference's own compiled code inside reprojectMap.  Both may be null.
+int ref_reproject_map_keys(int width, int height, double fx, double fy, double cx, double cy, int n_levels, int grid_size, int max_fts,
+                           int n_pyr_levels, int n_kf, const uint8_t* const* const* kf_pyr, const double* T_kf_w,
+                           const uint8_t* const* cur_pyr, const double* T_cur_w, int n_points, const double* pt_pos, const int* pt_type,
+                           const int* pt_n_failed, const int* pt_n_succeeded, int n_obs, const int* obs_point, const int* obs_kf,
+                           const double* obs_px, const double* obs_f, const int* obs_level, const uint8_t* obs_edgelet,
+                           const double* obs_grad, const int* kf_ftr_offset, const int* kf_ftr_obs, int n_candidates,
+                           const int* cand_point, const int* cand_obs,
+                           int* kf_key_point, int* type_out, int* n_failed_out, int* n_succeeded_out, uint8_t* unlinked_out,
+                           int* n_overlap, int* overlap_kf, int* overlap_count, int* feat_point, double* feat_px, int* feat_level,
+                           int* feat_type, double* feat_grad, size_t* n_matches, size_t* n_trials,
+                           const int* key_override, int* kf_key_after);
+
 int ref_reproject_map(int width, int height, double fx, double fy, double cx, double cy, int n_levels, int grid_size, int max_fts,
                       int n_pyr_levels, int n_kf, const uint8_t* const* const* kf_pyr, const double* T_kf_w,
                       const uint8_t* const* cur_pyr, const double* T_cur_w, int n_points, const double* pt_pos, const int* pt_type,
@@ -385,6 +402,24 @@ int ref_reproject_map(int width, int height, double fx, double fy, double cx, do
                       int* kf_key_point, int* type_out, int* n_failed_out, int* n_succeeded_out, uint8_t* unlinked_out,
                       int* n_overlap, int* overlap_kf, int* overlap_count, int* feat_point, double* feat_px, int* feat_level,
                       int* feat_type, double* feat_grad, size_t* n_matches, size_t* n_trials) {
+  return ref_reproject_map_keys(width, height, fx, fy, cx, cy, n_levels, grid_size, max_fts, n_pyr_levels, n_kf, kf_pyr, T_kf_w, cur_pyr, T_cur_w,
+                                n_points, pt_pos, pt_type, pt_n_failed, pt_n_succeeded, n_obs, obs_point, obs_kf, obs_px, obs_f, obs_level,
+                                obs_edgelet, obs_grad, kf_ftr_offset, kf_ftr_obs, n_candidates, cand_point, cand_obs, kf_key_point, type_out,
+                                n_failed_out, n_succeeded_out, unlinked_out, n_overlap, overlap_kf, overlap_count, feat_point, feat_px,
+                                feat_level, feat_type, feat_grad, n_matches, n_trials, nullptr, nullptr);
+}
+
+int ref_reproject_map_keys(int width, int height, double fx, double fy, double cx, double cy, int n_levels, int grid_size, int max_fts,
+                           int n_pyr_levels, int n_kf, const uint8_t* const* const* kf_pyr, const double* T_kf_w,
+                           const uint8_t* const* cur_pyr, const double* T_cur_w, int n_points, const double* pt_pos, const int* pt_type,
+                           const int* pt_n_failed, const int* pt_n_succeeded, int n_obs, const int* obs_point, const int* obs_kf,
+                           const double* obs_px, const double* obs_f, const int* obs_level, const uint8_t* obs_edgelet,
+                           const double* obs_grad, const int* kf_ftr_offset, const int* kf_ftr_obs, int n_candidates,
+                           const int* cand_point, const int* cand_obs,
+                           int* kf_key_point, int* type_out, int* n_failed_out, int* n_succeeded_out, uint8_t* unlinked_out,
+                           int* n_overlap, int* overlap_kf, int* overlap_count, int* feat_point, double* feat_px, int* feat_level,
+                           int* feat_type, double* feat_grad, size_t* n_matches, size_t* n_trials,
+                           const int* key_override, int* kf_key_after) {
   svo::Config::gridSize() = (size_t)grid_size;
   svo::Config::maxFts() = (size_t)max_fts;
   svo::Config::nPyrLevels() = (size_t)n_pyr_levels;
@@ -417,6 +452,15 @@ int ref_reproject_map(int width, int height, double fx, double fy, double cx, do
   for (int k = 0; k < n_kf; ++k) {
     for (int j = kf_ftr_offset[k]; j < kf_ftr_offset[k + 1]; ++j) { kfs[k]->f->fts_.push_back(obs[kf_ftr_obs[j]]); in_fts[kf_ftr_obs[j]] = 1; }
     kfs[k]->f->setKeyPoints();                                       // the reference's own choice (frame.cpp:79-133)
+    if (key_override)
+      for (int j = 0; j < 5; ++j) {
+        const int want = key_override[5 * k + j];
+        if (want == -2) continue;
+        svo::Feature* pick = nullptr;
+        if (want >= 0)
+          for (svo::Feature* ftr : kfs[k]->f->fts_) if (ftr->point == pts[want]) { pick = ftr; break; }
+        kfs[k]->f->key_pts_[j] = pick;
+      }
   }
   for (int k = 0; k < n_kf; ++k)
     for (int j = 0; j < 5; ++j) {
@@ -451,6 +495,14 @@ int ref_reproject_map(int width, int height, double fx, double fy, double cx, do
     // cut loose: a map point whose observation list was cleared (safeDeletePoint), a candidate that left candidates_
     unlinked_out[p] = is_cand[p] ? (cand_left[p] ? 0 : 1) : ((pt_obs_nonempty(pts[p]) ? 0 : 1));
   }
+  if (kf_key_after)
+    for (int k = 0; k < n_kf; ++k)
+      for (int j = 0; j < 5; ++j) {
+        kf_key_after[5 * k + j] = -1;
+        svo::Feature* kp = kfs[k]->f->key_pts_[j];
+        if (kp != nullptr && kp->point != nullptr)
+          for (int p = 0; p < n_points; ++p) if (pts[p] == kp->point) kf_key_after[5 * k + j] = p;
+      }
   int nf = 0;
   for (svo::Feature* ftr : cur.f->fts_) {
     int idx = -1;
