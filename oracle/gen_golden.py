@@ -397,23 +397,57 @@ def gen_reproject_ref():
     np.savez_compressed(os.path.join(OUT, "reproject_ref.npz"), **out)
 
 
-MAP_REF_CASES = (("near", dict(seed=31), 1200), ("cap", dict(seed=31), 40), ("wide", dict(seed=32, n_kf=9, n_points=900, n_candidates=60, cell_size=25, kf_step=0.55), 1200))
+MAP_REF_CASES = (("near", dict(seed=31), 1200), ("cap", dict(seed=31), 40), ("wide", dict(seed=32, n_kf=9, n_points=900, n_candidates=60, cell_size=25, kf_step=0.55), 1200),
+                 ("rekey", dict(seed=31), 1200))
+
+
+def rekey_override(cs, unlinked0):
+    """Key features for the "rekey" case: the reference's own choice except for the centre slot of every keyframe and the
+    lower-right slot of every third -- in the odd keyframes the centre slot holds a point the frame is going to delete
+    (unlinked0: what it deletes with the reference's own key points), so that Map::safeDeletePoint -> Frame::removeKeyPoint
+    makes the keyframe choose again; elsewhere some other live feature's point, an incumbent a fresh selection would not pick
+    and that must survive."""
+    rng = np.random.default_rng(5)
+    cu, cv = cs["cam"].width // 2, cs["cam"].height // 2
+    ko = np.full((cs["n_kf"], 5), -2, np.int32)
+    dead0 = unlinked0.astype(bool)
+    for k in range(cs["n_kf"]):
+        o = cs["kf_ftr_obs"][cs["kf_ftr_offset"][k]:cs["kf_ftr_offset"][k + 1]]
+        pts = cs["obs_point"][o]
+        pool = [int(p) for p in pts if (dead0[p] if k % 2 else (not dead0[p] and cs["pt_type"][p] != synth.TYPE_DELETED))]
+        if pool:
+            ko[k, 0] = pool[int(rng.integers(len(pool)))]
+        if k % 3 == 0:
+            quad = [int(cs["obs_point"][oo]) for oo in o if cs["obs_px"][oo][0] >= cu and cs["obs_px"][oo][1] >= cv and not dead0[cs["obs_point"][oo]]
+                    and cs["pt_type"][cs["obs_point"][oo]] != synth.TYPE_DELETED]
+            if quad:
+                ko[k, 1] = quad[int(rng.integers(len(quad)))]
+    return ko
 
 
 def gen_reproject_map_ref():
     """The WHOLE Reprojector::reprojectMap executed by the reference's own compiled code on a real svo::Map with keyframes,
     multi-observation points and point candidates (oracle/ref/ref_objects.cpp: ref_reproject_map): close-keyframe
     selection and ordering, the projection into grid cells, the candidate loop, the cell loop with its bookkeeping.
-    Stored: the key points Frame::setKeyPoints chose (an input of the restatement) and every output."""
+    Stored: the key points the call started from (Frame::setKeyPoints' choice; in the "rekey" case with some incumbents put
+    in by hand, rekey_override), every output, and the key points Map::safeDeletePoint -> Frame::removeKeyPoint left."""
     out = {}
     for tag, kw, max_fts in MAP_REF_CASES:
         cs = synth.make_map_case(**kw)
-        r = refpy.reproject_map(cs, max_fts=max_fts)
+        ko = None
+        if tag == "rekey":
+            ko = rekey_override(cs, refpy.reproject_map(cs, max_fts=max_fts)["unlinked"])
+        r = refpy.reproject_map(cs, max_fts=max_fts, key_override=ko)
         out[tag + "_crc"] = np.array([crc(cs["cur_pyr"][0]), crc(cs["obs_px"]), crc(cs["pt_pos"]), crc(cs["kf_ftr_obs"])], dtype=np.uint64)
         out[tag + "_n"] = np.array([r["n_matches"], r["n_trials"]], dtype=np.int64)
-        for k in ("kf_key_point", "type", "n_failed", "n_succeeded", "unlinked", "overlap_kf", "overlap_count", "feat_point", "feat_px",
+        for k in ("kf_key_point", "kf_key_point_after", "type", "n_failed", "n_succeeded", "unlinked", "overlap_kf", "overlap_count", "feat_point", "feat_px",
                   "feat_level", "feat_type", "feat_grad"):
             out[tag + "_" + k] = r[k]
+        lost = np.array([bool(r["unlinked"][kk[kk >= 0]].any()) for kk in r["kf_key_point"]])
+        if tag == "rekey":
+            assert lost.sum() >= 2 and (~lost).sum() >= 2 and (r["kf_key_point_after"][lost] != r["kf_key_point"][lost]).any()
+            assert (r["kf_key_point_after"][~lost] == r["kf_key_point"][~lost]).all()
+        print("reproject_map_ref", tag, "keyframes that lost a key feature:", int(lost.sum()), "key slots changed:", int((r["kf_key_point_after"] != r["kf_key_point"]).sum()))
         n_del_loop = int(((r["unlinked"] == 1) & (cs["pt_type"] != synth.TYPE_CANDIDATE)).sum())
         print("reproject_map_ref", tag, r["n_matches"], r["n_trials"], "overlap", list(r["overlap_kf"]), "deleted in the cell loop", n_del_loop,
               "candidates deleted", int(((r["unlinked"] == 1) & (cs["pt_type"] == synth.TYPE_CANDIDATE)).sum()), "edgelet features", int((r["feat_type"] == 1).sum()))

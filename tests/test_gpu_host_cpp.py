@@ -228,7 +228,7 @@ def test_cpp_frame_tracker_on_a_map_with_deletions(tmp_path):
     assert os.path.exists(DEMO)
     case, out = tmp_path / "case", tmp_path / "out"
     case.mkdir(); out.mkdir()
-    tag, kw, max_fts = CASES[0]
+    tag, kw, max_fts = [c for c in CASES if c[0] == "wide"][0]      # (a keyframe loses a key feature to a deleted point in this case)
     g = np.load(GOLD)
     cs = synth.make_map_case(**kw)
     cfg = dict(grid_size=cs["cell_size"], max_fts=max_fts, quality_min_fts=20, klt_min_level=2, max_frame_features=2048, structure_optim_max_pts=20)
@@ -269,6 +269,8 @@ def test_cpp_frame_tracker_on_a_map_with_deletions(tmp_path):
     # removeKeyPoint / setKeyPoints after the deletions: no key feature refers to a deleted point, and a keyframe that lost one
     # chose again among its remaining features
     key_after = rd("track_key_after_first.bin", np.int32).reshape(n_kf, 5)
+    np.testing.assert_array_equal(key_after, g[tag + "_kf_key_point_after"])     # what the reference's own removeKeyPoint / setKeyPoints left
+    assert (key_after != g[tag + "_kf_key_point"]).any()
     assert not deleted_now[key_after[key_after >= 0]].any()
     for k in range(n_kf):
         o = cs["kf_ftr_obs"][cs["kf_ftr_offset"][k]:cs["kf_ftr_offset"][k + 1]]

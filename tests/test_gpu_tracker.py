@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import tracking_chain as tc
-from test_oracle_reproject_map import CASES, GOLD, check_map_result
+from test_oracle_reproject_map import CASES, GOLD, check_map_result, rekey_expected
 from android_svo_amd import hip, synth
 from oracle import orc
 
@@ -233,70 +233,19 @@ def test_last_frame_indices_are_checked_against_the_map(ctx):
     trk.destroy()
 
 
-def _rekey_expected(cs, key, deleted):
-    """Frame::removeKeyPoint / setKeyPoints (S/frame.cpp:83-165) on every keyframe after Map::safeDeletePoint of the points in
-    `deleted`: a keyframe none of whose key features lost its point is left alone; in the others every slot is contested
-    again by every feature that still has a point, in fts_ order, an incumbent staying unless strictly beaten."""
-    cam = cs["cam"]
-    cu, cv = cam.width // 2, cam.height // 2
-    out = key.copy()
-    for k in range(cs["n_kf"]):
-        o = cs["kf_ftr_obs"][cs["kf_ftr_offset"][k]:cs["kf_ftr_offset"][k + 1]]
-        px_of = {int(cs["obs_point"][oo]): cs["obs_px"][oo] for oo in np.where(cs["obs_kf"] == k)[0]}
-        cur = [int(p) for p in key[k]]
-        found = False
-        for j in range(5):
-            if cur[j] >= 0 and deleted[cur[j]]:
-                cur[j] = -1
-                found = True
-        if not found:
-            continue
-
-        def value(j, x, y):
-            if j == 0:
-                return -max(abs(x - cu), abs(y - cv))                          # smaller distance = better: negated
-            cond = (x >= cu and y >= cv, x >= cu and y < cv, x < cv and y < cv, x < cv and y >= cv)[j - 1]
-            return (x - cu) * (y - cv) if cond else None
-        for oo in o:
-            p = int(cs["obs_point"][oo])
-            if deleted[p]:
-                continue
-            x, y = cs["obs_px"][oo]
-            for j in range(5):
-                v = value(j, x, y)
-                if v is None:
-                    continue
-                if cur[j] < 0:
-                    cur[j] = p
-                else:
-                    xi, yi = px_of[cur[j]]
-                    vi = -max(abs(xi - cu), abs(yi - cv)) if j == 0 else (xi - cu) * (yi - cv)
-                    if v > vi:
-                        cur[j] = p
-        out[k] = cur
-    return out
-
-
 def test_tracker_follows_deletions_on_the_device(ctx):
     """A frame that deletes map points (Map::safeDeletePoint / deleteCandidatePoint in the reprojector) does not need the map
     uploaded again: the points are unlinked in the device tables and the keyframes that lost a key feature choose their key
     features again with Frame::removeKeyPoint's rule (incumbents of untouched keyframes and slots stay, even non-optimal
     ones).  The next frame tracked straight on equals the next frame tracked after applying the deletions to the host
     tables and uploading them -- every integer, pixels bitwise."""
-    tag, kw, max_fts = CASES[0]
+    tag, kw, max_fts = [c for c in CASES if c[0] == "rekey"][0]
     g = np.load(GOLD)
     cs = synth.make_map_case(**kw)
-    rng = np.random.default_rng(5)
-    key = g[tag + "_kf_key_point"].copy()
-    deleted0 = g[tag + "_unlinked"].astype(bool)                                 # what the frame deletes with the fixture's key points
-    # Incumbents a fresh selection would not pick: in the even keyframes the centre slot holds some other live feature's point
-    # (must survive untouched), in the odd ones a point the frame is going to delete (the keyframe must choose again).
-    for k in range(cs["n_kf"]):
-        o = cs["kf_ftr_obs"][cs["kf_ftr_offset"][k]:cs["kf_ftr_offset"][k + 1]]
-        pts = cs["obs_point"][o]
-        pool = [int(p) for p in pts if (deleted0[p] if k % 2 else (not deleted0[p] and cs["pt_type"][p] != synth.TYPE_DELETED))]
-        if pool:
-            key[k, 0] = pool[int(rng.integers(len(pool)))]
+    # the "rekey" case of the fixture: key features with incumbents put in by hand (oracle/gen_golden.py: rekey_override) -- in some
+    # keyframes a point the frame deletes, in others a live feature a fresh selection would not pick -- and what the reference's
+    # own Map::safeDeletePoint -> Frame::removeKeyPoint made of them
+    key = g[tag + "_kf_key_point"]
     scene = synth.PlaneScene(seed=kw.get("seed", 31), depth=2.0, tilt=(0.08, -0.05))
     T2 = synth.se3_mul(synth.se3_from_twist([0.012, -0.006, 0.004], [0.002, -0.003, 0.001]), cs["T_cur_w"])
     img2 = scene.render(cs["cam"], T2)
@@ -308,14 +257,14 @@ def test_tracker_follows_deletions_on_the_device(ctx):
     # ---- A: straight on
     trk, r1 = first_frame()
     assert r1["map_changed"] == 1
-    deleted = (r1["type"] == synth.TYPE_DELETED) & (cs["pt_type"] != synth.TYPE_DELETED)      # (other key points, other close keyframes: not the fixture's set)
+    deleted = (r1["type"] == synth.TYPE_DELETED) & (cs["pt_type"] != synth.TYPE_DELETED)
+    np.testing.assert_array_equal(deleted.astype(np.uint8), g[tag + "_unlinked"].astype(np.uint8))
     key_dev = trk.download_key_points(cs["n_kf"])
-    expect = _rekey_expected(cs, key, deleted)
+    np.testing.assert_array_equal(key_dev, g[tag + "_kf_key_point_after"])        # the reference's own result
+    expect = rekey_expected(cs, key, deleted)
     np.testing.assert_array_equal(key_dev, expect)
     lost = np.array([deleted[key[k][key[k] >= 0]].any() for k in range(cs["n_kf"])])
-    assert lost.sum() >= 2 and (~lost).sum() >= 2                                  # some keyframes chose again ...
-    np.testing.assert_array_equal(expect[~lost], key[~lost])                       # ... the others kept their (partly non-optimal) incumbents
-    assert (expect[lost] != key[lost]).any()
+    assert lost.sum() >= 2 and (~lost).sum() >= 2 and (expect[lost] != key[lost]).any()
     ra = trk.track(img2)
     trk.destroy()
     # ---- B: the deletions applied to the host tables, the map uploaded again, the last frame handed over by the host
