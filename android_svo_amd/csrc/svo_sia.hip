@@ -1720,6 +1720,7 @@ struct svo_hip_sia {
   float4* wmem = nullptr;                                        // fused kernel: [batch][max_tiles][8][TILE] interpolated patches
   int max_tiles = 0;
   double* partial = nullptr;
+  double* partial_alt = nullptr;   // sharded solve: a launch reads the exchanged partials of the previous evaluation from one buffer and writes its own into the other
   double* reduce_own = nullptr;
   double* reduce = nullptr;
   unsigned int* n_pre_count = nullptr;
@@ -2011,6 +2012,7 @@ int svo_hip_sia_create(svo_hip_ctx* ctx, int batch, int max_features, svo_hip_si
   A(dev_alloc(ctx, &s->tile_h, (size_t)batch * s->max_tiles * TILE_ROW));
   A(dev_alloc(ctx, &s->wmem, (size_t)batch * s->max_tiles * 8 * TILE));
   A(dev_alloc(ctx, &s->partial, (size_t)batch * MAX_CHUNKS * RED));
+  A(dev_alloc(ctx, &s->partial_alt, (size_t)batch * MAX_CHUNKS * RED));
   A(dev_alloc(ctx, &s->reduce_own, (size_t)batch * RED));
   A(dev_alloc(ctx, &s->n_pre_count, batch));
   s->h_fc = new (std::nothrow) FrameConst[batch];
@@ -2035,7 +2037,7 @@ int svo_hip_sia_destroy(svo_hip_sia* s) {
   (void)hipStreamSynchronize(ctx->stream);
   drop_level_graphs(s);
   void* ptrs[] = {s->st_alt, s->fc, s->st, s->px, s->f, s->pos, s->has_point, s->visible, s->ref_cache, s->dxc, s->dyc,
-                  s->sxyz, s->xyz4, s->tile_h, s->wmem, s->partial, s->reduce_own, s->n_pre_count};
+                  s->sxyz, s->xyz4, s->tile_h, s->wmem, s->partial, s->partial_alt, s->reduce_own, s->n_pre_count};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev_res) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_pre) (void)hipEventDestroy(e);
@@ -2149,7 +2151,12 @@ int svo_hip_sia_level_begin(svo_hip_sia* s, int level) {
 
 // One evaluation.  st_in / st_out: the control step of the previous evaluation, whose block partials have been all-reduced
 // in place since, is taken at the head of the launch (state read from st_in, stepped state written to st_out).
-static int launch_residual(svo_hip_sia* s, const FrameState* st_in = nullptr, FrameState* st_out = nullptr) {
+// pending / out_partial (sharded solve): the exchanged block partials of the previous evaluation and where this launch
+// writes its own -- two DIFFERENT buffers: a block that is through writes its row while another block of the frame may still
+// be reading the previous evaluation's rows at its head.
+static int launch_residual(svo_hip_sia* s, const FrameState* st_in = nullptr, FrameState* st_out = nullptr, const double* pending = nullptr,
+                           double* out_partial = nullptr) {
+  if (!out_partial) out_partial = s->partial;
   svo_hip_ctx* ctx = s->ctx;
   const int level = s->level;
   LevelGeom g;
@@ -2161,15 +2168,15 @@ static int launch_residual(svo_hip_sia* s, const FrameState* st_in = nullptr, Fr
   const Shard sh = {s->shard_rank, s->shard_world};
   SiaStepFusion fu;
   memset(&fu, 0, sizeof(fu));
-  if (st_out) { fu.pending = s->partial; fu.st_out = st_out; fu.n_iter = s->prm.n_iter; fu.early_stop = s->prm.early_stop; fu.eps = s->prm.eps; }
+  if (st_out) { fu.pending = pending; fu.st_out = st_out; fu.n_iter = s->prm.n_iter; fu.early_stop = s->prm.early_stop; fu.eps = s->prm.eps; }
   if (st_in)
     hipLaunchKernelGGL(sia_residual_kernel<true>, grid, block, 0, ctx->stream, s->fc, st_in, s->cur->base, s->cur->pyr_bytes,
                        g, level, s->max_n, s->max_tiles, s->chunks, sh, s->ref_cache, s->dxc, s->dyc, s->sxyz, s->xyz4,
-                       s->tile_h, s->visible, s->partial, fu);
+                       s->tile_h, s->visible, out_partial, fu);
   else
     hipLaunchKernelGGL(sia_residual_kernel<false>, grid, block, 0, ctx->stream, s->fc, s->st, s->cur->base, s->cur->pyr_bytes,
                        g, level, s->max_n, s->max_tiles, s->chunks, sh, s->ref_cache, s->dxc, s->dyc, s->sxyz, s->xyz4,
-                       s->tile_h, s->visible, s->partial, fu);
+                       s->tile_h, s->visible, out_partial, fu);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
@@ -2177,11 +2184,11 @@ static int launch_residual(svo_hip_sia* s, const FrameState* st_in = nullptr, Fr
 
 // the control step as a launch of its own: from the block partials (single device) or from the reduce buffer; the state is
 // stepped in place in the home buffer unless st_in names the buffer it currently lives in
-static int launch_solve(svo_hip_sia* s, bool from_partials, const FrameState* st_in = nullptr) {
+static int launch_solve(svo_hip_sia* s, bool from_partials, const FrameState* st_in = nullptr, const double* partials = nullptr) {
   svo_hip_ctx* ctx = s->ctx;
   const FrameState* in = st_in ? st_in : s->st;
   if (from_partials)
-    hipLaunchKernelGGL(sia_solve_kernel<true>, dim3(s->n_slots), dim3(64), 0, ctx->stream, in, s->st, s->partial, s->chunks,
+    hipLaunchKernelGGL(sia_solve_kernel<true>, dim3(s->n_slots), dim3(64), 0, ctx->stream, in, s->st, partials ? partials : s->partial, s->chunks,
                        s->n_slots, s->level, s->prm.n_iter, s->prm.eps, s->prm.early_stop);
   else
     hipLaunchKernelGGL(sia_solve_kernel<false>, dim3(s->n_slots), dim3(64), 0, ctx->stream, in, s->st, s->reduce, s->chunks,
@@ -2261,13 +2268,17 @@ static int sharded_level(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, const 
   const FrameState* in = s->st;
   FrameState* out = s->st_alt;
   const size_t n_exchange = (size_t)n_slots * s->chunks * SVO_HIP_REDUCE_DOUBLES;
+  const double* pending = nullptr;           // exchanged partials of the previous evaluation
+  double* mine = s->partial;                 // where this evaluation's partials go (the two buffers change roles per step)
   for (int it = 0; it < prm->n_iter; ++it) {
-    rc = launch_residual(s, in, it == 0 ? nullptr : out);
+    rc = launch_residual(s, in, it == 0 ? nullptr : out, pending, mine);
     if (it > 0) { const FrameState* t = in; in = out; out = const_cast<FrameState*>(t); }
     if (rc != SVO_HIP_OK) return rc;
-    if ((rc = svo_comm_all_reduce_sum_f64(comm, s->partial, n_exchange)) != SVO_HIP_OK) return rc;
+    if ((rc = svo_comm_all_reduce_sum_f64(comm, mine, n_exchange)) != SVO_HIP_OK) return rc;
+    pending = mine;
+    mine = mine == s->partial ? s->partial_alt : s->partial;
   }
-  if (prm->n_iter > 0 && (rc = launch_solve(s, true, in)) != SVO_HIP_OK) return rc;
+  if (prm->n_iter > 0 && (rc = launch_solve(s, true, in, pending)) != SVO_HIP_OK) return rc;
   return SVO_HIP_OK;
 }
 

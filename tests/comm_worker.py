@@ -1,6 +1,6 @@
 """One rank of the native multi-GPU entry points (svo_hip_sia_run_sharded, svo_hip_seed_gather_converged_dev), started by
 tests/test_gpu_comm.py as a subprocess.  usage: comm_worker.py <what> <transport> <rank> <world> <token> <out.npz>
-  what      = sia | seeds
+  what      = sia | sia_c3 | sia_c3_full | sia_timing | seeds
   transport = shm (token = segment name; the ranks may share one GPU) | rccl (token = file holding the 128-byte unique id)
 """
 import os
@@ -36,6 +36,26 @@ def main():
         hip.sia_run_sharded(sia, comm, len(fps), prm)
         r = sia.download_all(len(fps))
         np.savez(out, T=np.array([list(x.T_cur_w) for x in r]), n=np.array([x.n_tracked for x in r]), H=np.array([list(x.H) for x in r]))
+    elif what == "sia_timing":
+        # the configuration that exposed a race inside one launch of the sharded solve (a block writing its new partial row
+        # while another block of the frame still read the previous evaluation's exchanged rows from the same buffer): small
+        # shards (short launches), event records around every launch (other launch timing), several solves in a row
+        fps = [synth.make_frame_pair(seed=12345 + i, n_features=2000) for i in range(6)]
+        cam = fps[0].cam
+        ref = hip.Pyramid(ctx, cam.width, cam.height, 5, len(fps))
+        cur = hip.Pyramid(ctx, cam.width, cam.height, 5, len(fps))
+        sia = hip.SparseImgAlign(ctx, len(fps), 2000)
+        sia.set_frames(ref, cur)
+        for s, fp in enumerate(fps):
+            ref.upload(s, fp.ref_pyr); cur.upload(s, fp.cur_pyr); sia.upload_pair(s, fp)
+        prm = sia.params(max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=False)
+        sia.set_profiling(True)
+        Ts = []
+        for rep in range(4):
+            hip.sia_run_sharded(sia, comm, len(fps), prm)
+            Ts.append(np.array([list(x.T_cur_w) for x in sia.download_all(len(fps))]))
+        sia.get_profile()
+        np.savez(out, T=np.stack(Ts))
     elif what == "sia":
         # three frame pairs of different sizes (one with point-less features), identical on every rank
         fps = [synth.make_frame_pair(seed=900 + i, n_features=n, null_point_every=k) for i, (n, k) in enumerate(((700, 0), (333, 7), (1500, 0)))]

@@ -97,6 +97,25 @@ def test_config_c3_shape_two_ranks_on_one_gpu(tmp_path):
         assert int(res[0]["n"][s]) == o.n_tracked == 2000
 
 
+@pytest.mark.parametrize("world", [3, 4])
+def test_sharded_solve_does_not_depend_on_launch_timing(tmp_path, world):
+    """Regression test for a race inside one launch of svo_hip_sia_run_sharded (found by rehearsing `bench.py --mode allreduce`
+    with 3 and 4 ranks on one GPU): the evaluation kernel read the previous evaluation's exchanged block partials at its head
+    and wrote its own partials at its tail into the SAME buffer, so a block that finished early could overwrite rows another
+    block of the frame had not read yet -- the ranks then stepped differently and drifted apart by ~1e-4 rad, in about half
+    of the runs with three or more ranks and event records around the launches.  The partials are double-buffered now: four
+    solves in a row, event profiling on, every rank and every repetition the same bits, poses at the oracle's."""
+    res = _run_ranks("sia_timing", "shm", world, tmp_path)
+    for r in res:
+        for rep in range(r["T"].shape[0]):
+            np.testing.assert_array_equal(r["T"][rep], res[0]["T"][0])
+    for s in range(6):
+        fp = synth.make_frame_pair(seed=12345 + s, n_features=2000)
+        o = orc.sparse_img_align(fp, n_iter=30, early_stop=False)
+        rot, trans = synth.pose_error(res[0]["T"][0][s], np.array(o.T_cur_w))
+        assert rot < 1e-8 and trans < 1e-8, (s, rot, trans)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_config_c3_full_size_on_one_gpu(tmp_path, world):
     """BASELINE config C3 at its full size -- 8 concurrent 1280x720 pairs, 2000 patches each, 5 levels x 30 evaluations --
