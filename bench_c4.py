@@ -48,10 +48,19 @@ def main():
     import torch
     import torch.distributed as dist
     multi = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (bench.py has the same): shared device(s), gloo
+    # process group, the library's shared-memory transport instead of RCCL; marked in the JSON line, measures nothing
+    n_dev = torch.cuda.device_count()
+    rehearsal = multi and n_dev < world
+    if rehearsal:
+        local_rank = local_rank % max(n_dev, 1)
     torch.cuda.set_device(local_rank)
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # the same synthetic keyframe / frame / seed set on every rank (same generator seed); each rank keeps its slice
     sc = seedsynth.make_seed_case(n_seeds=args.seeds, seed=9, width=args.width, height=args.height)
@@ -73,9 +82,15 @@ def main():
     cap = hi - lo if world == 1 else max(1, (args.seeds + world - 1) // world)
     if multi and args.gather == "native":
         # the C-ABI's own communicator: rank 0's ncclUniqueId travels through torch.distributed.run's process group
-        uid = [hip.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = hip.Comm(ctx, rank, world, kind="rccl", unique_id=uid[0])
+        if rehearsal:
+            import uuid
+            nm = ["/svo_c4_" + uuid.uuid4().hex[:10] if rank == 0 else None]
+            dist.broadcast_object_list(nm, src=0)
+            comm = hip.Comm(ctx, rank, world, kind="shm", name=nm[0], slot_bytes=max(1 << 20, cap * 48 + 64))
+        else:
+            uid = [hip.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = hip.Comm(ctx, rank, world, kind="rccl", unique_id=uid[0])
         rec_all = ctx.empty((world * cap, 6), np.float64)
         cnt_all = ctx.empty((world,), np.int32)
 
@@ -108,7 +123,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if comm is not None:
@@ -118,6 +133,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 geometry / f32 image math / int32 ZMSSD",
                "data": "synthetic",
+               **({"rehearsal": "%d ranks share %d GPU(s): gloo process group, shared-memory exchange -- a code-path rehearsal, not a scaling measurement" % (world, n_dev)} if rehearsal else {}),
                "config": {"workload": "C4: DepthFilter::updateSeeds, %d seeds on a %dx%d keyframe, seeds sharded over %d GPU(s), gather of converged records"
                                       % (args.seeds, args.width, args.height, world),
                           "seeds_per_gpu": hi - lo, "converged_records_gathered": int(n_conv_total),
