@@ -1,0 +1,38 @@
+"""bench.py's multi-rank code path, rehearsed with more ranks than GPUs (bench.py then uses a gloo process group and, for the
+sharded mode, the library's shared-memory exchange; its JSON line says `rehearsal`).  The driver launches the same command
+on a multi-GPU node at round end; nothing here measures scaling -- it keeps the branch that only runs with WORLD_SIZE > 1
+executable (rank-0-only sections, the timing all-reduce, the communicator hand-over, the parity check over the global batch)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _torchrun(n, port, *args):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--no-secondary",
+           "--no-cpu-baseline", "--distinct", "4"] + list(args)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                   # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_frame_parallel_two_ranks():
+    d = _torchrun(2, 29671, "--batch", "8")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "rehearsal" in d
+    assert d["config"]["global_frame_pairs_per_step"] == 16
+    assert d["pose_err_vs_cpu_ref"]["max_rot_rad_over_scenes"] < 1e-4 and d["value"] > 0
+
+
+def test_bench_sharded_three_ranks():
+    d = _torchrun(3, 29672, "--mode", "allreduce", "--batch", "1")
+    assert d["n_gpus"] == 3 and "rehearsal" in d and "patch-sharded" in d["config"]["parallelism"]
+    assert d["pose_err_vs_cpu_ref"]["max_rot_rad_over_scenes"] < 1e-8          # fixed work: the same evaluation sequence as the oracle
