@@ -336,3 +336,50 @@ def test_structure_optimisation_on_the_device_tables(ctx):
     np.testing.assert_array_equal(ra["feat_point"], rb["feat_point"])
     assert ra["feat_px"].tobytes() == rb["feat_px"].tobytes()
     assert int(ra["n_matches"]) == int(rb["n_matches"]) > 100
+
+
+def test_sequence_over_a_map_that_loses_points(ctx):
+    """Six frames along a path over the 14-keyframe map (multi-observation points, point candidates, points close to their
+    deletion thresholds): the reprojector deletes points in several of the frames.  The tracker is never given the map
+    again -- it unlinks the points and re-selects key points on the device -- and is compared frame by frame with the oracle
+    composition of processFrame, whose tables get Map::safeDeletePoint's key-point rule (rekey_expected) applied between the
+    frames: every integer equal, poses within 1e-6 (north_star: 1e-4 rad / 1e-3 m)."""
+    tag, kw, max_fts = [c for c in CASES if c[0] == "rekey"][0]
+    g = np.load(GOLD)
+    cs = synth.make_map_case(**kw)
+    key = g[tag + "_kf_key_point"].copy()
+    scene = synth.PlaneScene(seed=kw.get("seed", 31), depth=2.0, tilt=(0.08, -0.05))
+    step = synth.se3_from_twist([0.011, -0.005, 0.003], [0.0015, -0.0025, 0.001])
+    poses = [cs["T_cur_w"]]
+    for _ in range(5):
+        poses.append(synth.se3_mul(step, poses[-1]))
+    pyrs = [cs["cur_pyr"]] + [synth.build_pyramid(scene.render(cs["cam"], T)) for T in poses[1:]]
+    # ---- HIP: one set_map, then frames only
+    trk = _tracker_for(ctx, cs, key, max_fts=max_fts, quality_min_fts=20)
+    trk.set_last_frame(cs["T_cur_w"], np.zeros((0, 2)), np.zeros((0, 3)), np.zeros(0, np.int32), img=pyrs[0][0])
+    hip_res = [trk.track(p[0]) for p in pyrs]
+    trk.destroy()
+    # ---- oracle composition with the key points advanced between the frames
+    mp = dict(cs, kf_key_point=key.copy())
+    state = {"pt_type": cs["pt_type"].astype(np.int32).copy(), "pt_n_failed": cs["pt_n_failed"].astype(np.int32).copy(),
+             "pt_n_succeeded": cs["pt_n_succeeded"].astype(np.int32).copy(), "unlinked": np.zeros(cs["n_points"], np.uint8)}
+    last = dict(T=cs["T_cur_w"].copy(), px=np.zeros((0, 2)), f=np.zeros((0, 3)), point=np.zeros(0, np.int32))
+    frames_with_deletions = 0
+    for k, (pyr, rh) in enumerate(zip(pyrs, hip_res)):
+        before = state["unlinked"].copy()
+        ro = tc.oracle_track_frame(orc, mp, state, last, pyrs[k - 1] if k else pyrs[0], pyr, 2, max_fts=max_fts, quality_min_fts=20)
+        assert int(rh["n_matches"]) == int(ro["n_matches"]) and int(rh["n_trials"]) == int(ro["n_trials"]), k
+        np.testing.assert_array_equal(rh["feat_point"], ro["feat_point"], err_msg="frame %d" % k)
+        np.testing.assert_array_equal(rh["feat_level"], ro["feat_level"])
+        for name in ("type", "n_failed", "n_succeeded"):
+            np.testing.assert_array_equal(rh[name], ro[name], err_msg="frame %d %s" % (k, name))
+        np.testing.assert_array_equal(rh["overlap_kf"], ro["overlap_kf"])
+        rot, trans = synth.pose_error(rh["T_f_w"], ro["T_f_w"])
+        assert rot < 1e-6 and trans < 1e-6, (k, rot, trans)
+        assert int(rh["n_matches"]) > 100
+        if (state["unlinked"] != before).any():
+            frames_with_deletions += 1
+            assert rh["map_changed"] == 1
+            mp["kf_key_point"] = rekey_expected(cs, mp["kf_key_point"], state["unlinked"].astype(bool))
+        last = dict(T=ro["T_f_w"].copy(), px=ro["feat_px"], f=ro["feat_f"], point=ro["feat_point"])
+    assert frames_with_deletions >= 2
