@@ -118,7 +118,8 @@ static int track_demo(const std::string& dir, const std::string& out) {
 
   svo_hip_tracker_config cfg;
   svo_hip_tracker_default_config(&cfg);
-  cfg.max_keyframes = n_kf > 1 ? n_kf : 1; cfg.grid_size = (int)m[12]; cfg.max_fts = (int)m[13]; cfg.quality_min_fts = (int)m[14];
+  cfg.max_keyframes = n_kf + 2;                                               // room for a frame that becomes a keyframe
+  cfg.grid_size = (int)m[12]; cfg.max_fts = (int)m[13]; cfg.quality_min_fts = (int)m[14];
   cfg.klt_min_level = (int)m[15]; cfg.max_frame_features = (int)m[16];
   FrameTracker tracker(cam, cfg);
   if (!tracker.ok()) throw std::runtime_error("svo::FrameTracker: no device tracker");
@@ -187,6 +188,16 @@ static int track_demo(const std::string& dir, const std::string& out) {
         linked.push_back(cand_alive && feature_of_obs[o] && feature_of_obs[o]->point != nullptr ? 1 : 0);
       }
       write_bin(out + "/track_obs_linked_after_first.bin", linked);
+    }
+    if (m.size() > 19 && (int)m[19] == k) {
+      // FrameHandlerMono::processFrame :284-330: the tracked frame becomes a keyframe -- setKeyframe (key points), every feature
+      // with a point becomes an observation of it (Point::addFrameRef: front of obs_), the map takes the frame, the device
+      // keeps its pyramid; the tracker flattens the grown map before the next frame
+      cur->setKeyframe();
+      for (Feature* ftr : cur->fts_) if (ftr->point != nullptr) ftr->point->addFrameRef(ftr);
+      map.addKeyframe(cur);
+      kfs.push_back(cur);
+      if (!tracker.lastFrameBecameKeyframe(*cur)) throw std::runtime_error("svo::FrameTracker::lastFrameBecameKeyframe failed");
     }
     last = cur;
   }

@@ -93,6 +93,7 @@ struct Point {                                      // I/point.h: position + the
   int last_structure_optim_ = 0;                                                 // id of the frame that optimised it last (:51)
   explicit Point(const Vector3d& p) : pos_(p) {}
   Point(const Vector3d& p, Feature* ftr) : pos_(p) { obs_.push_front(ftr); }     // S/point.cpp:39-48
+  void addFrameRef(Feature* ftr) { obs_.push_front(ftr); }                       // S/point.cpp:52-55
 };
 struct Frame;
 struct Feature {

@@ -156,7 +156,7 @@ def _write_track_case(case, cs, frames, cfg, last_kf=-1, last_img=None, last_pos
     _write(case / "track_manifest.bin",
            [cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, n_kf, n_points, len(cs["obs_point"]), len(cs["kf_ftr_obs"]), len(cs["cand_obs"]),
             len(frames), cfg["grid_size"], cfg["max_fts"], cfg["quality_min_fts"], cfg["klt_min_level"], cfg["max_frame_features"], last_kf,
-            cfg.get("structure_optim_max_pts", 0)], np.float64)
+            cfg.get("structure_optim_max_pts", 0), cfg.get("keyframe_at", -1)], np.float64)
     for k in range(n_kf):
         _write(case / ("kf_%d_img.bin" % k), cs["kf_pyr"][k][0], np.uint8)
     _write(case / "kf_pose.bin", cs["T_kf_w"], np.float64)
@@ -298,3 +298,42 @@ def test_cpp_frame_tracker_on_a_map_with_deletions(tmp_path):
     poses = rd("track_poses.bin", np.float64).reshape(-1, 7)
     rot, trans = synth.pose_error(poses[1], T2)
     assert rot < 3e-3 and trans < 1e-2, (rot, trans)                            # the second frame's true pose
+
+
+def test_cpp_frame_tracker_promotes_a_frame_to_keyframe(tmp_path):
+    """The keyframe flow of FrameHandlerMono::processFrame (:284-330) through the C++ host twin: after the fifth tracked frame
+    the svo::Frame becomes a keyframe (Frame::setKeyframe -> key points, Point::addFrameRef for its features, Map::addKeyframe),
+    svo::FrameTracker::lastFrameBecameKeyframe keeps its pyramid on the device, and the next call flattens the grown object
+    graph (two keyframes, two observations per re-observed point, newest first).  All eight frames equal the Python-driven
+    tracker fed with the same grown map as tables (tests/test_gpu_tracker.py::test_last_frame_becomes_a_keyframe) bit for bit."""
+    import tracking_chain as tc
+    from android_svo_amd import hip
+    assert os.path.exists(DEMO)
+    case, out = tmp_path / "case", tmp_path / "out"
+    case.mkdir(); out.mkdir()
+    seq = tc.make_sequence(n_frames=9)
+    mp = tc.sequence_map(seq)
+    n = len(seq["px0"])
+    cs = dict(mp, obs_point=np.arange(n, dtype=np.int32), kf_ftr_obs=np.arange(n, dtype=np.int32), cand_obs=np.zeros(0, np.int32))
+    cfg = dict(grid_size=tc.CELL, max_fts=tc.MAX_FTS, quality_min_fts=40, klt_min_level=2, max_frame_features=1024, keyframe_at=4)
+    _write_track_case(case, cs, [seq["pyrs"][k][0] for k in range(1, 9)], cfg, last_kf=0)
+    rd = _run_track_demo(case, out)
+    poses = rd("track_poses.bin", np.float64).reshape(-1, 7)
+    ctx = hip.Context(0)
+    trk = hip.Tracker(ctx, seq["cam"], max_keyframes=4, grid_size=tc.CELL, max_fts=tc.MAX_FTS, klt_min_level=2, max_frame_features=1024)
+    trk.upload_keyframe(0, seq["pyrs"][0][0])
+    trk.set_map(mp)
+    trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)
+    used_new_kf = False
+    for k in range(1, 9):
+        r = trk.track(seq["pyrs"][k][0])
+        np.testing.assert_array_equal(poses[k - 1], r["T_f_w"], err_msg="frame %d" % k)
+        np.testing.assert_array_equal(rd("track_feat_%d_point.bin" % (k - 1), np.int32), r["feat_point"])
+        np.testing.assert_array_equal(rd("track_feat_%d_px.bin" % (k - 1), np.float64).reshape(-1, 2), r["feat_px"])
+        used_new_kf = used_new_kf or 1 in list(r["overlap_kf"])
+        if k == 5:
+            trk.keyframe_from_last_frame(1)
+            trk.set_map(tc.map_with_tracked_frame_as_keyframe(seq, mp, r))
+    assert used_new_kf
+    trk.destroy(); ctx.close()
+

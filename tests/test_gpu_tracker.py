@@ -383,3 +383,49 @@ def test_sequence_over_a_map_that_loses_points(ctx):
             mp["kf_key_point"] = rekey_expected(cs, mp["kf_key_point"], state["unlinked"].astype(bool))
         last = dict(T=ro["T_f_w"].copy(), px=ro["feat_px"], f=ro["feat_f"], point=ro["feat_point"])
     assert frames_with_deletions >= 2
+
+
+def test_last_frame_becomes_a_keyframe(ctx):
+    """FrameHandlerMono::processFrame :284-330 -- new_frame_->setKeyframe(); point->addFrameRef(feature); map_.addKeyframe(new_frame_):
+    svo_hip_tracker_keyframe_from_last_frame keeps the tracked frame's pyramid on the device as a keyframe, the host uploads the
+    grown map (same point numbering: the last frame stays where it is), tracking goes on.  Equal, bit for bit, to a tracker
+    that gets the new keyframe's image and the last frame from the host."""
+    seq = tc.make_sequence(n_frames=9)
+    mp = tc.sequence_map(seq)
+    cam = seq["cam"]
+    n = len(seq["px0"])
+    cfg = dict(max_keyframes=4, grid_size=tc.CELL, max_fts=tc.MAX_FTS, klt_min_level=2, max_frame_features=1024)
+
+    def start():
+        trk = hip.Tracker(ctx, cam, **cfg)
+        trk.upload_keyframe(0, seq["pyrs"][0][0])
+        trk.set_map(mp)
+        trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)
+        rs = [trk.track(seq["pyrs"][k][0]) for k in range(1, 6)]
+        return trk, rs
+    trk, rs = start()
+    r5 = rs[-1]
+    mp2 = tc.map_with_tracked_frame_as_keyframe(seq, mp, r5)
+    # ---- A: the device keeps the frame
+    trk.keyframe_from_last_frame(1)
+    trk.set_map(mp2)
+    ra = [trk.track(seq["pyrs"][k][0]) for k in range(6, 9)]
+    trk.destroy()
+    # ---- B: everything from the host
+    trk, rs_b = start()
+    np.testing.assert_array_equal(rs_b[-1]["T_f_w"], r5["T_f_w"])
+    trk.upload_keyframe(1, seq["pyrs"][5][0])
+    trk.set_map(mp2)
+    trk.set_last_frame(r5["T_f_w"], r5["feat_px"], r5["feat_f"], r5["feat_point"], img=seq["pyrs"][5][0])
+    rb = [trk.track(seq["pyrs"][k][0]) for k in range(6, 9)]
+    trk.destroy()
+    used_new_kf = False
+    for a, b in zip(ra, rb):
+        np.testing.assert_array_equal(a["T_f_w"], b["T_f_w"])
+        np.testing.assert_array_equal(a["feat_point"], b["feat_point"])
+        assert a["feat_px"].tobytes() == b["feat_px"].tobytes()
+        assert int(a["n_matches"]) == int(b["n_matches"]) > 50
+        used_new_kf = used_new_kf or 1 in list(a["overlap_kf"])
+    assert used_new_kf                                                           # the new keyframe took part in the reprojection
+    err = np.array([synth.pose_error(a["T_f_w"], t) for a, t in zip(ra, seq["truth"][6:9])])
+    assert err[:, 0].max() < 3e-3 and err[:, 1].max() < 1e-2

@@ -177,3 +177,30 @@ def run_tracker_chain(seq, track, min_level, stop_when_lost=False):
         winners.append(r["feat_point"][keep])
         feats.append(r["feat_px"].copy())
     return poses, n_matches, winners, feats
+
+
+def map_with_tracked_frame_as_keyframe(seq, mp, r):
+    """sequence_map grown by one keyframe: the tracked frame of result r (hip.Tracker.track layout) becomes keyframe 1
+    (FrameHandlerMono::processFrame :284-330: setKeyframe, point->addFrameRef(feature) for every feature with a point,
+    map_.addKeyframe).  Its features with a point are new observations of those points, pushed to the FRONT of Point::obs_
+    (S/point.cpp:52-55); point numbering and counters as the frame left them."""
+    cam = seq["cam"]
+    n = len(seq["px0"])
+    keep = r["feat_point"] >= 0
+    kp, kpx, kf_, klv = r["feat_point"][keep], r["feat_px"][keep], r["feat_f"][keep], r["feat_level"][keep]
+    obs_kf, obs_px, obs_f, obs_level, off = [], [], [], [], [0]
+    new_obs_of = {int(p): i for i, p in enumerate(kp)}
+    for p in range(n):
+        if p in new_obs_of:
+            i = new_obs_of[p]
+            obs_kf.append(1); obs_px.append(kpx[i]); obs_f.append(kf_[i]); obs_level.append(int(klv[i]))
+        obs_kf.append(0); obs_px.append(seq["px0"][p]); obs_f.append(seq["f0"][p]); obs_level.append(0)
+        off.append(len(obs_kf))
+    key1 = synth.key_points(cam, kpx, np.ones(len(kp), bool))
+    return dict(mp, n_kf=2, kf_slot=np.array([0, 1], np.int32), T_kf_w=np.stack([seq["T0"], r["T_f_w"]]),
+                kf_key_point=np.stack([mp["kf_key_point"][0], np.where(key1 >= 0, kp[np.maximum(key1, 0)], -1)]).astype(np.int32),
+                kf_ftr_offset=np.array([0, n, n + len(kp)], np.int32), kf_ftr_point=np.concatenate([np.arange(n), kp]).astype(np.int32),
+                pt_type=r["type"], pt_n_failed=r["n_failed"], pt_n_succeeded=r["n_succeeded"],
+                pt_obs_offset=np.array(off, np.int32), obs_kf=np.array(obs_kf, np.int32), obs_px=np.array(obs_px), obs_f=np.array(obs_f),
+                obs_level=np.array(obs_level, np.int32), obs_edgelet=np.zeros(len(obs_kf), np.uint8), obs_grad=np.tile([1.0, 0.0], (len(obs_kf), 1)))
+
