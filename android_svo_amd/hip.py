@@ -421,6 +421,15 @@ class Comm:
             ctx.check(ctx.lib.svo_hip_comm_create_shm(ctx.h, name.encode(), rank, world, C.c_size_t(slot_bytes), C.byref(self.h)),
                       "comm_create_shm")
 
+    @classmethod
+    def from_nccl(cls, ctx: Context, nccl_comm: int, rank: int, world: int) -> "Comm":
+        """Adopt an ncclComm_t the application made itself (svo_hip_comm_from_nccl): the library uses it, never destroys it."""
+        self = cls.__new__(cls)
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.svo_hip_comm_from_nccl(ctx.h, C.c_void_p(nccl_comm), rank, world, C.byref(self.h)), "comm_from_nccl")
+        return self
+
     @staticmethod
     def unique_id() -> bytes:
         buf = (C.c_char * 128)()

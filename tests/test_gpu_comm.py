@@ -161,3 +161,55 @@ def test_seed_gather_two_ranks_on_one_gpu(tmp_path):
 
 def test_seed_gather_rccl_one_rank(tmp_path):
     _check_seeds(_run_ranks("seeds", "rccl", 1, tmp_path), 1)
+
+
+def test_adopted_nccl_communicator(tmp_path):
+    """svo_hip_comm_from_nccl: a communicator the application created itself (here: RCCL called directly, one rank) carries the
+    sharded solve -- same bits as the library's own communicator -- and is still alive after svo_hip_comm_destroy."""
+    import ctypes as C
+    rccl = None
+    for name in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    assert rccl is not None, "librccl is part of the image"
+    ctx = hip.Context(0)
+    uid = (C.c_char * 128)()
+    assert rccl.ncclGetUniqueId(uid) == 0
+
+    class NcclId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    nid = NcclId()
+    C.memmove(C.byref(nid), uid, 128)
+    comm_ptr = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm_ptr), 1, nid, 0) == 0
+    fps = [synth.make_frame_pair(seed=900 + i, n_features=n) for i, n in enumerate((700, 1500))]
+    cam = fps[0].cam
+    ref = hip.Pyramid(ctx, cam.width, cam.height, 5, 2); cur = hip.Pyramid(ctx, cam.width, cam.height, 5, 2)
+    sia = hip.SparseImgAlign(ctx, 2, 1500)
+    sia.set_frames(ref, cur)
+    for s, fp in enumerate(fps):
+        ref.upload(s, fp.ref_pyr); cur.upload(s, fp.cur_pyr); sia.upload_pair(s, fp)
+    prm = sia.params(max_level=4, min_level=0, n_iter=6, eps=1e-6, early_stop=False)
+    adopted = hip.Comm.from_nccl(ctx, comm_ptr.value, 0, 1)
+    hip.sia_run_sharded(sia, adopted, 2, prm)
+    Ta = np.array([list(x.T_cur_w) for x in sia.download_all(2)])
+    adopted.destroy()
+    own = hip.Comm(ctx, 0, 1, kind="rccl", unique_id=hip.Comm.unique_id())
+    hip.sia_run_sharded(sia, own, 2, prm)
+    To = np.array([list(x.T_cur_w) for x in sia.download_all(2)])
+    own.destroy()
+    np.testing.assert_array_equal(Ta, To)
+    for s, fp in enumerate(fps):
+        o = orc.sparse_img_align(fp, n_iter=6, early_stop=False)
+        rot, trans = synth.pose_error(Ta[s], np.array(o.T_cur_w))
+        assert rot < 1e-9 and trans < 1e-9
+    # the adopted communicator is the application's: still usable, and the application's to destroy
+    cnt = C.c_int(0)
+    assert rccl.ncclCommCount(comm_ptr, C.byref(cnt)) == 0 and cnt.value == 1
+    assert rccl.ncclCommDestroy(comm_ptr) == 0
+    ctx.close()
+
