@@ -429,3 +429,36 @@ def test_last_frame_becomes_a_keyframe(ctx):
     assert used_new_kf                                                           # the new keyframe took part in the reprojection
     err = np.array([synth.pose_error(a["T_f_w"], t) for a, t in zip(ra, seq["truth"][6:9])])
     assert err[:, 0].max() < 3e-3 and err[:, 1].max() < 1e-2
+
+
+@pytest.mark.parametrize("seed", list(range(60, 72)))
+def test_reprojection_stage_random_maps(ctx, seed):
+    """A dozen random maps (number of keyframes, points, candidates, cell size, keyframe spacing, share of edgelets, maxFts cap
+    all drawn from the seed) through the tracker's reprojection stage against the oracle's Reprojector::reprojectMap: every
+    integer equal, pixels and gradients bitwise, key points after the frame by the reference's rule."""
+    rng = np.random.default_rng(seed)
+    kw = dict(seed=seed, n_kf=int(rng.integers(3, 16)), n_points=int(rng.integers(150, 2500)), n_candidates=int(rng.integers(0, 250)),
+              cell_size=int(rng.choice([8, 12, 20, 25, 30, 40])), edgelet_frac=float(rng.choice([0.0, 0.04, 0.3])),
+              kf_step=float(rng.choice([0.05, 0.16, 0.4])))
+    max_fts = int(rng.choice([25, 120, 1200]))
+    cs = synth.make_map_case(**kw)
+    key = _key_points_of(cs)
+    ro = orc.reproject_map(cs, key, max_fts=max_fts)
+    trk = _tracker_for(ctx, cs, key, max_fts=max_fts, quality_min_fts=10, max_frame_features=2816)
+    trk.set_last_frame(cs["T_cur_w"], np.zeros((0, 2)), np.zeros((0, 3)), np.zeros(0, np.int32), img=cs["cur_pyr"][0])
+    r = trk.track(cs["cur_pyr"][0])
+    assert r["result"].items_overflow == 0
+    assert [int(r["n_matches"]), int(r["n_trials"])] == [int(ro["n_matches"]), int(ro["n_trials"])], kw
+    np.testing.assert_array_equal(r["overlap_kf"], ro["overlap_kf"])
+    np.testing.assert_array_equal(r["overlap_count"], ro["overlap_count"])
+    dropped = r["feat_point"] < 0
+    np.testing.assert_array_equal(np.where(dropped, ro["feat_point"], r["feat_point"]), ro["feat_point"])
+    np.testing.assert_array_equal(r["feat_level"], ro["feat_level"])
+    np.testing.assert_array_equal(r["feat_type"], ro["feat_type"])
+    assert np.asarray(r["feat_px"], dtype=np.float64).tobytes() == np.asarray(ro["feat_px"], dtype=np.float64).tobytes()
+    assert np.asarray(r["feat_grad"], dtype=np.float64).tobytes() == np.asarray(ro["feat_grad"], dtype=np.float64).tobytes()
+    for k in ("type", "n_failed", "n_succeeded"):
+        np.testing.assert_array_equal(r[k], ro[k], err_msg=k)
+    deleted = (r["type"] == synth.TYPE_DELETED) & (cs["pt_type"] != synth.TYPE_DELETED)
+    np.testing.assert_array_equal(trk.download_key_points(cs["n_kf"]), rekey_expected(cs, key, deleted))
+    trk.destroy()
