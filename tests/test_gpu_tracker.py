@@ -462,3 +462,53 @@ def test_reprojection_stage_random_maps(ctx, seed):
     deleted = (r["type"] == synth.TYPE_DELETED) & (cs["pt_type"] != synth.TYPE_DELETED)
     np.testing.assert_array_equal(trk.download_key_points(cs["n_kf"]), rekey_expected(cs, key, deleted))
     trk.destroy()
+
+
+def test_tracker_edge_cases(ctx):
+    """What a tracked frame does at the edges: a map without keyframes, too few matches for the pose refinement
+    (frame_handler_mono.cpp:208-215: the new frame gets the last frame's pose, tracking goes on from it), and more candidates
+    than max_items (reported, nothing written out of bounds)."""
+    seq = tc.make_sequence(n_frames=4)
+    mp = tc.sequence_map(seq)
+    cam = seq["cam"]
+    n = len(seq["px0"])
+    # ---- an empty map: nothing to reproject, the pose stays the last frame's
+    trk = hip.Tracker(ctx, cam, max_keyframes=2, grid_size=tc.CELL, max_fts=tc.MAX_FTS, max_frame_features=1024)
+    empty = dict(mp, n_kf=0, n_points=0, kf_slot=np.zeros(0, np.int32), T_kf_w=np.zeros((0, 7)), kf_key_point=np.zeros((0, 5), np.int32),
+                 kf_ftr_offset=np.zeros(1, np.int32), kf_ftr_point=np.zeros(0, np.int32), pt_pos=np.zeros((0, 3)), pt_type=np.zeros(0, np.int32),
+                 pt_n_failed=np.zeros(0, np.int32), pt_n_succeeded=np.zeros(0, np.int32), pt_obs_offset=np.zeros(1, np.int32),
+                 obs_kf=np.zeros(0, np.int32), obs_px=np.zeros((0, 2)), obs_f=np.zeros((0, 3)), obs_level=np.zeros(0, np.int32),
+                 obs_edgelet=np.zeros(0, np.uint8), obs_grad=np.zeros((0, 2)), cand_point=np.zeros(0, np.int32))
+    trk.set_map(empty)
+    trk.set_last_frame(seq["T0"], np.zeros((0, 2)), np.zeros((0, 3)), np.zeros(0, np.int32), img=seq["pyrs"][0][0])
+    r = trk.track(seq["pyrs"][1][0])
+    assert int(r["n_matches"]) == 0 and len(r["feat_px"]) == 0 and r["result"].pose.ran == 0 and r["map_changed"] == 0
+    np.testing.assert_array_equal(r["T_f_w"], seq["T0"])
+    trk.destroy()
+    # ---- too few matches: the reference's failure branch, frame by frame equal to the oracle composition
+    trk = hip.Tracker(ctx, cam, max_keyframes=2, grid_size=tc.CELL, max_fts=tc.MAX_FTS, max_frame_features=1024, quality_min_fts=100000, klt_min_level=2)
+    trk.upload_keyframe(0, seq["pyrs"][0][0])
+    trk.set_map(mp)
+    trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)
+    state = {"pt_type": mp["pt_type"].copy(), "pt_n_failed": mp["pt_n_failed"].copy(), "pt_n_succeeded": mp["pt_n_succeeded"].copy(),
+             "unlinked": np.zeros(n, np.uint8)}
+    last = dict(T=seq["T0"].copy(), px=seq["px0"].copy(), f=seq["f0"].copy(), point=np.arange(n, dtype=np.int32))
+    for k in (1, 2, 3):
+        r = trk.track(seq["pyrs"][k][0])
+        ro = tc.oracle_track_frame(orc, mp, state, last, seq["pyrs"][k - 1], seq["pyrs"][k], 2, quality_min_fts=100000)
+        assert r["result"].pose.ran == 0 and int(r["n_matches"]) == int(ro["n_matches"]) > 50
+        np.testing.assert_array_equal(r["T_f_w"], last["T"])                      # new_frame_->T_f_w_ = last_frame_->T_f_w_ (:211)
+        np.testing.assert_array_equal(r["feat_point"], ro["feat_point"])          # the reprojector's features stay on the frame
+        rot, trans = synth.pose_error(r["T_f_w_sia"], ro["T_f_w_sia"])
+        assert rot < 1e-9 and trans < 1e-9
+        last = dict(T=ro["T_f_w"].copy(), px=ro["feat_px"], f=ro["feat_f"], point=ro["feat_point"])
+    trk.destroy()
+    # ---- more candidates than max_items: flagged; what is returned is still a consistent frame
+    trk = hip.Tracker(ctx, cam, max_keyframes=2, grid_size=tc.CELL, max_fts=tc.MAX_FTS, max_frame_features=1024, max_items=64)
+    trk.upload_keyframe(0, seq["pyrs"][0][0])
+    trk.set_map(mp)
+    trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)
+    r = trk.track(seq["pyrs"][1][0])
+    assert r["result"].items_overflow == 1 and int(r["result"].n_candidates) == 64
+    assert 0 < int(r["n_matches"]) <= 64 and (r["feat_point"][r["feat_point"] >= 0] < n).all()
+    trk.destroy()
