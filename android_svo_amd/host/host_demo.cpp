@@ -135,7 +135,7 @@ static int track_demo(const std::string& dir, const std::string& out) {
     last = std::make_shared<Frame>(&cam, std::move(pyr));
     last->T_f_w_ = SE3(read_bin<double>(dir + "/last_pose.bin").data());
   }
-  std::vector<double> poses, stats, overlap;
+  std::vector<double> poses, stats, overlap, uploads;
   for (int k = 0; k < n_frames; ++k) {
     std::vector<std::vector<uint8_t>> pyr;
     pyr.push_back(read_bin<uint8_t>(dir + "/trk_frame_" + std::to_string(k) + ".bin"));
@@ -189,6 +189,21 @@ static int track_demo(const std::string& dir, const std::string& out) {
       }
       write_bin(out + "/track_obs_linked_after_first.bin", linked);
     }
+    uploads.push_back((double)tracker.mapUploads());
+    if (m.size() > 20 && (int)m[20] == k && !map.point_candidates_.candidates_.empty()) {
+      // what the depth filter's thread does when a seed converges (MapPointCandidates::newCandidatePoint): a new candidate
+      // appears in the list behind the tracker's back -- here a twin of the list's first one
+      const MapPointCandidates::PointCandidate& c0 = map.point_candidates_.candidates_.front();
+      points.emplace_back(new Point(c0.first->pos_));
+      Point* np_ = points.back().get();
+      np_->type_ = Point::TYPE_CANDIDATE;
+      Feature* nf = new Feature(c0.second->frame, c0.second->px, c0.second->f, c0.second->level);
+      nf->point = np_;
+      np_->obs_.push_front(nf);
+      index_of_point[np_] = (int)points.size() - 1;
+      std::unique_lock<std::mutex> lock(map.point_candidates_.mut_);
+      map.point_candidates_.candidates_.push_back(MapPointCandidates::PointCandidate(np_, nf));
+    }
     if (m.size() > 19 && (int)m[19] == k) {
       // FrameHandlerMono::processFrame :284-330: the tracked frame becomes a keyframe -- setKeyframe (key points), every feature
       // with a point becomes an observation of it (Point::addFrameRef: front of obs_), the map takes the frame, the device
@@ -203,6 +218,7 @@ static int track_demo(const std::string& dir, const std::string& out) {
   }
   write_bin(out + "/track_poses.bin", poses);
   write_bin(out + "/track_stats.bin", stats);
+  write_bin(out + "/track_uploads.bin", uploads);
   write_bin(out + "/track_overlap_first.bin", overlap);
   std::printf("svo_host_demo track OK\n");
   return 0;

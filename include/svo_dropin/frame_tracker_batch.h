@@ -74,6 +74,8 @@ class FrameTrackerT {
   }
   ~FrameTrackerT() { if (trk_) svo_hip_tracker_destroy(trk_); }
   bool ok() const { return trk_ != NULL; }
+  /// how often the map has been flattened and uploaded (diagnostic)
+  size_t mapUploads() const { return n_uploads_; }
 
   /// the map changed behind the tracker's back (keyframe added / removed, points optimised or deleted, candidates added):
   /// flatten it again before the next frame.  processFrame calls this after map_.addKeyframe, optimizeStructure etc.
@@ -101,6 +103,12 @@ class FrameTrackerT {
   bool track(const FramePtr& last_frame, const FramePtr& new_frame, Map& map,
              std::vector<std::pair<FramePtr, size_t> >& overlap_kfs, Outcome& out) {
     if (!trk_) return false;
+    if (!map_dirty_) {
+      // the depth filter's thread adds candidates behind the tracker's back (its convergence callback is
+      // MapPointCandidates::newCandidatePoint, frame_handler_mono.cpp:46-48): a list that has grown is flattened again
+      std::unique_lock<std::mutex> lock(map.point_candidates_.mut_);
+      if (map.point_candidates_.candidates_.size() != n_candidates_) map_dirty_ = true;
+    }
     if (map_dirty_ && !uploadMap(map)) return false;
     if (!have_last_ && !uploadLastFrame(*last_frame)) return false;
     int stride = 0, cols = 0, rows = 0;
@@ -136,7 +144,7 @@ class FrameTrackerT {
       pt->n_failed_reproj_ = p_failed_[p];
       pt->n_succeeded_reproj_ = p_succ_[p];
       if (!deleted_now) { pt->type_ = (typename Point::PointType)p_type_[p]; continue; }
-      if (pt->type_ == Point::TYPE_CANDIDATE) map.point_candidates_.deleteCandidatePoint(pt);
+      if (pt->type_ == Point::TYPE_CANDIDATE) { if (map.point_candidates_.deleteCandidatePoint(pt) && n_candidates_ > 0) --n_candidates_; }
       else map.safeDeletePoint(pt);
       // the point now belongs to the map's trash (freed by Map::emptyTrash): this table forgets the object, the index stays
       // taken (the device tables keep the dead entry until the map is flattened again)
@@ -300,6 +308,8 @@ class FrameTrackerT {
     m.obs_edgelet = obs_edge.data(); m.obs_grad = obs_grad.data();
     m.n_candidates = (int)cand.size(); m.cand_point = cand.data();
     if (svo_hip_tracker_set_map(trk_, &m) != SVO_HIP_OK) return false;
+    n_candidates_ = cand.size();
+    ++n_uploads_;
     map_dirty_ = false;
     have_last_ = false;                                      // point indices changed: the last frame's features refer to them
     return true;
@@ -309,6 +319,8 @@ class FrameTrackerT {
   svo_hip_tracker* trk_;
   svo_hip_tracker_config cfg_;
   bool map_dirty_, have_last_;
+  size_t n_uploads_ = 0;
+  size_t n_candidates_ = 0;                                  // MapPointCandidates::candidates_.size() as uploaded, minus our own deletions
   int next_slot_;
   std::vector<FramePtr> keyframes_;
   std::vector<Point*> points_;

@@ -156,7 +156,7 @@ def _write_track_case(case, cs, frames, cfg, last_kf=-1, last_img=None, last_pos
     _write(case / "track_manifest.bin",
            [cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, n_kf, n_points, len(cs["obs_point"]), len(cs["kf_ftr_obs"]), len(cs["cand_obs"]),
             len(frames), cfg["grid_size"], cfg["max_fts"], cfg["quality_min_fts"], cfg["klt_min_level"], cfg["max_frame_features"], last_kf,
-            cfg.get("structure_optim_max_pts", 0), cfg.get("keyframe_at", -1)], np.float64)
+            cfg.get("structure_optim_max_pts", 0), cfg.get("keyframe_at", -1), cfg.get("new_candidate_at", -1)], np.float64)
     for k in range(n_kf):
         _write(case / ("kf_%d_img.bin" % k), cs["kf_pyr"][k][0], np.uint8)
     _write(case / "kf_pose.bin", cs["T_kf_w"], np.float64)
@@ -231,13 +231,15 @@ def test_cpp_frame_tracker_on_a_map_with_deletions(tmp_path):
     tag, kw, max_fts = [c for c in CASES if c[0] == "wide"][0]      # (a keyframe loses a key feature to a deleted point in this case)
     g = np.load(GOLD)
     cs = synth.make_map_case(**kw)
-    cfg = dict(grid_size=cs["cell_size"], max_fts=max_fts, quality_min_fts=20, klt_min_level=2, max_frame_features=2048, structure_optim_max_pts=20)
+    cfg = dict(grid_size=cs["cell_size"], max_fts=max_fts, quality_min_fts=20, klt_min_level=2, max_frame_features=2048, structure_optim_max_pts=20,
+               new_candidate_at=1)
     # the second frame: the same scene a small step further (make_map_case's own scene; the same image twice would make the
     # alignment's update exactly zero, for which SE3::exp returns a NaN translation -- in the reference too)
     scene = synth.PlaneScene(seed=kw.get("seed", 31), depth=2.0, tilt=(0.08, -0.05))
     T2 = synth.se3_mul(synth.se3_from_twist([0.012, -0.006, 0.004], [0.002, -0.003, 0.001]), cs["T_cur_w"])
     img2 = scene.render(cs["cam"], T2)
-    _write_track_case(case, cs, [cs["cur_pyr"][0], img2], cfg, last_kf=-1, last_img=cs["cur_pyr"][0], last_pose=cs["T_cur_w"])
+    img3 = scene.render(cs["cam"], synth.se3_mul(synth.se3_from_twist([0.012, -0.006, 0.004], [0.002, -0.003, 0.001]), T2))
+    _write_track_case(case, cs, [cs["cur_pyr"][0], img2, img3], cfg, last_kf=-1, last_img=cs["cur_pyr"][0], last_pose=cs["T_cur_w"])
     rd = _run_track_demo(case, out)
     n_kf, n_points = cs["n_kf"], cs["n_points"]
     # Frame::setKeyPoints of the twin == the reference's (the fixture's key points)
@@ -295,6 +297,10 @@ def test_cpp_frame_tracker_on_a_map_with_deletions(tmp_path):
     assert np.ascontiguousarray(so[:, 1:]).tobytes() == pos_ref.tobytes()
     # the second frame: tracked straight on (the device tables followed the deletions and the new positions)
     assert stats[1, 4] == 1 and stats[1, 1] >= 0.8 * stats[0, 1] and stats[1, 3] > 0.5 * stats[0, 0], stats
+    # map uploads: one before the first frame; none for the second (the deletions of the first are followed on the device); one
+    # for the third (a candidate was added to the list after the second frame, as the depth filter's thread does)
+    np.testing.assert_array_equal(rd("track_uploads.bin", np.float64), [1, 1, 2])
+    assert stats[2, 4] == 1 and stats[2, 1] >= 0.8 * stats[0, 1]
     poses = rd("track_poses.bin", np.float64).reshape(-1, 7)
     rot, trans = synth.pose_error(poses[1], T2)
     assert rot < 3e-3 and trans < 1e-2, (rot, trans)                            # the second frame's true pose
