@@ -69,7 +69,7 @@ class FrameTrackerT {
 
   /// cfg: svo_hip_tracker_default_config with the caller's Config values filled in (the bindings do that)
   FrameTrackerT(const svo_hip_camera& cam, const svo_hip_tracker_config& cfg)
-      : ctx_(0), trk_(NULL), cfg_(cfg), map_dirty_(true), have_last_(false), next_slot_(0) {
+      : ctx_(0), trk_(NULL), cfg_(cfg), map_dirty_(true), have_last_(false) {
     if (ctx_.ok() && svo_hip_tracker_create(ctx_.get(), &cam, &cfg, &trk_) != SVO_HIP_OK) trk_ = NULL;
   }
   ~FrameTrackerT() { if (trk_) svo_hip_tracker_destroy(trk_); }
@@ -203,13 +203,21 @@ class FrameTrackerT {
 
   /// new_frame_->setKeyframe(); map_.addKeyframe(new_frame_) (:284-330): keep the frame's pyramid on the device as a keyframe
   bool lastFrameBecameKeyframe(const Frame& frame) {
-    const int slot = next_slot_++ % cfg_.max_keyframes;
+    const int slot = freeSlot();
+    if (slot < 0) return false;                               // max_keyframes pyramids are all in use: raise the capacity
     slot_of_frame_[frame.id_] = slot;
     map_dirty_ = true;
     return svo_hip_tracker_keyframe_from_last_frame(trk_, slot) == SVO_HIP_OK;
   }
 
  private:
+  /// lowest keyframe pyramid slot no known keyframe occupies, or -1
+  int freeSlot() const {
+    std::vector<char> used((size_t)cfg_.max_keyframes, 0);
+    for (std::map<int, int>::const_iterator it = slot_of_frame_.begin(); it != slot_of_frame_.end(); ++it) used[(size_t)it->second] = 1;
+    for (int s_ = 0; s_ < cfg_.max_keyframes; ++s_) if (!used[(size_t)s_]) return s_;
+    return -1;
+  }
   struct LastOptimLess {                                   // ptLastOptimComparator (frame_handler_base.cpp:181-184)
     bool operator()(const Point* a, const Point* b) const { return a->last_structure_optim_ < b->last_structure_optim_; }
   };
@@ -239,6 +247,15 @@ class FrameTrackerT {
   /// svo::Map -> index tables (Map::keyframes_ order, fts_ order, Point::obs_ order, candidates_ order)
   bool uploadMap(Map& map) {
     keyframes_.assign(map.keyframes_.begin(), map.keyframes_.end());
+    {
+      // pyramid slots of keyframes the map no longer holds (Map::safeDeleteFrame) are free again
+      std::map<int, int> live;
+      for (size_t k = 0; k < keyframes_.size(); ++k) {
+        std::map<int, int>::const_iterator si = slot_of_frame_.find(keyframes_[k]->id_);
+        if (si != slot_of_frame_.end()) live[si->first] = si->second;
+      }
+      slot_of_frame_.swap(live);
+    }
     points_.clear(); index_of_point_.clear();
     std::map<int, int> index_of_frame;
     std::vector<int32_t> kf_slot, key, ftr_off(1, 0), ftr_pt, ty, nf, ns, obs_off(1, 0), obs_kf, obs_level, cand;
@@ -261,8 +278,8 @@ class FrameTrackerT {
         int stride = 0, cols = 0, rows = 0;
         const uint8_t* img = Host::level0(kf, &stride, &cols, &rows);
         if (stride != cols) return false;
-        const int slot = next_slot_++ % cfg_.max_keyframes;
-        if (svo_hip_tracker_upload_keyframe(trk_, slot, img) != SVO_HIP_OK) return false;
+        const int slot = freeSlot();
+        if (slot < 0 || svo_hip_tracker_upload_keyframe(trk_, slot, img) != SVO_HIP_OK) return false;
         slot_of_frame_[kf.id_] = slot;
         si = slot_of_frame_.find(kf.id_);
       }
@@ -321,7 +338,6 @@ class FrameTrackerT {
   bool map_dirty_, have_last_;
   size_t n_uploads_ = 0;
   size_t n_candidates_ = 0;                                  // MapPointCandidates::candidates_.size() as uploaded, minus our own deletions
-  int next_slot_;
   std::vector<FramePtr> keyframes_;
   std::vector<Point*> points_;
   std::map<const Point*, int> index_of_point_;
