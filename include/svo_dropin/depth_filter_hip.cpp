@@ -49,7 +49,8 @@ DepthFilterHip::~DepthFilterHip() { stopThread(); }
 
 void DepthFilterHip::updateSeeds(FramePtr frame) {
   lock_t lock(seeds_mut_);
-  if (!ctx_.ok() || seeds_.empty()) return;
+  if (seeds_.empty()) return;
+  if (!ctx_.ok()) { hip_bridge::reportDeviceFailure(NULL, "DepthFilterHip::updateSeeds"); return; }
   svo_hip_df_params prm;
   prm.n_pyr_levels = (int)Config::nPyrLevels();
   prm.align_max_iter = 10;             // Matcher::Options defaults (I/matcher.h:83-91)

@@ -21,7 +21,8 @@ inline std::vector<bool> align2D_batch(hip_bridge::Context& ctx, hip_bridge::Pyr
                                        std::vector<Vector2d>& cur_px_estimate) {
   const int n = (int)cur_px_estimate.size();
   std::vector<bool> out((size_t)n, false);
-  if (n == 0 || !ctx.ok()) return out;
+  if (n == 0) return out;
+  if (!ctx.ok()) { hip_bridge::reportDeviceFailure(NULL, "feature_alignment::align2D_batch"); return out; }
   const int slot = pyr.slotOf(cur_frame);
   if (slot < 0) return out;
   std::vector<double> px(2 * (size_t)n);

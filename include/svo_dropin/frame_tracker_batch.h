@@ -25,6 +25,7 @@
 #define SVO_FRAME_TRACKER_BATCH_H_
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <list>
@@ -124,8 +125,10 @@ class FrameTrackerT {
     p_type_.resize(np + 1); p_failed_.resize(np + 1); p_succ_.resize(np + 1);
     svo_hip_track_result r;
     if (svo_hip_tracker_track(trk_, level0, &r, f_px_.data(), f_f_.data(), f_level_.data(), f_point_.data(), f_edge_.data(), f_grad_.data(),
-                              p_type_.data(), p_failed_.data(), p_succ_.data()) != SVO_HIP_OK)
+                              p_type_.data(), p_failed_.data(), p_succ_.data()) != SVO_HIP_OK) {
+      fprintf(stderr, "[svo_hip] FrameTracker::track FAILED: %s\n", svo_hip_last_error(ctx_.get()));
       return false;
+    }
     // ---- what processFrame would have found on its objects after the three stages
     Host::setPose(*new_frame, r.T_f_w);
     for (int i = 0; i < r.n_features; ++i) {                 // Reprojector::reprojectCell :217-231

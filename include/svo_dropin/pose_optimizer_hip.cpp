@@ -36,7 +36,7 @@ namespace pose_optimizer {
 void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const bool verbose, FramePtr& frame,
                          double& estimated_scale, double& error_init, double& error_final, size_t& num_obs) {
   hip_bridge::Context& ctx = refineContext();
-  if (!ctx.ok()) return;                                   // as if no observation had a point: nothing is touched
+  if (!ctx.ok()) { hip_bridge::reportDeviceFailure(NULL, "pose_optimizer::optimizeGaussNewton"); return; }   // nothing is touched
   const int n = (int)frame->fts_.size();
   std::vector<double> f(3 * (size_t)n), pos(3 * (size_t)n, 0.0);
   std::vector<int32_t> level((size_t)n, 0);
@@ -56,7 +56,8 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
   svo_hip_pose_opt_result res;
   const int rc = svo_hip_pose_optimize(ctx.get(), n, T, f.data(), pos.data(), level.data(), has_point.data(),
                                        frame->cam_->errorMultiplier2(), reproj_thresh, (int)n_iter, &res);
-  if (rc != SVO_HIP_OK || !res.ran) return;                // pose_optimizer.cpp:61-62: returns before touching anything
+  if (rc != SVO_HIP_OK) { hip_bridge::reportDeviceFailure(ctx.get(), "pose_optimizer::optimizeGaussNewton"); return; }
+  if (!res.ran) return;                                    // pose_optimizer.cpp:61-62: returns before touching anything
   frame->T_f_w_ = hip_bridge::fromPose7(res.T_f_w);
   for (int r = 0; r < 6; ++r)
     for (int c = 0; c < 6; ++c) frame->Cov_(r, c) = res.Cov[6 * r + c];
@@ -110,10 +111,13 @@ void optimizeStructureHip(FramePtr frame, size_t max_n_pts, int max_iter) {
                     svo_hip_point_optimize_batch(ctx.get(), (int)max_n_pts, max_iter, pos.data(), offset.data(),
                                                  obs_T.empty() ? NULL : obs_T.data(), obs_f.empty() ? NULL : obs_f.data(),
                                                  NULL) == SVO_HIP_OK;
+  if (!done) {                                              // no CPU stand-in: the points stay as they are, and the log says why
+    hip_bridge::reportDeviceFailure(ctx.ok() ? ctx.get() : NULL, "optimizeStructureHip");
+    return;
+  }
   for (size_t k = 0; k < max_n_pts; ++k) {
     Point* pt = pts[k];
-    if (done) pt->pos_ = Vector3d(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2]);
-    else pt->optimize(max_iter);                            // device unavailable: the reference's own member
+    pt->pos_ = Vector3d(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2]);
     pt->last_structure_optim_ = frame->id_;
   }
 }

@@ -62,7 +62,7 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   cur_frame_ = cur_frame;
 
   AlignDevice& dev = device();
-  if (!dev.ctx.ok()) { stop_ = true; return 0; }
+  if (!dev.ctx.ok()) { hip_bridge::reportDeviceFailure(NULL, "SparseImgAlign::run"); stop_ = true; return 0; }
   const int n = (int)ref_frame->fts_.size();
   std::vector<double> px(2 * (size_t)n), f(3 * (size_t)n), pos(3 * (size_t)n, 0.0);
   std::vector<uint8_t> has_point((size_t)n, 0);
@@ -101,6 +101,7 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   if (rc == SVO_HIP_OK) rc = svo_hip_sia_download(dev.sia, 0, &res);
   if (rc != SVO_HIP_OK) {
     // device errors degrade to "not converged": pose untouched, 0 tracked (SURVEY 8b "Error conventions")
+    hip_bridge::reportDeviceFailure(dev.ctx.get(), "SparseImgAlign::run");
     SVO_WARN_STREAM("SparseImgAlign: device path failed, pose left unchanged");
     stop_ = true;
     return 0;

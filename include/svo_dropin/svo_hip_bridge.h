@@ -10,6 +10,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <cstdio>
 #include <vector>
 
 #include <svo/abstract_camera.h>
@@ -49,6 +50,14 @@ inline svo_hip_camera toCamera(const vk::AbstractCamera* cam) {
     c.cx = cam->width() / 2.0; c.cy = cam->height() / 2.0;
   }
   return c;
+}
+
+/// A device-side failure is never papered over with the CPU path: it is reported on stderr, loudly, and the caller degrades
+/// to the reference's own "nothing found" outcome (tracking failure, no seed update) -- visible in the log and in the
+/// tracking quality, never silent and never a different arithmetic.
+inline void reportDeviceFailure(svo_hip_ctx* ctx, const char* where) {
+  fprintf(stderr, "[svo_hip] %s FAILED: %s\n", where, ctx ? svo_hip_last_error(ctx) : "no device context (libsvo_hip.so / GPU unavailable)");
+  fflush(stderr);
 }
 
 /// One context (stream) per host thread that enters the library (tracking thread,
