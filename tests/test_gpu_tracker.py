@@ -512,3 +512,43 @@ def test_tracker_edge_cases(ctx):
     assert r["result"].items_overflow == 1 and int(r["result"].n_candidates) == 64
     assert 0 < int(r["n_matches"]) <= 64 and (r["feat_point"][r["feat_point"] >= 0] < n).all()
     trk.destroy()
+
+
+def test_tracker_refuses_bad_arguments(ctx):
+    """Every index the kernels follow is checked on the host: bad arguments come back as errors, nothing is launched."""
+    seq = tc.make_sequence(n_frames=2)
+    mp = tc.sequence_map(seq)
+    cam = seq["cam"]
+    n = len(seq["px0"])
+    for bad in (dict(max_keyframes=0), dict(max_keyframes=257), dict(max_frame_features=5000), dict(reproj_max_n_kfs=17), dict(klt_max_level=7)):
+        with pytest.raises(hip.SvoHipError):
+            hip.Tracker(ctx, cam, **bad)
+    trk = hip.Tracker(ctx, cam, max_keyframes=2, max_points=n, grid_size=tc.CELL, max_fts=tc.MAX_FTS, max_frame_features=256)
+    with pytest.raises(hip.SvoHipError):
+        trk.track(seq["pyrs"][1][0])                                              # no map, no last frame
+    with pytest.raises(hip.SvoHipError):
+        trk.optimize_structure([0])                                               # no map
+    for key, val in (("kf_ftr_point", np.full(n, n, np.int32)), ("kf_key_point", np.full((1, 5), n, np.int32)), ("obs_kf", np.ones(n, np.int32)),
+                     ("obs_level", np.full(n, 9, np.int32)), ("pt_type", np.full(n, 4, np.int32)), ("kf_slot", np.array([2], np.int32))):
+        with pytest.raises(hip.SvoHipError):
+            trk.set_map(dict(mp, **{key: val}))
+    with pytest.raises(hip.SvoHipError):                                          # more points than the tracker was created for
+        trk.set_map(dict(mp, n_points=n + 1, pt_pos=np.zeros((n + 1, 3)), pt_type=np.full(n + 1, 2, np.int32), pt_n_failed=np.zeros(n + 1, np.int32),
+                         pt_n_succeeded=np.zeros(n + 1, np.int32), pt_obs_offset=np.concatenate([mp["pt_obs_offset"], [n]]).astype(np.int32)))
+    trk.upload_keyframe(0, seq["pyrs"][0][0])
+    trk.set_map(mp)
+    with pytest.raises(hip.SvoHipError):
+        trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)      # 600 features > max_frame_features = 256
+    with pytest.raises(hip.SvoHipError):
+        trk.set_last_frame(seq["T0"], seq["px0"][:10], seq["f0"][:10], np.arange(10, dtype=np.int32), kf_slot=5)
+    with pytest.raises(hip.SvoHipError):
+        trk.optimize_structure(list(range(65)))
+    with pytest.raises(hip.SvoHipError):
+        trk.optimize_structure([n])
+    with pytest.raises(hip.SvoHipError):
+        trk.update_point_positions([n], np.zeros((1, 3)))
+    # ... and the object still works
+    trk.set_last_frame(seq["T0"], seq["px0"][:200], seq["f0"][:200], np.arange(200, dtype=np.int32), kf_slot=0)
+    r = trk.track(seq["pyrs"][1][0])
+    assert int(r["n_matches"]) > 50
+    trk.destroy()
