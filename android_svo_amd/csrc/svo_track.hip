@@ -864,17 +864,6 @@ int svo_hip_tracker_set_map(svo_hip_tracker* t, const svo_hip_tracker_map* mp) {
   SVO_REQUIRE(ctx, n_ftr >= 0 && n_ftr <= c.max_kf_features && n_obs >= 0 && n_obs <= c.max_obs);
   SVO_REQUIRE(ctx, n_ftr == 0 || mp->kf_ftr_point);
   SVO_REQUIRE(ctx, n_obs == 0 || (mp->obs_kf && mp->obs_px && mp->obs_f && mp->obs_level));
-  if (t->have_last) {
-    // the last frame's features keep referring to map points by index: a map with fewer points than the largest of them
-    // needs svo_hip_tracker_set_last_frame again (the result block still holds the features of a tracked frame)
-    int max_point = t->last_max_point;
-    if (t->last_from_track) {
-      const int32_t* fp = reinterpret_cast<const int32_t*>(t->res_host + t->o_point);
-      max_point = -1;
-      for (int i = 0; i < t->last_n_host; ++i) if (fp[i] > max_point) max_point = fp[i];
-    }
-    if (max_point >= mp->n_points) t->have_last = false;     // svo_hip_tracker_track will ask for svo_hip_tracker_set_last_frame
-  }
   // every index the kernels follow is checked here, once, on the host
   for (int k = 0; k < mp->n_kf; ++k) {
     SVO_REQUIRE(ctx, mp->kf_slot[k] >= 0 && mp->kf_slot[k] < c.max_keyframes && mp->kf_ftr_offset[k] <= mp->kf_ftr_offset[k + 1] && mp->kf_ftr_offset[k] >= 0);
@@ -890,6 +879,17 @@ int svo_hip_tracker_set_map(svo_hip_tracker* t, const svo_hip_tracker_map* mp) {
     const size_t need = K_ * (56 + 4 + 20) + (K_ + 1) * 4 + (size_t)n_ftr * 4 + P_ * (24 + 12) + (P_ + 1) * 4 + O_ * (4 + 16 + 24 + 4 + 1 + 16) +
                         (size_t)mp->n_candidates * 4 + (size_t)c.max_keyframes * 56 + 32 * 16;
     if (need > t->map_host_bytes) return svo_fail(ctx, SVO_HIP_ERR_NOMEM, "svo_hip_tracker_set_map", "staging area too small");
+  }
+  if (t->have_last) {                       // (after the checks: a refused map changes nothing)
+    // the last frame's features keep referring to map points by index: a map with fewer points than the largest of them
+    // needs svo_hip_tracker_set_last_frame again (the result block still holds the features of a tracked frame)
+    int max_point = t->last_max_point;
+    if (t->last_from_track) {
+      const int32_t* fp = reinterpret_cast<const int32_t*>(t->res_host + t->o_point);
+      max_point = -1;
+      for (int i = 0; i < t->last_n_host; ++i) if (fp[i] > max_point) max_point = fp[i];
+    }
+    if (max_point >= mp->n_points) t->have_last = false;     // svo_hip_tracker_track will ask for svo_hip_tracker_set_last_frame
   }
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   // the staging area may still feed the copies of the previous upload

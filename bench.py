@@ -45,6 +45,10 @@ from android_svo_amd import hip, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PRECOMPUTE = 945           # per patch per level
 BYTES_RESIDUAL = 881             # per patch per Gauss-Newton evaluation
+# frame pairs per GPU per launch.  One 8-wave workgroup solves one pair and fills one CU: with 256 pairs every CU runs
+# exactly one workgroup and the launch lasts as long as its slowest scene; four workgroups per CU balance that
+# (tools/batch_sweep.sh, same box: 256 / 512 / 1024 / 2048 pairs -> 203.1 / 207.9 / 210.7 / 213.3 k frames/s)
+DEFAULT_BATCH = 1024
 
 
 def parse_args():
@@ -52,7 +56,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)     # 100 steps = 0.23 s of timed GPU work at N = 1
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="frame pairs per GPU per step")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--width", type=int, default=640, help="image width (1280 for BASELINE config C3)")
     ap.add_argument("--height", type=int, default=480)
@@ -455,7 +459,7 @@ def main():
         bytes_frame = n_pre_per_frame * BYTES_PRECOMPUTE + n_res_per_frame * BYTES_RESIDUAL
         roofline = None
         mode = sia.last_run_mode() if not allreduce else 0
-        default_c1 = (not allreduce and not args.early_stop and B == 256 and n_feat == 2000 and args.width == 640 and
+        default_c1 = (not allreduce and not args.early_stop and B == DEFAULT_BATCH and n_feat == 2000 and args.width == 640 and
                       args.height == 480 and args.distinct == 64)       # the configuration the committed PMC passes profiled
         if prof and prof["residual_launches"]:
             launches = prof["residual_launches"]
