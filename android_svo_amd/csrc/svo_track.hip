@@ -1055,7 +1055,7 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   svo_hip_pyramid* ref = t->frame_pyr[t->last_idx];
   svo_hip_pyramid* cur = t->frame_pyr[1 - t->last_idx];
   // ---- new Frame(cam, img, t): the image crosses the link once, from page-locked memory; the pyramid is built on the device
-  memcpy(t->img_host, level0, l0);
+  if (level0 != reinterpret_cast<const uint8_t*>(t->img_host)) memcpy(t->img_host, level0, l0);      // (svo_hip_tracker_image_buffer: already there)
   int rc = svo_pyramid_build_levels(cur, 0, 1, t->img_dev);
   if (rc != SVO_HIP_OK) return rc;
   // ---- SparseImgAlign(kltMaxLevel, kltMinLevel, 30, GaussNewton, false, false).run(last_frame_, new_frame_)
@@ -1140,6 +1140,12 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   t->last_from_track = true;
   t->need_gather = false;
   if (result->map_changed) t->rekey_pending = true;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_image_buffer(svo_hip_tracker* t, uint8_t** buffer) {
+  if (!t || !buffer) return SVO_HIP_ERR_INVALID;
+  *buffer = reinterpret_cast<uint8_t*>(t->img_host);
   return SVO_HIP_OK;
 }
 

@@ -789,6 +789,13 @@ class Tracker:
                                                                        _ptr(it, C.c_int32)), "tracker_optimize_structure")
         return pos[:len(pt)], it[:len(pt)]
 
+    def image_buffer(self) -> np.ndarray:
+        """the tracker's page-locked image buffer as a (height, width) u8 view (svo_hip_tracker_image_buffer): an image written
+        there and passed to track() as this very array is not copied again"""
+        p = C.POINTER(C.c_uint8)()
+        self.ctx.check(self.ctx.lib.svo_hip_tracker_image_buffer(self.h, C.byref(p)), "tracker_image_buffer")
+        return np.ctypeslib.as_array(p, shape=(self.cam.height, self.cam.width))
+
     def download_key_points(self, n_kf: int) -> np.ndarray:
         """[n_kf][5] point indices of the keyframes' key features as the device holds them (after the re-selections that follow
         deletions)"""

@@ -78,6 +78,13 @@ class FrameTrackerT {
   /// how often the map has been flattened and uploaded (diagnostic)
   size_t mapUploads() const { return n_uploads_; }
 
+  /// page-locked buffer of one full-resolution image (svo_hip_tracker_image_buffer): a new frame whose level 0 lives there
+  /// (cv::Mat(rows, cols, CV_8UC1, tracker.imageBuffer()) handed to the Frame constructor) is tracked without the copy of its
+  /// image into the buffer; NULL if the tracker could not be created
+  uint8_t* imageBuffer() const {
+    uint8_t* b = NULL;
+    return trk_ && svo_hip_tracker_image_buffer(trk_, &b) == SVO_HIP_OK ? b : NULL;
+  }
   /// the map changed behind the tracker's back (keyframe added / removed, points optimised or deleted, candidates added):
   /// flatten it again before the next frame.  processFrame calls this after map_.addKeyframe, optimizeStructure etc.
   void mapChanged() { map_dirty_ = true; }

@@ -543,6 +543,12 @@ int svo_hip_tracker_optimize_structure(svo_hip_tracker* trk, int n, const int32_
  * kf_slot), pose and features: px[n][2], f[n][3], point[n] (index or -1) */
 int svo_hip_tracker_set_last_frame(svo_hip_tracker* trk, const uint8_t* level0, int kf_slot, const double T_f_w[7], int n,
                                    const double* px, const double* f, const int32_t* point);
+/* The tracker's own image buffer: width x height bytes of page-locked, device-mapped host memory the first kernel of a
+ * frame reads level 0 from.  svo_hip_tracker_track copies the caller's image there; a caller whose camera frames can land
+ * in this buffer (a cv::Mat header over it, Frame::img_pyr_[0] of the new frame) passes the buffer itself as level0 and
+ * saves that copy (about 10 us of a 640x480 frame).  The buffer belongs to the tracker, is free again when
+ * svo_hip_tracker_track returns, and lives until svo_hip_tracker_destroy. */
+int svo_hip_tracker_image_buffer(svo_hip_tracker* trk, uint8_t** buffer);
 /* One frame.  Outputs (host, any may be NULL except result): the new frame's features in creation order -- px[n][2],
  * f[n][3], level[n], point[n] (-1 where the pose refinement dropped the observation, pose_optimizer.cpp:154-157),
  * edgelet[n], grad[n][2], capacity max_frame_features -- and the point counters after the frame (capacity n_points of

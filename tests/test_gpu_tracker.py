@@ -111,6 +111,36 @@ def test_twenty_frame_sequence_through_the_tracker(ctx, min_level):
     assert err_gpu[:, 0].max() < 2e-3 and err_gpu[:, 1].max() < 5e-3, err_gpu.max(axis=0)
 
 
+def test_image_in_the_tracker_buffer_tracks_the_same(ctx):
+    """svo_hip_tracker_image_buffer: frames written into the tracker's own page-locked buffer and passed as that very pointer
+    (no copy inside svo_hip_tracker_track) give bit for bit the poses, matches and features of frames passed from caller memory"""
+    seq = tc.make_sequence(n_frames=8)
+    mp = tc.sequence_map(seq)
+    n = len(seq["px0"])
+    outs = []
+    for through_buffer in (False, True):
+        trk = hip.Tracker(ctx, seq["cam"], max_keyframes=2, max_points=1024, max_obs=1024, max_kf_features=1024, max_candidates=16,
+                          max_items=1024, max_frame_features=1024, grid_size=tc.CELL, max_fts=tc.MAX_FTS, klt_min_level=2)
+        trk.upload_keyframe(0, seq["pyrs"][0][0])
+        trk.set_map(mp)
+        trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], np.arange(n, dtype=np.int32), kf_slot=0)
+        buf = trk.image_buffer()
+        assert buf.shape == (seq["cam"].height, seq["cam"].width) and buf.dtype == np.uint8
+        frames = []
+        for k in range(1, 8):
+            if through_buffer:
+                buf[:] = seq["pyrs"][k][0]
+                r = trk.track(buf)
+            else:
+                buf[:] = 0                                   # whatever the buffer held is overwritten by the call's own copy
+                r = trk.track(seq["pyrs"][k][0])
+            frames.append((r["T_f_w"].tobytes(), r["n_matches"], r["feat_px"].tobytes(), r["feat_point"].tobytes()))
+        outs.append(frames)
+        trk.destroy()
+    assert outs[0] == outs[1]
+    assert all(f[1] >= 50 for f in outs[0])
+
+
 def test_update_point_positions_equals_a_fresh_map(ctx):
     """FrameHandlerBase::optimizeStructure moves a few points between two frames: pushing the new positions with
     svo_hip_tracker_update_point_positions must give bit for bit what a fresh upload of the whole map gives (the last
