@@ -633,7 +633,7 @@ def main():
         c4 = None
         if not allreduce and world == 1 and not args.no_secondary and not args.early_stop:
             import bench_c2
-            c2 = {"what": "BASELINE config C2 on this GPU, inputs resident in HBM (python bench_c2.py gives the long form)"}
+            c2 = {"what": "BASELINE config C2 on this GPU, inputs resident in HBM; per-call time = best of 3 rounds of back-to-back calls after 30 ms of warm-up (python bench_c2.py gives the long form)"}
             c2["align2d"], _ = bench_c2.measure_align2d(ctx, 5000, steps=20, warmup=3)
             c2["depth_filter"], _, sb2, pyr2 = bench_c2.measure_depth_filter(ctx, 100000, steps=20, warmup=3)
             sb2.free()
