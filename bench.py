@@ -220,6 +220,20 @@ def valu_issue_cycles(c):
     return 2.0 * (total - f64 - trans - cvt) + 4.0 * (f64 + cvt) + 8.0 * trans, f64, trans
 
 
+PREWARM_S = 0.1
+
+
+def prewarm(ctx, fn, seconds=PREWARM_S):
+    """Part of the set-up, never of a timed region: call fn (a launch of the workload about to be measured) for `seconds` so
+    that the chip is at its running clocks.  Every measurement here follows seconds of host work (scene generation, uploads,
+    oracle checks) with the GPU idle, and an idle MI355X was seen to run its first tens of milliseconds many times slower
+    (bench_c2.timed has the figures)."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        fn()
+        ctx.sync()
+
+
 def with_uploads(torch, ctx, stream, local_rank, sia, ref, fps, n_slots, prm, steps):
     """Upload-inclusive throughput: every step a NEW current image per frame pair (level 0, n_slots x 307 200 B from one
     page-locked buffer) crosses PCIe on a second stream, its pyramid is built on the device
@@ -379,6 +393,14 @@ def main():
         if multi:
             dist.barrier()
 
+    # set-up: the chip at its running clocks before the W warm-up steps (a fixed count where a step holds a collective:
+    # every rank must run the same number of them)
+    if allreduce:
+        for _ in range(5):
+            step()
+    else:
+        prewarm(ctx, step)
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -547,9 +569,7 @@ def main():
         if not allreduce and world == 1 and not args.no_secondary and not args.early_stop:
             # (1) the same batch with the REFERENCE's Gauss-Newton exits (error increase, |x| <= eps)
             prm_es = sia.params(max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=True)
-            for _ in range(2):
-                sia.run(n_slots, prm_es)
-            ctx.sync()
+            prewarm(ctx, lambda: sia.run(n_slots, prm_es))
             es_steps = max(5, min(args.steps, 20))
             t1 = time.perf_counter()
             for _ in range(es_steps):
@@ -569,9 +589,7 @@ def main():
             # contracted interpolation, f32 sums over a patch's 16 pixels), every distinct scene against the CPU oracle
             sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_FAST)
             try:
-                for _ in range(2):
-                    sia.run(n_slots, prm)
-                ctx.sync()
+                prewarm(ctx, lambda: sia.run(n_slots, prm))
                 fa_steps = max(5, min(args.steps, 20))
                 t1 = time.perf_counter()
                 for _ in range(fa_steps):
@@ -592,8 +610,7 @@ def main():
             # (2) the streaming implementation of the Jacobian / residual pass: the HBM-bound form (north_star: >= 50 % of the HBM roofline)
             sia.set_mode(stream=True)           # an option of this solver object (svo_hip_sia_set_option), not a process-wide switch
             try:
-                sia.run(n_slots, prm)
-                ctx.sync()
+                prewarm(ctx, lambda: sia.run(n_slots, prm))
                 sia.set_profiling(True)
                 sia.run(n_slots, prm)
                 sp = sia.get_profile()
