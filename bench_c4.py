@@ -114,6 +114,11 @@ def main():
         if multi:
             dist.barrier()
 
+    # set-up: 40 passes (~30 ms) bring a chip that idled through the case generation to its running clocks (a fixed count:
+    # a step holds collectives, every rank must run the same number; see bench_c2.timed)
+    for _ in range(40):
+        step()
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
