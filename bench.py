@@ -333,7 +333,13 @@ def main():
     allreduce = args.mode in ("allreduce", "allreduce-torch") and multi
     native = args.mode == "allreduce"
     # ---- synthetic inputs (host), then resident in HBM before anything is timed
-    fps = [synth.make_frame_pair(seed=12345 + 17 * rank + i, n_features=n_feat, width=args.width, height=args.height) for i in range(args.distinct)]
+    def make_scenes(first_seed):
+        # (rendering is numpy-bound and releases the GIL for most of its time: a few threads cut the set-up time)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, min(8, host_cpus()[1]))) as pool:
+            return list(pool.map(lambda i: synth.make_frame_pair(seed=first_seed + i, n_features=n_feat, width=args.width, height=args.height),
+                                 range(args.distinct)))
+    fps = make_scenes(12345 + 17 * rank)
     cam = fps[0].cam
     stream = torch.cuda.Stream(device=local_rank)
     ctx = hip.Context(local_rank, stream=stream.cuda_stream)
@@ -346,7 +352,7 @@ def main():
         sia.set_mode(stream=True)
     if allreduce:
         # every rank holds every frame of the global batch (same seeds on all ranks), evaluates its patch shard
-        fps = [synth.make_frame_pair(seed=12345 + i, n_features=n_feat, width=args.width, height=args.height) for i in range(args.distinct)]
+        fps = make_scenes(12345)
         sia.set_shard(rank, world)
     for s in range(n_slots):
         fp = fps[s % len(fps)]
