@@ -46,8 +46,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PRECOMPUTE = 945           # per patch per level
 BYTES_RESIDUAL = 881             # per patch per Gauss-Newton evaluation
 # frame pairs per GPU per launch.  One 8-wave workgroup solves one pair and fills one CU: with 256 pairs every CU runs
-# exactly one workgroup and the launch lasts as long as its slowest scene; four workgroups per CU balance that
-# (tools/batch_sweep.sh, same box: 256 / 512 / 1024 / 2048 pairs -> 203.1 / 207.9 / 210.7 / 213.3 k frames/s)
+# exactly one workgroup and the launch lasts as long as its slowest scene; four workgroups per CU balance that a little
+# (tools/batch_sweep.sh on a warm chip, same box: 256 / 1024 / 2048 pairs -> 210.5 / 211.8 / 213.3 k frames/s) and the
+# streaming form of the pass, whose launches are 29 us at 256 pairs, gains more (0.58 -> 0.65 of HBM peak)
 DEFAULT_BATCH = 1024
 
 
