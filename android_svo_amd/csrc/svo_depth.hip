@@ -962,7 +962,7 @@ __global__ __launch_bounds__(1024) void conv_scan_kernel(int n_blocks, int* __re
     s_part[threadIdx.x] = v;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {                     // Hillis-Steele inclusive scan
-      const int t = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+      const int t = (int)threadIdx.x >= o ? s_part[(int)threadIdx.x - o] : 0;
       __syncthreads();
       s_part[threadIdx.x] += t;
       __syncthreads();
