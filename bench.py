@@ -186,7 +186,7 @@ def latest_profile(pattern):
     return files[-1] if files else None
 
 
-def pmc_of(path, kernel_prefix, allow_stale=False):
+def pmc_of(path, kernel_prefix, allow_stale=False, pairs=None):
     """counters per dispatch of the first kernel whose name starts with kernel_prefix (tools/pmc_json.py output).  A profile
     taken from other kernel sources than the tree's (tools/pmc_json.py stores their sha256) is refused: returns the string
     that says so."""
@@ -201,9 +201,15 @@ def pmc_of(path, kernel_prefix, allow_stale=False):
         changed = sorted(k for k in want if not have or have.get(k) != want[k])
         return "%s was taken from other kernel sources than this tree's (%s differ%s): re-run tools/pmc_fused.sh" % (
             os.path.relpath(path, ROOT), ", ".join(changed), "" if len(changed) > 1 else "s")
+    # every counter of these kernels is proportional to the frame pairs in the launch (256 -> 1024 pairs: x 4.000 on all of
+    # them): a profile taken at another launch size is scaled to the one being timed
+    prof_pairs = d.get("frame_pairs_per_launch")
+    scale = (float(pairs) / prof_pairs) if (pairs and prof_pairs) else 1.0
     for name, ctr in d.get("kernels", {}).items():
         if name.startswith(kernel_prefix):
-            return dict(ctr, _kernel=name, _file=os.path.relpath(path, ROOT), _command=d.get("command", ""))
+            out = {k: (v * scale if isinstance(v, (int, float)) else v) for k, v in ctr.items()}
+            return dict(out, _kernel=name, _file=os.path.relpath(path, ROOT), _command=d.get("command", ""),
+                        _scaled_from_pairs=prof_pairs if scale != 1.0 else None)
     return None
 
 
@@ -488,7 +494,7 @@ def main():
         bytes_frame = n_pre_per_frame * BYTES_PRECOMPUTE + n_res_per_frame * BYTES_RESIDUAL
         roofline = None
         mode = sia.last_run_mode() if not allreduce else 0
-        default_c1 = (not allreduce and not args.early_stop and B == DEFAULT_BATCH and n_feat == 2000 and args.width == 640 and
+        default_c1 = (not allreduce and not args.early_stop and n_feat == 2000 and args.width == 640 and
                       args.height == 480 and args.distinct == 64)       # the configuration the committed PMC passes profiled
         if prof and prof["residual_launches"]:
             launches = prof["residual_launches"]
@@ -508,7 +514,7 @@ def main():
                            "cache per patch); the kernels form H and Jres from {sum dx^2, sum dx dy, sum dy^2} and two moments per patch and "
                            "never move that stream, so this ratio is not a roofline fraction"}
             pmc_file = latest_profile("r*_pmc_fused.json" if mode == 1 else "r*_pmc_stream.json")
-            ctr = pmc_of(pmc_file, kernel, args.allow_stale_profile) if (pmc_file and default_c1) else None
+            ctr = pmc_of(pmc_file, kernel, args.allow_stale_profile, pairs=n_slots) if (pmc_file and default_c1) else None
             profile_refused = ctr if isinstance(ctr, str) else None
             if profile_refused:
                 ctr = None
@@ -548,6 +554,8 @@ def main():
                                                "correction of FETCH_SIZE, which holds for 16 B/lane streams (the stored interpolated patches) "
                                                "but not for the 8 B/lane image rows: lower and upper bound"}
                     roofline["sources"] = [ctr["_file"], "profiles/%s" % os.path.basename(pmc_file).replace("_pmc_fused.json", "_kernel_stats.md")]
+                    if ctr.get("_scaled_from_pairs"):
+                        roofline["counters_scaled_from_frame_pairs_per_launch"] = ctr["_scaled_from_pairs"]
             else:
                 ach = alg_bytes / avg_s / 1e9
                 roofline = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -557,6 +565,8 @@ def main():
                     phys = (2.0 * ctr.get("FETCH_SIZE", 0.0) + ctr.get("WRITE_SIZE", 0.0)) * 1024.0
                     roofline.update({"achieved": phys / avg_s / 1e9, "frac": phys / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": phys,
                                      "sources": [ctr["_file"]]})
+                    if ctr.get("_scaled_from_pairs"):
+                        roofline["counters_scaled_from_frame_pairs_per_launch"] = ctr["_scaled_from_pairs"]
             if prof["precompute_launches"]:
                 roofline["precompute_avg_launch_us"] = prof["precompute_ms"] / prof["precompute_launches"] * 1e3
             hp = os.path.join(ROOT, "profiles", "r01_hbm_probe.json")
@@ -639,7 +649,7 @@ def main():
                        "note": "one launch = one Gauss-Newton evaluation of %d frame pairs: per-pixel f32 caches + {x,y,z,1/z} + "
                                "{sum dx^2, sum dx dy, sum dy^2} streamed from HBM (227 B/patch instead of the reference layout's 881 B)" % n_slots}
                 sfile = latest_profile("r*_pmc_stream.json")
-                sc = pmc_of(sfile, "sia_residual_kernel", args.allow_stale_profile) if (sfile and default_c1) else None
+                sc = pmc_of(sfile, "sia_residual_kernel", args.allow_stale_profile, pairs=n_slots) if (sfile and default_c1) else None
                 if isinstance(sc, str):
                     jac["profile_refused"] = sc
                     sc = None

@@ -30,8 +30,17 @@ def main():
         elif not line.startswith(" "):
             cur = line.strip()
             kernels.setdefault(cur, {})
+    # frame pairs per launch of the profiled command: every counter of these kernels is proportional to it (256 -> 1024
+    # pairs: x 4.000), so bench.py scales a profile to the launch size it times
+    m = re.search(r"--batch\s+(\d+)", cmd)
+    if m:
+        pairs = int(m.group(1))
+    else:
+        sys.path.insert(0, ROOT)
+        import bench
+        pairs = bench.DEFAULT_BATCH
     json.dump({"command": cmd, "unit": "counter value per dispatch (mean over the dispatches of the pass)",
-               "source_sha256": source_sha256(), "kernels": kernels}, open(dst, "w"), indent=1)
+               "frame_pairs_per_launch": pairs, "source_sha256": source_sha256(), "kernels": kernels}, open(dst, "w"), indent=1)
     print(dst, {k: len(v) - 1 for k, v in kernels.items()})
 
 
