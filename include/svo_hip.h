@@ -525,7 +525,8 @@ int svo_hip_tracker_upload_keyframe(svo_hip_tracker* trk, int slot, const uint8_
 int svo_hip_tracker_keyframe_from_last_frame(svo_hip_tracker* trk, int slot);
 /* The map as index tables (every index is checked here, on the host).  The last frame's features refer to map points by index: a
  * map with the same point numbering may be set between two tracked frames; if the new map has fewer points than the largest
- * index the last frame uses, the last frame is forgotten and svo_hip_tracker_set_last_frame has to follow. */
+ * index the last frame uses, the last frame is forgotten and svo_hip_tracker_set_last_frame has to follow.  A map that is
+ * refused (an index out of range, a table above its capacity) changes nothing. */
 int svo_hip_tracker_set_map(svo_hip_tracker* trk, const svo_hip_tracker_map* map);
 /* the keyframes' key points as the device holds them ([n_kf][5] point indices, -1 = none): what was uploaded, advanced by the
  * re-selections that followed deletions (parity tests) */

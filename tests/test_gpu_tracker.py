@@ -546,7 +546,7 @@ def test_tracker_edge_cases(ctx):
 
 def test_tracker_refuses_bad_arguments(ctx):
     """Every index the kernels follow is checked on the host: bad arguments come back as errors, nothing is launched."""
-    seq = tc.make_sequence(n_frames=2)
+    seq = tc.make_sequence(n_frames=3)
     mp = tc.sequence_map(seq)
     cam = seq["cam"]
     n = len(seq["px0"])
@@ -581,4 +581,20 @@ def test_tracker_refuses_bad_arguments(ctx):
     trk.set_last_frame(seq["T0"], seq["px0"][:200], seq["f0"][:200], np.arange(200, dtype=np.int32), kf_slot=0)
     r = trk.track(seq["pyrs"][1][0])
     assert int(r["n_matches"]) > 50
+    # a refused map changes nothing: this one has fewer points than the tracked frame refers to (accepted, it would make the
+    # tracker forget its last frame) and one bad point type
+    m = 50
+    o_end = int(mp["pt_obs_offset"][m])
+    keep = mp["kf_ftr_point"][mp["kf_ftr_point"] < m]
+    small = dict(mp, n_points=m, pt_pos=mp["pt_pos"][:m], pt_type=np.concatenate([[4], mp["pt_type"][1:m]]).astype(np.int32),
+                 pt_n_failed=mp["pt_n_failed"][:m], pt_n_succeeded=mp["pt_n_succeeded"][:m], pt_obs_offset=mp["pt_obs_offset"][:m + 1],
+                 obs_kf=mp["obs_kf"][:o_end], obs_px=mp["obs_px"][:o_end], obs_f=mp["obs_f"][:o_end], obs_level=mp["obs_level"][:o_end],
+                 kf_ftr_point=keep, kf_ftr_offset=np.array([0, len(keep)], np.int32), kf_key_point=np.full((1, 5), -1, np.int32))
+    for k in ("obs_edgelet", "obs_grad"):
+        if small.get(k) is not None:
+            small[k] = small[k][:o_end]
+    with pytest.raises(hip.SvoHipError):
+        trk.set_map(small)
+    r2 = trk.track(seq["pyrs"][2][0])                                             # no svo_hip_tracker_set_last_frame needed
+    assert int(r2["n_matches"]) > 50
     trk.destroy()
