@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""How far the REFERENCE moves between its two build flavours (test infrastructure, this container only).
+
+oracle/_ref      g++ -O2, no contraction (x86-64: what the parity fixtures were recorded with)
+oracle/_ref_fma  clang++ -O2 -ffp-contract=on -mfma (`make -C oracle ref-fma`): the contraction the NDK's clang applies by
+                 default on arm64, the platform the reference ships on
+
+Runs the reference's own compiled SparseImgAlign::run over synthetic frame pairs (BASELINE configs C0 and C1 sizes, both
+pyramid ranges) and feature_alignment::align2D over 5000 patches through both libraries and prints one JSON line: the
+largest pose difference between the flavours, whether the tracked-patch counts and iteration counts agree, how many align2D
+outcomes differ.  The HIP path follows the first flavour to 3.6e-14 rad (tests/test_gpu_parity.py); this figure says what
+"the reference" means to that many digits."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from android_svo_amd import seedsynth, synth  # noqa: E402
+from oracle.ref import refpy  # noqa: E402
+
+
+def with_lib(path):
+    refpy._LIB_PATH = path
+    refpy._lib = None
+    return refpy
+
+
+def run(path, scenes, ac):
+    r = with_lib(path)
+    if not r.available():
+        raise SystemExit("%s is missing: make -C oracle ref ref-fma" % path)
+    out = {"sia": [], "align": []}
+    for fp, min_level in scenes:
+        o = r.sparse_img_align_run(fp, max_level=4, min_level=min_level, n_iter=30)
+        out["sia"].append((o["T_cur_w"].copy(), int(o["n_tracked"]), [int(v) for v in o["iter"][:5]], o["ref_patch_cache"].copy()))
+    for i in range(len(ac.px_init)):
+        ok, p = r.align2d(ac.cur_pyr[0], ac.pwb[i], ac.patch[i], 10, ac.px_init[i])
+        out["align"].append((ok, p[0], p[1]))
+    return out
+
+
+def main():
+    scenes = []
+    for k in range(6):
+        scenes.append((synth.make_frame_pair(seed=12345 + k, n_features=2000), 0))
+        scenes.append((synth.make_frame_pair(seed=12345 + k, n_features=200), 2))
+    ac = seedsynth.make_align_case(n=5000)
+    a = run(os.path.join(ROOT, "oracle", "_ref", "libsvo_ref.so"), scenes, ac)
+    b = run(os.path.join(ROOT, "oracle", "_ref_fma", "libsvo_ref.so"), scenes, ac)
+    err = np.array([synth.pose_error(x[0], y[0]) for x, y in zip(a["sia"], b["sia"])])
+    truth = np.array([synth.pose_error(x[0], fp.T_cur_w_true) for x, (fp, _) in zip(a["sia"], scenes)])
+    res = {"what": "the reference's own SparseImgAlign::run and align2D, g++ -O2 (no contraction) against clang++ -O2 -ffp-contract=on -mfma",
+           "sparse_img_align": {"scenes": len(scenes), "max_rot_rad_between_flavours": float(err[:, 0].max()),
+                                "max_trans_m_between_flavours": float(err[:, 1].max()),
+                                "median_rot_rad_between_flavours": float(np.median(err[:, 0])),
+                                "n_tracked_equal": bool(all(x[1] == y[1] for x, y in zip(a["sia"], b["sia"]))),
+                                "scenes_with_other_iteration_counts": int(sum(x[2] != y[2] for x, y in zip(a["sia"], b["sia"]))),
+                                "ref_patch_cache_bitwise_equal_scenes": int(sum(x[3].tobytes() == y[3].tobytes() for x, y in zip(a["sia"], b["sia"]))),
+                                "max_pose_error_vs_ground_truth": {"rot_rad": float(truth[:, 0].max()), "trans_m": float(truth[:, 1].max())}},
+           "align2d": {"patches": len(a["align"]),
+                       "converged_flag_differs": int(sum(x[0] != y[0] for x, y in zip(a["align"], b["align"]))),
+                       "pixel_not_bitwise_equal": int(sum((x[1], x[2]) != (y[1], y[2]) for x, y in zip(a["align"], b["align"]))),
+                       "max_pixel_difference": float(max(max(abs(x[1] - y[1]), abs(x[2] - y[2])) for x, y in zip(a["align"], b["align"])))}}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
