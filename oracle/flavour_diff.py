@@ -6,7 +6,8 @@ oracle/_ref_fma  clang++ -O2 -ffp-contract=on -mfma (`make -C oracle ref-fma`): 
                  default on arm64, the platform the reference ships on
 
 Runs the reference's own compiled SparseImgAlign::run over synthetic frame pairs (BASELINE configs C0 and C1 sizes, both
-pyramid ranges) and feature_alignment::align2D over 5000 patches through both libraries and prints one JSON line: the
+pyramid ranges), feature_alignment::align2D over 5000 patches and Reprojector::reprojectMap over the three map cases of the
+fixtures through both libraries and prints one JSON line: the
 largest pose difference between the flavours, whether the tracked-patch counts and iteration counts agree, how many align2D
 outcomes differ.  The HIP path follows the first flavour to 3.6e-14 rad (tests/test_gpu_parity.py); this figure says what
 "the reference" means to that many digits."""
@@ -40,7 +41,17 @@ def run(path, scenes, ac):
     for i in range(len(ac.px_init)):
         ok, p = r.align2d(ac.cur_pyr[0], ac.pwb[i], ac.patch[i], 10, ac.px_init[i])
         out["align"].append((ok, p[0], p[1]))
+    out["map"] = []
+    for kw, max_fts in MAP_CASES:
+        cs = synth.make_map_case(**kw)
+        m = r.reproject_map(cs, max_fts=max_fts)
+        out["map"].append(m)
     return out
+
+
+# the cases of tests/golden/reproject_map_ref.npz (oracle/gen_golden.py: MAP_REF_CASES)
+MAP_CASES = ((dict(seed=31), 1200), (dict(seed=31), 40),
+             (dict(seed=32, n_kf=9, n_points=900, n_candidates=60, cell_size=25, kf_step=0.55), 1200))
 
 
 def main():
@@ -65,6 +76,14 @@ def main():
                        "converged_flag_differs": int(sum(x[0] != y[0] for x, y in zip(a["align"], b["align"]))),
                        "pixel_not_bitwise_equal": int(sum((x[1], x[2]) != (y[1], y[2]) for x, y in zip(a["align"], b["align"]))),
                        "max_pixel_difference": float(max(max(abs(x[1] - y[1]), abs(x[2] - y[2])) for x, y in zip(a["align"], b["align"])))}}
+    mm = []
+    for x, y in zip(a["map"], b["map"]):
+        same_int = all(np.array_equal(np.asarray(x[k]), np.asarray(y[k])) for k in ("feat_point", "feat_level", "type", "n_failed", "n_succeeded", "unlinked", "overlap_kf"))
+        px_x, px_y = np.asarray(x["feat_px"]), np.asarray(y["feat_px"])
+        mm.append({"n_matches": [int(x["n_matches"]), int(y["n_matches"])], "every_integer_output_equal": bool(same_int),
+                   "matched_pixels_not_bitwise_equal": int((px_x != px_y).any(axis=1).sum()) if px_x.shape == px_y.shape else -1,
+                   "max_pixel_difference": float(np.abs(px_x - px_y).max()) if px_x.shape == px_y.shape and px_x.size else None})
+    res["reproject_map"] = mm
     print(json.dumps(res))
 
 
