@@ -35,6 +35,7 @@ typedef int (*fn_CommDestroy)(NcclComm);
 typedef int (*fn_AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t);
 typedef int (*fn_AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t);
 typedef const char* (*fn_GetErrorString)(int);
+typedef int (*fn_CommCount)(NcclComm, int*);
 constexpr int kNcclSum = 0, kNcclInt8 = 0, kNcclFloat64 = 8;      // ncclRedOp_t / ncclDataType_t values
 
 struct Rccl {
@@ -45,6 +46,7 @@ struct Rccl {
   fn_AllReduce AllReduce = nullptr;
   fn_AllGather AllGather = nullptr;
   fn_GetErrorString GetErrorString = nullptr;
+  fn_CommCount CommCount = nullptr;
   std::string err;
 };
 
@@ -65,6 +67,7 @@ Rccl& rccl() {
   r.AllReduce = (fn_AllReduce)dlsym(r.lib, "ncclAllReduce");
   r.AllGather = (fn_AllGather)dlsym(r.lib, "ncclAllGather");
   r.GetErrorString = (fn_GetErrorString)dlsym(r.lib, "ncclGetErrorString");
+  r.CommCount = (fn_CommCount)dlsym(r.lib, "ncclCommCount");
   if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.AllGather) {
     r.err = "librccl lacks an expected symbol";
     r.lib = nullptr;
@@ -361,6 +364,24 @@ int svo_hip_comm_info(const svo_hip_comm* c, int* rank, int* world, int* kind) {
   if (rank) *rank = c->rank;
   if (world) *world = c->world;
   if (kind) *kind = c->kind;
+  return SVO_HIP_OK;
+}
+
+// The number of ranks the TRANSPORT itself reports: ncclCommCount of the RCCL communicator, the world size stored in the
+// shared-memory segment's header.  (svo_hip_comm_info returns what the caller passed at creation.)
+int svo_hip_comm_count(const svo_hip_comm* c, int* count) {
+  if (!c || !count) return SVO_HIP_ERR_INVALID;
+  if (c->kind == 0) {
+    const Rccl& r = rccl();
+    if (!r.CommCount || !c->nccl) return SVO_HIP_ERR_STATE;
+    int n = 0;
+    const int rc = r.CommCount(c->nccl, &n);
+    if (rc != 0) return nccl_fail(c->ctx, "ncclCommCount", rc);
+    *count = n;
+  } else {
+    if (!c->shm) return SVO_HIP_ERR_STATE;
+    *count = (int)reinterpret_cast<const ShmHeader*>(c->shm)->world;
+  }
   return SVO_HIP_OK;
 }
 

@@ -438,6 +438,12 @@ class Comm:
             raise SvoHipError("svo_hip_comm_unique_id failed (%d): is librccl loadable?" % rc)
         return bytes(buf)
 
+    def count(self) -> int:
+        """ranks the transport itself reports (ncclCommCount / the shared-memory header): svo_hip_comm_count"""
+        n = C.c_int(0)
+        self.ctx.check(self.ctx.lib.svo_hip_comm_count(self.h, C.byref(n)), "comm_count")
+        return n.value
+
     def destroy(self):
         if self.h:
             self.ctx.lib.svo_hip_comm_destroy(self.h)

@@ -6,7 +6,8 @@ solve (5 pyramid levels x 30 Gauss-Newton evaluations, fixed work = config C1) o
 independent 640x480 pairs with 2000 patches each, inputs already resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
-  N > 1: launched by torch.distributed.run, one rank per GPU.  Default sharding is by frame
+  N > 1: one rank per GPU -- launched by torch.distributed.run, or started plainly, in which case this process starts
+  the N ranks itself (android_svo_amd/launcher.py) and relays rank 0's line.  Default sharding is by frame
   pair (independent objects, no data-path collective, weak scaling).  --mode allreduce runs
   BASELINE config C3's variant instead: every frame's patches are split over the ranks and the
   per-frame 6x6 H / 6x1 b sums are all-reduced (RCCL over xGMI) at every Gauss-Newton step.
@@ -40,7 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from android_svo_amd import hip, synth  # noqa: E402
+from android_svo_amd import hip, launcher, synth  # noqa: E402   (none of them touches the GPU at import)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PRECOMPUTE = 945           # per patch per level
@@ -307,6 +308,10 @@ def with_uploads(torch, ctx, stream, local_rank, sia, ref, fps, n_slots, prm, st
 
 def main():
     args = parse_args()
+    # `python bench.py --gpus N` started plainly: this process starts the N ranks itself (as a child process; it has not
+    # touched the GPU and never does), relays rank 0's JSON line and leaves with the children's status
+    if args.gpus > 1 and not launcher.launched_by_torchrun():
+        sys.exit(launcher.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     # RCCL prints a version banner on stdout when a communicator is created; the contract is ONE JSON
     # line on stdout, so everything else this process (or a library) prints is sent to stderr.
     sys.stdout.flush()
@@ -386,6 +391,8 @@ def main():
         from android_svo_amd import dist as svodist
         aligner = svodist.HipShardedAligner(sia, n_slots, prm, rank, world, stream)
         graphed = svodist.GraphedAllreduceSolver(aligner, prm.max_level, prm.min_level, prm.n_iter, stream) if args.graph else None
+
+    comm_ranks = comm.count() if comm is not None else None     # what the transport itself reports (ncclCommCount)
 
     def step():
         if not allreduce:
@@ -699,6 +706,7 @@ def main():
                                        (", HIP-graph replay" if args.graph else "") if allreduce
                                        else "frame-parallel (no collective)") + ", %d GPU(s)" % world,
                        "distinct_scenes": args.distinct,
+                       **({"comm_ranks": comm_ranks} if comm_ranks is not None else {}),
                        "implementation": "fused (one workgroup per frame pair, one launch per solve)" if (not allreduce and mode == 1) else "streaming (one launch per Gauss-Newton evaluation)"},
             "pose_err_vs_cpu_ref": {"rot_rad": rot, "trans_m": trans, "tolerance": "1e-4 rad / 1e-3 m",
                                     "scenes_checked": int(n_scenes), "max_rot_rad_over_scenes": float(scene_err[:, 0].max()),

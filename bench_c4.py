@@ -24,11 +24,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from android_svo_amd import dist as svodist, hip, seedsynth  # noqa: E402
+from android_svo_amd import dist as svodist, hip, launcher, seedsynth  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="started plainly with N > 1: this process starts the N ranks itself")
     ap.add_argument("--seeds", type=int, default=1000000)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
@@ -39,6 +40,8 @@ def main():
     ap.add_argument("--sigma-scale", type=float, default=0.0045,
                     help="seed variance relative to a fresh seed: small enough that part of the seeds converge in this pass")
     args = ap.parse_args()
+    if args.gpus > 1 and not launcher.launched_by_torchrun():
+        sys.exit(launcher.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)                      # RCCL prints a banner on stdout
@@ -141,6 +144,7 @@ def main():
                **({"rehearsal": "%d ranks share %d GPU(s): gloo process group, shared-memory exchange -- a code-path rehearsal, not a scaling measurement" % (world, n_dev)} if rehearsal else {}),
                "config": {"workload": "C4: DepthFilter::updateSeeds, %d seeds on a %dx%d keyframe, seeds sharded over %d GPU(s), gather of converged records"
                                       % (args.seeds, args.width, args.height, world),
+                          **({"comm_ranks": comm.count()} if comm is not None else {}),
                           "seeds_per_gpu": hi - lo, "converged_records_gathered": int(n_conv_total),
                           "gather": "svo_hip_seed_gather_converged_dev (RCCL called by libsvo_hip.so)" if comm is not None else "torch.distributed driver",
                           "note": "a step = the update pass + the on-device packing of the converged records + the RCCL all-gather"}}

@@ -164,6 +164,8 @@ int svo_hip_comm_from_nccl(svo_hip_ctx* ctx, void* nccl_comm, int rank, int worl
 int svo_hip_comm_create_shm(svo_hip_ctx* ctx, const char* name, int rank, int world, size_t slot_bytes, svo_hip_comm** out);
 int svo_hip_comm_destroy(svo_hip_comm* comm);
 int svo_hip_comm_info(const svo_hip_comm* comm, int* rank, int* world, int* kind /* 0 RCCL, 1 shared memory */);
+/* the rank count the transport itself reports (ncclCommCount / the segment header), not the creation argument */
+int svo_hip_comm_count(const svo_hip_comm* comm, int* count);
 
 /* SparseImgAlign::run with every frame's patches split over the ranks of `comm` (BASELINE config C3's variant): each
  * rank evaluates patches [n*rank/world, n*(rank+1)/world) of every slot, ONE all-reduce of n_slots x

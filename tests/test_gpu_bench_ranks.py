@@ -36,3 +36,33 @@ def test_bench_sharded_three_ranks():
     d = _torchrun(3, 29672, "--mode", "allreduce", "--batch", "1")
     assert d["n_gpus"] == 3 and "rehearsal" in d and "patch-sharded" in d["config"]["parallelism"]
     assert d["pose_err_vs_cpu_ref"]["max_rot_rad_over_scenes"] < 1e-8          # fixed work: the same evaluation sequence as the oracle
+
+
+def _plain(script, *args):
+    """`python <script> --gpus N ...` started plainly: no launcher, no RANK / WORLD_SIZE in the environment -- the script
+    starts its own ranks (android_svo_amd/launcher.py) and relays rank 0's one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, script)] + list(args), cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_started_plainly_starts_its_own_ranks():
+    d = _plain("bench.py", "--gpus", "2", "--batch", "8", "--steps", "2", "--warmup", "1", "--no-secondary", "--no-cpu-baseline",
+               "--distinct", "4")
+    assert d["n_gpus"] == 2 and "rehearsal" in d and d["config"]["global_frame_pairs_per_step"] == 16
+    assert d["pose_err_vs_cpu_ref"]["max_rot_rad_over_scenes"] < 1e-4
+
+
+def test_bench_sharded_started_plainly_reports_the_communicators_rank_count():
+    d = _plain("bench.py", "--gpus", "2", "--mode", "allreduce", "--batch", "1", "--steps", "2", "--warmup", "1", "--no-secondary",
+               "--no-cpu-baseline", "--distinct", "2")
+    assert d["n_gpus"] == 2 and d["config"]["comm_ranks"] == 2 and "patch-sharded" in d["config"]["parallelism"]
+
+
+def test_bench_c4_gpus_2_started_plainly():
+    d = _plain("bench_c4.py", "--gpus", "2", "--seeds", "20000", "--width", "640", "--height", "480", "--steps", "2", "--warmup", "1")
+    assert d["n_gpus"] == 2 and "rehearsal" in d and d["config"]["comm_ranks"] == 2
+    assert d["config"]["converged_records_gathered"] > 0
