@@ -117,7 +117,7 @@ SVO_DEV void quad_serial_sums(const float (&t)[NSUM][16], float (&s)[NSUM]) {
 
 // The lane's 16 interpolated residuals (rows 2q, 2q+1 of the patch) at integer position (u_r, v_r) with the bilinear
 // weights of the reference; `base` = cur_img + (v_r - 4) * cur_step + (u_r - 4).
-SVO_DEV void quad_residuals(const uint8_t* __restrict__ base, int cur_step, int q, const QuadPatch& qp, float wTL, float wTR,
+SVO_DEV void quad_residuals(const uint8_t* __restrict__ base, int cur_step, int q, const float (&pf)[16], float wTL, float wTR,
                             float wBL, float wBR, float mean_diff, float (&res)[16]) {
   // image rows 2q, 2q+1, 2q+2 of the 9-row footprint: the third one is the right neighbour's first, so only lane 3
   // loads it (row 8); the others take it through the quad -- 2 1/4 scattered loads per lane instead of 3
@@ -141,9 +141,16 @@ SVO_DEV void quad_residuals(const uint8_t* __restrict__ base, int cur_step, int 
     for (int x = 0; x < 8; ++x) {
       const int r = y * 8 + x;
       const float search_pixel = wTL * f[y][x] + wTR * f[y][x + 1] + wBL * f[y + 1][x] + wBR * f[y + 1][x + 1];
-      res[r] = search_pixel - (float)SVO_BYTE(qp.p, r) + mean_diff;
+      res[r] = search_pixel - pf[r] + mean_diff;
     }
   }
+}
+
+// the lane's 16 reference-patch pixels as floats: the same in every iteration (converting them inside the loop cost 16
+// v_cvt_f32_ubyte per iteration, which issue at the f64 rate)
+SVO_DEV void patch_floats(const QuadPatch& qp, float (&pf)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pf[r] = (float)SVO_BYTE(qp.p, r);
 }
 
 // feature_alignment::align2D for the patch of this quad.  All four lanes of a quad must call it with the same
@@ -153,6 +160,8 @@ SVO_DEV void quad_residuals(const uint8_t* __restrict__ base, int cur_step, int 
 SVO_DEV bool align2d_quad(const uint8_t* __restrict__ cur_img, int cols, int rows, int cur_step, const QuadPatch& qp,
                           int n_iter, bool active, double* px_u, double* px_v, int* iters) {
   const int q = threadIdx.x & 3;
+  float pf[16];
+  patch_floats(qp, pf);
   float jx[16], jy[16];
   float H[9];
   {
@@ -192,7 +201,7 @@ SVO_DEV bool align2d_quad(const uint8_t* __restrict__ cur_img, int cols, int row
       const float wBL = (float)((1.0 - subpix_x) * subpix_y);
       const float wBR = subpix_x * subpix_y;
       float t[3][16];
-      quad_residuals(cur_img + (v_r - 4) * cur_step + (u_r - 4), cur_step, q, qp, wTL, wTR, wBL, wBR, mean_diff, t[2]);
+      quad_residuals(cur_img + (v_r - 4) * cur_step + (u_r - 4), cur_step, q, pf, wTL, wTR, wBL, wBR, mean_diff, t[2]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) { t[0][r] = t[2][r] * jx[r]; t[1][r] = t[2][r] * jy[r]; }
       float J[3];
@@ -217,6 +226,8 @@ SVO_DEV bool align1d_quad(const uint8_t* __restrict__ cur_img, int cols, int row
                           const QuadPatch& qp, int n_iter, bool active, double* px_u, double* px_v, double* h_inv,
                           int* iters) {
   const int q = threadIdx.x & 3;
+  float pf[16];
+  patch_floats(qp, pf);
   float dv[16];
   float H00, H01;
   {
@@ -262,7 +273,7 @@ SVO_DEV bool align1d_quad(const uint8_t* __restrict__ cur_img, int cols, int row
       const float wBL = (float)((1.0 - subpix_x) * subpix_y);
       const float wBR = subpix_x * subpix_y;
       float res[16];
-      quad_residuals(cur_img + (v_r - 4) * cur_step + (u_r - 4), cur_step, q, qp, wTL, wTR, wBL, wBR, mean_diff, res);
+      quad_residuals(cur_img + (v_r - 4) * cur_step + (u_r - 4), cur_step, q, pf, wTL, wTR, wBL, wBR, mean_diff, res);
       float t[2][16], c[1][16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) { t[0][r] = res[r] * dv[r]; t[1][r] = res[r]; c[0][r] = res[r] * res[r]; }

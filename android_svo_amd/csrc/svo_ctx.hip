@@ -176,6 +176,7 @@ int svo_hip_ctx_destroy(svo_hip_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->staging) (void)hipFree(ctx->staging);
   if (ctx->host_staging) (void)hipHostFree(ctx->host_staging);
+  for (hipEvent_t e : ctx->df_ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return SVO_HIP_OK;

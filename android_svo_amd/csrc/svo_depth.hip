@@ -290,8 +290,10 @@ template <bool EXPLICIT_DEPTH>
 __global__ __launch_bounds__(256) void df_geometry_kernel(
     DfFrame fr, int n, const double* __restrict__ px, const double* __restrict__ f, const int32_t* __restrict__ level,
     const float* __restrict__ smu, const float* __restrict__ ssigma2, const double* __restrict__ dep,
-    double* __restrict__ epi_len_out, SeedRec* __restrict__ recs) {
+    double* __restrict__ epi_len_out, SeedRec* __restrict__ recs, const uint8_t* __restrict__ alive = nullptr,
+    int* __restrict__ ev_hist = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ev_hist && i < 8) ev_hist[i] = 0;                   // status histogram of the pass (filled by the finalize stage)
   if (i >= n) return;
   const Cam cam = fr.cam;
   SeedRec rc;
@@ -303,6 +305,7 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
   const double px_ref[2] = {px[2 * (size_t)i], px[2 * (size_t)i + 1]};
   const int level_ref = level[i];
   bool live = true;
+  if (alive && !alive[i]) { rc.status = SVO_HIP_SEED_ERASED; live = false; }     // erased from the list (seed batches)
   double d_estimate, d_min, d_max;
   if (EXPLICIT_DEPTH) {
     d_estimate = dep[i]; d_min = dep[(size_t)n + i]; d_max = dep[2 * (size_t)n + i];
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
     const double pf[3] = {inv_mu * fi[0], inv_mu * fi[1], inv_mu * fi[2]};
     double xyz_f[3];
     se3_act(fr.T_cur_ref_vis, pf, xyz_f);
-    if (xyz_f[2] < 0.0) { rc.status = SVO_HIP_SEED_BEHIND; live = false; }
+    if (live && xyz_f[2] < 0.0) { rc.status = SVO_HIP_SEED_BEHIND; live = false; }
     if (live) {
       double pc[2];
       world2cam(cam, xyz_f, pc);
@@ -396,7 +399,10 @@ constexpr int WIN_PITCH = 32;
 constexpr int WIN_ROWS = 32;
 constexpr int WIN_BYTES = WIN_ROWS * WIN_PITCH;
 
-// lane cl (0..15) of a seed copies rows cl and cl + 16 of the h x WIN_PITCH box whose top-left byte is `src`
+// lane cl (0..15) of a seed copies rows cl and cl + 16 of the h x WIN_PITCH box whose top-left byte is `src`.
+// (Round 4 tried two lanes per row -- neighbouring lanes reading the two 16-byte halves of one row, four passes of eight
+// rows, so that the address unit sees half as many cache lines per load: the kernel ran 23 % (100 k seeds) and 43 % (1 M
+// seeds) SLOWER, same-box A/B; four conditional single-load blocks instead of two double-load ones.  Kept as it was.)
 SVO_DEV void win_fill(const uint8_t* __restrict__ src, int pitch, int h, int cl, uint8_t* win) {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -800,66 +806,89 @@ __global__ __launch_bounds__(ALIGN_BLOCK) void df_align_kernel(DfFrame fr, const
   }
 }
 
+// EVENTS (device-resident seed batches, svo_hip_seed_batch_*): the kernel also counts, per block, the seeds whose outcome
+// the HOST has to hear about -- converged and NaN seeds (callback / erase, depth_filter.cpp:310-337) and, on keyframes
+// (report_updated), every updated seed (its px_cur marks the detector grid, :302-306) -- clears their `alive` flag where
+// the reference erases them, and adds the block's status histogram to ev_hist[8] (slot status + 1; slot 0 = erased).
+template <bool EVENTS>
 __global__ __launch_bounds__(256) void df_finalize_kernel(
     DfFrame fr, int n, const double* __restrict__ f, const SeedRec* __restrict__ recs, float* __restrict__ sa,
     float* __restrict__ sb, float* __restrict__ smu, const float* __restrict__ sz_range, float* __restrict__ ssigma2,
     int32_t* __restrict__ status, double* __restrict__ z_out, double* __restrict__ xyz_world,
     int32_t* __restrict__ n_zmssd_out, int32_t* __restrict__ n_align_out, double* __restrict__ px_cur_out,
-    int32_t* __restrict__ search_level_out) {
+    int32_t* __restrict__ search_level_out, uint8_t* __restrict__ alive = nullptr, int report_updated = 0,
+    int* __restrict__ ev_block_count = nullptr, int* __restrict__ ev_hist = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const SeedRec rc = recs[i];
-  int st = rc.status;
-  double z = 0.0;
-  if (rc.path >= 0) {
-    const double fi[3] = {f[3 * (size_t)i], f[3 * (size_t)i + 1], f[3 * (size_t)i + 2]};
-    SeedState seed = {sa[i], sb[i], smu[i], sz_range[i], ssigma2[i]};
-    bool matched = false;
-    if (rc.matched) {
-      double fc[3];
-      cam2world(fr.cam, rc.step[0], rc.step[1], fc);
-      matched = depth_from_triangulation(fr.T_cur_ref, fi, fc, &z);
-    }
-    if (!matched) {
-      seed.b += 1.0f;                                   // depth_filter.cpp:286
-      st = SVO_HIP_SEED_NO_MATCH;
-      z = 0.0;
-    } else {
-      // ---- computeTau + updateSeed + convergence (depth_filter.cpp:294-337)
-      const double tau = compute_tau(fr.T_ref_cur, fi, z, fr.px_error_angle);
-      const double zmt = z - tau;
-      const double tau_inverse = 0.5 * (1.0 / (0.0000001 < zmt ? zmt : 0.0000001) - 1.0 / (z + tau));
-      update_seed((float)(1. / z), (float)(tau_inverse * tau_inverse), &seed);
-      if ((double)sqrtf(seed.sigma2) < seed.z_range / fr.conv_thresh) {
-        st = SVO_HIP_SEED_CONVERGED;
-        if (xyz_world) {
-          const double im = 1.0 / seed.mu;
-          const double pfw[3] = {fi[0] * im, fi[1] * im, fi[2] * im};
-          double xw[3];
-          se3_act(fr.T_ref_inv, pfw, xw);
-          xyz_world[3 * (size_t)i] = xw[0]; xyz_world[3 * (size_t)i + 1] = xw[1]; xyz_world[3 * (size_t)i + 2] = xw[2];
-        }
-      } else if (rc.z_inv_min != rc.z_inv_min) {
-        st = SVO_HIP_SEED_NAN;
-      } else {
-        st = SVO_HIP_SEED_UPDATED;
+  int st = SVO_HIP_SEED_ERASED;
+  if (i < n) {
+    const SeedRec rc = recs[i];
+    st = rc.status;
+    double z = 0.0;
+    if (rc.path >= 0) {
+      const double fi[3] = {f[3 * (size_t)i], f[3 * (size_t)i + 1], f[3 * (size_t)i + 2]};
+      SeedState seed = {sa[i], sb[i], smu[i], sz_range[i], ssigma2[i]};
+      bool matched = false;
+      if (rc.matched) {
+        double fc[3];
+        cam2world(fr.cam, rc.step[0], rc.step[1], fc);
+        matched = depth_from_triangulation(fr.T_cur_ref, fi, fc, &z);
       }
+      if (!matched) {
+        seed.b += 1.0f;                                   // depth_filter.cpp:286
+        st = SVO_HIP_SEED_NO_MATCH;
+        z = 0.0;
+      } else {
+        // ---- computeTau + updateSeed + convergence (depth_filter.cpp:294-337)
+        const double tau = compute_tau(fr.T_ref_cur, fi, z, fr.px_error_angle);
+        const double zmt = z - tau;
+        const double tau_inverse = 0.5 * (1.0 / (0.0000001 < zmt ? zmt : 0.0000001) - 1.0 / (z + tau));
+        update_seed((float)(1. / z), (float)(tau_inverse * tau_inverse), &seed);
+        if ((double)sqrtf(seed.sigma2) < seed.z_range / fr.conv_thresh) {
+          st = SVO_HIP_SEED_CONVERGED;
+          if (xyz_world) {
+            const double im = 1.0 / seed.mu;
+            const double pfw[3] = {fi[0] * im, fi[1] * im, fi[2] * im};
+            double xw[3];
+            se3_act(fr.T_ref_inv, pfw, xw);
+            xyz_world[3 * (size_t)i] = xw[0]; xyz_world[3 * (size_t)i + 1] = xw[1]; xyz_world[3 * (size_t)i + 2] = xw[2];
+          }
+        } else if (rc.z_inv_min != rc.z_inv_min) {
+          st = SVO_HIP_SEED_NAN;
+        } else {
+          st = SVO_HIP_SEED_UPDATED;
+        }
+      }
+      sa[i] = seed.a; sb[i] = seed.b; smu[i] = seed.mu; ssigma2[i] = seed.sigma2;
     }
-    sa[i] = seed.a; sb[i] = seed.b; smu[i] = seed.mu; ssigma2[i] = seed.sigma2;
+    status[i] = st;
+    if (z_out) z_out[i] = z;
+    if (n_zmssd_out) n_zmssd_out[i] = rc.n_zmssd;
+    if (n_align_out) n_align_out[i] = rc.n_align;
+    // Matcher::px_cur_ / search_level_ of this seed's findEpipolarMatchDirect call (matcher.cpp:345-346): what
+    // DepthFilter::updateSeeds hands to feature_detector_->setGridOccpuancy on keyframes (depth_filter.cpp:302-306)
+    if (px_cur_out) {
+      const bool updated = st >= SVO_HIP_SEED_UPDATED;
+      const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+      px_cur_out[2 * (size_t)i] = updated ? rc.step[0] : qnan;
+      px_cur_out[2 * (size_t)i + 1] = updated ? rc.step[1] : qnan;
+    }
+    if (search_level_out) search_level_out[i] = rc.path >= 0 ? rc.search_level : -1;
   }
-  status[i] = st;
-  if (z_out) z_out[i] = z;
-  if (n_zmssd_out) n_zmssd_out[i] = rc.n_zmssd;
-  if (n_align_out) n_align_out[i] = rc.n_align;
-  // Matcher::px_cur_ / search_level_ of this seed's findEpipolarMatchDirect call (matcher.cpp:345-346): what
-  // DepthFilter::updateSeeds hands to feature_detector_->setGridOccpuancy on keyframes (depth_filter.cpp:302-306)
-  if (px_cur_out) {
-    const bool updated = st >= SVO_HIP_SEED_UPDATED;
-    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-    px_cur_out[2 * (size_t)i] = updated ? rc.step[0] : qnan;
-    px_cur_out[2 * (size_t)i + 1] = updated ? rc.step[1] : qnan;
+  if (EVENTS) {
+    const bool gone = st == SVO_HIP_SEED_CONVERGED || st == SVO_HIP_SEED_NAN;      // the reference erases these (:330, :336)
+    const bool ev = gone || (report_updated && st >= SVO_HIP_SEED_UPDATED);
+    if (gone) alive[i] = 0;
+    __shared__ int s_ev[4];
+    __shared__ int s_hist[8];
+    if (threadIdx.x < 8) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long m = __ballot(ev);
+    if ((threadIdx.x & 63) == 0) s_ev[threadIdx.x >> 6] = __popcll(m);
+    if (i < n) atomicAdd(&s_hist[st + 1], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) ev_block_count[blockIdx.x] = s_ev[0] + s_ev[1] + s_ev[2] + s_ev[3];
+    if (threadIdx.x < 8 && s_hist[threadIdx.x]) atomicAdd(&ev_hist[threadIdx.x], s_hist[threadIdx.x]);
   }
-  if (search_level_out) search_level_out[i] = rc.path >= 0 ? rc.search_level : -1;
 }
 
 // Matcher::findEpipolarMatchDirect called directly (explicit depth interval): the tail of the function,
@@ -926,6 +955,14 @@ __global__ void md_finalize_kernel(int n, const SeedRec* __restrict__ recs, doub
   }
   success[i] = rc.path >= 0 && rc.matched;
   if (search_level) search_level[i] = rc.search_level;
+}
+
+// the alignment stage over records [0, n)
+template <bool ONE_D>
+void launch_df_align(svo_hip_ctx* ctx, const DfFrame& fr, const uint8_t* cur_img, int n, int n_pad, const uint32_t* pwb_t, SeedRec* recs,
+                     const int* n_dev = nullptr) {
+  hipLaunchKernelGGL(df_align_kernel<ONE_D>, dim3((n + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr, cur_img, n,
+                     n_pad, pwb_t, recs, n_dev);
 }
 
 int grid_for(int n, int block) {
@@ -1187,13 +1224,23 @@ static int df_scratch(svo_hip_ctx* ctx, int n, SeedRec** recs, uint32_t** pwb_t,
   return SVO_HIP_OK;
 }
 
-int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,
-                                    const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
-                                    const double T_ref_w[7], const double T_cur_w[7], int n, const double* px,
-                                    const double* f, const int32_t* level, float* a, float* b, float* mu,
-                                    const float* z_range, float* sigma2, const svo_hip_df_params* prm,
-                                    int32_t* status, double* z, double* xyz_world, int32_t* n_zmssd,
-                                    int32_t* n_align_iters, double* px_cur, int32_t* search_level) {
+}  // extern "C"
+
+// events of a device-resident seed batch (see svo_hip_seed_batch_* below): where the finalize stage leaves its counts
+struct DfEvents {
+  uint8_t* alive = nullptr;          // [n] in/out: 0 = erased from the list; cleared for seeds that converge / turn NaN
+  int report_updated = 0;
+  int* block_count = nullptr;        // [(n + 255) / 256]
+  int* hist = nullptr;               // [8]
+};
+
+// One DepthFilter::updateSeeds pass over n seeds in device SoA arrays: geometry -> search -> align -> finalize on the
+// context stream (shared by svo_hip_depth_filter_update_dev and the seed batches).
+static int df_run_pass(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot, const svo_hip_pyramid* cur, int cur_slot,
+                       const svo_hip_camera* cam, const double T_ref_w[7], const double T_cur_w[7], int n, const double* px,
+                       const double* f, const int32_t* level, float* a, float* b, float* mu, const float* z_range, float* sigma2,
+                       const svo_hip_df_params* prm, int32_t* status, double* z, double* xyz_world, int32_t* n_zmssd,
+                       int32_t* n_align_iters, double* px_cur, int32_t* search_level, const DfEvents* ev) {
   if (!ctx || !ref || !cur || !cam || !T_ref_w || !T_cur_w || !prm) return SVO_HIP_ERR_INVALID;
   SVO_REQUIRE(ctx, ref_slot >= 0 && ref_slot < ref->batch && cur_slot >= 0 && cur_slot < cur->batch);
   SVO_REQUIRE(ctx, ref->width == cam->width && ref->height == cam->height);
@@ -1215,17 +1262,67 @@ int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref
   }
   const uint8_t* ref_img = ref->base + (size_t)ref_slot * ref->pyr_bytes;
   const uint8_t* cur_img = cur->base + (size_t)cur_slot * cur->pyr_bytes;
+  const bool prof = ctx->df_profile;                     // diagnostic: events between the stages (svo_hip_df_set_profiling)
+  auto stamp = [&](int k) { if (prof) (void)hipEventRecord(ctx->df_ev[k], ctx->stream); };
+  stamp(0);
   hipLaunchKernelGGL(df_geometry_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, px, f, level, mu, sigma2,
-                     (const double*)nullptr, (double*)nullptr, recs);
+                     (const double*)nullptr, (double*)nullptr, recs, ev ? (const uint8_t*)ev->alive : (const uint8_t*)nullptr,
+                     ev ? ev->hist : (int*)nullptr);
   SVO_CHECK_HIP(ctx, hipGetLastError());
+  stamp(1);
   hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref_img, (size_t)0, cur_img, n, level, recs, pwb_t, n_pad);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(df_align_kernel<false>, dim3((n + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr, cur_img, n, n_pad, pwb_t, recs);
+  stamp(2);
+  launch_df_align<false>(ctx, fr, cur_img, n, n_pad, pwb_t, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(df_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, f, recs, a, b, mu, z_range,
-                     sigma2, status, z, xyz_world, n_zmssd, n_align_iters, px_cur, search_level);
+  stamp(3);
+  struct Last { const bool on; svo_hip_ctx* c; ~Last() { if (on) { (void)hipEventRecord(c->df_ev[4], c->stream); c->df_ev_recorded = true; } } } last{prof, ctx};
+  if (ev) {
+    hipLaunchKernelGGL(df_finalize_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, f, recs, a, b, mu, z_range,
+                       sigma2, status, z, xyz_world, n_zmssd, n_align_iters, px_cur, search_level, ev->alive, ev->report_updated,
+                       ev->block_count, ev->hist);
+  } else {
+    hipLaunchKernelGGL(df_finalize_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, f, recs, a, b, mu, z_range,
+                       sigma2, status, z, xyz_world, n_zmssd, n_align_iters, px_cur, search_level);
+  }
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
+}
+
+extern "C" {
+
+// Diagnostic: time the four stages of every following depth-filter pass of this context with HIP events on its stream
+// (geometry, search, align, finalize); svo_hip_df_get_profile waits for the last pass and returns their durations.
+int svo_hip_df_set_profiling(svo_hip_ctx* ctx, int enable) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  if (enable) for (hipEvent_t& e : ctx->df_ev) if (!e) SVO_CHECK_HIP(ctx, hipEventCreate(&e));
+  ctx->df_profile = enable != 0;
+  ctx->df_ev_recorded = false;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_df_get_profile(svo_hip_ctx* ctx, double stage_us[4]) {
+  if (!ctx || !stage_us) return SVO_HIP_ERR_INVALID;
+  if (!ctx->df_ev_recorded) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_df_get_profile", "no profiled pass yet");
+  SVO_CHECK_HIP(ctx, hipEventSynchronize(ctx->df_ev[4]));
+  for (int k = 0; k < 4; ++k) {
+    float ms = 0.0f;
+    SVO_CHECK_HIP(ctx, hipEventElapsedTime(&ms, ctx->df_ev[k], ctx->df_ev[k + 1]));
+    stage_us[k] = 1e3 * (double)ms;
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_depth_filter_update_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,
+                                    const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                                    const double T_ref_w[7], const double T_cur_w[7], int n, const double* px,
+                                    const double* f, const int32_t* level, float* a, float* b, float* mu,
+                                    const float* z_range, float* sigma2, const svo_hip_df_params* prm,
+                                    int32_t* status, double* z, double* xyz_world, int32_t* n_zmssd,
+                                    int32_t* n_align_iters, double* px_cur, int32_t* search_level) {
+  return df_run_pass(ctx, ref, ref_slot, cur, cur_slot, cam, T_ref_w, T_cur_w, n, px, f, level, a, b, mu, z_range, sigma2, prm, status, z,
+                     xyz_world, n_zmssd, n_align_iters, px_cur, search_level, nullptr);
 }
 
 int svo_hip_epipolar_match_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,
@@ -1261,7 +1358,7 @@ int svo_hip_epipolar_match_batch_dev(svo_hip_ctx* ctx, const svo_hip_pyramid* re
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref_img, (size_t)0, cur_img, n, level, recs, pwb_t, n_pad);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(df_align_kernel<false>, dim3((n + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr, cur_img, n, n_pad, pwb_t, recs);
+  launch_df_align<false>(ctx, fr, cur_img, n, n_pad, pwb_t, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(epi_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fr, n, f, recs, ok, depth, px_cur,
                      search_level, n_zmssd, n_align_iters);
@@ -1292,12 +1389,10 @@ int svo_match_stages(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip
   hipLaunchKernelGGL(df_search_kernel, dim3((n_cap + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref->base, ref->pyr_bytes,
                      cur_img, n_cap, level_ref_dev, recs, pwb_t, n_pad, n_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(df_align_kernel<false>, dim3((n_cap + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr, cur_img, n_cap, n_pad,
-                     pwb_t, recs, n_dev);
+  launch_df_align<false>(ctx, fr, cur_img, n_cap, n_pad, pwb_t, recs, n_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   if (edgelets) {
-    hipLaunchKernelGGL(df_align_kernel<true>, dim3((n_cap + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr, cur_img, n_cap,
-                       n_pad, pwb_t, recs, n_dev);
+    launch_df_align<true>(ctx, fr, cur_img, n_cap, n_pad, pwb_t, recs, n_dev);
     SVO_CHECK_HIP(ctx, hipGetLastError());
   }
   return SVO_HIP_OK;
@@ -1345,12 +1440,10 @@ int svo_match_direct_internal(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, cons
   hipLaunchKernelGGL(df_search_kernel, dim3((n + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref->base, ref->pyr_bytes,
                      cur->base + (size_t)cur_slot * cur->pyr_bytes, n, level_ref_dev, recs, pwb_t, n_pad);
   SVO_CHECK_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(df_align_kernel<false>, dim3((n + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr,
-                     cur->base + (size_t)cur_slot * cur->pyr_bytes, n, n_pad, pwb_t, recs);
+  launch_df_align<false>(ctx, fr, cur->base + (size_t)cur_slot * cur->pyr_bytes, n, n_pad, pwb_t, recs);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   if (edgelet_dev) {
-    hipLaunchKernelGGL(df_align_kernel<true>, dim3((n + ALIGN_PATCHES - 1) / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr,
-                       cur->base + (size_t)cur_slot * cur->pyr_bytes, n, n_pad, pwb_t, recs);
+    launch_df_align<true>(ctx, fr, cur->base + (size_t)cur_slot * cur->pyr_bytes, n, n_pad, pwb_t, recs);
     SVO_CHECK_HIP(ctx, hipGetLastError());
   }
   hipLaunchKernelGGL(md_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, recs, px_cur_dev, success_dev,
@@ -1565,6 +1658,258 @@ int svo_hip_reproject_cells(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const 
   }
   *n_matches_out = n_matches;
   *n_trials_out = n_trials;
+  return SVO_HIP_OK;
+}
+
+}  // extern "C"
+
+// ---- device-resident seed batches (include/svo_hip.h: svo_hip_seed_batch_*) -----------------------------------------
+namespace {
+
+struct EvHeader { int32_t n_events; int32_t counts[7]; };
+
+// exclusive scan of the per-block event counts (one workgroup) + the header of the page-locked event block
+__global__ __launch_bounds__(1024) void ev_scan_kernel(int n_blocks, int* __restrict__ block_count, const int* __restrict__ hist,
+                                                       EvHeader* __restrict__ header /* host memory */, int* __restrict__ n_events_dev) {
+  __shared__ int s_part[1024];
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n_blocks; base += 1024) {
+    const int k = base + threadIdx.x;
+    const int v = k < n_blocks ? block_count[k] : 0;
+    int incl = v;                                              // wave-level inclusive scan, then the 16 wave totals
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += t; }
+    if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += s_part[w];
+    const int carry = s_carry;
+    if (k < n_blocks) block_count[k] = carry + wave_off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { header->n_events = s_carry; *n_events_dev = s_carry; }
+  if (threadIdx.x < 7) header->counts[threadIdx.x] = hist[threadIdx.x];
+}
+
+// The events, ascending seed index (56 B records).  A handful of them -- every frame but a keyframe's -- goes straight into
+// the page-locked host block (no copy, no second wait); more than EV_DIRECT_MAX are packed in device memory and fetched
+// with one transfer after the wait (scattered 56-byte stores over the link run at a few GB/s: 100 k events took 1.4 ms).
+constexpr int EV_DIRECT_MAX = 512;
+__global__ __launch_bounds__(256) void ev_scatter_kernel(int n, int report_updated, const int32_t* __restrict__ status,
+                                                         const float* __restrict__ mu, const float* __restrict__ sigma2,
+                                                         const double* __restrict__ xyz, const double* __restrict__ px_cur,
+                                                         const int* __restrict__ block_offset, const int* __restrict__ n_events_dev,
+                                                         svo_hip_seed_event* __restrict__ events_host,
+                                                         svo_hip_seed_event* __restrict__ events_dev) {
+  svo_hip_seed_event* events = *n_events_dev <= EV_DIRECT_MAX ? events_host : events_dev;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int st = i < n ? status[i] : SVO_HIP_SEED_ERASED;
+  const bool ev = st == SVO_HIP_SEED_CONVERGED || st == SVO_HIP_SEED_NAN || (report_updated && st >= SVO_HIP_SEED_UPDATED);
+  const unsigned long long m = __ballot(ev);
+  __shared__ int s_w[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_w[wave] = __popcll(m);
+  __syncthreads();
+  if (!ev) return;
+  int off = block_offset[blockIdx.x];
+  for (int w = 0; w < wave; ++w) off += s_w[w];
+  off += __popcll(m & ((1ull << lane) - 1ull));
+  svo_hip_seed_event e;
+  e.index = i; e.status = st; e.mu = mu[i]; e.sigma2 = sigma2[i];
+  const bool conv = st == SVO_HIP_SEED_CONVERGED;
+  e.xyz_world[0] = conv ? xyz[3 * (size_t)i] : 0.0; e.xyz_world[1] = conv ? xyz[3 * (size_t)i + 1] : 0.0; e.xyz_world[2] = conv ? xyz[3 * (size_t)i + 2] : 0.0;
+  e.px_cur[0] = px_cur[2 * (size_t)i]; e.px_cur[1] = px_cur[2 * (size_t)i + 1];
+  events[off] = e;
+}
+
+}  // namespace
+
+struct svo_hip_seed_batch {
+  svo_hip_ctx* ctx = nullptr;
+  int n = 0, n_alive = 0, n_blocks = 0;
+  char* dev = nullptr;                  // one allocation: the arrays below
+  double *px = nullptr, *f = nullptr, *xyz = nullptr, *px_cur = nullptr;
+  int32_t *level = nullptr, *status = nullptr;
+  float *a = nullptr, *b = nullptr, *mu = nullptr, *z_range = nullptr, *sigma2 = nullptr;
+  uint8_t* alive = nullptr;
+  int *block_count = nullptr, *hist = nullptr;
+  svo_hip_seed_event* events_dev = nullptr;    // where the pass packs its events when there are many
+  char* host = nullptr;                 // page-locked, mapped: EvHeader + n events, written by the kernels
+  char* host_dev = nullptr;             // its device address
+  bool pending = false;                 // a pass is enqueued and not collected yet
+  int report_updated = 0;
+};
+
+static size_t sb_align(size_t v) { return (v + 255) & ~(size_t)255; }
+static constexpr size_t kEvHeaderBytes = 64;
+static_assert(sizeof(svo_hip_seed_event) == 56, "event record layout (include/svo_hip.h)");
+
+extern "C" {
+
+int svo_hip_seed_batch_create(svo_hip_ctx* ctx, int n, const double* px, const double* f, const int32_t* level, const float* a,
+                              const float* b, const float* mu, const float* z_range, const float* sigma2, svo_hip_seed_batch** out) {
+  if (!ctx || !out) return SVO_HIP_ERR_INVALID;
+  *out = nullptr;
+  SVO_REQUIRE(ctx, n > 0 && px && f && level && a && b && mu && z_range && sigma2);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  svo_hip_seed_batch* sb = new (std::nothrow) svo_hip_seed_batch;
+  if (!sb) return svo_fail(ctx, SVO_HIP_ERR_NOMEM, "svo_hip_seed_batch_create", "out of host memory");
+  sb->ctx = ctx; sb->n = n; sb->n_alive = n; sb->n_blocks = (n + 255) / 256;
+  const size_t N = (size_t)n;
+  // layout: uploaded part first (px f level a b mu z_range sigma2), then outputs and bookkeeping
+  size_t o = 0;
+  const size_t o_px = o; o = sb_align(o + 16 * N);
+  const size_t o_f = o; o = sb_align(o + 24 * N);
+  const size_t o_lvl = o; o = sb_align(o + 4 * N);
+  const size_t o_a = o; o = sb_align(o + 4 * N);
+  const size_t o_b = o; o = sb_align(o + 4 * N);
+  const size_t o_mu = o; o = sb_align(o + 4 * N);
+  const size_t o_zr = o; o = sb_align(o + 4 * N);
+  const size_t o_s2 = o; o = sb_align(o + 4 * N);
+  const size_t upload_bytes = o;
+  const size_t o_xyz = o; o = sb_align(o + 24 * N);
+  const size_t o_pc = o; o = sb_align(o + 16 * N);
+  const size_t o_st = o; o = sb_align(o + 4 * N);
+  const size_t o_al = o; o = sb_align(o + N);
+  const size_t o_bc = o; o = sb_align(o + 4 * (size_t)sb->n_blocks);
+  const size_t o_h = o; o = sb_align(o + 64);
+  const size_t o_ev = o; o = sb_align(o + N * sizeof(svo_hip_seed_event));
+  int rc = SVO_HIP_OK;
+  if (hipMalloc((void**)&sb->dev, o) != hipSuccess) rc = svo_fail(ctx, SVO_HIP_ERR_NOMEM, "svo_hip_seed_batch_create", "hipMalloc failed");
+  const size_t host_bytes = kEvHeaderBytes + N * sizeof(svo_hip_seed_event);
+  if (rc == SVO_HIP_OK && hipHostMalloc((void**)&sb->host, host_bytes, hipHostMallocMapped) != hipSuccess)
+    rc = svo_fail(ctx, SVO_HIP_ERR_NOMEM, "svo_hip_seed_batch_create", "hipHostMalloc failed");
+  if (rc == SVO_HIP_OK && hipHostGetDevicePointer((void**)&sb->host_dev, sb->host, 0) != hipSuccess)
+    rc = svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_seed_batch_create", "hipHostGetDevicePointer failed");
+  if (rc == SVO_HIP_OK) {
+    char* d = sb->dev;
+    sb->px = (double*)(d + o_px); sb->f = (double*)(d + o_f); sb->level = (int32_t*)(d + o_lvl);
+    sb->a = (float*)(d + o_a); sb->b = (float*)(d + o_b); sb->mu = (float*)(d + o_mu); sb->z_range = (float*)(d + o_zr);
+    sb->sigma2 = (float*)(d + o_s2); sb->xyz = (double*)(d + o_xyz); sb->px_cur = (double*)(d + o_pc);
+    sb->status = (int32_t*)(d + o_st); sb->alive = (uint8_t*)(d + o_al); sb->block_count = (int*)(d + o_bc); sb->hist = (int*)(d + o_h);
+    sb->events_dev = (svo_hip_seed_event*)(d + o_ev);
+    memset(sb->host, 0, kEvHeaderBytes);
+    // the uploaded arrays gathered in the context's page-locked staging area: one transfer
+    char* hs = nullptr;
+    rc = svo_ctx_host_staging(ctx, upload_bytes, &hs);
+    if (rc == SVO_HIP_OK) {
+      memcpy(hs + o_px, px, 16 * N); memcpy(hs + o_f, f, 24 * N); memcpy(hs + o_lvl, level, 4 * N); memcpy(hs + o_a, a, 4 * N);
+      memcpy(hs + o_b, b, 4 * N); memcpy(hs + o_mu, mu, 4 * N); memcpy(hs + o_zr, z_range, 4 * N); memcpy(hs + o_s2, sigma2, 4 * N);
+      hipError_t e = hipMemcpyAsync(d, hs, upload_bytes, hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipMemsetAsync(sb->alive, 1, N, ctx->stream);
+      if (e == hipSuccess) e = hipMemsetAsync(sb->status, 0xff, 4 * N, ctx->stream);       // SVO_HIP_SEED_ERASED until the first pass
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);                          // the staging area is free again
+      if (e != hipSuccess) rc = svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_seed_batch_create", hipGetErrorString(e));
+    }
+  }
+  if (rc != SVO_HIP_OK) { svo_hip_seed_batch_destroy(sb); return rc; }
+  *out = sb;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_seed_batch_destroy(svo_hip_seed_batch* sb) {
+  if (!sb) return SVO_HIP_OK;
+  if (sb->ctx) { (void)hipSetDevice(sb->ctx->device); if (sb->pending) (void)hipStreamSynchronize(sb->ctx->stream); }
+  if (sb->dev) (void)hipFree(sb->dev);
+  if (sb->host) (void)hipHostFree(sb->host);
+  delete sb;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_seed_batch_size(const svo_hip_seed_batch* sb, int* n, int* n_alive) {
+  if (!sb) return SVO_HIP_ERR_INVALID;
+  if (n) *n = sb->n;
+  if (n_alive) *n_alive = sb->n_alive;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_seed_batch_update_async(svo_hip_seed_batch* sb, const svo_hip_pyramid* ref, int ref_slot, const svo_hip_pyramid* cur,
+                                    int cur_slot, const svo_hip_camera* cam, const double T_ref_w[7], const double T_cur_w[7],
+                                    const svo_hip_df_params* prm, int report_updated) {
+  if (!sb) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = sb->ctx;
+  if (sb->pending) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_seed_batch_update_async", "the previous pass has not been collected");
+  DfEvents ev;
+  ev.alive = sb->alive; ev.report_updated = report_updated ? 1 : 0; ev.block_count = sb->block_count; ev.hist = sb->hist;
+  const int rc = df_run_pass(ctx, ref, ref_slot, cur, cur_slot, cam, T_ref_w, T_cur_w, sb->n, sb->px, sb->f, sb->level, sb->a, sb->b, sb->mu,
+                             sb->z_range, sb->sigma2, prm, sb->status, nullptr, sb->xyz, nullptr, nullptr, sb->px_cur, nullptr, &ev);
+  if (rc != SVO_HIP_OK) return rc;
+  hipLaunchKernelGGL(ev_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, sb->n_blocks, sb->block_count, sb->hist,
+                     reinterpret_cast<EvHeader*>(sb->host_dev), sb->hist + 8);
+  hipLaunchKernelGGL(ev_scatter_kernel, dim3(sb->n_blocks), dim3(256), 0, ctx->stream, sb->n, ev.report_updated, sb->status, sb->mu,
+                     sb->sigma2, sb->xyz, sb->px_cur, sb->block_count, sb->hist + 8,
+                     reinterpret_cast<svo_hip_seed_event*>(sb->host_dev + kEvHeaderBytes), sb->events_dev);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  sb->pending = true;
+  sb->report_updated = ev.report_updated;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_seed_batch_collect(svo_hip_seed_batch* sb, const svo_hip_seed_event** events, int* n_events, int32_t status_counts[7]) {
+  if (!sb) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = sb->ctx;
+  if (!sb->pending) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_seed_batch_collect", "no pass has been enqueued");
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  sb->pending = false;
+  const EvHeader* h = reinterpret_cast<const EvHeader*>(sb->host);
+  if (h->n_events > EV_DIRECT_MAX) {                      // many events (a keyframe): packed on the device, one transfer
+    SVO_CHECK_HIP(ctx, hipMemcpyAsync(sb->host + kEvHeaderBytes, sb->events_dev, (size_t)h->n_events * sizeof(svo_hip_seed_event),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (events) *events = reinterpret_cast<const svo_hip_seed_event*>(sb->host + kEvHeaderBytes);
+  if (n_events) *n_events = h->n_events;
+  if (status_counts) for (int k = 0; k < 7; ++k) status_counts[k] = h->counts[k];
+  sb->n_alive -= h->counts[SVO_HIP_SEED_CONVERGED + 1] + h->counts[SVO_HIP_SEED_NAN + 1];
+  return SVO_HIP_OK;
+}
+
+int svo_hip_seed_batch_erase(svo_hip_seed_batch* sb, int n, const int32_t* indices) {
+  if (!sb) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = sb->ctx;
+  SVO_REQUIRE(ctx, n >= 0 && (n == 0 || indices));
+  if (sb->pending) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_seed_batch_erase", "collect the enqueued pass first");
+  if (n == 0) return SVO_HIP_OK;
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  // the alive flags come down, are edited and go back: erasures are rare (removeKeyframe) and this keeps n_alive exact
+  std::vector<uint8_t> al((size_t)sb->n);
+  SVO_CHECK_HIP(ctx, hipMemcpyAsync(al.data(), sb->alive, (size_t)sb->n, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < n; ++k) {
+    SVO_REQUIRE(ctx, indices[k] >= 0 && indices[k] < sb->n);
+    if (al[(size_t)indices[k]]) { al[(size_t)indices[k]] = 0; --sb->n_alive; }
+  }
+  SVO_CHECK_HIP(ctx, hipMemcpyAsync(sb->alive, al.data(), (size_t)sb->n, hipMemcpyHostToDevice, ctx->stream));
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_seed_batch_download(svo_hip_seed_batch* sb, float* a, float* b, float* mu, float* sigma2, uint8_t* alive) {
+  if (!sb) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = sb->ctx;
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t N = (size_t)sb->n;
+  if (a) SVO_CHECK_HIP(ctx, hipMemcpyAsync(a, sb->a, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+  if (b) SVO_CHECK_HIP(ctx, hipMemcpyAsync(b, sb->b, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+  if (mu) SVO_CHECK_HIP(ctx, hipMemcpyAsync(mu, sb->mu, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+  if (sigma2) SVO_CHECK_HIP(ctx, hipMemcpyAsync(sigma2, sb->sigma2, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+  if (alive) SVO_CHECK_HIP(ctx, hipMemcpyAsync(alive, sb->alive, N, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_seed_batch_arrays(svo_hip_seed_batch* sb, float** a_dev, float** b_dev, float** mu_dev, float** sigma2_dev, int32_t** status_dev) {
+  if (!sb) return SVO_HIP_ERR_INVALID;
+  if (a_dev) *a_dev = sb->a;
+  if (b_dev) *b_dev = sb->b;
+  if (mu_dev) *mu_dev = sb->mu;
+  if (sigma2_dev) *sigma2_dev = sb->sigma2;
+  if (status_dev) *status_dev = sb->status;
   return SVO_HIP_OK;
 }
 

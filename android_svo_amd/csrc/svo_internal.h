@@ -20,6 +20,10 @@ struct svo_hip_ctx {
   size_t staging_bytes = 0;
   void* host_staging = nullptr;     // grow-only page-locked host mirror of it: one transfer each way per call
   size_t host_staging_bytes = 0;
+  // stage timing of the depth-filter pass (svo_hip_df_set_profiling): events around geometry / search / align / finalize
+  bool df_profile = false;
+  bool df_ev_recorded = false;
+  hipEvent_t df_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   char err[512] = {0};
 };
 

@@ -511,6 +511,82 @@ class SeedBatch:
             d.free()
 
 
+class CSeedEvent(C.Structure):
+    _fields_ = [("index", C.c_int32), ("status", C.c_int32), ("mu", C.c_float), ("sigma2", C.c_float),
+                ("xyz_world", C.c_double * 3), ("px_cur", C.c_double * 2)]
+
+
+SEED_EVENT_DTYPE = np.dtype([("index", np.int32), ("status", np.int32), ("mu", np.float32), ("sigma2", np.float32),
+                             ("xyz_world", np.float64, (3,)), ("px_cur", np.float64, (2,))])
+SEED_ERASED = -1
+
+
+class ResidentSeeds:
+    """svo_hip_seed_batch: the seeds of one keyframe resident on the device from creation to their end (uploaded once;
+    per frame two poses go down and only the converged / NaN seeds -- on keyframes also the updated ones -- come back)."""
+
+    def __init__(self, ctx: Context, px, f, level, a, b, mu, z_range, sigma2):
+        self.ctx, self.n = ctx, len(px)
+        self.h = C.c_void_p()
+        px, f = _f64(px), _f64(f)
+        lvl = np.ascontiguousarray(level, dtype=np.int32)
+        st = [np.ascontiguousarray(v, dtype=np.float32) for v in (a, b, mu, z_range, sigma2)]
+        ctx.check(ctx.lib.svo_hip_seed_batch_create(ctx.h, self.n, _ptr(px, C.c_double), _ptr(f, C.c_double), _ptr(lvl, C.c_int32),
+                                                    *[_ptr(v, C.c_float) for v in st], C.byref(self.h)), "seed_batch_create")
+
+    def update_async(self, ref: Pyramid, ref_slot: int, cur: Pyramid, cur_slot: int, cam, T_ref_w, T_cur_w, prm=None, report_updated=False):
+        prm = prm or depth_filter_params()
+        c = make_camera(cam)
+        Tr, Tc = _f64(T_ref_w), _f64(T_cur_w)
+        self.ctx.check(self.ctx.lib.svo_hip_seed_batch_update_async(self.h, ref.h, ref_slot, cur.h, cur_slot, C.byref(c), _ptr(Tr, C.c_double),
+                                                                    _ptr(Tc, C.c_double), C.byref(prm), 1 if report_updated else 0),
+                       "seed_batch_update_async")
+
+    def collect(self):
+        """(events as a structured array -- a copy --, status counts [7]: slot = status + 1)"""
+        ev = C.POINTER(CSeedEvent)()
+        n = C.c_int(0)
+        counts = (C.c_int32 * 7)()
+        self.ctx.check(self.ctx.lib.svo_hip_seed_batch_collect(self.h, C.byref(ev), C.byref(n), counts), "seed_batch_collect")
+        if n.value:
+            buf = (C.c_char * (n.value * C.sizeof(CSeedEvent))).from_address(C.addressof(ev.contents))
+            arr = np.frombuffer(buf, dtype=SEED_EVENT_DTYPE).copy()
+        else:
+            arr = np.zeros(0, dtype=SEED_EVENT_DTYPE)
+        return arr, np.array(list(counts), dtype=np.int64)
+
+    def update(self, *args, **kw):
+        self.update_async(*args, **kw)
+        return self.collect()
+
+    def erase(self, indices):
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        self.ctx.check(self.ctx.lib.svo_hip_seed_batch_erase(self.h, len(idx), _ptr(idx, C.c_int32)), "seed_batch_erase")
+
+    def n_alive(self) -> int:
+        n, na = C.c_int(0), C.c_int(0)
+        self.ctx.check(self.ctx.lib.svo_hip_seed_batch_size(self.h, C.byref(n), C.byref(na)), "seed_batch_size")
+        return na.value
+
+    def download(self):
+        out = {k: np.empty(self.n, np.float32) for k in ("a", "b", "mu", "sigma2")}
+        out["alive"] = np.empty(self.n, np.uint8)
+        self.ctx.check(self.ctx.lib.svo_hip_seed_batch_download(self.h, _ptr(out["a"], C.c_float), _ptr(out["b"], C.c_float),
+                                                                _ptr(out["mu"], C.c_float), _ptr(out["sigma2"], C.c_float),
+                                                                _ptr(out["alive"], C.c_uint8)), "seed_batch_download")
+        return out
+
+    def status(self) -> np.ndarray:
+        p = C.c_void_p()
+        self.ctx.check(self.ctx.lib.svo_hip_seed_batch_arrays(self.h, None, None, None, None, C.byref(p)), "seed_batch_arrays")
+        return DeviceView(self.ctx, p.value, (self.n,), np.int32).download()
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.svo_hip_seed_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 class DeviceView:
     """A typed window into somebody else's device allocation (never freed through the view)."""
 

@@ -240,6 +240,7 @@ int main(int argc, char** argv) {
     Case c;
     c.cam = PinholeCamera{(int)m[0], (int)m[1], m[2], m[3], m[4], m[5]};
     c.n_levels = (int)m[6]; c.n_frames = (int)m[7];
+    if (m.size() >= 13) for (int k = 0; k < 5; ++k) c.cam.d[k] = m[8 + (size_t)k];      // radtan coefficients k1 k2 p1 p2 k3
     for (int k = 0; k < c.n_frames; ++k) c.frames.push_back(load_frame(dir, &c.cam, k, c.n_levels));
 
     // ---- SparseImgAlign: frame 0 (with features + points) -> frame 1 starting from frame 0's pose

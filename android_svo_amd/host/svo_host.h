@@ -5,7 +5,7 @@
 // the host side can be built and RUN wherever libsvo_hip.so runs.  The bindings that plug into the
 // reference's real headers are include/svo_dropin/ (compile-checked only); this file is
 // their executable counterpart.  DepthFilter::updateSeeds is NOT a second copy: both sides instantiate
-// hip_bridge::updateSeedsBatched (include/svo_dropin/depth_filter_batch.h) with a small Host policy, so the
+// hip_bridge::DeviceSeedMirror (include/svo_dropin/depth_filter_batch.h) with a small Host policy, so the
 // batching / ordering / halt logic the GPU tests exercise is the code the drop-in ships.  The same holds for the tracking
 // chain: svo::FrameTracker here and in include/svo_dropin/frame_tracker_hip.h are both hip_bridge::FrameTrackerT
 // (frame_tracker_batch.h) -- the flattening of svo::Map's pointer graph into the tracker's index tables and the write-back
@@ -71,14 +71,15 @@ struct SE3 {
   }
 };
 
-struct PinholeCamera {            // distortion-free vk::PinholeCamera
+struct PinholeCamera {            // vk::PinholeCamera: pinhole + optional 5-coefficient radtan distortion (S/pinhole_camera.cpp:19-38)
   int width, height;
   double fx, fy, cx, cy;
+  double d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   svo_hip_camera toC() const {
     svo_hip_camera c;
     c.width = width; c.height = height; c.fx = fx; c.fy = fy; c.cx = cx; c.cy = cy;
-    for (double& d : c.d) d = 0.0;
-    c.distortion = 0;
+    for (int k = 0; k < 5; ++k) c.d[k] = d[k];
+    c.distortion = std::fabs(d[0]) > 0.0000001 ? 1 : 0;       // distortion_(fabs(d0) > 0.0000001), S/pinhole_camera.cpp:26
     return c;
   }
 };
@@ -359,7 +360,7 @@ class DepthFilter {
     kf_pyr_.reset(new hip_bridge::PyramidCache(ctx_, 8));
     cur_pyr_.reset(new hip_bridge::PyramidCache(ctx_, 2));
   }
-  virtual ~DepthFilter() { stopThread(); kf_pyr_.reset(); cur_pyr_.reset(); svo_hip_ctx_destroy(ctx_); }
+  virtual ~DepthFilter() { stopThread(); mirror_.clear(); kf_pyr_.reset(); cur_pyr_.reset(); svo_hip_ctx_destroy(ctx_); }
 
   void startThread() { thread_stop_ = false; thread_ = new std::thread(&DepthFilter::updateSeedsLoop, this); }
   void stopThread() {
@@ -412,9 +413,15 @@ class DepthFilter {
     while (!frame_queue_.empty()) frame_queue_.pop();
     seeds_updating_halt_ = false;
   }
-  std::list<Seed>& getSeeds() { return seeds_; }
+  /// The seeds' state lives on the device between frames (hip_bridge::DeviceSeedMirror): bring it into the list
+  void syncSeeds() {
+    lock_t lock(seeds_mut_);
+    if (!mirror_.syncToHost()) throw std::runtime_error(std::string("seed_batch_download: ") + svo_hip_last_error(ctx_));
+  }
+  std::list<Seed>& getSeeds() { syncSeeds(); return seeds_; }
   void getSeedsCopy(const FramePtr& frame, std::list<Seed>& seeds) {           // :349-357
     lock_t lock(seeds_mut_);
+    if (!mirror_.syncToHost()) throw std::runtime_error(std::string("seed_batch_download: ") + svo_hip_last_error(ctx_));
     for (const Seed& s : seeds_) if (s.ftr->frame == frame.get()) seeds.push_back(s);
   }
   bool idle() {
@@ -460,7 +467,7 @@ class DepthFilter {
     }
   }
 
-  /// Host policy of hip_bridge::updateSeedsBatched on this file's data model
+  /// Host policy of hip_bridge::DeviceSeedMirror on this file's data model
   struct BatchHost {
     DepthFilter* df;
     Frame* keyframeOf(const Seed& s) const { return s.ftr->frame; }
@@ -492,18 +499,20 @@ class DepthFilter {
     if (seeds_.empty()) return;
     svo_hip_df_params prm{3, 10, 1000, options_.seed_convergence_sigma2_thresh};
     BatchHost host{this};
-    last_stats_ = hip_bridge::updateSeedsBatched(host, ctx_, seeds_, *frame, prm, Seed::batch_counter, options_.max_n_kfs,
-                                                 seeds_updating_halt_, sub_batch_);
+    last_stats_ = mirror_.update(host, ctx_, seeds_, *frame, prm, Seed::batch_counter, options_.max_n_kfs, seeds_updating_halt_, sub_batch_);
+    total_uploaded_ += last_stats_.n_uploaded;
     if (last_stats_.n_device_errors) throw std::runtime_error(std::string("depth_filter_update: ") + svo_hip_last_error(ctx_));
   }
 
  public:
-  int sub_batch_ = 4096;                         ///< seeds per device call (the halt flag is polled in between)
+  int sub_batch_ = 4096;                         ///< seeds per device batch (the halt flag is polled in between)
   hip_bridge::SeedBatchStats last_stats_;
+  long total_uploaded_ = 0;                      ///< seeds ever mirrored on the device: every seed exactly once
  protected:
   DetectorGrid* feature_detector_ = nullptr;
   callback_t seed_converged_cb_;
   std::list<Seed> seeds_;
+  hip_bridge::DeviceSeedMirror<std::list<Seed> > mirror_;    // the seeds' device-resident state
   std::mutex seeds_mut_;
   volatile bool seeds_updating_halt_ = false;
   bool thread_stop_ = false;

@@ -137,6 +137,8 @@ class PlaneScene:
         o = T_w_f[:3]
         x = (u - cam.cx) / cam.fx
         y = (v - cam.cy) / cam.fy
+        if getattr(cam, "dist", None) is not None and any(cam.dist):
+            x, y = undistort_normalized(cam.dist, x, y)      # radtan camera: the ray of a DISTORTED pixel
         dirs = np.stack([x, y, np.ones_like(x)], axis=-1) @ R.T
         lam = (self.d - o @ self.n) / (dirs @ self.n)
         return o + dirs * lam[..., None]
@@ -149,6 +151,23 @@ class PlaneScene:
         val = self.texture(s, t)
         img = np.clip(np.rint(127.5 + 110.0 * val), 0, 255).astype(np.uint8)
         return np.ascontiguousarray(img)
+
+
+def undistort_normalized(dist, xd, yd, iters: int = 40):
+    """Inverse of the 5-coefficient radtan model vk::PinholeCamera::world2cam applies (S/pinhole_camera.cpp:88-104; d =
+    k1, k2, p1, p2, k3) on normalised coordinates, by fixed-point iteration in f64 to convergence -- the generator's
+    ground truth for images of a distorted camera (the reference itself inverts with cv::undistortPoints: five float
+    iterations)."""
+    k1, k2, p1, p2, k3 = (float(c) for c in dist)
+    xd, yd = np.asarray(xd, dtype=np.float64), np.asarray(yd, dtype=np.float64)
+    x, y = xd.copy(), yd.copy()
+    for _ in range(iters):
+        r2 = x * x + y * y
+        cdist = 1.0 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2
+        dx = p1 * 2.0 * x * y + p2 * (r2 + 2.0 * x * x)
+        dy = p1 * (r2 + 2.0 * y * y) + p2 * 2.0 * x * y
+        x, y = (xd - dx) / cdist, (yd - dy) / cdist
+    return x, y
 
 
 def half_sample(img: np.ndarray) -> np.ndarray:

@@ -1,20 +1,28 @@
-// depth_filter_batch.h -- DepthFilter::updateSeeds (S/depth_filter.cpp:237-341) batched for the device, written ONCE
-// against a small Host policy so that the drop-in for the reference's own types (depth_filter_hip.cpp) and the
-// executable host layer on minimal types (android_svo_amd/host/svo_host.h, run on the GPU by
+// depth_filter_batch.h -- DepthFilter::updateSeeds (S/depth_filter.cpp:237-341) with the seeds RESIDENT ON THE DEVICE,
+// written ONCE against a small Host policy so that the drop-in for the reference's own types (depth_filter_hip.cpp) and
+// the executable host layer on minimal types (android_svo_amd/host/svo_host.h, run on the GPU by
 // tests/test_gpu_host_cpp.py) execute the same code.  Depends on svo_hip.h and the standard library only.
 //
-// What the reference does seed by seed, in list order, and how this keeps it:
-//   * age-out of old seeds (:256-261), halt flag polled per seed (:253)            -> pass 1, identical
-//   * visibility test, findEpipolarMatchDirect, computeTau, updateSeed (:264-299)   -> device, per reference keyframe,
-//     in sub-batches of at most `sub_batch` seeds; the halt flag is polled between sub-batches, and what the
-//     finished sub-batches computed is applied before returning (a seed is either updated by this frame or not,
-//     as in the reference, where the prefix that got updated also depends on when the flag rises)
-//   * on keyframes: feature_detector_->setGridOccpuancy(matcher_.px_cur_) for every updated seed (:302-306),
+// The reference keeps its seeds in a std::list<Seed> and walks it once per frame.  Here every keyframe's seeds are
+// mirrored on the device when they are first seen (svo_hip_seed_batch_create: Feature px / f / level and the Seed
+// constructor's state, uploaded ONCE, in chunks of at most `sub_batch` seeds), and a frame costs two poses down and the
+// seeds the host has to act on back (round 3 moved 144 B per seed over the link every frame):
+//   * age-out of old seeds (:256-261)                     -> whole device batches dropped, their list entries erased
+//   * visibility test, findEpipolarMatchDirect, computeTau, updateSeed (:264-299)
+//                                                         -> device, one pass per batch, all batches of the frame enqueued
+//     back to back and awaited once; the halt flag (:253) is polled before every batch is enqueued, and what was
+//     enqueued is applied (a seed is either updated by this frame or not, as in the reference, where the prefix that
+//     got updated also depends on when the flag rises)
+//   * on keyframes feature_detector_->setGridOccpuancy(matcher_.px_cur_) for every updated seed (:302-306),
 //     convergence -> new Point + seed_converged_cb_ + erase (:310-331), NaN -> erase (:333-337)
-//                                                                                   -> pass 2, over the list IN LIST
-//     ORDER, so callbacks (candidate-list insertion order) and erasures happen in the reference's order whatever
-//     order the device batches ran in.  Keyframe buckets are processed in first-appearance order (deterministic; the
-//     results do not depend on it).
+//                                                         -> the batch's EVENTS, ascending seed index, batches in list
+//     order: the callbacks (candidate-list insertion order), grid marks and erasures happen in the reference's order.
+// The list entries of live seeds keep their CONSTRUCTION-time a / b / mu / sigma2 until syncToHost() copies the device
+// state back (getSeeds() / getSeedsCopy() callers; the reference app has none) -- a converged seed's mu / sigma2 are
+// written before its callback, which is all the reference's callback reads.
+// Erasures behind the mirror's back (DepthFilter::removeKeyframe, reset: non-virtual in the reference) are noticed at the
+// next call -- the list's size or its last seed id no longer match -- and the mirror is re-built from the list: seeds
+// still there keep their device state, the others are erased on the device too.
 //
 // Host policy (duck-typed; see the two users):
 //   Frame*  keyframeOf(const Seed&)                       it->ftr->frame
@@ -31,6 +39,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <unordered_map>
 #include <vector>
 
 #include "svo_hip.h"
@@ -41,111 +50,235 @@ namespace hip_bridge {
 struct SeedBatchStats {
   int n_seeds = 0, n_aged_out = 0, n_updated = 0, n_failed_matches = 0, n_converged = 0, n_nan = 0;
   int n_device_calls = 0, n_device_errors = 0;
+  int n_uploaded = 0;                  // seeds mirrored on the device by this call (0 on every frame but a keyframe's next)
+  bool resynced = false;               // the list had changed behind the mirror's back
   bool halted = false;
 };
 
-template <class Host, class SeedList, class Frame>
-SeedBatchStats updateSeedsBatched(Host& host, svo_hip_ctx* ctx, SeedList& seeds, Frame& frame, const svo_hip_df_params& prm,
-                                  int batch_counter, int max_n_kfs, const volatile bool& halt, int sub_batch = 4096) {
+/// The device mirror of a std::list<Seed>: owned by the depth filter object, used under its seeds mutex.
+template <class SeedList>
+class DeviceSeedMirror {
+ public:
   typedef typename SeedList::iterator It;
-  SeedBatchStats st;
-  if (sub_batch < 1) sub_batch = 1;
+  typedef typename SeedList::value_type SeedT;
 
-  // ---- pass 1: age-out and indexing, in list order
-  struct Item {
-    It it;
-    int32_t status;
-    bool done;
-    float a, b, mu, sigma2;
-    double xyz[3], px_cur[2];
-  };
-  std::vector<Item> items;
-  std::vector<decltype(host.keyframeOf(*seeds.begin()))> kfs;      // first-appearance order
-  std::vector<std::vector<int> > buckets;
-  for (It it = seeds.begin(); it != seeds.end();) {
+  DeviceSeedMirror() {}
+  ~DeviceSeedMirror() { clear(); }
+  DeviceSeedMirror(const DeviceSeedMirror&) = delete;
+  DeviceSeedMirror& operator=(const DeviceSeedMirror&) = delete;
+
+  void clear() {
+    for (size_t k = 0; k < batches_.size(); ++k) svo_hip_seed_batch_destroy(batches_[k].dev);
+    batches_.clear();
+    where_.clear();
+    known_size_ = 0; known_back_id_ = -1;
+  }
+  size_t deviceBatches() const { return batches_.size(); }
+
+  /// DepthFilter::updateSeeds(frame).  `sub_batch`: seeds per device batch (the halt flag is polled in between).
+  template <class Host, class Frame>
+  SeedBatchStats update(Host& host, svo_hip_ctx* ctx, SeedList& seeds, Frame& frame, const svo_hip_df_params& prm, int batch_counter,
+                        int max_n_kfs, const volatile bool& halt, int sub_batch = 4096) {
+    SeedBatchStats st;
+    if (sub_batch < 1) sub_batch = 1;
     if (halt) { st.halted = true; return st; }
-    if ((batch_counter - it->batch_id) > max_n_kfs) { it = seeds.erase(it); ++st.n_aged_out; continue; }
-    auto kf = host.keyframeOf(*it);
-    size_t k = kfs.size();
-    while (k > 0 && kfs[k - 1] != kf) --k;                         // newest first: seeds of a keyframe are contiguous
-    if (k == 0) { kfs.push_back(kf); buckets.push_back(std::vector<int>()); k = kfs.size(); }
-    buckets[k - 1].push_back((int)items.size());
-    Item item;
-    item.it = it; item.status = -1; item.done = false;
-    items.push_back(item);
-    ++it;
-  }
-  st.n_seeds = (int)items.size();
-  if (items.empty()) return st;
+    // ---- the list against the mirror: new seeds (initializeSeeds pushed a keyframe's batch) or foreign erasures
+    const int back_id = seeds.empty() ? -1 : seeds.back().id;
+    if (seeds.size() != known_size_ || back_id != known_back_id_) {
+      if (!reconcile(host, ctx, seeds, sub_batch, st)) { ++st.n_device_errors; return st; }
+    }
+    // ---- age-out (:256-261): batches older than max_n_kfs keyframes leave the list and the device
+    for (size_t k = 0; k < batches_.size();) {
+      if (halt) { st.halted = true; remember(seeds); return st; }
+      Batch& b = batches_[k];
+      if ((batch_counter - b.batch_id) > max_n_kfs) {
+        for (size_t i = 0; i < b.its.size(); ++i)
+          if (b.alive[i]) { where_.erase(&*b.its[i]); seeds.erase(b.its[i]); ++st.n_aged_out; }
+        svo_hip_seed_batch_destroy(b.dev);
+        batches_.erase(batches_.begin() + (std::ptrdiff_t)k);
+      } else {
+        ++k;
+      }
+    }
+    for (size_t k = 0; k < batches_.size(); ++k) st.n_seeds += batches_[k].n_alive;
+    remember(seeds);
+    if (batches_.empty()) return st;
 
-  const svo_hip_camera cam = host.camera(frame);
-  const int cur_slot = host.currentSlot(frame);
-  if (cur_slot < 0) return st;
-  double T_cur[7];
-  host.pose7(frame, T_cur);
+    const svo_hip_camera cam = host.camera(frame);
+    const int cur_slot = host.currentSlot(frame);
+    if (cur_slot < 0) return st;
+    double T_cur[7];
+    host.pose7(frame, T_cur);
+    const bool is_keyframe = host.isKeyframe(frame);
 
-  // ---- device: per reference keyframe, sub-batches of at most sub_batch seeds
-  std::vector<double> px, f, z, xyz, px_cur;
-  std::vector<int32_t> level, status;
-  std::vector<float> a, b, mu, zr, s2;
-  for (size_t k = 0; k < kfs.size() && !st.halted; ++k) {
-    const std::vector<int>& ids = buckets[k];
-    const int ref_slot = host.keyframeSlot(*kfs[k]);
-    if (ref_slot < 0) continue;
-    double T_ref[7];
-    host.pose7(*kfs[k], T_ref);
-    for (size_t first = 0; first < ids.size(); first += (size_t)sub_batch) {
+    // ---- device: one pass per batch, enqueued back to back (list order), awaited in the same order
+    std::vector<size_t> enqueued;
+    for (size_t k = 0; k < batches_.size(); ++k) {
       if (halt) { st.halted = true; break; }
-      const int n = (int)((ids.size() - first < (size_t)sub_batch) ? ids.size() - first : (size_t)sub_batch);
-      px.resize(2 * (size_t)n); f.resize(3 * (size_t)n); z.resize((size_t)n); xyz.resize(3 * (size_t)n);
-      px_cur.resize(2 * (size_t)n); level.resize((size_t)n); status.resize((size_t)n);
-      a.resize((size_t)n); b.resize((size_t)n); mu.resize((size_t)n); zr.resize((size_t)n); s2.resize((size_t)n);
-      for (int i = 0; i < n; ++i) {
-        const It it = items[(size_t)ids[first + (size_t)i]].it;
-        int lvl = 0;
-        host.feature(*it, &px[2 * (size_t)i], &f[3 * (size_t)i], &lvl);
-        level[(size_t)i] = lvl;
-        a[(size_t)i] = it->a; b[(size_t)i] = it->b; mu[(size_t)i] = it->mu; zr[(size_t)i] = it->z_range; s2[(size_t)i] = it->sigma2;
-      }
+      Batch& b = batches_[k];
+      if (b.n_alive == 0) continue;
+      const int ref_slot = host.keyframeSlot(*b.kf);
+      if (ref_slot < 0) continue;
+      double T_ref[7];
+      host.pose7(*b.kf, T_ref);
       ++st.n_device_calls;
-      const int rc = svo_hip_depth_filter_update(ctx, host.keyframePyramids(), ref_slot, host.currentPyramids(), cur_slot, &cam,
-                                                 T_ref, T_cur, n, px.data(), f.data(), level.data(), a.data(), b.data(),
-                                                 mu.data(), zr.data(), s2.data(), &prm, status.data(), z.data(), xyz.data(),
-                                                 NULL, NULL, px_cur.data(), NULL);
+      const int rc = svo_hip_seed_batch_update_async(b.dev, host.keyframePyramids(), ref_slot, host.currentPyramids(), cur_slot, &cam,
+                                                     T_ref, T_cur, &prm, is_keyframe ? 1 : 0);
       if (rc != SVO_HIP_OK) { ++st.n_device_errors; continue; }    // device error: these seeds keep their old state
-      for (int i = 0; i < n; ++i) {
-        Item& item = items[(size_t)ids[first + (size_t)i]];
-        item.done = true;
-        item.status = status[(size_t)i];
-        item.a = a[(size_t)i]; item.b = b[(size_t)i]; item.mu = mu[(size_t)i]; item.sigma2 = s2[(size_t)i];
-        for (int c = 0; c < 3; ++c) item.xyz[c] = xyz[3 * (size_t)i + (size_t)c];
-        item.px_cur[0] = px_cur[2 * (size_t)i]; item.px_cur[1] = px_cur[2 * (size_t)i + 1];
+      enqueued.push_back(k);
+    }
+    // ---- the events, in list order: grid marks, callbacks, erasures (:302-337)
+    for (size_t e = 0; e < enqueued.size(); ++e) {
+      Batch& b = batches_[enqueued[e]];
+      const svo_hip_seed_event* ev = NULL;
+      int n_ev = 0;
+      int32_t counts[7];
+      if (svo_hip_seed_batch_collect(b.dev, &ev, &n_ev, counts) != SVO_HIP_OK) { ++st.n_device_errors; continue; }
+      st.n_failed_matches += counts[SVO_HIP_SEED_NO_MATCH + 1];
+      st.n_updated += counts[SVO_HIP_SEED_UPDATED + 1] + counts[SVO_HIP_SEED_CONVERGED + 1] + counts[SVO_HIP_SEED_NAN + 1];
+      for (int j = 0; j < n_ev; ++j) {
+        const svo_hip_seed_event& x = ev[j];
+        if (x.index < 0 || (size_t)x.index >= b.its.size() || !b.alive[(size_t)x.index]) continue;
+        It it = b.its[(size_t)x.index];
+        if (is_keyframe) host.setGridOccupancy(x.px_cur);           // :302-306
+        if (x.status == SVO_HIP_SEED_CONVERGED) {                   // :310-331
+          it->mu = x.mu; it->sigma2 = x.sigma2;
+          host.converged(*it, x.xyz_world);
+          forget(b, (size_t)x.index, seeds);
+          ++st.n_converged;
+        } else if (x.status == SVO_HIP_SEED_NAN) {                  // :333-337
+          forget(b, (size_t)x.index, seeds);
+          ++st.n_nan;
+        }
       }
     }
+    // batches without a live seed are of no further use
+    for (size_t k = 0; k < batches_.size();) {
+      if (batches_[k].n_alive == 0) { svo_hip_seed_batch_destroy(batches_[k].dev); batches_.erase(batches_.begin() + (std::ptrdiff_t)k); }
+      else ++k;
+    }
+    remember(seeds);
+    return st;
   }
 
-  // ---- pass 2: apply in list order
-  const bool is_keyframe = host.isKeyframe(frame);
-  for (size_t j = 0; j < items.size(); ++j) {
-    Item& item = items[j];
-    if (!item.done) continue;
-    It it = item.it;
-    it->a = item.a; it->b = item.b; it->mu = item.mu; it->sigma2 = item.sigma2;
-    if (item.status == SVO_HIP_SEED_NO_MATCH) ++st.n_failed_matches;
-    if (item.status < SVO_HIP_SEED_UPDATED) continue;
-    ++st.n_updated;
-    if (is_keyframe) host.setGridOccupancy(item.px_cur);           // :302-306
-    if (item.status == SVO_HIP_SEED_CONVERGED) {                   // :310-331
-      host.converged(*it, item.xyz);
-      seeds.erase(it);
-      ++st.n_converged;
-    } else if (item.status == SVO_HIP_SEED_NAN) {                  // :333-337
-      seeds.erase(it);
-      ++st.n_nan;
+  /// Copy the device state (a, b, mu, sigma2) of every live seed into its list entry: before the host reads the list
+  /// (getSeeds() / getSeedsCopy()).  Returns false on a device error.
+  bool syncToHost() {
+    std::vector<float> a, b, mu, s2;
+    for (size_t k = 0; k < batches_.size(); ++k) {
+      Batch& bt = batches_[k];
+      const size_t n = bt.its.size();
+      a.resize(n); b.resize(n); mu.resize(n); s2.resize(n);
+      if (svo_hip_seed_batch_download(bt.dev, a.data(), b.data(), mu.data(), s2.data(), NULL) != SVO_HIP_OK) return false;
+      for (size_t i = 0; i < n; ++i)
+        if (bt.alive[i]) { It it = bt.its[i]; it->a = a[i]; it->b = b[i]; it->mu = mu[i]; it->sigma2 = s2[i]; }
     }
+    return true;
   }
-  return st;
-}
+
+ private:
+  struct Batch {
+    size_t serial;                       // never reused: what where_ refers to
+    int batch_id;                        // Seed::batch_id of its seeds (age-out)
+    decltype(((SeedT*)0)->ftr->frame) kf;   // the reference keyframe (Frame*)
+    svo_hip_seed_batch* dev;
+    std::vector<It> its;                 // device index -> list entry
+    std::vector<uint8_t> alive;          // ... still in the list
+    int n_alive;
+  };
+  struct Where { size_t batch_serial; int index; int id; };   // id: Seed::id (a recycled list node is another seed)
+
+  std::vector<Batch> batches_;                           // list order (= creation order of the keyframes' seed batches)
+  std::unordered_map<const SeedT*, Where> where_;        // list node -> (its batch, index): the re-build after foreign erasures
+  size_t next_serial_ = 0;
+  size_t known_size_ = 0;
+  int known_back_id_ = -1;
+
+  void remember(const SeedList& seeds) {
+    known_size_ = seeds.size();
+    known_back_id_ = seeds.empty() ? -1 : seeds.back().id;
+  }
+  void forget(Batch& b, size_t index, SeedList& seeds) {
+    where_.erase(&*b.its[index]);
+    seeds.erase(b.its[index]);
+    b.alive[index] = 0;
+    --b.n_alive;
+  }
+
+  /// Bring the mirror in line with the list: seeds the mirror does not know become new device batches (per keyframe batch
+  /// id, chunks of at most sub_batch, list order); mirrored seeds that left the list are erased on the device.
+  template <class Host>
+  bool reconcile(Host& host, svo_hip_ctx* ctx, SeedList& seeds, int sub_batch, SeedBatchStats& st) {
+    // present[k][i]: list entries found for batch k
+    std::vector<std::vector<uint8_t> > present(batches_.size());
+    for (size_t k = 0; k < batches_.size(); ++k) present[k].assign(batches_[k].its.size(), 0);
+    std::unordered_map<size_t, size_t> pos_of_serial;
+    for (size_t k = 0; k < batches_.size(); ++k) pos_of_serial[batches_[k].serial] = k;
+    std::vector<It> fresh;                                         // list entries without a mirror, list order
+    for (It it = seeds.begin(); it != seeds.end(); ++it) {
+      typename std::unordered_map<const SeedT*, Where>::const_iterator w = where_.find(&*it);
+      if (w == where_.end() || w->second.id != it->id) { fresh.push_back(it); continue; }
+      present[pos_of_serial[w->second.batch_serial]][(size_t)w->second.index] = 1;
+    }
+    // foreign erasures
+    std::vector<int32_t> gone;
+    for (size_t k = 0; k < batches_.size(); ++k) {
+      Batch& b = batches_[k];
+      gone.clear();
+      for (size_t i = 0; i < b.its.size(); ++i)
+        if (b.alive[i] && !present[k][i]) { gone.push_back((int32_t)i); b.alive[i] = 0; --b.n_alive; }
+      if (!gone.empty()) {
+        st.resynced = true;
+        if (svo_hip_seed_batch_erase(b.dev, (int)gone.size(), gone.data()) != SVO_HIP_OK) return false;
+      }
+    }
+    if (st.resynced) {                                             // stale node addresses must not alias new seeds
+      for (typename std::unordered_map<const SeedT*, Where>::iterator w = where_.begin(); w != where_.end();) {
+        const Batch& b = batches_[pos_of_serial[w->second.batch_serial]];
+        if (!b.alive[(size_t)w->second.index]) w = where_.erase(w); else ++w;
+      }
+    }
+    for (size_t k = 0; k < batches_.size();) {
+      if (batches_[k].n_alive == 0) { svo_hip_seed_batch_destroy(batches_[k].dev); batches_.erase(batches_.begin() + (std::ptrdiff_t)k); }
+      else ++k;
+    }
+    // new seeds: runs of equal (batch id, keyframe), chunked
+    std::vector<double> px, f;
+    std::vector<int32_t> level;
+    std::vector<float> a, b, mu, zr, s2;
+    size_t first = 0;
+    while (first < fresh.size()) {
+      size_t last = first + 1;
+      while (last < fresh.size() && last - first < (size_t)sub_batch && fresh[last]->batch_id == fresh[first]->batch_id &&
+             host.keyframeOf(*fresh[last]) == host.keyframeOf(*fresh[first])) ++last;
+      const size_t n = last - first;
+      px.resize(2 * n); f.resize(3 * n); level.resize(n); a.resize(n); b.resize(n); mu.resize(n); zr.resize(n); s2.resize(n);
+      for (size_t i = 0; i < n; ++i) {
+        const It it = fresh[first + i];
+        int lvl = 0;
+        host.feature(*it, &px[2 * i], &f[3 * i], &lvl);
+        level[i] = lvl;
+        a[i] = it->a; b[i] = it->b; mu[i] = it->mu; zr[i] = it->z_range; s2[i] = it->sigma2;
+      }
+      Batch nb;
+      nb.batch_id = fresh[first]->batch_id;
+      nb.kf = host.keyframeOf(*fresh[first]);
+      nb.dev = NULL;
+      if (svo_hip_seed_batch_create(ctx, (int)n, px.data(), f.data(), level.data(), a.data(), b.data(), mu.data(), zr.data(), s2.data(),
+                                    &nb.dev) != SVO_HIP_OK) return false;
+      nb.its.assign(fresh.begin() + (std::ptrdiff_t)first, fresh.begin() + (std::ptrdiff_t)last);
+      nb.alive.assign(n, 1);
+      nb.n_alive = (int)n;
+      nb.serial = next_serial_++;
+      for (size_t i = 0; i < n; ++i) { Where w; w.batch_serial = nb.serial; w.index = (int)i; w.id = nb.its[i]->id; where_[&*nb.its[i]] = w; }
+      // batches_ stays in list order: new seeds are pushed to the back of the list, so a new batch goes to the end
+      batches_.push_back(nb);
+      st.n_uploaded += (int)n;
+      first = last;
+    }
+    return true;
+  }
+};
 
 }  // namespace hip_bridge
 }  // namespace svo

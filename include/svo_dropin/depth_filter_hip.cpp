@@ -1,5 +1,5 @@
-// depth_filter_hip.cpp -- see depth_filter_hip.h.  The batching, ordering and halt logic is
-// hip_bridge::updateSeedsBatched (depth_filter_batch.h), shared with the executable host layer
+// depth_filter_hip.cpp -- see depth_filter_hip.h.  The device mirror of the seed list, the ordering and the halt logic are
+// hip_bridge::DeviceSeedMirror (depth_filter_batch.h), shared with the executable host layer
 // android_svo_amd/host/svo_host.h; this file only adapts the reference's types to it.
 #include <svo/config.h>
 #include <svo/feature.h>
@@ -13,7 +13,7 @@
 namespace svo {
 
 namespace {
-/// Host policy of updateSeedsBatched on the reference's data model
+/// Host policy of hip_bridge::DeviceSeedMirror on the reference's data model
 struct RefHost {
   hip_bridge::PyramidCache* kf_pyr;
   hip_bridge::PyramidCache* cur_pyr;
@@ -45,11 +45,16 @@ struct RefHost {
 DepthFilterHip::DepthFilterHip(feature_detection::DetectorPtr feature_detector, callback_t seed_converged_cb)
     : DepthFilter(feature_detector, seed_converged_cb), ctx_(0), kf_pyr_(ctx_.get(), 8), cur_pyr_(ctx_.get(), 2) {}
 
-DepthFilterHip::~DepthFilterHip() { stopThread(); }
+DepthFilterHip::~DepthFilterHip() { stopThread(); mirror_.clear(); }
+
+bool DepthFilterHip::syncSeeds() {
+  lock_t lock(seeds_mut_);
+  return mirror_.syncToHost();
+}
 
 void DepthFilterHip::updateSeeds(FramePtr frame) {
   lock_t lock(seeds_mut_);
-  if (seeds_.empty()) return;
+  if (seeds_.empty()) { mirror_.clear(); return; }
   if (!ctx_.ok()) { hip_bridge::reportDeviceFailure(NULL, "DepthFilterHip::updateSeeds"); return; }
   svo_hip_df_params prm;
   prm.n_pyr_levels = (int)Config::nPyrLevels();
@@ -59,8 +64,7 @@ void DepthFilterHip::updateSeeds(FramePtr frame) {
   RefHost host;
   host.kf_pyr = &kf_pyr_; host.cur_pyr = &cur_pyr_;
   host.detector = feature_detector_.get(); host.seed_converged_cb = &seed_converged_cb_;
-  hip_bridge::updateSeedsBatched(host, ctx_.get(), seeds_, *frame, prm, Seed::batch_counter, options_.max_n_kfs,
-                                 seeds_updating_halt_);
+  mirror_.update(host, ctx_.get(), seeds_, *frame, prm, Seed::batch_counter, options_.max_n_kfs, seeds_updating_halt_);
 }
 
 }  // namespace svo

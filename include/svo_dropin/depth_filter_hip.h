@@ -12,6 +12,7 @@
 
 #include <svo/depth_filter.h>
 
+#include "depth_filter_batch.h"
 #include "svo_hip_bridge.h"
 
 namespace svo {
@@ -22,6 +23,11 @@ class DepthFilterHip : public DepthFilter {
   DepthFilterHip(feature_detection::DetectorPtr feature_detector, callback_t seed_converged_cb);
   virtual ~DepthFilterHip();
 
+  /// Between frames the seeds' state (a, b, mu, sigma2) lives on the device; the list entries are brought up to date by
+  /// this call -- make it before reading getSeeds() / getSeedsCopy() (both non-virtual in the reference; the app never
+  /// calls them).  Returns false on a device error.
+  bool syncSeeds();
+
  protected:
   /// One pass over all seeds against `frame`, batched per reference keyframe.
   virtual void updateSeeds(FramePtr frame);
@@ -30,6 +36,7 @@ class DepthFilterHip : public DepthFilter {
   hip_bridge::Context ctx_;            // the depth-filter thread's own stream
   hip_bridge::PyramidCache kf_pyr_;    // keyframes that still own seeds (max_n_kfs + 1 batches alive)
   hip_bridge::PyramidCache cur_pyr_;
+  hip_bridge::DeviceSeedMirror<std::list<Seed> > mirror_;   // per-keyframe seed batches resident on the device (under seeds_mut_)
 };
 
 }  // namespace svo

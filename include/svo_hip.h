@@ -331,6 +331,7 @@ typedef struct {
 #define SVO_HIP_SEED_UPDATED 3
 #define SVO_HIP_SEED_CONVERGED 4
 #define SVO_HIP_SEED_NAN 5
+#define SVO_HIP_SEED_ERASED (-1)   /* seed batches only: the seed had left the list before this pass (nothing was computed) */
 
 /* DepthFilter::updateSeeds for n seeds created in keyframe ref->ref_slot, measured in frame
  * cur->cur_slot: visibility test, Matcher::findEpipolarMatchDirect (epipolar ZMSSD search +
@@ -379,6 +380,51 @@ int svo_hip_seed_gather_converged_dev(svo_hip_ctx* ctx, svo_hip_comm* comm, int 
                                       const int32_t* status_dev, const float* mu_dev, const float* sigma2_dev,
                                       const double* xyz_world_dev, int cap, double* records_all_dev,
                                       int32_t* counts_all_dev);
+
+/* diagnostic: HIP events around the four stages (geometry, search, align, finalize) of every following depth-filter pass
+ * of this context; svo_hip_df_get_profile waits for the last pass and returns its stage durations in microseconds */
+int svo_hip_df_set_profiling(svo_hip_ctx* ctx, int enable);
+int svo_hip_df_get_profile(svo_hip_ctx* ctx, double stage_us[4]);
+
+/* ---- device-resident seeds: the seeds DepthFilter::initializeSeeds creates for one keyframe (depth_filter.cpp:129-151)
+ * live on the device from their creation to their end.  The host uploads a batch ONCE (Feature px / f / level and the
+ * Seed constructor's a, b, mu, z_range, sigma2); every frame only the two poses go down (svo_hip_seed_batch_update_async)
+ * and only the seeds whose outcome the host must act on come back (svo_hip_seed_batch_collect): seeds that converged
+ * (:310-331: new Point at xyz_world, seed_converged_cb(point, sigma2), erase) or turned NaN (:333-337: erase) -- the
+ * device stops updating them, as the list erase does -- and, when report_updated is set (the frame is a keyframe,
+ * :302-306), every updated seed with its Matcher::px_cur_ for feature_detector_->setGridOccpuancy.  Events are ordered
+ * by seed index = list order, so callbacks happen in the reference's order.  Seeds the HOST erases (removeKeyframe,
+ * age-out of a part of a batch) are reported with svo_hip_seed_batch_erase.  svo_hip_seed_batch_download returns the
+ * current state of every seed for getSeeds() / getSeedsCopy().  One batch belongs to one context (one host thread). */
+typedef struct svo_hip_seed_batch svo_hip_seed_batch;
+typedef struct {
+  int32_t index;            /* position in the batch = creation order of the keyframe's seeds */
+  int32_t status;           /* SVO_HIP_SEED_CONVERGED, SVO_HIP_SEED_NAN or (report_updated) SVO_HIP_SEED_UPDATED */
+  float mu, sigma2;         /* Seed::mu / Seed::sigma2 after the update */
+  double xyz_world[3];      /* converged seeds: ref.T_f_w_.inverse() * (f / mu) (:313) */
+  double px_cur[2];         /* Matcher::px_cur_ (level-0 pixel in the current frame) */
+} svo_hip_seed_event;
+int svo_hip_seed_batch_create(svo_hip_ctx* ctx, int n, const double* px, const double* f, const int32_t* level,
+                              const float* a, const float* b, const float* mu, const float* z_range, const float* sigma2,
+                              svo_hip_seed_batch** out);                     /* host arrays, uploaded once */
+int svo_hip_seed_batch_destroy(svo_hip_seed_batch* batch);
+int svo_hip_seed_batch_size(const svo_hip_seed_batch* batch, int* n, int* n_alive);     /* n_alive: as of the last collect */
+/* enqueue one updateSeeds pass of the batch against cur->cur_slot on the context stream (returns at once) */
+int svo_hip_seed_batch_update_async(svo_hip_seed_batch* batch, const svo_hip_pyramid* ref, int ref_slot,
+                                    const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                                    const double T_ref_w[7], const double T_cur_w[7], const svo_hip_df_params* prm,
+                                    int report_updated);
+/* wait for the pass; *events points into page-locked memory owned by the batch (valid until its next update_async);
+ * status_counts[7]: seeds per outcome of this pass, slot = status + 1 (slot 0 = SVO_HIP_SEED_ERASED ... slot 6 =
+ * SVO_HIP_SEED_NAN).  Either output may be NULL. */
+int svo_hip_seed_batch_collect(svo_hip_seed_batch* batch, const svo_hip_seed_event** events, int* n_events,
+                               int32_t status_counts[7]);
+int svo_hip_seed_batch_erase(svo_hip_seed_batch* batch, int n, const int32_t* indices);      /* host array */
+/* state of every seed of the batch, erased ones included (alive[i] = 0); any output may be NULL; synchronises */
+int svo_hip_seed_batch_download(svo_hip_seed_batch* batch, float* a, float* b, float* mu, float* sigma2, uint8_t* alive);
+/* the batch's device arrays (tests, benchmarks): a, b, mu, sigma2 [n] f32, status [n] i32 of the last pass */
+int svo_hip_seed_batch_arrays(svo_hip_seed_batch* batch, float** a_dev, float** b_dev, float** mu_dev, float** sigma2_dev,
+                              int32_t** status_dev);
 
 /* host-buffer convenience form of the above (copies in, runs, copies out, synchronises) */
 int svo_hip_depth_filter_update(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, int ref_slot,

@@ -63,6 +63,6 @@ def test_bench_sharded_started_plainly_reports_the_communicators_rank_count():
 
 
 def test_bench_c4_gpus_2_started_plainly():
-    d = _plain("bench_c4.py", "--gpus", "2", "--seeds", "20000", "--width", "640", "--height", "480", "--steps", "2", "--warmup", "1")
+    d = _plain("bench_c4.py", "--gpus", "2", "--seeds", "40000", "--steps", "2", "--warmup", "1")
     assert d["n_gpus"] == 2 and "rehearsal" in d and d["config"]["comm_ranks"] == 2
-    assert d["config"]["converged_records_gathered"] > 0
+    assert d["config"]["converged_records_gathered"] > 0 and d["config"]["seeds_per_gpu"] == 20000

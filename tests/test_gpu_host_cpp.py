@@ -21,12 +21,32 @@ def _write(path, arr, dtype):
     np.ascontiguousarray(arr, dtype=dtype).tofile(path)
 
 
-def test_cpp_host_layer_end_to_end(tmp_path):
+def _bearings(cam, px):
+    """Feature::f as the reference forms it: cam->cam2world(px) -- for a radtan camera the cv::undistortPoints route
+    (five float iterations; the oracle's restatement of it, parity unpinned) instead of the closed form"""
+    if getattr(cam, "dist", None) is None:
+        return synth.cam2world(cam, px)
+    import ctypes
+    c = orc.camera(cam)
+    f = np.zeros((len(px), 3))
+    for i in range(len(px)):
+        orc.lib().svo_orc_cam2world(ctypes.byref(c), ctypes.c_double(px[i, 0]), ctypes.c_double(px[i, 1]), orc._p(f[i], ctypes.c_double))
+    return f
+
+
+@pytest.mark.parametrize("dist", [None, (-0.12, 0.03, 2e-4, -1e-4, 0.0)], ids=["pinhole", "radtan"])
+def test_cpp_host_layer_end_to_end(tmp_path, dist):
+    """SparseImgAlign + the DepthFilter protocol through the C++ host layer.  `radtan`: a distorted camera end to end --
+    images rendered through the distortion, Feature::f by the reference's cv::undistortPoints route, world2cam by the
+    pinned forward model -- the same oracle replay must hold (the depth filter's cam2world branch that no reference
+    binary pins, run through the C++ layer and not only through the kernel)."""
     assert os.path.exists(DEMO), "build() must have produced android_svo_amd/host/svo_host_demo"
     case, out = tmp_path / "case", tmp_path / "out"
     case.mkdir(); out.mkdir()
     rng = np.random.default_rng(4)
     cam = synth.Camera.default()
+    if dist is not None:
+        cam.dist = dist
     scene = synth.PlaneScene(seed=4, depth=2.0, tilt=(0.08, 0.05))
     n_frames = 7
     T0 = synth.se3_from_twist([0.02, -0.01, 0.0], [0.01, 0.005, -0.01])
@@ -34,14 +54,15 @@ def test_cpp_host_layer_end_to_end(tmp_path):
     poses = [T0] + [synth.se3_mul(synth.se3_from_twist(direction * 0.035 * k, rng.uniform(-0.004, 0.004, 3)), T0)
                     for k in range(1, n_frames)]
     pyrs = [synth.build_pyramid(scene.render(cam, T)) for T in poses]
-    _write(case / "manifest.bin", [cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, 5, n_frames], np.float64)
+    _write(case / "manifest.bin", [cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, 5, n_frames] + (list(dist) if dist is not None else []),
+           np.float64)
     for k in range(n_frames):
         _write(case / ("frame_%d_pose.bin" % k), poses[k], np.float64)
         for l in range(5):
             _write(case / ("frame_%d_L%d.bin" % (k, l)), pyrs[k][l], np.uint8)
     # alignment features on frame 0
     px = synth.grid_features(cam, 800, rng)
-    f = synth.cam2world(cam, px)
+    f = _bearings(cam, px)
     pos = scene.intersect(cam, T0, px[:, 0], px[:, 1])
     has = np.ones(len(px), dtype=np.uint8); has[::9] = 0
     for name, arr, dt in (("sia_px", px, np.float64), ("sia_f", f, np.float64), ("sia_pos", pos, np.float64), ("sia_has", has, np.uint8)):
@@ -54,7 +75,7 @@ def test_cpp_host_layer_end_to_end(tmp_path):
         spx = np.floor(np.stack([rng.uniform(40, cam.width - 40, n_seeds), rng.uniform(40, cam.height - 40, n_seeds)], axis=1))
         slevel = rng.choice([0, 0, 1, 2], n_seeds).astype(np.int32)
         spx -= spx % (1 << slevel)[:, None]
-        sf = synth.cam2world(cam, spx)
+        sf = _bearings(cam, spx)
         X = scene.intersect(cam, poses[kf], spx[:, 0], spx[:, 1])
         true_depth = np.linalg.norm(X - synth.se3_inv(poses[kf])[:3], axis=1)
         if zbar is None:

@@ -643,6 +643,52 @@ def test_full_size_c4_seeds_properties(ctx):
     _free(sb, kf, cf)
 
 
+def test_full_size_c2_seeds_against_the_oracle(ctx):
+    """Config C2's own depth-filter workload -- the 100 000 seeds of a 640x480 keyframe bench.py times (seedsynth seed 9):
+    valid outcomes, run-to-run determinism, shard invariance, every per-seed integer (status, ZMSSD evaluations, align2D
+    iterations, search level) and the matched pixel equal to the CPU oracle's on a 3 000-seed subset, and the same pass
+    through a device-resident seed batch (what the drop-in DepthFilter runs) bit for bit."""
+    n = 100000
+    sc = seedsynth.make_seed_case(n_seeds=n, seed=9)
+    kf = hip.Pyramid(ctx, 640, 480, 5, 1)
+    cf = hip.Pyramid(ctx, 640, 480, 5, 1)
+    kf.upload(0, sc.ref_pyr)
+    cf.upload(0, sc.cur_pyr)
+    sb = hip.SeedBatch(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, sc.sigma2)
+    hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb)
+    st, mu, s2, z = sb.status.download(), sb.mu.download(), sb.sigma2.download(), sb.z.download()
+    nz, na, pc, sl = sb.n_zmssd.download(), sb.n_align.download(), sb.px_cur.download(), sb.search_level.download()
+    assert set(np.unique(st)) <= {0, 1, 2, 3, 4, 5} and (st >= hip.SEED_UPDATED).mean() > 0.95
+    sb.reset_state(sc.a, sc.b, sc.mu, sc.sigma2)
+    hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb, lo=0, hi=33333)
+    hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb, lo=33333, hi=n)
+    np.testing.assert_array_equal(sb.mu.download(), mu)
+    np.testing.assert_array_equal(sb.sigma2.download(), s2)
+    np.testing.assert_array_equal(sb.status.download(), st)
+    rng = np.random.default_rng(3)
+    idx = np.sort(rng.choice(n, 3000, replace=False))
+    a, b, m, v = (x[idx].copy() for x in (sc.a, sc.b, sc.mu, sc.sigma2))
+    o = orc.update_seeds(sc.cam, sc.ref_pyr, sc.cur_pyr, sc.T_ref_w, sc.T_cur_w, sc.px[idx], sc.f[idx], sc.level[idx], a, b, m,
+                         sc.z_range[idx].copy(), v)
+    np.testing.assert_array_equal(o["status"], st[idx])
+    np.testing.assert_array_equal(o["n_zmssd"], nz[idx])
+    np.testing.assert_array_equal(o["n_align_iters"], na[idx])
+    np.testing.assert_array_equal(o["search_level"], sl[idx])
+    good = st[idx] >= hip.SEED_UPDATED
+    np.testing.assert_array_equal(o["px_cur"][good], pc[idx][good])          # align2D is bit-identical
+    np.testing.assert_allclose(z[idx][good], o["z"][good], rtol=1e-12)
+    np.testing.assert_allclose(mu[idx][good], m[good], rtol=3e-6)
+    rs = hip.ResidentSeeds(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, sc.sigma2)
+    ev, counts = rs.update(kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w)
+    d = rs.download()
+    np.testing.assert_array_equal(d["mu"], mu)
+    np.testing.assert_array_equal(d["sigma2"], s2)
+    np.testing.assert_array_equal(rs.status(), st)
+    assert counts[1:].tolist() == np.bincount(st, minlength=6).tolist() and len(ev) == int(((st == 4) | (st == 5)).sum())
+    rs.destroy()
+    _free(sb, kf, cf)
+
+
 def test_c2_align_batch_properties(ctx):
     """5000 patches (C2): refinement is idempotent on converged patches and lands near the true pixel."""
     ac = seedsynth.make_align_case(n=5000, seed=5)

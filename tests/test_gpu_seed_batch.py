@@ -1,0 +1,114 @@
+"""Device-resident seed batches (svo_hip_seed_batch_*: what the drop-in DepthFilter keeps per keyframe) against the
+stateless pass svo_hip_depth_filter_update_dev and the CPU oracle: same states bit for bit over several frames, the
+events are exactly the seeds the reference's list walk acts on (converged -> callback + erase, NaN -> erase, on keyframes
+every updated seed's px_cur), in list order, and erased seeds are never touched again (S/depth_filter.cpp:237-341)."""
+import numpy as np
+import pytest
+
+from android_svo_amd import hip, seedsynth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return hip.Context(0)
+
+
+def _case(ctx, n, sigma_scale, width=640, height=480):
+    sc = seedsynth.make_seed_case(n_seeds=n, seed=21, width=width, height=height)
+    kf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
+    cf = hip.Pyramid(ctx, sc.cam.width, sc.cam.height, 5, 1)
+    kf.upload(0, sc.ref_pyr)
+    cf.upload(0, sc.cur_pyr)
+    s2 = (sc.sigma2 * np.float32(sigma_scale)).astype(np.float32)
+    return sc, kf, cf, s2
+
+
+def test_resident_batch_equals_the_stateless_pass_over_several_frames(ctx):
+    n = 20000
+    sc, kf, cf, s2 = _case(ctx, n, 0.0045, 1280, 720)          # bench_c4's seed variance: about half converge in the first pass
+    sb = hip.SeedBatch(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, s2)
+    rs = hip.ResidentSeeds(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, s2)
+    alive = np.ones(n, bool)
+    total_events = 0
+    for frame in range(4):
+        keyframe = frame == 2
+        hip.depth_filter_update(ctx, kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, sb)
+        ctx.sync()
+        st = sb.status.download()
+        ev, counts = rs.update(kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w, report_updated=keyframe)
+        gone = alive & ((st == hip.SEED_CONVERGED) | (st == hip.SEED_NAN))
+        want = gone | (alive & (st >= hip.SEED_UPDATED)) if keyframe else gone
+        idx = np.nonzero(want)[0]
+        assert np.array_equal(ev["index"], idx)                       # ascending seed index = list order
+        assert np.array_equal(ev["status"], st[idx])
+        assert np.array_equal(ev["mu"], sb.mu.download()[idx]) and np.array_equal(ev["sigma2"], sb.sigma2.download()[idx])
+        pc = sb.px_cur.download()[idx]
+        assert np.array_equal(ev["px_cur"], pc)
+        conv = ev["status"] == hip.SEED_CONVERGED
+        assert np.array_equal(ev["xyz_world"][conv], sb.xyz.download()[idx][conv])
+        # the pass's status histogram: erased seeds in slot 0, the others as the stateless pass reports them
+        assert counts[0] == int((~alive).sum())
+        for s_ in range(6):
+            assert counts[s_ + 1] == int((alive & (st == s_)).sum()), (frame, s_)
+        assert np.array_equal(rs.status()[alive], st[alive]) and (rs.status()[~alive] == hip.SEED_ERASED).all()
+        alive &= ~gone
+        total_events += len(ev)
+        d = rs.download()
+        assert np.array_equal(d["alive"].astype(bool), alive) and rs.n_alive() == int(alive.sum())
+        for k, arr in (("a", sb.a), ("b", sb.b), ("mu", sb.mu), ("sigma2", sb.sigma2)):
+            assert np.array_equal(d[k][alive], arr.download()[alive]), (frame, k)
+    assert total_events > 500 and alive.sum() < n                     # the case does converge seeds
+    rs.destroy()
+    sb.free()
+
+
+def test_erased_seeds_are_left_alone_and_first_pass_matches_the_oracle(ctx):
+    from oracle import orc
+    n = 3000
+    sc, kf, cf, s2 = _case(ctx, n, 1.0)
+    rs = hip.ResidentSeeds(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, s2)
+    erased = np.arange(5, n, 7)
+    rs.erase(erased)
+    rs.erase(erased[:10])                                             # erasing twice changes nothing
+    assert rs.n_alive() == n - len(erased)
+    ev, counts = rs.update(kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w)
+    a, b, mu, s2o = sc.a.copy(), sc.b.copy(), sc.mu.copy(), s2.copy()
+    o = orc.update_seeds(sc.cam, sc.ref_pyr, sc.cur_pyr, sc.T_ref_w, sc.T_cur_w, sc.px, sc.f, sc.level, a, b, mu, sc.z_range, s2o)
+    st = rs.status()
+    keep = np.ones(n, bool)
+    keep[erased] = False
+    assert (st[erased] == hip.SEED_ERASED).all() and counts[0] == len(erased)
+    assert np.array_equal(st[keep], o["status"][keep])
+    d = rs.download()
+    assert np.array_equal(d["mu"][erased], sc.mu[erased]) and np.array_equal(d["sigma2"][erased], s2[erased])   # untouched
+    same = (d["mu"][keep] == mu[keep]).mean()
+    assert same > 0.995                                                # the HIP pass vs the oracle: as the stateless pass
+    assert not np.isin(ev["index"], erased).any()
+    # an update without a collect in between is refused, so is a collect without an update
+    rs.update_async(kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w)
+    with pytest.raises(hip.SvoHipError):
+        rs.update_async(kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w)
+    rs.collect()
+    with pytest.raises(hip.SvoHipError):
+        rs.collect()
+    rs.destroy()
+
+
+def test_two_batches_enqueued_back_to_back_one_wait(ctx):
+    n = 5000
+    sc, kf, cf, s2 = _case(ctx, n, 0.0045, 1280, 720)
+    half = n // 2
+    whole = hip.ResidentSeeds(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, s2)
+    parts = [hip.ResidentSeeds(ctx, sc.px[s], sc.f[s], sc.level[s], sc.a[s], sc.b[s], sc.mu[s], sc.z_range[s], s2[s])
+             for s in (slice(0, half), slice(half, n))]
+    ev_w, _ = whole.update(kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w)
+    for p in parts:
+        p.update_async(kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w)
+    evs = [p.collect()[0] for p in parts]
+    idx = np.concatenate([evs[0]["index"], evs[1]["index"] + half])
+    assert np.array_equal(idx, ev_w["index"]) and len(idx) > 500
+    assert np.array_equal(np.concatenate([e["sigma2"] for e in evs]), ev_w["sigma2"])
+    for o_ in [whole] + parts:
+        o_.destroy()
