@@ -1792,6 +1792,7 @@ int svo_hip_seed_batch_create(svo_hip_ctx* ctx, int n, const double* px, const d
     sb->sigma2 = (float*)(d + o_s2); sb->xyz = (double*)(d + o_xyz); sb->px_cur = (double*)(d + o_pc);
     sb->status = (int32_t*)(d + o_st); sb->alive = (uint8_t*)(d + o_al); sb->block_count = (int*)(d + o_bc); sb->hist = (int*)(d + o_h);
     sb->events_dev = (svo_hip_seed_event*)(d + o_ev);
+    sb->events_dev = (svo_hip_seed_event*)(d + o_ev);
     memset(sb->host, 0, kEvHeaderBytes);
     // the uploaded arrays gathered in the context's page-locked staging area: one transfer
     char* hs = nullptr;
@@ -1857,6 +1858,11 @@ int svo_hip_seed_batch_collect(svo_hip_seed_batch* sb, const svo_hip_seed_event*
   SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   sb->pending = false;
   const EvHeader* h = reinterpret_cast<const EvHeader*>(sb->host);
+  if (h->n_events > EV_DIRECT_MAX) {                      // many events (a keyframe): packed on the device, one transfer
+    SVO_CHECK_HIP(ctx, hipMemcpyAsync(sb->host + kEvHeaderBytes, sb->events_dev, (size_t)h->n_events * sizeof(svo_hip_seed_event),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   if (h->n_events > EV_DIRECT_MAX) {                      // many events (a keyframe): packed on the device, one transfer
     SVO_CHECK_HIP(ctx, hipMemcpyAsync(sb->host + kEvHeaderBytes, sb->events_dev, (size_t)h->n_events * sizeof(svo_hip_seed_event),
                                       hipMemcpyDeviceToHost, ctx->stream));

@@ -72,7 +72,12 @@ def parse_args():
     ap.add_argument("--stream-mode", action="store_true",
                     help="time the streaming implementation (one launch per Gauss-Newton evaluation) instead of the fused kernel: the run the PMC "
                          "passes of the Jacobian pass profile (tools/pmc_stream.sh)")
+    ap.add_argument("--arith", choices=["exact", "fast"], default="exact",
+                    help="arithmetic of the fused kernel in the TIMED workload: exact = the reference's (the headline); fast = the opt-in "
+                         "SVO_HIP_SIA_ARITH_FAST flavour -- for the PMC passes of that instance (tools/pmc_fused.sh <tag> --arith fast), not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose-json", action="store_true", help="keep the explanatory strings in the JSON line (default: numbers and sources only; "
+                                                                "what every key means is in profiles/BENCH_KEYS.md)")
     ap.add_argument("--cpu-frames-per-thread", type=int, default=16)
     ap.add_argument("--latency-probe", action="store_true",
                     help="(kept for old command lines: the single-pair latency is measured by default, outside the timed region, unless --no-secondary)")
@@ -174,6 +179,8 @@ def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=16):
             "what": "one frame pair, reference early-stop semantics, 1 thread: the reference's own compiled SparseImgAlign (oracle/_ref) beside the port",
             "reference_ms": timed(lambda: refpy.sparse_img_align_run(fps[0], n_iter=n_iter)),
             "port_ms": timed(lambda: orc.sparse_img_align(fps[0], n_iter=n_iter, early_stop=True))}
+        # the port is slower than the reference's own code: a ratio of `value` to the port is that much LARGER than one to the reference
+        out["port_vs_reference_speed"] = out["reference_check"]["reference_ms"] / out["reference_check"]["port_ms"]
     return out
 
 
@@ -229,6 +236,25 @@ def valu_issue_cycles(c):
 
 
 PREWARM_S = 0.1
+
+# keys that hold explanations, not measurements: left out of the JSON line unless --verbose-json (profiles/BENCH_KEYS.md
+# says what every key means; round 3's 14 kB line lost its first half in the driver's tail)
+PROSE_KEYS = {"what", "note", "rule", "traffic_rule", "sample", "legs", "measured_ceiling"}
+
+
+def slim(o, verbose=False):
+    """the JSON line without explanatory strings, floats to 6 significant digits"""
+    if isinstance(o, dict):
+        return {k: slim(v, verbose) for k, v in o.items() if verbose or k not in PROSE_KEYS}
+    if isinstance(o, (list, tuple)):
+        return [slim(v, verbose) for v in o]
+    if isinstance(o, float):
+        return float("%.6g" % o) if o == o and abs(o) != float("inf") else None
+    if isinstance(o, (np.floating,)):
+        return float("%.6g" % float(o))
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    return o
 
 
 def prewarm(ctx, fn, seconds=PREWARM_S):
@@ -362,6 +388,8 @@ def main():
     sia.set_frames(ref, cur)
     if args.stream_mode:
         sia.set_mode(stream=True)
+    if args.arith == "fast":
+        sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_FAST)
     if allreduce:
         # every rank holds every frame of the global batch (same seeds on all ranks), evaluates its patch shard
         fps = make_scenes(12345)
@@ -520,7 +548,7 @@ def main():
                    "note": "SURVEY 8(d): 945 B/patch/level + 881 B/patch/evaluation in the REFERENCE's data layout (768 B of fp64 Jacobian "
                            "cache per patch); the kernels form H and Jres from {sum dx^2, sum dx dy, sum dy^2} and two moments per patch and "
                            "never move that stream, so this ratio is not a roofline fraction"}
-            pmc_file = latest_profile("r*_pmc_fused.json" if mode == 1 else "r*_pmc_stream.json")
+            pmc_file = latest_profile(("r*_pmc_fused_fast.json" if args.arith == "fast" else "r*_pmc_fused.json") if mode == 1 else "r*_pmc_stream.json")
             ctr = pmc_of(pmc_file, kernel, args.allow_stale_profile, pairs=n_slots) if (pmc_file and default_c1) else None
             profile_refused = ctr if isinstance(ctr, str) else None
             if profile_refused:
@@ -624,9 +652,22 @@ def main():
             finally:
                 sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_EXACT)
             fa_err = np.array([synth.pose_error(np.array(r_fa[i].T_cur_w), np.array(oracle_res[i].T_cur_w)) for i in range(n_scenes)])
+            # the same VALU-issue accounting as `roofline`, from the PMC passes of the FAST instance (tools/pmc_fused.sh <tag> --arith fast)
+            fa_roof = None
+            fa_file = latest_profile("r*_pmc_fused_fast.json")
+            fa_ctr = pmc_of(fa_file, "sia_fused_kernel", args.allow_stale_profile, pairs=n_slots) if (fa_file and default_c1) else None
+            if isinstance(fa_ctr, str):
+                fa_roof = {"profile_refused": fa_ctr}
+            elif fa_ctr:
+                fa_cyc, _, _ = valu_issue_cycles(fa_ctr)
+                fa_s = dt_fa / fa_steps
+                fa_roof = {"bound": "valu", "kernel": fa_ctr["_kernel"], "achieved": fa_cyc / fa_s / 1e9, "peak": N_SIMD * PEAK_CLOCK_GHZ,
+                           "frac": fa_cyc / fa_s / 1e9 / (N_SIMD * PEAK_CLOCK_GHZ), "insts_per_launch": fa_ctr["SQ_INSTS_VALU"],
+                           "cvt_insts": fa_ctr.get("SQ_INSTS_VALU_CVT"), "sources": [fa_ctr["_file"]]}
             fast = {"what": "the timed workload with svo_hip_sia_set_option(SVO_HIP_SIA_OPT_ARITH, SVO_HIP_SIA_ARITH_FAST): opt-in, not the "
                             "reference's arithmetic (`value` above is the exact flavour)",
                     "value": n_slots * fa_steps / dt_fa, "unit": "frames/s", "steps": fa_steps, "ms_per_step": dt_fa / fa_steps * 1e3,
+                    "roofline": fa_roof,
                     "pose_err_vs_cpu_ref": {"scenes_checked": int(n_scenes), "max_rot_rad_over_scenes": float(fa_err[:, 0].max()),
                                             "max_trans_m_over_scenes": float(fa_err[:, 1].max()), "tolerance": "1e-4 rad / 1e-3 m",
                                             "n_tracked_equal_in_every_scene": bool(all(int(r_fa[i].n_tracked) == int(oracle_res[i].n_tracked) for i in range(n_scenes)))}}
@@ -676,11 +717,28 @@ def main():
             import bench_c2
             c2 = {"what": "BASELINE config C2 on this GPU, inputs resident in HBM; per-call time = best of 3 rounds of back-to-back calls after 30 ms of warm-up (python bench_c2.py gives the long form)"}
             c2["align2d"], _ = bench_c2.measure_align2d(ctx, 5000, steps=20, warmup=3)
+            # 5000 patches are 313 waves on 1024 SIMDs -- a launch-latency figure; 200 000 patches say what the kernel sustains
+            a200, _ = bench_c2.measure_align2d(ctx, 200000, steps=20, warmup=3)
+            c2["align2d_200k"] = {k_: a200[k_] for k_ in ("patches", "patches_per_s", "us_per_batch", "mean_iters", "frac_hbm")}
             c2["depth_filter"], _, sb2, pyr2 = bench_c2.measure_depth_filter(ctx, 100000, steps=20, warmup=3)
             sb2.free()
             [p_.destroy() for p_ in pyr2]
+            pf2 = latest_profile("r*_pmc_df_c2.json")
+            if pf2 and c2["depth_filter"].get("stages_us"):
+                c2["depth_filter"]["roofline"] = bench_c2.stage_rooflines(c2["depth_filter"]["stages_us"], pf2)
+            # the SAME pass through the entry the drop-in DepthFilter calls per frame (device-resident seed batch: poses down,
+            # events back, one wait), host side included -- what ships, beside the resident-array figure above
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import df_hostentry_bench
+            he = df_hostentry_bench.measure(ctx, 100000, reps=20)
+            c2["depth_filter"]["through_dropin_entry_us"] = he["resident"]["ms_per_call_median"] * 1e3
+            c2["depth_filter"]["through_dropin_entry_keyframe_us"] = he["resident_keyframe"]["ms_per_call_median"] * 1e3
+            c2["depth_filter"]["through_round3_host_buffer_entry_us"] = he["host"]["ms_per_call_median"] * 1e3
             c4, _, sb4, pyr4 = bench_c2.measure_depth_filter(ctx, 1000000, steps=5, warmup=2, width=1280, height=720, sigma_scale=0.0045,
                                                              compact=True)
+            pf4 = latest_profile("r*_pmc_df_c4.json")
+            if pf4 and c4.get("stages_us"):
+                c4["roofline"] = bench_c2.stage_rooflines(c4["stages_us"], pf4)
             c4["what"] = ("BASELINE config C4 on ONE GPU: DepthFilter::updateSeeds over 1 M seeds of a 1280x720 keyframe + packing of the "
                           "converged records on the device; the multi-GPU form (seeds sharded, RCCL gather) is bench_c4.py")
             sb4.free()
@@ -731,7 +789,7 @@ def main():
         assert scene_err[:, 0].max() < 1e-4 and scene_err[:, 1].max() < 1e-3, "pose parity violated: %s (rotation error per scene: %s)" % (scene_err.max(axis=0), np.array2string(scene_err[:, 0], precision=2))
         assert tracked_equal or args.early_stop, "n_tracked differs from the oracle's in some scene"
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        os.write(json_fd, (json.dumps(slim(out, args.verbose_json), separators=(",", ":")) + "\n").encode())
     if multi:
         dist.barrier()
         graphed = None          # captured graphs hold RCCL kernels: release them before the communicator goes away

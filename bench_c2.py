@@ -20,6 +20,68 @@ sys.path.insert(0, ROOT)
 from android_svo_amd import hip, seedsynth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
+N_SIMD = 1024                     # 256 CUs x 4 SIMD-32
+PEAK_CLOCK_GHZ = 2.4
+DF_STAGES = (("geometry", "df_geometry_kernel"), ("search", "df_search_kernel"), ("align", "df_align_kernel"), ("finalize", "df_finalize_kernel"))
+
+
+def stage_times(ctx, run_pass, repeats=5):
+    """{stage: microseconds} of the depth-filter pass, measured live with HIP events on the context stream between the
+    stages (svo_hip_df_set_profiling; the alignment stage's three launches count as one stage): the pass with the smallest
+    total of `repeats`."""
+    ctx.check(ctx.lib.svo_hip_df_set_profiling(ctx.h, 1), "df_set_profiling")
+    best = None
+    try:
+        for _ in range(repeats):
+            run_pass()
+            us = (C.c_double * 4)()
+            ctx.check(ctx.lib.svo_hip_df_get_profile(ctx.h, us), "df_get_profile")
+            best = list(us) if best is None or sum(us) < sum(best) else best
+    finally:
+        ctx.check(ctx.lib.svo_hip_df_set_profiling(ctx.h, 0), "df_set_profiling")
+    return {name: best[k] for k, (name, _) in enumerate(DF_STAGES)}
+
+
+def stage_rooflines(stages_us, pmc_path):
+    """Per stage of the depth-filter pass: {kernel, us, valu_frac, hbm_frac, bound, frac}.
+    valu_frac = VALU issue cycles of the stage's launches (per-type instruction counters of the rocprofv3 PMC passes in
+    `pmc_path`, made by tools/pmc_c2.sh: 2 cycles per wave64 f32/int instruction, 4 per f64 and per conversion, 8 per
+    transcendental -- bench.py's rule for the fused SparseImgAlign kernel) / (1024 SIMDs x 2.4 GHz x the stage's live time);
+    hbm_frac = (2 x FETCH_SIZE + WRITE_SIZE) KB of the same passes / live time / 8 TB/s.  `bound` names the larger one.
+    A profile taken from other kernel sources than the tree's is refused (returns the reason as a string)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_json
+    try:
+        d = json.load(open(pmc_path))
+    except Exception:
+        return None
+    have, want = d.get("source_sha256"), pmc_json.source_sha256("df")
+    if have != want:
+        changed = sorted(k for k in want if not have or have.get(k) != want[k])
+        return "%s was taken from other kernel sources (%s): re-run tools/pmc_c2.sh" % (os.path.relpath(pmc_path, ROOT), ", ".join(changed))
+    passes = float(d.get("passes", 4))
+    out = {}
+    for name, prefix in DF_STAGES:
+        ctr = None
+        for kname, c in d.get("kernels", {}).items():
+            if kname.startswith(prefix):
+                ctr = c
+                break
+        if ctr is None or name not in stages_us:
+            continue
+        per_pass = {k: v * ctr.get("_dispatches", {}).get(k, passes) / passes for k, v in ctr.items() if isinstance(v, (int, float))}
+        f64 = per_pass.get("SQ_INSTS_VALU_ADD_F64", 0.0) + per_pass.get("SQ_INSTS_VALU_MUL_F64", 0.0) + per_pass.get("SQ_INSTS_VALU_FMA_F64", 0.0)
+        trans = per_pass.get("SQ_INSTS_VALU_TRANS_F64", 0.0) + per_pass.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+        cvt = per_pass.get("SQ_INSTS_VALU_CVT", 0.0)
+        cyc = 2.0 * (per_pass["SQ_INSTS_VALU"] - f64 - trans - cvt) + 4.0 * (f64 + cvt) + 8.0 * trans
+        t = stages_us[name] * 1e-6
+        valu = cyc / (N_SIMD * PEAK_CLOCK_GHZ * 1e9 * t)
+        phys = (2.0 * per_pass.get("FETCH_SIZE", 0.0) + per_pass.get("WRITE_SIZE", 0.0)) * 1024.0
+        hbm = phys / t / 1e9 / HBM_PEAK_GBS
+        out[name] = {"kernel": prefix, "us": stages_us[name], "valu_frac": valu, "hbm_frac": hbm, "traffic": phys,
+                     "bound": "valu" if valu >= hbm else "hbm", "frac": max(valu, hbm)}
+    out["source"] = os.path.relpath(pmc_path, ROOT)
+    return out
 
 
 TIMED_REPEATS = 3
@@ -104,12 +166,19 @@ def measure_depth_filter(ctx, seeds=100000, steps=20, warmup=3, width=640, heigh
                                                                  C.c_void_p(sb.sigma2.ptr), C.c_void_p(sb.xyz.ptr), C.c_void_p(rec.ptr),
                                                                  C.c_void_p(cnt.ptr)), "seed_compact_converged")
     t_df = timed(ctx, run_df, steps, warmup)
+    stages = None
+    try:
+        stages = stage_times(ctx, run_df)
+    except (AttributeError, hip.SvoHipError):
+        pass                                  # a library build without the hook (A/B runs against an older build)
     nz, na, st = sb.n_zmssd.download(), sb.n_align.download(), sb.status.download()
     alg_df = float(np.sum(44 + 56 + 100 + 64 * nz.astype(np.int64) + 81 * na.astype(np.int64)))
     res = {"seeds": seeds, "image": "%dx%d" % (width, height), "seeds_per_s": seeds / t_df, "us_per_frame": t_df * 1e6,
            "status_counts": np.bincount(st, minlength=6).tolist(), "mean_zmssd": float(nz.mean()),
            "mean_align_iters": float(na.mean()), "algorithmic_bytes": alg_df,
            "algorithmic_GBps": alg_df / t_df / 1e9, "frac_hbm": alg_df / t_df / 1e9 / HBM_PEAK_GBS}
+    if stages:
+        res["stages_us"] = stages
     if compact:
         res["converged_records_packed"] = int(cnt.download()[0])
         rec.free(); cnt.free()

@@ -39,7 +39,10 @@ def main():
     # frame pairs per launch of the profiled command: every counter of these kernels is proportional to it (256 -> 1024
     # pairs: x 4.000), so bench.py scales a profile to the launch size it times
     if kind == "df":
-        json.dump({"command": cmd, "unit": "counter value per dispatch (mean over the dispatches of the pass)",
+        # tools/dfbench_only.py [seeds w h sigma_scale passes]: a stage may be several launches per pass (the alignment stage:
+        # three), so a per-pass figure is mean x dispatches / passes (bench_c2.stage_rooflines)
+        m = re.search(r"dfbench_only\.py\s+\d+\s+\d+\s+\d+\s+\S+\s+(\d+)", cmd)
+        json.dump({"command": cmd, "unit": "counter value per dispatch (mean over the dispatches of the pass)", "passes": int(m.group(1)) if m else 4,
                    "source_sha256": source_sha256("df"), "kernels": kernels}, open(dst, "w"), indent=1)
         print(dst, {k: len(v) - 1 for k, v in kernels.items()})
         return
