@@ -87,6 +87,7 @@ struct ShmHeader {
   unsigned long long slot_bytes;
   unsigned arrived;            // barrier: ranks that reached the current generation
   unsigned generation;
+  unsigned go;                 // set by rank 0 once IT has passed the first barrier: the segment belongs to a live group
 };
 constexpr unsigned kShmMagic = 0x53564f43u;      // "SVOC"
 constexpr size_t kShmHeaderBytes = 256;
@@ -283,9 +284,10 @@ int svo_hip_comm_create_shm(svo_hip_ctx* ctx, const char* name, int rank, int wo
     if (p == MAP_FAILED) return fail("mmap failed");
     c->shm = static_cast<unsigned char*>(p);
     ShmHeader* h = hdr(c);
-    h->world = (unsigned)world; h->slot_bytes = slot_bytes; h->arrived = 0; h->generation = 0;
+    h->world = (unsigned)world; h->slot_bytes = slot_bytes; h->arrived = 0; h->generation = 0; h->go = 0;
     __atomic_store_n(&h->magic, kShmMagic, __ATOMIC_RELEASE);
     if (!shm_barrier(c)) return fail("timed out at the first barrier");
+    __atomic_store_n(&h->go, 1u, __ATOMIC_RELEASE);            // the attaching ranks wait for this before they trust the segment
     shm_unlink(name);                                          // everybody has it mapped: the name can go
     *out = c;
     return SVO_HIP_OK;
@@ -340,6 +342,18 @@ int svo_hip_comm_create_shm(svo_hip_ctx* ctx, const char* name, int rank, int wo
           if (t - t_check > 0.01) { t_check = t; if (name_moved()) { restart = true; break; } }
           usleep(20);
         }
+      }
+    }
+    if (!restart) {
+      // The barrier of a DEAD segment can open too: a rank 0 that was killed while it sat in its first barrier leaves
+      // magic set and arrived == world - 1, and this rank's own increment completes the count.  Only a live rank 0 sets
+      // `go` (after it has passed the barrier itself); until then the name is watched as above.
+      double t_check = now_s();
+      while (__atomic_load_n(&h->go, __ATOMIC_ACQUIRE) != 1u) {
+        const double t = now_s();
+        if (t - t0 > c->timeout_s) return fail("timed out waiting for rank 0 behind the first barrier");
+        if (t - t_check > 0.01) { t_check = t; if (name_moved()) { restart = true; break; } }
+        usleep(20);
       }
     }
     if (!restart) break;

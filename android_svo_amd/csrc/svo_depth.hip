@@ -20,6 +20,7 @@
 // epipolar abscissa uv_i is produced by the same repeated addition uv += step as
 // S/matcher.cpp:299 (each lane replays its prefix).
 #include "svo_align_device.h"
+#include <cstddef>
 #include <vector>
 
 #include "svo_internal.h"
@@ -767,23 +768,39 @@ __global__ __launch_bounds__(ALIGN_BLOCK) void df_align_kernel(DfFrame fr, const
   const int i = blockIdx.x * ALIGN_PATCHES + (threadIdx.x >> 2);
   const int q = threadIdx.x & 3;
   const bool have = i < n;
+  if (__builtin_amdgcn_ballot_w64(have) == 0ull) return;
   SeedRec* rp = recs + (have ? i : 0);
-  const int path = have ? rp->path : -1;
-  const bool mine = ONE_D ? path == 3 : (path == 0 || path == 1);
-  const bool do_align = mine && rp->matched == 2;
-  if (__builtin_amdgcn_ballot_w64(do_align) == 0ull) return;      // wave-uniform
-  const int search_level = do_align ? rp->search_level : 0;
-  const int ccols = fr.cam.width >> search_level, crows = fr.cam.height >> search_level;
-  const uint8_t* cur_img = cur_pyr + fr.cur_level_off[search_level];
+  // ONE trip to memory for everything the quad needs: lane q takes one 16-byte word of the seed's record -- {step}, {search
+  // level, path, status, warp_nan}, {matched, counters}, {uv0} -- and its ten words of the warped patch, all asked for at
+  // once; the fields then go round the quad by DPP.  (Round 3 read `path` and `matched` first, the other fields and the
+  // patch words -- only where the seed is to be aligned -- after them: two dependent trips to HBM at the head of every
+  // wave, in a stage whose set-up part is a third of its time: 79 of 264 us at 1 M seeds, tools/df_iter_probe.py.)
+  static_assert(offsetof(SeedRec, step) == 16 && offsetof(SeedRec, search_level) == 64 && offsetof(SeedRec, path) == 68 &&
+                offsetof(SeedRec, matched) == 80 && offsetof(SeedRec, uv0) == 0, "record words read below");
+  const int word = q == 0 ? 1 : (q == 1 ? 4 : (q == 2 ? 5 : 0));
+  const uint4 mine_w = reinterpret_cast<const uint4*>(rp)[word];
   QuadPatch qp;
 #pragma unroll
-  for (int k = 0; k < 10; ++k) qp.b[k] = do_align ? pwb_t[(size_t)(5 * q + k) * n_pad + i] : 0u;
+  for (int k = 0; k < 10; ++k) qp.b[k] = pwb_t[(size_t)(5 * q + k) * n_pad + (have ? i : 0)];     // (read-only scratch: any content is valid)
+  const int search_level_r = quad_bcast<1>((int)mine_w.x);
+  const int path = have ? quad_bcast<1>((int)mine_w.y) : -1;
+  const int matched_r = quad_bcast<2>((int)mine_w.x);
+  const bool mine = ONE_D ? path == 3 : (path == 0 || path == 1);
+  const bool do_align = mine && matched_r == 2;
+  const double step0 = __hiloint2double(quad_bcast<0>((int)mine_w.y), quad_bcast<0>((int)mine_w.x));
+  const double step1 = __hiloint2double(quad_bcast<0>((int)mine_w.w), quad_bcast<0>((int)mine_w.z));
+  const double uv00 = __hiloint2double(quad_bcast<3>((int)mine_w.y), quad_bcast<3>((int)mine_w.x));
+  const double uv01 = __hiloint2double(quad_bcast<3>((int)mine_w.w), quad_bcast<3>((int)mine_w.z));
+  if (__builtin_amdgcn_ballot_w64(do_align) == 0ull) return;      // wave-uniform
+  const int search_level = do_align ? search_level_r : 0;
+  const int ccols = fr.cam.width >> search_level, crows = fr.cam.height >> search_level;
+  const uint8_t* cur_img = cur_pyr + fr.cur_level_off[search_level];
   patch_from_border(qp);
   double px_cur[2] = {0.0, 0.0};
   float dir0 = 0.0f, dir1 = 0.0f;
   if (do_align) {
-    if (ONE_D) { px_cur[0] = rp->uv0[0]; px_cur[1] = rp->uv0[1]; dir0 = (float)rp->step[0]; dir1 = (float)rp->step[1]; }
-    else { px_cur[0] = rp->step[0]; px_cur[1] = rp->step[1]; }
+    if (ONE_D) { px_cur[0] = uv00; px_cur[1] = uv01; dir0 = (float)step0; dir1 = (float)step1; }
+    else { px_cur[0] = step0; px_cur[1] = step1; }
   }
   const double inv_scale = 1.0 / (1 << search_level);    // exact: a power of two
   double us = px_cur[0] * inv_scale, vs = px_cur[1] * inv_scale;
@@ -987,28 +1004,28 @@ __global__ __launch_bounds__(256) void conv_count_kernel(int n, const int32_t* _
   if (threadIdx.x == 0) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// exclusive scan of the block counts in place, one workgroup; total -> *count
+// exclusive scan of the block counts in place, one workgroup; total -> *count.  Wave-level scans by lane shuffles and one
+// pass over the 16 wave totals per 1024 counts (round 3: a Hillis-Steele scan in LDS, 20 barriers per 1024 counts: 8.3 us
+// for the 3 907 blocks of 1 M seeds)
 __global__ __launch_bounds__(1024) void conv_scan_kernel(int n_blocks, int* __restrict__ block_count, int* __restrict__ count) {
-  __shared__ int s_part[1024];
+  __shared__ int s_part[16];
   __shared__ int s_carry;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
   for (int base = 0; base < n_blocks; base += 1024) {
     const int k = base + threadIdx.x;
     const int v = k < n_blocks ? block_count[k] : 0;
-    s_part[threadIdx.x] = v;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += t; }
+    if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = incl;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {                     // Hillis-Steele inclusive scan
-      const int t = (int)threadIdx.x >= o ? s_part[(int)threadIdx.x - o] : 0;
-      __syncthreads();
-      s_part[threadIdx.x] += t;
-      __syncthreads();
-    }
-    const int incl = s_part[threadIdx.x];
+    int wave_off = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += s_part[w];
     const int carry = s_carry;
-    if (k < n_blocks) block_count[k] = carry + incl - v;
+    if (k < n_blocks) block_count[k] = carry + wave_off + incl - v;
     __syncthreads();
-    if (threadIdx.x == 1023) s_carry = carry + incl;
+    if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
     __syncthreads();
   }
   if (threadIdx.x == 0) *count = s_carry;

@@ -2459,10 +2459,14 @@ int svo_hip_sia_download_fused_patches(svo_hip_sia* s, int slot, int level, floa
   if (!s) return SVO_HIP_ERR_INVALID;
   svo_hip_ctx* ctx = s->ctx;
   SVO_REQUIRE(ctx, slot >= 0 && slot < s->batch && s->ref && level >= 0 && level < s->ref->n_levels);
+  // the dump goes through the streaming path's cache arrays: not in the middle of a step-wise solve that is using them
+  if (s->begun)
+    return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_download_fused_patches", "a step-wise solve is in progress (svo_hip_sia_finish it first)");
   int rc = flush_fc(s);
   if (rc != SVO_HIP_OK) return rc;
   const int n = s->h_fc[slot].n_feat;
   if (n <= 0) return SVO_HIP_OK;
+  s->last_mode = 1;          // ... and what svo_hip_sia_download_caches would return from now on is this dump, not a run's caches: stale
   LevelGeom g;
   g.cols = s->ref->width >> level; g.rows = s->ref->height >> level;
   g.ref_off = s->ref->level_offset[level]; g.cur_off = 0;

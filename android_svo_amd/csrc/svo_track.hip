@@ -773,6 +773,8 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
   SVO_REQUIRE(ctx, cfg->max_keyframes <= TRK_LDS_KF);
   SVO_REQUIRE(ctx, cfg->max_keyframes >= 1 && cfg->max_points >= 1 && cfg->max_obs >= 1 && cfg->max_kf_features >= 1 && cfg->max_candidates >= 0);
   SVO_REQUIRE(ctx, cfg->max_items >= 1 && cfg->max_frame_features >= 1 && cfg->max_frame_features <= 2816);
+  // the cell loop stops AFTER the match that exceeds max_fts (reprojector.cpp:164-165): a frame can gain max_fts + 1 features
+  SVO_REQUIRE(ctx, cfg->max_frame_features >= cfg->max_fts + 1);
   SVO_REQUIRE(ctx, cfg->n_levels >= 1 && cfg->n_levels <= SVO_HIP_MAX_LEVELS && cfg->klt_max_level < cfg->n_levels && cfg->klt_min_level >= 0 &&
                        cfg->klt_min_level <= cfg->klt_max_level && cfg->sia_n_iter >= 0);
   SVO_REQUIRE(ctx, cfg->grid_size >= 1 && cfg->max_fts >= 0 && cfg->reproj_max_n_kfs >= 1 && cfg->reproj_max_n_kfs <= TRK_MAX_SEL);

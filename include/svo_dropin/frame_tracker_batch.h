@@ -189,7 +189,6 @@ class FrameTrackerT {
       }
     if ((map_dirty_ || unknown) && !uploadMap(map)) return false;
     max_n_pts = std::min(max_n_pts, pts.size());
-    if (max_n_pts > 64) max_n_pts = 64;                      // one device call (Config::structureOptimMaxPts() is 20)
     if (max_n_pts == 0) return true;
     std::nth_element(pts.begin(), pts.begin() + max_n_pts, pts.end(), LastOptimLess());
     std::vector<int32_t> idx;
@@ -202,8 +201,13 @@ class FrameTrackerT {
       if (twice) continue;
       idx.push_back(pi->second); chosen.push_back(pts[i]);
     }
+    // one device call takes at most 64 points (Config::structureOptimMaxPts() is 20): larger selections go in chunks --
+    // a point's refinement reads keyframe poses and bearings only, never another point, so the split changes nothing
     std::vector<double> pos(idx.size() * 3 + 3);
-    if (!idx.empty() && svo_hip_tracker_optimize_structure(trk_, (int)idx.size(), idx.data(), max_iter, pos.data(), NULL) != SVO_HIP_OK) return false;
+    for (size_t first = 0; first < idx.size(); first += 64) {
+      const size_t n_here = std::min<size_t>(64, idx.size() - first);
+      if (svo_hip_tracker_optimize_structure(trk_, (int)n_here, idx.data() + first, max_iter, pos.data() + 3 * first, NULL) != SVO_HIP_OK) return false;
+    }
     for (size_t i = 0; i < chosen.size(); ++i) {
       chosen[i]->pos_[0] = pos[3 * i]; chosen[i]->pos_[1] = pos[3 * i + 1]; chosen[i]->pos_[2] = pos[3 * i + 2];
     }

@@ -213,3 +213,31 @@ def test_adopted_nccl_communicator(tmp_path):
     assert rccl.ncclCommDestroy(comm_ptr) == 0
     ctx.close()
 
+
+
+def test_dead_segment_of_a_killed_rank0_is_not_joined(tmp_path):
+    """A rank 0 that was killed while it sat in its first barrier leaves a segment with the magic set and arrived == world - 1
+    under the group's name: the barrier of that DEAD segment opens for the next attaching rank's own increment.  The attaching
+    rank must not trust a segment until a live rank 0 has set `go` behind the barrier -- it keeps watching the name and moves
+    to the segment the new rank 0 creates."""
+    import struct
+    import time
+    token = "/svo_test_" + uuid.uuid4().hex[:12]
+    world, slot_bytes = 2, 8 << 20                       # comm_worker.py's geometry
+    total = 256 + world * slot_bytes
+    path = "/dev/shm" + token
+    with open(path, "wb") as fh:                         # header: magic, world, slot_bytes (u64), arrived, generation, go
+        fh.write(struct.pack("<IIQIII", 0x53564F43, world, slot_bytes, world - 1, 0, 0))
+        fh.truncate(total)
+    outs = [str(tmp_path / ("dead_%d.npz" % r)) for r in range(world)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    start = lambda r: subprocess.Popen([sys.executable, WORKER, "seeds", "shm", str(r), str(world), token, outs[r]], cwd=ROOT, env=env,
+                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    p1 = start(1)                                        # the attaching rank first: it finds the dead segment under the name
+    time.sleep(4.0)
+    p0 = start(0)
+    for p in (p0, p1):
+        so, se = p.communicate(timeout=200)
+        assert p.returncode == 0, se.decode()[-3000:]
+    _check_seeds([dict(np.load(o)) for o in outs], world)
+    assert not os.path.exists(path)                      # rank 0 removed the name once everybody was in

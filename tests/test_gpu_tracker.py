@@ -550,7 +550,8 @@ def test_tracker_refuses_bad_arguments(ctx):
     mp = tc.sequence_map(seq)
     cam = seq["cam"]
     n = len(seq["px0"])
-    for bad in (dict(max_keyframes=0), dict(max_keyframes=257), dict(max_frame_features=5000), dict(reproj_max_n_kfs=17), dict(klt_max_level=7)):
+    for bad in (dict(max_keyframes=0), dict(max_keyframes=257), dict(max_frame_features=5000), dict(reproj_max_n_kfs=17), dict(klt_max_level=7),
+                dict(max_fts=1200, max_frame_features=1200)):             # a frame can gain max_fts + 1 features (reprojector.cpp:164-165)
         with pytest.raises(hip.SvoHipError):
             hip.Tracker(ctx, cam, **bad)
     trk = hip.Tracker(ctx, cam, max_keyframes=2, max_points=n, grid_size=tc.CELL, max_fts=tc.MAX_FTS, max_frame_features=256)
