@@ -542,6 +542,14 @@ class ResidentSeeds:
                                                                     _ptr(Tc, C.c_double), C.byref(prm), 1 if report_updated else 0),
                        "seed_batch_update_async")
 
+    def collect_raw(self):
+        """(address of the batch's page-locked event block, number of events, status counts [7]) -- no copy"""
+        ev = C.POINTER(CSeedEvent)()
+        n = C.c_int(0)
+        counts = (C.c_int32 * 7)()
+        self.ctx.check(self.ctx.lib.svo_hip_seed_batch_collect(self.h, C.byref(ev), C.byref(n), counts), "seed_batch_collect")
+        return (C.addressof(ev.contents) if n.value else 0), n.value, np.array(list(counts), dtype=np.int64)
+
     def collect(self):
         """(events as a structured array -- a copy --, status counts [7]: slot = status + 1)"""
         ev = C.POINTER(CSeedEvent)()

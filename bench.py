@@ -239,7 +239,9 @@ PREWARM_S = 0.1
 
 # keys that hold explanations, not measurements: left out of the JSON line unless --verbose-json (profiles/BENCH_KEYS.md
 # says what every key means; round 3's 14 kB line lost its first half in the driver's tail)
-PROSE_KEYS = {"what", "note", "rule", "traffic_rule", "sample", "legs", "measured_ceiling"}
+PROSE_KEYS = {"what", "note", "rule", "traffic_rule", "sample", "legs", "measured_ceiling", "ms_per_frame_image_in_tracker_buffer_median",
+              "ms_per_frame_min", "algorithmic_bytes", "algorithmic_GBps", "nproc", "cpus_granted_to_this_process", "patches_per_s",
+              "seeds_per_s"}
 
 
 def slim(o, verbose=False):
@@ -555,7 +557,7 @@ def main():
                 ctr = None
             if mode == 1:
                 roofline = {"bound": "valu", "kernel": kernel, "achieved": None, "peak": N_SIMD * PEAK_CLOCK_GHZ,
-                            "unit": "G VALU issue-cycles/s (1024 SIMD-32 x 2.4 GHz)", "frac": None, "traffic": None,
+                            "unit": "G VALU issue-cycles/s", "frac": None, "traffic": None,
                             "avg_launch_us": avg_ms * 1e3, "launches": int(launches), "algorithmic": alg,
                             "note": "one launch = whole coarse-to-fine solve of %d frame pairs (150 Gauss-Newton evaluations each); the kernel is "
                                     "bound by VALU issue (f32 image math + fp64 projection / normal equations) plus a serial solve phase between two "
@@ -734,7 +736,7 @@ def main():
             c2["depth_filter"]["through_dropin_entry_us"] = he["resident"]["ms_per_call_median"] * 1e3
             c2["depth_filter"]["through_dropin_entry_keyframe_us"] = he["resident_keyframe"]["ms_per_call_median"] * 1e3
             c2["depth_filter"]["through_round3_host_buffer_entry_us"] = he["host"]["ms_per_call_median"] * 1e3
-            c4, _, sb4, pyr4 = bench_c2.measure_depth_filter(ctx, 1000000, steps=5, warmup=2, width=1280, height=720, sigma_scale=0.0045,
+            c4, _, sb4, pyr4 = bench_c2.measure_depth_filter(ctx, 1000000, steps=10, warmup=2, width=1280, height=720, sigma_scale=0.0045,
                                                              compact=True)
             pf4 = latest_profile("r*_pmc_df_c4.json")
             if pf4 and c4.get("stages_us"):

@@ -43,7 +43,8 @@ def stage_times(ctx, run_pass, repeats=5):
 
 
 def stage_rooflines(stages_us, pmc_path):
-    """Per stage of the depth-filter pass: {kernel, us, valu_frac, hbm_frac, bound, frac}.
+    """Per stage of the depth-filter pass (kernel df_<stage>_kernel; its live time is stages_us[stage]): {bound, frac, valu_frac,
+    hbm_frac}.
     valu_frac = VALU issue cycles of the stage's launches (per-type instruction counters of the rocprofv3 PMC passes in
     `pmc_path`, made by tools/pmc_c2.sh: 2 cycles per wave64 f32/int instruction, 4 per f64 and per conversion, 8 per
     transcendental -- bench.py's rule for the fused SparseImgAlign kernel) / (1024 SIMDs x 2.4 GHz x the stage's live time);
@@ -78,8 +79,7 @@ def stage_rooflines(stages_us, pmc_path):
         valu = cyc / (N_SIMD * PEAK_CLOCK_GHZ * 1e9 * t)
         phys = (2.0 * per_pass.get("FETCH_SIZE", 0.0) + per_pass.get("WRITE_SIZE", 0.0)) * 1024.0
         hbm = phys / t / 1e9 / HBM_PEAK_GBS
-        out[name] = {"kernel": prefix, "us": stages_us[name], "valu_frac": valu, "hbm_frac": hbm, "traffic": phys,
-                     "bound": "valu" if valu >= hbm else "hbm", "frac": max(valu, hbm)}
+        out[name] = {"bound": "valu" if valu >= hbm else "hbm", "frac": max(valu, hbm), "valu_frac": valu, "hbm_frac": hbm}
     out["source"] = os.path.relpath(pmc_path, ROOT)
     return out
 
