@@ -289,7 +289,7 @@ int main(int argc, char** argv) {
       c.frames[kf2]->setKeyframe();
       size_t align_runs = 0;
       std::vector<double> conv_count;
-      auto run_protocol = [&](bool threaded, int sub_batch, const std::string& tag) {
+      auto run_protocol = [&](bool threaded, int sub_batch, const std::string& tag, int remove_a_after = -1) {
         Seed::batch_counter = 0;
         std::vector<double> conv;                 // per callback, in callback order: seed id, x, y, z, sigma2
         std::map<Feature*, int> index;
@@ -320,6 +320,16 @@ int main(int argc, char** argv) {
             if (k == kf2) df.addKeyframe(c.frames[k], dm[0], dm[1], fb);
             else df.addFrame(c.frames[k]);
             wait_idle();
+            if (k == remove_a_after) {
+              // Map::removeKeyframe path (depth_filter.cpp:153-170): every seed of the SECOND keyframe leaves the list BEHIND the
+              // device mirror's back (removeKeyframe is not virtual in the reference); a copy taken just before shows the synced state
+              std::list<Seed> copy_a;
+              df.getSeedsCopy(c.frames[kf2], copy_a);
+              std::vector<double> rows;
+              for (const Seed& s : copy_a) { rows.push_back((double)index.at(s.ftr)); rows.push_back(s.a); rows.push_back(s.b); rows.push_back(s.mu); rows.push_back(s.sigma2); }
+              write_bin(out + "/" + tag + "_copy_b.bin", rows);
+              df.removeKeyframe(c.frames[kf2]);
+            }
           }
           if (threaded) df.stopThread();
           dump_filter(df, index, conv, out, tag);
@@ -333,7 +343,8 @@ int main(int argc, char** argv) {
       run_protocol(false, 4096, "sync");          // (a) synchronous protocol (no thread)
       run_protocol(false, 700, "sync_small");     // (b) the same with small device sub-batches: identical results
       run_protocol(true, 4096, "thread");         // (c) worker thread, while this thread keeps running SparseImgAlign
-      write_bin(out + "/summary.bin", std::vector<double>{(double)align_runs, conv_count[0], conv_count[1], conv_count[2]});
+      run_protocol(false, 1000, "remove", kf2 + 1);   // (d) the second keyframe removed one frame after it came: its seeds vanish from the list
+      write_bin(out + "/summary.bin", std::vector<double>{(double)align_runs, conv_count[0], conv_count[1], conv_count[2], conv_count[3]});
     }
     std::printf("svo_host_demo OK\n");
     return 0;

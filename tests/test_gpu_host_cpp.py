@@ -104,8 +104,9 @@ def test_cpp_host_layer_end_to_end(tmp_path, dist):
     # initialises seeds (depth_filter.cpp:109-123), with it the keyframe itself is also an update frame (:191-229).
     cell, gcols, grows = 30, int(np.ceil(cam.width / 30)), int(np.ceil(cam.height / 30))
 
-    def replay(update_on_keyframe):
+    def replay(update_on_keyframe, remove_a_after=None):
         st = []
+        copy_a = None
         for (kf, spx, sf, slevel) in sets:
             a, b, mu, zr, s2 = seedsynth.seed_ctor(1.1 * zbar, 0.5 * zbar, len(spx))
             st.append(dict(kf=kf, px=spx, f=sf, level=slevel, a=a, b=b, mu=mu, zr=zr, s2=s2, alive=np.ones(len(spx), dtype=bool),
@@ -115,7 +116,7 @@ def test_cpp_host_layer_end_to_end(tmp_path, dist):
             if k != kf2 or update_on_keyframe:
                 id0 = 0
                 for S in st:
-                    if S["active"]:
+                    if S["active"] and S["alive"].any():
                         idx = np.where(S["alive"])[0]
                         aa, bb, mm, ss = (S[v][idx].copy() for v in ("a", "b", "mu", "s2"))
                         res = orc.update_seeds(cam, pyrs[S["kf"]], pyrs[k], poses[S["kf"]], poses[k], S["px"][idx], S["f"][idx],
@@ -131,7 +132,11 @@ def test_cpp_host_layer_end_to_end(tmp_path, dist):
                     id0 += len(S["px"])
             if k == kf2:
                 st[1]["active"] = True
-        return st, conv, grid
+            if k == remove_a_after:                     # DepthFilter::removeKeyframe(second keyframe): its seeds leave the list
+                S = st[1]
+                copy_a = np.stack([np.where(S["alive"])[0].astype(np.float64)] + [S[v][S["alive"]].astype(np.float64) for v in ("a", "b", "mu", "s2")], axis=1)
+                S["alive"][:] = False
+        return (st, conv, grid, copy_a) if remove_a_after is not None else (st, conv, grid)
 
     summary = np.fromfile(out / "summary.bin")
     expected = {"sync": replay(False), "sync_small": None, "thread": replay(True)}
@@ -163,6 +168,22 @@ def test_cpp_host_layer_end_to_end(tmp_path, dist):
         # converged points are where the plane is
         d = np.abs((conv[:, 1:4] - scene.d * scene.n / (scene.n @ scene.n)) @ scene.n)
         assert np.median(d) < 0.05
+    # (d) the second keyframe removed behind the mirror's back one frame after it came (DepthFilter::removeKeyframe is not
+    # virtual): the copy taken just before holds the device state of its seeds after their one update, afterwards the first
+    # keyframe's seeds go on as if nothing had happened -- same callbacks in the same order as the plain run
+    st, conv_expected, _, copy_expected = replay(False, remove_a_after=kf2 + 1)
+    rows = np.fromfile(out / "remove_seeds.bin").reshape(-1, 5)
+    conv = np.fromfile(out / "remove_conv.bin").reshape(-1, 5)
+    copy_b = np.fromfile(out / "remove_copy_b.bin").reshape(-1, 5)
+    assert int(summary[4]) == len(conv) == len(conv_expected) and len(conv) > 0.2 * 3000
+    np.testing.assert_array_equal(conv[:, 0].astype(int), np.array([c[0] for c in conv_expected]))
+    assert (conv[:, 0] < 3000).all()
+    np.testing.assert_array_equal(copy_b[:, 0].astype(int), 3000 + copy_expected[:, 0].astype(int))
+    np.testing.assert_allclose(copy_b[:, 1:], copy_expected[:, 1:], rtol=1e-5)          # getSeedsCopy sees the device's state
+    assert len(copy_b) > 1000 and not st[1]["alive"].any()
+    assert not np.allclose(copy_b[:, 3], seedsynth.seed_ctor(1.1 * zbar, 0.5 * zbar, 1)[2][0])      # ... not the constructor's mu
+    np.testing.assert_array_equal(rows[:, 0].astype(int), np.where(st[0]["alive"])[0])
+    np.testing.assert_allclose(rows[:, 3], st[0]["mu"][st[0]["alive"]], rtol=1e-5)
     # device sub-batch size does not change anything
     np.testing.assert_array_equal(np.fromfile(out / "sync_seeds.bin"), np.fromfile(out / "sync_small_seeds.bin"))
     np.testing.assert_array_equal(np.fromfile(out / "sync_conv.bin"), np.fromfile(out / "sync_small_conv.bin"))
