@@ -664,14 +664,14 @@ constexpr int FUSED_EXTRA_TILES = 3;              // 8-wave shape: at most this 
 constexpr int FUSED_MAX_TPW = 6;                  // the older wave's share of a SIMD's 11 tiles
 constexpr int FUSED_EXACT_ROW_BELOW = 16;         // frames with fewer patches: H rows entry by entry (fused_tile_row_exact)
 // instances of a kernel shape: the plain one, the one whose workgroups may take the exact rows, the fast arithmetic
-constexpr int FUSED_PLAIN = 0, FUSED_EXACT_ROWS = 1, FUSED_FAST = 2;
+constexpr int FUSED_PLAIN = 0, FUSED_EXACT_ROWS = 1, FUSED_FAST = 2, FUSED_M32 = 3;
 
 struct FusedLevels {
   int cols[SVO_HIP_MAX_LEVELS], rows[SVO_HIP_MAX_LEVELS];
   unsigned long long ref_off[SVO_HIP_MAX_LEVELS], cur_off[SVO_HIP_MAX_LEVELS];
 };
 
-struct FusedParams { int max_level, min_level, n_iter, early_stop; double eps; };
+struct FusedParams { int max_level, min_level, n_iter, early_stop; double eps; int moments_f32; };
 
 // interpolated value at footprint row pair (R, Rn) and byte column k, with the reference's operation order
 SVO_DEV float interp_at(uint2 R, uint2 Rn, int k, float a_tl, float a_tr, float a_bl, float a_br) {
@@ -1002,6 +1002,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
   // loop registers -- 36 instead of 20 spilled VGPRs in <8,4,2>, -1.4 % fixed work, -3 % with the reference's exits.
   constexpr bool EXACT_ROWS = VARIANT == FUSED_EXACT_ROWS;
   constexpr bool FAST = VARIANT == FUSED_FAST;
+  // SVO_HIP_SIA_ARITH_MOMENTS_F32: the reference's residuals and chi2, the two gradient moments of a patch summed in f32.
+  // The EXACT_ROWS instance (a batch that holds a frame of a handful of patches) takes the level from a kernel argument, so
+  // that a frame's result does not depend on the company it is launched in.
+  const bool M32 = VARIANT == FUSED_M32 || (VARIANT == FUSED_EXACT_ROWS && prm.moments_f32 != 0);
   const bool exact_rows = EXACT_ROWS && n < FUSED_EXACT_ROW_BELOW;
   const int n_tiles = (n + TILE - 1) / TILE;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPRs
@@ -1323,6 +1327,13 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
               const float inten = interp_at(Cr[y], Cr[y + 1], x, g.w_tl, g.w_tr, g.w_bl, g.w_br);
               const float res = inten - refv;                                      // half the residual
               chi += res * res;
+              if (M32) {
+                // the 16 products dx * res, dy * res of a patch accumulated in f32 (fused: one rounding per term) instead of
+                // exactly in f64: three conversions and two f64 operations per pixel less; residuals and chi2 untouched
+                sdxf = __builtin_fmaf(dxv, res, sdxf);
+                sdyf = __builtin_fmaf(dyv, res, sdyf);
+                continue;
+              }
               const double dres = (double)res;
               // f32 x f32 is exact in f64 (48-bit product): the fused form rounds exactly like mul + add
               sdx = __builtin_fma((double)dxv, dres, sdx);
@@ -1331,7 +1342,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sia_fused_kernel(
           }
         }
         // ---- normal equations
-        if (FAST) { sdx = (double)sdxf; sdy = (double)sdyf; }
+        if (FAST || M32) { sdx = (double)sdxf; sdy = (double)sdyf; }
         const bool lin = ok && jvalid;
         if (ok) { acc_chi += (double)chi; acc_n += 16; }
         if (lin) {
@@ -1729,7 +1740,7 @@ struct svo_hip_sia {
   bool fc_dirty = true;
   int shard_rank = 0, shard_world = 1;
   // tuning / diagnostic switches of this object (svo_hip_sia_set_option); 0 / -1 = automatic
-  int opt_mode = 0, opt_waves = 0, opt_chunks = 0, opt_extra_lds = -1, opt_old_tiles = 0, opt_arith = SVO_HIP_SIA_ARITH_EXACT;
+  int opt_mode = 0, opt_waves = 0, opt_chunks = 0, opt_extra_lds = -1, opt_old_tiles = 0, opt_arith = SVO_HIP_SIA_ARITH_MOMENTS_F32;
   // stepwise state
   svo_hip_sia_params prm{};
   int n_slots = 0, level = -1, chunks = 1;
@@ -1823,6 +1834,7 @@ int launch_fused_x(svo_hip_sia* s, int n_launch, const svo_hip_sia_params* prm, 
   FusedParams fp;
   fp.max_level = prm->max_level; fp.min_level = prm->min_level; fp.n_iter = prm->n_iter;
   fp.early_stop = prm->early_stop; fp.eps = prm->eps;
+  fp.moments_f32 = s->opt_arith == SVO_HIP_SIA_ARITH_MOMENTS_F32 ? 1 : 0;
   hipLaunchKernelGGL((sia_fused_kernel<NW, TPW, CK, VARIANT>), dim3(n_launch), dim3(NW * 64), lds_bytes, ctx->stream, s->fc, s->st,
                      s->ref->base, s->cur->base, s->ref->pyr_bytes, lv, s->max_n, s->px, s->f, s->pos, s->has_point, s->sxyz, s->tile_h,
                      s->wmem, s->max_tiles, fp, tiles_young, n_extra);
@@ -1946,10 +1958,11 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) {
   }
   hipEvent_t* ev = next_events(s, s->ev_res, s->ev_res_used);
   if (ev) (void)hipEventRecord(ev[0], ctx->stream);
-  // (the fast arithmetic is an option of the plain instance: a batch with a tiny frame runs in the reference's arithmetic)
+  // (the fast arithmetic is an option of the plain instance: a batch with a tiny frame runs with exact or f32 moments, as set)
   rc = tiny ? launch_fused_shape<FUSED_EXACT_ROWS>(s, n_slots, max_n, prm)
-            : (s->opt_arith == SVO_HIP_SIA_ARITH_FAST ? launch_fused_shape<FUSED_FAST>(s, n_slots, max_n, prm)
-                                                      : launch_fused_shape<FUSED_PLAIN>(s, n_slots, max_n, prm));
+            : s->opt_arith == SVO_HIP_SIA_ARITH_FAST ? launch_fused_shape<FUSED_FAST>(s, n_slots, max_n, prm)
+            : s->opt_arith == SVO_HIP_SIA_ARITH_MOMENTS_F32 ? launch_fused_shape<FUSED_M32>(s, n_slots, max_n, prm)
+                                                            : launch_fused_shape<FUSED_PLAIN>(s, n_slots, max_n, prm);
   if (ev) (void)hipEventRecord(ev[1], ctx->stream);
   return rc;
 }
@@ -2351,7 +2364,10 @@ int svo_hip_sia_set_option(svo_hip_sia* s, int option, int value) {
     case SVO_HIP_SIA_OPT_CHUNKS: SVO_REQUIRE(ctx, value >= 0 && value <= MAX_CHUNKS); s->opt_chunks = value; break;
     case SVO_HIP_SIA_OPT_EXTRA_LDS: SVO_REQUIRE(ctx, value >= -1 && value <= FUSED_EXTRA_TILES); s->opt_extra_lds = value; break;
     case SVO_HIP_SIA_OPT_OLD_TILES: SVO_REQUIRE(ctx, value >= 0 && value <= FUSED_MAX_TPW); s->opt_old_tiles = value; break;
-    case SVO_HIP_SIA_OPT_ARITH: SVO_REQUIRE(ctx, value == SVO_HIP_SIA_ARITH_EXACT || value == SVO_HIP_SIA_ARITH_FAST); s->opt_arith = value; break;
+    case SVO_HIP_SIA_OPT_ARITH:
+      SVO_REQUIRE(ctx, value == SVO_HIP_SIA_ARITH_EXACT || value == SVO_HIP_SIA_ARITH_FAST || value == SVO_HIP_SIA_ARITH_MOMENTS_F32);
+      s->opt_arith = value;
+      break;
     default: return svo_fail(ctx, SVO_HIP_ERR_INVALID, "svo_hip_sia_set_option", "unknown option");
   }
   return SVO_HIP_OK;

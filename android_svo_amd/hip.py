@@ -22,7 +22,7 @@ SEED_BEHIND, SEED_NOT_IN_FRAME, SEED_NO_MATCH, SEED_UPDATED, SEED_CONVERGED, SEE
 # svo_hip_sia_set_option (per solver object; the library itself reads no environment variable)
 SIA_OPT_MODE, SIA_OPT_WAVES, SIA_OPT_CHUNKS, SIA_OPT_EXTRA_LDS, SIA_OPT_OLD_TILES, SIA_OPT_ARITH = range(6)
 SIA_MODE_AUTO, SIA_MODE_STREAM = 0, 1
-SIA_ARITH_EXACT, SIA_ARITH_FAST = 0, 1      # include/svo_hip.h: the reference's arithmetic / contracted f32 sums in the fused kernel
+SIA_ARITH_EXACT, SIA_ARITH_FAST, SIA_ARITH_MOMENTS_F32 = 0, 1, 2      # include/svo_hip.h: the reference's arithmetic / contracted f32 sums in the fused kernel
 # options every SparseImgAlign object created from now on starts with: {option: value}.  Test fixtures and A/B scripts
 # set this (a Python-side default, applied per object through the C-ABI).
 SIA_DEFAULT_OPTIONS: dict = {}

@@ -72,9 +72,10 @@ def parse_args():
     ap.add_argument("--stream-mode", action="store_true",
                     help="time the streaming implementation (one launch per Gauss-Newton evaluation) instead of the fused kernel: the run the PMC "
                          "passes of the Jacobian pass profile (tools/pmc_stream.sh)")
-    ap.add_argument("--arith", choices=["exact", "fast"], default="exact",
-                    help="arithmetic of the fused kernel in the TIMED workload: exact = the reference's (the headline); fast = the opt-in "
-                         "SVO_HIP_SIA_ARITH_FAST flavour -- for the PMC passes of that instance (tools/pmc_fused.sh <tag> --arith fast), not the headline")
+    ap.add_argument("--arith", choices=["default", "exact", "fast"], default="default",
+                    help="arithmetic level of the fused kernel in the TIMED workload: default = the library's (SVO_HIP_SIA_ARITH_MOMENTS_F32: the "
+                         "reference's residuals and chi2, a patch's two gradient moments summed in f32 -- the headline); exact / fast = the other "
+                         "two levels, for their PMC passes (tools/pmc_fused.sh <tag> --arith exact), reported as secondary sections")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose-json", action="store_true", help="keep the explanatory strings in the JSON line (default: numbers and sources only; "
                                                                 "what every key means is in profiles/BENCH_KEYS.md)")
@@ -390,8 +391,9 @@ def main():
     sia.set_frames(ref, cur)
     if args.stream_mode:
         sia.set_mode(stream=True)
-    if args.arith == "fast":
-        sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_FAST)
+    ARITH_OF = {"default": hip.SIA_ARITH_MOMENTS_F32, "exact": hip.SIA_ARITH_EXACT, "fast": hip.SIA_ARITH_FAST}
+    if args.arith != "default":
+        sia.set_option(hip.SIA_OPT_ARITH, ARITH_OF[args.arith])
     if allreduce:
         # every rank holds every frame of the global batch (same seeds on all ranks), evaluates its patch shard
         fps = make_scenes(12345)
@@ -550,7 +552,8 @@ def main():
                    "note": "SURVEY 8(d): 945 B/patch/level + 881 B/patch/evaluation in the REFERENCE's data layout (768 B of fp64 Jacobian "
                            "cache per patch); the kernels form H and Jres from {sum dx^2, sum dx dy, sum dy^2} and two moments per patch and "
                            "never move that stream, so this ratio is not a roofline fraction"}
-            pmc_file = latest_profile(("r*_pmc_fused_fast.json" if args.arith == "fast" else "r*_pmc_fused.json") if mode == 1 else "r*_pmc_stream.json")
+            pmc_file = latest_profile({"default": "r*_pmc_fused.json", "exact": "r*_pmc_fused_exact.json", "fast": "r*_pmc_fused_fast.json"}[args.arith]
+                                      if mode == 1 else "r*_pmc_stream.json")
             ctr = pmc_of(pmc_file, kernel, args.allow_stale_profile, pairs=n_slots) if (pmc_file and default_c1) else None
             profile_refused = ctr if isinstance(ctr, str) else None
             if profile_refused:
@@ -618,6 +621,7 @@ def main():
         # ---- secondary measurements, outside the timed region (rank 0, one GPU, default workload)
         early = None
         fast = None
+        exact_sec = None
         jac = None
         upl = None
         if not allreduce and world == 1 and not args.no_secondary and not args.early_stop:
@@ -639,41 +643,42 @@ def main():
                      "pose_err_vs_cpu_ref": {"rot_rad": rot_es, "trans_m": trans_es},
                      "pose_err_vs_ground_truth": dict(zip(("rot_rad", "trans_m"), synth.pose_error(np.array(r_es.T_cur_w), fps[0].T_cur_w_true)))}
             assert rot_es < 1e-4 and trans_es < 1e-3, "early-stop pose parity violated: %g rad %g m" % (rot_es, trans_es)
-            # (1b) the same batch, fixed work, with the opt-in fast arithmetic of the fused kernel (SVO_HIP_SIA_ARITH_FAST:
-            # contracted interpolation, f32 sums over a patch's 16 pixels), every distinct scene against the CPU oracle
-            sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_FAST)
-            try:
-                prewarm(ctx, lambda: sia.run(n_slots, prm))
-                fa_steps = max(5, min(args.steps, 20))
-                t1 = time.perf_counter()
-                for _ in range(fa_steps):
-                    sia.run(n_slots, prm)
-                ctx.sync()
-                dt_fa = time.perf_counter() - t1
-                r_fa = sia.download_all(n_slots)
-            finally:
-                sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_EXACT)
-            fa_err = np.array([synth.pose_error(np.array(r_fa[i].T_cur_w), np.array(oracle_res[i].T_cur_w)) for i in range(n_scenes)])
-            # the same VALU-issue accounting as `roofline`, from the PMC passes of the FAST instance (tools/pmc_fused.sh <tag> --arith fast)
-            fa_roof = None
-            fa_file = latest_profile("r*_pmc_fused_fast.json")
-            fa_ctr = pmc_of(fa_file, "sia_fused_kernel", args.allow_stale_profile, pairs=n_slots) if (fa_file and default_c1) else None
-            if isinstance(fa_ctr, str):
-                fa_roof = {"profile_refused": fa_ctr}
-            elif fa_ctr:
-                fa_cyc, _, _ = valu_issue_cycles(fa_ctr)
-                fa_s = dt_fa / fa_steps
-                fa_roof = {"bound": "valu", "kernel": fa_ctr["_kernel"], "achieved": fa_cyc / fa_s / 1e9, "peak": N_SIMD * PEAK_CLOCK_GHZ,
-                           "frac": fa_cyc / fa_s / 1e9 / (N_SIMD * PEAK_CLOCK_GHZ), "insts_per_launch": fa_ctr["SQ_INSTS_VALU"],
-                           "cvt_insts": fa_ctr.get("SQ_INSTS_VALU_CVT"), "sources": [fa_ctr["_file"]]}
-            fast = {"what": "the timed workload with svo_hip_sia_set_option(SVO_HIP_SIA_OPT_ARITH, SVO_HIP_SIA_ARITH_FAST): opt-in, not the "
-                            "reference's arithmetic (`value` above is the exact flavour)",
-                    "value": n_slots * fa_steps / dt_fa, "unit": "frames/s", "steps": fa_steps, "ms_per_step": dt_fa / fa_steps * 1e3,
-                    "roofline": fa_roof,
-                    "pose_err_vs_cpu_ref": {"scenes_checked": int(n_scenes), "max_rot_rad_over_scenes": float(fa_err[:, 0].max()),
-                                            "max_trans_m_over_scenes": float(fa_err[:, 1].max()), "tolerance": "1e-4 rad / 1e-3 m",
-                                            "n_tracked_equal_in_every_scene": bool(all(int(r_fa[i].n_tracked) == int(oracle_res[i].n_tracked) for i in range(n_scenes)))}}
-            assert fa_err[:, 0].max() < 1e-4 and fa_err[:, 1].max() < 1e-3, "fast-arithmetic pose parity violated: %s" % fa_err.max(axis=0)
+            # (1b) the same batch, fixed work, at the two other arithmetic levels of the fused kernel -- EXACT (the reference's
+            # arithmetic to the last operation) and FAST (contracted interpolation, f32 sums) --, every distinct scene against the CPU oracle
+            other = {}
+            for lvl_name, lvl, prof_pat in (("exact", hip.SIA_ARITH_EXACT, "r*_pmc_fused_exact.json"), ("fast", hip.SIA_ARITH_FAST, "r*_pmc_fused_fast.json")):
+                sia.set_option(hip.SIA_OPT_ARITH, lvl)
+                try:
+                    prewarm(ctx, lambda: sia.run(n_slots, prm))
+                    fa_steps = max(5, min(args.steps, 20))
+                    t1 = time.perf_counter()
+                    for _ in range(fa_steps):
+                        sia.run(n_slots, prm)
+                    ctx.sync()
+                    dt_fa = time.perf_counter() - t1
+                    r_fa = sia.download_all(n_slots)
+                finally:
+                    sia.set_option(hip.SIA_OPT_ARITH, ARITH_OF[args.arith])
+                fa_err = np.array([synth.pose_error(np.array(r_fa[i].T_cur_w), np.array(oracle_res[i].T_cur_w)) for i in range(n_scenes)])
+                # the same VALU-issue accounting as `roofline`, from the PMC passes of that instance (tools/pmc_fused.sh <tag> --arith <level>)
+                fa_roof = None
+                fa_file = latest_profile(prof_pat)
+                fa_ctr = pmc_of(fa_file, "sia_fused_kernel", args.allow_stale_profile, pairs=n_slots) if (fa_file and default_c1) else None
+                if isinstance(fa_ctr, str):
+                    fa_roof = {"profile_refused": fa_ctr}
+                elif fa_ctr:
+                    fa_cyc, _, _ = valu_issue_cycles(fa_ctr)
+                    fa_s = dt_fa / fa_steps
+                    fa_roof = {"bound": "valu", "frac": fa_cyc / fa_s / 1e9 / (N_SIMD * PEAK_CLOCK_GHZ), "insts_per_launch": fa_ctr["SQ_INSTS_VALU"],
+                               "cvt_insts": fa_ctr.get("SQ_INSTS_VALU_CVT"), "sources": [fa_ctr["_file"]]}
+                other[lvl_name] = {"what": "the timed workload with svo_hip_sia_set_option(SVO_HIP_SIA_OPT_ARITH, SVO_HIP_SIA_ARITH_%s)" % lvl_name.upper(),
+                                   "value": n_slots * fa_steps / dt_fa, "unit": "frames/s", "ms_per_step": dt_fa / fa_steps * 1e3,
+                                   "roofline": fa_roof,
+                                   "pose_err_vs_cpu_ref": {"max_rot_rad_over_scenes": float(fa_err[:, 0].max()),
+                                                           "max_trans_m_over_scenes": float(fa_err[:, 1].max()),
+                                                           "n_tracked_equal_in_every_scene": bool(all(int(r_fa[i].n_tracked) == int(oracle_res[i].n_tracked) for i in range(n_scenes)))}}
+                assert fa_err[:, 0].max() < 1e-4 and fa_err[:, 1].max() < 1e-3, "%s-arithmetic pose parity violated: %s" % (lvl_name, fa_err.max(axis=0))
+            fast, exact_sec = other["fast"], other["exact"]
             # (2) the streaming implementation of the Jacobian / residual pass: the HBM-bound form (north_star: >= 50 % of the HBM roofline)
             sia.set_mode(stream=True)           # an option of this solver object (svo_hip_sia_set_option), not a process-wide switch
             try:
@@ -757,7 +762,8 @@ def main():
                              (world, n_dev, ", shared-memory exchange instead of RCCL" if allreduce else "")} if rehearsal else {}),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 normal equations / f32 image math (as the reference)", "data": "synthetic",
+            "dtype": "f64 normal equations / f32 image math" + {"default": " (a patch's two gradient moments summed in f32)", "exact": " (as the reference)",
+                                                                 "fast": " (contracted, f32 sums per patch)"}[args.arith], "data": "synthetic",
             "config": {"workload": "%s: SparseImgAlign %dx%d, %d patches, 5 pyramid levels (L4-L0), %s" %
                                    ("C1" if args.width == 640 else "C3 shape", args.width, args.height, n_feat, "reference early-stop GN" if args.early_stop else "30 GN evaluations per level (fixed work)"),
                        "frame_pairs_per_gpu_per_step": B, "global_frame_pairs_per_step": frames_global,
@@ -765,7 +771,8 @@ def main():
                                        ("RCCL called by libsvo_hip.so (svo_hip_sia_run_sharded)" if native else "torch.distributed driver") +
                                        (", HIP-graph replay" if args.graph else "") if allreduce
                                        else "frame-parallel (no collective)") + ", %d GPU(s)" % world,
-                       "distinct_scenes": args.distinct,
+                       "distinct_scenes": args.distinct, "arithmetic": {"default": "SVO_HIP_SIA_ARITH_MOMENTS_F32 (library default)", "exact": "SVO_HIP_SIA_ARITH_EXACT",
+                                                                       "fast": "SVO_HIP_SIA_ARITH_FAST"}[args.arith],
                        **({"comm_ranks": comm_ranks} if comm_ranks is not None else {}),
                        "implementation": "fused (one workgroup per frame pair, one launch per solve)" if (not allreduce and mode == 1) else "streaming (one launch per Gauss-Newton evaluation)"},
             "pose_err_vs_cpu_ref": {"rot_rad": rot, "trans_m": trans, "tolerance": "1e-4 rad / 1e-3 m",
@@ -783,6 +790,7 @@ def main():
             "cpu_baseline": cpu,
             "roofline_jacobian_pass": jac,
             "reference_semantics": early,
+            "exact_arithmetic": exact_sec,
             "fast_arithmetic": fast,
             "with_image_uploads": upl,
             "c2": c2,

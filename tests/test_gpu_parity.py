@@ -23,18 +23,38 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=["fused", "fused4", "stream"])
+@pytest.fixture(params=["fused", "fused_exact", "fused4", "stream"])
 def sia_mode(request):
     """svo_hip_sia_run has two implementations (one fused launch per run / one launch per Gauss-Newton
-    evaluation), and the fused kernel two shapes (8 waves per frame pair; 4 waves, two pairs per CU, which large
-    launches of small frames get -- forced here); every run()-level parity test is executed against all three."""
+    evaluation), the fused kernel two shapes (8 waves per frame pair; 4 waves, two pairs per CU, which large
+    launches of small frames get -- forced here) and, since round 4, a default arithmetic that sums a patch's two gradient
+    moments in f32 (SVO_HIP_SIA_ARITH_MOMENTS_F32) beside the reference's own (EXACT): every run()-level parity test is
+    executed against all four.  `_tight()` tells a test whether the run reproduces the CPU path to rounding level."""
     old = dict(hip.SIA_DEFAULT_OPTIONS)
     hip.SIA_DEFAULT_OPTIONS.clear()
     if request.param == "stream":
         hip.SIA_DEFAULT_OPTIONS[hip.SIA_OPT_MODE] = hip.SIA_MODE_STREAM
     if request.param == "fused4":
         hip.SIA_DEFAULT_OPTIONS[hip.SIA_OPT_WAVES] = 4
-    yield "fused" if request.param == "fused4" else request.param
+    if request.param in ("fused_exact", "fused4"):
+        hip.SIA_DEFAULT_OPTIONS[hip.SIA_OPT_ARITH] = hip.SIA_ARITH_EXACT
+    yield "fused" if request.param.startswith("fused") else request.param
+    hip.SIA_DEFAULT_OPTIONS.clear()
+    hip.SIA_DEFAULT_OPTIONS.update(old)
+
+
+def _tight():
+    """the solver objects created now use the reference's arithmetic to the last operation (EXACT level or the streaming kernels)"""
+    return (hip.SIA_DEFAULT_OPTIONS.get(hip.SIA_OPT_ARITH) == hip.SIA_ARITH_EXACT or
+            hip.SIA_DEFAULT_OPTIONS.get(hip.SIA_OPT_MODE) == hip.SIA_MODE_STREAM)
+
+
+@pytest.fixture
+def exact_arith():
+    """tests whose bounds are the exact level's (stage chains compared decision by decision with the CPU chain)"""
+    old = dict(hip.SIA_DEFAULT_OPTIONS)
+    hip.SIA_DEFAULT_OPTIONS[hip.SIA_OPT_ARITH] = hip.SIA_ARITH_EXACT
+    yield
     hip.SIA_DEFAULT_OPTIONS.clear()
     hip.SIA_DEFAULT_OPTIONS.update(old)
 
@@ -209,7 +229,8 @@ def test_points_in_the_camera_plane(ctx, sia_mode):
     assert r.n_residual_patches == o.n_residual_patches
     assert r.n_tracked == o.n_tracked
     rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
-    assert rot < 1e-9 and trans < 1e-9, (rot, trans)
+    tol = 1e-9 if _tight() else 2e-7            # the default level sums a patch's gradient moments in f32
+    assert rot < tol and trans < tol, (rot, trans)
     H, Ho = np.array(r.H), np.array(o.H)
     assert np.abs(H - Ho).max() <= 1e-9 * np.abs(Ho).max()
     _free(sia, ref, cur)
@@ -579,7 +600,7 @@ def test_large_launch_of_small_frames_picks_two_pairs_per_cu(ctx):
                 # (DESIGN.md section 7): a last, tiny update may be accepted on one side and rolled back on the other
                 assert rot < 1e-4 and trans < 1e-3, (i, rot, trans)
             else:
-                assert rot < 1e-7 and trans < 1e-7, (i, rot, trans)
+                assert rot < 5e-7 and trans < 5e-7, (i, rot, trans)     # default arithmetic level (f32 moment sums): observed 8e-8 / 1.7e-7
             assert res[i].n_tracked == o.n_tracked
     _free(sia, ref, cur)
 
@@ -894,6 +915,34 @@ def test_sparse_img_align_against_reference_run(ctx, sia_mode, golden, case):
             assert rot < 1e-7 and trans < 1e-7, (rot, trans)     # 5e-9 in the large-motion case, 1e-13 otherwise
             H = np.array(r.H)
             assert np.abs(H - g[name + "_H"]).max() <= 1e-6 * np.abs(g[name + "_H"]).max()
+    _free(sia, ref, cur)
+
+
+@pytest.mark.parametrize("case", _ref_cases(), ids=[c[0] for c in _ref_cases()])
+def test_default_arithmetic_against_reference_run_and_exact_level(ctx, golden, case):
+    """The DEFAULT arithmetic of svo_hip_sia_run since round 4 (SVO_HIP_SIA_ARITH_MOMENTS_F32: the reference's residuals and
+    chi2, a patch's two gradient moments summed in f32) against SparseImgAlign::run executed by the reference's own code and
+    against the EXACT level on the same object: H_ bit for bit, iteration counts, tracked patches and stop flag equal, poses
+    within 1e-7 of each other and of the reference where the evaluation sequence is the same."""
+    from oracle import gen_golden
+    name, kw, max_level, min_level, n_iter = case
+    g = golden("sia_ref.npz")
+    fp = gen_golden.make_sia_case(kw)
+    assert not hip.SIA_DEFAULT_OPTIONS
+    ref, cur, sia = _upload_pair(ctx, [fp], max_feat=max(len(fp.px), 1))
+    prm = sia.params(max_level=max_level, min_level=min_level, n_iter=n_iter, eps=1e-6, early_stop=True)
+    sia.run(1, prm)
+    r = sia.download(0)
+    sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_EXACT)
+    sia.run(1, prm)
+    e = sia.download(0)
+    assert list(r.H) == list(e.H) or any(np.isnan(r.H))          # H comes from the per-level gradient sums, not from the residuals
+    assert list(r.iters) == list(e.iters) and r.n_tracked == e.n_tracked == int(g[name + "_n_tracked"]) and int(r.stop) == int(e.stop) == int(g[name + "_stop"])
+    rot, trans = synth.pose_error(np.array(r.T_cur_w), g[name + "_T"])
+    assert rot < 1e-4 and trans < 1e-3, (rot, trans)            # north_star tolerance
+    if len(fp.px) >= 16:                                        # (a frame of a handful of patches wanders on rounding noise in the reference itself)
+        d_rot, d_trans = synth.pose_error(np.array(r.T_cur_w), np.array(e.T_cur_w))
+        assert d_rot < 1e-7 and d_trans < 1e-7, (d_rot, d_trans)
     _free(sia, ref, cur)
 
 
@@ -1255,7 +1304,7 @@ def test_error_conventions(ctx):
     r = sia.download(0)
     o = orc.sparse_img_align(fp, n_iter=30, early_stop=True)
     rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
-    assert rot < 1e-9 and trans < 1e-9
+    assert rot < 2e-7 and trans < 2e-7             # default arithmetic level: observed 4e-8
     _free(sia, ref, cur)
 
 
@@ -1282,7 +1331,7 @@ def test_converged_seed_records_packed_on_device(ctx):
     sb.free(); kf.destroy(); cf.destroy()
 
 
-def test_frame_pipeline_stages_together(ctx):
+def test_frame_pipeline_stages_together(ctx, exact_arith):
     """The per-frame data path of FrameHandlerMono::processFrame on the device, stage by stage against the oracle chain:
     SparseImgAlign -> reprojection matching (findMatchDirect) -> pose_optimizer::optimizeGaussNewton -> Point::optimize."""
     fp = synth.make_frame_pair(seed=4242, n_features=500, border=40)
