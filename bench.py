@@ -242,7 +242,7 @@ PREWARM_S = 0.1
 # says what every key means; round 3's 14 kB line lost its first half in the driver's tail)
 PROSE_KEYS = {"what", "note", "rule", "traffic_rule", "sample", "legs", "measured_ceiling", "ms_per_frame_image_in_tracker_buffer_median",
               "ms_per_frame_min", "algorithmic_bytes", "algorithmic_GBps", "nproc", "cpus_granted_to_this_process", "patches_per_s",
-              "seeds_per_s"}
+              "seeds_per_s", "ms_per_frame_median", "converged", "steps_secondary"}
 
 
 def slim(o, verbose=False):
@@ -669,8 +669,7 @@ def main():
                 elif fa_ctr:
                     fa_cyc, _, _ = valu_issue_cycles(fa_ctr)
                     fa_s = dt_fa / fa_steps
-                    fa_roof = {"bound": "valu", "frac": fa_cyc / fa_s / 1e9 / (N_SIMD * PEAK_CLOCK_GHZ), "insts_per_launch": fa_ctr["SQ_INSTS_VALU"],
-                               "cvt_insts": fa_ctr.get("SQ_INSTS_VALU_CVT"), "sources": [fa_ctr["_file"]]}
+                    fa_roof = {"bound": "valu", "frac": fa_cyc / fa_s / 1e9 / (N_SIMD * PEAK_CLOCK_GHZ), "sources": [fa_ctr["_file"]]}
                 other[lvl_name] = {"what": "the timed workload with svo_hip_sia_set_option(SVO_HIP_SIA_OPT_ARITH, SVO_HIP_SIA_ARITH_%s)" % lvl_name.upper(),
                                    "value": n_slots * fa_steps / dt_fa, "unit": "frames/s", "ms_per_step": dt_fa / fa_steps * 1e3,
                                    "roofline": fa_roof,
@@ -762,7 +761,7 @@ def main():
                              (world, n_dev, ", shared-memory exchange instead of RCCL" if allreduce else "")} if rehearsal else {}),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 normal equations / f32 image math" + {"default": " (a patch's two gradient moments summed in f32)", "exact": " (as the reference)",
+            "dtype": "f64 normal equations / f32 image math" + {"default": " (f32 moment sums per patch)", "exact": " (as the reference)",
                                                                  "fast": " (contracted, f32 sums per patch)"}[args.arith], "data": "synthetic",
             "config": {"workload": "%s: SparseImgAlign %dx%d, %d patches, 5 pyramid levels (L4-L0), %s" %
                                    ("C1" if args.width == 640 else "C3 shape", args.width, args.height, n_feat, "reference early-stop GN" if args.early_stop else "30 GN evaluations per level (fixed work)"),
@@ -771,8 +770,7 @@ def main():
                                        ("RCCL called by libsvo_hip.so (svo_hip_sia_run_sharded)" if native else "torch.distributed driver") +
                                        (", HIP-graph replay" if args.graph else "") if allreduce
                                        else "frame-parallel (no collective)") + ", %d GPU(s)" % world,
-                       "distinct_scenes": args.distinct, "arithmetic": {"default": "SVO_HIP_SIA_ARITH_MOMENTS_F32 (library default)", "exact": "SVO_HIP_SIA_ARITH_EXACT",
-                                                                       "fast": "SVO_HIP_SIA_ARITH_FAST"}[args.arith],
+                       "distinct_scenes": args.distinct, "arithmetic": {"default": "MOMENTS_F32 (library default)", "exact": "EXACT", "fast": "FAST"}[args.arith],
                        **({"comm_ranks": comm_ranks} if comm_ranks is not None else {}),
                        "implementation": "fused (one workgroup per frame pair, one launch per solve)" if (not allreduce and mode == 1) else "streaming (one launch per Gauss-Newton evaluation)"},
             "pose_err_vs_cpu_ref": {"rot_rad": rot, "trans_m": trans, "tolerance": "1e-4 rad / 1e-3 m",
