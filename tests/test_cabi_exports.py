@@ -33,6 +33,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(hip.CSiaParams) == 32
     assert C.sizeof(hip.CSiaResult) == 7 * 8 + 8 + 36 * 8 + 8 + 4 + 8 * 4 + 4 + 16
     assert C.sizeof(hip.CDfParams) == 24
+    assert C.sizeof(hip.CSeedEvent) == 56 == hip.SEED_EVENT_DTYPE.itemsize       # svo_hip_seed_event: 2 x i32, 2 x f32, 5 x f64
     assert C.sizeof(hip.CTrackerConfig) == 96 and C.sizeof(hip.CTrackerMap) == 160
     assert C.sizeof(hip.CTrackResult) == 14 * 8 + 8 + 8 * 4 + 2 * 4 + 2 * 8 + 2 * 4 + 32 * 4 + 2 * 4 + C.sizeof(hip.CPoseOptResult)
 
