@@ -66,3 +66,35 @@ def test_bench_c4_gpus_2_started_plainly():
     d = _plain("bench_c4.py", "--gpus", "2", "--seeds", "40000", "--steps", "2", "--warmup", "1")
     assert d["n_gpus"] == 2 and "rehearsal" in d and d["config"]["comm_ranks"] == 2
     assert d["config"]["converged_records_gathered"] > 0 and d["config"]["seeds_per_gpu"] == 20000
+
+
+def test_default_bench_line_fits_the_drivers_tail_and_carries_the_contract():
+    """`python bench.py` as the driver runs it (N = 1, every secondary section on): ONE JSON line of at most 6 KiB (round 3's 14 kB
+    line lost its first half in the driver's tail), with the contract keys, `roofline` and `cpu_baseline` objects, the per-stage
+    bounds of the depth filter and the drop-in entry's timing."""
+    d_line = None
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d_line = lines[0]
+    assert len(d_line.encode()) <= 6144, len(d_line)
+    d = json.loads(d_line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["vs_baseline"] is None and "workload" in d["config"] and d["config"]["workload"].startswith("C1")
+    r = d["roofline"]
+    assert r["bound"] in ("valu", "hbm") and 0.0 < r["frac"] <= 1.0 and r["peak"] > 0 and r["traffic"] > 0 and "profile_refused" not in r
+    c = d["cpu_baseline"]
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] in ("port", "reference") and 0.5 < c["port_vs_reference_speed"] < 1.5
+    assert d["pose_err_vs_cpu_ref"]["max_rot_rad_over_scenes"] < 1e-4 and d["pose_err_vs_cpu_ref"]["n_tracked_equal_in_every_scene"]
+    for lvl in ("exact_arithmetic", "fast_arithmetic"):
+        assert d[lvl]["value"] > 0 and 0.0 < d[lvl]["roofline"]["frac"] <= 1.0 and d[lvl]["pose_err_vs_cpu_ref"]["max_rot_rad_over_scenes"] < 1e-6
+    df = d["c2"]["depth_filter"]
+    assert set(df["stages_us"]) == {"geometry", "search", "align", "finalize"} and df["through_dropin_entry_us"] < df["through_round3_host_buffer_entry_us"]
+    for stage in ("geometry", "search", "align", "finalize"):
+        assert df["roofline"][stage]["bound"] in ("valu", "hbm") and 0.0 < df["roofline"][stage]["frac"] <= 1.0
+        assert 0.0 < d["c4_one_gpu"]["roofline"][stage]["frac"] <= 1.0
+    assert d["single_stream_chain"]["L4_L2_shipping_default"]["matched_points_equal_in_every_frame"] is True

@@ -661,6 +661,14 @@ def test_full_size_c4_seeds_properties(ctx):
     good = st[idx] >= hip.SEED_UPDATED
     np.testing.assert_allclose(z[idx][good], o["z"][good], rtol=1e-12)
     np.testing.assert_allclose(mu[idx][good], m[good], rtol=3e-6)
+    # the same 1 M seeds as ONE device-resident batch: same states, one event per converged / NaN seed, in seed order
+    rs = hip.ResidentSeeds(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, sc.sigma2)
+    ev, counts = rs.update(kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w)
+    np.testing.assert_array_equal(rs.status(), st)
+    np.testing.assert_array_equal(rs.download()["mu"], mu)
+    np.testing.assert_array_equal(ev["index"], np.nonzero((st == hip.SEED_CONVERGED) | (st == hip.SEED_NAN))[0])
+    assert counts[1:].tolist() == np.bincount(st, minlength=6).tolist()
+    rs.destroy()
     _free(sb, kf, cf)
 
 
