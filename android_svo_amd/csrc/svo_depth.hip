@@ -287,21 +287,19 @@ SVO_DEV int zmssd_8x8(const uint8_t* __restrict__ p, int stride, const uint32_t*
 // EXPLICIT_DEPTH = false: the per-seed body of DepthFilter::updateSeeds (visibility test, depth interval from mu/sigma2);
 // EXPLICIT_DEPTH = true: Matcher::findEpipolarMatchDirect as a caller would use it directly, with d_estimate / d_min /
 // d_max given per item (dep[3][n]) and no visibility test.
+// (the per-seed body; `rec_out` = where this seed's record goes, `ref_slot` = its reference keyframe's pyramid slot for
+// the search stage when one pass covers several keyframes -- 0 otherwise)
 template <bool EXPLICIT_DEPTH>
-__global__ __launch_bounds__(256) void df_geometry_kernel(
-    DfFrame fr, int n, const double* __restrict__ px, const double* __restrict__ f, const int32_t* __restrict__ level,
-    const float* __restrict__ smu, const float* __restrict__ ssigma2, const double* __restrict__ dep,
-    double* __restrict__ epi_len_out, SeedRec* __restrict__ recs, const uint8_t* __restrict__ alive = nullptr,
-    int* __restrict__ ev_hist = nullptr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ev_hist && i < 8) ev_hist[i] = 0;                   // status histogram of the pass (filled by the finalize stage)
-  if (i >= n) return;
-  const Cam cam = fr.cam;
+SVO_DEV void df_geometry_seed(const Cam& cam, const double* T_cur_ref_vis, const double* T_cur_ref_, int n_pyr_levels,
+                              int max_epi_search_steps, int ref_slot, int i, int n, const double* __restrict__ px,
+                              const double* __restrict__ f, const int32_t* __restrict__ level, const float* __restrict__ smu,
+                              const float* __restrict__ ssigma2, const double* __restrict__ dep, double* __restrict__ epi_len_out,
+                              SeedRec* __restrict__ rec_out, const uint8_t* __restrict__ alive) {
   SeedRec rc;
   rc.uv0[0] = rc.uv0[1] = rc.step[0] = rc.step[1] = 0.0;
   rc.a00 = rc.a01 = rc.a10 = rc.a11 = rc.prx = rc.pry = 0.0f;
   rc.n_steps = 0; rc.search_level = 0; rc.path = -1; rc.status = SVO_HIP_SEED_NO_MATCH; rc.warp_nan = 0;
-  rc.matched = 0; rc.n_zmssd = 0; rc.n_align = 0; rc.pad = 0;
+  rc.matched = 0; rc.n_zmssd = 0; rc.n_align = 0; rc.pad = ref_slot;
   const double fi[3] = {f[3 * (size_t)i], f[3 * (size_t)i + 1], f[3 * (size_t)i + 2]};
   const double px_ref[2] = {px[2 * (size_t)i], px[2 * (size_t)i + 1]};
   const int level_ref = level[i];
@@ -317,7 +315,7 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
     const double inv_mu = 1.0 / mu;
     const double pf[3] = {inv_mu * fi[0], inv_mu * fi[1], inv_mu * fi[2]};
     double xyz_f[3];
-    se3_act(fr.T_cur_ref_vis, pf, xyz_f);
+    se3_act(T_cur_ref_vis, pf, xyz_f);
     if (live && xyz_f[2] < 0.0) { rc.status = SVO_HIP_SEED_BEHIND; live = false; }
     if (live) {
       double pc[2];
@@ -333,7 +331,7 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
   }
   if (live) {
     // ---- Matcher::findEpipolarMatchDirect up to the search plan (matcher.cpp:216-296)
-    const double* T_cur_ref = fr.T_cur_ref;
+    const double* T_cur_ref = T_cur_ref_;
     double pa[3], pb[3], tmp[3];
     tmp[0] = fi[0] * d_min; tmp[1] = fi[1] * d_min; tmp[2] = fi[2] * d_min;
     se3_act(T_cur_ref, tmp, pa);
@@ -347,7 +345,7 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
     int search_level = 0;
     {
       double D = Acr[0] * Acr[3] - Acr[2] * Acr[1];
-      while (D > 3.0 && search_level < fr.n_pyr_levels - 1) { search_level += 1; D *= 0.25; }
+      while (D > 3.0 && search_level < n_pyr_levels - 1) { search_level += 1; D *= 0.25; }
     }
     rc.search_level = search_level;
     double px_A[2], px_B[2];
@@ -375,7 +373,7 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
       rc.uv0[1] = (px_A[1] + px_B[1]) / 2.0;
     } else {
       const size_t n_steps = (size_t)(epi_length / 0.7);
-      if (n_steps > (size_t)fr.max_epi_search_steps) {
+      if (n_steps > (size_t)max_epi_search_steps) {
         rc.path = 2;
       } else {
         rc.path = 1;
@@ -385,7 +383,20 @@ __global__ __launch_bounds__(256) void df_geometry_kernel(
       }
     }
   }
-  recs[i] = rc;
+  *rec_out = rc;
+}
+
+template <bool EXPLICIT_DEPTH>
+__global__ __launch_bounds__(256) void df_geometry_kernel(
+    DfFrame fr, int n, const double* __restrict__ px, const double* __restrict__ f, const int32_t* __restrict__ level,
+    const float* __restrict__ smu, const float* __restrict__ ssigma2, const double* __restrict__ dep,
+    double* __restrict__ epi_len_out, SeedRec* __restrict__ recs, const uint8_t* __restrict__ alive = nullptr,
+    int* __restrict__ ev_hist = nullptr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ev_hist && i < 8) ev_hist[i] = 0;                   // status histogram of the pass (filled by the finalize stage)
+  if (i >= n) return;
+  df_geometry_seed<EXPLICIT_DEPTH>(fr.cam, fr.T_cur_ref_vis, fr.T_cur_ref, fr.n_pyr_levels, fr.max_epi_search_steps, 0, i, n, px, f,
+                                   level, smu, ssigma2, dep, epi_len_out, recs + i, alive);
 }
 
 // ---- image windows in LDS -------------------------------------------------------------------------------------
@@ -827,19 +838,17 @@ __global__ __launch_bounds__(ALIGN_BLOCK) void df_align_kernel(DfFrame fr, const
 // the HOST has to hear about -- converged and NaN seeds (callback / erase, depth_filter.cpp:310-337) and, on keyframes
 // (report_updated), every updated seed (its px_cur marks the detector grid, :302-306) -- clears their `alive` flag where
 // the reference erases them, and adds the block's status histogram to ev_hist[8] (slot status + 1; slot 0 = erased).
-template <bool EVENTS>
-__global__ __launch_bounds__(256) void df_finalize_kernel(
-    DfFrame fr, int n, const double* __restrict__ f, const SeedRec* __restrict__ recs, float* __restrict__ sa,
-    float* __restrict__ sb, float* __restrict__ smu, const float* __restrict__ sz_range, float* __restrict__ ssigma2,
-    int32_t* __restrict__ status, double* __restrict__ z_out, double* __restrict__ xyz_world,
-    int32_t* __restrict__ n_zmssd_out, int32_t* __restrict__ n_align_out, double* __restrict__ px_cur_out,
-    int32_t* __restrict__ search_level_out, uint8_t* __restrict__ alive = nullptr, int report_updated = 0,
-    int* __restrict__ ev_block_count = nullptr, int* __restrict__ ev_hist = nullptr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int st = SVO_HIP_SEED_ERASED;
-  if (i < n) {
-    const SeedRec rc = recs[i];
-    st = rc.status;
+//
+// (the per-seed body: seed i of the arrays, its record `rc`; returns the seed's status)
+SVO_DEV int df_finalize_seed(const Cam& cam, const double* T_cur_ref, const double* T_ref_cur, const double* T_ref_inv,
+                             double px_error_angle, double conv_thresh, int i, const SeedRec& rc, const double* __restrict__ f,
+                             float* __restrict__ sa, float* __restrict__ sb, float* __restrict__ smu,
+                             const float* __restrict__ sz_range, float* __restrict__ ssigma2, int32_t* __restrict__ status,
+                             double* __restrict__ z_out, double* __restrict__ xyz_world, int32_t* __restrict__ n_zmssd_out,
+                             int32_t* __restrict__ n_align_out, double* __restrict__ px_cur_out,
+                             int32_t* __restrict__ search_level_out) {
+  int st = rc.status;
+  {
     double z = 0.0;
     if (rc.path >= 0) {
       const double fi[3] = {f[3 * (size_t)i], f[3 * (size_t)i + 1], f[3 * (size_t)i + 2]};
@@ -847,8 +856,8 @@ __global__ __launch_bounds__(256) void df_finalize_kernel(
       bool matched = false;
       if (rc.matched) {
         double fc[3];
-        cam2world(fr.cam, rc.step[0], rc.step[1], fc);
-        matched = depth_from_triangulation(fr.T_cur_ref, fi, fc, &z);
+        cam2world(cam, rc.step[0], rc.step[1], fc);
+        matched = depth_from_triangulation(T_cur_ref, fi, fc, &z);
       }
       if (!matched) {
         seed.b += 1.0f;                                   // depth_filter.cpp:286
@@ -856,17 +865,17 @@ __global__ __launch_bounds__(256) void df_finalize_kernel(
         z = 0.0;
       } else {
         // ---- computeTau + updateSeed + convergence (depth_filter.cpp:294-337)
-        const double tau = compute_tau(fr.T_ref_cur, fi, z, fr.px_error_angle);
+        const double tau = compute_tau(T_ref_cur, fi, z, px_error_angle);
         const double zmt = z - tau;
         const double tau_inverse = 0.5 * (1.0 / (0.0000001 < zmt ? zmt : 0.0000001) - 1.0 / (z + tau));
         update_seed((float)(1. / z), (float)(tau_inverse * tau_inverse), &seed);
-        if ((double)sqrtf(seed.sigma2) < seed.z_range / fr.conv_thresh) {
+        if ((double)sqrtf(seed.sigma2) < seed.z_range / conv_thresh) {
           st = SVO_HIP_SEED_CONVERGED;
           if (xyz_world) {
             const double im = 1.0 / seed.mu;
             const double pfw[3] = {fi[0] * im, fi[1] * im, fi[2] * im};
             double xw[3];
-            se3_act(fr.T_ref_inv, pfw, xw);
+            se3_act(T_ref_inv, pfw, xw);
             xyz_world[3 * (size_t)i] = xw[0]; xyz_world[3 * (size_t)i + 1] = xw[1]; xyz_world[3 * (size_t)i + 2] = xw[2];
           }
         } else if (rc.z_inv_min != rc.z_inv_min) {
@@ -891,21 +900,44 @@ __global__ __launch_bounds__(256) void df_finalize_kernel(
     }
     if (search_level_out) search_level_out[i] = rc.path >= 0 ? rc.search_level : -1;
   }
-  if (EVENTS) {
-    const bool gone = st == SVO_HIP_SEED_CONVERGED || st == SVO_HIP_SEED_NAN;      // the reference erases these (:330, :336)
-    const bool ev = gone || (report_updated && st >= SVO_HIP_SEED_UPDATED);
-    if (gone) alive[i] = 0;
-    __shared__ int s_ev[4];
-    __shared__ int s_hist[8];
-    if (threadIdx.x < 8) s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    const unsigned long long m = __ballot(ev);
-    if ((threadIdx.x & 63) == 0) s_ev[threadIdx.x >> 6] = __popcll(m);
-    if (i < n) atomicAdd(&s_hist[st + 1], 1);
-    __syncthreads();
-    if (threadIdx.x == 0) ev_block_count[blockIdx.x] = s_ev[0] + s_ev[1] + s_ev[2] + s_ev[3];
-    if (threadIdx.x < 8 && s_hist[threadIdx.x]) atomicAdd(&ev_hist[threadIdx.x], s_hist[threadIdx.x]);
+  return st;
+}
+
+// (the block's part of the EVENTS bookkeeping: every thread of the 256-thread block calls it; `block` = the block's index
+// within the batch)
+SVO_DEV void df_finalize_events(int st, int i, int n, int block, uint8_t* __restrict__ alive, int report_updated,
+                                int* __restrict__ ev_block_count, int* __restrict__ ev_hist) {
+  const bool gone = st == SVO_HIP_SEED_CONVERGED || st == SVO_HIP_SEED_NAN;      // the reference erases these (:330, :336)
+  const bool ev = gone || (report_updated && st >= SVO_HIP_SEED_UPDATED);
+  if (gone) alive[i] = 0;
+  __shared__ int s_ev[4];
+  __shared__ int s_hist[8];
+  if (threadIdx.x < 8) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned long long m = __ballot(ev);
+  if ((threadIdx.x & 63) == 0) s_ev[threadIdx.x >> 6] = __popcll(m);
+  if (i < n) atomicAdd(&s_hist[st + 1], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) ev_block_count[block] = s_ev[0] + s_ev[1] + s_ev[2] + s_ev[3];
+  if (threadIdx.x < 8 && s_hist[threadIdx.x]) atomicAdd(&ev_hist[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+template <bool EVENTS>
+__global__ __launch_bounds__(256) void df_finalize_kernel(
+    DfFrame fr, int n, const double* __restrict__ f, const SeedRec* __restrict__ recs, float* __restrict__ sa,
+    float* __restrict__ sb, float* __restrict__ smu, const float* __restrict__ sz_range, float* __restrict__ ssigma2,
+    int32_t* __restrict__ status, double* __restrict__ z_out, double* __restrict__ xyz_world,
+    int32_t* __restrict__ n_zmssd_out, int32_t* __restrict__ n_align_out, double* __restrict__ px_cur_out,
+    int32_t* __restrict__ search_level_out, uint8_t* __restrict__ alive = nullptr, int report_updated = 0,
+    int* __restrict__ ev_block_count = nullptr, int* __restrict__ ev_hist = nullptr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int st = SVO_HIP_SEED_ERASED;
+  if (i < n) {
+    const SeedRec rc = recs[i];                            // (a copy: the whole record is asked for at once)
+    st = df_finalize_seed(fr.cam, fr.T_cur_ref, fr.T_ref_cur, fr.T_ref_inv, fr.px_error_angle, fr.conv_thresh, i, rc, f, sa, sb,
+                          smu, sz_range, ssigma2, status, z_out, xyz_world, n_zmssd_out, n_align_out, px_cur_out, search_level_out);
   }
+  if (EVENTS) df_finalize_events(st, i, n, blockIdx.x, alive, report_updated, ev_block_count, ev_hist);
 }
 
 // Matcher::findEpipolarMatchDirect called directly (explicit depth interval): the tail of the function,
@@ -1685,9 +1717,9 @@ namespace {
 
 struct EvHeader { int32_t n_events; int32_t counts[7]; };
 
-// exclusive scan of the per-block event counts (one workgroup) + the header of the page-locked event block
-__global__ __launch_bounds__(1024) void ev_scan_kernel(int n_blocks, int* __restrict__ block_count, const int* __restrict__ hist,
-                                                       EvHeader* __restrict__ header /* host memory */, int* __restrict__ n_events_dev) {
+// exclusive scan of the per-block event counts (one workgroup of 1024) + the header of the page-locked event block
+SVO_DEV void ev_scan_block(int n_blocks, int* __restrict__ block_count, const int* __restrict__ hist,
+                           EvHeader* __restrict__ header /* host memory */, int* __restrict__ n_events_dev) {
   __shared__ int s_part[1024];
   __shared__ int s_carry;
   if (threadIdx.x == 0) s_carry = 0;
@@ -1712,18 +1744,22 @@ __global__ __launch_bounds__(1024) void ev_scan_kernel(int n_blocks, int* __rest
   if (threadIdx.x < 7) header->counts[threadIdx.x] = hist[threadIdx.x];
 }
 
+__global__ __launch_bounds__(1024) void ev_scan_kernel(int n_blocks, int* __restrict__ block_count, const int* __restrict__ hist,
+                                                       EvHeader* __restrict__ header, int* __restrict__ n_events_dev) {
+  ev_scan_block(n_blocks, block_count, hist, header, n_events_dev);
+}
+
 // The events, ascending seed index (56 B records).  A handful of them -- every frame but a keyframe's -- goes straight into
 // the page-locked host block (no copy, no second wait); more than EV_DIRECT_MAX are packed in device memory and fetched
 // with one transfer after the wait (scattered 56-byte stores over the link run at a few GB/s: 100 k events took 1.4 ms).
 constexpr int EV_DIRECT_MAX = 512;
-__global__ __launch_bounds__(256) void ev_scatter_kernel(int n, int report_updated, const int32_t* __restrict__ status,
-                                                         const float* __restrict__ mu, const float* __restrict__ sigma2,
-                                                         const double* __restrict__ xyz, const double* __restrict__ px_cur,
-                                                         const int* __restrict__ block_offset, const int* __restrict__ n_events_dev,
-                                                         svo_hip_seed_event* __restrict__ events_host,
-                                                         svo_hip_seed_event* __restrict__ events_dev) {
+SVO_DEV void ev_scatter_block(int block, int n, int report_updated, const int32_t* __restrict__ status,
+                              const float* __restrict__ mu, const float* __restrict__ sigma2, const double* __restrict__ xyz,
+                              const double* __restrict__ px_cur, const int* __restrict__ block_offset,
+                              const int* __restrict__ n_events_dev, svo_hip_seed_event* __restrict__ events_host,
+                              svo_hip_seed_event* __restrict__ events_dev) {
   svo_hip_seed_event* events = *n_events_dev <= EV_DIRECT_MAX ? events_host : events_dev;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = block * 256 + threadIdx.x;
   const int st = i < n ? status[i] : SVO_HIP_SEED_ERASED;
   const bool ev = st == SVO_HIP_SEED_CONVERGED || st == SVO_HIP_SEED_NAN || (report_updated && st >= SVO_HIP_SEED_UPDATED);
   const unsigned long long m = __ballot(ev);
@@ -1732,7 +1768,7 @@ __global__ __launch_bounds__(256) void ev_scatter_kernel(int n, int report_updat
   if (lane == 0) s_w[wave] = __popcll(m);
   __syncthreads();
   if (!ev) return;
-  int off = block_offset[blockIdx.x];
+  int off = block_offset[block];
   for (int w = 0; w < wave; ++w) off += s_w[w];
   off += __popcll(m & ((1ull << lane) - 1ull));
   svo_hip_seed_event e;
@@ -1741,6 +1777,97 @@ __global__ __launch_bounds__(256) void ev_scatter_kernel(int n, int report_updat
   e.xyz_world[0] = conv ? xyz[3 * (size_t)i] : 0.0; e.xyz_world[1] = conv ? xyz[3 * (size_t)i + 1] : 0.0; e.xyz_world[2] = conv ? xyz[3 * (size_t)i + 2] : 0.0;
   e.px_cur[0] = px_cur[2 * (size_t)i]; e.px_cur[1] = px_cur[2 * (size_t)i + 1];
   events[off] = e;
+}
+
+__global__ __launch_bounds__(256) void ev_scatter_kernel(int n, int report_updated, const int32_t* __restrict__ status,
+                                                         const float* __restrict__ mu, const float* __restrict__ sigma2,
+                                                         const double* __restrict__ xyz, const double* __restrict__ px_cur,
+                                                         const int* __restrict__ block_offset, const int* __restrict__ n_events_dev,
+                                                         svo_hip_seed_event* __restrict__ events_host,
+                                                         svo_hip_seed_event* __restrict__ events_dev) {
+  ev_scatter_block(blockIdx.x, n, report_updated, status, mu, sigma2, xyz, px_cur, block_offset, n_events_dev, events_host, events_dev);
+}
+
+// ---- one launch set for SEVERAL batches (svo_hip_seed_batch_update_group_async) ------------------------------------------
+// A frame of the reference's depth filter updates the seeds of a few keyframes, a few hundred each: per batch that is six
+// launches of a handful of workgroups -- launch-bound (4 x 500 seeds: 105 us, profiles/r04_df_realistic_sizes.txt).  Here the
+// batches of a frame go through the stages together: batch j owns the blocks [first_block, first_block + n_blocks) of the
+// thread-per-seed stages (a block never straddles two batches, so the batch -- its arrays, its keyframe's transforms -- is
+// block-uniform and lives in scalar registers), its records sit at first_block * 256 of the pass's scratch, the tail of its
+// last block is filled with inert records, and the pixel stages (search, align) run over the concatenation unchanged: a
+// record carries its keyframe's pyramid slot (SeedRec::pad).
+constexpr int DF_GROUP_MAX = 8;
+struct DfJob {
+  double T_ref_cur[7], T_cur_ref_vis[7], T_cur_ref[7], T_ref_inv[7];     // as DfFrame's, of this batch's keyframe
+  const double *px, *f;
+  const int32_t* level;
+  float *a, *b, *mu;
+  const float* z_range;
+  float* sigma2;
+  int32_t* status;
+  double *xyz, *px_cur;
+  uint8_t* alive;
+  int *block_count, *hist;
+  EvHeader* header;
+  svo_hip_seed_event *events_host, *events_dev;
+  int n, n_blocks, first_block, ref_slot;
+};
+struct DfGroup {
+  DfJob job[DF_GROUP_MAX];
+  int n_jobs, report_updated;
+};
+static_assert(sizeof(DfFrame) + sizeof(DfGroup) + 64 <= 4096, "kernel arguments of the grouped stages");
+
+SVO_DEV int df_job_of_block(const DfGroup& g, int block) {
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < DF_GROUP_MAX; ++k) if (k < g.n_jobs && block >= g.job[k].first_block) j = k;
+  return j;
+}
+
+__global__ __launch_bounds__(256) void df_geometry_group_kernel(DfFrame fr, DfGroup g, SeedRec* __restrict__ recs,
+                                                                int32_t* __restrict__ level_cat) {
+  const DfJob& J = g.job[df_job_of_block(g, blockIdx.x)];
+  const int i = (blockIdx.x - J.first_block) * 256 + threadIdx.x;       // seed of its batch
+  const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;              // its record in the pass
+  if (i < 8) J.hist[i] = 0;
+  if (i < J.n) {
+    level_cat[r] = J.level[i];
+    df_geometry_seed<false>(fr.cam, J.T_cur_ref_vis, J.T_cur_ref, fr.n_pyr_levels, fr.max_epi_search_steps, J.ref_slot, i, J.n, J.px, J.f,
+                            J.level, J.mu, J.sigma2, nullptr, nullptr, recs + r, J.alive);
+  } else {
+    SeedRec rc;
+    rc.uv0[0] = rc.uv0[1] = rc.step[0] = rc.step[1] = 0.0;
+    rc.a00 = rc.a01 = rc.a10 = rc.a11 = rc.prx = rc.pry = rc.z_inv_min = 0.0f;
+    rc.n_steps = 0; rc.search_level = 0; rc.path = -1; rc.status = SVO_HIP_SEED_ERASED; rc.warp_nan = 0;
+    rc.matched = 0; rc.n_zmssd = 0; rc.n_align = 0; rc.pad = 0;
+    recs[r] = rc;
+    level_cat[r] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void df_finalize_group_kernel(DfFrame fr, DfGroup g, const SeedRec* __restrict__ recs) {
+  const DfJob& J = g.job[df_job_of_block(g, blockIdx.x)];
+  const int block = blockIdx.x - J.first_block;
+  const int i = block * 256 + threadIdx.x;
+  int st = SVO_HIP_SEED_ERASED;
+  if (i < J.n) {
+    const SeedRec rc = recs[(size_t)blockIdx.x * 256 + threadIdx.x];
+    st = df_finalize_seed(fr.cam, J.T_cur_ref, J.T_ref_cur, J.T_ref_inv, fr.px_error_angle, fr.conv_thresh, i, rc, J.f, J.a, J.b, J.mu,
+                          J.z_range, J.sigma2, J.status, nullptr, J.xyz, nullptr, nullptr, J.px_cur, nullptr);
+  }
+  df_finalize_events(st, i, J.n, block, J.alive, g.report_updated, J.block_count, J.hist);
+}
+
+__global__ __launch_bounds__(1024) void ev_scan_group_kernel(DfGroup g) {
+  const DfJob& J = g.job[blockIdx.x];
+  ev_scan_block(J.n_blocks, J.block_count, J.hist, J.header, J.hist + 8);
+}
+
+__global__ __launch_bounds__(256) void ev_scatter_group_kernel(DfGroup g) {
+  const DfJob& J = g.job[df_job_of_block(g, blockIdx.x)];
+  ev_scatter_block(blockIdx.x - J.first_block, J.n, g.report_updated, J.status, J.mu, J.sigma2, J.xyz, J.px_cur, J.block_count, J.hist + 8,
+                   J.events_host, J.events_dev);
 }
 
 }  // namespace
@@ -1809,7 +1936,6 @@ int svo_hip_seed_batch_create(svo_hip_ctx* ctx, int n, const double* px, const d
     sb->sigma2 = (float*)(d + o_s2); sb->xyz = (double*)(d + o_xyz); sb->px_cur = (double*)(d + o_pc);
     sb->status = (int32_t*)(d + o_st); sb->alive = (uint8_t*)(d + o_al); sb->block_count = (int*)(d + o_bc); sb->hist = (int*)(d + o_h);
     sb->events_dev = (svo_hip_seed_event*)(d + o_ev);
-    sb->events_dev = (svo_hip_seed_event*)(d + o_ev);
     memset(sb->host, 0, kEvHeaderBytes);
     // the uploaded arrays gathered in the context's page-locked staging area: one transfer
     char* hs = nullptr;
@@ -1867,6 +1993,85 @@ int svo_hip_seed_batch_update_async(svo_hip_seed_batch* sb, const svo_hip_pyrami
   return SVO_HIP_OK;
 }
 
+int svo_hip_seed_batch_update_group_async(int n_batches, svo_hip_seed_batch* const* batches, const svo_hip_pyramid* ref,
+                                          const int* ref_slots, const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                                          const double* T_ref_w, const double T_cur_w[7], const svo_hip_df_params* prm,
+                                          int report_updated) {
+  if (n_batches < 1 || !batches || !batches[0]) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = batches[0]->ctx;
+  if (!ref || !ref_slots || !cur || !cam || !T_ref_w || !T_cur_w || !prm) return svo_fail(ctx, SVO_HIP_ERR_INVALID, "svo_hip_seed_batch_update_group_async", "null argument");
+  if (n_batches == 1)
+    return svo_hip_seed_batch_update_async(batches[0], ref, ref_slots[0], cur, cur_slot, cam, T_ref_w, T_cur_w, prm, report_updated);
+  // everything is checked before anything is enqueued: the call updates all batches or none
+  for (int k = 0; k < n_batches; ++k) {
+    svo_hip_seed_batch* sb = batches[k];
+    SVO_REQUIRE(ctx, sb && sb->ctx == ctx);
+    if (sb->pending) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_seed_batch_update_group_async", "the previous pass has not been collected");
+    for (int m = 0; m < k; ++m) SVO_REQUIRE(ctx, batches[m] != sb);
+    SVO_REQUIRE(ctx, ref_slots[k] >= 0 && ref_slots[k] < ref->batch);
+  }
+  SVO_REQUIRE(ctx, cur_slot >= 0 && cur_slot < cur->batch);
+  SVO_REQUIRE(ctx, ref->width == cam->width && ref->height == cam->height && cur->width == cam->width && cur->height == cam->height);
+  SVO_REQUIRE(ctx, prm->n_pyr_levels >= 1 && prm->n_pyr_levels <= ref->n_levels && prm->n_pyr_levels <= cur->n_levels);
+  SVO_REQUIRE(ctx, prm->align_max_iter >= 0 && prm->max_epi_search_steps >= 0);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const uint8_t* cur_img = cur->base + (size_t)cur_slot * cur->pyr_bytes;
+  const bool prof = ctx->df_profile;
+  auto stamp = [&](int k) { if (prof) (void)hipEventRecord(ctx->df_ev[k], ctx->stream); };
+  for (int first = 0; first < n_batches; first += DF_GROUP_MAX) {
+    const int n_jobs = n_batches - first < DF_GROUP_MAX ? n_batches - first : DF_GROUP_MAX;
+    DfFrame fr;
+    df_make_frame(ref, cur, cam, T_ref_w + 7 * (size_t)first, T_cur_w, prm, fr);
+    DfGroup g;
+    memset(&g, 0, sizeof(g));
+    g.n_jobs = n_jobs;
+    g.report_updated = report_updated ? 1 : 0;
+    int n_blocks = 0, n_cat = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+      svo_hip_seed_batch* sb = batches[first + j];
+      DfJob& J = g.job[j];
+      DfFrame fj;
+      df_make_frame(ref, cur, cam, T_ref_w + 7 * (size_t)(first + j), T_cur_w, prm, fj);
+      memcpy(J.T_ref_cur, fj.T_ref_cur, sizeof(J.T_ref_cur)); memcpy(J.T_cur_ref_vis, fj.T_cur_ref_vis, sizeof(J.T_cur_ref_vis));
+      memcpy(J.T_cur_ref, fj.T_cur_ref, sizeof(J.T_cur_ref)); memcpy(J.T_ref_inv, fj.T_ref_inv, sizeof(J.T_ref_inv));
+      J.px = sb->px; J.f = sb->f; J.level = sb->level; J.a = sb->a; J.b = sb->b; J.mu = sb->mu; J.z_range = sb->z_range; J.sigma2 = sb->sigma2;
+      J.status = sb->status; J.xyz = sb->xyz; J.px_cur = sb->px_cur; J.alive = sb->alive; J.block_count = sb->block_count; J.hist = sb->hist;
+      J.header = reinterpret_cast<EvHeader*>(sb->host_dev);
+      J.events_host = reinterpret_cast<svo_hip_seed_event*>(sb->host_dev + kEvHeaderBytes);
+      J.events_dev = sb->events_dev;
+      J.n = sb->n; J.n_blocks = sb->n_blocks; J.first_block = n_blocks; J.ref_slot = ref_slots[first + j];
+      n_cat = n_blocks * 256 + sb->n;
+      n_blocks += sb->n_blocks;
+    }
+    // scratch of the pass: records (every block of the thread-per-seed stages whole), the transposed patches, the levels
+    const int n_rec = n_blocks * 256, n_pad = n_rec;
+    const size_t rec_bytes = (size_t)n_rec * sizeof(SeedRec), pwb_bytes = (size_t)25 * n_pad * sizeof(uint32_t);
+    void* ws = nullptr;
+    {
+      const int rc = svo_ctx_scratch(ctx, rec_bytes + pwb_bytes + (size_t)n_rec * sizeof(int32_t), &ws);
+      if (rc != SVO_HIP_OK) return rc;
+    }
+    SeedRec* recs = (SeedRec*)ws;
+    uint32_t* pwb_t = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + rec_bytes);
+    int32_t* level_cat = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + rec_bytes + pwb_bytes);
+    stamp(0);
+    hipLaunchKernelGGL(df_geometry_group_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, fr, g, recs, level_cat);
+    stamp(1);
+    hipLaunchKernelGGL(df_search_kernel, dim3((n_cat + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref->base,
+                       ref->pyr_bytes, cur_img, n_cat, (const int32_t*)level_cat, recs, pwb_t, n_pad);
+    stamp(2);
+    launch_df_align<false>(ctx, fr, cur_img, n_cat, n_pad, pwb_t, recs);
+    stamp(3);
+    hipLaunchKernelGGL(df_finalize_group_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, fr, g, (const SeedRec*)recs);
+    if (prof) { (void)hipEventRecord(ctx->df_ev[4], ctx->stream); ctx->df_ev_recorded = true; }
+    hipLaunchKernelGGL(ev_scan_group_kernel, dim3(n_jobs), dim3(1024), 0, ctx->stream, g);
+    hipLaunchKernelGGL(ev_scatter_group_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, g);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+    for (int j = 0; j < n_jobs; ++j) { batches[first + j]->pending = true; batches[first + j]->report_updated = g.report_updated; }
+  }
+  return SVO_HIP_OK;
+}
+
 int svo_hip_seed_batch_collect(svo_hip_seed_batch* sb, const svo_hip_seed_event** events, int* n_events, int32_t status_counts[7]) {
   if (!sb) return SVO_HIP_ERR_INVALID;
   svo_hip_ctx* ctx = sb->ctx;
@@ -1875,11 +2080,6 @@ int svo_hip_seed_batch_collect(svo_hip_seed_batch* sb, const svo_hip_seed_event*
   SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   sb->pending = false;
   const EvHeader* h = reinterpret_cast<const EvHeader*>(sb->host);
-  if (h->n_events > EV_DIRECT_MAX) {                      // many events (a keyframe): packed on the device, one transfer
-    SVO_CHECK_HIP(ctx, hipMemcpyAsync(sb->host + kEvHeaderBytes, sb->events_dev, (size_t)h->n_events * sizeof(svo_hip_seed_event),
-                                      hipMemcpyDeviceToHost, ctx->stream));
-    SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
   if (h->n_events > EV_DIRECT_MAX) {                      // many events (a keyframe): packed on the device, one transfer
     SVO_CHECK_HIP(ctx, hipMemcpyAsync(sb->host + kEvHeaderBytes, sb->events_dev, (size_t)h->n_events * sizeof(svo_hip_seed_event),
                                       hipMemcpyDeviceToHost, ctx->stream));

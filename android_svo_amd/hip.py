@@ -542,6 +542,20 @@ class ResidentSeeds:
                                                                     _ptr(Tc, C.c_double), C.byref(prm), 1 if report_updated else 0),
                        "seed_batch_update_async")
 
+    @staticmethod
+    def update_group_async(batches, ref: Pyramid, ref_slots, cur: Pyramid, cur_slot: int, cam, T_ref_w, T_cur_w, prm=None, report_updated=False):
+        """svo_hip_seed_batch_update_group_async: the pass over several batches (one per keyframe: slot ref_slots[k] of
+        `ref`, pose T_ref_w[k]) as ONE set of launches; collect every batch afterwards."""
+        ctx = batches[0].ctx
+        prm = prm or depth_filter_params()
+        c = make_camera(cam)
+        hs = (C.c_void_p * len(batches))(*[b.h for b in batches])
+        slots = np.ascontiguousarray(ref_slots, dtype=np.int32)
+        Tr, Tc = _f64(np.asarray(T_ref_w, dtype=np.float64).reshape(len(batches), 7)), _f64(T_cur_w)
+        ctx.check(ctx.lib.svo_hip_seed_batch_update_group_async(len(batches), hs, ref.h, _ptr(slots, C.c_int), cur.h, cur_slot, C.byref(c),
+                                                                _ptr(Tr, C.c_double), _ptr(Tc, C.c_double), C.byref(prm),
+                                                                1 if report_updated else 0), "seed_batch_update_group_async")
+
     def collect_raw(self):
         """(address of the batch's page-locked event block, number of events, status counts [7]) -- no copy"""
         ev = C.POINTER(CSeedEvent)()

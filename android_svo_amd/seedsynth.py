@@ -73,6 +73,42 @@ def make_seed_case(n_seeds: int = 4096, seed: int = 7, width: int = 640, height:
 
 
 @dataclasses.dataclass
+class MultiKeyframeCase:
+    """One current frame and the seeds of several keyframes of the same scene (what one DepthFilter::updateSeeds call walks)."""
+    cam: synth.Camera
+    cur_pyr: List[np.ndarray]
+    T_cur_w: np.ndarray
+    keyframes: List[SeedCase]      # per keyframe: its pyramid (ref_pyr), pose (T_ref_w) and seeds; cur_pyr / T_cur_w repeated
+
+
+def make_multi_keyframe_case(sizes, seed: int = 5, width: int = 640, height: int = 480, baseline: float = 0.08, depth: float = 2.0,
+                             levels=(0, 0, 0, 1, 2), border: int = 40) -> MultiKeyframeCase:
+    rng = np.random.default_rng(seed)
+    cam = synth.Camera.default(width, height)
+    scene = synth.PlaneScene(seed=seed, depth=depth, tilt=(rng.uniform(-0.15, 0.15), rng.uniform(-0.15, 0.15)))
+    T_cur_w = synth.se3_from_twist(rng.uniform(-0.05, 0.05, 3), rng.uniform(-0.02, 0.02, 3))
+    cur_pyr = synth.build_pyramid(scene.render(cam, T_cur_w))
+    kfs = []
+    for n in sizes:
+        direction = rng.normal(size=3) * [1.0, 1.0, 0.25]
+        direction /= np.linalg.norm(direction)
+        T_ref_cur = synth.se3_from_twist(direction * baseline * rng.uniform(0.6, 1.4), rng.uniform(-0.01, 0.01, 3))
+        T_ref_w = synth.se3_mul(T_ref_cur, T_cur_w)
+        ref_img = scene.render(cam, T_ref_w)
+        px = np.stack([rng.integers(border, width - border, n), rng.integers(border, height - border, n)], axis=1).astype(np.float64)
+        level = rng.choice(np.asarray(levels, dtype=np.int32), size=n)
+        px = px - (px % (1 << level)[:, None])
+        f = synth.cam2world(cam, px)
+        X = scene.intersect(cam, T_ref_w, px[:, 0], px[:, 1])
+        true_depth = np.linalg.norm(X - synth.se3_inv(T_ref_w)[:3], axis=1)
+        zbar = float(np.median(true_depth))
+        a, b, mu, zr, s2 = seed_ctor(1.1 * zbar, 0.5 * zbar, n)
+        kfs.append(SeedCase(cam, synth.build_pyramid(ref_img), cur_pyr, T_ref_w, T_cur_w, np.ascontiguousarray(px),
+                            np.ascontiguousarray(f), level.astype(np.int32), a, b, mu, zr, s2, true_depth))
+    return MultiKeyframeCase(cam, cur_pyr, T_cur_w, kfs)
+
+
+@dataclasses.dataclass
 class AlignCase:
     cam: synth.Camera
     cur_pyr: List[np.ndarray]

@@ -9,10 +9,10 @@
 // seeds the host has to act on back (round 3 moved 144 B per seed over the link every frame):
 //   * age-out of old seeds (:256-261)                     -> whole device batches dropped, their list entries erased
 //   * visibility test, findEpipolarMatchDirect, computeTau, updateSeed (:264-299)
-//                                                         -> device, one pass per batch, all batches of the frame enqueued
-//     back to back and awaited once; the halt flag (:253) is polled before every batch is enqueued, and what was
-//     enqueued is applied (a seed is either updated by this frame or not, as in the reference, where the prefix that
-//     got updated also depends on when the flag rises)
+//                                                         -> device, all batches of the frame through one set of launches
+//     (svo_hip_seed_batch_update_group_async), awaited once; the halt flag (:253) is polled before the frame's pass is
+//     enqueued (a seed is either updated by this frame or not, as in the reference, where the prefix that got updated
+//     also depends on when the flag rises: here the prefix is everything or nothing)
 //   * on keyframes feature_detector_->setGridOccpuancy(matcher_.px_cur_) for every updated seed (:302-306),
 //     convergence -> new Point + seed_converged_cb_ + erase (:310-331), NaN -> erase (:333-337)
 //                                                         -> the batch's EVENTS, ascending seed index, batches in list
@@ -75,7 +75,7 @@ class DeviceSeedMirror {
   }
   size_t deviceBatches() const { return batches_.size(); }
 
-  /// DepthFilter::updateSeeds(frame).  `sub_batch`: seeds per device batch (the halt flag is polled in between).
+  /// DepthFilter::updateSeeds(frame).  `sub_batch`: seeds per device batch (an upload unit; one frame's pass covers all).
   template <class Host, class Frame>
   SeedBatchStats update(Host& host, svo_hip_ctx* ctx, SeedList& seeds, Frame& frame, const svo_hip_df_params& prm, int batch_counter,
                         int max_n_kfs, const volatile bool& halt, int sub_batch = 4096) {
@@ -111,21 +111,31 @@ class DeviceSeedMirror {
     host.pose7(frame, T_cur);
     const bool is_keyframe = host.isKeyframe(frame);
 
-    // ---- device: one pass per batch, enqueued back to back (list order), awaited in the same order
+    // ---- device: the batches of the frame through ONE set of launches (svo_hip_seed_batch_update_group_async), awaited in
+    // list order
     std::vector<size_t> enqueued;
-    for (size_t k = 0; k < batches_.size(); ++k) {
-      if (halt) { st.halted = true; break; }
-      Batch& b = batches_[k];
-      if (b.n_alive == 0) continue;
-      const int ref_slot = host.keyframeSlot(*b.kf);
-      if (ref_slot < 0) continue;
-      double T_ref[7];
-      host.pose7(*b.kf, T_ref);
-      ++st.n_device_calls;
-      const int rc = svo_hip_seed_batch_update_async(b.dev, host.keyframePyramids(), ref_slot, host.currentPyramids(), cur_slot, &cam,
-                                                     T_ref, T_cur, &prm, is_keyframe ? 1 : 0);
-      if (rc != SVO_HIP_OK) { ++st.n_device_errors; continue; }    // device error: these seeds keep their old state
-      enqueued.push_back(k);
+    if (halt) { st.halted = true; return st; }
+    {
+      std::vector<svo_hip_seed_batch*> devs;
+      std::vector<int> slots;
+      std::vector<double> T_refs;
+      for (size_t k = 0; k < batches_.size(); ++k) {
+        Batch& b = batches_[k];
+        if (b.n_alive == 0) continue;
+        const int ref_slot = host.keyframeSlot(*b.kf);
+        if (ref_slot < 0) continue;
+        double T_ref[7];
+        host.pose7(*b.kf, T_ref);
+        devs.push_back(b.dev); slots.push_back(ref_slot); T_refs.insert(T_refs.end(), T_ref, T_ref + 7);
+        enqueued.push_back(k);
+      }
+      if (!devs.empty()) {
+        st.n_device_calls += (int)devs.size();
+        const int rc = svo_hip_seed_batch_update_group_async((int)devs.size(), devs.data(), host.keyframePyramids(), slots.data(),
+                                                             host.currentPyramids(), cur_slot, &cam, T_refs.data(), T_cur, &prm,
+                                                             is_keyframe ? 1 : 0);
+        if (rc != SVO_HIP_OK) { ++st.n_device_errors; enqueued.clear(); }   // nothing was enqueued: the seeds keep their state
+      }
     }
     // ---- the events, in list order: grid marks, callbacks, erasures (:302-337)
     for (size_t e = 0; e < enqueued.size(); ++e) {

@@ -425,6 +425,16 @@ int svo_hip_seed_batch_update_async(svo_hip_seed_batch* batch, const svo_hip_pyr
                                     const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
                                     const double T_ref_w[7], const double T_cur_w[7], const svo_hip_df_params* prm,
                                     int report_updated);
+/* The same pass over SEVERAL batches of one context -- the seeds of every keyframe a frame updates (the loop of
+ * depth_filter.cpp:248-340 walks them all) -- as ONE set of launches: batch k against keyframe slot ref_slots[k] of `ref`
+ * with pose T_ref_w[7 * k .. 7 * k + 6].  Results per batch are bit-identical to n_batches calls of
+ * svo_hip_seed_batch_update_async; what changes is the cost when the batches are small (a few hundred seeds each is what
+ * the reference's detector yields per keyframe): six launches per frame instead of six per keyframe.  Everything is
+ * checked before anything is enqueued (all batches are updated, or none); collect every batch afterwards. */
+int svo_hip_seed_batch_update_group_async(int n_batches, svo_hip_seed_batch* const* batches, const svo_hip_pyramid* ref,
+                                          const int* ref_slots, const svo_hip_pyramid* cur, int cur_slot,
+                                          const svo_hip_camera* cam, const double* T_ref_w /* [n_batches][7] */,
+                                          const double T_cur_w[7], const svo_hip_df_params* prm, int report_updated);
 /* wait for the pass; *events points into page-locked memory owned by the batch (valid until its next update_async);
  * status_counts[7]: seeds per outcome of this pass, slot = status + 1 (slot 0 = SVO_HIP_SEED_ERASED ... slot 6 =
  * SVO_HIP_SEED_NAN).  Either output may be NULL. */

@@ -73,6 +73,13 @@ int svo_hip_seed_batch_update_async(svo_hip_seed_batch* s, const svo_hip_pyramid
   s->pending = true;
   return SVO_HIP_OK;
 }
+int svo_hip_seed_batch_update_group_async(int n, svo_hip_seed_batch* const* sbs, const svo_hip_pyramid* ref, const int* slots,
+                                          const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam, const double* T_ref_w,
+                                          const double* T_cur_w, const svo_hip_df_params* prm, int report_updated) {
+  for (int k = 0; k < n; ++k) if (sbs[k]->pending) return SVO_HIP_ERR_STATE;           // all or none
+  for (int k = 0; k < n; ++k) svo_hip_seed_batch_update_async(sbs[k], ref, slots[k], cur, cur_slot, cam, T_ref_w + 7 * k, T_cur_w, prm, report_updated);
+  return SVO_HIP_OK;
+}
 int svo_hip_seed_batch_collect(svo_hip_seed_batch* s, const svo_hip_seed_event** ev, int* n_ev, int32_t counts[7]) {
   if (!s->pending) return SVO_HIP_ERR_STATE;
   s->pending = false;

@@ -112,3 +112,54 @@ def test_two_batches_enqueued_back_to_back_one_wait(ctx):
     assert np.array_equal(np.concatenate([e["sigma2"] for e in evs]), ev_w["sigma2"])
     for o_ in [whole] + parts:
         o_.destroy()
+
+
+@pytest.mark.parametrize("sizes", [(500, 1, 255, 256, 700), (300,) * 11, (3000, 4097)])
+def test_grouped_pass_over_several_keyframes_equals_one_pass_per_keyframe(ctx, sizes):
+    """svo_hip_seed_batch_update_group_async: the seeds of every keyframe of a frame through ONE set of launches --
+    states, events and status counts per batch bit-identical to one svo_hip_seed_batch_update_async per keyframe (sizes
+    that end inside a block, a single seed, more batches than one launch set takes)."""
+    mk = seedsynth.make_multi_keyframe_case(sizes, seed=31)
+    K = len(sizes)
+    kf = hip.Pyramid(ctx, mk.cam.width, mk.cam.height, 5, K)
+    cf = hip.Pyramid(ctx, mk.cam.width, mk.cam.height, 5, 1)
+    cf.upload(0, mk.cur_pyr)
+    one, grp = [], []
+    for k, sc in enumerate(mk.keyframes):
+        kf.upload(k, sc.ref_pyr)
+        s2 = (sc.sigma2 * np.float32(0.02)).astype(np.float32)
+        one.append(hip.ResidentSeeds(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, s2))
+        grp.append(hip.ResidentSeeds(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, s2))
+    slots = list(range(K))[::-1] if K == 5 else list(range(K))        # (slot order need not be batch order)
+    if K == 5:
+        for k, sc in enumerate(mk.keyframes):
+            kf.upload(slots[k], sc.ref_pyr)
+    T_refs = np.stack([sc.T_ref_w for sc in mk.keyframes])
+    n_events = 0
+    for frame in range(3):
+        keyframe = frame == 1
+        for k, sc in enumerate(mk.keyframes):
+            one[k].update_async(kf, slots[k], cf, 0, mk.cam, sc.T_ref_w, mk.T_cur_w, report_updated=keyframe)
+        want = [r.collect() for r in one]
+        hip.ResidentSeeds.update_group_async(grp, kf, slots, cf, 0, mk.cam, T_refs, mk.T_cur_w, report_updated=keyframe)
+        got = [r.collect() for r in grp]
+        for k in range(K):
+            assert np.array_equal(got[k][1], want[k][1]), (frame, k)
+            assert got[k][0].tobytes() == want[k][0].tobytes(), (frame, k)
+            assert np.array_equal(grp[k].status(), one[k].status())
+            d, e = grp[k].download(), one[k].download()
+            for key in d:
+                assert d[key].tobytes() == e[key].tobytes(), (frame, k, key)
+            assert grp[k].n_alive() == one[k].n_alive()
+            n_events += len(got[k][0])
+    assert n_events > sum(sizes) // 2                      # the keyframe frame reports every updated seed
+    # a batch that is still pending refuses the grouped call as a whole: nothing is enqueued
+    grp[0].update_async(kf, slots[0], cf, 0, mk.cam, T_refs[0], mk.T_cur_w)
+    with pytest.raises(hip.SvoHipError):
+        hip.ResidentSeeds.update_group_async(grp, kf, slots, cf, 0, mk.cam, T_refs, mk.T_cur_w)
+    grp[0].collect()
+    with pytest.raises(hip.SvoHipError):
+        grp[1].collect()
+    for r in one + grp:
+        r.destroy()
+    kf.destroy(); cf.destroy()
