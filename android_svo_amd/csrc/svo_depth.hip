@@ -471,11 +471,11 @@ SVO_DEV int zmssd_8x8_win(const uint8_t* row0, int ox, const uint32_t* patch_wor
 constexpr int SEEDS_PER_WAVE = 4;
 constexpr int SEEDS_PER_BLOCK = 16;
 
-__global__ __launch_bounds__(256, 7) void df_search_kernel(
-    DfFrame fr, const uint8_t* __restrict__ ref_base, size_t ref_pyr_bytes, const uint8_t* __restrict__ cur_pyr, int n,
-    const int32_t* __restrict__ level, SeedRec* __restrict__ recs, uint32_t* __restrict__ pwb_t, int n_pad,
-    const int* __restrict__ n_dev = nullptr) {
-  if (n_dev) { const int nd = *n_dev; n = nd < n ? nd : n; }       // item count left by an earlier kernel of the stream (svo_track.hip)
+// (the body: workgroup `block` of 256 threads, seeds [16 * block, 16 * block + 16); no block-level barrier inside -- every wave
+// works on its own four seeds)
+SVO_DEV void df_search_block(const DfFrame& fr, const uint8_t* __restrict__ ref_base, size_t ref_pyr_bytes,
+                             const uint8_t* __restrict__ cur_pyr, int n, const int32_t* __restrict__ level,
+                             SeedRec* __restrict__ recs, uint32_t* __restrict__ pwb_t, int n_pad, int block) {
   __shared__ __attribute__((aligned(16))) uint8_t s_pwb[SEEDS_PER_BLOCK][112];
   __shared__ __attribute__((aligned(16))) uint32_t s_patch[SEEDS_PER_BLOCK][16];
   __shared__ double s_px[SEEDS_PER_BLOCK][2];
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, 7) void df_search_kernel(
   __shared__ __attribute__((aligned(16))) uint8_t s_win[SEEDS_PER_BLOCK * WIN_BYTES + 16];   // image windows (+ pad: see zmssd_8x8_win)
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform -> SGPRs
   const int lane = threadIdx.x & 63;
-  const int i0 = (blockIdx.x * 4 + wib) * SEEDS_PER_WAVE;
+  const int i0 = (block * 4 + wib) * SEEDS_PER_WAVE;
   if (i0 >= n) return;                     // wave-uniform; no block-level barrier is used below
   const Cam cam = fr.cam;
   // the wave's four records (384 contiguous bytes) and levels go to LDS in one round trip: every phase below reads
@@ -767,18 +767,23 @@ __global__ __launch_bounds__(256, 7) void df_search_kernel(
   }
 }
 
+__global__ __launch_bounds__(256, 7) void df_search_kernel(
+    DfFrame fr, const uint8_t* __restrict__ ref_base, size_t ref_pyr_bytes, const uint8_t* __restrict__ cur_pyr, int n,
+    const int32_t* __restrict__ level, SeedRec* __restrict__ recs, uint32_t* __restrict__ pwb_t, int n_pad,
+    const int* __restrict__ n_dev = nullptr) {
+  if (n_dev) { const int nd = *n_dev; n = nd < n ? nd : n; }       // item count left by an earlier kernel of the stream (svo_track.hip)
+  df_search_block(fr, ref_base, ref_pyr_bytes, cur_pyr, n, level, recs, pwb_t, n_pad, blockIdx.x);
+}
+
 // Sub-pixel refinement of every seed the search stage flagged: one quad per seed, the reference's serial pixel order
 // (svo_align_device.h), so `converged`, the refined pixel and the iteration count equal the CPU path's bit for bit.
 // ONE_D = false refines the corner features with align2D; ONE_D = true the EDGELET reference features of
 // findMatchDirect with align1D (matcher.cpp:183-191; the depth filter never produces them).
+// (the body: this lane is lane q = threadIdx.x & 3 of the quad of seed i; `have` = the seed exists)
 template <bool ONE_D>
-__global__ __launch_bounds__(ALIGN_BLOCK) void df_align_kernel(DfFrame fr, const uint8_t* __restrict__ cur_pyr, int n, int n_pad,
-                                                               const uint32_t* __restrict__ pwb_t, SeedRec* __restrict__ recs,
-                                                               const int* __restrict__ n_dev = nullptr) {
-  if (n_dev) { const int nd = *n_dev; n = nd < n ? nd : n; }
-  const int i = blockIdx.x * ALIGN_PATCHES + (threadIdx.x >> 2);
+SVO_DEV void df_align_quad(const DfFrame& fr, const uint8_t* __restrict__ cur_pyr, int n_pad, const uint32_t* __restrict__ pwb_t,
+                           SeedRec* __restrict__ recs, int i, bool have) {
   const int q = threadIdx.x & 3;
-  const bool have = i < n;
   if (__builtin_amdgcn_ballot_w64(have) == 0ull) return;
   SeedRec* rp = recs + (have ? i : 0);
   // ONE trip to memory for everything the quad needs: lane q takes one 16-byte word of the seed's record -- {step}, {search
@@ -832,6 +837,15 @@ __global__ __launch_bounds__(ALIGN_BLOCK) void df_align_kernel(DfFrame fr, const
     rp->step[0] = px_cur[0]; rp->step[1] = px_cur[1];
     rp->n_align = n_align;
   }
+}
+
+template <bool ONE_D>
+__global__ __launch_bounds__(ALIGN_BLOCK) void df_align_kernel(DfFrame fr, const uint8_t* __restrict__ cur_pyr, int n, int n_pad,
+                                                               const uint32_t* __restrict__ pwb_t, SeedRec* __restrict__ recs,
+                                                               const int* __restrict__ n_dev = nullptr) {
+  if (n_dev) { const int nd = *n_dev; n = nd < n ? nd : n; }
+  const int i = blockIdx.x * ALIGN_PATCHES + (threadIdx.x >> 2);
+  df_align_quad<ONE_D>(fr, cur_pyr, n_pad, pwb_t, recs, i, i < n);
 }
 
 // EVENTS (device-resident seed batches, svo_hip_seed_batch_*): the kernel also counts, per block, the seeds whose outcome
@@ -1870,6 +1884,119 @@ __global__ __launch_bounds__(256) void ev_scatter_group_kernel(DfGroup g) {
                    J.events_host, J.events_dev);
 }
 
+// ---- small passes: two launches ------------------------------------------------------------------------------------------
+// Below a few thousand seeds every stage is a handful of workgroups whose time is its launch and a chain of dependent memory
+// trips (4 keyframes x 500 seeds: geometry 11, search 10, align 18, finalize 12 us with events between them), six launches a
+// frame.  Here ONE wave takes its four seeds through all four stages -- geometry on lanes 0-3, the search stage as it is (it
+// never had a block-level barrier: a wave works on its own four seeds), alignment on lanes 0-15 (a quad per seed), the update
+// on lanes 0-3 -- handing the records and warped patches from stage to stage through the same scratch as the large pass
+// (same wave, same CU: a workgroup-scope fence orders them), and a second launch of one workgroup per batch does what the
+// finalize stage's bookkeeping, ev_scan and ev_scatter do: outcome counts, `alive`, the scan and the ordered events.
+// The lanes that idle through the f64 stages cost nothing here: the chip is empty.  Same device functions as the large pass,
+// so every per-seed result is bit-identical (tests/test_gpu_seed_batch.py).
+constexpr int DF_SMALL_MAX = 16384;                       // upper limit of svo_hip_df_set_small_pass_limit
+__global__ __launch_bounds__(256) void df_small_pass_kernel(DfFrame fr, DfGroup g, const uint8_t* __restrict__ ref_base,
+                                                            size_t ref_pyr_bytes, const uint8_t* __restrict__ cur_pyr, int n_cat,
+                                                            SeedRec* __restrict__ recs, uint32_t* __restrict__ pwb_t,
+                                                            int32_t* __restrict__ level_cat, int n_pad) {
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int r0 = (blockIdx.x * 4 + wib) * SEEDS_PER_WAVE;   // the wave's first record
+  if (r0 >= n_cat) return;                                 // wave-uniform; no block-level barrier below
+  const DfJob& J = g.job[df_job_of_block(g, blockIdx.x >> 4)];          // 16 of these workgroups per 256-seed block
+  const int i0 = r0 - J.first_block * 256;                 // ... and its first seed within its batch
+  // ---- geometry
+  if (lane < SEEDS_PER_WAVE) {
+    const int i = i0 + lane;
+    const size_t r = (size_t)r0 + lane;
+    if (i < J.n) {
+      level_cat[r] = J.level[i];
+      df_geometry_seed<false>(fr.cam, J.T_cur_ref_vis, J.T_cur_ref, fr.n_pyr_levels, fr.max_epi_search_steps, J.ref_slot, i, J.n, J.px, J.f,
+                              J.level, J.mu, J.sigma2, nullptr, nullptr, recs + r, J.alive);
+    } else {
+      SeedRec rc;
+      rc.uv0[0] = rc.uv0[1] = rc.step[0] = rc.step[1] = 0.0;
+      rc.a00 = rc.a01 = rc.a10 = rc.a11 = rc.prx = rc.pry = rc.z_inv_min = 0.0f;
+      rc.n_steps = 0; rc.search_level = 0; rc.path = -1; rc.status = SVO_HIP_SEED_ERASED; rc.warp_nan = 0;
+      rc.matched = 0; rc.n_zmssd = 0; rc.n_align = 0; rc.pad = 0;
+      recs[r] = rc;
+      level_cat[r] = 0;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // ---- warp + epipolar search
+  df_search_block(fr, ref_base, ref_pyr_bytes, cur_pyr, n_cat, level_cat, recs, pwb_t, n_pad, blockIdx.x);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // ---- align2D
+  {
+    const int r = r0 + (lane >> 2);
+    df_align_quad<false>(fr, cur_pyr, n_pad, pwb_t, recs, r, lane < 4 * SEEDS_PER_WAVE && r < n_cat);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // ---- triangulation, computeTau, updateSeed
+  if (lane < SEEDS_PER_WAVE && i0 + lane < J.n) {
+    const SeedRec rc = recs[(size_t)r0 + lane];
+    (void)df_finalize_seed(fr.cam, J.T_cur_ref, J.T_ref_cur, J.T_ref_inv, fr.px_error_angle, fr.conv_thresh, i0 + lane, rc, J.f, J.a, J.b,
+                           J.mu, J.z_range, J.sigma2, J.status, nullptr, J.xyz, nullptr, nullptr, J.px_cur, nullptr);
+  }
+}
+
+// one workgroup of 1024 per batch: what df_finalize_events + ev_scan_block + ev_scatter_block do, for a batch of at most
+// DF_SMALL_MAX seeds
+__global__ __launch_bounds__(1024) void ev_small_kernel(DfGroup g) {
+  const DfJob& J = g.job[blockIdx.x];
+  const int n = J.n, report_updated = g.report_updated;
+  __shared__ int s_cnt[DF_SMALL_MAX / 256], s_off[DF_SMALL_MAX / 256], s_hist[8], s_w[16], s_total;
+  if (threadIdx.x < DF_SMALL_MAX / 256) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 8) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const int st = J.status[i];
+    const bool gone = st == SVO_HIP_SEED_CONVERGED || st == SVO_HIP_SEED_NAN;
+    if (gone) J.alive[i] = 0;
+    atomicAdd(&s_hist[st + 1], 1);
+    if (gone || (report_updated && st >= SVO_HIP_SEED_UPDATED)) atomicAdd(&s_cnt[i >> 8], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {                                  // exclusive scan of the (at most 64) block counts
+    const int v = threadIdx.x < J.n_blocks ? s_cnt[threadIdx.x] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += t; }
+    s_off[threadIdx.x] = incl - v;
+    if (threadIdx.x == 63) s_total = incl;
+  }
+  __syncthreads();
+  const int total = s_total;
+  if (threadIdx.x == 0) { J.header->n_events = total; J.hist[8] = total; }
+  if (threadIdx.x < 7) J.header->counts[threadIdx.x] = s_hist[threadIdx.x];
+  svo_hip_seed_event* events = total <= EV_DIRECT_MAX ? J.events_host : J.events_dev;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int st = i < n ? J.status[i] : SVO_HIP_SEED_ERASED;
+    const bool ev = st == SVO_HIP_SEED_CONVERGED || st == SVO_HIP_SEED_NAN || (report_updated && st >= SVO_HIP_SEED_UPDATED);
+    const unsigned long long m = __ballot(ev);
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    if (ev) {
+      int off = s_off[i >> 8];
+      for (int w = wave & ~3; w < wave; ++w) off += s_w[w];          // the waves of this 256-seed block before mine
+      off += __popcll(m & ((1ull << lane) - 1ull));
+      svo_hip_seed_event e;
+      e.index = i; e.status = st; e.mu = J.mu[i]; e.sigma2 = J.sigma2[i];
+      const bool conv = st == SVO_HIP_SEED_CONVERGED;
+      e.xyz_world[0] = conv ? J.xyz[3 * (size_t)i] : 0.0; e.xyz_world[1] = conv ? J.xyz[3 * (size_t)i + 1] : 0.0; e.xyz_world[2] = conv ? J.xyz[3 * (size_t)i + 2] : 0.0;
+      e.px_cur[0] = J.px_cur[2 * (size_t)i]; e.px_cur[1] = J.px_cur[2 * (size_t)i + 1];
+      events[off] = e;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 struct svo_hip_seed_batch {
@@ -1971,12 +2098,26 @@ int svo_hip_seed_batch_size(const svo_hip_seed_batch* sb, int* n, int* n_alive) 
   return SVO_HIP_OK;
 }
 
+static int sb_enqueue_jobs(svo_hip_ctx* ctx, int n_jobs, svo_hip_seed_batch* const* batches, const svo_hip_pyramid* ref, const int* ref_slots,
+                           const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam, const double* T_ref_w,
+                           const double T_cur_w[7], const svo_hip_df_params* prm, int report_updated);
+static int sb_check_pass_args(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                              const svo_hip_df_params* prm);
+
 int svo_hip_seed_batch_update_async(svo_hip_seed_batch* sb, const svo_hip_pyramid* ref, int ref_slot, const svo_hip_pyramid* cur,
                                     int cur_slot, const svo_hip_camera* cam, const double T_ref_w[7], const double T_cur_w[7],
                                     const svo_hip_df_params* prm, int report_updated) {
   if (!sb) return SVO_HIP_ERR_INVALID;
   svo_hip_ctx* ctx = sb->ctx;
   if (sb->pending) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_seed_batch_update_async", "the previous pass has not been collected");
+  if (sb->n_blocks * 256 <= ctx->df_small_max) {           // a small batch: the two-launch form (sb_enqueue_jobs)
+    if (!ref || !cur || !cam || !T_ref_w || !T_cur_w || !prm) return SVO_HIP_ERR_INVALID;
+    SVO_REQUIRE(ctx, ref_slot >= 0 && ref_slot < ref->batch);
+    const int rc = sb_check_pass_args(ctx, ref, cur, cur_slot, cam, prm);
+    if (rc != SVO_HIP_OK) return rc;
+    SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    return sb_enqueue_jobs(ctx, 1, &sb, ref, &ref_slot, cur, cur_slot, cam, T_ref_w, T_cur_w, prm, report_updated);
+  }
   DfEvents ev;
   ev.alive = sb->alive; ev.report_updated = report_updated ? 1 : 0; ev.block_count = sb->block_count; ev.hist = sb->hist;
   const int rc = df_run_pass(ctx, ref, ref_slot, cur, cur_slot, cam, T_ref_w, T_cur_w, sb->n, sb->px, sb->f, sb->level, sb->a, sb->b, sb->mu,
@@ -1990,6 +2131,83 @@ int svo_hip_seed_batch_update_async(svo_hip_seed_batch* sb, const svo_hip_pyrami
   SVO_CHECK_HIP(ctx, hipGetLastError());
   sb->pending = true;
   sb->report_updated = ev.report_updated;
+  return SVO_HIP_OK;
+}
+
+// one launch set over at most DF_GROUP_MAX batches (arguments checked by the callers)
+static int sb_enqueue_jobs(svo_hip_ctx* ctx, int n_jobs, svo_hip_seed_batch* const* batches, const svo_hip_pyramid* ref, const int* ref_slots,
+                           const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam, const double* T_ref_w,
+                           const double T_cur_w[7], const svo_hip_df_params* prm, int report_updated) {
+  const uint8_t* cur_img = cur->base + (size_t)cur_slot * cur->pyr_bytes;
+  const bool prof = ctx->df_profile;
+  auto stamp = [&](int k) { if (prof) (void)hipEventRecord(ctx->df_ev[k], ctx->stream); };
+  DfFrame fr;
+  df_make_frame(ref, cur, cam, T_ref_w, T_cur_w, prm, fr);
+  DfGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n_jobs = n_jobs;
+  g.report_updated = report_updated ? 1 : 0;
+  int n_blocks = 0, n_cat = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    svo_hip_seed_batch* sb = batches[j];
+    DfJob& J = g.job[j];
+    DfFrame fj;
+    df_make_frame(ref, cur, cam, T_ref_w + 7 * (size_t)j, T_cur_w, prm, fj);
+    memcpy(J.T_ref_cur, fj.T_ref_cur, sizeof(J.T_ref_cur)); memcpy(J.T_cur_ref_vis, fj.T_cur_ref_vis, sizeof(J.T_cur_ref_vis));
+    memcpy(J.T_cur_ref, fj.T_cur_ref, sizeof(J.T_cur_ref)); memcpy(J.T_ref_inv, fj.T_ref_inv, sizeof(J.T_ref_inv));
+    J.px = sb->px; J.f = sb->f; J.level = sb->level; J.a = sb->a; J.b = sb->b; J.mu = sb->mu; J.z_range = sb->z_range; J.sigma2 = sb->sigma2;
+    J.status = sb->status; J.xyz = sb->xyz; J.px_cur = sb->px_cur; J.alive = sb->alive; J.block_count = sb->block_count; J.hist = sb->hist;
+    J.header = reinterpret_cast<EvHeader*>(sb->host_dev);
+    J.events_host = reinterpret_cast<svo_hip_seed_event*>(sb->host_dev + kEvHeaderBytes);
+    J.events_dev = sb->events_dev;
+    J.n = sb->n; J.n_blocks = sb->n_blocks; J.first_block = n_blocks; J.ref_slot = ref_slots[j];
+    n_cat = n_blocks * 256 + sb->n;
+    n_blocks += sb->n_blocks;
+  }
+  // scratch of the pass: records (every block of the thread-per-seed stages whole), the transposed patches, the levels
+  const int n_rec = n_blocks * 256, n_pad = n_rec;
+  const size_t rec_bytes = (size_t)n_rec * sizeof(SeedRec), pwb_bytes = (size_t)25 * n_pad * sizeof(uint32_t);
+  void* ws = nullptr;
+  {
+    const int rc = svo_ctx_scratch(ctx, rec_bytes + pwb_bytes + (size_t)n_rec * sizeof(int32_t), &ws);
+    if (rc != SVO_HIP_OK) return rc;
+  }
+  SeedRec* recs = (SeedRec*)ws;
+  uint32_t* pwb_t = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + rec_bytes);
+  int32_t* level_cat = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + rec_bytes + pwb_bytes);
+  stamp(0);
+  if (n_rec <= ctx->df_small_max) {
+    // two launches: a wave takes its four seeds through every stage, then one workgroup per batch does the events
+    hipLaunchKernelGGL(df_small_pass_kernel, dim3((n_cat + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, g,
+                       ref->base, ref->pyr_bytes, cur_img, n_cat, recs, pwb_t, level_cat, n_pad);
+    stamp(1); stamp(2); stamp(3);
+    if (prof) { (void)hipEventRecord(ctx->df_ev[4], ctx->stream); ctx->df_ev_recorded = true; }
+    hipLaunchKernelGGL(ev_small_kernel, dim3(n_jobs), dim3(1024), 0, ctx->stream, g);
+  } else {
+    hipLaunchKernelGGL(df_geometry_group_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, fr, g, recs, level_cat);
+    stamp(1);
+    hipLaunchKernelGGL(df_search_kernel, dim3((n_cat + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref->base,
+                       ref->pyr_bytes, cur_img, n_cat, (const int32_t*)level_cat, recs, pwb_t, n_pad);
+    stamp(2);
+    launch_df_align<false>(ctx, fr, cur_img, n_cat, n_pad, pwb_t, recs);
+    stamp(3);
+    hipLaunchKernelGGL(df_finalize_group_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, fr, g, (const SeedRec*)recs);
+    if (prof) { (void)hipEventRecord(ctx->df_ev[4], ctx->stream); ctx->df_ev_recorded = true; }
+    hipLaunchKernelGGL(ev_scan_group_kernel, dim3(n_jobs), dim3(1024), 0, ctx->stream, g);
+    hipLaunchKernelGGL(ev_scatter_group_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, g);
+  }
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  for (int j = 0; j < n_jobs; ++j) { batches[j]->pending = true; batches[j]->report_updated = g.report_updated; }
+  return SVO_HIP_OK;
+}
+
+// the argument checks df_run_pass makes, for the entry points that build their launches themselves
+static int sb_check_pass_args(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
+                              const svo_hip_df_params* prm) {
+  SVO_REQUIRE(ctx, cur_slot >= 0 && cur_slot < cur->batch);
+  SVO_REQUIRE(ctx, ref->width == cam->width && ref->height == cam->height && cur->width == cam->width && cur->height == cam->height);
+  SVO_REQUIRE(ctx, prm->n_pyr_levels >= 1 && prm->n_pyr_levels <= ref->n_levels && prm->n_pyr_levels <= cur->n_levels);
+  SVO_REQUIRE(ctx, prm->align_max_iter >= 0 && prm->max_epi_search_steps >= 0);
   return SVO_HIP_OK;
 }
 
@@ -2010,65 +2228,24 @@ int svo_hip_seed_batch_update_group_async(int n_batches, svo_hip_seed_batch* con
     for (int m = 0; m < k; ++m) SVO_REQUIRE(ctx, batches[m] != sb);
     SVO_REQUIRE(ctx, ref_slots[k] >= 0 && ref_slots[k] < ref->batch);
   }
-  SVO_REQUIRE(ctx, cur_slot >= 0 && cur_slot < cur->batch);
-  SVO_REQUIRE(ctx, ref->width == cam->width && ref->height == cam->height && cur->width == cam->width && cur->height == cam->height);
-  SVO_REQUIRE(ctx, prm->n_pyr_levels >= 1 && prm->n_pyr_levels <= ref->n_levels && prm->n_pyr_levels <= cur->n_levels);
-  SVO_REQUIRE(ctx, prm->align_max_iter >= 0 && prm->max_epi_search_steps >= 0);
+  {
+    const int rc = sb_check_pass_args(ctx, ref, cur, cur_slot, cam, prm);
+    if (rc != SVO_HIP_OK) return rc;
+  }
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  const uint8_t* cur_img = cur->base + (size_t)cur_slot * cur->pyr_bytes;
-  const bool prof = ctx->df_profile;
-  auto stamp = [&](int k) { if (prof) (void)hipEventRecord(ctx->df_ev[k], ctx->stream); };
   for (int first = 0; first < n_batches; first += DF_GROUP_MAX) {
     const int n_jobs = n_batches - first < DF_GROUP_MAX ? n_batches - first : DF_GROUP_MAX;
-    DfFrame fr;
-    df_make_frame(ref, cur, cam, T_ref_w + 7 * (size_t)first, T_cur_w, prm, fr);
-    DfGroup g;
-    memset(&g, 0, sizeof(g));
-    g.n_jobs = n_jobs;
-    g.report_updated = report_updated ? 1 : 0;
-    int n_blocks = 0, n_cat = 0;
-    for (int j = 0; j < n_jobs; ++j) {
-      svo_hip_seed_batch* sb = batches[first + j];
-      DfJob& J = g.job[j];
-      DfFrame fj;
-      df_make_frame(ref, cur, cam, T_ref_w + 7 * (size_t)(first + j), T_cur_w, prm, fj);
-      memcpy(J.T_ref_cur, fj.T_ref_cur, sizeof(J.T_ref_cur)); memcpy(J.T_cur_ref_vis, fj.T_cur_ref_vis, sizeof(J.T_cur_ref_vis));
-      memcpy(J.T_cur_ref, fj.T_cur_ref, sizeof(J.T_cur_ref)); memcpy(J.T_ref_inv, fj.T_ref_inv, sizeof(J.T_ref_inv));
-      J.px = sb->px; J.f = sb->f; J.level = sb->level; J.a = sb->a; J.b = sb->b; J.mu = sb->mu; J.z_range = sb->z_range; J.sigma2 = sb->sigma2;
-      J.status = sb->status; J.xyz = sb->xyz; J.px_cur = sb->px_cur; J.alive = sb->alive; J.block_count = sb->block_count; J.hist = sb->hist;
-      J.header = reinterpret_cast<EvHeader*>(sb->host_dev);
-      J.events_host = reinterpret_cast<svo_hip_seed_event*>(sb->host_dev + kEvHeaderBytes);
-      J.events_dev = sb->events_dev;
-      J.n = sb->n; J.n_blocks = sb->n_blocks; J.first_block = n_blocks; J.ref_slot = ref_slots[first + j];
-      n_cat = n_blocks * 256 + sb->n;
-      n_blocks += sb->n_blocks;
-    }
-    // scratch of the pass: records (every block of the thread-per-seed stages whole), the transposed patches, the levels
-    const int n_rec = n_blocks * 256, n_pad = n_rec;
-    const size_t rec_bytes = (size_t)n_rec * sizeof(SeedRec), pwb_bytes = (size_t)25 * n_pad * sizeof(uint32_t);
-    void* ws = nullptr;
-    {
-      const int rc = svo_ctx_scratch(ctx, rec_bytes + pwb_bytes + (size_t)n_rec * sizeof(int32_t), &ws);
-      if (rc != SVO_HIP_OK) return rc;
-    }
-    SeedRec* recs = (SeedRec*)ws;
-    uint32_t* pwb_t = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + rec_bytes);
-    int32_t* level_cat = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + rec_bytes + pwb_bytes);
-    stamp(0);
-    hipLaunchKernelGGL(df_geometry_group_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, fr, g, recs, level_cat);
-    stamp(1);
-    hipLaunchKernelGGL(df_search_kernel, dim3((n_cat + SEEDS_PER_BLOCK - 1) / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref->base,
-                       ref->pyr_bytes, cur_img, n_cat, (const int32_t*)level_cat, recs, pwb_t, n_pad);
-    stamp(2);
-    launch_df_align<false>(ctx, fr, cur_img, n_cat, n_pad, pwb_t, recs);
-    stamp(3);
-    hipLaunchKernelGGL(df_finalize_group_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, fr, g, (const SeedRec*)recs);
-    if (prof) { (void)hipEventRecord(ctx->df_ev[4], ctx->stream); ctx->df_ev_recorded = true; }
-    hipLaunchKernelGGL(ev_scan_group_kernel, dim3(n_jobs), dim3(1024), 0, ctx->stream, g);
-    hipLaunchKernelGGL(ev_scatter_group_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, g);
-    SVO_CHECK_HIP(ctx, hipGetLastError());
-    for (int j = 0; j < n_jobs; ++j) { batches[first + j]->pending = true; batches[first + j]->report_updated = g.report_updated; }
+    const int rc = sb_enqueue_jobs(ctx, n_jobs, batches + first, ref, ref_slots + first, cur, cur_slot, cam, T_ref_w + 7 * (size_t)first, T_cur_w,
+                                   prm, report_updated);
+    if (rc != SVO_HIP_OK) return rc;
   }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_df_set_small_pass_limit(svo_hip_ctx* ctx, int max_seeds) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, max_seeds >= 0 && max_seeds <= DF_SMALL_MAX);
+  ctx->df_small_max = max_seeds;
   return SVO_HIP_OK;
 }
 

@@ -22,6 +22,7 @@ struct svo_hip_ctx {
   size_t host_staging_bytes = 0;
   // stage timing of the depth-filter pass (svo_hip_df_set_profiling): events around geometry / search / align / finalize
   bool df_profile = false;
+  int df_small_max = 8192;             // passes of at most this many seed records take the two-launch form (svo_depth.hip)
   bool df_ev_recorded = false;
   hipEvent_t df_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   char err[512] = {0};

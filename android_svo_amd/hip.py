@@ -113,6 +113,11 @@ class Context:
     def stream(self) -> int:
         return self.lib.svo_hip_ctx_stream(self.h) or 0
 
+    def set_small_pass_limit(self, max_seeds: int):
+        """svo_hip_df_set_small_pass_limit: depth-filter passes over resident seed batches of at most this many seed
+        records take the two-launch form (0: never)."""
+        self.check(self.lib.svo_hip_df_set_small_pass_limit(self.h, int(max_seeds)), "df_set_small_pass_limit")
+
     def malloc(self, nbytes: int) -> int:
         p = C.c_void_p()
         self.check(self.lib.svo_hip_malloc(self.h, C.byref(p), C.c_size_t(nbytes)), "malloc")

@@ -435,6 +435,11 @@ int svo_hip_seed_batch_update_group_async(int n_batches, svo_hip_seed_batch* con
                                           const int* ref_slots, const svo_hip_pyramid* cur, int cur_slot,
                                           const svo_hip_camera* cam, const double* T_ref_w /* [n_batches][7] */,
                                           const double T_cur_w[7], const svo_hip_df_params* prm, int report_updated);
+/* diagnostic / tuning: passes of at most max_seeds seed records (sum over the batches of a call, each rounded up to 256)
+ * run as TWO launches -- one wave takes its four seeds through geometry, search, alignment and update, then one workgroup
+ * per batch writes the events -- instead of six; results are bit-identical.  0 switches the form off; at most 16384;
+ * the default is 8192 (DESIGN.md section 8 has the crossover measurement). */
+int svo_hip_df_set_small_pass_limit(svo_hip_ctx* ctx, int max_seeds);
 /* wait for the pass; *events points into page-locked memory owned by the batch (valid until its next update_async);
  * status_counts[7]: seeds per outcome of this pass, slot = status + 1 (slot 0 = SVO_HIP_SEED_ERASED ... slot 6 =
  * SVO_HIP_SEED_NAN).  Either output may be NULL. */

@@ -25,8 +25,8 @@ def _case(ctx, n, sigma_scale, width=640, height=480):
     return sc, kf, cf, s2
 
 
-def test_resident_batch_equals_the_stateless_pass_over_several_frames(ctx):
-    n = 20000
+@pytest.mark.parametrize("n", [20000, 1500])               # 1500: the two-launch form of small passes (svo_hip_df_set_small_pass_limit)
+def test_resident_batch_equals_the_stateless_pass_over_several_frames(ctx, n):
     sc, kf, cf, s2 = _case(ctx, n, 0.0045, 1280, 720)          # bench_c4's seed variance: about half converge in the first pass
     sb = hip.SeedBatch(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, s2)
     rs = hip.ResidentSeeds(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, s2)
@@ -59,7 +59,7 @@ def test_resident_batch_equals_the_stateless_pass_over_several_frames(ctx):
         assert np.array_equal(d["alive"].astype(bool), alive) and rs.n_alive() == int(alive.sum())
         for k, arr in (("a", sb.a), ("b", sb.b), ("mu", sb.mu), ("sigma2", sb.sigma2)):
             assert np.array_equal(d[k][alive], arr.download()[alive]), (frame, k)
-    assert total_events > 500 and alive.sum() < n                     # the case does converge seeds
+    assert total_events > n // 40 and alive.sum() < n                 # the case does converge seeds
     rs.destroy()
     sb.free()
 
@@ -114,11 +114,13 @@ def test_two_batches_enqueued_back_to_back_one_wait(ctx):
         o_.destroy()
 
 
+@pytest.mark.parametrize("small_limit", [16384, 0])
 @pytest.mark.parametrize("sizes", [(500, 1, 255, 256, 700), (300,) * 11, (3000, 4097)])
-def test_grouped_pass_over_several_keyframes_equals_one_pass_per_keyframe(ctx, sizes):
+def test_grouped_pass_over_several_keyframes_equals_one_pass_per_keyframe(ctx, sizes, small_limit):
     """svo_hip_seed_batch_update_group_async: the seeds of every keyframe of a frame through ONE set of launches --
     states, events and status counts per batch bit-identical to one svo_hip_seed_batch_update_async per keyframe (sizes
-    that end inside a block, a single seed, more batches than one launch set takes)."""
+    that end inside a block, a single seed, more batches than one launch set takes).  The passes per keyframe run as six
+    launches each (the two-launch form of small passes switched off); the grouped ones in both forms."""
     mk = seedsynth.make_multi_keyframe_case(sizes, seed=31)
     K = len(sizes)
     kf = hip.Pyramid(ctx, mk.cam.width, mk.cam.height, 5, K)
@@ -138,9 +140,11 @@ def test_grouped_pass_over_several_keyframes_equals_one_pass_per_keyframe(ctx, s
     n_events = 0
     for frame in range(3):
         keyframe = frame == 1
+        ctx.set_small_pass_limit(0)
         for k, sc in enumerate(mk.keyframes):
             one[k].update_async(kf, slots[k], cf, 0, mk.cam, sc.T_ref_w, mk.T_cur_w, report_updated=keyframe)
         want = [r.collect() for r in one]
+        ctx.set_small_pass_limit(small_limit)
         hip.ResidentSeeds.update_group_async(grp, kf, slots, cf, 0, mk.cam, T_refs, mk.T_cur_w, report_updated=keyframe)
         got = [r.collect() for r in grp]
         for k in range(K):
@@ -163,3 +167,4 @@ def test_grouped_pass_over_several_keyframes_equals_one_pass_per_keyframe(ctx, s
     for r in one + grp:
         r.destroy()
     kf.destroy(); cf.destroy()
+    ctx.set_small_pass_limit(8192)

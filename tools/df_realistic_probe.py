@@ -1,6 +1,7 @@
 """What a frame of the drop-in DepthFilter costs at the sizes the reference produces (a few keyframes, a few hundred seeds
-each): one pass per keyframe (svo_hip_seed_batch_update_async per batch) against ONE set of launches for all of them
-(svo_hip_seed_batch_update_group_async), events collected, host side included.  -> profiles/r*_df_realistic_sizes.txt"""
+each): one pass per keyframe (svo_hip_seed_batch_update_async per batch, six launches each) against ONE set of launches for
+all of them (svo_hip_seed_batch_update_group_async) in its six-launch and its two-launch form
+(svo_hip_df_set_small_pass_limit), events collected, host side included.  -> profiles/r*_df_realistic_sizes.txt"""
 import os
 import sys
 import time
@@ -11,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from android_svo_amd import hip, seedsynth  # noqa: E402
 
 ctx = hip.Context(0)
-for n_b, n_s in ((4, 500), (4, 2000), (8, 300), (1, 2000), (1, 500)):
+for n_b, n_s in ((4, 500), (4, 2000), (8, 300), (1, 500), (1, 2000), (1, 4000), (1, 8000), (2, 8000), (1, 16000)):
     mk = seedsynth.make_multi_keyframe_case((n_s,) * n_b, seed=9)
     kf = hip.Pyramid(ctx, 640, 480, 5, n_b)
     cf = hip.Pyramid(ctx, 640, 480, 5, 1)
@@ -34,7 +35,9 @@ for n_b, n_s in ((4, 500), (4, 2000), (8, 300), (1, 2000), (1, 500)):
             r.collect_raw()
 
     out = []
-    for name, fn in (("one pass per keyframe", per_keyframe), ("one launch set", grouped)):
+    for name, fn, limit in (("one pass per keyframe", per_keyframe, 0), ("one launch set (6 launches)", grouped, 0),
+                            ("one launch set, small-pass form (2 launches)", grouped, 16384)):
+        ctx.set_small_pass_limit(limit)
         for r in rs:
             r.destroy()
         rs[:] = [hip.ResidentSeeds(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, sc.sigma2) for sc in mk.keyframes]   # same seed state for both forms
