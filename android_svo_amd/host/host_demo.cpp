@@ -316,9 +316,16 @@ int main(int argc, char** argv) {
           if (threaded) df.startThread();
           df.addKeyframe(c.frames[0], dm[0], dm[1], fa);
           wait_idle();
+          std::vector<double> frame_us;           // synchronous protocols: what DepthFilter::addFrame (= updateSeeds) took, per frame
           for (int k = 1; k < c.n_frames; ++k) {
+            const auto t0 = std::chrono::steady_clock::now();
             if (k == kf2) df.addKeyframe(c.frames[k], dm[0], dm[1], fb);
             else df.addFrame(c.frames[k]);
+            if (!threaded) {                      // rows of: us, seeds on the device, uploaded by this call, converged, NaN, list re-read
+              frame_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+              const svo::hip_bridge::SeedBatchStats& ls = df.last_stats_;
+              frame_us.insert(frame_us.end(), {(double)ls.n_seeds, (double)ls.n_uploaded, (double)ls.n_converged, (double)ls.n_nan, ls.resynced ? 1.0 : 0.0});
+            }
             wait_idle();
             if (k == remove_a_after) {
               // Map::removeKeyframe path (depth_filter.cpp:153-170): every seed of the SECOND keyframe leaves the list BEHIND the
@@ -332,6 +339,7 @@ int main(int argc, char** argv) {
             }
           }
           if (threaded) df.stopThread();
+          if (!threaded) write_bin(out + "/" + tag + "_frame_us.bin", frame_us);
           dump_filter(df, index, conv, out, tag);
         }
         std::vector<uint8_t> occ(grid.grid_occupancy_.begin(), grid.grid_occupancy_.end());

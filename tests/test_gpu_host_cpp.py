@@ -188,6 +188,17 @@ def test_cpp_host_layer_end_to_end(tmp_path, dist):
     np.testing.assert_array_equal(np.fromfile(out / "sync_seeds.bin"), np.fromfile(out / "sync_small_seeds.bin"))
     np.testing.assert_array_equal(np.fromfile(out / "sync_conv.bin"), np.fromfile(out / "sync_small_conv.bin"))
     assert summary[0] >= 1                                     # the main thread really aligned frames meanwhile
+    # what DepthFilter::addFrame (= updateSeeds through the device mirror, host side included) took per frame in the synchronous
+    # protocols: a record for profiles/ (3000 seeds of one keyframe, then + 1500 of a second), no timing assertion
+    frame_us = np.fromfile(out / "sync_frame_us.bin").reshape(-1, 6)
+    assert len(frame_us) == n_frames - 1 and (frame_us[:, 0] > 0).all()
+    log_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(log_dir):
+        with open(os.path.join(log_dir, "host_cpp_frame_us_%s.txt" % ("radtan" if dist is not None else "pinhole")), "w") as fh:
+            for tag in ("sync", "sync_small", "remove"):
+                fh.write("%s: per addFrame / addKeyframe call: us | seeds on the device, uploaded by the call, converged, NaN, list re-read\n" % tag)
+                for row in np.fromfile(out / (tag + "_frame_us.bin")).reshape(-1, 6):
+                    fh.write("   %8.1f | %5d %5d %5d %5d %d\n" % (row[0], row[1], row[2], row[3], row[4], row[5]))
 
 
 # ---- svo::FrameTracker (hip_bridge::FrameTrackerT, the template the drop-in instantiates on the reference's types) run on
