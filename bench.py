@@ -47,10 +47,10 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PRECOMPUTE = 945           # per patch per level
 BYTES_RESIDUAL = 881             # per patch per Gauss-Newton evaluation
 # frame pairs per GPU per launch.  One 8-wave workgroup solves one pair and fills one CU: with 256 pairs every CU runs
-# exactly one workgroup and the launch lasts as long as its slowest scene; four workgroups per CU balance that a little
-# (tools/batch_sweep.sh on a warm chip, same box: 256 / 1024 / 2048 pairs -> 210.5 / 211.8 / 213.3 k frames/s) and the
-# streaming form of the pass, whose launches are 29 us at 256 pairs, gains more (0.58 -> 0.65 of HBM peak)
-DEFAULT_BATCH = 1024
+# exactly one workgroup and the launch lasts as long as its slowest scene; more workgroups per CU balance that
+# (same box, default arithmetic, profiles/r04_batch_sweep.txt: 1024 / 2048 / 4096 pairs -> 225.1 / 227.1 / 229.0 k frames/s;
+# 4096 pairs are 3.9 GB of resident pyramids of the 288 GB) and the streaming form of the pass gains more
+DEFAULT_BATCH = 4096
 
 
 def parse_args():
@@ -242,7 +242,8 @@ PREWARM_S = 0.1
 # says what every key means; round 3's 14 kB line lost its first half in the driver's tail)
 PROSE_KEYS = {"what", "note", "rule", "traffic_rule", "sample", "legs", "measured_ceiling", "ms_per_frame_image_in_tracker_buffer_median",
               "ms_per_frame_min", "algorithmic_bytes", "algorithmic_GBps", "nproc", "cpus_granted_to_this_process", "patches_per_s",
-              "seeds_per_s", "ms_per_frame_median", "converged", "steps_secondary"}
+              "seeds_per_s", "ms_per_frame_median", "converged", "steps_secondary", "transcendental_insts", "bytes_per_launch_as_counted",
+              "upload_only_ms_per_step", "bytes_uploaded_per_step"}
 
 
 def slim(o, verbose=False):
