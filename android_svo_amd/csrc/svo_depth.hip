@@ -1849,12 +1849,9 @@ __global__ __launch_bounds__(256) void df_geometry_group_kernel(DfFrame fr, DfGr
     level_cat[r] = J.level[i];
     df_geometry_seed<false>(fr.cam, J.T_cur_ref_vis, J.T_cur_ref, fr.n_pyr_levels, fr.max_epi_search_steps, J.ref_slot, i, J.n, J.px, J.f,
                             J.level, J.mu, J.sigma2, nullptr, nullptr, recs + r, J.alive);
-  } else {
-    SeedRec rc;
-    rc.uv0[0] = rc.uv0[1] = rc.step[0] = rc.step[1] = 0.0;
-    rc.a00 = rc.a01 = rc.a10 = rc.a11 = rc.prx = rc.pry = rc.z_inv_min = 0.0f;
-    rc.n_steps = 0; rc.search_level = 0; rc.path = -1; rc.status = SVO_HIP_SEED_ERASED; rc.warp_nan = 0;
-    rc.matched = 0; rc.n_zmssd = 0; rc.n_align = 0; rc.pad = 0;
+  } else {                                                 // the tail of the batch's last block: records no stage touches
+    SeedRec rc = md_dead_record();
+    rc.status = SVO_HIP_SEED_ERASED;
     recs[r] = rc;
     level_cat[r] = 0;
   }
@@ -1913,12 +1910,9 @@ __global__ __launch_bounds__(256) void df_small_pass_kernel(DfFrame fr, DfGroup 
       level_cat[r] = J.level[i];
       df_geometry_seed<false>(fr.cam, J.T_cur_ref_vis, J.T_cur_ref, fr.n_pyr_levels, fr.max_epi_search_steps, J.ref_slot, i, J.n, J.px, J.f,
                               J.level, J.mu, J.sigma2, nullptr, nullptr, recs + r, J.alive);
-    } else {
-      SeedRec rc;
-      rc.uv0[0] = rc.uv0[1] = rc.step[0] = rc.step[1] = 0.0;
-      rc.a00 = rc.a01 = rc.a10 = rc.a11 = rc.prx = rc.pry = rc.z_inv_min = 0.0f;
-      rc.n_steps = 0; rc.search_level = 0; rc.path = -1; rc.status = SVO_HIP_SEED_ERASED; rc.warp_nan = 0;
-      rc.matched = 0; rc.n_zmssd = 0; rc.n_align = 0; rc.pad = 0;
+    } else {                                               // the tail of a batch's last block
+      SeedRec rc = md_dead_record();
+      rc.status = SVO_HIP_SEED_ERASED;
       recs[r] = rc;
       level_cat[r] = 0;
     }
