@@ -429,7 +429,8 @@ int svo_hip_seed_batch_update_async(svo_hip_seed_batch* batch, const svo_hip_pyr
  * depth_filter.cpp:248-340 walks them all) -- as ONE set of launches: batch k against keyframe slot ref_slots[k] of `ref`
  * with pose T_ref_w[7 * k .. 7 * k + 6].  Results per batch are bit-identical to n_batches calls of
  * svo_hip_seed_batch_update_async; what changes is the cost when the batches are small (a few hundred seeds each is what
- * the reference's detector yields per keyframe): six launches per frame instead of six per keyframe.  Everything is
+ * the reference's detector yields per keyframe): one set of launches per frame -- two for passes of a few thousand seeds,
+ * six beyond (svo_hip_df_set_small_pass_limit) -- instead of one set per keyframe.  Everything is
  * checked before anything is enqueued (all batches are updated, or none); collect every batch afterwards. */
 int svo_hip_seed_batch_update_group_async(int n_batches, svo_hip_seed_batch* const* batches, const svo_hip_pyramid* ref,
                                           const int* ref_slots, const svo_hip_pyramid* cur, int cur_slot,
