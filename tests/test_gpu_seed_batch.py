@@ -168,3 +168,44 @@ def test_grouped_pass_over_several_keyframes_equals_one_pass_per_keyframe(ctx, s
         r.destroy()
     kf.destroy(); cf.destroy()
     ctx.set_small_pass_limit(8192)
+
+
+def test_grouped_pass_random_shapes_both_forms_agree(ctx):
+    """Eight random frames' worth of batches (1-12 keyframes, 1-2500 seeds each, some erased by hand, some frames keyframes):
+    the two-launch form of small passes against the six-launch form, states and events bit for bit."""
+    rng = np.random.default_rng(2024)
+    for trial in range(8):
+        K = int(rng.integers(1, 13))
+        sizes = tuple(int(v) for v in rng.integers(1, 2500, K))
+        mk = seedsynth.make_multi_keyframe_case(sizes, seed=100 + trial, width=320, height=240, border=24)
+        kf = hip.Pyramid(ctx, 320, 240, 5, K)
+        cf = hip.Pyramid(ctx, 320, 240, 5, 1)
+        cf.upload(0, mk.cur_pyr)
+        sets = ([], [])
+        for k, sc in enumerate(mk.keyframes):
+            kf.upload(k, sc.ref_pyr)
+            s2 = (sc.sigma2 * np.float32(0.03)).astype(np.float32)
+            for s_ in sets:
+                s_.append(hip.ResidentSeeds(ctx, sc.px, sc.f, sc.level, sc.a, sc.b, sc.mu, sc.z_range, s2))
+        for k in range(K):                                   # seeds removed behind the pass's back (removeKeyframe, reset)
+            if sizes[k] > 10 and rng.random() < 0.5:
+                gone = rng.choice(sizes[k], size=sizes[k] // 7, replace=False)
+                for s_ in sets:
+                    s_[k].erase(gone)
+        T_refs = np.stack([sc.T_ref_w for sc in mk.keyframes])
+        for frame in range(2):
+            keyframe = bool(rng.random() < 0.4)
+            out = []
+            for s_, limit in zip(sets, (0, 16384)):
+                ctx.set_small_pass_limit(limit)
+                hip.ResidentSeeds.update_group_async(s_, kf, list(range(K)), cf, 0, mk.cam, T_refs, mk.T_cur_w, report_updated=keyframe)
+                out.append([r.collect() for r in s_])
+            for k in range(K):
+                assert out[0][k][0].tobytes() == out[1][k][0].tobytes() and np.array_equal(out[0][k][1], out[1][k][1]), (trial, frame, k)
+                d, e = sets[0][k].download(), sets[1][k].download()
+                assert all(d[key].tobytes() == e[key].tobytes() for key in d), (trial, frame, k)
+        for s_ in sets:
+            for r in s_:
+                r.destroy()
+        kf.destroy(); cf.destroy()
+    ctx.set_small_pass_limit(8192)
