@@ -1740,7 +1740,7 @@ struct svo_hip_sia {
   bool fc_dirty = true;
   int shard_rank = 0, shard_world = 1;
   // tuning / diagnostic switches of this object (svo_hip_sia_set_option); 0 / -1 = automatic
-  int opt_mode = 0, opt_waves = 0, opt_chunks = 0, opt_extra_lds = -1, opt_old_tiles = 0, opt_arith = SVO_HIP_SIA_ARITH_MOMENTS_F32;
+  int opt_mode = 0, opt_waves = 0, opt_chunks = 0, opt_extra_lds = -1, opt_old_tiles = 0, opt_arith = SVO_HIP_SIA_ARITH_EXACT;
   // stepwise state
   svo_hip_sia_params prm{};
   int n_slots = 0, level = -1, chunks = 1;

@@ -72,10 +72,11 @@ def parse_args():
     ap.add_argument("--stream-mode", action="store_true",
                     help="time the streaming implementation (one launch per Gauss-Newton evaluation) instead of the fused kernel: the run the PMC "
                          "passes of the Jacobian pass profile (tools/pmc_stream.sh)")
-    ap.add_argument("--arith", choices=["default", "exact", "fast"], default="default",
-                    help="arithmetic level of the fused kernel in the TIMED workload: default = the library's (SVO_HIP_SIA_ARITH_MOMENTS_F32: the "
-                         "reference's residuals and chi2, a patch's two gradient moments summed in f32 -- the headline); exact / fast = the other "
-                         "two levels, for their PMC passes (tools/pmc_fused.sh <tag> --arith exact), reported as secondary sections")
+    ap.add_argument("--arith", choices=["default", "exact", "moments_f32", "fast"], default="default",
+                    help="arithmetic level of the fused kernel in the TIMED workload: default = the library's = exact "
+                         "(SVO_HIP_SIA_ARITH_EXACT: the reference's arithmetic statement by statement, f64 Jres moments -- the headline); "
+                         "moments_f32 / fast = the two opt-in levels, for their PMC passes (tools/pmc_fused.sh <tag> --arith moments_f32), "
+                         "reported as secondary sections")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose-json", action="store_true", help="keep the explanatory strings in the JSON line (default: numbers and sources only; "
                                                                 "what every key means is in profiles/BENCH_KEYS.md)")
@@ -392,7 +393,9 @@ def main():
     sia.set_frames(ref, cur)
     if args.stream_mode:
         sia.set_mode(stream=True)
-    ARITH_OF = {"default": hip.SIA_ARITH_MOMENTS_F32, "exact": hip.SIA_ARITH_EXACT, "fast": hip.SIA_ARITH_FAST}
+    if args.arith == "exact":
+        args.arith = "default"         # the library default IS the reference's arithmetic (nothing is set on the solver object)
+    ARITH_OF = {"default": hip.SIA_ARITH_EXACT, "moments_f32": hip.SIA_ARITH_MOMENTS_F32, "fast": hip.SIA_ARITH_FAST}
     if args.arith != "default":
         sia.set_option(hip.SIA_OPT_ARITH, ARITH_OF[args.arith])
     if allreduce:
@@ -553,7 +556,7 @@ def main():
                    "note": "SURVEY 8(d): 945 B/patch/level + 881 B/patch/evaluation in the REFERENCE's data layout (768 B of fp64 Jacobian "
                            "cache per patch); the kernels form H and Jres from {sum dx^2, sum dx dy, sum dy^2} and two moments per patch and "
                            "never move that stream, so this ratio is not a roofline fraction"}
-            pmc_file = latest_profile({"default": "r*_pmc_fused.json", "exact": "r*_pmc_fused_exact.json", "fast": "r*_pmc_fused_fast.json"}[args.arith]
+            pmc_file = latest_profile({"default": "r*_pmc_fused.json", "moments_f32": "r*_pmc_fused_m32.json", "fast": "r*_pmc_fused_fast.json"}[args.arith]
                                       if mode == 1 else "r*_pmc_stream.json")
             ctr = pmc_of(pmc_file, kernel, args.allow_stale_profile, pairs=n_slots) if (pmc_file and default_c1) else None
             profile_refused = ctr if isinstance(ctr, str) else None
@@ -622,7 +625,7 @@ def main():
         # ---- secondary measurements, outside the timed region (rank 0, one GPU, default workload)
         early = None
         fast = None
-        exact_sec = None
+        m32_sec = None
         jac = None
         upl = None
         if not allreduce and world == 1 and not args.no_secondary and not args.early_stop:
@@ -644,10 +647,11 @@ def main():
                      "pose_err_vs_cpu_ref": {"rot_rad": rot_es, "trans_m": trans_es},
                      "pose_err_vs_ground_truth": dict(zip(("rot_rad", "trans_m"), synth.pose_error(np.array(r_es.T_cur_w), fps[0].T_cur_w_true)))}
             assert rot_es < 1e-4 and trans_es < 1e-3, "early-stop pose parity violated: %g rad %g m" % (rot_es, trans_es)
-            # (1b) the same batch, fixed work, at the two other arithmetic levels of the fused kernel -- EXACT (the reference's
-            # arithmetic to the last operation) and FAST (contracted interpolation, f32 sums) --, every distinct scene against the CPU oracle
+            # (1b) the same batch, fixed work, at the two OPT-IN arithmetic levels of the fused kernel -- MOMENTS_F32 (a patch's two
+            # gradient moments summed in f32) and FAST (contracted interpolation, f32 sums) --, every distinct scene against the CPU
+            # oracle.  Narrower than the reference's arithmetic: secondary figures, never the headline
             other = {}
-            for lvl_name, lvl, prof_pat in (("exact", hip.SIA_ARITH_EXACT, "r*_pmc_fused_exact.json"), ("fast", hip.SIA_ARITH_FAST, "r*_pmc_fused_fast.json")):
+            for lvl_name, lvl, prof_pat in (("moments_f32", hip.SIA_ARITH_MOMENTS_F32, "r*_pmc_fused_m32.json"), ("fast", hip.SIA_ARITH_FAST, "r*_pmc_fused_fast.json")):
                 sia.set_option(hip.SIA_OPT_ARITH, lvl)
                 try:
                     prewarm(ctx, lambda: sia.run(n_slots, prm))
@@ -678,7 +682,7 @@ def main():
                                                            "max_trans_m_over_scenes": float(fa_err[:, 1].max()),
                                                            "n_tracked_equal_in_every_scene": bool(all(int(r_fa[i].n_tracked) == int(oracle_res[i].n_tracked) for i in range(n_scenes)))}}
                 assert fa_err[:, 0].max() < 1e-4 and fa_err[:, 1].max() < 1e-3, "%s-arithmetic pose parity violated: %s" % (lvl_name, fa_err.max(axis=0))
-            fast, exact_sec = other["fast"], other["exact"]
+            fast, m32_sec = other["fast"], other["moments_f32"]
             # (2) the streaming implementation of the Jacobian / residual pass: the HBM-bound form (north_star: >= 50 % of the HBM roofline)
             sia.set_mode(stream=True)           # an option of this solver object (svo_hip_sia_set_option), not a process-wide switch
             try:
@@ -762,7 +766,7 @@ def main():
                              (world, n_dev, ", shared-memory exchange instead of RCCL" if allreduce else "")} if rehearsal else {}),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 normal equations / f32 image math" + {"default": " (f32 moment sums per patch)", "exact": " (as the reference)",
+            "dtype": "f64 normal equations / f32 image math" + {"default": " (as the reference)", "moments_f32": " (f32 moment sums per patch)",
                                                                  "fast": " (contracted, f32 sums per patch)"}[args.arith], "data": "synthetic",
             "config": {"workload": "%s: SparseImgAlign %dx%d, %d patches, 5 pyramid levels (L4-L0), %s" %
                                    ("C1" if args.width == 640 else "C3 shape", args.width, args.height, n_feat, "reference early-stop GN" if args.early_stop else "30 GN evaluations per level (fixed work)"),
@@ -771,7 +775,7 @@ def main():
                                        ("RCCL called by libsvo_hip.so (svo_hip_sia_run_sharded)" if native else "torch.distributed driver") +
                                        (", HIP-graph replay" if args.graph else "") if allreduce
                                        else "frame-parallel (no collective)") + ", %d GPU(s)" % world,
-                       "distinct_scenes": args.distinct, "arithmetic": {"default": "MOMENTS_F32 (library default)", "exact": "EXACT", "fast": "FAST"}[args.arith],
+                       "distinct_scenes": args.distinct, "arithmetic": {"default": "EXACT (library default, the reference's)", "moments_f32": "MOMENTS_F32 (opt-in)", "fast": "FAST (opt-in)"}[args.arith],
                        **({"comm_ranks": comm_ranks} if comm_ranks is not None else {}),
                        "implementation": "fused (one workgroup per frame pair, one launch per solve)" if (not allreduce and mode == 1) else "streaming (one launch per Gauss-Newton evaluation)"},
             "pose_err_vs_cpu_ref": {"rot_rad": rot, "trans_m": trans, "tolerance": "1e-4 rad / 1e-3 m",
@@ -789,7 +793,7 @@ def main():
             "cpu_baseline": cpu,
             "roofline_jacobian_pass": jac,
             "reference_semantics": early,
-            "exact_arithmetic": exact_sec,
+            "moments_f32_arithmetic": m32_sec,
             "fast_arithmetic": fast,
             "with_image_uploads": upl,
             "c2": c2,

@@ -208,16 +208,18 @@ int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
 #define SVO_HIP_SIA_OPT_CHUNKS 2        /* streaming residual kernel: workgroups per frame, 0 (automatic) .. 64 */
 #define SVO_HIP_SIA_OPT_EXTRA_LDS 3     /* fused kernel: waves with a third tile in LDS, -1 (automatic) .. 3 */
 #define SVO_HIP_SIA_OPT_OLD_TILES 4     /* fused kernel: tiles of the older wave of a SIMD, 0 (automatic) .. 6 */
-#define SVO_HIP_SIA_OPT_ARITH 5         /* fused kernel: SVO_HIP_SIA_ARITH_MOMENTS_F32 (default), _EXACT or _FAST */
+#define SVO_HIP_SIA_OPT_ARITH 5         /* fused kernel: SVO_HIP_SIA_ARITH_EXACT (default: the reference's arithmetic), _MOMENTS_F32 or _FAST (opt-in) */
 #define SVO_HIP_SIA_MODE_AUTO 0
 #define SVO_HIP_SIA_MODE_STREAM 1
 /* Arithmetic levels of the fused kernel.  At every level the image math is the reference's f32, pixel choice, projection,
  * H_ (formed once per level from the patches' gradient sums), normal equations, solve and the Gauss-Newton control flow are
  * unchanged: H_, the tracked-patch count and -- on every scene tested -- the iteration counts are bit for bit the same.
- * EXACT: the reference's arithmetic statement by statement -- uncontracted f32 interpolation, residual products and
- *   Jacobian moments in f64 (sparse_img_align.cpp:238-279): with a fixed evaluation count poses agree with the CPU path to
- *   ~1e-13 ... 6e-9 rad.
- * MOMENTS_F32 (the default since round 4): EXACT's residuals and chi2; the 16 products dx*res and dy*res of a patch are
+ * EXACT (the default; round 4 shipped MOMENTS_F32 as the default, round 5 took that back: every caller that sets nothing --
+ *   the drop-in SparseImgAlign::run binding included -- gets the reference's arithmetic): the reference's arithmetic
+ *   statement by statement -- uncontracted f32 interpolation, residual products and Jacobian moments in f64
+ *   (sparse_img_align.cpp:238-279): with a fixed evaluation count poses agree with the CPU path to ~1e-13 ... 6e-9 rad.
+ * MOMENTS_F32 (opt-in, pays only in launches of thousands of frame pairs): EXACT's residuals and chi2; the 16 products
+ *   dx*res and dy*res of a patch are
  *   accumulated in f32 (one fused rounding per term) and widened once per patch, instead of exactly in f64 -- three
  *   conversions and two f64 operations per pixel less, the solve runs ~7 % faster.  Poses agree with the CPU path to
  *   ~3e-8 rad / 6e-8 m with a fixed evaluation count (tests assert 1e-7 against EXACT) and, with the reference's own exits
@@ -225,9 +227,8 @@ int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
  *   translation units built for arm64 move by 1.4e-8 rad.  north_star allows 1e-4 rad / 1e-3 m.
  * FAST: additionally the bilinear sum contracted (one product + three fused multiply-adds) and chi2 summed with fused
  *   multiply-adds: ~10 % faster than EXACT, poses ~2e-8 rad from the CPU path.
- * Applies to the fused kernel (svo_hip_sia_run); the streaming / step-wise / sharded paths always use EXACT, and
- * svo_hip_tracker pins EXACT for its own solver (one frame at a time gains nothing, and the chain's per-cell decisions then
- * equal the CPU chain's frame by frame). */
+ * Applies to the fused kernel (svo_hip_sia_run); the streaming / step-wise / sharded paths and svo_hip_tracker's own
+ * solver always use EXACT. */
 #define SVO_HIP_SIA_ARITH_EXACT 0
 #define SVO_HIP_SIA_ARITH_FAST 1
 #define SVO_HIP_SIA_ARITH_MOMENTS_F32 2

@@ -90,7 +90,7 @@ def test_default_bench_line_fits_the_drivers_tail_and_carries_the_contract():
     c = d["cpu_baseline"]
     assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] in ("port", "reference") and 0.5 < c["port_vs_reference_speed"] < 1.5
     assert d["pose_err_vs_cpu_ref"]["max_rot_rad_over_scenes"] < 1e-4 and d["pose_err_vs_cpu_ref"]["n_tracked_equal_in_every_scene"]
-    for lvl in ("exact_arithmetic", "fast_arithmetic"):
+    for lvl in ("moments_f32_arithmetic", "fast_arithmetic"):
         assert d[lvl]["value"] > 0 and 0.0 < d[lvl]["roofline"]["frac"] <= 1.0 and d[lvl]["pose_err_vs_cpu_ref"]["max_rot_rad_over_scenes"] < 1e-6
     df = d["c2"]["depth_filter"]
     assert set(df["stages_us"]) == {"geometry", "search", "align", "finalize"} and df["through_dropin_entry_us"] < df["through_round3_host_buffer_entry_us"]

@@ -23,40 +23,30 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=["fused", "fused_exact", "fused4", "stream"])
+@pytest.fixture(params=["fused", "fused_m32", "fused4", "stream"])
 def sia_mode(request):
     """svo_hip_sia_run has two implementations (one fused launch per run / one launch per Gauss-Newton
     evaluation), the fused kernel two shapes (8 waves per frame pair; 4 waves, two pairs per CU, which large
-    launches of small frames get -- forced here) and, since round 4, a default arithmetic that sums a patch's two gradient
-    moments in f32 (SVO_HIP_SIA_ARITH_MOMENTS_F32) beside the reference's own (EXACT): every run()-level parity test is
-    executed against all four.  `_tight()` tells a test whether the run reproduces the CPU path to rounding level."""
+    launches of small frames get -- forced here) and an OPT-IN arithmetic level that sums a patch's two gradient
+    moments in f32 (SVO_HIP_SIA_ARITH_MOMENTS_F32; the library default is the reference's own arithmetic, EXACT, again since
+    round 5): every run()-level parity test is executed against all four.  `_tight()` tells a test whether the run
+    reproduces the CPU path to rounding level (everything but the opt-in level)."""
     old = dict(hip.SIA_DEFAULT_OPTIONS)
     hip.SIA_DEFAULT_OPTIONS.clear()
     if request.param == "stream":
         hip.SIA_DEFAULT_OPTIONS[hip.SIA_OPT_MODE] = hip.SIA_MODE_STREAM
     if request.param == "fused4":
         hip.SIA_DEFAULT_OPTIONS[hip.SIA_OPT_WAVES] = 4
-    if request.param in ("fused_exact", "fused4"):
-        hip.SIA_DEFAULT_OPTIONS[hip.SIA_OPT_ARITH] = hip.SIA_ARITH_EXACT
+    if request.param == "fused_m32":
+        hip.SIA_DEFAULT_OPTIONS[hip.SIA_OPT_ARITH] = hip.SIA_ARITH_MOMENTS_F32
     yield "fused" if request.param.startswith("fused") else request.param
     hip.SIA_DEFAULT_OPTIONS.clear()
     hip.SIA_DEFAULT_OPTIONS.update(old)
 
 
 def _tight():
-    """the solver objects created now use the reference's arithmetic to the last operation (EXACT level or the streaming kernels)"""
-    return (hip.SIA_DEFAULT_OPTIONS.get(hip.SIA_OPT_ARITH) == hip.SIA_ARITH_EXACT or
-            hip.SIA_DEFAULT_OPTIONS.get(hip.SIA_OPT_MODE) == hip.SIA_MODE_STREAM)
-
-
-@pytest.fixture
-def exact_arith():
-    """tests whose bounds are the exact level's (stage chains compared decision by decision with the CPU chain)"""
-    old = dict(hip.SIA_DEFAULT_OPTIONS)
-    hip.SIA_DEFAULT_OPTIONS[hip.SIA_OPT_ARITH] = hip.SIA_ARITH_EXACT
-    yield
-    hip.SIA_DEFAULT_OPTIONS.clear()
-    hip.SIA_DEFAULT_OPTIONS.update(old)
+    """the solver objects created now use the reference's arithmetic to the last operation (the library default)"""
+    return hip.SIA_DEFAULT_OPTIONS.get(hip.SIA_OPT_ARITH, hip.SIA_ARITH_EXACT) == hip.SIA_ARITH_EXACT
 
 
 def _upload_pair(ctx, fps, max_feat=None):
@@ -229,7 +219,7 @@ def test_points_in_the_camera_plane(ctx, sia_mode):
     assert r.n_residual_patches == o.n_residual_patches
     assert r.n_tracked == o.n_tracked
     rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
-    tol = 1e-9 if _tight() else 2e-7            # the default level sums a patch's gradient moments in f32
+    tol = 1e-9 if _tight() else 2e-7            # the opt-in MOMENTS_F32 level sums a patch's gradient moments in f32
     assert rot < tol and trans < tol, (rot, trans)
     H, Ho = np.array(r.H), np.array(o.H)
     assert np.abs(H - Ho).max() <= 1e-9 * np.abs(Ho).max()
@@ -600,7 +590,7 @@ def test_large_launch_of_small_frames_picks_two_pairs_per_cu(ctx):
                 # (DESIGN.md section 7): a last, tiny update may be accepted on one side and rolled back on the other
                 assert rot < 1e-4 and trans < 1e-3, (i, rot, trans)
             else:
-                assert rot < 5e-7 and trans < 5e-7, (i, rot, trans)     # default arithmetic level (f32 moment sums): observed 8e-8 / 1.7e-7
+                assert rot < 1e-7 and trans < 1e-7, (i, rot, trans)     # library default = the reference's arithmetic
             assert res[i].n_tracked == o.n_tracked
     _free(sia, ref, cur)
 
@@ -927,11 +917,11 @@ def test_sparse_img_align_against_reference_run(ctx, sia_mode, golden, case):
 
 
 @pytest.mark.parametrize("case", _ref_cases(), ids=[c[0] for c in _ref_cases()])
-def test_default_arithmetic_against_reference_run_and_exact_level(ctx, golden, case):
-    """The DEFAULT arithmetic of svo_hip_sia_run since round 4 (SVO_HIP_SIA_ARITH_MOMENTS_F32: the reference's residuals and
-    chi2, a patch's two gradient moments summed in f32) against SparseImgAlign::run executed by the reference's own code and
-    against the EXACT level on the same object: H_ bit for bit, iteration counts, tracked patches and stop flag equal, poses
-    within 1e-7 of each other and of the reference where the evaluation sequence is the same."""
+def test_moments_f32_arithmetic_against_reference_run_and_exact_level(ctx, golden, case):
+    """The opt-in SVO_HIP_SIA_ARITH_MOMENTS_F32 level (the reference's residuals and chi2, a patch's two gradient moments
+    summed in f32) against SparseImgAlign::run executed by the reference's own code and against the library default (EXACT)
+    on the same object: H_ bit for bit, iteration counts, tracked patches and stop flag equal, poses within 1e-7 of each
+    other and of the reference where the evaluation sequence is the same."""
     from oracle import gen_golden
     name, kw, max_level, min_level, n_iter = case
     g = golden("sia_ref.npz")
@@ -939,11 +929,15 @@ def test_default_arithmetic_against_reference_run_and_exact_level(ctx, golden, c
     assert not hip.SIA_DEFAULT_OPTIONS
     ref, cur, sia = _upload_pair(ctx, [fp], max_feat=max(len(fp.px), 1))
     prm = sia.params(max_level=max_level, min_level=min_level, n_iter=n_iter, eps=1e-6, early_stop=True)
+    sia.run(1, prm)                                             # nothing set: the library default
+    e = sia.download(0)
+    sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_EXACT)      # ... which IS the reference's arithmetic: bit for bit
+    sia.run(1, prm)
+    e2 = sia.download(0)
+    assert [float(v).hex() for v in e.T_cur_w] == [float(v).hex() for v in e2.T_cur_w] and list(e.iters) == list(e2.iters)
+    sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_MOMENTS_F32)
     sia.run(1, prm)
     r = sia.download(0)
-    sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_EXACT)
-    sia.run(1, prm)
-    e = sia.download(0)
     assert list(r.H) == list(e.H) or any(np.isnan(r.H))          # H comes from the per-level gradient sums, not from the residuals
     assert list(r.iters) == list(e.iters) and r.n_tracked == e.n_tracked == int(g[name + "_n_tracked"]) and int(r.stop) == int(e.stop) == int(g[name + "_stop"])
     rot, trans = synth.pose_error(np.array(r.T_cur_w), g[name + "_T"])
@@ -1312,7 +1306,7 @@ def test_error_conventions(ctx):
     r = sia.download(0)
     o = orc.sparse_img_align(fp, n_iter=30, early_stop=True)
     rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
-    assert rot < 2e-7 and trans < 2e-7             # default arithmetic level: observed 4e-8
+    assert rot < 1e-9 and trans < 1e-9             # library default = the reference's arithmetic
     _free(sia, ref, cur)
 
 
@@ -1339,7 +1333,7 @@ def test_converged_seed_records_packed_on_device(ctx):
     sb.free(); kf.destroy(); cf.destroy()
 
 
-def test_frame_pipeline_stages_together(ctx, exact_arith):
+def test_frame_pipeline_stages_together(ctx):
     """The per-frame data path of FrameHandlerMono::processFrame on the device, stage by stage against the oracle chain:
     SparseImgAlign -> reprojection matching (findMatchDirect) -> pose_optimizer::optimizeGaussNewton -> Point::optimize."""
     fp = synth.make_frame_pair(seed=4242, n_features=500, border=40)

@@ -41,9 +41,8 @@ class HipStages:
         self.ref = hip.Pyramid(ctx, cam.width, cam.height, 5, 1)
         self.cur = hip.Pyramid(ctx, cam.width, cam.height, 5, 1)
         self.sia = hip.SparseImgAlign(ctx, 1, 2048)
-        # the reference's arithmetic to the last operation (as svo_hip_tracker pins it): the chain is compared with the CPU chain
-        # decision by decision; the library's default level sums a patch's gradient moments in f32 (poses 1e-8 away)
-        self.sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_EXACT)
+        # the library default: the reference's arithmetic to the last operation -- the chain is compared with the CPU chain
+        # decision by decision
         self.sia.set_frames(self.ref, self.cur)
         self.zeros = np.zeros(len(seq["px0"]), dtype=np.int32)
 
