@@ -176,9 +176,40 @@ int svo_hip_ctx_destroy(svo_hip_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->staging) (void)hipFree(ctx->staging);
   if (ctx->host_staging) (void)hipHostFree(ctx->host_staging);
+  for (svo_seed_block& blk : ctx->seed_pool) {         // (blocks still held by live seed batches go with those batches)
+    if (blk.dev) (void)hipFree(blk.dev);
+    if (blk.host) (void)hipHostFree(blk.host);
+  }
+  ctx->seed_pool.clear();
   for (hipEvent_t e : ctx->df_ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_ctx_info(svo_hip_ctx* ctx, svo_hip_ctx_stats* out) {
+  if (!ctx || !out) return SVO_HIP_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  out->allocator_calls = ctx->n_allocs;
+  out->free_calls = ctx->n_frees;
+  out->seed_blocks_in_use = ctx->seed_blocks_in_use;
+  out->seed_blocks_free = (int)ctx->seed_pool.size();
+  for (const svo_seed_block& blk : ctx->seed_pool) { out->seed_pool_free_device_bytes += blk.dev_bytes; out->seed_pool_free_host_bytes += blk.host_bytes; }
+  out->scratch_bytes = ctx->scratch_bytes;
+  out->staging_bytes = ctx->staging_bytes + ctx->host_staging_bytes;
+  return SVO_HIP_OK;
+}
+
+// Drops the free blocks of the seed-batch pool (an application that has shrunk for good; hipFree synchronises the device).
+int svo_hip_ctx_trim(svo_hip_ctx* ctx) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (svo_seed_block& blk : ctx->seed_pool) {
+    if (blk.dev) { (void)hipFree(blk.dev); ++ctx->n_frees; }
+    if (blk.host) { (void)hipHostFree(blk.host); ++ctx->n_frees; }
+  }
+  ctx->seed_pool.clear();
   return SVO_HIP_OK;
 }
 

@@ -2007,11 +2007,59 @@ struct svo_hip_seed_batch {
   char* host_dev = nullptr;             // its device address
   bool pending = false;                 // a pass is enqueued and not collected yet
   int report_updated = 0;
+  svo_seed_block blk;                   // the pool block behind dev / host (returned to the context on destroy)
 };
 
 static size_t sb_align(size_t v) { return (v + 255) & ~(size_t)255; }
 static constexpr size_t kEvHeaderBytes = 64;
 static_assert(sizeof(svo_hip_seed_event) == 56, "event record layout (include/svo_hip.h)");
+
+// Capacity classes of the context's seed-batch pool: powers of two from 256 seeds (the drop-in's batches are <= 4096 seeds).
+static int sb_capacity_class(int n) {
+  int c = 256;
+  while (c < n && c < (1 << 30)) c <<= 1;
+  return c;
+}
+
+// A block for a batch of n seeds: a free block of n's capacity class, else a new one sized for the class (so that the next
+// keyframe of about this size reuses it).  dev_need / host_need are the bytes a batch of n seeds lays out; both grow with n.
+static int sb_take_block(svo_hip_ctx* ctx, int n, size_t dev_need, size_t host_need, svo_seed_block* out) {
+  const int cap = sb_capacity_class(n);
+  for (size_t i = 0; i < ctx->seed_pool.size(); ++i) {
+    const svo_seed_block& b = ctx->seed_pool[i];
+    if (b.cap == cap && b.dev_bytes >= dev_need && b.host_bytes >= host_need) {
+      *out = b;
+      ctx->seed_pool[i] = ctx->seed_pool.back();
+      ctx->seed_pool.pop_back();
+      ++ctx->seed_blocks_in_use;
+      return SVO_HIP_OK;
+    }
+  }
+  svo_seed_block b;
+  b.cap = cap;
+  // the layout of `cap` seeds bounds that of any n <= cap: per seed 16+24+4*6 uploaded, 24+16+4+1 outputs, one event record;
+  // 15 sections rounded up to 256 bytes each, the block counts and the histogram
+  const size_t C = (size_t)cap;
+  b.dev_bytes = C * (16 + 24 + 4 * 6 + 24 + 16 + 4 + 1 + sizeof(svo_hip_seed_event)) + 4 * ((C + 255) / 256) + 64 + 16 * 256;
+  if (b.dev_bytes < dev_need) b.dev_bytes = dev_need;
+  b.host_bytes = kEvHeaderBytes + C * sizeof(svo_hip_seed_event);
+  if (b.host_bytes < host_need) b.host_bytes = host_need;
+  if (hipMalloc((void**)&b.dev, b.dev_bytes) != hipSuccess) return svo_fail(ctx, SVO_HIP_ERR_NOMEM, "svo_hip_seed_batch_create", "hipMalloc failed");
+  ++ctx->n_allocs;
+  if (hipHostMalloc((void**)&b.host, b.host_bytes, hipHostMallocMapped) != hipSuccess) {
+    (void)hipFree(b.dev);
+    return svo_fail(ctx, SVO_HIP_ERR_NOMEM, "svo_hip_seed_batch_create", "hipHostMalloc failed");
+  }
+  ++ctx->n_allocs;
+  if (hipHostGetDevicePointer((void**)&b.host_dev, b.host, 0) != hipSuccess) {
+    (void)hipFree(b.dev); (void)hipHostFree(b.host);
+    return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_seed_batch_create", "hipHostGetDevicePointer failed");
+  }
+  *out = b;
+  ++ctx->seed_blocks_in_use;
+  return SVO_HIP_OK;
+}
+
 
 extern "C" {
 
@@ -2043,13 +2091,8 @@ int svo_hip_seed_batch_create(svo_hip_ctx* ctx, int n, const double* px, const d
   const size_t o_bc = o; o = sb_align(o + 4 * (size_t)sb->n_blocks);
   const size_t o_h = o; o = sb_align(o + 64);
   const size_t o_ev = o; o = sb_align(o + N * sizeof(svo_hip_seed_event));
-  int rc = SVO_HIP_OK;
-  if (hipMalloc((void**)&sb->dev, o) != hipSuccess) rc = svo_fail(ctx, SVO_HIP_ERR_NOMEM, "svo_hip_seed_batch_create", "hipMalloc failed");
-  const size_t host_bytes = kEvHeaderBytes + N * sizeof(svo_hip_seed_event);
-  if (rc == SVO_HIP_OK && hipHostMalloc((void**)&sb->host, host_bytes, hipHostMallocMapped) != hipSuccess)
-    rc = svo_fail(ctx, SVO_HIP_ERR_NOMEM, "svo_hip_seed_batch_create", "hipHostMalloc failed");
-  if (rc == SVO_HIP_OK && hipHostGetDevicePointer((void**)&sb->host_dev, sb->host, 0) != hipSuccess)
-    rc = svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_seed_batch_create", "hipHostGetDevicePointer failed");
+  int rc = sb_take_block(ctx, n, o, kEvHeaderBytes + N * sizeof(svo_hip_seed_event), &sb->blk);
+  sb->dev = sb->blk.dev; sb->host = sb->blk.host; sb->host_dev = sb->blk.host_dev;
   if (rc == SVO_HIP_OK) {
     char* d = sb->dev;
     sb->px = (double*)(d + o_px); sb->f = (double*)(d + o_f); sb->level = (int32_t*)(d + o_lvl);
@@ -2079,8 +2122,17 @@ int svo_hip_seed_batch_create(svo_hip_ctx* ctx, int n, const double* px, const d
 int svo_hip_seed_batch_destroy(svo_hip_seed_batch* sb) {
   if (!sb) return SVO_HIP_OK;
   if (sb->ctx) { (void)hipSetDevice(sb->ctx->device); if (sb->pending) (void)hipStreamSynchronize(sb->ctx->stream); }
-  if (sb->dev) (void)hipFree(sb->dev);
-  if (sb->host) (void)hipHostFree(sb->host);
+  // the block goes back to the context's pool: no hipFree (a device-wide synchronisation) at keyframe rate
+#ifndef SVO_NO_SEED_POOL          // (the A/B build of tools/ab_churn.sh frees every block: what rounds 3-4 did)
+  if (sb->ctx && sb->blk.dev && sb->blk.host) { sb->ctx->seed_pool.push_back(sb->blk); --sb->ctx->seed_blocks_in_use; }
+  else
+#else
+  if (sb->ctx && sb->blk.dev) { --sb->ctx->seed_blocks_in_use; sb->ctx->n_frees += 2; }
+#endif
+  {
+    if (sb->blk.dev) (void)hipFree(sb->blk.dev);
+    if (sb->blk.host) (void)hipHostFree(sb->blk.host);
+  }
   delete sb;
   return SVO_HIP_OK;
 }
@@ -2214,7 +2266,7 @@ int svo_hip_seed_batch_update_group_async(int n_batches, svo_hip_seed_batch* con
   if (!ref || !ref_slots || !cur || !cam || !T_ref_w || !T_cur_w || !prm) return svo_fail(ctx, SVO_HIP_ERR_INVALID, "svo_hip_seed_batch_update_group_async", "null argument");
   if (n_batches == 1)
     return svo_hip_seed_batch_update_async(batches[0], ref, ref_slots[0], cur, cur_slot, cam, T_ref_w, T_cur_w, prm, report_updated);
-  // everything is checked before anything is enqueued: the call updates all batches or none
+  // every batch's arguments are checked before anything is enqueued; up to DF_GROUP_MAX batches per set of launches
   for (int k = 0; k < n_batches; ++k) {
     svo_hip_seed_batch* sb = batches[k];
     SVO_REQUIRE(ctx, sb && sb->ctx == ctx);
@@ -2242,6 +2294,8 @@ int svo_hip_df_set_small_pass_limit(svo_hip_ctx* ctx, int max_seeds) {
   ctx->df_small_max = max_seeds;
   return SVO_HIP_OK;
 }
+
+int svo_hip_seed_batch_pending(const svo_hip_seed_batch* sb) { return sb && sb->pending ? 1 : 0; }
 
 int svo_hip_seed_batch_collect(svo_hip_seed_batch* sb, const svo_hip_seed_event** events, int* n_events, int32_t status_counts[7]) {
   if (!sb) return SVO_HIP_ERR_INVALID;

@@ -5,9 +5,20 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/svo_hip.h"
 #include "svo_device_math.h"
+
+// One block of the context's seed-batch pool (svo_depth.hip): the device arrays and the page-locked, device-mapped event
+// block of a seed batch of up to `cap` seeds.
+struct svo_seed_block {
+  char* dev = nullptr;
+  char* host = nullptr;
+  char* host_dev = nullptr;
+  size_t dev_bytes = 0, host_bytes = 0;
+  int cap = 0;
+};
 
 struct svo_hip_ctx {
   int device = 0;
@@ -25,6 +36,15 @@ struct svo_hip_ctx {
   int df_small_max = 8192;             // passes of at most this many seed records take the two-launch form (svo_depth.hip)
   bool df_ev_recorded = false;
   hipEvent_t df_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // Seed batches are created and destroyed at keyframe rate on the depth-filter thread (S/depth_filter.cpp:129-151,256-261);
+  // hipFree synchronises the whole DEVICE, i.e. it would stall the tracking thread's stream too (SURVEY 8(b) "Threading": no
+  // implicit device synchronisation).  So a destroyed batch returns its block here and a new one takes a free block of its
+  // capacity class (powers of two from 256 seeds); blocks are freed with the context only.
+  std::vector<svo_seed_block> seed_pool;      // free blocks
+  int seed_blocks_in_use = 0;
+  // allocator calls (hipMalloc / hipHostMalloc, hipFree / hipHostFree) made on behalf of this context after its creation:
+  // seed-batch blocks, scratch, staging areas.  Flat once the working set has been seen (svo_hip_ctx_info).
+  unsigned long long n_allocs = 0, n_frees = 0;
   char err[512] = {0};
 };
 
@@ -59,11 +79,13 @@ inline int svo_ctx_scratch(svo_hip_ctx* ctx, size_t need, void** out) {
     if (ctx->scratch) {
       SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
       (void)hipFree(ctx->scratch);
+      ++ctx->n_frees;
       ctx->scratch = nullptr;
       ctx->scratch_bytes = 0;
     }
     void* p = nullptr;
     SVO_CHECK_HIP(ctx, hipMalloc(&p, need + need / 4));
+    ++ctx->n_allocs;
     ctx->scratch = p;
     ctx->scratch_bytes = need + need / 4;
   }
@@ -78,11 +100,13 @@ inline int svo_ctx_staging(svo_hip_ctx* ctx, size_t need, char** out) {
     if (ctx->staging) {
       SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
       (void)hipFree(ctx->staging);
+      ++ctx->n_frees;
       ctx->staging = nullptr;
       ctx->staging_bytes = 0;
     }
     void* p = nullptr;
     SVO_CHECK_HIP(ctx, hipMalloc(&p, need + need / 4));
+    ++ctx->n_allocs;
     ctx->staging = p;
     ctx->staging_bytes = need + need / 4;
   }
@@ -97,11 +121,13 @@ inline int svo_ctx_host_staging(svo_hip_ctx* ctx, size_t need, char** out) {
     if (ctx->host_staging) {
       SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
       (void)hipHostFree(ctx->host_staging);
+      ++ctx->n_frees;
       ctx->host_staging = nullptr;
       ctx->host_staging_bytes = 0;
     }
     void* p = nullptr;
     SVO_CHECK_HIP(ctx, hipHostMalloc(&p, need + need / 4, hipHostMallocDefault));
+    ++ctx->n_allocs;
     ctx->host_staging = p;
     ctx->host_staging_bytes = need + need / 4;
   }

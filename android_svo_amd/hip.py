@@ -37,6 +37,14 @@ class CCamera(C.Structure):
                 ("cx", C.c_double), ("cy", C.c_double), ("d", C.c_double * 5), ("distortion", C.c_int)]
 
 
+class CCtxStats(C.Structure):
+    """svo_hip_ctx_stats (include/svo_hip.h)"""
+    _fields_ = [("allocator_calls", C.c_ulonglong), ("free_calls", C.c_ulonglong),
+                ("seed_pool_free_device_bytes", C.c_ulonglong), ("seed_pool_free_host_bytes", C.c_ulonglong),
+                ("scratch_bytes", C.c_ulonglong), ("staging_bytes", C.c_ulonglong),
+                ("seed_blocks_in_use", C.c_int), ("seed_blocks_free", C.c_int)]
+
+
 class CSiaParams(C.Structure):
     _fields_ = [("max_level", C.c_int), ("min_level", C.c_int), ("n_iter", C.c_int), ("eps", C.c_double),
                 ("early_stop", C.c_int)]
@@ -112,6 +120,16 @@ class Context:
     @property
     def stream(self) -> int:
         return self.lib.svo_hip_ctx_stream(self.h) or 0
+
+    def info(self) -> dict:
+        """svo_hip_ctx_info: allocator / free calls made for this context's work areas and seed-batch pool, pool occupancy"""
+        st = CCtxStats()
+        self.check(self.lib.svo_hip_ctx_info(self.h, C.byref(st)), "ctx_info")
+        return {k: int(getattr(st, k)) for k, _ in CCtxStats._fields_}
+
+    def trim(self):
+        """svo_hip_ctx_trim: the free blocks of the seed-batch pool go back to the driver (synchronises the device)"""
+        self.check(self.lib.svo_hip_ctx_trim(self.h), "ctx_trim")
 
     def set_small_pass_limit(self, max_seeds: int):
         """svo_hip_df_set_small_pass_limit: depth-filter passes over resident seed batches of at most this many seed

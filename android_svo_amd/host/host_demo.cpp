@@ -4,6 +4,11 @@
 // Usage: svo_host_demo <case_dir> <out_dir>      (inputs written by tests/test_gpu_host_cpp.py)
 //        svo_host_demo <case_dir> <out_dir> track   the tracking chain: svo::FrameTracker (hip_bridge::FrameTrackerT on this
 //                                                   file's data model) over a map built as an object graph from index tables
+//        svo_host_demo <case_dir> <out_dir> churn   SURVEY 8(b) "Threading": latency of SparseImgAlign::run on the tracking
+//                                                   thread while a second thread (own context) creates seed batches, runs a
+//                                                   pass and drops them at keyframe rate -- and with that thread idle
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -224,9 +229,102 @@ static int track_demo(const std::string& dir, const std::string& out) {
   return 0;
 }
 
+// ---- the tracking thread's SparseImgAlign::run while the depth-filter thread creates and drops device seed batches.
+// A keyframe's seeds are a svo_hip_seed_batch created when the keyframe is first seen and destroyed when its seeds age out
+// or are used up (S/depth_filter.cpp:129-151,256-261): allocator traffic on the depth-filter thread at keyframe rate.
+// hipFree synchronises the whole device; with the per-context pool (svo_hip_ctx_info) nothing is allocated or freed after
+// warm-up.  Prints median / 99th percentile / worst latency of run() with the second thread idle and busy.
+static int churn_demo(const std::string& dir, const std::string& out) {
+  const std::vector<double> m = read_bin<double>(dir + "/manifest.bin");
+  PinholeCamera cam{(int)m[0], (int)m[1], m[2], m[3], m[4], m[5]};
+  const int n_levels = (int)m[6];
+  const auto px = read_bin<double>(dir + "/sia_px.bin"), f = read_bin<double>(dir + "/sia_f.bin"), pos = read_bin<double>(dir + "/sia_pos.bin");
+  const auto has = read_bin<uint8_t>(dir + "/sia_has.bin");
+  FramePtr ref = load_frame(dir, &cam, 0, n_levels);
+  std::vector<std::unique_ptr<Point>> points;
+  for (size_t i = 0; i < has.size(); ++i) {
+    Feature* ftr = new Feature(ref.get(), Vector2d{{px[2 * i], px[2 * i + 1]}}, Vector3d{{f[3 * i], f[3 * i + 1], f[3 * i + 2]}}, 0);
+    if (has[i]) { points.emplace_back(new Point(Vector3d{{pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]}})); ftr->point = points.back().get(); }
+    ref->fts_.push_back(ftr);
+  }
+  FramePtr cur = load_frame(dir, &cam, 1, n_levels);
+  const SE3 T_start = ref->T_f_w_;
+  SparseImgAlign align(4, 2, 30, SparseImgAlign::GaussNewton, false, false);      // the shipping range L4..L2
+  auto one_run = [&]() {
+    cur->T_f_w_ = T_start;
+    const auto t0 = std::chrono::steady_clock::now();
+    align.run(ref, cur);
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  };
+  for (int k = 0; k < 20; ++k) one_run();
+  const auto spx = read_bin<double>(dir + "/seed_px.bin"), sf = read_bin<double>(dir + "/seed_f.bin");
+  const auto slevel = read_bin<int32_t>(dir + "/seed_level.bin");
+  const int n_all = (int)slevel.size();
+  std::atomic<int> mode{0};                  // 0 idle, 1 churn, 2 stop
+  std::atomic<long> n_created{0};
+  svo_hip_ctx_stats st_before{}, st_after{};
+  std::thread filter([&]() {
+    svo_hip_ctx* ctx = nullptr;
+    if (svo_hip_ctx_create(&ctx, 0, nullptr) != SVO_HIP_OK) return;
+    std::vector<float> a((size_t)n_all, 10.f), b((size_t)n_all, 10.f), mu((size_t)n_all, 0.5f), zr((size_t)n_all, 1.f), s2((size_t)n_all, 1.f / 36.f);
+    std::vector<svo_hip_seed_batch*> alive;
+    unsigned rng = 12345u;
+    auto keyframe = [&]() {                  // a new keyframe's seeds come, the oldest keyframe's go
+      rng = rng * 1664525u + 1013904223u;
+      const int n = 300 + (int)((rng >> 8) % 700u);
+      svo_hip_seed_batch* sb = nullptr;
+      if (svo_hip_seed_batch_create(ctx, n < n_all ? n : n_all, spx.data(), sf.data(), slevel.data(), a.data(), b.data(), mu.data(), zr.data(), s2.data(), &sb) == SVO_HIP_OK) {
+        alive.push_back(sb);
+        ++n_created;
+      }
+      if (alive.size() > 3) { svo_hip_seed_batch_destroy(alive.front()); alive.erase(alive.begin()); }
+    };
+    for (int k = 0; k < 8; ++k) keyframe();  // warm-up: the pool has seen the working set
+    svo_hip_ctx_info(ctx, &st_before);
+    while (mode.load() != 2) {
+      if (mode.load() == 1) keyframe();
+      else std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    svo_hip_ctx_info(ctx, &st_after);
+    for (svo_hip_seed_batch* sb : alive) svo_hip_seed_batch_destroy(sb);
+    svo_hip_ctx_destroy(ctx);
+  });
+  auto measure = [&](int n) {
+    std::vector<double> us;
+    for (int k = 0; k < n; ++k) us.push_back(one_run());
+    std::sort(us.begin(), us.end());
+    return std::vector<double>{us[us.size() / 2], us[us.size() * 99 / 100], us.back()};
+  };
+  std::this_thread::sleep_for(std::chrono::milliseconds(300));     // the filter thread's warm-up is over
+  const std::vector<double> idle = measure(2000);
+  const long c0 = n_created.load();
+  mode = 1;
+  const std::vector<double> busy = measure(2000);
+  const long c1 = n_created.load();
+  mode = 2;
+  filter.join();
+  std::printf("churn: SparseImgAlign::run (L4-L2, %zu features) on the tracking thread, us: median / p99 / worst\n", has.size());
+  std::printf("churn:   second thread idle:                          %8.1f %8.1f %8.1f\n", idle[0], idle[1], idle[2]);
+  std::printf("churn:   second thread creating + dropping batches:   %8.1f %8.1f %8.1f   (%ld batches created meanwhile)\n", busy[0], busy[1], busy[2], c1 - c0);
+  std::printf("churn:   allocator calls of the second context during the measurement: %llu, free calls: %llu\n",
+              st_after.allocator_calls - st_before.allocator_calls, st_after.free_calls - st_before.free_calls);
+  write_bin(out + "/churn.bin", std::vector<double>{idle[0], idle[1], idle[2], busy[0], busy[1], busy[2], (double)(c1 - c0),
+                                                    (double)(st_after.allocator_calls - st_before.allocator_calls),
+                                                    (double)(st_after.free_calls - st_before.free_calls)});
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 3) { std::fprintf(stderr, "usage: %s case_dir out_dir [track]\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s case_dir out_dir [track|churn]\n", argv[0]); return 2; }
   const std::string dir = argv[1], out = argv[2];
+  if (argc > 3 && std::string(argv[3]) == "churn") {
+    try {
+      return churn_demo(dir, out);
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "svo_host_demo FAILED: %s\n", e.what());
+      return 1;
+    }
+  }
   if (argc > 3 && std::string(argv[3]) == "track") {
     try {
       return track_demo(dir, out);

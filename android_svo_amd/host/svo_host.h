@@ -31,11 +31,13 @@
 #include <memory>
 #include <mutex>
 #include <queue>
+#include <set>
 #include <stdexcept>
 #include <thread>
 #include <vector>
 
 #include "svo_hip.h"
+#include "svo_dropin/slot_table.h"
 #include "svo_dropin/depth_filter_batch.h"
 #include "svo_dropin/frame_tracker_batch.h"
 
@@ -155,29 +157,47 @@ namespace hip_bridge {
 inline void check(int rc, svo_hip_ctx* ctx, const char* what) {
   if (rc != SVO_HIP_OK) throw std::runtime_error(std::string(what) + ": " + (ctx ? svo_hip_last_error(ctx) : "no context"));
 }
-/// device copies of frame pyramids, cached by Frame::id_
+/// device copies of frame pyramids, cached by Frame::id_ (the slot bookkeeping is the drop-in's: include/svo_dropin/slot_table.h)
 class PyramidCache {
  public:
-  PyramidCache(svo_hip_ctx* ctx, int capacity) : ctx_(ctx), capacity_(capacity) {}
+  PyramidCache(svo_hip_ctx* ctx, int capacity) : ctx_(ctx), table_(capacity) {}
   ~PyramidCache() { if (pyr_) svo_hip_pyramid_destroy(pyr_); }
   int slotOf(const Frame& f) {
-    if (!pyr_) {
-      check(svo_hip_pyramid_create(ctx_, f.cam_->width, f.cam_->height, (int)f.img_pyr_.size(), capacity_, &pyr_), ctx_, "pyramid_create");
-      ids_.assign(capacity_, -1);
+    std::vector<const Frame*> one(1, &f);
+    std::vector<int> slots;
+    acquire(one, slots);
+    return slots[0];
+  }
+  /// all frames of one device call at once: a slot handed out for one of them is not recycled for another
+  bool acquire(const std::vector<const Frame*>& frames, std::vector<int>& slots) {
+    slots.assign(frames.size(), -1);
+    if (frames.empty()) return true;
+    std::vector<int> ids;
+    std::set<int> distinct;
+    for (const Frame* f : frames) { ids.push_back(f->id_); distinct.insert(f->id_); }
+    const int need = table_.capacityFor((int)distinct.size());
+    if (need != table_.capacity() || !pyr_) {
+      if (pyr_) { svo_hip_pyramid_destroy(pyr_); pyr_ = nullptr; }
+      const Frame& f = *frames[0];
+      check(svo_hip_pyramid_create(ctx_, f.cam_->width, f.cam_->height, (int)f.img_pyr_.size(), need, &pyr_), ctx_, "pyramid_create");
+      table_.reset(need);
+      ++n_created_;
     }
-    for (int s = 0; s < capacity_; ++s) if (ids_[s] == f.id_) return s;
-    const int s = next_;
-    next_ = (next_ + 1) % capacity_;
-    const uint8_t* lv[SVO_HIP_MAX_LEVELS] = {nullptr};
-    for (size_t l = 0; l < f.img_pyr_.size(); ++l) lv[l] = f.img_pyr_[l].data();
-    check(svo_hip_pyramid_upload(pyr_, s, lv), ctx_, "pyramid_upload");
-    check(svo_hip_ctx_sync(ctx_), ctx_, "sync");
-    ids_[s] = f.id_;
-    return s;
+    return table_.acquire(ids, slots, [&](size_t k, int s) {
+      const Frame& f = *frames[k];
+      const uint8_t* lv[SVO_HIP_MAX_LEVELS] = {nullptr};
+      for (size_t l = 0; l < f.img_pyr_.size(); ++l) lv[l] = f.img_pyr_[l].data();
+      check(svo_hip_pyramid_upload(pyr_, s, lv), ctx_, "pyramid_upload");
+      check(svo_hip_ctx_sync(ctx_), ctx_, "sync");
+      ++n_uploads_;
+      return true;
+    });
   }
   svo_hip_pyramid* pyramid() const { return pyr_; }
+  int capacity() const { return table_.capacity(); }
+  int uploads() const { return n_uploads_; }
  private:
-  svo_hip_ctx* ctx_; svo_hip_pyramid* pyr_ = nullptr; int capacity_, next_ = 0; std::vector<int> ids_;
+  svo_hip_ctx* ctx_; svo_hip_pyramid* pyr_ = nullptr; SlotTable table_; int n_uploads_ = 0, n_created_ = 0;
 };
 }  // namespace hip_bridge
 
@@ -477,7 +497,10 @@ class DepthFilter {
       *level = s.ftr->level;
     }
     void pose7(const Frame& fr, double T[7]) const { std::memcpy(T, fr.T_f_w_.p, sizeof(double) * 7); }
-    int keyframeSlot(Frame& fr) { return df->kf_pyr_->slotOf(fr); }
+    bool keyframeSlots(const std::vector<Frame*>& kfs, std::vector<int>& slots) {
+      std::vector<const Frame*> c(kfs.begin(), kfs.end());
+      return df->kf_pyr_->acquire(c, slots);
+    }
     int currentSlot(Frame& fr) { return df->cur_pyr_->slotOf(fr); }
     svo_hip_pyramid* keyframePyramids() const { return df->kf_pyr_->pyramid(); }
     svo_hip_pyramid* currentPyramids() const { return df->cur_pyr_->pyramid(); }

@@ -7,6 +7,7 @@ CHILD process (never `os.exec*`), waits for it and exits with its status."""
 from __future__ import annotations
 
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -24,6 +25,36 @@ def free_port() -> int:
     return port
 
 
+def _end_group(proc, grace_s: float = 5.0) -> str:
+    """SIGTERM to the process group `proc` leads (torch.distributed.run tears its workers down), SIGKILL to what is left after
+    grace_s; returns what the children had written.  Only ever the group this module created (start_new_session)."""
+    try:
+        pgid = os.getpgid(proc.pid)
+    except ProcessLookupError:
+        pgid = None
+    out = ""
+    if pgid is not None and pgid == proc.pid:
+        try:
+            os.killpg(pgid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+        try:
+            out, _ = proc.communicate(timeout=grace_s)
+            return out or ""
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(pgid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+    else:
+        proc.kill()
+    try:
+        out, _ = proc.communicate(timeout=grace_s)
+    except subprocess.TimeoutExpired:
+        out = ""
+    return out or ""
+
+
 def self_launch(script: str, argv, n_ranks: int, timeout_s: float | None = None) -> int:
     """Start n_ranks ranks of `script argv` under torch.distributed.run on this node (rendezvous on 127.0.0.1), pass the
     children's stdout (rank 0's one JSON line) and stderr through, return their exit status."""
@@ -32,12 +63,13 @@ def self_launch(script: str, argv, n_ranks: int, timeout_s: float | None = None)
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    # its own session = its own process group: on a timeout the group this process started is ended as a whole (torchrun's
+    # workers inherit the stdout pipe; killing torchrun alone would orphan them on their GPUs and block the read below)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
     try:
         out, _ = proc.communicate(timeout=timeout_s)
     except subprocess.TimeoutExpired:
-        proc.kill()                                            # the exact child this process started
-        out, _ = proc.communicate()
+        out = _end_group(proc)
         sys.stderr.write("launcher: %d ranks of %s did not finish in %s s\n" % (n_ranks, os.path.basename(script), timeout_s))
         sys.stdout.write(out or "")
         return 124

@@ -186,6 +186,97 @@ def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=16):
     return out
 
 
+def c0_leg(ctx, n_scenes=8, batch=1024):
+    """BASELINE config C0 -- the reference's own CPU-runnable case: one 640x480 pair, ~200 patches (a 40-px grid: 165), L4-L0 --
+    timed as SURVEY 8(d) 'CPU baseline timing' asks: both Gauss-Newton modes; ONE PINNED CORE, median of 20 runs after 3
+    warm-ups (the reference's run() is serial); all granted cores, one independent pair per thread.  Early stop is the
+    reference's OWN compiled SparseImgAlign (oracle/_ref, kind "reference") when the prebuilt library is on this box, else the
+    port; fixed work is the port (the reference's error-increase exit cannot be switched off).  Beside it the GPU's C0 figures:
+    one pair at a time (latency) and `batch` pairs per launch (the 4-wave shape: two pairs per CU)."""
+    from oracle import orc
+    orc.lib()
+    try:
+        from oracle.ref import refpy
+        have_ref = refpy.available()
+        if have_ref:
+            refpy.lib()
+    except Exception:
+        have_ref = False
+    fps = [synth.make_frame_pair(seed=777 + i, n_features=200) for i in range(n_scenes)]
+    n_patches = len(fps[0].px)
+    es = (lambda fp: refpy.sparse_img_align_run(fp, n_iter=30)) if have_ref else (lambda fp: orc.sparse_img_align(fp, n_iter=30, early_stop=True))
+    fw = lambda fp: orc.sparse_img_align(fp, n_iter=30, early_stop=False)
+
+    def pinned_median(fn):
+        old = None
+        try:
+            old = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, {sorted(old)[-1]})               # this thread on one of the CPUs the process was granted
+        except Exception:
+            old = None
+        try:
+            for _ in range(3):
+                fn(fps[0])
+            ts = []
+            for k in range(20):
+                t = time.perf_counter()
+                fn(fps[k % len(fps)])
+                ts.append(time.perf_counter() - t)
+        finally:
+            if old is not None:
+                os.sched_setaffinity(0, old)
+        return float(np.median(ts)) * 1e3
+
+    def all_cores(fn, per_thread):
+        n_threads = host_cpus()[1]
+        def work(t):
+            for k in range(per_thread):
+                fn(fps[(t + k) % len(fps)])
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return n_threads * per_thread / (time.perf_counter() - t0), n_threads
+
+    es_ms, fw_ms = pinned_median(es), pinned_median(fw)
+    es_fps, cores = all_cores(es, 40)
+    fw_fps, _ = all_cores(fw, 8)
+    cpu = {"es_ms_1core": es_ms, "fw_ms_1core": fw_ms, "es_fps": es_fps, "fw_fps": fw_fps, "cores": cores,
+           "kind_es": "reference" if have_ref else "port", "kind_fw": "port"}
+    # ---- the GPU on the same pairs
+    cam = fps[0].cam
+    ref = hip.Pyramid(ctx, cam.width, cam.height, 5, batch)
+    cur = hip.Pyramid(ctx, cam.width, cam.height, 5, batch)
+    sia = hip.SparseImgAlign(ctx, batch, n_patches)
+    sia.set_frames(ref, cur)
+    for s_ in range(batch):
+        fp = fps[s_ % len(fps)]
+        ref.upload(s_, fp.ref_pyr); cur.upload(s_, fp.cur_pyr); sia.upload_pair(s_, fp)
+    gpu = {"pairs_per_launch": batch}
+    worst = 0.0
+    for tag, early in (("es", True), ("fw", False)):
+        prm = sia.params(max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=early)
+        for n_l, key in ((1, "%s_ms_1pair" % tag), (batch, "%s_fps" % tag)):
+            prewarm(ctx, lambda: sia.run(n_l, prm), 0.05)
+            reps = 20
+            t = time.perf_counter()
+            for _ in range(reps):
+                sia.run(n_l, prm)
+                if n_l == 1:
+                    ctx.sync()
+            ctx.sync()
+            dt = (time.perf_counter() - t) / reps
+            gpu[key] = dt * 1e3 if n_l == 1 else n_l / dt
+        res = sia.download_all(len(fps))
+        for i, fp in enumerate(fps):                       # every C0 scene against the CPU path, both modes
+            o = orc.sparse_img_align(fp, n_iter=30, early_stop=early)
+            worst = max(worst, *synth.pose_error(np.array(res[i].T_cur_w), np.array(o.T_cur_w)))
+            assert int(res[i].n_tracked) == int(o.n_tracked)
+    assert worst < 1e-4, "C0 pose parity violated: %g" % worst
+    sia.destroy(); ref.destroy(); cur.destroy()
+    return {"patches": n_patches, "cpu": cpu, "gpu": gpu, "max_pose_err_vs_cpu": worst}
+
+
 N_SIMD = 1024                    # 256 CUs x 4 SIMD-32
 PEAK_CLOCK_GHZ = 2.4             # MI355X_MICROARCH.md, chip-level parameters
 
@@ -754,6 +845,9 @@ def main():
                           "converged records on the device; the multi-GPU form (seeds sharded, RCCL gather) is bench_c4.py")
             sb4.free()
             [p_.destroy() for p_ in pyr4]
+        c0 = None
+        if not args.no_cpu_baseline and world == 1 and not allreduce and not args.no_secondary and not args.early_stop and args.width == 640:
+            c0 = c0_leg(ctx)
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # reported at N=1 only (rank 0)
             cpu = cpu_baseline(fps[:16], n_iter=30, early_stop=args.early_stop, frames_per_thread=args.cpu_frames_per_thread)
@@ -796,6 +890,7 @@ def main():
             "moments_f32_arithmetic": m32_sec,
             "fast_arithmetic": fast,
             "with_image_uploads": upl,
+            "c0": c0,
             "c2": c2,
             "c4_one_gpu": c4,
         }

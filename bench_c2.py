@@ -44,8 +44,12 @@ def stage_times(ctx, run_pass, repeats=5):
 
 def stage_rooflines(stages_us, pmc_path):
     """Per stage of the depth-filter pass (kernel df_<stage>_kernel; its live time is stages_us[stage]): {bound, frac, valu_frac,
-    hbm_frac}.
-    valu_frac = VALU issue cycles of the stage's launches (per-type instruction counters of the rocprofv3 PMC passes in
+    hbm_frac, lane_util}.
+    lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) -- the share of a VALU instruction's 64 lanes that were
+    switched on (a quad whose seed has converged, a thread past its last ZMSSD step ride along masked) -- when the profile holds
+    the two counters; valu_frac is then the USEFUL fraction, issue fraction x lane_util (the issue fraction alone counts a
+    masked lane as busy; it is valu_frac / lane_util).
+    issue fraction = VALU issue cycles of the stage's launches (per-type instruction counters of the rocprofv3 PMC passes in
     `pmc_path`, made by tools/pmc_c2.sh: 2 cycles per wave64 f32/int instruction, 4 per f64 and per conversion, 8 per
     transcendental -- bench.py's rule for the fused SparseImgAlign kernel) / (1024 SIMDs x 2.4 GHz x the stage's live time);
     hbm_frac = (2 x FETCH_SIZE + WRITE_SIZE) KB of the same passes / live time / 8 TB/s.  `bound` names the larger one.
@@ -77,9 +81,15 @@ def stage_rooflines(stages_us, pmc_path):
         cyc = 2.0 * (per_pass["SQ_INSTS_VALU"] - f64 - trans - cvt) + 4.0 * (f64 + cvt) + 8.0 * trans
         t = stages_us[name] * 1e-6
         valu = cyc / (N_SIMD * PEAK_CLOCK_GHZ * 1e9 * t)
+        lane_util = None
+        if per_pass.get("SQ_THREAD_CYCLES_VALU") and per_pass.get("SQ_ACTIVE_INST_VALU"):
+            lane_util = min(1.0, per_pass["SQ_THREAD_CYCLES_VALU"] / (64.0 * per_pass["SQ_ACTIVE_INST_VALU"]))
+            valu *= lane_util
         phys = (2.0 * per_pass.get("FETCH_SIZE", 0.0) + per_pass.get("WRITE_SIZE", 0.0)) * 1024.0
         hbm = phys / t / 1e9 / HBM_PEAK_GBS
         out[name] = {"bound": "valu" if valu >= hbm else "hbm", "frac": max(valu, hbm), "valu_frac": valu, "hbm_frac": hbm}
+        if lane_util is not None:
+            out[name]["lane_util"] = lane_util
     out["source"] = os.path.relpath(pmc_path, ROOT)
     return out
 

@@ -28,7 +28,9 @@
 //   Frame*  keyframeOf(const Seed&)                       it->ftr->frame
 //   void    feature(const Seed&, double px[2], double f[3], int* level)
 //   void    pose7(const Frame&, double T[7])              {t, q(xyzw)} of T_f_w_
-//   int     keyframeSlot(Frame&), currentSlot(Frame&)     device pyramid slots (negative: unavailable)
+//   bool    keyframeSlots(const std::vector<Frame*>&, std::vector<int>&)   device pyramid slots of ALL the frame's keyframes,
+//                                                         resolved together (slot_table.h); false: unavailable
+//   int     currentSlot(Frame&)                           device pyramid slot of the current frame (negative: unavailable)
 //   svo_hip_pyramid* keyframePyramids(), currentPyramids()
 //   svo_hip_camera camera(const Frame&)
 //   bool    isKeyframe(const Frame&)
@@ -119,22 +121,33 @@ class DeviceSeedMirror {
       std::vector<svo_hip_seed_batch*> devs;
       std::vector<int> slots;
       std::vector<double> T_refs;
-      for (size_t k = 0; k < batches_.size(); ++k) {
-        Batch& b = batches_[k];
-        if (b.n_alive == 0) continue;
-        const int ref_slot = host.keyframeSlot(*b.kf);
-        if (ref_slot < 0) continue;
+      // the keyframes of every batch with live seeds, resolved TOGETHER: a slot handed out for one keyframe of this pass must
+      // not be recycled for another (with more keyframes alive than the cache had slots, a one-at-a-time look-up did that,
+      // and the first keyframe's seeds were matched against the second one's image)
+      typedef decltype(((SeedT*)0)->ftr->frame) FramePtrT;
+      std::vector<FramePtrT> kfs;
+      std::vector<size_t> which;
+      for (size_t k = 0; k < batches_.size(); ++k)
+        if (batches_[k].n_alive != 0) { kfs.push_back(batches_[k].kf); which.push_back(k); }
+      std::vector<int> kf_slots;
+      if (!kfs.empty() && !host.keyframeSlots(kfs, kf_slots)) { ++st.n_device_errors; return st; }
+      for (size_t j = 0; j < which.size(); ++j) {
+        Batch& b = batches_[which[j]];
+        if (kf_slots[j] < 0) continue;
         double T_ref[7];
         host.pose7(*b.kf, T_ref);
-        devs.push_back(b.dev); slots.push_back(ref_slot); T_refs.insert(T_refs.end(), T_ref, T_ref + 7);
-        enqueued.push_back(k);
+        devs.push_back(b.dev); slots.push_back(kf_slots[j]); T_refs.insert(T_refs.end(), T_ref, T_ref + 7);
+        enqueued.push_back(which[j]);
       }
       if (!devs.empty()) {
         st.n_device_calls += (int)devs.size();
         const int rc = svo_hip_seed_batch_update_group_async((int)devs.size(), devs.data(), host.keyframePyramids(), slots.data(),
                                                              host.currentPyramids(), cur_slot, &cam, T_refs.data(), T_cur, &prm,
                                                              is_keyframe ? 1 : 0);
-        if (rc != SVO_HIP_OK) { ++st.n_device_errors; enqueued.clear(); }   // nothing was enqueued: the seeds keep their state
+        // A failure leaves up to 8 batches at a time either enqueued or not (svo_hip.h): the collect loop below takes
+        // every batch that has a pass pending -- its seeds WERE updated -- and skips the others, so nothing stays
+        // pending into the next frame.
+        if (rc != SVO_HIP_OK) ++st.n_device_errors;
       }
     }
     // ---- the events, in list order: grid marks, callbacks, erasures (:302-337)
@@ -143,6 +156,7 @@ class DeviceSeedMirror {
       const svo_hip_seed_event* ev = NULL;
       int n_ev = 0;
       int32_t counts[7];
+      if (st.n_device_errors && !svo_hip_seed_batch_pending(b.dev)) continue;      // (not reached by a failed group call)
       if (svo_hip_seed_batch_collect(b.dev, &ev, &n_ev, counts) != SVO_HIP_OK) { ++st.n_device_errors; continue; }
       st.n_failed_matches += counts[SVO_HIP_SEED_NO_MATCH + 1];
       st.n_updated += counts[SVO_HIP_SEED_UPDATED + 1] + counts[SVO_HIP_SEED_CONVERGED + 1] + counts[SVO_HIP_SEED_NAN + 1];

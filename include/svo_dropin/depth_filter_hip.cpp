@@ -27,7 +27,10 @@ struct RefHost {
     *level = s.ftr->level;
   }
   void pose7(const Frame& fr, double T[7]) const { hip_bridge::toPose7(fr.T_f_w_, T); }
-  int keyframeSlot(Frame& fr) { return kf_pyr->slotOf(fr); }
+  bool keyframeSlots(const std::vector<Frame*>& kfs, std::vector<int>& slots) {
+    std::vector<const Frame*> c(kfs.begin(), kfs.end());
+    return kf_pyr->acquire(c, slots);
+  }
   int currentSlot(Frame& fr) { return cur_pyr->slotOf(fr); }
   svo_hip_pyramid* keyframePyramids() const { return kf_pyr->pyramid(); }
   svo_hip_pyramid* currentPyramids() const { return cur_pyr->pyramid(); }
@@ -64,7 +67,20 @@ void DepthFilterHip::updateSeeds(FramePtr frame) {
   RefHost host;
   host.kf_pyr = &kf_pyr_; host.cur_pyr = &cur_pyr_;
   host.detector = feature_detector_.get(); host.seed_converged_cb = &seed_converged_cb_;
-  mirror_.update(host, ctx_.get(), seeds_, *frame, prm, Seed::batch_counter, options_.max_n_kfs, seeds_updating_halt_);
+  const hip_bridge::SeedBatchStats st =
+      mirror_.update(host, ctx_.get(), seeds_, *frame, prm, Seed::batch_counter, options_.max_n_kfs, seeds_updating_halt_);
+  // a device failure is never silent: the seeds it did not reach keep their state (as after a failed match of the reference)
+  if (st.n_device_errors) hip_bridge::reportDeviceFailure(ctx_.get(), "DepthFilterHip::updateSeeds");
+}
+
+std::list<Seed>& DepthFilterHip::getSeeds() {
+  syncSeeds();
+  return seeds_;
+}
+
+void DepthFilterHip::getSeedsCopy(const FramePtr& frame, std::list<Seed>& seeds) {
+  syncSeeds();
+  DepthFilter::getSeedsCopy(frame, seeds);
 }
 
 }  // namespace svo

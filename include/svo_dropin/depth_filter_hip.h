@@ -27,6 +27,11 @@ class DepthFilterHip : public DepthFilter {
   /// this call -- make it before reading getSeeds() / getSeedsCopy() (both non-virtual in the reference; the app never
   /// calls them).  Returns false on a device error.
   bool syncSeeds();
+  /// The reference's accessors (I/depth_filter.h:117-123, non-virtual) with the synchronisation in front: a caller that
+  /// holds a DepthFilterHip* (FrameHandlerMono::depth_filter_ after the one-line change of INTEGRATION.md is declared
+  /// DepthFilter*: cast, or call syncSeeds() first) reads the device's a / b / mu / sigma2, not the construction-time values.
+  std::list<Seed>& getSeeds();
+  void getSeedsCopy(const FramePtr& frame, std::list<Seed>& seeds);
 
  protected:
   /// One pass over all seeds against `frame`, batched per reference keyframe.

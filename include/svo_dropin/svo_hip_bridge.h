@@ -20,6 +20,7 @@
 #include <svo/pinhole_camera.h>
 #include <svo/point.h>
 
+#include "slot_table.h"
 #include "svo_hip.h"
 
 namespace svo {
@@ -76,24 +77,56 @@ class Context {
   svo_hip_ctx* ctx_;
 };
 
-/// Device copy of a Frame's image pyramid, cached by frame id so a keyframe is uploaded once.
+/// Device copy of a Frame's image pyramid, cached by frame id so a keyframe is uploaded once (slot_table.h says why a
+/// call that needs several frames has to resolve them together).
 class PyramidCache {
  public:
-  PyramidCache(svo_hip_ctx* ctx, int capacity) : ctx_(ctx), pyr_(NULL), capacity_(capacity), next_(0) {}
+  PyramidCache(svo_hip_ctx* ctx, int capacity) : ctx_(ctx), pyr_(NULL), table_(capacity) {}
   ~PyramidCache() { if (pyr_) svo_hip_pyramid_destroy(pyr_); }
 
-  /// slot holding `frame`'s pyramid, uploading it (all levels, stride == cols) if needed; -1 on error
+  /// slot holding `frame`'s pyramid, uploading it (all levels, stride == cols) if needed; -1 on error.  For ONE frame per
+  /// device call; a call that reads several frames' pyramids uses acquire().
   int slotOf(const Frame& frame) {
-    const int n_levels = (int)frame.img_pyr_.size();
-    const cv::Mat& l0 = frame.img_pyr_[0];
-    if (!pyr_) {
-      if (svo_hip_pyramid_create(ctx_, l0.cols, l0.rows, n_levels, capacity_, &pyr_) != SVO_HIP_OK) return -1;
-      slot_frame_.assign(capacity_, -1);
+    std::vector<const Frame*> one(1, &frame);
+    std::vector<int> slots;
+    return acquire(one, slots) ? slots[0] : -1;
+  }
+  /// Slots holding the pyramids of ALL `frames` at once (the reprojector matches against every keyframe that observes a
+  /// candidate point, the depth filter against every keyframe that still owns seeds: the map is unbounded, so is their
+  /// number).  Frames already resident keep their slot; the others go to slots no frame of this call uses; the cache
+  /// grows (to a multiple of 16 slots) when the set does not fit.  Returns false on a device error.
+  bool acquire(const std::vector<const Frame*>& frames, std::vector<int>& slots) {
+    slots.assign(frames.size(), -1);
+    if (frames.empty()) return true;
+    std::vector<int> ids(frames.size());
+    int distinct = 0;
+    for (size_t k = 0; k < frames.size(); ++k) {
+      ids[k] = frames[k]->id_;
+      bool seen = false;
+      for (size_t m = 0; m < k && !seen; ++m) seen = ids[m] == ids[k];
+      if (!seen) ++distinct;
     }
-    for (int s = 0; s < capacity_; ++s)
-      if (slot_frame_[s] == frame.id_) return s;
-    const int s = next_;
-    next_ = (next_ + 1) % capacity_;
+    const int need = table_.capacityFor(distinct);
+    if (need != table_.capacity() || !pyr_) {
+      if (pyr_) { svo_hip_pyramid_destroy(pyr_); pyr_ = NULL; }
+      const cv::Mat& l0 = frames[0]->img_pyr_[0];
+      if (svo_hip_pyramid_create(ctx_, l0.cols, l0.rows, (int)frames[0]->img_pyr_.size(), need, &pyr_) != SVO_HIP_OK) return false;
+      table_.reset(need);
+    }
+    Uploader up = {this, &frames};
+    return table_.acquire(ids, slots, up);
+  }
+  int capacity() const { return table_.capacity(); }
+  svo_hip_pyramid* pyramid() const { return pyr_; }
+
+ private:
+  struct Uploader {
+    PyramidCache* self;
+    const std::vector<const Frame*>* frames;
+    bool operator()(size_t k, int slot) const { return self->upload(*(*frames)[k], slot); }
+  };
+  bool upload(const Frame& frame, int s) {
+    const int n_levels = (int)frame.img_pyr_.size();
     std::vector<const uint8_t*> levels(SVO_HIP_MAX_LEVELS, (const uint8_t*)NULL);
     std::vector<std::vector<uint8_t> > packed(n_levels);
     for (int l = 0; l < n_levels; ++l) {
@@ -106,52 +139,13 @@ class PyramidCache {
         levels[l] = packed[l].data();
       }
     }
-    if (svo_hip_pyramid_upload(pyr_, s, levels.data()) != SVO_HIP_OK) return -1;
-    if (svo_hip_ctx_sync(ctx_) != SVO_HIP_OK) return -1;
-    slot_frame_[s] = frame.id_;
-    return s;
+    if (svo_hip_pyramid_upload(pyr_, s, levels.data()) != SVO_HIP_OK) return false;
+    return svo_hip_ctx_sync(ctx_) == SVO_HIP_OK;
   }
-  /// Slots holding the pyramids of ALL `frames` at once (the reprojector matches against every keyframe that observes
-  /// a candidate point: the map is unbounded, so is their number).  Frames already resident keep their slot; the
-  /// others go to slots no frame of this call uses; the cache grows (in steps of 16 slots) when the set does not
-  /// fit.  Returns false on a device error.
-  bool acquire(const std::vector<const Frame*>& frames, std::vector<int>& slots) {
-    slots.assign(frames.size(), -1);
-    if (frames.empty()) return true;
-    if ((int)frames.size() > capacity_ || !pyr_) {
-      if ((int)frames.size() > capacity_) {
-        if (pyr_) { svo_hip_pyramid_destroy(pyr_); pyr_ = NULL; }
-        capacity_ = ((int)frames.size() + 15) / 16 * 16;
-        next_ = 0;
-      }
-      if (!pyr_) {
-        const cv::Mat& l0 = frames[0]->img_pyr_[0];
-        if (svo_hip_pyramid_create(ctx_, l0.cols, l0.rows, (int)frames[0]->img_pyr_.size(), capacity_, &pyr_) != SVO_HIP_OK) return false;
-        slot_frame_.assign(capacity_, -1);
-      }
-    }
-    std::vector<char> used(capacity_, 0);
-    for (size_t k = 0; k < frames.size(); ++k)
-      for (int s = 0; s < capacity_; ++s)
-        if (slot_frame_[s] == frames[k]->id_) { slots[k] = s; used[s] = 1; break; }
-    for (size_t k = 0; k < frames.size(); ++k) {
-      if (slots[k] >= 0) continue;
-      while (used[next_]) next_ = (next_ + 1) % capacity_;       // terminates: frames.size() <= capacity_
-      slot_frame_[next_] = -1;
-      const int got = slotOf(*frames[k]);                          // uploads into next_
-      if (got < 0) return false;
-      slots[k] = got; used[got] = 1;
-    }
-    return true;
-  }
-  int capacity() const { return capacity_; }
-  svo_hip_pyramid* pyramid() const { return pyr_; }
 
- private:
   svo_hip_ctx* ctx_;
   svo_hip_pyramid* pyr_;
-  int capacity_, next_;
-  std::vector<int> slot_frame_;
+  SlotTable table_;
 };
 
 }  // namespace hip_bridge

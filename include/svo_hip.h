@@ -61,6 +61,19 @@ typedef struct {
 int svo_hip_ctx_create(svo_hip_ctx** out, int device, void* stream);
 int svo_hip_ctx_destroy(svo_hip_ctx* ctx);
 int svo_hip_ctx_sync(svo_hip_ctx* ctx);            /* hipStreamSynchronize on the context stream */
+/* Memory bookkeeping of a context.  The library takes device / page-locked memory for a context's grow-only work areas
+ * and for the blocks of its seed-batch pool (svo_hip_seed_batch_create / _destroy recycle blocks: the reference creates and
+ * drops a keyframe's seeds at keyframe rate on the depth-filter thread, S/depth_filter.cpp:129-151,256-261, and hipFree
+ * would synchronise the whole device under the tracking thread).  `allocator_calls` counts hipMalloc + hipHostMalloc calls,
+ * `free_calls` hipFree + hipHostFree: both stay flat once the context has seen its working set (asserted over 20 keyframes
+ * in tests/test_gpu_seed_batch.py).  svo_hip_ctx_trim returns the pool's free blocks to the driver (synchronises). */
+typedef struct svo_hip_ctx_stats {
+  unsigned long long allocator_calls, free_calls;
+  unsigned long long seed_pool_free_device_bytes, seed_pool_free_host_bytes, scratch_bytes, staging_bytes;
+  int seed_blocks_in_use, seed_blocks_free;
+} svo_hip_ctx_stats;
+int svo_hip_ctx_info(svo_hip_ctx* ctx, svo_hip_ctx_stats* out);
+int svo_hip_ctx_trim(svo_hip_ctx* ctx);
 void* svo_hip_ctx_stream(svo_hip_ctx* ctx);
 const char* svo_hip_last_error(svo_hip_ctx* ctx);  /* text of the last failure on this context */
 const char* svo_hip_version(void);
@@ -431,8 +444,11 @@ int svo_hip_seed_batch_update_async(svo_hip_seed_batch* batch, const svo_hip_pyr
  * with pose T_ref_w[7 * k .. 7 * k + 6].  Results per batch are bit-identical to n_batches calls of
  * svo_hip_seed_batch_update_async; what changes is the cost when the batches are small (a few hundred seeds each is what
  * the reference's detector yields per keyframe): one set of launches per frame -- two for passes of a few thousand seeds,
- * six beyond (svo_hip_df_set_small_pass_limit) -- instead of one set per keyframe.  Everything is
- * checked before anything is enqueued (all batches are updated, or none); collect every batch afterwards. */
+ * six beyond (svo_hip_df_set_small_pass_limit) -- instead of one set per keyframe.  The arguments of every batch are
+ * checked before anything is enqueued.  Up to 8 batches go down per set of launches: with at most 8 the call updates all
+ * batches or none; with more, a device failure in a later set (out of memory for its work area, a launch error) returns
+ * the error while the earlier sets are already enqueued -- svo_hip_seed_batch_pending tells which batches then have a
+ * pass to collect (DeviceSeedMirror collects exactly those). */
 int svo_hip_seed_batch_update_group_async(int n_batches, svo_hip_seed_batch* const* batches, const svo_hip_pyramid* ref,
                                           const int* ref_slots, const svo_hip_pyramid* cur, int cur_slot,
                                           const svo_hip_camera* cam, const double* T_ref_w /* [n_batches][7] */,
@@ -442,6 +458,8 @@ int svo_hip_seed_batch_update_group_async(int n_batches, svo_hip_seed_batch* con
  * per batch writes the events -- instead of six; results are bit-identical.  0 switches the form off; at most 16384;
  * the default is 8192 (DESIGN.md section 8 has the crossover measurement). */
 int svo_hip_df_set_small_pass_limit(svo_hip_ctx* ctx, int max_seeds);
+/* 1 while a pass of the batch is enqueued and not collected yet, else 0 (also for NULL) */
+int svo_hip_seed_batch_pending(const svo_hip_seed_batch* batch);
 /* wait for the pass; *events points into page-locked memory owned by the batch (valid until its next update_async);
  * status_counts[7]: seeds per outcome of this pass, slot = status + 1 (slot 0 = SVO_HIP_SEED_ERASED ... slot 6 =
  * SVO_HIP_SEED_NAN).  Either output may be NULL. */

@@ -2,7 +2,9 @@
 // drop-in DepthFilter against a MOCK of the svo_hip_seed_batch_* entry points (no GPU, no oracle: the mock "device" gives every
 // seed a countdown -- it is "updated" every pass and "converges" when the countdown reaches zero, every 7th seed turns NaN on
 // its third pass).  What is checked is the host logic: upload once, events applied in list order, age-out of whole batches,
-// erasures behind the mirror's back (removeKeyframe / reset), recycled list nodes, the halt flag, syncToHost.
+// erasures behind the mirror's back (removeKeyframe / reset), recycled list nodes, the halt flag, syncToHost; more keyframes
+// alive than the pyramid cache has slots (every batch of a pass must see ITS keyframe's image: slot_table.h); a grouped pass
+// that fails half-way (what was enqueued is collected, nothing stays pending).
 // Built and run by tests/test_host_mirror_mock.py with g++ -std=c++11.
 #include <algorithm>
 #include <cstdio>
@@ -13,6 +15,7 @@
 #include <vector>
 
 #include "svo_hip.h"
+#include "svo_dropin/slot_table.h"
 #include "svo_dropin/depth_filter_batch.h"
 
 #define CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "CHECK failed at line %d: %s\n", __LINE__, #cond); std::exit(1); } } while (0)
@@ -26,8 +29,13 @@ struct svo_hip_seed_batch {
   int32_t counts[7];
   bool pending;
   int report_updated;
+  int kf_id;                  // the test encodes the keyframe's id in px[1] of the batch's first seed
 };
 static int g_created = 0, g_destroyed = 0, g_uploaded_seeds = 0, g_updates = 0;
+static int g_fail_group_after = -1;          // >= 0: the grouped pass enqueues this many batches, then reports a device failure
+static int g_wrong_image = 0;                // passes in which a batch was handed a slot that holds another keyframe's pyramid
+// the mock "pyramid batch": which frame's image every slot holds (what svo_hip_pyramid* points at in this test)
+struct svo_hip_pyramid { std::vector<int> holds; };
 
 extern "C" {
 int svo_hip_seed_batch_create(svo_hip_ctx*, int n, const double* px, const double*, const int32_t*, const float* a, const float* b,
@@ -37,6 +45,7 @@ int svo_hip_seed_batch_create(svo_hip_ctx*, int n, const double* px, const doubl
   s->countdown.resize((size_t)n); s->passes.assign((size_t)n, 0); s->alive.assign((size_t)n, 1);
   for (int i = 0; i < n; ++i) s->countdown[(size_t)i] = (int)px[2 * i];          // the test encodes the countdown in px[0]
   s->pending = false; s->report_updated = 0;
+  s->kf_id = (int)px[1];
   ++g_created; g_uploaded_seeds += n;
   *out = s;
   return SVO_HIP_OK;
@@ -76,10 +85,15 @@ int svo_hip_seed_batch_update_async(svo_hip_seed_batch* s, const svo_hip_pyramid
 int svo_hip_seed_batch_update_group_async(int n, svo_hip_seed_batch* const* sbs, const svo_hip_pyramid* ref, const int* slots,
                                           const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam, const double* T_ref_w,
                                           const double* T_cur_w, const svo_hip_df_params* prm, int report_updated) {
-  for (int k = 0; k < n; ++k) if (sbs[k]->pending) return SVO_HIP_ERR_STATE;           // all or none
-  for (int k = 0; k < n; ++k) svo_hip_seed_batch_update_async(sbs[k], ref, slots[k], cur, cur_slot, cam, T_ref_w + 7 * k, T_cur_w, prm, report_updated);
+  for (int k = 0; k < n; ++k) if (sbs[k]->pending) return SVO_HIP_ERR_STATE;           // checked before anything is enqueued
+  for (int k = 0; k < n; ++k) {
+    if (g_fail_group_after >= 0 && k == g_fail_group_after) return SVO_HIP_ERR_DEVICE;   // a later set of launches failed
+    if (ref && ref->holds[(size_t)slots[k]] != sbs[k]->kf_id) ++g_wrong_image;
+    svo_hip_seed_batch_update_async(sbs[k], ref, slots[k], cur, cur_slot, cam, T_ref_w + 7 * k, T_cur_w, prm, report_updated);
+  }
   return SVO_HIP_OK;
 }
+int svo_hip_seed_batch_pending(const svo_hip_seed_batch* s) { return s && s->pending ? 1 : 0; }
 int svo_hip_seed_batch_collect(svo_hip_seed_batch* s, const svo_hip_seed_event** ev, int* n_ev, int32_t counts[7]) {
   if (!s->pending) return SVO_HIP_ERR_STATE;
   s->pending = false;
@@ -122,9 +136,26 @@ struct Host {
   Frame* keyframeOf(const Seed& s) const { return s.ftr->frame; }
   void feature(const Seed& s, double px[2], double f[3], int* level) const { px[0] = s.ftr->px[0]; px[1] = s.ftr->px[1]; f[0] = f[1] = 0; f[2] = 1; *level = 0; }
   void pose7(const Frame&, double T[7]) const { for (int k = 0; k < 7; ++k) T[k] = k == 6 ? 1.0 : 0.0; }
-  int keyframeSlot(Frame& f) { return f.id; }
+  // the keyframe pyramid cache of the drop-in in miniature: TWO slots to start with, the real slot bookkeeping
+  svo::hip_bridge::SlotTable table;
+  svo_hip_pyramid pyr;
+  int n_uploads, n_grown;
+  Host() : table(2), n_uploads(0), n_grown(0) { pyr.holds.assign(2, -1); }
+  struct Up {
+    Host* h; const std::vector<Frame*>* kfs;
+    bool operator()(size_t k, int slot) const { h->pyr.holds[(size_t)slot] = (*kfs)[k]->id; ++h->n_uploads; return true; }
+  };
+  bool keyframeSlots(const std::vector<Frame*>& kfs, std::vector<int>& slots) {
+    std::vector<int> ids;
+    std::map<int, int> distinct;
+    for (size_t k = 0; k < kfs.size(); ++k) { ids.push_back(kfs[k]->id); distinct[kfs[k]->id] = 1; }
+    const int need = table.capacityFor((int)distinct.size());
+    if (need != table.capacity()) { table.reset(need); pyr.holds.assign((size_t)need, -1); ++n_grown; }
+    Up up = {this, &kfs};
+    return table.acquire(ids, slots, up);
+  }
   int currentSlot(Frame&) { return 0; }
-  svo_hip_pyramid* keyframePyramids() const { return NULL; }
+  svo_hip_pyramid* keyframePyramids() { return &pyr; }
   svo_hip_pyramid* currentPyramids() const { return NULL; }
   svo_hip_camera camera(const Frame&) const { svo_hip_camera c = svo_hip_camera(); c.width = 640; c.height = 480; return c; }
   bool isKeyframe(const Frame& f) const { return f.keyframe; }
@@ -138,7 +169,7 @@ static std::vector<Feature*> add_keyframe(SeedList& seeds, Frame* kf, int n, int
   ++Seed::batch_counter;
   std::vector<Feature*> fts;
   for (int i = 0; i < n; ++i) {
-    Feature* f = new Feature; f->frame = kf; f->px[0] = countdown_base + (i % 5); f->px[1] = 0;
+    Feature* f = new Feature; f->frame = kf; f->px[0] = countdown_base + (i % 5); f->px[1] = kf->id;
     fts.push_back(f);
     seeds.push_back(Seed(f));
   }
@@ -210,6 +241,34 @@ int main() {
   st = mirror.update(host, NULL, seeds, cur, prm, Seed::batch_counter, 3, halt, 40);
   CHECK(st.n_aged_out == 30 && seeds.size() == 25 && mirror.deviceBatches() == 1);
   for (SeedList::iterator it = seeds.begin(); it != seeds.end(); ++it) CHECK(it->ftr->frame == &kfC);
+
+  // ---- more keyframes alive than the cache has slots (it started with two): every batch of the grouped pass is handed the
+  // ---- slot that holds ITS keyframe, over several frames; the cache grows once and uploads every keyframe once
+  {
+    std::vector<Frame> kfs(20);
+    for (int k = 0; k < 20; ++k) { kfs[(size_t)k].id = 100 + k; kfs[(size_t)k].keyframe = true; add_keyframe(seeds, &kfs[(size_t)k], 6, 40); }
+    const int up0 = host.n_uploads, grown0 = host.n_grown;
+    for (int frame = 0; frame < 3; ++frame) {
+      st = mirror.update(host, NULL, seeds, cur, prm, Seed::batch_counter, 1000, halt, 40);
+      CHECK(st.n_device_errors == 0 && st.n_updated == st.n_seeds && st.n_seeds > 120);   // every live seed of all 21 keyframes
+    }
+    CHECK(g_wrong_image == 0);
+    CHECK(host.n_grown == grown0 + 1 && host.table.capacity() >= 21);
+    CHECK(host.n_uploads - up0 == 21);                     // kfC again after the growth + the 20 new ones, each once
+    // ---- a grouped pass that fails after 5 of its 21 batches: those five are collected (their seeds were updated), the others
+    // ---- keep their state, nothing is left pending and the next frame runs normally
+    g_fail_group_after = 5;
+    const int updates0 = g_updates;
+    st = mirror.update(host, NULL, seeds, cur, prm, Seed::batch_counter, 1000, halt, 40);
+    CHECK(st.n_device_errors == 1 && g_updates == updates0 + 5 && st.n_updated > 0 && st.n_updated < st.n_seeds);
+    g_fail_group_after = -1;
+    st = mirror.update(host, NULL, seeds, cur, prm, Seed::batch_counter, 1000, halt, 40);
+    CHECK(st.n_device_errors == 0 && st.n_updated == st.n_seeds && g_wrong_image == 0);
+    for (SeedList::iterator it = seeds.begin(); it != seeds.end();) it = (it->ftr->frame != &kfC) ? seeds.erase(it) : ++it;
+    st = mirror.update(host, NULL, seeds, cur, prm, Seed::batch_counter, 1000, halt, 40);
+    CHECK(st.resynced && mirror.deviceBatches() == 1);
+    for (SeedList::iterator it = seeds.begin(); it != seeds.end(); ++it) CHECK(it->ftr->frame == &kfC);
+  }
 
   // ---- reset(): the list is cleared behind the mirror's back
   seeds.clear();

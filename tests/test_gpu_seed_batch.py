@@ -209,3 +209,58 @@ def test_grouped_pass_random_shapes_both_forms_agree(ctx):
                 r.destroy()
         kf.destroy(); cf.destroy()
     ctx.set_small_pass_limit(8192)
+
+
+def test_seed_batches_at_keyframe_rate_do_not_allocate_after_warm_up(ctx):
+    """The drop-in DepthFilter creates a keyframe's seed batch and drops the batches that age out or empty at keyframe rate, on
+    the depth-filter thread (S/depth_filter.cpp:129-151,256-261).  hipFree synchronises the whole device -- the tracking thread's
+    stream too -- so batches take their memory from a per-context pool: after the first keyframes have been seen, 20 more
+    keyframes (a new batch of 100-500 seeds each, the oldest dropped, a pass in between) make NO allocator or free call, and a
+    recycled block gives the same results as a fresh one."""
+    rng = np.random.default_rng(5)
+    sc, kf, cf, s2 = _case(ctx, 512, 0.02)
+
+    def make(n):
+        return hip.ResidentSeeds(ctx, sc.px[:n], sc.f[:n], sc.level[:n], sc.a[:n], sc.b[:n], sc.mu[:n], sc.z_range[:n], s2[:n])
+
+    def one_pass(rs):
+        ev, counts = rs.update(kf, 0, cf, 0, sc.cam, sc.T_ref_w, sc.T_cur_w)
+        return ev, counts, rs.download()
+
+    alive = []
+    for _ in range(4):                                   # warm-up: max_n_kfs + 1 batches alive, both capacity classes (256..512) seen
+        alive.append(make(int(rng.integers(300, 500))))
+        one_pass(alive[-1])
+        alive.append(make(int(rng.integers(100, 250))))
+        one_pass(alive[-1])
+    for rs in alive[:4]:
+        rs.destroy()
+    alive = alive[4:]
+    first = make(400)
+    ev0, counts0, d0 = one_pass(first)                   # reference outcome of a 400-seed batch (first pass)
+    first.destroy()
+    before = ctx.info()
+    assert before["seed_blocks_free"] >= 1
+    for k in range(20):
+        n = int(rng.integers(300, 500)) if k % 2 == 0 else int(rng.integers(100, 250))
+        alive.append(make(n))
+        for rs in alive:
+            one_pass(rs)
+        alive.pop(0).destroy()                           # the oldest keyframe's seeds age out
+    again = make(400)                                    # a recycled block: same results as the fresh one, bit for bit
+    ev1, counts1, d1 = one_pass(again)
+    again.destroy()
+    after = ctx.info()
+    assert after["allocator_calls"] == before["allocator_calls"], (before, after)
+    assert after["free_calls"] == before["free_calls"], (before, after)
+    assert list(counts0) == list(counts1) and np.array_equal(ev0["index"], ev1["index"])
+    for key in ("a", "b", "mu", "sigma2", "alive"):
+        assert np.array_equal(d0[key], d1[key], equal_nan=True), key
+    for rs in alive:
+        rs.destroy()
+    info = ctx.info()
+    assert info["seed_blocks_in_use"] == 0 and info["seed_blocks_free"] >= 4
+    ctx.trim()
+    info = ctx.info()
+    assert info["seed_blocks_free"] == 0 and info["free_calls"] > after["free_calls"]
+    kf.destroy(); cf.destroy()

@@ -54,3 +54,40 @@ def test_self_launch_relays_one_json_line_and_the_status(tmp_path):
 def test_self_launch_returns_a_failing_rank_status(tmp_path):
     p = _run(tmp_path, 3)
     assert p.returncode != 0
+
+
+HANG_SCRIPT = textwrap.dedent('''
+    import os, sys, time
+    open(os.path.join(sys.argv[1], "pid_%s" % os.environ["RANK"]), "w").write(str(os.getpid()))
+    time.sleep(600)
+''')
+
+TIMEOUT_PARENT = textwrap.dedent('''
+    import sys
+    sys.path.insert(0, %r)
+    from android_svo_amd import launcher
+    sys.exit(launcher.self_launch(sys.argv[1], sys.argv[2:], 2, timeout_s=20))
+''') % ROOT
+
+
+def test_ranks_that_hang_are_ended_as_a_group_on_timeout(tmp_path):
+    """A timeout ends torch.distributed.run AND its workers (own process group: SIGTERM, then SIGKILL): no rank is left behind
+    holding a GPU or the stdout pipe, and the launcher returns 124 promptly."""
+    import time
+    script = tmp_path / "hang.py"
+    script.write_text(HANG_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", TIMEOUT_PARENT, str(script), str(tmp_path)], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 124, (p.returncode, p.stderr[-1500:])
+    assert time.time() - t0 < 60
+    pids = [int((tmp_path / ("pid_%d" % r)).read_text()) for r in range(2) if (tmp_path / ("pid_%d" % r)).exists()]
+    assert len(pids) == 2, "the ranks did not start within the timeout"
+    time.sleep(1.0)
+    for pid in pids:                                     # the exact processes this test's launcher started
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        assert not alive, "rank process %d outlived the launcher's timeout" % pid

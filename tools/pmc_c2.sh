@@ -16,6 +16,9 @@ groups=(
   "WRITE_SIZE"
   "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum TA_BUSY_avr"
+  # lane utilisation of the VALU (rocprof's VALUUtilization = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)): the issue
+  # fractions above count a masked lane as busy; both counters from ONE pass, last, so that this pair is what the JSON keeps
+  "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU"
 )
 PMC_ARGS="100000 640 480 0 4" bash tools/pmc_pass.sh "${tag}_df_c2" "${groups[@]}" > /dev/null
 python3 tools/pmc_json.py "gpurun_out/${tag}_df_c2_pmc_extra.txt" "gpurun_out/${tag}_pmc_df_c2.json" \

@@ -14,5 +14,6 @@ bash tools/pmc_pass.sh "$tag" \
   "WRITE_SIZE" \
   "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_DRAM_sum" \
   "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
-  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum" > /dev/null
+  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum" \
+  "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU" > /dev/null
 python3 tools/pmc_json.py "gpurun_out/${tag}_pmc_extra.txt" "gpurun_out/${tag}_pmc.json" "rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py $PMC_ARGS"
