@@ -263,6 +263,7 @@ static int churn_demo(const std::string& dir, const std::string& out) {
   std::atomic<int> mode{0};                  // 0 idle, 1 churn, 2 stop
   std::atomic<long> n_created{0};
   svo_hip_ctx_stats st_before{}, st_after{};
+  std::vector<double> create_us;            // per keyframe on the second thread: svo_hip_seed_batch_create (+ the drop of the oldest batch)
   std::thread filter([&]() {
     svo_hip_ctx* ctx = nullptr;
     if (svo_hip_ctx_create(&ctx, 0, nullptr) != SVO_HIP_OK) return;
@@ -273,13 +274,15 @@ static int churn_demo(const std::string& dir, const std::string& out) {
       rng = rng * 1664525u + 1013904223u;
       const int n = 300 + (int)((rng >> 8) % 700u);
       svo_hip_seed_batch* sb = nullptr;
+      const auto t0 = std::chrono::steady_clock::now();
       if (svo_hip_seed_batch_create(ctx, n < n_all ? n : n_all, spx.data(), sf.data(), slevel.data(), a.data(), b.data(), mu.data(), zr.data(), s2.data(), &sb) == SVO_HIP_OK) {
         alive.push_back(sb);
         ++n_created;
       }
       if (alive.size() > 3) { svo_hip_seed_batch_destroy(alive.front()); alive.erase(alive.begin()); }
+      if (mode.load() == 1) create_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     };
-    for (int k = 0; k < 8; ++k) keyframe();  // warm-up: the pool has seen the working set
+    for (int k = 0; k < 64; ++k) keyframe(); // warm-up: the pool has seen the working set (both capacity classes, every size)
     svo_hip_ctx_info(ctx, &st_before);
     while (mode.load() != 2) {
       if (mode.load() == 1) keyframe();
@@ -308,6 +311,10 @@ static int churn_demo(const std::string& dir, const std::string& out) {
   std::printf("churn:   second thread creating + dropping batches:   %8.1f %8.1f %8.1f   (%ld batches created meanwhile)\n", busy[0], busy[1], busy[2], c1 - c0);
   std::printf("churn:   allocator calls of the second context during the measurement: %llu, free calls: %llu\n",
               st_after.allocator_calls - st_before.allocator_calls, st_after.free_calls - st_before.free_calls);
+  std::sort(create_us.begin(), create_us.end());
+  if (!create_us.empty())
+    std::printf("churn:   a keyframe on the second thread (create a batch of 300-1000 seeds incl. its upload, drop the oldest), us: median %.1f  p99 %.1f\n",
+                create_us[create_us.size() / 2], create_us[create_us.size() * 99 / 100]);
   write_bin(out + "/churn.bin", std::vector<double>{idle[0], idle[1], idle[2], busy[0], busy[1], busy[2], (double)(c1 - c0),
                                                     (double)(st_after.allocator_calls - st_before.allocator_calls),
                                                     (double)(st_after.free_calls - st_before.free_calls)});

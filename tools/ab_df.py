@@ -19,11 +19,24 @@ def stages(res):
 
 a5, _ = bench_c2.measure_align2d(ctx, 5000, steps=20, warmup=3)
 a200, _ = bench_c2.measure_align2d(ctx, 200000, steps=20, warmup=3)
+import hashlib
+
+
+def digest(sb):
+    """the seeds' state and outcome after the timed passes: equal between two builds that compute the same thing"""
+    h = hashlib.sha256()
+    for arr in (sb.a, sb.b, sb.mu, sb.sigma2, sb.status, sb.px_cur):
+        h.update(arr.download().tobytes())
+    return h.hexdigest()[:12]
+
+
 c2, sc, sb, pyr = bench_c2.measure_depth_filter(ctx, 100000, steps=20, warmup=3)
 st2 = stages(c2)
+d2 = digest(sb)
 sb.free(); [p.destroy() for p in pyr]
 c4, sc, sb, pyr = bench_c2.measure_depth_filter(ctx, 1000000, steps=10, warmup=2, width=1280, height=720, sigma_scale=0.0045, compact=True)
 st4 = stages(c4)
-print("%-34s align2D 5k %.1f us  200k %.1f us | C2 %.1f us%s | C4 %.1f us%s (%d packed)" % (
+d4 = digest(sb)
+print("%-34s align2D 5k %.1f us  200k %.1f us | C2 %.1f us%s | C4 %.1f us%s (%d packed) | state sha %s %s" % (
     os.environ.get("SVO_HIP_LIB", "default")[-34:], a5["us_per_batch"], a200["us_per_batch"], c2["us_per_frame"], st2, c4["us_per_frame"], st4,
-    c4["converged_records_packed"]))
+    c4["converged_records_packed"], d2, d4))

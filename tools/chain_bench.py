@@ -204,12 +204,90 @@ def tracker_leg(ctx, seq, min_level, repeats=3):
             "what": "svo_hip_tracker_track: image upload + pyramid + SparseImgAlign + reprojectMap + pose refinement + hand-over + result download, one sync"}
 
 
+def multi_camera(seq, min_level, cams=(1, 2, 4, 8), repeats=6):
+    """north_star's "concurrent frame pairs" for the WHOLE per-frame chain: N independent cameras, each its own svo_hip_tracker
+    on its own context (= its own stream) driven by its own host thread, one frame at a time each -- what an application with N
+    cameras does with the C-ABI as it is (no grouped entry point: every kernel of a tracker's chain is a single workgroup or a
+    few, so N chains occupy N sets of CUs side by side).  Returns frames/s of the whole job per camera count and checks that
+    every camera's last pose of every pass is bit-equal to the one-camera run's."""
+    import ctypes as C
+    import threading
+    mp = tc.sequence_map(seq)
+    n = len(seq["px0"])
+    imgs = [np.ascontiguousarray(p[0]) for p in seq["pyrs"]]
+    ptrs = [im.ctypes.data_as(C.POINTER(C.c_uint8)) for im in imgs]
+    idx = np.arange(n, dtype=np.int32)
+    out = {}
+    ref_pose = None
+    for n_cam in cams:
+        ctxs = [hip.Context(0) for _ in range(n_cam)]
+        trks = [hip.Tracker(c, seq["cam"], max_keyframes=2, max_points=1024, max_obs=1024, max_kf_features=1024, max_candidates=16, max_items=1024,
+                            max_frame_features=1024, grid_size=tc.CELL, max_fts=tc.MAX_FTS, klt_min_level=min_level) for c in ctxs]
+        for t in trks:
+            t.upload_keyframe(0, seq["pyrs"][0][0])
+        start = threading.Barrier(n_cam + 1)
+        done = threading.Barrier(n_cam + 1)
+        last_pose = [None] * n_cam
+        errs = []
+
+        def work(ci):
+            ctx, trk = ctxs[ci], trks[ci]
+            res = hip.CTrackResult()
+            try:
+                for rep in range(repeats + 1):
+                    trk.set_map(mp)
+                    trk.set_last_frame(seq["T0"], seq["px0"], seq["f0"], idx, kf_slot=0)
+                    ctx.sync()
+                    if rep == 1:
+                        start.wait()                       # pass 0 is the warm-up; the clock runs over passes 1..repeats
+                    for k in range(1, len(imgs)):
+                        rc = ctx.lib.svo_hip_tracker_track(trk.h, ptrs[k], C.byref(res), None, None, None, None, None, None, None, None, None)
+                        if rc != 0:
+                            raise RuntimeError("tracker_track failed: %d" % rc)
+                    pose = tuple(float(v) for v in res.T_f_w)
+                    if last_pose[ci] is not None and pose != last_pose[ci]:
+                        raise RuntimeError("camera %d: a pass ended on another pose than the one before" % ci)
+                    last_pose[ci] = pose
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+                try:
+                    start.abort(); done.abort()
+                except Exception:
+                    pass
+                return
+            done.wait()
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(n_cam)]
+        [t.start() for t in ths]
+        start.wait()
+        t0 = time.perf_counter()
+        done.wait()
+        dt = time.perf_counter() - t0
+        [t.join() for t in ths]
+        if errs:
+            raise errs[0]
+        if ref_pose is None:
+            ref_pose = last_pose[0]
+        assert all(p == ref_pose for p in last_pose), "a camera's result depends on its company"
+        frames = n_cam * repeats * (len(imgs) - 1)
+        out[str(n_cam)] = frames / dt
+        for t in trks:
+            t.destroy()
+        for c in ctxs:
+            c.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--min-level", type=int, default=2)     # the shipping default: L4 -> L2
     ap.add_argument("--tracker-only", action="store_true")
+    ap.add_argument("--cameras", action="store_true", help="only the multi-camera figure (1 / 2 / 4 / 8 trackers on as many host threads)")
     args = ap.parse_args()
+    if args.cameras:
+        seq = tc.make_sequence(n_frames=args.frames)
+        print(json.dumps({"chain_frames_per_s_by_cameras": multi_camera(seq, args.min_level), "min_level": args.min_level}))
+        return
     if args.tracker_only:
         seq = tc.make_sequence(n_frames=args.frames)
         print(json.dumps({"hip_tracker": tracker_leg(hip.Context(0), seq, args.min_level)}))
