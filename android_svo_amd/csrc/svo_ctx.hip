@@ -49,13 +49,15 @@ __global__ void half_sample_kernel(const uint8_t* __restrict__ in, int w, int h,
 // (64 x 16 tiles, i.e. 64-byte requests, read the image at a third of the link rate).
 constexpr int PYR_STRIP_MAX_W = 2048;
 __global__ __launch_bounds__(256) void pyramid_strip_kernel(uint8_t* __restrict__ base, int w, int h, int n_levels, size_t o1, size_t o2,
-                                                            size_t o3, size_t o4, size_t slot_stride, const uint8_t* __restrict__ src0) {
+                                                            size_t o3, size_t o4, size_t slot_stride, const uint8_t* __restrict__ src0,
+                                                            size_t src_stride = 0) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* l0 = lds;                      // [16][w]
   uint8_t* l1 = l0 + 16 * w;              // [8][w/2]
   uint8_t* l2 = l1 + 4 * w;               // [4][w/4]
   uint8_t* l3 = l2 + w;                   // [2][w/8]
   base += (size_t)blockIdx.z * slot_stride;
+  if (src0) src0 += (size_t)blockIdx.z * src_stride;       // (a tracker group: the cameras' page-locked images lie src_stride apart)
   const int t = threadIdx.x, nt = blockDim.x;
   const int ty = blockIdx.x;
   {
@@ -105,14 +107,17 @@ __global__ __launch_bounds__(256) void pyramid_strip_kernel(uint8_t* __restrict_
 }  // namespace
 
 // levels 1.. of n_slots pyramids starting at first_slot, from their level 0 (already in place), on the context stream
-// (level0_mapped: device address of a page-locked host image to take level 0 from -- one slot only; null: level 0 is in place)
-int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* level0_mapped) {
+// (level0_mapped: device address of a page-locked host image to take level 0 from -- slot k's image at level0_mapped + k *
+// mapped_stride; null: level 0 is in place)
+int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* level0_mapped, size_t mapped_stride) {
   svo_hip_ctx* ctx = pyr->ctx;
   uint8_t* base = pyr->base + (size_t)first_slot * pyr->pyr_bytes;
   const bool tiled = pyr->width % 16 == 0 && pyr->width <= PYR_STRIP_MAX_W && pyr->height % 16 == 0 && pyr->n_levels <= 5 && pyr->n_levels >= 2 &&
                      (pyr->pyr_bytes % 16) == 0;
   if (level0_mapped && !tiled) {       // shapes the tile kernel does not take: an ordinary copy first
-    SVO_CHECK_HIP(ctx, hipMemcpyAsync(base, level0_mapped, (size_t)pyr->width * pyr->height, hipMemcpyDefault, ctx->stream));
+    for (int k = 0; k < n_slots; ++k)
+      SVO_CHECK_HIP(ctx, hipMemcpyAsync(base + (size_t)k * pyr->pyr_bytes, level0_mapped + (size_t)k * mapped_stride, (size_t)pyr->width * pyr->height,
+                                        hipMemcpyDefault, ctx->stream));
     level0_mapped = nullptr;
   }
   if (pyr->n_levels < 2) return SVO_HIP_OK;
@@ -121,7 +126,7 @@ int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots, 
                  o4 = pyr->n_levels > 4 ? pyr->level_offset[4] : 0;
     const size_t lds = (size_t)16 * pyr->width + 4 * pyr->width + pyr->width + pyr->width / 4 + 64;
     hipLaunchKernelGGL(pyramid_strip_kernel, dim3(pyr->height / 16, 1, n_slots), dim3(256), lds, ctx->stream, base, pyr->width, pyr->height,
-                       pyr->n_levels, o1, o2, o3, o4, pyr->pyr_bytes, level0_mapped);
+                       pyr->n_levels, o1, o2, o3, o4, pyr->pyr_bytes, level0_mapped, mapped_stride);
     SVO_CHECK_HIP(ctx, hipGetLastError());
     return SVO_HIP_OK;
   }
@@ -355,7 +360,7 @@ int svo_hip_pyramid_upload_level0_and_build(svo_hip_pyramid* pyr, int slot, cons
   SVO_REQUIRE(ctx, slot >= 0 && slot < pyr->batch);
   uint8_t* base = pyr->base + (size_t)slot * pyr->pyr_bytes;
   SVO_CHECK_HIP(ctx, hipMemcpyAsync(base, level0, (size_t)pyr->width * pyr->height, hipMemcpyHostToDevice, ctx->stream));
-  return svo_pyramid_build_levels(pyr, slot, 1, nullptr);
+  return svo_pyramid_build_levels(pyr, slot, 1, nullptr, 0);
 }
 
 int svo_hip_pyramid_upload_level0_batch_and_build(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* level0_packed) {
@@ -366,7 +371,7 @@ int svo_hip_pyramid_upload_level0_batch_and_build(svo_hip_pyramid* pyr, int firs
   const size_t l0 = (size_t)pyr->width * pyr->height;
   // n_slots level-0 images, back to back on the host, into their slots (one strided transfer)
   SVO_CHECK_HIP(ctx, hipMemcpy2DAsync(base, pyr->pyr_bytes, level0_packed, l0, l0, (size_t)n_slots, hipMemcpyHostToDevice, ctx->stream));
-  return svo_pyramid_build_levels(pyr, first_slot, n_slots, nullptr);
+  return svo_pyramid_build_levels(pyr, first_slot, n_slots, nullptr, 0);
 }
 
 int svo_hip_pyramid_download_level(svo_hip_pyramid* pyr, int slot, int level, uint8_t* out_host) {

@@ -848,6 +848,31 @@ __global__ __launch_bounds__(ALIGN_BLOCK) void df_align_kernel(DfFrame fr, const
   df_align_quad<ONE_D>(fr, cur_pyr, n_pad, pwb_t, recs, i, i < n);
 }
 
+// ---- the warp / search and alignment stages over the candidates of SEVERAL cameras (svo_hip_tracker_group): camera c's
+// records are [c * cap, c * cap + n_c) of one record array (cap a multiple of the 16 items a block takes, so a block never
+// straddles two cameras), n_c = counters[c * counter_stride] as the camera's planning kernel left it, its current image is
+// slot c of the frame pyramid batch; the reference keyframe of an item is the slot in its record, as always.
+__global__ __launch_bounds__(256, 7) void df_search_cams_kernel(
+    DfFrame fr, const uint8_t* __restrict__ ref_base, size_t ref_pyr_bytes, const uint8_t* __restrict__ cur_base, size_t cur_pyr_bytes,
+    int cap, const int* __restrict__ counters, int counter_stride, const int32_t* __restrict__ level, SeedRec* __restrict__ recs,
+    uint32_t* __restrict__ pwb_t, int n_pad) {
+  const int c = (int)(((long long)blockIdx.x * SEEDS_PER_BLOCK) / cap);
+  int n_c = counters[(size_t)c * counter_stride];
+  n_c = n_c < cap ? n_c : cap;
+  df_search_block(fr, ref_base, ref_pyr_bytes, cur_base + (size_t)c * cur_pyr_bytes, c * cap + n_c, level, recs, pwb_t, n_pad, blockIdx.x);
+}
+
+template <bool ONE_D>
+__global__ __launch_bounds__(ALIGN_BLOCK) void df_align_cams_kernel(DfFrame fr, const uint8_t* __restrict__ cur_base, size_t cur_pyr_bytes, int cap,
+                                                                    const int* __restrict__ counters, int counter_stride, int n_pad,
+                                                                    const uint32_t* __restrict__ pwb_t, SeedRec* __restrict__ recs) {
+  const int i = blockIdx.x * ALIGN_PATCHES + (threadIdx.x >> 2);
+  const int c = (int)(((long long)blockIdx.x * ALIGN_PATCHES) / cap);
+  int n_c = counters[(size_t)c * counter_stride];
+  n_c = n_c < cap ? n_c : cap;
+  df_align_quad<ONE_D>(fr, cur_base + (size_t)c * cur_pyr_bytes, n_pad, pwb_t, recs, i, i < c * cap + n_c);
+}
+
 // EVENTS (device-resident seed batches, svo_hip_seed_batch_*): the kernel also counts, per block, the seeds whose outcome
 // the HOST has to hear about -- converged and NaN seeds (callback / erase, depth_filter.cpp:310-337) and, on keyframes
 // (report_updated), every updated seed (its px_cur marks the detector grid, :302-306) -- clears their `alive` flag where
@@ -1461,6 +1486,34 @@ int svo_match_stages(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip
   return SVO_HIP_OK;
 }
 
+// the same stages for n_cams cameras in one set of launches (svo_hip_tracker_group_track): see df_search_cams_kernel
+int svo_match_stages_cams(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, const svo_hip_camera* cam, int n_cams,
+                          int cap, const int* counters_dev, int counter_stride, const int32_t* level_ref_dev, svo_dev::SeedRec* recs,
+                          uint32_t* pwb_t, int n_pad, int n_pyr_levels, int align_max_iter, bool edgelets) {
+  if (!ctx || !ref || !cur || !cam || !recs || !pwb_t || !level_ref_dev || !counters_dev) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, n_cams >= 1 && n_cams <= cur->batch && cap > 0 && cap % SEEDS_PER_BLOCK == 0 && cap % ALIGN_PATCHES == 0 && counter_stride >= 1);
+  SVO_REQUIRE(ctx, n_pad >= n_cams * cap);
+  DfFrame fr;
+  memset(&fr, 0, sizeof(fr));
+  fr.cam = svo_make_cam(*cam);
+  for (int l = 0; l < ref->n_levels; ++l) fr.ref_level_off[l] = ref->level_offset[l];
+  for (int l = 0; l < cur->n_levels; ++l) fr.cur_level_off[l] = cur->level_offset[l];
+  fr.n_pyr_levels = n_pyr_levels; fr.align_max_iter = align_max_iter; fr.keep_px_on_failure = 1;
+  const int n_all = n_cams * cap;
+  hipLaunchKernelGGL(df_search_cams_kernel, dim3(n_all / SEEDS_PER_BLOCK), dim3(256), 0, ctx->stream, fr, ref->base, ref->pyr_bytes, cur->base,
+                     cur->pyr_bytes, cap, counters_dev, counter_stride, level_ref_dev, recs, pwb_t, n_pad);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(df_align_cams_kernel<false>, dim3(n_all / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr, cur->base, cur->pyr_bytes, cap,
+                     counters_dev, counter_stride, n_pad, pwb_t, recs);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  if (edgelets) {
+    hipLaunchKernelGGL(df_align_cams_kernel<true>, dim3(n_all / ALIGN_PATCHES), dim3(ALIGN_BLOCK), 0, ctx->stream, fr, cur->base, cur->pyr_bytes, cap,
+                       counters_dev, counter_stride, n_pad, pwb_t, recs);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+  }
+  return SVO_HIP_OK;
+}
+
 // svo_hip_match_direct_batch_dev with, optionally, the pose of the current frame and the number of items left on the
 // device by earlier kernels of the stream (T_cur_w_dev / n_dev non-null: the tracking chain of svo_track.hip; n is then
 // the capacity the launches cover)
@@ -1490,7 +1543,7 @@ int svo_match_direct_internal(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, cons
   if (T_cur_w) memcpy(mf.T_cur_w, T_cur_w, sizeof(double) * 7);
   else memset(mf.T_cur_w, 0, sizeof(double) * 7);
   mf.n_pyr_levels = n_pyr_levels;
-  mf.n_kf = n_kf; mf.n_ref_levels = ref->n_levels;
+  mf.n_kf = n_kf; mf.n_ref_levels = ref->n_levels; mf.slot_base = 0;
   DfFrame fr;
   memset(&fr, 0, sizeof(fr));
   fr.cam = mf.cam;

@@ -135,7 +135,7 @@ inline int svo_ctx_host_staging(svo_hip_ctx* ctx, size_t need, char** out) {
   return SVO_HIP_OK;
 }
 
-int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* level0_mapped);    // levels 1.. from level 0 (svo_ctx.hip)
+int svo_pyramid_build_levels(svo_hip_pyramid* pyr, int first_slot, int n_slots, const uint8_t* level0_mapped, size_t mapped_stride);    // levels 1.. from level 0 (svo_ctx.hip)
 
 inline svo_dev::Cam svo_make_cam(const svo_hip_camera& c) {
   svo_dev::Cam d;
@@ -177,18 +177,19 @@ struct FrameState {
 };
 }  // namespace svo_dev
 
-// internal entries of svo_sia.hip for the device-resident tracking chain (svo_track.hip): slot 0 of the solver is filled
+// internal entries of svo_sia.hip for the device-resident tracking chain (svo_track.hip): a slot of the solver is filled
 // by a kernel from device arrays -- the previous frame's features (pixel, bearing, map point index or -1) and the point
 // table -- with ref_frame->T_f_w_ = cur_frame->T_f_w_ = *T_last_w_dev (frame_handler_mono.cpp:175); n_feat_host is the
 // feature count the host knows from the previous frame's result (it chooses the kernel shape; the kernel itself reads
 // the count the device wrote).  The solve leaves its result in the device record svo_sia_state_dev returns.
 struct svo_hip_sia;
-int svo_sia_prepare_from_device(svo_hip_sia* s, const svo_hip_camera* cam, int n_feat_host, const int* n_feat_dev,
+// (slot: the solver slot of the caller -- 0 for a lone tracker, the camera's index inside a tracker group)
+int svo_sia_prepare_from_device(svo_hip_sia* s, int slot, const svo_hip_camera* cam, int n_feat_host, const int* n_feat_dev,
                                 const double* T_last_w_dev, const double* px_dev, const double* f_dev, const int32_t* point_dev,
                                 const double* pt_pos_dev);
-const svo_dev::FrameState* svo_sia_state_dev(const svo_hip_sia* s);
-int svo_sia_slot0_arrays(svo_hip_sia* s, svo_dev::FrameConst** fc, double** px, double** f, double** pos, uint8_t** has_point, int* max_n);
-int svo_sia_note_device_slot0(svo_hip_sia* s, const svo_hip_camera* cam, int n_feat_host);
+const svo_dev::FrameState* svo_sia_state_dev(const svo_hip_sia* s, int slot);
+int svo_sia_slot_arrays(svo_hip_sia* s, int slot, svo_dev::FrameConst** fc, double** px, double** f, double** pos, uint8_t** has_point, int* max_n);
+int svo_sia_note_device_slot(svo_hip_sia* s, int slot, const svo_hip_camera* cam, int n_feat_host);
 
 // svo_depth.hip: Matcher::findMatchDirect over n items (svo_hip_match_direct_batch_dev) with, optionally, the current
 // frame's pose and the item count read from device memory
@@ -204,6 +205,14 @@ int svo_match_scratch(svo_hip_ctx* ctx, int n_cap, svo_dev::SeedRec** recs, uint
 int svo_match_stages(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, int cur_slot, const svo_hip_camera* cam,
                      int n_cap, const int* n_dev, const int32_t* level_ref_dev, svo_dev::SeedRec* recs, uint32_t* pwb_t, int n_pad,
                      int n_pyr_levels, int align_max_iter, bool edgelets);
+int svo_match_stages_cams(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, const svo_hip_pyramid* cur, const svo_hip_camera* cam, int n_cams,
+                          int cap, const int* counters_dev, int counter_stride, const int32_t* level_ref_dev, svo_dev::SeedRec* recs,
+                          uint32_t* pwb_t, int n_pad, int n_pyr_levels, int align_max_iter, bool edgelets);
+// svo_refine.hip: svo_hip_pose_optimize_batch_dev with the counts / poses of the batch n_feat_stride ints / T_stride doubles apart
+int svo_pose_optimize_batch_strided(svo_hip_ctx* ctx, int batch, int max_n, const int32_t* n_feat_dev, int n_feat_stride,
+                                    const double* T_f_w_dev, int T_stride, const double* f_dev, const double* pos_dev,
+                                    const int32_t* level_dev, uint8_t* has_point_dev, double error_multiplier2,
+                                    double reproj_thresh, int n_iter, svo_hip_pose_opt_result* results_dev);
 
 // ---- multi-GPU exchange (svo_comm.hip): RCCL over xGMI, or a host-staged shared-memory transport for bring-up / tests.
 // Both all-reduce in place on the communicator's context stream and give every rank bitwise the same result.

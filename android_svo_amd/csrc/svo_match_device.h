@@ -29,6 +29,8 @@ struct MdFrame {
   double T_cur_w[7];
   int n_pyr_levels;
   int n_kf, n_ref_levels;      // valid ranges of the caller's kf_slot / level values
+  int slot_base;               // added to an item's slot in its record: where the caller's keyframe slots start in the pyramid batch
+                               // the warp stage reads (a tracker group keeps all cameras' keyframes in one batch); 0 otherwise
 };
 
 // a record no stage touches (items past the count, candidates the matcher rejects at once)
@@ -49,7 +51,7 @@ SVO_DEV SeedRec md_geometry_item(const MdFrame& fr, const double* __restrict__ T
   const Cam& cam = fr.cam;
   SeedRec rc = md_dead_record();
   rc.uv0[0] = px_cur[0]; rc.uv0[1] = px_cur[1];
-  rc.pad = slot;
+  rc.pad = slot + fr.slot_base;
   // isInFrame(px.cast<int>()/(1<<level), halfpatch_size_+2, level) (:164-166)
   // a slot or level outside the pyramids the caller handed over is rejected like a failed frame test (never indexed)
   const bool in_range = slot >= 0 && slot < fr.n_kf && level_ref >= 0 && level_ref < fr.n_ref_levels;

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
     int max_n, const int* __restrict__ n_feat, const double* __restrict__ T_in, const double* __restrict__ f,
     const double* __restrict__ pos, const int* __restrict__ level, uint8_t* __restrict__ has_point, double em,
     double reproj_thresh, int n_iter, float* __restrict__ err_ws, double* __restrict__ sq_init_ws,
-    double* __restrict__ sq_final_ws, PoseOptOut* __restrict__ out) {
+    double* __restrict__ sq_final_ws, PoseOptOut* __restrict__ out, int n_feat_stride = 1, int T_stride = 7) {
   __shared__ int hist[256];
   __shared__ __attribute__((aligned(16))) unsigned long long s_keys[2][PR_THREADS];
   __shared__ unsigned s_cnt[4][PR_THREADS];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
   __shared__ unsigned s_count;
 
   const int b = blockIdx.x;
-  const int n = n_feat[b];
+  const int n = n_feat[(size_t)b * n_feat_stride];      // (strides: a tracker group reads the counts / poses where its other kernels left them)
   const size_t base = (size_t)b * max_n;
   const double* fb = f + 3 * base;
   const double* pb = pos + 3 * base;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(
   };
 
   if (threadIdx.x == 0) {
-    for (int i = 0; i < 7; ++i) { s_T[i] = T_in[7 * b + i]; s_Told[i] = s_T[i]; }            // :45
+    for (int i = 0; i < 7; ++i) { s_T[i] = T_in[(size_t)T_stride * b + i]; s_Told[i] = s_T[i]; }            // :45
     s_chi2 = 0.0; s_done = 0; s_iters = 0; s_count = 0;
   }
   if (lane >= 28 && lane < 32) red[wave][lane] = 0.0;
@@ -563,6 +563,32 @@ __global__ void ldlt6_batch_kernel(int n, const double* __restrict__ H, const do
 }
 
 }  // namespace
+
+// the batch entry with the counts n_feat_stride ints and the poses T_stride doubles apart (svo_track.hip: a tracker group's
+// cameras keep them in their counter blocks and solver records)
+int svo_pose_optimize_batch_strided(svo_hip_ctx* ctx, int batch, int max_n, const int32_t* n_feat_dev, int n_feat_stride,
+                                    const double* T_f_w_dev, int T_stride, const double* f_dev, const double* pos_dev,
+                                    const int32_t* level_dev, uint8_t* has_point_dev, double error_multiplier2,
+                                    double reproj_thresh, int n_iter, svo_hip_pose_opt_result* results_dev) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, batch > 0 && max_n > 0 && n_iter >= 0 && n_feat_stride >= 1 && T_stride >= 7);
+  SVO_REQUIRE(ctx, n_feat_dev && T_f_w_dev && f_dev && pos_dev && level_dev && has_point_dev && results_dev);
+  SVO_REQUIRE(ctx, error_multiplier2 > 0.0);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t per = (size_t)batch * max_n;
+  void* ws = nullptr;
+  const int rc = svo_ctx_scratch(ctx, per * (sizeof(float) + 2 * sizeof(double)) + 64, &ws);
+  if (rc != SVO_HIP_OK) return rc;
+  double* sq_init = reinterpret_cast<double*>(ws);
+  double* sq_final = sq_init + per;
+  float* err = reinterpret_cast<float*>(sq_final + per);
+  hipLaunchKernelGGL(pose_refine_kernel, dim3(batch), dim3(PR_THREADS), 0, ctx->stream, max_n, n_feat_dev, T_f_w_dev, f_dev,
+                     pos_dev, level_dev, has_point_dev, error_multiplier2, reproj_thresh, n_iter, err, sq_init, sq_final,
+                     reinterpret_cast<PoseOptOut*>(results_dev), n_feat_stride, T_stride);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
+}
+
 
 extern "C" {
 

@@ -1969,37 +1969,41 @@ int run_fused(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) {
 
 }  // namespace
 
-int svo_sia_prepare_from_device(svo_hip_sia* s, const svo_hip_camera* cam, int n_feat_host, const int* n_feat_dev,
+// (slot: the solver slot of the caller -- 0 for a lone tracker, the camera's index inside a tracker group)
+int svo_sia_prepare_from_device(svo_hip_sia* s, int slot, const svo_hip_camera* cam, int n_feat_host, const int* n_feat_dev,
                                 const double* T_last_w_dev, const double* px_dev, const double* f_dev, const int32_t* point_dev,
                                 const double* pt_pos_dev) {
   if (!s || !cam) return SVO_HIP_ERR_INVALID;
   svo_hip_ctx* ctx = s->ctx;
+  SVO_REQUIRE(ctx, slot >= 0 && slot < s->batch);
   SVO_REQUIRE(ctx, n_feat_host >= 0 && n_feat_host <= s->max_n && n_feat_dev && T_last_w_dev && px_dev && f_dev && point_dev && pt_pos_dev);
-  hipLaunchKernelGGL(sia_gather_kernel, dim3(1), dim3(256), 0, ctx->stream, s->fc, svo_make_cam(*cam), n_feat_dev, s->max_n, T_last_w_dev,
-                     px_dev, f_dev, point_dev, pt_pos_dev, s->px, s->f, s->pos, s->has_point);
+  const size_t o = (size_t)slot * s->max_n;
+  hipLaunchKernelGGL(sia_gather_kernel, dim3(1), dim3(256), 0, ctx->stream, s->fc + slot, svo_make_cam(*cam), n_feat_dev, s->max_n, T_last_w_dev,
+                     px_dev, f_dev, point_dev, pt_pos_dev, s->px + 2 * o, s->f + 3 * o, s->pos + 3 * o, s->has_point + o);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   // the host mirror only steers the launch (kernel shape by the feature count); the device record is authoritative
-  s->h_fc[0].n_feat = n_feat_host;
-  s->h_fc[0].cam = svo_make_cam(*cam);
+  s->h_fc[slot].n_feat = n_feat_host;
+  s->h_fc[slot].cam = svo_make_cam(*cam);
   s->fc_dirty = false;
   return SVO_HIP_OK;
 }
 
-const svo_dev::FrameState* svo_sia_state_dev(const svo_hip_sia* s) { return s ? s->st : nullptr; }
+const svo_dev::FrameState* svo_sia_state_dev(const svo_hip_sia* s, int slot) { return s ? s->st + slot : nullptr; }
 
-// slot 0's input arrays, for a caller whose own kernel fills them (the hand-over kernel of svo_track.hip writes the next
-// frame's reference features there directly); svo_sia_note_device_slot0 then tells the host mirror what the device holds
-int svo_sia_slot0_arrays(svo_hip_sia* s, svo_dev::FrameConst** fc, double** px, double** f, double** pos, uint8_t** has_point, int* max_n) {
-  if (!s) return SVO_HIP_ERR_INVALID;
-  *fc = s->fc; *px = s->px; *f = s->f; *pos = s->pos; *has_point = s->has_point; *max_n = s->max_n;
+// a slot's input arrays, for a caller whose own kernel fills them (the hand-over kernel of svo_track.hip writes the next
+// frame's reference features there directly); svo_sia_note_device_slot then tells the host mirror what the device holds
+int svo_sia_slot_arrays(svo_hip_sia* s, int slot, svo_dev::FrameConst** fc, double** px, double** f, double** pos, uint8_t** has_point, int* max_n) {
+  if (!s || slot < 0 || slot >= s->batch) return SVO_HIP_ERR_INVALID;
+  const size_t o = (size_t)slot * s->max_n;
+  *fc = s->fc + slot; *px = s->px + 2 * o; *f = s->f + 3 * o; *pos = s->pos + 3 * o; *has_point = s->has_point + o; *max_n = s->max_n;
   return SVO_HIP_OK;
 }
 
-int svo_sia_note_device_slot0(svo_hip_sia* s, const svo_hip_camera* cam, int n_feat_host) {
+int svo_sia_note_device_slot(svo_hip_sia* s, int slot, const svo_hip_camera* cam, int n_feat_host) {
   if (!s || !cam) return SVO_HIP_ERR_INVALID;
-  SVO_REQUIRE(s->ctx, n_feat_host >= 0 && n_feat_host <= s->max_n);
-  s->h_fc[0].n_feat = n_feat_host;
-  s->h_fc[0].cam = svo_make_cam(*cam);
+  SVO_REQUIRE(s->ctx, slot >= 0 && slot < s->batch && n_feat_host >= 0 && n_feat_host <= s->max_n);
+  s->h_fc[slot].n_feat = n_feat_host;
+  s->h_fc[slot].cam = svo_make_cam(*cam);
   s->fc_dirty = false;
   return SVO_HIP_OK;
 }

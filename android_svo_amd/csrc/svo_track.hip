@@ -188,8 +188,8 @@ SVO_DEV void block_exclusive_scan(int* v, int n, int* s_part) {
 
 // ---- Reprojector::reprojectMap up to the cell loop (S/reprojector.cpp:72-146) + the per-candidate choice of the reference
 // feature (Point::getCloseViewObs, the first statement of Matcher::findMatchDirect).  One workgroup.
-__global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan pl, MdFrame mf, const double* __restrict__ T_slot_w,
-                                                               SeedRec* __restrict__ recs, const FrameState* __restrict__ sia_state) {
+SVO_DEV void trk_plan_body(const TrkMap& m, const TrkPlan& pl, MdFrame mf, const double* __restrict__ T_slot_w,
+                           SeedRec* __restrict__ recs, const FrameState* __restrict__ sia_state) {
   const Cam cam = mf.cam;
   __shared__ int s_part[TRK_THREADS];
   __shared__ int s_sel[TRK_MAX_SEL], s_seq_base[TRK_MAX_SEL + 1], s_ftr_off[TRK_MAX_SEL], s_ftr_cnt[TRK_MAX_SEL];
@@ -378,9 +378,9 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan
 // ---- the cell loop of Reprojector::reprojectMap (S/reprojector.cpp:149-166) with reprojectCell (:180-241) replayed over
 // the batch results: per cell the first successful candidate wins, the loop stops after the cell that takes n_matches
 // beyond max_fts; point bookkeeping (:202-215), the frame's new features (:217-231) and the inputs of the pose refinement.
-__global__ __launch_bounds__(TRK_THREADS) void trk_replay_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, Cam cam, const FrameState* __restrict__ sia_state,
-                                                                 const SeedRec* __restrict__ recs, int* __restrict__ cell_winner,
-                                                                 int* __restrict__ cell_cum, int max_fts, int quality_min_fts) {
+SVO_DEV void trk_replay_body(const TrkMap& m, const TrkPlan& pl, const TrkFeat& ft, const Cam& cam, const FrameState* __restrict__ sia_state,
+                             const SeedRec* __restrict__ recs, int* __restrict__ cell_winner,
+                             int* __restrict__ cell_cum, int max_fts, int quality_min_fts) {
   __shared__ int s_part[TRK_THREADS];
   __shared__ int s_cut, s_changed;
   __shared__ unsigned long long s_trials;
@@ -582,12 +582,13 @@ __global__ __launch_bounds__(256) void trk_structure_kernel(TrkMap m, double* __
 }
 
 // ---- last_frame_ = new_frame_ (frame_handler_mono.cpp:91) and the result block.  One workgroup.
-__global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, TrkLast last, Cam cam, const FrameState* __restrict__ sia_state,
-                                                         const svo_hip_pose_opt_result* __restrict__ po, svo_hip_track_result* __restrict__ res,
-                                                         double* __restrict__ out_px, double* __restrict__ out_f, int* __restrict__ out_level,
-                                                         int* __restrict__ out_point, uint8_t* __restrict__ out_edgelet, double* __restrict__ out_grad,
-                                                         int* __restrict__ out_pt_type, int* __restrict__ out_pt_failed, int* __restrict__ out_pt_succeeded,
-                                                         unsigned long long* __restrict__ done_flag, unsigned long long seq) {
+SVO_DEV void trk_finish_body(const TrkMap& m, const TrkPlan& pl, const TrkFeat& ft, const TrkLast& last, const Cam& cam,
+                             const FrameState* __restrict__ sia_state,
+                             const svo_hip_pose_opt_result* __restrict__ po, svo_hip_track_result* __restrict__ res,
+                             double* __restrict__ out_px, double* __restrict__ out_f, int* __restrict__ out_level,
+                             int* __restrict__ out_point, uint8_t* __restrict__ out_edgelet, double* __restrict__ out_grad,
+                             int* __restrict__ out_pt_type, int* __restrict__ out_pt_failed, int* __restrict__ out_pt_succeeded,
+                             unsigned long long* __restrict__ done_flag, unsigned long long seq) {
   __shared__ double s_Tnew[7];
   const int t = threadIdx.x, nt = blockDim.x;
   const int n_feat = pl.counters[4];
@@ -657,6 +658,63 @@ __global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, T
   if (t == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- the kernels of one camera's chain, and the same bodies for the cameras of a tracker group: workgroup c of a launch takes
+// camera c's arguments from a table in device memory (svo_hip_tracker_group_track rewrites it every call)
+struct TrkCamArgs {
+  TrkMap m;
+  TrkPlan pl;
+  TrkFeat ft;
+  TrkLast last;
+  MdFrame mf;
+  const double* T_slot_w;
+  SeedRec* recs;
+  const FrameState* sia_state;
+  int *cell_winner, *cell_cum;
+  const svo_hip_pose_opt_result* po;
+  char* res;                           // the camera's result block (device address of page-locked memory)
+  size_t o_px, o_f, o_level, o_point, o_edge, o_grad, o_pt, o_flag;
+  int n_points_cap;                    // (unused by the kernels; keeps the layout self-describing)
+  unsigned long long seq;
+};
+
+__global__ __launch_bounds__(TRK_THREADS) void trk_plan_kernel(TrkMap m, TrkPlan pl, MdFrame mf, const double* __restrict__ T_slot_w,
+                                                               SeedRec* __restrict__ recs, const FrameState* __restrict__ sia_state) {
+  trk_plan_body(m, pl, mf, T_slot_w, recs, sia_state);
+}
+__global__ __launch_bounds__(TRK_THREADS) void trk_plan_cams_kernel(const TrkCamArgs* __restrict__ args) {
+  const TrkCamArgs& a = args[blockIdx.x];
+  trk_plan_body(a.m, a.pl, a.mf, a.T_slot_w, a.recs, a.sia_state);
+}
+
+__global__ __launch_bounds__(TRK_THREADS) void trk_replay_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, Cam cam, const FrameState* __restrict__ sia_state,
+                                                                 const SeedRec* __restrict__ recs, int* __restrict__ cell_winner,
+                                                                 int* __restrict__ cell_cum, int max_fts, int quality_min_fts) {
+  trk_replay_body(m, pl, ft, cam, sia_state, recs, cell_winner, cell_cum, max_fts, quality_min_fts);
+}
+__global__ __launch_bounds__(TRK_THREADS) void trk_replay_cams_kernel(const TrkCamArgs* __restrict__ args, int max_fts, int quality_min_fts) {
+  const TrkCamArgs& a = args[blockIdx.x];
+  trk_replay_body(a.m, a.pl, a.ft, a.mf.cam, a.sia_state, a.recs, a.cell_winner, a.cell_cum, max_fts, quality_min_fts);
+}
+
+SVO_DEV void trk_finish_from_args(const TrkCamArgs& a) {
+  char* rd = a.res;
+  int* pt = reinterpret_cast<int*>(rd + a.o_pt);
+  trk_finish_body(a.m, a.pl, a.ft, a.last, a.mf.cam, a.sia_state, a.po, reinterpret_cast<svo_hip_track_result*>(rd),
+                  reinterpret_cast<double*>(rd + a.o_px), reinterpret_cast<double*>(rd + a.o_f), reinterpret_cast<int*>(rd + a.o_level),
+                  reinterpret_cast<int*>(rd + a.o_point), reinterpret_cast<uint8_t*>(rd + a.o_edge), reinterpret_cast<double*>(rd + a.o_grad),
+                  pt, pt + a.m.n_points, pt + 2 * (size_t)a.m.n_points, reinterpret_cast<unsigned long long*>(rd + a.o_flag), a.seq);
+}
+__global__ __launch_bounds__(256) void trk_finish_kernel(TrkMap m, TrkPlan pl, TrkFeat ft, TrkLast last, Cam cam, const FrameState* __restrict__ sia_state,
+                                                         const svo_hip_pose_opt_result* __restrict__ po, svo_hip_track_result* __restrict__ res,
+                                                         double* __restrict__ out_px, double* __restrict__ out_f, int* __restrict__ out_level,
+                                                         int* __restrict__ out_point, uint8_t* __restrict__ out_edgelet, double* __restrict__ out_grad,
+                                                         int* __restrict__ out_pt_type, int* __restrict__ out_pt_failed, int* __restrict__ out_pt_succeeded,
+                                                         unsigned long long* __restrict__ done_flag, unsigned long long seq) {
+  trk_finish_body(m, pl, ft, last, cam, sia_state, po, res, out_px, out_f, out_level, out_point, out_edgelet, out_grad, out_pt_type, out_pt_failed,
+                  out_pt_succeeded, done_flag, seq);
+}
+__global__ __launch_bounds__(256) void trk_finish_cams_kernel(const TrkCamArgs* __restrict__ args) { trk_finish_from_args(args[blockIdx.x]); }
+
 // Point::pos_ of n points after the host optimised them: one staged block in, one launch
 __global__ void trk_scatter_positions_kernel(int n, const int* __restrict__ idx, const double* __restrict__ pos, double* __restrict__ pt_pos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -675,15 +733,40 @@ int trk_alloc(svo_hip_ctx* ctx, T** p, size_t count) {
 
 }  // namespace
 
+// What the cameras of a tracker group share (a lone tracker is a group of one): the pyramid batches, the SparseImgAlign solver
+// (camera c = slot c), the arrays the batched stages index by camera with a fixed stride, and the page-locked image block.
+struct svo_hip_tracker_shared {
+  svo_hip_ctx* ctx = nullptr;
+  int n_cams = 1;
+  svo_hip_pyramid* kf_pyr = nullptr;        // n_cams x max_keyframes slots: camera c's keyframe slot s is slot c * max_keyframes + s
+  svo_hip_pyramid* frame_pyr[2] = {nullptr, nullptr};   // n_cams slots each
+  int last_idx = 0;                         // frame_pyr[last_idx] holds the cameras' last frames (they advance together)
+  svo_hip_sia* sia = nullptr;               // batch n_cams
+  uint8_t* img_host = nullptr;              // page-locked, mapped: n_cams images, img_stride apart
+  uint8_t* img_dev = nullptr;
+  size_t img_stride = 0;
+  // [n_cams][...] arrays of the stages that run over all cameras at once
+  int* counters = nullptr;                  // [n_cams][8]
+  int* cand_level_ref = nullptr;            // [n_cams][cap]
+  double *ft_f = nullptr, *ft_pos = nullptr;   // [n_cams][NF][3]
+  int* ft_level = nullptr;                  // [n_cams][NF]
+  uint8_t* ft_has_point = nullptr;          // [n_cams][NF]
+  svo_hip_pose_opt_result* po = nullptr;    // [n_cams]
+  // the group's argument table (TrkCamArgs per camera): page-locked staging + device copy
+  char* args_host = nullptr;
+  char* args_dev = nullptr;
+  std::vector<svo_hip_tracker*> members;
+  std::vector<void*> dev_allocs;
+};
+
 struct svo_hip_tracker {
   svo_hip_ctx* ctx = nullptr;
   svo_hip_camera cam{};
   svo_hip_tracker_config cfg{};
   int n_cells = 0, grid_cols = 0, grid_rows = 0;
-  svo_hip_pyramid* kf_pyr = nullptr;        // max_keyframes slots
-  svo_hip_pyramid* frame_pyr[2] = {nullptr, nullptr};
-  int last_idx = 0;                         // frame_pyr[last_idx] holds the last frame
-  svo_hip_sia* sia = nullptr;
+  svo_hip_tracker_shared* sh = nullptr;     // owned by the tracker itself (a lone tracker) or by its group
+  bool owns_shared = false;
+  int cam_index = 0;                        // this camera's slot in the shared solver / frame pyramids / per-camera arrays
   // map tables
   double *T_kf_w = nullptr, *T_slot_w = nullptr, *pt_pos = nullptr, *obs_px = nullptr, *obs_f = nullptr, *obs_grad = nullptr;
   int *kf_slot = nullptr, *kf_key_point = nullptr, *kf_ftr_offset = nullptr, *kf_ftr_point = nullptr, *pt_type = nullptr, *pt_n_failed = nullptr,
@@ -702,18 +785,18 @@ struct svo_hip_tracker {
   int *cell_winner = nullptr, *cell_cum = nullptr;
   bool need_gather = true;                  // the solver's slot 0 does not hold the last frame yet (a host upload came in between)
   bool any_edgelet = false;                 // the map holds EDGELET reference features (align1D stage needed)
-  svo_hip_pose_opt_result* po = nullptr;
+  svo_hip_pose_opt_result* po = nullptr;    // (its entry of the shared array)
   // result block: [svo_hip_track_result][px][f][level][point][edgelet][grad][pt_type][pt_failed][pt_succeeded]
   char* res_dev = nullptr;                  // device address of res_host
   char* res_host = nullptr;                 // page-locked, mapped into the device: the hand-over kernel writes it directly
   unsigned long long seq = 0;               // frames tracked: the kernel stores it behind the block (o_flag) when the block is complete
   size_t o_flag = 0;
-  uint8_t* img_dev = nullptr;               // device address of img_host
+  uint8_t* img_dev = nullptr;               // device address of img_host (this camera's part of the shared image block)
   char* st_host = nullptr;                  // page-locked result of svo_hip_tracker_optimize_structure: [pos 64 x 3][iters 64][flag]
   char* st_dev = nullptr;
   unsigned long long st_seq = 0;
   size_t o_px = 0, o_f = 0, o_level = 0, o_point = 0, o_edge = 0, o_grad = 0, o_pt = 0, res_bytes = 0;
-  // page-locked staging: one frame image, the map tables
+  // page-locked staging: one frame image (inside the shared block), the map tables
   uint8_t* img_host = nullptr;
   char* map_host = nullptr;
   size_t map_host_bytes = 0;
@@ -751,25 +834,38 @@ int svo_hip_tracker_default_config(svo_hip_tracker_config* c) {
   return SVO_HIP_OK;
 }
 
-int svo_hip_tracker_destroy(svo_hip_tracker* t) {
-  if (!t) return SVO_HIP_ERR_INVALID;
-  svo_hip_ctx* ctx = t->ctx;
-  (void)hipStreamSynchronize(ctx->stream);
-  if (t->sia) svo_hip_sia_destroy(t->sia);
-  if (t->kf_pyr) svo_hip_pyramid_destroy(t->kf_pyr);
-  for (int i = 0; i < 2; ++i) if (t->frame_pyr[i]) svo_hip_pyramid_destroy(t->frame_pyr[i]);
+static void trk_shared_destroy(svo_hip_tracker_shared* sh) {
+  if (!sh) return;
+  if (sh->sia) svo_hip_sia_destroy(sh->sia);
+  if (sh->kf_pyr) svo_hip_pyramid_destroy(sh->kf_pyr);
+  for (int i = 0; i < 2; ++i) if (sh->frame_pyr[i]) svo_hip_pyramid_destroy(sh->frame_pyr[i]);
+  for (void* p : sh->dev_allocs) if (p) (void)hipFree(p);
+  if (sh->img_host) (void)hipHostFree(sh->img_host);
+  if (sh->args_host) (void)hipHostFree(sh->args_host);
+  delete sh;
+}
+
+// one camera's own objects (everything but what svo_hip_tracker_shared holds)
+static void trk_member_destroy(svo_hip_tracker* t) {
   for (void* p : t->dev_allocs) if (p) (void)hipFree(p);
   if (t->res_host) (void)hipHostFree(t->res_host);
-  if (t->img_host) (void)hipHostFree(t->img_host);
   if (t->st_host) (void)hipHostFree(t->st_host);
   if (t->map_host) (void)hipHostFree(t->map_host);
   delete t;
+}
+
+int svo_hip_tracker_destroy(svo_hip_tracker* t) {
+  if (!t) return SVO_HIP_ERR_INVALID;
+  svo_hip_ctx* ctx = t->ctx;
+  if (t->sh && !t->owns_shared) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_destroy", "a camera of a tracker group goes with its group (svo_hip_tracker_group_destroy)");
+  (void)hipStreamSynchronize(ctx->stream);
+  svo_hip_tracker_shared* sh = t->sh;
+  trk_member_destroy(t);
+  trk_shared_destroy(sh);
   return SVO_HIP_OK;
 }
 
-int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const svo_hip_tracker_config* cfg, svo_hip_tracker** out) {
-  if (!ctx || !cam || !cfg || !out) return SVO_HIP_ERR_INVALID;
-  *out = nullptr;
+static int trk_check_config(svo_hip_ctx* ctx, const svo_hip_camera* cam, const svo_hip_tracker_config* cfg) {
   SVO_REQUIRE(ctx, cfg->max_keyframes <= TRK_LDS_KF);
   SVO_REQUIRE(ctx, cfg->max_keyframes >= 1 && cfg->max_points >= 1 && cfg->max_obs >= 1 && cfg->max_kf_features >= 1 && cfg->max_candidates >= 0);
   SVO_REQUIRE(ctx, cfg->max_items >= 1 && cfg->max_frame_features >= 1 && cfg->max_frame_features <= 2816);
@@ -780,25 +876,58 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
   SVO_REQUIRE(ctx, cfg->grid_size >= 1 && cfg->max_fts >= 0 && cfg->reproj_max_n_kfs >= 1 && cfg->reproj_max_n_kfs <= TRK_MAX_SEL);
   SVO_REQUIRE(ctx, cfg->n_pyr_levels >= 1 && cfg->n_pyr_levels <= cfg->n_levels && cfg->align_max_iter >= 0 && cfg->pose_optim_num_iter >= 0);
   SVO_REQUIRE(ctx, cam->width > 16 && cam->height > 16);
-  svo_hip_tracker* t = new (std::nothrow) svo_hip_tracker();
-  if (!t) return SVO_HIP_ERR_NOMEM;
-  t->ctx = ctx; t->cam = *cam; t->cfg = *cfg;
-  t->grid_cols = (cam->width + cfg->grid_size - 1) / cfg->grid_size;        // ceil(width / cell_size) (reprojector.cpp:46-47)
-  t->grid_rows = (cam->height + cfg->grid_size - 1) / cfg->grid_size;
-  t->n_cells = t->grid_cols * t->grid_rows;
+  return SVO_HIP_OK;
+}
+
+// the shared part of n_cams cameras with one camera model and one configuration
+static int trk_shared_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const svo_hip_tracker_config* cfg, int n_cams, svo_hip_tracker_shared** out) {
+  *out = nullptr;
+  svo_hip_tracker_shared* sh = new (std::nothrow) svo_hip_tracker_shared();
+  if (!sh) return SVO_HIP_ERR_NOMEM;
+  sh->ctx = ctx; sh->n_cams = n_cams;
   int rc = SVO_HIP_OK;
   auto A = [&](int r) { if (rc == SVO_HIP_OK) rc = r; };
   auto D = [&](auto** p, size_t count) {
     if (rc != SVO_HIP_OK) return;
     rc = trk_alloc(ctx, p, count);
+    if (rc == SVO_HIP_OK) sh->dev_allocs.push_back((void*)*p);
+  };
+  A(svo_hip_pyramid_create(ctx, cam->width, cam->height, cfg->n_levels, n_cams * cfg->max_keyframes, &sh->kf_pyr));
+  for (int i = 0; i < 2; ++i) A(svo_hip_pyramid_create(ctx, cam->width, cam->height, cfg->n_levels, n_cams, &sh->frame_pyr[i]));
+  A(svo_hip_sia_create(ctx, n_cams, cfg->max_frame_features, &sh->sia));
+  // (the library default, pinned here: the chain's decisions -- matches per cell, frame by frame -- equal the CPU chain's)
+  if (rc == SVO_HIP_OK) rc = svo_hip_sia_set_option(sh->sia, SVO_HIP_SIA_OPT_ARITH, SVO_HIP_SIA_ARITH_EXACT);
+  const size_t N = (size_t)n_cams, C = cfg->max_items, NF = cfg->max_frame_features;
+  D(&sh->counters, N * 8); D(&sh->cand_level_ref, N * C);
+  D(&sh->ft_f, N * NF * 3); D(&sh->ft_pos, N * NF * 3); D(&sh->ft_level, N * NF); D(&sh->ft_has_point, N * NF); D(&sh->po, N);
+  sh->img_stride = ((size_t)cam->width * cam->height + 64 + 255) & ~(size_t)255;
+  if (rc == SVO_HIP_OK && hipHostMalloc((void**)&sh->img_host, N * sh->img_stride, hipHostMallocMapped) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
+  if (rc == SVO_HIP_OK && hipHostGetDevicePointer((void**)&sh->img_dev, sh->img_host, 0) != hipSuccess) rc = SVO_HIP_ERR_DEVICE;
+  if (n_cams > 1) {
+    if (rc == SVO_HIP_OK && hipHostMalloc((void**)&sh->args_host, N * sizeof(TrkCamArgs), hipHostMallocDefault) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
+    D(&sh->args_dev, N * sizeof(TrkCamArgs));
+  }
+  if (rc != SVO_HIP_OK) { trk_shared_destroy(sh); return rc; }
+  *out = sh;
+  return SVO_HIP_OK;
+}
+
+// camera `index` of the shared part: its own map tables, plan scratch, result block
+static int trk_member_create(svo_hip_tracker_shared* sh, int index, const svo_hip_camera* cam, const svo_hip_tracker_config* cfg, svo_hip_tracker** out) {
+  svo_hip_ctx* ctx = sh->ctx;
+  *out = nullptr;
+  svo_hip_tracker* t = new (std::nothrow) svo_hip_tracker();
+  if (!t) return SVO_HIP_ERR_NOMEM;
+  t->ctx = ctx; t->cam = *cam; t->cfg = *cfg; t->sh = sh; t->cam_index = index;
+  t->grid_cols = (cam->width + cfg->grid_size - 1) / cfg->grid_size;        // ceil(width / cell_size) (reprojector.cpp:46-47)
+  t->grid_rows = (cam->height + cfg->grid_size - 1) / cfg->grid_size;
+  t->n_cells = t->grid_cols * t->grid_rows;
+  int rc = SVO_HIP_OK;
+  auto D = [&](auto** p, size_t count) {
+    if (rc != SVO_HIP_OK) return;
+    rc = trk_alloc(ctx, p, count);
     if (rc == SVO_HIP_OK) t->dev_allocs.push_back((void*)*p);
   };
-  A(svo_hip_pyramid_create(ctx, cam->width, cam->height, cfg->n_levels, cfg->max_keyframes, &t->kf_pyr));
-  for (int i = 0; i < 2; ++i) A(svo_hip_pyramid_create(ctx, cam->width, cam->height, cfg->n_levels, 1, &t->frame_pyr[i]));
-  A(svo_hip_sia_create(ctx, 1, cfg->max_frame_features, &t->sia));
-  // one frame at a time gains nothing from the cheaper moment sums (the solve is latency-bound: -1.5 of 51 us for the FAST
-  // level), and with the reference's arithmetic the chain's decisions (matches per cell, frame by frame) equal the CPU chain's
-  if (rc == SVO_HIP_OK) rc = svo_hip_sia_set_option(t->sia, SVO_HIP_SIA_OPT_ARITH, SVO_HIP_SIA_ARITH_EXACT);
   const size_t K = cfg->max_keyframes, P = cfg->max_points, O = cfg->max_obs, F = cfg->max_kf_features, CN = cfg->max_candidates > 0 ? cfg->max_candidates : 1;
   D(&t->T_kf_w, K * 7); D(&t->T_slot_w, K * 7); D(&t->kf_slot, K); D(&t->kf_key_point, K * 5); D(&t->kf_ftr_offset, K + 1); D(&t->kf_ftr_point, F);
   D(&t->pt_pos, P * 3); D(&t->pt_type, P); D(&t->pt_n_failed, P); D(&t->pt_n_succeeded, P); D(&t->pt_unlinked, P); D(&t->pt_obs_offset, P + 1);
@@ -807,13 +936,18 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
   const size_t C = cfg->max_items, NC = t->n_cells;
   pl.cap = cfg->max_items; pl.n_cells = t->n_cells; pl.grid_cols = t->grid_cols; pl.grid_size = cfg->grid_size; pl.max_n_kfs = cfg->reproj_max_n_kfs;
   D(&pl.first_seq, P); D(&pl.item_point, C); D(&pl.item_px, C * 2); D(&pl.item_cell, C); D(&pl.item_key, C);
-  D(&pl.seg, C); D(&pl.seg_key, C); D(&pl.cell_count, NC + 1); D(&pl.cell_fill, NC); D(&pl.counters, 8); D(&pl.cell_offset, NC + 1); D(&pl.overlap_kf, TRK_MAX_SEL);
-  D(&pl.overlap_count, TRK_MAX_SEL); D(&pl.cand_point, C); D(&pl.cand_obs, C); D(&pl.cand_level_ref, C); D(&pl.cand_deleted, C);
-  D(&t->cell_winner, NC + 1); D(&t->cell_cum, NC + 1); D(&t->po, 1);
+  D(&pl.seg, C); D(&pl.seg_key, C); D(&pl.cell_count, NC + 1); D(&pl.cell_fill, NC); D(&pl.cell_offset, NC + 1); D(&pl.overlap_kf, TRK_MAX_SEL);
+  D(&pl.overlap_count, TRK_MAX_SEL); D(&pl.cand_point, C); D(&pl.cand_obs, C); D(&pl.cand_deleted, C);
+  pl.counters = sh->counters + 8 * (size_t)index;                              // (per-camera entries of the shared arrays)
+  pl.cand_level_ref = sh->cand_level_ref + C * (size_t)index;
+  D(&t->cell_winner, NC + 1); D(&t->cell_cum, NC + 1);
+  t->po = sh->po + index;
   const size_t NF = cfg->max_frame_features;
   TrkFeat& ft = t->ft;
   ft.cap = cfg->max_frame_features;
-  D(&ft.px, NF * 2); D(&ft.f, NF * 3); D(&ft.pos, NF * 3); D(&ft.level, NF); D(&ft.point, NF); D(&ft.edgelet, NF); D(&ft.grad, NF * 2); D(&ft.has_point, NF);
+  D(&ft.px, NF * 2); D(&ft.point, NF); D(&ft.edgelet, NF); D(&ft.grad, NF * 2);
+  ft.f = sh->ft_f + 3 * NF * (size_t)index; ft.pos = sh->ft_pos + 3 * NF * (size_t)index;
+  ft.level = sh->ft_level + NF * (size_t)index; ft.has_point = sh->ft_has_point + NF * (size_t)index;
   D(&t->last.n, 1); D(&t->last.T_f_w, 7); D(&t->last.px, NF * 2); D(&t->last.f, NF * 3); D(&t->last.point, NF);
   // result block
   auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -823,8 +957,8 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
   if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->res_host, t->res_bytes, hipHostMallocMapped) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
   if (rc == SVO_HIP_OK && hipHostGetDevicePointer((void**)&t->res_dev, t->res_host, 0) != hipSuccess) rc = SVO_HIP_ERR_DEVICE;
   if (rc == SVO_HIP_OK) memset(t->res_host, 0, t->res_bytes);
-  if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->img_host, (size_t)cam->width * cam->height + 64, hipHostMallocMapped) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
-  if (rc == SVO_HIP_OK && hipHostGetDevicePointer((void**)&t->img_dev, t->img_host, 0) != hipSuccess) rc = SVO_HIP_ERR_DEVICE;
+  t->img_host = sh->img_host + sh->img_stride * (size_t)index;
+  t->img_dev = sh->img_dev + sh->img_stride * (size_t)index;
   const size_t st_bytes = TRK_MAX_STRUCT * (24 + 4) + 64;
   if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->st_host, st_bytes, hipHostMallocMapped) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
   if (rc == SVO_HIP_OK) memset(t->st_host, 0, st_bytes);
@@ -833,9 +967,26 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
   // alignment slack per table
   t->map_host_bytes = K * (56 + 56 + 4 + 20 + 4) + 8 + F * 4 + P * (24 + 12 + 4) + 8 + O * (4 + 16 + 24 + 4 + 1 + 16) + CN * 4 + 32 * 16;
   if (rc == SVO_HIP_OK && hipHostMalloc((void**)&t->map_host, t->map_host_bytes, hipHostMallocDefault) != hipSuccess) rc = SVO_HIP_ERR_NOMEM;
-  if (rc != SVO_HIP_OK) { svo_hip_tracker_destroy(t); return rc; }
+  if (rc != SVO_HIP_OK) { trk_member_destroy(t); return rc; }
   (void)hipMemsetAsync(t->last.n, 0, sizeof(int), ctx->stream);
-  svo_sia_slot0_arrays(t->sia, &t->last.sia_fc, &t->last.sia_px, &t->last.sia_f, &t->last.sia_pos, &t->last.sia_has_point, &t->last.sia_max_n);
+  svo_sia_slot_arrays(sh->sia, index, &t->last.sia_fc, &t->last.sia_px, &t->last.sia_f, &t->last.sia_pos, &t->last.sia_has_point, &t->last.sia_max_n);
+  *out = t;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const svo_hip_tracker_config* cfg, svo_hip_tracker** out) {
+  if (!ctx || !cam || !cfg || !out) return SVO_HIP_ERR_INVALID;
+  *out = nullptr;
+  int rc = trk_check_config(ctx, cam, cfg);
+  if (rc != SVO_HIP_OK) return rc;
+  svo_hip_tracker_shared* sh = nullptr;
+  rc = trk_shared_create(ctx, cam, cfg, 1, &sh);
+  if (rc != SVO_HIP_OK) return rc;
+  svo_hip_tracker* t = nullptr;
+  rc = trk_member_create(sh, 0, cam, cfg, &t);
+  if (rc != SVO_HIP_OK) { trk_shared_destroy(sh); return rc; }
+  t->owns_shared = true;
+  sh->members.push_back(t);
   *out = t;
   return SVO_HIP_OK;
 }
@@ -843,7 +994,7 @@ int svo_hip_tracker_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const sv
 int svo_hip_tracker_upload_keyframe(svo_hip_tracker* t, int slot, const uint8_t* level0) {
   if (!t || !level0) return SVO_HIP_ERR_INVALID;
   SVO_REQUIRE(t->ctx, slot >= 0 && slot < t->cfg.max_keyframes);
-  return svo_hip_pyramid_upload_level0_and_build(t->kf_pyr, slot, level0);
+  return svo_hip_pyramid_upload_level0_and_build(t->sh->kf_pyr, t->cam_index * t->cfg.max_keyframes + slot, level0);
 }
 
 int svo_hip_tracker_keyframe_from_last_frame(svo_hip_tracker* t, int slot) {
@@ -851,8 +1002,10 @@ int svo_hip_tracker_keyframe_from_last_frame(svo_hip_tracker* t, int slot) {
   svo_hip_ctx* ctx = t->ctx;
   SVO_REQUIRE(ctx, slot >= 0 && slot < t->cfg.max_keyframes);
   if (!t->have_last) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_keyframe_from_last_frame", "no frame has been tracked or set yet");
-  const svo_hip_pyramid* src = t->frame_pyr[t->last_idx];
-  return svo_hip_copy_d2d(ctx, t->kf_pyr->base + (size_t)slot * t->kf_pyr->pyr_bytes, src->base, src->pyr_bytes);
+  const svo_hip_pyramid* src = t->sh->frame_pyr[t->sh->last_idx];
+  const svo_hip_pyramid* kf = t->sh->kf_pyr;
+  return svo_hip_copy_d2d(ctx, kf->base + ((size_t)t->cam_index * t->cfg.max_keyframes + slot) * kf->pyr_bytes,
+                          src->base + (size_t)t->cam_index * src->pyr_bytes, src->pyr_bytes);
 }
 
 int svo_hip_tracker_set_map(svo_hip_tracker* t, const svo_hip_tracker_map* mp) {
@@ -1026,10 +1179,12 @@ int svo_hip_tracker_set_last_frame(svo_hip_tracker* t, const uint8_t* level0, in
     SVO_REQUIRE(ctx, point[i] >= -1 && point[i] < (t->have_map ? t->n_points : 0));
     if (point[i] > max_point) max_point = point[i];
   }
-  svo_hip_pyramid* dst = t->frame_pyr[t->last_idx];
+  svo_hip_pyramid* dst = t->sh->frame_pyr[t->sh->last_idx];
+  const svo_hip_pyramid* kf = t->sh->kf_pyr;
   int rc;
-  if (level0) rc = svo_hip_pyramid_upload_level0_and_build(dst, 0, level0);
-  else rc = svo_hip_copy_d2d(ctx, dst->base, t->kf_pyr->base + (size_t)kf_slot * t->kf_pyr->pyr_bytes, dst->pyr_bytes);
+  if (level0) rc = svo_hip_pyramid_upload_level0_and_build(dst, t->cam_index, level0);
+  else rc = svo_hip_copy_d2d(ctx, dst->base + (size_t)t->cam_index * dst->pyr_bytes,
+                             kf->base + ((size_t)t->cam_index * t->cfg.max_keyframes + kf_slot) * kf->pyr_bytes, dst->pyr_bytes);
   if (rc != SVO_HIP_OK) return rc;
   const int32_t n32 = n;
   SVO_CHECK_HIP(ctx, hipMemcpyAsync(t->last.n, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1047,89 +1202,14 @@ int svo_hip_tracker_set_last_frame(svo_hip_tracker* t, const uint8_t* level0, in
   return SVO_HIP_OK;
 }
 
-int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_track_result* result, double* feat_px, double* feat_f,
-                          int32_t* feat_level, int32_t* feat_point, uint8_t* feat_edgelet, double* feat_grad, int32_t* pt_type,
-                          int32_t* pt_n_failed, int32_t* pt_n_succeeded) {
-  if (!t || !level0 || !result) return SVO_HIP_ERR_INVALID;
-  svo_hip_ctx* ctx = t->ctx;
-  const svo_hip_tracker_config& c = t->cfg;
-  if (!t->have_map || !t->have_last)
-    return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_track", "svo_hip_tracker_set_map and svo_hip_tracker_set_last_frame come first");
-  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  const size_t l0 = (size_t)t->cam.width * t->cam.height;
-  svo_hip_pyramid* ref = t->frame_pyr[t->last_idx];
-  svo_hip_pyramid* cur = t->frame_pyr[1 - t->last_idx];
-  // ---- new Frame(cam, img, t): the image crosses the link once, from page-locked memory; the pyramid is built on the device
-  if (level0 != reinterpret_cast<const uint8_t*>(t->img_host)) memcpy(t->img_host, level0, l0);      // (svo_hip_tracker_image_buffer: already there)
-  int rc = svo_pyramid_build_levels(cur, 0, 1, t->img_dev);
-  if (rc != SVO_HIP_OK) return rc;
-  // ---- SparseImgAlign(kltMaxLevel, kltMinLevel, 30, GaussNewton, false, false).run(last_frame_, new_frame_)
-  rc = svo_hip_sia_set_frames(t->sia, ref, cur);
-  if (rc != SVO_HIP_OK) return rc;
-  // the previous call's hand-over kernel has written the solver's inputs already, unless the host changed the last frame,
-  // the map or point positions since
-  if (t->need_gather) rc = svo_sia_prepare_from_device(t->sia, &t->cam, t->last_n_host, t->last.n, t->last.T_f_w, t->last.px, t->last.f, t->last.point, t->pt_pos);
-  else rc = svo_sia_note_device_slot0(t->sia, &t->cam, t->last_n_host);
-  if (rc != SVO_HIP_OK) return rc;
-  svo_hip_sia_params sp;
-  sp.max_level = c.klt_max_level; sp.min_level = c.klt_min_level; sp.n_iter = c.sia_n_iter; sp.eps = c.sia_eps; sp.early_stop = 1;
-  rc = svo_hip_sia_run(t->sia, 1, &sp);
-  if (rc != SVO_HIP_OK) return rc;
-  const FrameState* st = svo_sia_state_dev(t->sia);
-  // ---- Reprojector::reprojectMap
-  const TrkMap m = make_map(t);
-  const Cam cam = svo_make_cam(t->cam);
-  if (t->rekey_pending && t->n_kf > 0) {    // Map::safeDeletePoint of the previous frame: Frame::removeKeyPoint on the keyframes
-    hipLaunchKernelGGL(trk_rekey_kernel, dim3(t->n_kf), dim3(256), 0, ctx->stream, m, t->kf_key_point, cam);
-    SVO_CHECK_HIP(ctx, hipGetLastError());
-  }
-  t->rekey_pending = false;
-  SeedRec* recs = nullptr;
-  uint32_t* pwb_t = nullptr;
-  int n_pad = 0;
-  rc = svo_match_scratch(ctx, t->pl.cap, &recs, &pwb_t, &n_pad);
-  if (rc != SVO_HIP_OK) return rc;
-  MdFrame mf;
-  memset(&mf, 0, sizeof(mf));
-  mf.cam = cam; mf.n_pyr_levels = c.n_pyr_levels; mf.n_kf = c.max_keyframes; mf.n_ref_levels = c.n_levels;
-  hipLaunchKernelGGL(trk_plan_kernel, dim3(1), dim3(TRK_THREADS), 0, ctx->stream, m, t->pl, mf, t->T_slot_w, recs, st);
-  SVO_CHECK_HIP(ctx, hipGetLastError());
-  // warp + align2D (+ align1D when the map holds edgelets) over the candidates
-  rc = svo_match_stages(ctx, t->kf_pyr, cur, 0, &t->cam, t->pl.cap, t->pl.counters, t->pl.cand_level_ref, recs, pwb_t, n_pad, c.n_pyr_levels,
-                        c.align_max_iter, t->any_edgelet);
-  if (rc != SVO_HIP_OK) return rc;
-  hipLaunchKernelGGL(trk_replay_kernel, dim3(1), dim3(TRK_THREADS), 0, ctx->stream, m, t->pl, t->ft, cam, st, recs, t->cell_winner, t->cell_cum,
-                     c.max_fts, c.quality_min_fts);
-  SVO_CHECK_HIP(ctx, hipGetLastError());
-  // ---- pose_optimizer::optimizeGaussNewton(poseOptimThresh, poseOptimNumIter, ...) on the matched features, from the aligned pose
-  rc = svo_hip_pose_optimize_batch_dev(ctx, 1, c.max_frame_features, t->pl.counters + 5, st->T_cur_w, t->ft.f, t->ft.pos, t->ft.level, t->ft.has_point,
-                                       fabs(t->cam.fx), c.pose_optim_thresh, c.pose_optim_num_iter, t->po);
-  if (rc != SVO_HIP_OK) return rc;
-  // ---- hand-over + result: written straight into the page-locked block, the frame's sequence number last
-  char* rd = t->res_dev;
-  const unsigned long long seq = ++t->seq;
-  hipLaunchKernelGGL(trk_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, m, t->pl, t->ft, t->last, cam, st, t->po,
-                     reinterpret_cast<svo_hip_track_result*>(rd), reinterpret_cast<double*>(rd + t->o_px), reinterpret_cast<double*>(rd + t->o_f),
-                     reinterpret_cast<int*>(rd + t->o_level), reinterpret_cast<int*>(rd + t->o_point), reinterpret_cast<uint8_t*>(rd + t->o_edge),
-                     reinterpret_cast<double*>(rd + t->o_grad), reinterpret_cast<int*>(rd + t->o_pt), reinterpret_cast<int*>(rd + t->o_pt) + t->n_points,
-                     reinterpret_cast<int*>(rd + t->o_pt) + 2 * (size_t)t->n_points, reinterpret_cast<unsigned long long*>(rd + t->o_flag), seq);
-  SVO_CHECK_HIP(ctx, hipGetLastError());
-  // the one synchronisation of the frame: wait for the sequence number (a spin on host memory: no driver call on the way
-  // back), with the stream's own synchronisation as the fall-back and the error check
-  {
-    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(t->res_host + t->o_flag);
-    bool seen = false;
-    for (long spins = 0; spins < 4000000L; ++spins) {                      // a few hundred milliseconds at most
-      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
-      __builtin_ia32_pause();
-    }
-    if (!seen) SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
-      return svo_fail(ctx, SVO_HIP_ERR_DEVICE, "svo_hip_tracker_track", "the frame's kernels did not complete");
-  }
+// a tracked frame's outcome from the camera's page-locked result block (valid until the camera's next frame)
+static void trk_copy_out(svo_hip_tracker* t, svo_hip_track_result* result, double* feat_px, double* feat_f, int32_t* feat_level, int32_t* feat_point,
+                         uint8_t* feat_edgelet, double* feat_grad, int32_t* pt_type, int32_t* pt_n_failed, int32_t* pt_n_succeeded) {
   const char* rh = t->res_host;
-  memcpy(result, rh, sizeof(*result));
-  const size_t nf = (size_t)(result->n_features > 0 ? result->n_features : 0);
+  svo_hip_track_result r;
+  memcpy(&r, rh, sizeof(r));
+  if (result) *result = r;
+  const size_t nf = (size_t)(r.n_features > 0 ? r.n_features : 0);
   if (feat_px) memcpy(feat_px, rh + t->o_px, nf * 16);
   if (feat_f) memcpy(feat_f, rh + t->o_f, nf * 24);
   if (feat_level) memcpy(feat_level, rh + t->o_level, nf * 4);
@@ -1140,11 +1220,238 @@ int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_tra
   if (pt_type) memcpy(pt_type, rh + t->o_pt, np4);
   if (pt_n_failed) memcpy(pt_n_failed, rh + t->o_pt + np4, np4);
   if (pt_n_succeeded) memcpy(pt_n_succeeded, rh + t->o_pt + 2 * np4, np4);
-  t->last_idx = 1 - t->last_idx;            // the new frame's pyramid is the next call's reference
-  t->last_n_host = result->n_features;
-  t->last_from_track = true;
-  t->need_gather = false;
-  if (result->map_changed) t->rekey_pending = true;
+}
+
+// One frame for every camera of the shared part: ONE chain of launches whatever the number of cameras.  level0[c]: camera c's
+// new image (its own page-locked buffer: no copy).
+static int trk_track_all(svo_hip_tracker_shared* sh, const uint8_t* const* level0, const char* who) {
+  svo_hip_ctx* ctx = sh->ctx;
+  const int N = sh->n_cams;
+  svo_hip_tracker* t0 = sh->members[0];
+  const svo_hip_tracker_config& c = t0->cfg;
+  for (int k = 0; k < N; ++k) {
+    svo_hip_tracker* t = sh->members[(size_t)k];
+    if (!t->have_map || !t->have_last)
+      return svo_fail(ctx, SVO_HIP_ERR_STATE, who, "svo_hip_tracker_set_map and svo_hip_tracker_set_last_frame come first (every camera)");
+  }
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t l0 = (size_t)t0->cam.width * t0->cam.height;
+  svo_hip_pyramid* ref = sh->frame_pyr[sh->last_idx];
+  svo_hip_pyramid* cur = sh->frame_pyr[1 - sh->last_idx];
+  // ---- new Frame(cam, img, t): the images cross the link once, from page-locked memory; the pyramids are built on the device
+  for (int k = 0; k < N; ++k) {
+    svo_hip_tracker* t = sh->members[(size_t)k];
+    if (level0[k] != reinterpret_cast<const uint8_t*>(t->img_host)) memcpy(t->img_host, level0[k], l0);      // (svo_hip_tracker_image_buffer: already there)
+  }
+  int rc = svo_pyramid_build_levels(cur, 0, N, sh->img_dev, sh->img_stride);
+  if (rc != SVO_HIP_OK) return rc;
+  // ---- SparseImgAlign(kltMaxLevel, kltMinLevel, 30, GaussNewton, false, false).run(last_frame_, new_frame_)
+  rc = svo_hip_sia_set_frames(sh->sia, ref, cur);
+  if (rc != SVO_HIP_OK) return rc;
+  // the previous call's hand-over kernel has written the solver's inputs already, unless the host changed the last frame,
+  // the map or point positions since
+  for (int k = 0; k < N; ++k) {
+    svo_hip_tracker* t = sh->members[(size_t)k];
+    if (t->need_gather) rc = svo_sia_prepare_from_device(sh->sia, k, &t->cam, t->last_n_host, t->last.n, t->last.T_f_w, t->last.px, t->last.f, t->last.point, t->pt_pos);
+    else rc = svo_sia_note_device_slot(sh->sia, k, &t->cam, t->last_n_host);
+    if (rc != SVO_HIP_OK) return rc;
+  }
+  svo_hip_sia_params sp;
+  sp.max_level = c.klt_max_level; sp.min_level = c.klt_min_level; sp.n_iter = c.sia_n_iter; sp.eps = c.sia_eps; sp.early_stop = 1;
+  rc = svo_hip_sia_run(sh->sia, N, &sp);
+  if (rc != SVO_HIP_OK) return rc;
+  // ---- Reprojector::reprojectMap
+  const Cam cam = svo_make_cam(t0->cam);
+  bool any_edgelet = false;
+  for (int k = 0; k < N; ++k) {
+    svo_hip_tracker* t = sh->members[(size_t)k];
+    if (t->rekey_pending && t->n_kf > 0) {    // Map::safeDeletePoint of the previous frame: Frame::removeKeyPoint on the keyframes
+      hipLaunchKernelGGL(trk_rekey_kernel, dim3(t->n_kf), dim3(256), 0, ctx->stream, make_map(t), t->kf_key_point, cam);
+      SVO_CHECK_HIP(ctx, hipGetLastError());
+    }
+    t->rekey_pending = false;
+    any_edgelet = any_edgelet || t->any_edgelet;
+  }
+  SeedRec* recs = nullptr;
+  uint32_t* pwb_t = nullptr;
+  int n_pad = 0;
+  const int cap = t0->pl.cap;
+  rc = svo_match_scratch(ctx, N * cap, &recs, &pwb_t, &n_pad);
+  if (rc != SVO_HIP_OK) return rc;
+  MdFrame mf;
+  memset(&mf, 0, sizeof(mf));
+  mf.cam = cam; mf.n_pyr_levels = c.n_pyr_levels; mf.n_kf = c.max_keyframes; mf.n_ref_levels = c.n_levels;
+  if (N == 1) {
+    svo_hip_tracker* t = t0;
+    const TrkMap m = make_map(t);
+    const FrameState* st = svo_sia_state_dev(sh->sia, 0);
+    hipLaunchKernelGGL(trk_plan_kernel, dim3(1), dim3(TRK_THREADS), 0, ctx->stream, m, t->pl, mf, t->T_slot_w, recs, st);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+    // warp + align2D (+ align1D when the map holds edgelets) over the candidates
+    rc = svo_match_stages(ctx, sh->kf_pyr, cur, 0, &t->cam, t->pl.cap, t->pl.counters, t->pl.cand_level_ref, recs, pwb_t, n_pad, c.n_pyr_levels,
+                          c.align_max_iter, t->any_edgelet);
+    if (rc != SVO_HIP_OK) return rc;
+    hipLaunchKernelGGL(trk_replay_kernel, dim3(1), dim3(TRK_THREADS), 0, ctx->stream, m, t->pl, t->ft, cam, st, recs, t->cell_winner, t->cell_cum,
+                       c.max_fts, c.quality_min_fts);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+    // ---- pose_optimizer::optimizeGaussNewton(poseOptimThresh, poseOptimNumIter, ...) on the matched features, from the aligned pose
+    rc = svo_hip_pose_optimize_batch_dev(ctx, 1, c.max_frame_features, t->pl.counters + 5, st->T_cur_w, t->ft.f, t->ft.pos, t->ft.level, t->ft.has_point,
+                                         fabs(t->cam.fx), c.pose_optim_thresh, c.pose_optim_num_iter, t->po);
+    if (rc != SVO_HIP_OK) return rc;
+    // ---- hand-over + result: written straight into the page-locked block, the frame's sequence number last
+    char* rd = t->res_dev;
+    const unsigned long long seq = ++t->seq;
+    hipLaunchKernelGGL(trk_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, m, t->pl, t->ft, t->last, cam, st, t->po,
+                       reinterpret_cast<svo_hip_track_result*>(rd), reinterpret_cast<double*>(rd + t->o_px), reinterpret_cast<double*>(rd + t->o_f),
+                       reinterpret_cast<int*>(rd + t->o_level), reinterpret_cast<int*>(rd + t->o_point), reinterpret_cast<uint8_t*>(rd + t->o_edge),
+                       reinterpret_cast<double*>(rd + t->o_grad), reinterpret_cast<int*>(rd + t->o_pt), reinterpret_cast<int*>(rd + t->o_pt) + t->n_points,
+                       reinterpret_cast<int*>(rd + t->o_pt) + 2 * (size_t)t->n_points, reinterpret_cast<unsigned long long*>(rd + t->o_flag), seq);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+  } else {
+    // the cameras' arguments: one table, one transfer (the previous call's kernels are through with it: this thread waited for them)
+    TrkCamArgs* ah = reinterpret_cast<TrkCamArgs*>(sh->args_host);
+    for (int k = 0; k < N; ++k) {
+      svo_hip_tracker* t = sh->members[(size_t)k];
+      TrkCamArgs& a = ah[k];
+      memset(&a, 0, sizeof(a));
+      a.m = make_map(t); a.pl = t->pl; a.ft = t->ft; a.last = t->last;
+      a.mf = mf; a.mf.slot_base = k * c.max_keyframes;
+      a.T_slot_w = t->T_slot_w;
+      a.recs = recs + (size_t)k * cap;
+      a.sia_state = svo_sia_state_dev(sh->sia, k);
+      a.cell_winner = t->cell_winner; a.cell_cum = t->cell_cum;
+      a.po = t->po;
+      a.res = t->res_dev;
+      a.o_px = t->o_px; a.o_f = t->o_f; a.o_level = t->o_level; a.o_point = t->o_point; a.o_edge = t->o_edge; a.o_grad = t->o_grad; a.o_pt = t->o_pt;
+      a.o_flag = t->o_flag;
+      a.n_points_cap = c.max_points;
+      a.seq = ++t->seq;
+    }
+    SVO_CHECK_HIP(ctx, hipMemcpyAsync(sh->args_dev, sh->args_host, (size_t)N * sizeof(TrkCamArgs), hipMemcpyHostToDevice, ctx->stream));
+    const TrkCamArgs* ad = reinterpret_cast<const TrkCamArgs*>(sh->args_dev);
+    hipLaunchKernelGGL(trk_plan_cams_kernel, dim3(N), dim3(TRK_THREADS), 0, ctx->stream, ad);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+    rc = svo_match_stages_cams(ctx, sh->kf_pyr, cur, &t0->cam, N, cap, sh->counters, 8, sh->cand_level_ref, recs, pwb_t, n_pad, c.n_pyr_levels,
+                               c.align_max_iter, any_edgelet);
+    if (rc != SVO_HIP_OK) return rc;
+    hipLaunchKernelGGL(trk_replay_cams_kernel, dim3(N), dim3(TRK_THREADS), 0, ctx->stream, ad, c.max_fts, c.quality_min_fts);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+    const FrameState* st0 = svo_sia_state_dev(sh->sia, 0);
+    static_assert(sizeof(FrameState) % sizeof(double) == 0, "the solver records are a whole number of doubles apart");
+    rc = svo_pose_optimize_batch_strided(ctx, N, c.max_frame_features, sh->counters + 5, 8, st0->T_cur_w, (int)(sizeof(FrameState) / sizeof(double)),
+                                         sh->ft_f, sh->ft_pos, sh->ft_level, sh->ft_has_point, fabs(t0->cam.fx), c.pose_optim_thresh,
+                                         c.pose_optim_num_iter, sh->po);
+    if (rc != SVO_HIP_OK) return rc;
+    hipLaunchKernelGGL(trk_finish_cams_kernel, dim3(N), dim3(256), 0, ctx->stream, ad);
+    SVO_CHECK_HIP(ctx, hipGetLastError());
+  }
+  // the one synchronisation of the frame: wait for every camera's sequence number (a spin on host memory: no driver call on the
+  // way back), with the stream's own synchronisation as the fall-back and the error check
+  {
+    bool all = false;
+    for (long spins = 0; spins < 4000000L && !all; ++spins) {                 // a few hundred milliseconds at most
+      all = true;
+      for (int k = 0; k < N && all; ++k) {
+        svo_hip_tracker* t = sh->members[(size_t)k];
+        volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(t->res_host + t->o_flag);
+        all = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == t->seq;
+      }
+      if (!all) __builtin_ia32_pause();
+    }
+    if (!all) SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < N; ++k) {
+      svo_hip_tracker* t = sh->members[(size_t)k];
+      volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(t->res_host + t->o_flag);
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != t->seq) return svo_fail(ctx, SVO_HIP_ERR_DEVICE, who, "the frame's kernels did not complete");
+    }
+  }
+  sh->last_idx = 1 - sh->last_idx;          // the new frames' pyramids are the next call's references
+  for (int k = 0; k < N; ++k) {
+    svo_hip_tracker* t = sh->members[(size_t)k];
+    const svo_hip_track_result* r = reinterpret_cast<const svo_hip_track_result*>(t->res_host);
+    t->last_n_host = r->n_features;
+    t->last_from_track = true;
+    t->need_gather = false;
+    if (r->map_changed) t->rekey_pending = true;
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_track(svo_hip_tracker* t, const uint8_t* level0, svo_hip_track_result* result, double* feat_px, double* feat_f,
+                          int32_t* feat_level, int32_t* feat_point, uint8_t* feat_edgelet, double* feat_grad, int32_t* pt_type,
+                          int32_t* pt_n_failed, int32_t* pt_n_succeeded) {
+  if (!t || !level0 || !result) return SVO_HIP_ERR_INVALID;
+  if (t->sh->n_cams != 1)
+    return svo_fail(t->ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_track", "a camera of a tracker group is tracked with its group (svo_hip_tracker_group_track)");
+  const int rc = trk_track_all(t->sh, &level0, "svo_hip_tracker_track");
+  if (rc != SVO_HIP_OK) return rc;
+  trk_copy_out(t, result, feat_px, feat_f, feat_level, feat_point, feat_edgelet, feat_grad, pt_type, pt_n_failed, pt_n_succeeded);
+  return SVO_HIP_OK;
+}
+
+// ---- a group of cameras: N trackers with one camera model and one configuration whose frames are tracked TOGETHER -- one
+// chain of launches per call whatever N (every kernel of the chain takes one workgroup, or one slice of its grid, per camera).
+// Every camera keeps its own map, last frame and result block and is set up with the svo_hip_tracker_* functions of its
+// handle (svo_hip_tracker_group_camera); only the per-frame call is the group's.
+struct svo_hip_tracker_group {
+  svo_hip_tracker_shared* sh = nullptr;
+};
+
+int svo_hip_tracker_group_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const svo_hip_tracker_config* cfg, int n_cameras,
+                                 svo_hip_tracker_group** out) {
+  if (!ctx || !cam || !cfg || !out) return SVO_HIP_ERR_INVALID;
+  *out = nullptr;
+  SVO_REQUIRE(ctx, n_cameras >= 1 && n_cameras <= 1024);
+  int rc = trk_check_config(ctx, cam, cfg);
+  if (rc != SVO_HIP_OK) return rc;
+  // a block of the batched warp / alignment stages takes 16 candidates and must not straddle two cameras
+  SVO_REQUIRE(ctx, n_cameras == 1 || cfg->max_items % 16 == 0);
+  svo_hip_tracker_group* g = new (std::nothrow) svo_hip_tracker_group();
+  if (!g) return SVO_HIP_ERR_NOMEM;
+  rc = trk_shared_create(ctx, cam, cfg, n_cameras, &g->sh);
+  for (int k = 0; k < n_cameras && rc == SVO_HIP_OK; ++k) {
+    svo_hip_tracker* t = nullptr;
+    rc = trk_member_create(g->sh, k, cam, cfg, &t);
+    if (rc == SVO_HIP_OK) g->sh->members.push_back(t);
+  }
+  if (rc != SVO_HIP_OK) { svo_hip_tracker_group_destroy(g); return rc; }
+  *out = g;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_group_destroy(svo_hip_tracker_group* g) {
+  if (!g) return SVO_HIP_ERR_INVALID;
+  if (g->sh) {
+    (void)hipStreamSynchronize(g->sh->ctx->stream);
+    for (svo_hip_tracker* t : g->sh->members) trk_member_destroy(t);
+    trk_shared_destroy(g->sh);
+  }
+  delete g;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_group_camera(svo_hip_tracker_group* g, int index, svo_hip_tracker** camera) {
+  if (!g || !g->sh || !camera) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(g->sh->ctx, index >= 0 && index < g->sh->n_cams);
+  *camera = g->sh->members[(size_t)index];
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_group_track(svo_hip_tracker_group* g, const uint8_t* const* level0, svo_hip_track_result* results) {
+  if (!g || !g->sh || !level0) return SVO_HIP_ERR_INVALID;
+  for (int k = 0; k < g->sh->n_cams; ++k) if (!level0[k]) return SVO_HIP_ERR_INVALID;
+  const int rc = trk_track_all(g->sh, level0, "svo_hip_tracker_group_track");
+  if (rc != SVO_HIP_OK) return rc;
+  if (results) for (int k = 0; k < g->sh->n_cams; ++k) trk_copy_out(g->sh->members[(size_t)k], results + k, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return SVO_HIP_OK;
+}
+
+int svo_hip_tracker_last_result(svo_hip_tracker* t, svo_hip_track_result* result, double* feat_px, double* feat_f, int32_t* feat_level,
+                                int32_t* feat_point, uint8_t* feat_edgelet, double* feat_grad, int32_t* pt_type, int32_t* pt_n_failed,
+                                int32_t* pt_n_succeeded) {
+  if (!t) return SVO_HIP_ERR_INVALID;
+  if (!t->last_from_track) return svo_fail(t->ctx, SVO_HIP_ERR_STATE, "svo_hip_tracker_last_result", "no frame has been tracked since the last frame was set");
+  trk_copy_out(t, result, feat_px, feat_f, feat_level, feat_point, feat_edgelet, feat_grad, pt_type, pt_n_failed, pt_n_succeeded);
   return SVO_HIP_OK;
 }
 
@@ -1176,7 +1483,7 @@ int svo_hip_tracker_info(const svo_hip_tracker* t, int* n_cells, int* grid_cols,
   if (n_cells) *n_cells = t->n_cells;
   if (grid_cols) *grid_cols = t->grid_cols;
   if (grid_rows) *grid_rows = t->grid_rows;
-  if (keyframe_pyramids) *keyframe_pyramids = t->kf_pyr;
+  if (keyframe_pyramids) *keyframe_pyramids = t->sh->kf_pyr;      // (a group member's keyframe slot s is slot cam_index * max_keyframes + s of it)
   return SVO_HIP_OK;
 }
 

@@ -883,16 +883,20 @@ class Tracker:
     """svo_hip_tracker: SparseImgAlign -> Reprojector::reprojectMap -> pose_optimizer on one stream, one synchronisation per
     frame, the frame's matches handed over to the next call on the device."""
 
-    def __init__(self, ctx: Context, cam, **overrides):
+    def __init__(self, ctx: Context, cam, _group_handle=None, _cfg=None, **overrides):
         self.ctx, self.cam = ctx, cam
-        self.cfg = CTrackerConfig()
-        ctx.check(ctx.lib.svo_hip_tracker_default_config(C.byref(self.cfg)), "tracker_default_config")
-        for k, v in overrides.items():
-            assert hasattr(self.cfg, k), k
-            setattr(self.cfg, k, v)
         self.ccam = make_camera(cam)
-        self.h = C.c_void_p()
-        ctx.check(ctx.lib.svo_hip_tracker_create(ctx.h, C.byref(self.ccam), C.byref(self.cfg), C.byref(self.h)), "tracker_create")
+        if _group_handle is not None:              # a camera of a TrackerGroup: the handle belongs to the group
+            self.cfg, self.h, self._in_group = _cfg, _group_handle, True
+        else:
+            self.cfg = CTrackerConfig()
+            ctx.check(ctx.lib.svo_hip_tracker_default_config(C.byref(self.cfg)), "tracker_default_config")
+            for k, v in overrides.items():
+                assert hasattr(self.cfg, k), k
+                setattr(self.cfg, k, v)
+            self.h = C.c_void_p()
+            self._in_group = False
+            ctx.check(ctx.lib.svo_hip_tracker_create(ctx.h, C.byref(self.ccam), C.byref(self.cfg), C.byref(self.h)), "tracker_create")
         nc, gc, gr = C.c_int(), C.c_int(), C.c_int()
         ctx.check(ctx.lib.svo_hip_tracker_info(self.h, C.byref(nc), C.byref(gc), C.byref(gr), None), "tracker_info")
         self.n_cells, self.grid_cols, self.grid_rows = nc.value, gc.value, gr.value
@@ -962,21 +966,38 @@ class Tracker:
                        "tracker_set_last_frame")
         self.ctx.sync()
 
-    def track(self, img: np.ndarray, want_points: bool = True) -> dict:
-        im = np.ascontiguousarray(img, dtype=np.uint8)
-        assert im.shape == (self.cam.height, self.cam.width)
+    def _outputs(self):
         nf = self.cfg.max_frame_features
         if not hasattr(self, "_out") or len(self._out["pt_type"]) != max(self.n_points, 1):
             self._out = dict(px=np.zeros((nf, 2)), f=np.zeros((nf, 3)), level=np.zeros(nf, np.int32), point=np.zeros(nf, np.int32),
                              edgelet=np.zeros(nf, np.uint8), grad=np.zeros((nf, 2)), pt_type=np.zeros(max(self.n_points, 1), np.int32),
                              pt_n_failed=np.zeros(max(self.n_points, 1), np.int32), pt_n_succeeded=np.zeros(max(self.n_points, 1), np.int32))
-        o = self._out
+        return self._out
+
+    def track(self, img: np.ndarray, want_points: bool = True) -> dict:
+        im = np.ascontiguousarray(img, dtype=np.uint8)
+        assert im.shape == (self.cam.height, self.cam.width)
+        o = self._outputs()
         res = CTrackResult()
         I, D = C.c_int32, C.c_double
         self.ctx.check(self.ctx.lib.svo_hip_tracker_track(
             self.h, _ptr(im, C.c_uint8), C.byref(res), _ptr(o["px"], D), _ptr(o["f"], D), _ptr(o["level"], I), _ptr(o["point"], I),
             _ptr(o["edgelet"], C.c_uint8), _ptr(o["grad"], D), _ptr(o["pt_type"], I) if want_points else None,
             _ptr(o["pt_n_failed"], I) if want_points else None, _ptr(o["pt_n_succeeded"], I) if want_points else None), "tracker_track")
+        return self._as_dict(res, o)
+
+    def last_result(self) -> dict:
+        """svo_hip_tracker_last_result: the outcome of the camera's last tracked frame (what track() returns), read again from its
+        page-locked result block -- how the cameras of a TrackerGroup hand out their features and point counters"""
+        o = self._outputs()
+        res = CTrackResult()
+        I, D = C.c_int32, C.c_double
+        self.ctx.check(self.ctx.lib.svo_hip_tracker_last_result(
+            self.h, C.byref(res), _ptr(o["px"], D), _ptr(o["f"], D), _ptr(o["level"], I), _ptr(o["point"], I), _ptr(o["edgelet"], C.c_uint8),
+            _ptr(o["grad"], D), _ptr(o["pt_type"], I), _ptr(o["pt_n_failed"], I), _ptr(o["pt_n_succeeded"], I)), "tracker_last_result")
+        return self._as_dict(res, o)
+
+    def _as_dict(self, res, o) -> dict:
         n = res.n_features
         return {"result": res, "T_f_w": np.array(res.T_f_w), "T_f_w_sia": np.array(res.T_f_w_sia), "n_matches": int(res.n_matches),
                 "n_trials": int(res.n_trials), "feat_px": o["px"][:n].copy(), "feat_f": o["f"][:n].copy(), "feat_level": o["level"][:n].copy(),
@@ -986,6 +1007,49 @@ class Tracker:
                 "n_succeeded": o["pt_n_succeeded"][:self.n_points].copy(), "map_changed": int(res.map_changed)}
 
     def destroy(self):
-        if self.h:
+        if self.h and not self._in_group:
             self.ctx.lib.svo_hip_tracker_destroy(self.h)
+        self.h = C.c_void_p()
+
+
+class TrackerGroup:
+    """svo_hip_tracker_group: n cameras (one camera model, one configuration) tracked together, one chain of launches per call.
+    `cameras[c]` is a Tracker bound to camera c's handle: set_map / set_last_frame / upload_keyframe / optimize_structure /
+    image_buffer / last_result work on it; track() and destroy() are the group's."""
+
+    def __init__(self, ctx: Context, cam, n_cameras: int, **overrides):
+        self.ctx, self.cam, self.n = ctx, cam, int(n_cameras)
+        self.cfg = CTrackerConfig()
+        ctx.check(ctx.lib.svo_hip_tracker_default_config(C.byref(self.cfg)), "tracker_default_config")
+        for k, v in overrides.items():
+            assert hasattr(self.cfg, k), k
+            setattr(self.cfg, k, v)
+        self.ccam = make_camera(cam)
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.svo_hip_tracker_group_create(ctx.h, C.byref(self.ccam), C.byref(self.cfg), self.n, C.byref(self.h)), "tracker_group_create")
+        self.cameras = []
+        for c in range(self.n):
+            th = C.c_void_p()
+            ctx.check(ctx.lib.svo_hip_tracker_group_camera(self.h, c, C.byref(th)), "tracker_group_camera")
+            self.cameras.append(Tracker(ctx, cam, _group_handle=th, _cfg=self.cfg))
+        self._ptrs = (C.POINTER(C.c_uint8) * self.n)()
+        self._res = (CTrackResult * self.n)()
+
+    def track(self, imgs) -> list:
+        """one frame of every camera; imgs[c]: (height, width) u8 (camera c's image_buffer() array is not copied).  Returns the
+        cameras' CTrackResult records (features and point counters: cameras[c].last_result())."""
+        keep = []
+        for c in range(self.n):
+            im = np.ascontiguousarray(imgs[c], dtype=np.uint8)
+            assert im.shape == (self.cam.height, self.cam.width)
+            keep.append(im)
+            self._ptrs[c] = im.ctypes.data_as(C.POINTER(C.c_uint8))
+        self.ctx.check(self.ctx.lib.svo_hip_tracker_group_track(self.h, self._ptrs, self._res), "tracker_group_track")
+        return [self._res[c] for c in range(self.n)]
+
+    def destroy(self):
+        if self.h:
+            for t in self.cameras:
+                t.h = C.c_void_p()
+            self.ctx.lib.svo_hip_tracker_group_destroy(self.h)
             self.h = C.c_void_p()

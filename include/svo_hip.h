@@ -652,6 +652,34 @@ int svo_hip_tracker_track(svo_hip_tracker* trk, const uint8_t* level0, svo_hip_t
                           double* feat_f, int32_t* feat_level, int32_t* feat_point, uint8_t* feat_edgelet, double* feat_grad,
                           int32_t* pt_type, int32_t* pt_n_failed, int32_t* pt_n_succeeded);
 
+/* ---- several cameras: FrameHandlerMono::processFrame (frame_handler_mono.cpp:171-229) of N independent cameras per call.
+ * north_star's "concurrent frame pairs" for the whole per-frame chain: N svo::FrameHandlerMono objects (N cameras, or N
+ * sequences replayed side by side) each track one frame at a time; with N trackers on N host threads the HIP runtime's launch
+ * path serialises them (measured: 5.5 k frames/s for one camera, 20 k for 4, 21-26 k for 8-16, whatever the number of hardware
+ * queues: profiles/r05_cameras_threads.txt).  A group creates N trackers with one camera model and one configuration that
+ * share the SparseImgAlign solver (camera c = slot c), the frame and keyframe pyramid batches and the per-camera arrays of
+ * the batched stages, and tracks one frame of EVERY camera with ONE chain of launches: every kernel of the chain takes one
+ * workgroup (or one slice of its grid) per camera, the cameras' arguments come from a table in device memory.
+ * A camera's handle (svo_hip_tracker_group_camera) takes every svo_hip_tracker_* call except _track and _destroy: its map,
+ * its last frame, its keyframe slots (0 .. max_keyframes - 1, its own), structure optimisation, image buffer.  Outcomes are
+ * bit for bit those of the same camera tracked by a lone svo_hip_tracker (tests/test_gpu_tracker_group.py), provided the
+ * SparseImgAlign kernel shape is the same: it is chosen by the largest feature count among the cameras' last frames
+ * (svo_hip_sia_last_run_mode).  cfg->max_items must be a multiple of 16 when n_cameras > 1. */
+typedef struct svo_hip_tracker_group svo_hip_tracker_group;
+int svo_hip_tracker_group_create(svo_hip_ctx* ctx, const svo_hip_camera* cam, const svo_hip_tracker_config* cfg, int n_cameras,
+                                 svo_hip_tracker_group** out);
+int svo_hip_tracker_group_destroy(svo_hip_tracker_group* group);
+int svo_hip_tracker_group_camera(svo_hip_tracker_group* group, int index, svo_hip_tracker** camera);
+/* One frame of every camera: level0[c] = camera c's new image (its svo_hip_tracker_image_buffer: no copy); results[n_cameras]
+ * (may be NULL).  Synchronises once, for all cameras.  The cameras' features and point counters are read afterwards with
+ * svo_hip_tracker_last_result on the handles that need them. */
+int svo_hip_tracker_group_track(svo_hip_tracker_group* group, const uint8_t* const* level0, svo_hip_track_result* results);
+/* The outcome of the camera's last tracked frame again (same outputs as svo_hip_tracker_track; any may be NULL): a copy from
+ * the camera's page-locked result block, no device call. */
+int svo_hip_tracker_last_result(svo_hip_tracker* trk, svo_hip_track_result* result, double* feat_px, double* feat_f,
+                                int32_t* feat_level, int32_t* feat_point, uint8_t* feat_edgelet, double* feat_grad,
+                                int32_t* pt_type, int32_t* pt_n_failed, int32_t* pt_n_succeeded);
+
 /* The 6x6 pivoted LDL^T solve both Gauss-Newton solvers use (x = H.ldlt().solve(b), Eigen 3.4 semantics incl. the
  * pseudo-inverse of D), n systems from host buffers: exposed so that the parity tests can show it is bit-identical
  * to Eigen's result. */

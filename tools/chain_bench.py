@@ -140,6 +140,10 @@ def single_stream_chain(ctx, n_frames=20):
                     "cpu_oracle_1_thread_ms_per_frame": cpu["ms_per_frame_total"], "speedup_vs_1_thread": cpu["ms_per_frame_total"] / leg["ms_per_frame_total"],
                     "max_pose_diff_vs_cpu_chain": {"rot_rad": float(diff[:, 0].max()), "trans_m": float(diff[:, 1].max())},
                     "matched_points_equal_in_every_frame": bool(same)}
+    # N cameras = N trackers on N contexts driven by N host threads (no grouped entry point): whole-job frames/s, L4-L2
+    out["cameras_frames_per_s"] = multi_camera(seq, 2, cams=(1, 4, 8), repeats=4)
+    # ... and through svo_hip_tracker_group_track: one host thread, one chain of launches per call for all cameras
+    out["group_frames_per_s"] = group_cameras(ctx, seq, 2, cams=(1, 8, 64), repeats=3)
     return out
 
 
@@ -277,16 +281,65 @@ def multi_camera(seq, min_level, cams=(1, 2, 4, 8), repeats=6):
     return out
 
 
+def group_cameras(ctx, seq, min_level, cams=(1, 8, 64), repeats=4):
+    """The same N cameras through svo_hip_tracker_group_track: ONE host thread, one chain of launches per call for all cameras
+    (every kernel takes a workgroup, or a slice of its grid, per camera).  Whole-job frames/s per camera count; every camera's last
+    pose of every pass bit-equal to a lone tracker's."""
+    mp = tc.sequence_map(seq)
+    n = len(seq["px0"])
+    idx = np.arange(n, dtype=np.int32)
+    cfg = dict(max_keyframes=2, max_points=1024, max_obs=1024, max_kf_features=1024, max_candidates=16, max_items=1024,
+               max_frame_features=1024, grid_size=tc.CELL, max_fts=tc.MAX_FTS, klt_min_level=min_level)
+    lone = hip.Tracker(ctx, seq["cam"], **cfg)
+    lone.upload_keyframe(0, seq["pyrs"][0][0])
+    lone.set_map(mp)
+    lone.set_last_frame(seq["T0"], seq["px0"], seq["f0"], idx, kf_slot=0)
+    for k in range(1, len(seq["pyrs"])):
+        want = lone.track(seq["pyrs"][k][0])["T_f_w"]
+    lone.destroy()
+    out = {}
+    for n_cam in cams:
+        grp = hip.TrackerGroup(ctx, seq["cam"], n_cam, **cfg)
+        bufs = [t.image_buffer() for t in grp.cameras]                 # the cameras' frames land in the trackers' own page-locked buffers
+        for t in grp.cameras:
+            t.upload_keyframe(0, seq["pyrs"][0][0])
+        dt = 0.0
+        for rep in range(repeats + 1):
+            for t in grp.cameras:
+                t.set_map(mp)
+                t.set_last_frame(seq["T0"], seq["px0"], seq["f0"], idx, kf_slot=0)
+            ctx.sync()
+            t0 = time.perf_counter()
+            t_copy = 0.0
+            for k in range(1, len(seq["pyrs"])):
+                tc0 = time.perf_counter()
+                for b in bufs:
+                    b[:] = seq["pyrs"][k][0]
+                t_copy += time.perf_counter() - tc0                    # (the camera pipeline's write into the buffer: not the tracker's time)
+                res = grp.track(bufs)
+            if rep > 0:
+                dt += time.perf_counter() - t0 - t_copy
+            for c in range(n_cam):
+                assert list(res[c].T_f_w) == list(want), "camera %d of %d differs from the lone tracker" % (c, n_cam)
+        out[str(n_cam)] = n_cam * repeats * (len(seq["pyrs"]) - 1) / dt
+        grp.destroy()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--min-level", type=int, default=2)     # the shipping default: L4 -> L2
     ap.add_argument("--tracker-only", action="store_true")
     ap.add_argument("--cameras", action="store_true", help="only the multi-camera figure (1 / 2 / 4 / 8 trackers on as many host threads)")
+    ap.add_argument("--camera-counts", default="1,2,4,8")
     args = ap.parse_args()
     if args.cameras:
         seq = tc.make_sequence(n_frames=args.frames)
-        print(json.dumps({"chain_frames_per_s_by_cameras": multi_camera(seq, args.min_level), "min_level": args.min_level}))
+        print(json.dumps({"group_frames_per_s_by_cameras": group_cameras(hip.Context(0), seq, args.min_level, cams=tuple(int(c) for c in args.camera_counts.split(","))),
+                          "min_level": args.min_level}))
+        print(json.dumps({"chain_frames_per_s_by_cameras": multi_camera(seq, args.min_level, cams=tuple(int(c) for c in args.camera_counts.split(","))),
+                          "min_level": args.min_level, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}))
         return
     if args.tracker_only:
         seq = tc.make_sequence(n_frames=args.frames)
