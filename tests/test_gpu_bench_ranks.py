@@ -71,11 +71,12 @@ def test_bench_c4_gpus_2_started_plainly():
 def test_default_bench_line_fits_the_drivers_tail_and_carries_the_contract():
     """`python bench.py` as the driver runs it (N = 1, every secondary section on): ONE JSON line of at most 6 KiB (round 3's 14 kB
     line lost its first half in the driver's tail), with the contract keys, `roofline` and `cpu_baseline` objects, the per-stage
-    bounds of the depth filter and the drop-in entry's timing."""
+    bounds of the depth filter and the drop-in entry's timing.  (The one GPU test whose process maps oracle/_ref/libsvo_ref.so:
+    bench.py's `cpu_baseline` / `c0` legs time the reference's own compiled SparseImgAlign where the prebuilt library is present.)"""
     d_line = None
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True,
-                       text=True, timeout=280)
+                       text=True, timeout=400)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -98,3 +99,16 @@ def test_default_bench_line_fits_the_drivers_tail_and_carries_the_contract():
         assert df["roofline"][stage]["bound"] in ("valu", "hbm") and 0.0 < df["roofline"][stage]["frac"] <= 1.0
         assert 0.0 < d["c4_one_gpu"]["roofline"][stage]["frac"] <= 1.0
     assert d["single_stream_chain"]["L4_L2_shipping_default"]["matched_points_equal_in_every_frame"] is True
+    # the headline is measured at the reference's arithmetic (the library default), the narrower levels are secondary legs
+    assert "as the reference" in d["dtype"] and d["config"]["arithmetic"].startswith("EXACT")
+    assert d["pose_err_vs_cpu_ref"]["max_rot_rad_over_scenes"] < 1e-7
+    # BASELINE config C0 beside C1 (SURVEY 8d "CPU baseline timing"): one pinned core and all cores, both Gauss-Newton modes
+    c0 = d["c0"]
+    assert 100 <= c0["patches"] <= 260 and c0["max_pose_err_vs_cpu"] < 1e-4
+    assert c0["cpu"]["es_ms_1core"] > 0 and c0["cpu"]["fw_ms_1core"] > c0["cpu"]["es_ms_1core"] and c0["cpu"]["kind_es"] in ("reference", "port")
+    assert c0["gpu"]["es_fps"] > c0["cpu"]["es_fps"] and c0["gpu"]["fw_fps"] > c0["cpu"]["fw_fps"]
+    # N cameras: N trackers on N host threads, and one tracker group (one chain of launches per call)
+    ch = d["single_stream_chain"]
+    assert ch["group_frames_per_s"]["8"] > 2.0 * ch["group_frames_per_s"]["1"] and ch["cameras_frames_per_s"]["1"] > 0
+    for stage in ("search", "align"):
+        assert 0.0 < df["roofline"][stage]["lane_util"] <= 1.0

@@ -333,7 +333,12 @@ def main():
     ap.add_argument("--tracker-only", action="store_true")
     ap.add_argument("--cameras", action="store_true", help="only the multi-camera figure (1 / 2 / 4 / 8 trackers on as many host threads)")
     ap.add_argument("--camera-counts", default="1,2,4,8")
+    ap.add_argument("--group-only", action="store_true", help="only svo_hip_tracker_group_track for --camera-counts (tools/trace_group.sh)")
     args = ap.parse_args()
+    if args.group_only:
+        seq = tc.make_sequence(n_frames=args.frames)
+        print(json.dumps({"group_frames_per_s_by_cameras": group_cameras(hip.Context(0), seq, args.min_level, cams=tuple(int(c) for c in args.camera_counts.split(",")))}))
+        return
     if args.cameras:
         seq = tc.make_sequence(n_frames=args.frames)
         print(json.dumps({"group_frames_per_s_by_cameras": group_cameras(hip.Context(0), seq, args.min_level, cams=tuple(int(c) for c in args.camera_counts.split(","))),
