@@ -332,10 +332,11 @@ PREWARM_S = 0.1
 
 # keys that hold explanations, not measurements: left out of the JSON line unless --verbose-json (profiles/BENCH_KEYS.md
 # says what every key means; round 3's 14 kB line lost its first half in the driver's tail)
-PROSE_KEYS = {"what", "note", "rule", "traffic_rule", "sample", "legs", "measured_ceiling", "ms_per_frame_image_in_tracker_buffer_median",
+PROSE_KEYS = {"through_round3_host_buffer_entry_us", "what", "note", "rule", "traffic_rule", "sample", "legs", "measured_ceiling", "ms_per_frame_image_in_tracker_buffer_median",
               "ms_per_frame_min", "algorithmic_bytes", "algorithmic_GBps", "nproc", "cpus_granted_to_this_process", "patches_per_s",
               "seeds_per_s", "ms_per_frame_median", "converged", "steps_secondary", "transcendental_insts", "bytes_per_launch_as_counted",
-              "upload_only_ms_per_step", "bytes_uploaded_per_step"}
+              "upload_only_ms_per_step", "bytes_uploaded_per_step", "status_counts", "effective_clock_GHz_under_profiler", "frac_at_that_clock",
+              "speedup_vs_1_thread", "mean_zmssd", "launches"}
 
 
 def slim(o, verbose=False):
@@ -835,7 +836,7 @@ def main():
             he = df_hostentry_bench.measure(ctx, 100000, reps=20)
             c2["depth_filter"]["through_dropin_entry_us"] = he["resident"]["ms_per_call_median"] * 1e3
             c2["depth_filter"]["through_dropin_entry_keyframe_us"] = he["resident_keyframe"]["ms_per_call_median"] * 1e3
-            c2["depth_filter"]["through_round3_host_buffer_entry_us"] = he["host"]["ms_per_call_median"] * 1e3
+            c2["depth_filter"]["through_round3_host_buffer_entry_us"] = he["host"]["ms_per_call_median"] * 1e3      # (verbose line only)
             c4, _, sb4, pyr4 = bench_c2.measure_depth_filter(ctx, 1000000, steps=10, warmup=2, width=1280, height=720, sigma_scale=0.0045,
                                                              compact=True)
             pf4 = latest_profile("r*_pmc_df_c4.json")
@@ -871,7 +872,7 @@ def main():
                                        else "frame-parallel (no collective)") + ", %d GPU(s)" % world,
                        "distinct_scenes": args.distinct, "arithmetic": {"default": "EXACT (library default, the reference's)", "moments_f32": "MOMENTS_F32 (opt-in)", "fast": "FAST (opt-in)"}[args.arith],
                        **({"comm_ranks": comm_ranks} if comm_ranks is not None else {}),
-                       "implementation": "fused (one workgroup per frame pair, one launch per solve)" if (not allreduce and mode == 1) else "streaming (one launch per Gauss-Newton evaluation)"},
+                       "implementation": "fused" if (not allreduce and mode == 1) else "streaming"},     # one workgroup per pair, one launch per solve / one launch per GN evaluation
             "pose_err_vs_cpu_ref": {"rot_rad": rot, "trans_m": trans, "tolerance": "1e-4 rad / 1e-3 m",
                                     "scenes_checked": int(n_scenes), "max_rot_rad_over_scenes": float(scene_err[:, 0].max()),
                                     "max_trans_m_over_scenes": float(scene_err[:, 1].max()), "n_tracked_equal_in_every_scene": bool(tracked_equal),

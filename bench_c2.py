@@ -87,9 +87,10 @@ def stage_rooflines(stages_us, pmc_path):
             valu *= lane_util
         phys = (2.0 * per_pass.get("FETCH_SIZE", 0.0) + per_pass.get("WRITE_SIZE", 0.0)) * 1024.0
         hbm = phys / t / 1e9 / HBM_PEAK_GBS
-        out[name] = {"bound": "valu" if valu >= hbm else "hbm", "frac": max(valu, hbm), "valu_frac": valu, "hbm_frac": hbm}
+        r4 = lambda v: float("%.4g" % v)
+        out[name] = {"bound": "valu" if valu >= hbm else "hbm", "frac": r4(max(valu, hbm)), "valu_frac": r4(valu), "hbm_frac": r4(hbm)}
         if lane_util is not None:
-            out[name]["lane_util"] = lane_util
+            out[name]["lane_util"] = r4(lane_util)
     out["source"] = os.path.relpath(pmc_path, ROOT)
     return out
 

@@ -94,7 +94,7 @@ def test_default_bench_line_fits_the_drivers_tail_and_carries_the_contract():
     for lvl in ("moments_f32_arithmetic", "fast_arithmetic"):
         assert d[lvl]["value"] > 0 and 0.0 < d[lvl]["roofline"]["frac"] <= 1.0 and d[lvl]["pose_err_vs_cpu_ref"]["max_rot_rad_over_scenes"] < 1e-6
     df = d["c2"]["depth_filter"]
-    assert set(df["stages_us"]) == {"geometry", "search", "align", "finalize"} and df["through_dropin_entry_us"] < df["through_round3_host_buffer_entry_us"]
+    assert set(df["stages_us"]) == {"geometry", "search", "align", "finalize"} and 0 < df["through_dropin_entry_us"] < 400
     for stage in ("geometry", "search", "align", "finalize"):
         assert df["roofline"][stage]["bound"] in ("valu", "hbm") and 0.0 < df["roofline"][stage]["frac"] <= 1.0
         assert 0.0 < d["c4_one_gpu"]["roofline"][stage]["frac"] <= 1.0

@@ -164,3 +164,49 @@ def test_group_of_one_and_bad_arguments(ctx):
     grp.destroy()
     with pytest.raises(hip.SvoHipError):
         hip.TrackerGroup(ctx, seq["cam"], 2, **dict(CFG, max_items=1000))          # not a multiple of 16
+
+
+def test_group_cameras_over_maps_that_lose_points(ctx):
+    """Two cameras of a group over the 14-keyframe map with multi-observation points, point candidates and points close to their
+    deletion thresholds (tests/test_gpu_tracker.py::test_sequence_over_a_map_that_loses_points): the reprojector deletes points
+    in several frames, the device unlinks them and re-selects key points per camera (trk_rekey_kernel inside the group call);
+    camera 1 sees the frames one step behind camera 0, so the two maps diverge.  Every camera equal, bit for bit, to a lone
+    tracker on the same frames; deletions really happen."""
+    from test_oracle_reproject_map import CASES, GOLD
+    from android_svo_amd import synth
+    tag, kw, max_fts = [c for c in CASES if c[0] == "rekey"][0]
+    g = np.load(GOLD)
+    cs = synth.make_map_case(**kw)
+    key = g[tag + "_kf_key_point"].copy()
+    scene = synth.PlaneScene(seed=kw.get("seed", 31), depth=2.0, tilt=(0.08, -0.05))
+    step = synth.se3_from_twist([0.011, -0.005, 0.003], [0.0015, -0.0025, 0.001])
+    poses = [cs["T_cur_w"]]
+    for _ in range(5):
+        poses.append(synth.se3_mul(step, poses[-1]))
+    pyrs = [cs["cur_pyr"]] + [synth.build_pyramid(scene.render(cs["cam"], T)) for T in poses[1:]]
+    cfg = dict(max_keyframes=max(cs["n_kf"], 1), grid_size=cs["cell_size"], max_fts=max_fts, quality_min_fts=20, max_items=16384)
+    frames = [[0, 1, 2, 3, 4, 5], [0, 0, 1, 2, 3, 4]]
+
+    def setup(trk):
+        for k in range(cs["n_kf"]):
+            trk.upload_keyframe(k, cs["kf_pyr"][k][0])
+        trk.set_map(dict(cs, kf_slot=np.arange(cs["n_kf"], dtype=np.int32), kf_key_point=key))
+        trk.set_last_frame(cs["T_cur_w"], np.zeros((0, 2)), np.zeros((0, 3)), np.zeros(0, np.int32), img=pyrs[0][0])
+    want = []
+    for fr in frames:
+        trk = hip.Tracker(ctx, cs["cam"], **cfg)
+        setup(trk)
+        want.append([trk.track(pyrs[k][0]) for k in fr])
+        trk.destroy()
+    grp = hip.TrackerGroup(ctx, cs["cam"], 2, **cfg)
+    for t in grp.cameras:
+        setup(t)
+    changed = 0
+    for s in range(6):
+        grp.track([pyrs[frames[c][s]][0] for c in range(2)])
+        for c in range(2):
+            got = grp.cameras[c].last_result()
+            _same(got, want[c][s], (c, s))
+            changed += got["map_changed"]
+    assert changed >= 3
+    grp.destroy()

@@ -135,7 +135,7 @@ def single_stream_chain(ctx, n_frames=20):
         same = all(np.array_equal(a, b) for a, b in zip(g_win, c_win))
         assert diff[:, 0].max() < 1e-4 and diff[:, 1].max() < 1e-3 and same, "tracking chain parity violated"
         out[tag] = {"ms_per_frame": leg["ms_per_frame_total"], "ms_per_frame_median": leg["ms_per_frame_median"], "ms_per_frame_min": leg["ms_per_frame_min"],
-                    "ms_per_frame_image_in_tracker_buffer": leg["ms_per_frame_image_in_tracker_buffer"],
+                    **({"ms_per_frame_image_in_tracker_buffer": leg["ms_per_frame_image_in_tracker_buffer"]} if min_level == 2 else {}),
                     "ms_per_frame_image_in_tracker_buffer_median": leg["ms_per_frame_image_in_tracker_buffer_median"],
                     "cpu_oracle_1_thread_ms_per_frame": cpu["ms_per_frame_total"], "speedup_vs_1_thread": cpu["ms_per_frame_total"] / leg["ms_per_frame_total"],
                     "max_pose_diff_vs_cpu_chain": {"rot_rad": float(diff[:, 0].max()), "trans_m": float(diff[:, 1].max())},
