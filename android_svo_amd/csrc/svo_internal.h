@@ -31,6 +31,10 @@ struct svo_hip_ctx {
   size_t staging_bytes = 0;
   void* host_staging = nullptr;     // grow-only page-locked host mirror of it: one transfer each way per call
   size_t host_staging_bytes = 0;
+  // svo_hip_pyramid_upload leaves ONE transfer out of the host staging area in flight when it returns (it does not synchronise):
+  // the next user of the area waits for this event first
+  hipEvent_t host_staging_ev = nullptr;
+  bool host_staging_in_flight = false;
   // stage timing of the depth-filter pass (svo_hip_df_set_profiling): events around geometry / search / align / finalize
   bool df_profile = false;
   int df_small_max = 8192;             // passes of at most this many seed records take the two-launch form (svo_depth.hip)
@@ -117,6 +121,10 @@ inline int svo_ctx_staging(svo_hip_ctx* ctx, size_t need, char** out) {
 // page-locked host area of the same kind: the entry points gather their (pageable) arguments here and move them with
 // one transfer instead of one ~10 us transfer per array
 inline int svo_ctx_host_staging(svo_hip_ctx* ctx, size_t need, char** out) {
+  if (ctx->host_staging_in_flight) {          // an asynchronous pyramid upload still reads the area
+    SVO_CHECK_HIP(ctx, hipEventSynchronize(ctx->host_staging_ev));
+    ctx->host_staging_in_flight = false;
+  }
   if (ctx->host_staging_bytes < need) {
     if (ctx->host_staging) {
       SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
