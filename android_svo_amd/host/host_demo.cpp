@@ -4,6 +4,9 @@
 // Usage: svo_host_demo <case_dir> <out_dir>      (inputs written by tests/test_gpu_host_cpp.py)
 //        svo_host_demo <case_dir> <out_dir> track   the tracking chain: svo::FrameTracker (hip_bridge::FrameTrackerT on this
 //                                                   file's data model) over a map built as an object graph from index tables
+//        svo_host_demo <case_dir> <out_dir> trackgroup [n]   the same tracking chain for n (default 2) copies of the world at once through
+//                                                   svo::FrameTrackerGroup (hip_bridge::FrameTrackerGroupT, svo_hip_tracker_group): outputs of
+//                                                   world w under <out_dir>/g<w>/, each equal to the lone tracker's
 //        svo_host_demo <case_dir> <out_dir> churn   SURVEY 8(b) "Threading": latency of SparseImgAlign::run on the tracking
 //                                                   thread while a second thread (own context) creates seed batches, runs a
 //                                                   pass and drops them at keyframe rate -- and with that thread idle
@@ -15,6 +18,7 @@
 #include <iostream>
 #include <map>
 #include <string>
+#include <sys/stat.h>
 
 #include "svo_host.h"
 
@@ -63,7 +67,58 @@ static void dump_filter(DepthFilter& df, const std::map<Feature*, int>& index, c
 // ---- svo::FrameTracker over a svo::Map: the object graph (frames, features, points with their observation lists,
 // point candidates) is built from the index tables the test wrote, the frames are tracked one after the other (each
 // tracked frame is the next one's last frame), and what the tracker left on the objects is written out as tables again.
-static int track_demo(const std::string& dir, const std::string& out) {
+// What track_demo tracks through: a lone svo::FrameTracker, or camera w of a svo::FrameTrackerGroup.  In a group the worlds run on
+// one thread each but in lockstep: a thread only runs while it holds the rendezvous' mutex (the C-ABI context is one host thread's
+// at a time), gives it up inside track() and goes on when the group call -- made by the last world to arrive -- has returned.
+typedef hip_bridge::FrameTrackerT<HostTrackerPolicy> TrackerCamera;
+struct GroupRendezvous {
+  std::mutex mu;
+  std::condition_variable cv;
+  FrameTrackerGroup* group = nullptr;
+  size_t n = 0, arrived = 0, failed = 0;                // failed: worlds that gave up (the others must not wait for them)
+  unsigned long generation = 0;
+  bool ok = true;
+  std::vector<FramePtr> last, cur;
+  std::vector<Map*> maps;
+  std::vector<std::vector<std::pair<FramePtr, size_t>>> overlap;
+  std::vector<TrackerCamera::Outcome> out;
+};
+struct TrackerPort {
+  FrameTracker* lone = nullptr;
+  GroupRendezvous* rz = nullptr;
+  std::unique_lock<std::mutex>* baton = nullptr;       // the world thread's hold on rz->mu
+  size_t w = 0;
+  TrackerCamera& camera() { return lone ? static_cast<TrackerCamera&>(*lone) : rz->group->camera(w); }
+  bool track(const FramePtr& last, const FramePtr& cur, Map& map, std::vector<std::pair<FramePtr, size_t>>& overlap, TrackerCamera::Outcome& oc) {
+    if (lone) return lone->track(last, cur, map, overlap, oc);
+    GroupRendezvous& r = *rz;
+    if (r.failed) return false;
+    r.last[w] = last; r.cur[w] = cur; r.maps[w] = &map;
+    const unsigned long my_gen = r.generation;
+    if (++r.arrived == r.n) {
+      r.ok = r.group->trackAll(r.last, r.cur, r.maps, r.overlap, r.out);
+      r.arrived = 0;
+      ++r.generation;
+      r.cv.notify_all();
+    } else {
+      r.cv.wait(*baton, [&]() { return r.generation != my_gen; });
+      if (r.failed) return false;
+    }
+    if (r.ok) { overlap = r.overlap[w]; oc = r.out[w]; }
+    return r.ok;
+  }
+};
+
+static svo_hip_tracker_config track_config(const std::vector<double>& m) {
+  svo_hip_tracker_config cfg;
+  svo_hip_tracker_default_config(&cfg);
+  cfg.max_keyframes = (int)m[6] + 2;                                          // room for a frame that becomes a keyframe
+  cfg.grid_size = (int)m[12]; cfg.max_fts = (int)m[13]; cfg.quality_min_fts = (int)m[14];
+  cfg.klt_min_level = (int)m[15]; cfg.max_frame_features = (int)m[16];
+  return cfg;
+}
+
+static int track_demo(const std::string& dir, const std::string& out, TrackerPort& port) {
   const std::vector<double> m = read_bin<double>(dir + "/track_manifest.bin");
   PinholeCamera cam{(int)m[0], (int)m[1], m[2], m[3], m[4], m[5]};
   const int n_kf = (int)m[6], n_points = (int)m[7], n_obs = (int)m[8], n_cand = (int)m[10], n_frames = (int)m[11];
@@ -121,12 +176,7 @@ static int track_demo(const std::string& dir, const std::string& out) {
   };
   write_bin(out + "/track_key_before.bin", key_table());
 
-  svo_hip_tracker_config cfg;
-  svo_hip_tracker_default_config(&cfg);
-  cfg.max_keyframes = n_kf + 2;                                               // room for a frame that becomes a keyframe
-  cfg.grid_size = (int)m[12]; cfg.max_fts = (int)m[13]; cfg.quality_min_fts = (int)m[14];
-  cfg.klt_min_level = (int)m[15]; cfg.max_frame_features = (int)m[16];
-  FrameTracker tracker(cam, cfg);
+  TrackerCamera& tracker = port.camera();
   if (!tracker.ok()) throw std::runtime_error("svo::FrameTracker: no device tracker");
 
   // the last frame: a keyframe of the map, or a frame of its own without features (SparseImgAlign::run then returns at once)
@@ -147,7 +197,7 @@ static int track_demo(const std::string& dir, const std::string& out) {
     FramePtr cur = std::make_shared<Frame>(&cam, std::move(pyr));
     std::vector<std::pair<FramePtr, size_t>> overlap_kfs;
     FrameTracker::Outcome oc;
-    if (!tracker.track(last, cur, map, overlap_kfs, oc)) throw std::runtime_error("svo::FrameTracker::track failed at frame " + std::to_string(k));
+    if (!port.track(last, cur, map, overlap_kfs, oc)) throw std::runtime_error("svo::FrameTracker::track failed at frame " + std::to_string(k));
     poses.insert(poses.end(), cur->T_f_w_.p, cur->T_f_w_.p + 7);
     stats.insert(stats.end(), {(double)cur->fts_.size(), (double)oc.repr_n_matches, (double)oc.repr_n_trials, (double)oc.img_align_n_tracked,
                                oc.pose_optimised ? 1.0 : 0.0, (double)oc.sfba_n_edges_final, oc.sfba_error_init, oc.sfba_error_final, (double)overlap_kfs.size()});
@@ -225,7 +275,48 @@ static int track_demo(const std::string& dir, const std::string& out) {
   write_bin(out + "/track_stats.bin", stats);
   write_bin(out + "/track_uploads.bin", uploads);
   write_bin(out + "/track_overlap_first.bin", overlap);
-  std::printf("svo_host_demo track OK\n");
+  if (port.lone) std::printf("svo_host_demo track OK\n");
+  return 0;
+}
+
+static int track_lone(const std::string& dir, const std::string& out) {
+  const std::vector<double> m = read_bin<double>(dir + "/track_manifest.bin");
+  PinholeCamera cam{(int)m[0], (int)m[1], m[2], m[3], m[4], m[5]};
+  FrameTracker tracker(cam, track_config(m));
+  TrackerPort port;
+  port.lone = &tracker;
+  return track_demo(dir, out, port);
+}
+
+// n copies of the world, one svo::FrameTrackerGroup: every world's outputs must equal the lone tracker's
+static int track_group(const std::string& dir, const std::string& out, int n) {
+  const std::vector<double> m = read_bin<double>(dir + "/track_manifest.bin");
+  PinholeCamera cam{(int)m[0], (int)m[1], m[2], m[3], m[4], m[5]};
+  svo_hip_tracker_config cfg = track_config(m);
+  cfg.max_items = (cfg.max_items + 15) / 16 * 16;
+  FrameTrackerGroup group(cam, cfg, n);
+  if (!group.ok()) throw std::runtime_error("svo::FrameTrackerGroup: no device tracker group");
+  GroupRendezvous rz;
+  rz.group = &group; rz.n = (size_t)n;
+  rz.last.resize((size_t)n); rz.cur.resize((size_t)n); rz.maps.resize((size_t)n); rz.overlap.resize((size_t)n); rz.out.resize((size_t)n);
+  std::vector<std::string> errors((size_t)n);
+  for (int w = 0; w < n; ++w) (void)::mkdir((out + "/g" + std::to_string(w)).c_str(), 0755);
+  std::vector<std::thread> worlds;
+  for (int w = 0; w < n; ++w)
+    worlds.emplace_back([&, w]() {
+      std::unique_lock<std::mutex> baton(rz.mu);                               // this world runs only while it holds the baton
+      TrackerPort port;
+      port.rz = &rz; port.baton = &baton; port.w = (size_t)w;
+      try {
+        track_demo(dir, out + "/g" + std::to_string(w), port);
+      } catch (const std::exception& e) {
+        errors[(size_t)w] = e.what();
+        rz.ok = false; ++rz.failed; ++rz.generation; rz.cv.notify_all();      // let the others go (they fail at their next frame)
+      }
+    });
+  for (std::thread& t : worlds) t.join();
+  for (const std::string& e : errors) if (!e.empty()) throw std::runtime_error(e);
+  std::printf("svo_host_demo trackgroup OK (%d worlds)\n", n);
   return 0;
 }
 
@@ -324,6 +415,14 @@ static int churn_demo(const std::string& dir, const std::string& out) {
 int main(int argc, char** argv) {
   if (argc < 3) { std::fprintf(stderr, "usage: %s case_dir out_dir [track|churn]\n", argv[0]); return 2; }
   const std::string dir = argv[1], out = argv[2];
+  if (argc > 3 && std::string(argv[3]) == "trackgroup") {
+    try {
+      return track_group(dir, out, argc > 4 ? std::atoi(argv[4]) : 2);
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "svo_host_demo FAILED: %s\n", e.what());
+      return 1;
+    }
+  }
   if (argc > 3 && std::string(argv[3]) == "churn") {
     try {
       return churn_demo(dir, out);
@@ -334,7 +433,7 @@ int main(int argc, char** argv) {
   }
   if (argc > 3 && std::string(argv[3]) == "track") {
     try {
-      return track_demo(dir, out);
+      return track_lone(dir, out);
     } catch (const std::exception& e) {
       std::fprintf(stderr, "svo_host_demo FAILED: %s\n", e.what());
       return 1;

@@ -271,6 +271,13 @@ class FrameTracker : public hip_bridge::FrameTrackerT<HostTrackerPolicy> {
   FrameTracker(const PinholeCamera& cam, const svo_hip_tracker_config& cfg) : hip_bridge::FrameTrackerT<HostTrackerPolicy>(cam.toC(), cfg) {}
 };
 
+/// N cameras with a map each, tracked together (hip_bridge::FrameTrackerGroupT on this file's data model; svo_hip_tracker_group)
+class FrameTrackerGroup : public hip_bridge::FrameTrackerGroupT<HostTrackerPolicy> {
+ public:
+  FrameTrackerGroup(const PinholeCamera& cam, const svo_hip_tracker_config& cfg, int n_cameras)
+      : hip_bridge::FrameTrackerGroupT<HostTrackerPolicy>(cam.toC(), cfg, n_cameras) {}
+};
+
 /// I/sparse_img_align.h:33-79
 class SparseImgAlign {
  public:

@@ -42,7 +42,8 @@ namespace hip_bridge {
 /// svo_hip_ctx with scope (the bindings' Context of svo_hip_bridge.h is the same thing on the reference's side)
 class TrackerContext {
  public:
-  explicit TrackerContext(int device) : ctx_(NULL) { if (svo_hip_ctx_create(&ctx_, device, NULL) != SVO_HIP_OK) ctx_ = NULL; }
+  /// device < 0: no context of its own (a camera of a FrameTrackerGroupT uses the group's)
+  explicit TrackerContext(int device) : ctx_(NULL) { if (device >= 0 && svo_hip_ctx_create(&ctx_, device, NULL) != SVO_HIP_OK) ctx_ = NULL; }
   ~TrackerContext() { if (ctx_) svo_hip_ctx_destroy(ctx_); }
   bool ok() const { return ctx_ != NULL; }
   svo_hip_ctx* get() const { return ctx_; }
@@ -70,10 +71,13 @@ class FrameTrackerT {
 
   /// cfg: svo_hip_tracker_default_config with the caller's Config values filled in (the bindings do that)
   FrameTrackerT(const svo_hip_camera& cam, const svo_hip_tracker_config& cfg)
-      : ctx_(0), trk_(NULL), cfg_(cfg), map_dirty_(true), have_last_(false) {
+      : ctx_(0), err_ctx_(ctx_.get()), trk_(NULL), owns_trk_(true), cfg_(cfg), map_dirty_(true), have_last_(false) {
     if (ctx_.ok() && svo_hip_tracker_create(ctx_.get(), &cam, &cfg, &trk_) != SVO_HIP_OK) trk_ = NULL;
   }
-  ~FrameTrackerT() { if (trk_) svo_hip_tracker_destroy(trk_); }
+  /// a camera of a FrameTrackerGroupT: handle and context belong to the group (svo_hip_tracker_group_camera)
+  FrameTrackerT(svo_hip_ctx* group_ctx, svo_hip_tracker* camera, const svo_hip_tracker_config& cfg)
+      : ctx_(-1), err_ctx_(group_ctx), trk_(camera), owns_trk_(false), cfg_(cfg), map_dirty_(true), have_last_(false) {}
+  ~FrameTrackerT() { if (trk_ && owns_trk_) svo_hip_tracker_destroy(trk_); }
   bool ok() const { return trk_ != NULL; }
   /// how often the map has been flattened and uploaded (diagnostic)
   size_t mapUploads() const { return n_uploads_; }
@@ -110,6 +114,22 @@ class FrameTrackerT {
   /// Returns false on a device error (the caller treats the frame as a tracking failure).
   bool track(const FramePtr& last_frame, const FramePtr& new_frame, Map& map,
              std::vector<std::pair<FramePtr, size_t> >& overlap_kfs, Outcome& out) {
+    const uint8_t* level0 = NULL;
+    if (!prepare(last_frame, new_frame, map, &level0)) return false;
+    svo_hip_track_result r;
+    if (svo_hip_tracker_track(trk_, level0, &r, f_px_.data(), f_f_.data(), f_level_.data(), f_point_.data(), f_edge_.data(), f_grad_.data(),
+                              p_type_.data(), p_failed_.data(), p_succ_.data()) != SVO_HIP_OK) {
+      fprintf(stderr, "[svo_hip] FrameTracker::track FAILED: %s\n", svo_hip_last_error(err_ctx_));
+      return false;
+    }
+    apply(r, new_frame, map, overlap_kfs, out);
+    return true;
+  }
+
+  /// The host side BEFORE the device call: the map flattened again if it changed, the last frame handed over if somebody else
+  /// set it, the new frame's full-resolution image (*level0: valid until the next prepare).  track() = prepare + the device
+  /// call + apply; a FrameTrackerGroupT calls prepare on every camera, svo_hip_tracker_group_track once, then fetch + apply.
+  bool prepare(const FramePtr& last_frame, const FramePtr& new_frame, Map& map, const uint8_t** level0_out) {
     if (!trk_) return false;
     if (!map_dirty_) {
       // the depth filter's thread adds candidates behind the tracker's back (its convergence callback is
@@ -121,22 +141,28 @@ class FrameTrackerT {
     if (!have_last_ && !uploadLastFrame(*last_frame)) return false;
     int stride = 0, cols = 0, rows = 0;
     const uint8_t* level0 = Host::level0(*new_frame, &stride, &cols, &rows);
-    std::vector<uint8_t> packed;
     if (stride != cols) {                                    // the kernels assume stride == cols
-      packed.resize((size_t)rows * cols);
-      for (int y = 0; y < rows; ++y) memcpy(&packed[(size_t)y * cols], level0 + (size_t)y * stride, cols);
-      level0 = packed.data();
+      packed_.resize((size_t)rows * cols);
+      for (int y = 0; y < rows; ++y) memcpy(&packed_[(size_t)y * cols], level0 + (size_t)y * stride, cols);
+      level0 = packed_.data();
     }
     const size_t cap = (size_t)cfg_.max_frame_features, np = points_.size();
     f_px_.resize(cap * 2); f_f_.resize(cap * 3); f_level_.resize(cap); f_point_.resize(cap); f_edge_.resize(cap); f_grad_.resize(cap * 2);
     p_type_.resize(np + 1); p_failed_.resize(np + 1); p_succ_.resize(np + 1);
-    svo_hip_track_result r;
-    if (svo_hip_tracker_track(trk_, level0, &r, f_px_.data(), f_f_.data(), f_level_.data(), f_point_.data(), f_edge_.data(), f_grad_.data(),
-                              p_type_.data(), p_failed_.data(), p_succ_.data()) != SVO_HIP_OK) {
-      fprintf(stderr, "[svo_hip] FrameTracker::track FAILED: %s\n", svo_hip_last_error(ctx_.get()));
-      return false;
-    }
-    // ---- what processFrame would have found on its objects after the three stages
+    *level0_out = level0;
+    return true;
+  }
+
+  /// a group's camera after svo_hip_tracker_group_track: the frame's features and point counters out of the camera's result block
+  bool fetch(svo_hip_track_result* r) {
+    return trk_ && svo_hip_tracker_last_result(trk_, r, f_px_.data(), f_f_.data(), f_level_.data(), f_point_.data(), f_edge_.data(), f_grad_.data(),
+                                               p_type_.data(), p_failed_.data(), p_succ_.data()) == SVO_HIP_OK;
+  }
+
+  /// The host side AFTER the device call: what processFrame would have found on its objects after the three stages
+  void apply(const svo_hip_track_result& r, const FramePtr& new_frame, Map& map, std::vector<std::pair<FramePtr, size_t> >& overlap_kfs,
+             Outcome& out) {
+    const size_t np = points_.size();
     Host::setPose(*new_frame, r.T_f_w);
     for (int i = 0; i < r.n_features; ++i) {                 // Reprojector::reprojectCell :217-231
       Feature* ftr = Host::makeFeature(&*new_frame, &f_px_[2 * i], &f_f_[3 * i], f_level_[i]);      // new Feature(frame, px, f, level)
@@ -170,7 +196,6 @@ class FrameTrackerT {
     out.sfba_thresh = r.pose.estimated_scale; out.sfba_error_init = r.pose.error_init; out.sfba_error_final = r.pose.error_final;
     if (r.pose.ran) Host::setCov(*new_frame, r.pose.Cov);
     have_last_ = true;                                       // the device handed the frame over to itself
-    return true;
   }
 
   /// FrameHandlerBase::optimizeStructure(frame, max_n_pts, max_iter) (S/frame_handler_base.cpp:190-210) with Point::optimize on
@@ -347,7 +372,9 @@ class FrameTrackerT {
   }
 
   TrackerContext ctx_;
+  svo_hip_ctx* err_ctx_;                                     // the context whose last error a failure reports (own or the group's)
   svo_hip_tracker* trk_;
+  bool owns_trk_;
   svo_hip_tracker_config cfg_;
   bool map_dirty_, have_last_;
   size_t n_uploads_ = 0;
@@ -359,6 +386,64 @@ class FrameTrackerT {
   std::vector<double> f_px_, f_f_, f_grad_;
   std::vector<int32_t> f_level_, f_point_, p_type_, p_failed_, p_succ_;
   std::vector<uint8_t> f_edge_;
+  std::vector<uint8_t> packed_;                              // a padded image compacted to stride == cols
+};
+
+/// N cameras -- N FrameHandlerMono objects, each with its own svo::Map -- tracked together: svo_hip_tracker_group (one chain of
+/// launches per call for all of them).  camera(c) is camera c's FrameTrackerT (mapChanged, pointsOptimised, optimiseStructure,
+/// lastFrameBecameKeyframe, imageBuffer as for a lone tracker); trackAll is processFrame's three stages for every camera.
+template <class Host>
+class FrameTrackerGroupT {
+ public:
+  typedef FrameTrackerT<Host> Camera;
+  typedef typename Host::FramePtr FramePtr;
+  typedef typename Host::Map Map;
+  typedef typename Camera::Outcome Outcome;
+
+  FrameTrackerGroupT(const svo_hip_camera& cam, const svo_hip_tracker_config& cfg, int n_cameras) : ctx_(0), group_(NULL) {
+    if (ctx_.ok() && svo_hip_tracker_group_create(ctx_.get(), &cam, &cfg, n_cameras, &group_) != SVO_HIP_OK) group_ = NULL;
+    for (int c = 0; group_ && c < n_cameras; ++c) {
+      svo_hip_tracker* t = NULL;
+      if (svo_hip_tracker_group_camera(group_, c, &t) != SVO_HIP_OK) { svo_hip_tracker_group_destroy(group_); group_ = NULL; break; }
+      cameras_.push_back(new Camera(ctx_.get(), t, cfg));
+    }
+  }
+  ~FrameTrackerGroupT() {
+    for (size_t c = 0; c < cameras_.size(); ++c) delete cameras_[c];
+    if (group_) svo_hip_tracker_group_destroy(group_);
+  }
+  bool ok() const { return group_ != NULL; }
+  size_t size() const { return cameras_.size(); }
+  Camera& camera(size_t c) { return *cameras_[c]; }
+
+  /// one frame of every camera: last[c] -> fresh[c] over maps[c].  Returns false on a device error (every camera's frame is then
+  /// a tracking failure for its caller); overlap_kfs / out: one entry per camera.
+  bool trackAll(const std::vector<FramePtr>& last, const std::vector<FramePtr>& fresh, const std::vector<Map*>& maps,
+                std::vector<std::vector<std::pair<FramePtr, size_t> > >& overlap_kfs, std::vector<Outcome>& out) {
+    const size_t n = cameras_.size();
+    if (!group_ || last.size() != n || fresh.size() != n || maps.size() != n) return false;
+    std::vector<const uint8_t*> img(n, (const uint8_t*)NULL);
+    for (size_t c = 0; c < n; ++c)
+      if (!cameras_[c]->prepare(last[c], fresh[c], *maps[c], &img[c])) return false;
+    std::vector<svo_hip_track_result> res(n);
+    if (svo_hip_tracker_group_track(group_, img.data(), res.data()) != SVO_HIP_OK) {
+      fprintf(stderr, "[svo_hip] FrameTrackerGroup::trackAll FAILED: %s\n", svo_hip_last_error(ctx_.get()));
+      return false;
+    }
+    overlap_kfs.resize(n); out.resize(n);
+    for (size_t c = 0; c < n; ++c) {
+      if (!cameras_[c]->fetch(&res[c])) return false;
+      cameras_[c]->apply(res[c], fresh[c], *maps[c], overlap_kfs[c], out[c]);
+    }
+    return true;
+  }
+
+ private:
+  FrameTrackerGroupT(const FrameTrackerGroupT&);
+  FrameTrackerGroupT& operator=(const FrameTrackerGroupT&);
+  TrackerContext ctx_;
+  svo_hip_tracker_group* group_;
+  std::vector<Camera*> cameras_;
 };
 
 }  // namespace hip_bridge

@@ -72,6 +72,21 @@ class FrameTracker : public FrameTrackerT<SvoTrackerHost> {
       : FrameTrackerT<SvoTrackerHost>(toCamera(cam), SvoTrackerHost::config(max_keyframes)) {}
 };
 
+/// Several FrameHandlerMono objects (cameras, or sequences replayed side by side) tracked together: one chain of launches per
+/// call for all of them (svo_hip_tracker_group).  camera(c) is camera c's FrameTrackerT; trackAll replaces the three stages of
+/// every camera's processFrame (INTEGRATION.md "Several cameras per call").
+class FrameTrackerGroup : public FrameTrackerGroupT<SvoTrackerHost> {
+ public:
+  FrameTrackerGroup(vk::AbstractCamera* cam, int n_cameras, int max_keyframes = 256)
+      : FrameTrackerGroupT<SvoTrackerHost>(toCamera(cam), groupConfig(max_keyframes), n_cameras) {}
+ private:
+  static svo_hip_tracker_config groupConfig(int max_keyframes) {
+    svo_hip_tracker_config cfg = SvoTrackerHost::config(max_keyframes);
+    cfg.max_items = (cfg.max_items + 15) / 16 * 16;          // a block of the batched warp stage takes 16 candidates of ONE camera
+    return cfg;
+  }
+};
+
 }  // namespace hip_bridge
 }  // namespace svo
 

@@ -396,3 +396,52 @@ def test_cpp_frame_tracker_promotes_a_frame_to_keyframe(tmp_path):
     assert used_new_kf
     trk.destroy(); ctx.close()
 
+
+
+def _files_equal(a_dir, b_dir):
+    names = sorted(f for f in os.listdir(a_dir) if f.startswith("track_") and f.endswith(".bin"))
+    assert len(names) > 10
+    for f in names:
+        if f == "track_uploads.bin":
+            continue
+        assert (a_dir / f).read_bytes() == (b_dir / f).read_bytes(), f
+    return names
+
+
+@pytest.mark.parametrize("which", ["sequence", "deletions"])
+def test_cpp_frame_tracker_group_equals_the_lone_tracker(tmp_path, which):
+    """svo::FrameTrackerGroup (hip_bridge::FrameTrackerGroupT, the template a drop-in with several FrameHandlerMono objects would
+    instantiate on the reference's types; svo_hip_tracker_group underneath): three copies of the world -- map object graph,
+    frames, candidates -- tracked together, one group call per frame-set, every camera's outcome applied to its own objects
+    (features added, counters, Map::safeDeletePoint, a tracked frame turned into a keyframe, a candidate added behind the tracker's
+    back, structure optimisation).  Every file a world writes must equal, byte for byte, what the lone svo::FrameTracker wrote
+    for the same case."""
+    import tracking_chain as tc
+    from test_oracle_reproject_map import CASES
+    assert os.path.exists(DEMO)
+    case, out, outg = tmp_path / "case", tmp_path / "out", tmp_path / "outg"
+    case.mkdir(); out.mkdir(); outg.mkdir()
+    if which == "sequence":
+        seq = tc.make_sequence(n_frames=12)
+        mp = tc.sequence_map(seq)
+        n = len(seq["px0"])
+        cs = dict(mp, obs_point=np.arange(n, dtype=np.int32), kf_ftr_obs=np.arange(n, dtype=np.int32), cand_obs=np.zeros(0, np.int32))
+        cfg = dict(grid_size=tc.CELL, max_fts=tc.MAX_FTS, quality_min_fts=40, klt_min_level=2, max_frame_features=1024, keyframe_at=5)
+        _write_track_case(case, cs, [seq["pyrs"][k][0] for k in range(1, 12)], cfg, last_kf=0)
+    else:
+        tag, kw, max_fts = [c for c in CASES if c[0] == "wide"][0]
+        cs = synth.make_map_case(**kw)
+        cfg = dict(grid_size=cs["cell_size"], max_fts=max_fts, quality_min_fts=20, klt_min_level=2, max_frame_features=2048,
+                   structure_optim_max_pts=20, new_candidate_at=1)
+        scene = synth.PlaneScene(seed=kw.get("seed", 31), depth=2.0, tilt=(0.08, -0.05))
+        step = synth.se3_from_twist([0.012, -0.006, 0.004], [0.002, -0.003, 0.001])
+        T2 = synth.se3_mul(step, cs["T_cur_w"])
+        _write_track_case(case, cs, [cs["cur_pyr"][0], scene.render(cs["cam"], T2), scene.render(cs["cam"], synth.se3_mul(step, T2))], cfg,
+                          last_kf=-1, last_img=cs["cur_pyr"][0], last_pose=cs["T_cur_w"])
+    _run_track_demo(case, out)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([DEMO, str(case), str(outg), "trackgroup", "3"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "trackgroup OK (3 worlds)" in p.stdout
+    for w in range(3):
+        _files_equal(out, outg / ("g%d" % w))
