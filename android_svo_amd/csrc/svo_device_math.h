@@ -318,6 +318,39 @@ SVO_DEV void jacobian_xyz2uv(const double* p, double* J) {
 // Sums as Eigen 3.4 evaluates them inside its unrolled fixed-size triangular solves (Core/SolveTriangular.h,
 // Core/Redux.h): redux_tree = binary splitting [0, n/2) + [n/2, n) of the scalar unroller; redux_packet2 = the
 // SSE2 form used when both operands are contiguous (two lanes summed packet-wise, lanes added, then the remainder).
+// ---- SparseImgAlign: a patch's share of the normal equations (svo_sia.hip, svo_nlls.hip)
+// The 21 upper-triangle entries (row-major) of  sxx AA^T + sxy (AB^T + BA^T) + syy BB^T.
+SVO_DEV void patch_hessian(const double* A, const double* B, double sxx, double sxy, double syy, double* hp) {
+  int e = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) {
+      hp[e] = sxx * (A[i] * A[j]) + sxy * (A[i] * B[j] + B[i] * A[j]) + syy * (B[i] * B[j]);
+      ++e;
+    }
+}
+
+// A = row 0, B = row 1 of Frame::jacobian_xyz2uv (I/frame.h:110-132) times fx/2^L, from {x,y,z,1/z}
+SVO_DEV void patch_jacobian_rows(double x, double y, double z_inv, double jscale, double* A, double* B) {
+  const double z_inv_2 = z_inv * z_inv;
+  const double j02 = x * z_inv_2;
+  const double j03 = y * j02;
+  const double j12 = y * z_inv_2;
+  A[0] = -z_inv * jscale;
+  A[1] = 0.0 * jscale;
+  A[2] = j02 * jscale;
+  A[3] = j03 * jscale;
+  A[4] = -(1.0 + x * j02) * jscale;
+  A[5] = (y * z_inv) * jscale;
+  B[0] = 0.0 * jscale;
+  B[1] = -z_inv * jscale;
+  B[2] = j12 * jscale;
+  B[3] = (1.0 + y * j12) * jscale;
+  B[4] = -j03 * jscale;
+  B[5] = (-x * z_inv) * jscale;
+}
+
 template <int N>
 SVO_DEV double redux_tree(const double* a) {
   if constexpr (N == 1) return a[0];

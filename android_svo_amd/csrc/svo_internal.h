@@ -167,6 +167,9 @@ struct FrameConst {
 };
 
 // per-frame Gauss-Newton state (I/nlls_solver.h:51-60,96-111)
+constexpr uint8_t F_VISIBLE = 1;                // visible_fts_ (sticky across levels)
+constexpr uint8_t F_JVALID = 2;                 // jacobian_cache_ column block non-zero at this level
+
 struct FrameState {
   double model[7];        // T_cur_from_ref
   double old_model[7];
@@ -183,6 +186,61 @@ struct FrameState {
   int iters[SVO_HIP_MAX_LEVELS];
   double T_cur_w[7];      // result
 };
+
+// One Gauss-Newton control step of one frame from its sums r[0..28] (21 H, 6 Jres, chi2, n_meas):
+// I/nlls_solver_impl.hpp:35-99 with solve()/update() of S/sparse_img_align.cpp:291-308.  One thread.
+SVO_DEV void gn_control_step(FrameState& s, const double* r, int level, int n_iter, double eps, int early_stop) {
+  double H[36], Jres[6], x[6];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) { H[i * 6 + j] = r[k]; H[j * 6 + i] = r[k]; ++k; }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Jres[i] = r[21 + i];
+  const double chi2_sum = r[27];
+  const unsigned long long n_meas = (unsigned long long)(r[28] + 0.5);
+  // computeResiduals returns float chi2 / size_t n_meas evaluated in float (:285)
+  const double new_chi2 = (double)((float)chi2_sum / (float)n_meas);
+#pragma unroll
+  for (int i = 0; i < 36; ++i) s.H[i] = H[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) s.Jres[i] = Jres[i];
+  s.n_meas = n_meas;
+  s.n_res += n_meas / 16;
+  s.iters[level] += 1;
+
+  ldlt6_solve_reg(H, Jres, x);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) s.x[i] = x[i];
+  if (x[0] != x[0]) s.stop = 1;                               // NaN -> stop_ (:52-59)
+  const int iter = s.iter;
+  if ((early_stop && iter > 0 && new_chi2 > s.chi2) || s.stop) {
+    for (int i = 0; i < 7; ++i) s.model[i] = s.old_model[i];  // rollback (:72)
+    s.level_done = 1;
+    return;
+  }
+  double mx[6], dT[7], nm[7], cur[7];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) mx[i] = -x[i];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) cur[i] = s.model[i];
+  se3_exp(mx, dT);
+  se3_mul(cur, dT, nm);                                       // T_new = T_old * exp(-x) (:307)
+#pragma unroll
+  for (int i = 0; i < 7; ++i) { s.old_model[i] = cur[i]; s.model[i] = nm[i]; }
+  s.chi2 = new_chi2;
+  double mxn = -1;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { double a = fabs(x[i]); if (a > mxn) mxn = a; }
+  int done = 0;
+  if (early_stop && mxn <= eps) done = 1;                     // :97-98
+  s.iter = iter + 1;
+  if (iter + 1 >= n_iter) done = 1;
+  if (done) s.level_done = 1;
+}
 }  // namespace svo_dev
 
 // internal entries of svo_sia.hip for the device-resident tracking chain (svo_track.hip): a slot of the solver is filled
@@ -207,6 +265,29 @@ int svo_match_direct_internal(svo_hip_ctx* ctx, const svo_hip_pyramid* ref, cons
                               const double* px_ref_dev, const double* f_ref_dev, const int32_t* level_ref_dev,
                               const double* pt_pos_dev, const uint8_t* edgelet_dev, const double* grad_dev, int n_pyr_levels,
                               int align_max_iter, double* px_cur_dev, uint8_t* success_dev, int32_t* search_level_dev);
+
+// ---- svo_sia.hip <-> svo_nlls.hip: the solver's other NLLSSolver branches (Levenberg-Marquardt, robust weights) run
+// on the streaming solver's buffers.  The view is valid between svo_hip_sia_level_begin and the next call that changes
+// the solver.
+struct svo_sia_view {
+  svo_hip_ctx* ctx;
+  int batch, max_n, n_slots, level, chunks;
+  int cols, rows;                       // of the current level
+  svo_dev::FrameConst* fc;
+  svo_dev::FrameState* st;
+  const float4 *ref_cache, *dxc, *dyc;  // [slot][max_n][4 rows] x float4: reference patch, dx, dy of the level
+  const double4* xyz4;                  // {x, y, z, 1/z} of the feature in the reference frame
+  const uint8_t* flags;                 // svo_dev::F_VISIBLE | F_JVALID per patch
+  double* partial;                      // [slot][chunks][SVO_HIP_REDUCE_DOUBLES] block sums of an evaluation
+  const uint8_t* cur_level;             // level image of slot 0 of the current-frame pyramid; slot b is + b * pyr_bytes
+  size_t pyr_bytes;
+};
+struct svo_nlls_ext;                    // device state of the extra branches, owned by the solver (svo_nlls.hip)
+int svo_sia_view_get(svo_hip_sia* s, svo_sia_view* v);
+svo_nlls_ext** svo_sia_nlls_slot(svo_hip_sia* s);
+int svo_nlls_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int method, int scale_estimator, int weight_function);
+int svo_nlls_scale(svo_hip_sia* s, int slot, float* scale, double* mu, double* nu);
+void svo_nlls_free(svo_nlls_ext* e);
 
 namespace svo_dev { struct SeedRec; }
 int svo_match_scratch(svo_hip_ctx* ctx, int n_cap, svo_dev::SeedRec** recs, uint32_t** pwb_t, int* n_pad);

@@ -51,8 +51,7 @@ constexpr int RED = SVO_HIP_REDUCE_DOUBLES;     // 32
 constexpr int MAX_CHUNKS = 64;
 constexpr int TILE = 64;                        // patches per wavefront pass
 constexpr int TILE_ROW = 24;                    // doubles per tile-H row (21 used)
-constexpr uint8_t F_VISIBLE = 1;                // visible_fts_ (sticky across levels)
-constexpr uint8_t F_JVALID = 2;                 // jacobian_cache_ column block non-zero at this level
+// (F_VISIBLE, F_JVALID: svo_internal.h)
 constexpr uint8_t F_GONE = 4;
 constexpr uint8_t F_HASPOINT = 8;              // fused kernel: the feature has a map point (sticky)                   // fused kernel: outside the current image at the previous evaluation
 
@@ -98,37 +97,7 @@ SVO_DEV uint2 load_row8(const uint8_t* p) {
   return w;
 }
 
-// The 21 upper-triangle entries (row-major) of  sxx AA^T + sxy (AB^T + BA^T) + syy BB^T.
-SVO_DEV void patch_hessian(const double* A, const double* B, double sxx, double sxy, double syy, double* hp) {
-  int e = 0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = i; j < 6; ++j) {
-      hp[e] = sxx * (A[i] * A[j]) + sxy * (A[i] * B[j] + B[i] * A[j]) + syy * (B[i] * B[j]);
-      ++e;
-    }
-}
-
-// A = row 0, B = row 1 of Frame::jacobian_xyz2uv (I/frame.h:110-132) times fx/2^L, from {x,y,z,1/z}
-SVO_DEV void patch_jacobian_rows(double x, double y, double z_inv, double jscale, double* A, double* B) {
-  const double z_inv_2 = z_inv * z_inv;
-  const double j02 = x * z_inv_2;
-  const double j03 = y * j02;
-  const double j12 = y * z_inv_2;
-  A[0] = -z_inv * jscale;
-  A[1] = 0.0 * jscale;
-  A[2] = j02 * jscale;
-  A[3] = j03 * jscale;
-  A[4] = -(1.0 + x * j02) * jscale;
-  A[5] = (y * z_inv) * jscale;
-  B[0] = 0.0 * jscale;
-  B[1] = -z_inv * jscale;
-  B[2] = j12 * jscale;
-  B[3] = (1.0 + y * j12) * jscale;
-  B[4] = -j03 * jscale;
-  B[5] = (-x * z_inv) * jscale;
-}
+// (patch_hessian, patch_jacobian_rows: svo_device_math.h)
 
 __global__ void sia_begin_kernel(const FrameConst* __restrict__ fc, FrameState* __restrict__ st, int n_slots) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,60 +260,7 @@ template <bool EXACT_ROWS>
 SVO_DEV double fused_tile_row_body(double x, double y, double z_inv, double jscale, double sxx, double sxy, double syy, bool contributes,
                                    int lane);
 
-// One Gauss-Newton control step of one frame from its sums r[0..28] (21 H, 6 Jres, chi2, n_meas):
-// I/nlls_solver_impl.hpp:35-99 with solve()/update() of S/sparse_img_align.cpp:291-308.  One thread.
-SVO_DEV void gn_control_step(FrameState& s, const double* r, int level, int n_iter, double eps, int early_stop) {
-  double H[36], Jres[6], x[6];
-  {
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = i; j < 6; ++j) { H[i * 6 + j] = r[k]; H[j * 6 + i] = r[k]; ++k; }
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) Jres[i] = r[21 + i];
-  const double chi2_sum = r[27];
-  const unsigned long long n_meas = (unsigned long long)(r[28] + 0.5);
-  // computeResiduals returns float chi2 / size_t n_meas evaluated in float (:285)
-  const double new_chi2 = (double)((float)chi2_sum / (float)n_meas);
-#pragma unroll
-  for (int i = 0; i < 36; ++i) s.H[i] = H[i];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) s.Jres[i] = Jres[i];
-  s.n_meas = n_meas;
-  s.n_res += n_meas / 16;
-  s.iters[level] += 1;
-
-  ldlt6_solve_reg(H, Jres, x);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) s.x[i] = x[i];
-  if (x[0] != x[0]) s.stop = 1;                               // NaN -> stop_ (:52-59)
-  const int iter = s.iter;
-  if ((early_stop && iter > 0 && new_chi2 > s.chi2) || s.stop) {
-    for (int i = 0; i < 7; ++i) s.model[i] = s.old_model[i];  // rollback (:72)
-    s.level_done = 1;
-    return;
-  }
-  double mx[6], dT[7], nm[7], cur[7];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) mx[i] = -x[i];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) cur[i] = s.model[i];
-  se3_exp(mx, dT);
-  se3_mul(cur, dT, nm);                                       // T_new = T_old * exp(-x) (:307)
-#pragma unroll
-  for (int i = 0; i < 7; ++i) { s.old_model[i] = cur[i]; s.model[i] = nm[i]; }
-  s.chi2 = new_chi2;
-  double mxn = -1;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { double a = fabs(x[i]); if (a > mxn) mxn = a; }
-  int done = 0;
-  if (early_stop && mxn <= eps) done = 1;                     // :97-98
-  s.iter = iter + 1;
-  if (iter + 1 >= n_iter) done = 1;
-  if (done) s.level_done = 1;
-}
+// (gn_control_step: svo_internal.h)
 
 // The control step at the head of an evaluation launch (see sia_residual_kernel), called by the first wave of the block
 // and kept out of line: the 6x6 solve must not shape the register allocation of the streaming loop (inlined it took the
@@ -1741,6 +1657,9 @@ struct svo_hip_sia {
   int shard_rank = 0, shard_world = 1;
   // tuning / diagnostic switches of this object (svo_hip_sia_set_option); 0 / -1 = automatic
   int opt_mode = 0, opt_waves = 0, opt_chunks = 0, opt_extra_lds = -1, opt_old_tiles = 0, opt_arith = SVO_HIP_SIA_ARITH_EXACT;
+  // NLLSSolver's other branches (svo_nlls.hip): method_, setRobustCostFunction
+  int opt_method = SVO_HIP_SIA_METHOD_GAUSS_NEWTON, opt_scale = SVO_HIP_SIA_SCALE_UNIT, opt_weight = SVO_HIP_SIA_WEIGHT_UNIT;
+  svo_nlls_ext* nlls = nullptr;
   // stepwise state
   svo_hip_sia_params prm{};
   int n_slots = 0, level = -1, chunks = 1;
@@ -1920,6 +1839,9 @@ int launch_fused_shape(svo_hip_sia* s, int n_launch, int max_n, const svo_hip_si
   return svo_fail(ctx, SVO_HIP_ERR_INVALID, "fused SparseImgAlign", "unsupported tiles-per-wave");
 }
 
+// setRobustCostFunction switches use_weights_ on for every scale estimator but UnitScale (nlls_solver_impl.hpp:234-262)
+bool nlls_branches(const svo_hip_sia* s) { return s->opt_method != SVO_HIP_SIA_METHOD_GAUSS_NEWTON || s->opt_scale != SVO_HIP_SIA_SCALE_UNIT; }
+
 // The fused kernel handles frames of at most FUSED_MAX_TILES tiles that are not patch-sharded.
 bool fused_applies(const svo_hip_sia* s, int n_slots) {
   if (s->opt_mode == SVO_HIP_SIA_MODE_STREAM) return false;
@@ -2056,6 +1978,7 @@ int svo_hip_sia_destroy(svo_hip_sia* s) {
   void* ptrs[] = {s->st_alt, s->fc, s->st, s->px, s->f, s->pos, s->has_point, s->visible, s->ref_cache, s->dxc, s->dyc,
                   s->sxyz, s->xyz4, s->tile_h, s->wmem, s->partial, s->partial_alt, s->reduce_own, s->n_pre_count};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (s->nlls) svo_nlls_free(s->nlls);
   for (hipEvent_t e : s->ev_res) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_pre) (void)hipEventDestroy(e);
   delete[] s->h_fc;
@@ -2217,6 +2140,7 @@ static int launch_solve(svo_hip_sia* s, bool from_partials, const FrameState* st
 int svo_hip_sia_accumulate(svo_hip_sia* s) {
   if (!s) return SVO_HIP_ERR_INVALID;
   svo_hip_ctx* ctx = s->ctx;
+  if (nlls_branches(s)) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_accumulate", "Levenberg-Marquardt / robust weights run through svo_hip_sia_run only");
   if (!s->begun || s->level < 0) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_accumulate", "level_begin not called");
   int rc = launch_residual(s);
   if (rc != SVO_HIP_OK) return rc;
@@ -2248,6 +2172,8 @@ int svo_hip_sia_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) 
   if (!s || !prm) return SVO_HIP_ERR_INVALID;
   if (s->shard_world != 1)     // (svo_hip_sia_run_sharded / the step-wise entry points are the sharded forms)
     return svo_fail(s->ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_run", "a patch shard is set on this solver: the whole solve needs the all-reduce of svo_hip_sia_run_sharded");
+  // Levenberg-Marquardt and / or a robust cost (I/nlls_solver.h:46-48): their own driver over the streaming kernels
+  if (nlls_branches(s)) return svo_nlls_run(s, n_slots, prm, s->opt_method, s->opt_scale, s->opt_weight);
   if (n_slots > 0 && n_slots <= s->batch && fused_applies(s, n_slots)) return run_fused(s, n_slots, prm);
   s->last_mode = 0;
   int rc = svo_hip_sia_begin(s, n_slots, prm);
@@ -2348,6 +2274,7 @@ int svo_hip_sia_run_sharded(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, con
   svo_hip_ctx* ctx = s->ctx;
   // the collective is enqueued on the communicator's stream, the kernels on the solver's: they must be the same one
   SVO_REQUIRE(ctx, svo_comm_ctx(comm) == s->ctx);
+  if (nlls_branches(s)) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_run_sharded", "Levenberg-Marquardt / robust weights run through svo_hip_sia_run only");
   int rank = 0, world = 1, kind = 0;
   svo_hip_comm_info(comm, &rank, &world, &kind);
   // the shard of this call only: whatever svo_hip_sia_set_shard left on the object is back in place afterwards, on the
@@ -2372,6 +2299,12 @@ int svo_hip_sia_set_option(svo_hip_sia* s, int option, int value) {
       SVO_REQUIRE(ctx, value == SVO_HIP_SIA_ARITH_EXACT || value == SVO_HIP_SIA_ARITH_FAST || value == SVO_HIP_SIA_ARITH_MOMENTS_F32);
       s->opt_arith = value;
       break;
+    case SVO_HIP_SIA_OPT_METHOD:
+      SVO_REQUIRE(ctx, value == SVO_HIP_SIA_METHOD_GAUSS_NEWTON || value == SVO_HIP_SIA_METHOD_LEVENBERG_MARQUARDT);
+      s->opt_method = value;
+      break;
+    case SVO_HIP_SIA_OPT_SCALE_ESTIMATOR: SVO_REQUIRE(ctx, value >= SVO_HIP_SIA_SCALE_UNIT && value <= SVO_HIP_SIA_SCALE_NORMAL); s->opt_scale = value; break;
+    case SVO_HIP_SIA_OPT_WEIGHT_FUNCTION: SVO_REQUIRE(ctx, value >= SVO_HIP_SIA_WEIGHT_UNIT && value <= SVO_HIP_SIA_WEIGHT_HUBER); s->opt_weight = value; break;
     default: return svo_fail(ctx, SVO_HIP_ERR_INVALID, "svo_hip_sia_set_option", "unknown option");
   }
   return SVO_HIP_OK;
@@ -2523,3 +2456,17 @@ int svo_hip_sia_download_caches(svo_hip_sia* s, int slot, float* ref_patch, floa
 }
 
 }  // extern "C"
+
+// svo_nlls.hip works on the streaming solver's buffers (see svo_internal.h)
+int svo_sia_view_get(svo_hip_sia* s, svo_sia_view* v) {
+  if (!s || !v || !s->begun || s->level < 0) return SVO_HIP_ERR_STATE;
+  v->ctx = s->ctx; v->batch = s->batch; v->max_n = s->max_n; v->n_slots = s->n_slots; v->level = s->level; v->chunks = s->chunks;
+  v->cols = s->cur->width >> s->level; v->rows = s->cur->height >> s->level;
+  v->fc = s->fc; v->st = s->st;
+  v->ref_cache = s->ref_cache; v->dxc = s->dxc; v->dyc = s->dyc; v->xyz4 = s->xyz4; v->flags = s->visible; v->partial = s->partial;
+  v->cur_level = s->cur->base + s->cur->level_offset[s->level];
+  v->pyr_bytes = s->cur->pyr_bytes;
+  return SVO_HIP_OK;
+}
+
+svo_nlls_ext** svo_sia_nlls_slot(svo_hip_sia* s) { return &s->nlls; }

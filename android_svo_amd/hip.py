@@ -21,6 +21,11 @@ SEED_BEHIND, SEED_NOT_IN_FRAME, SEED_NO_MATCH, SEED_UPDATED, SEED_CONVERGED, SEE
 
 # svo_hip_sia_set_option (per solver object; the library itself reads no environment variable)
 SIA_OPT_MODE, SIA_OPT_WAVES, SIA_OPT_CHUNKS, SIA_OPT_EXTRA_LDS, SIA_OPT_OLD_TILES, SIA_OPT_ARITH = range(6)
+SIA_OPT_METHOD, SIA_OPT_SCALE_ESTIMATOR, SIA_OPT_WEIGHT_FUNCTION = 6, 7, 8
+# vk::NLLSSolver's enumerators (I/nlls_solver.h:46-48)
+SIA_METHOD_GAUSS_NEWTON, SIA_METHOD_LEVENBERG_MARQUARDT = 0, 1
+SIA_SCALE_UNIT, SIA_SCALE_TDIST, SIA_SCALE_MAD, SIA_SCALE_NORMAL = range(4)
+SIA_WEIGHT_UNIT, SIA_WEIGHT_TDIST, SIA_WEIGHT_TUKEY, SIA_WEIGHT_HUBER = range(4)
 SIA_MODE_AUTO, SIA_MODE_STREAM = 0, 1
 SIA_ARITH_EXACT, SIA_ARITH_FAST, SIA_ARITH_MOMENTS_F32 = 0, 1, 2      # include/svo_hip.h: the reference's arithmetic / contracted f32 sums in the fused kernel
 # options every SparseImgAlign object created from now on starts with: {option: value}.  Test fixtures and A/B scripts
@@ -242,6 +247,21 @@ class SparseImgAlign:
     def set_mode(self, stream: bool):
         """svo_hip_sia_run: True = always the streaming kernels, False = automatic (the fused kernel where it applies)"""
         self.set_option(SIA_OPT_MODE, SIA_MODE_STREAM if stream else SIA_MODE_AUTO)
+
+    def set_method(self, method: int):
+        """NLLSSolver::method_: SIA_METHOD_GAUSS_NEWTON (default) or SIA_METHOD_LEVENBERG_MARQUARDT"""
+        self.set_option(SIA_OPT_METHOD, method)
+
+    def set_robust_cost_function(self, scale_estimator: int, weight_function: int):
+        """NLLSSolver::setRobustCostFunction (I/nlls_solver_impl.hpp:229-281); SIA_SCALE_UNIT switches the weights off"""
+        self.set_option(SIA_OPT_SCALE_ESTIMATOR, scale_estimator)
+        self.set_option(SIA_OPT_WEIGHT_FUNCTION, weight_function)
+
+    def solver_state(self, slot: int = 0):
+        """(scale_, mu_, nu_) of a slot after a run with Levenberg-Marquardt or a robust cost"""
+        sc, mu, nu = C.c_float(), C.c_double(), C.c_double()
+        self.ctx.check(self.ctx.lib.svo_hip_sia_solver_state(self.h, slot, C.byref(sc), C.byref(mu), C.byref(nu)), "sia_solver_state")
+        return np.float32(sc.value), mu.value, nu.value
 
     def set_frames(self, ref: Pyramid, cur: Pyramid):
         self.ref, self.cur = ref, cur

@@ -467,6 +467,18 @@ int main(int argc, char** argv) {
       const auto I = align.getFisherInformation();
       res.insert(res.end(), I.begin(), I.end());
       write_bin(out + "/sia.bin", res);
+      // the same pair through NLLSSolver's other branches: Levenberg-Marquardt with setRobustCostFunction(MADScale, HuberWeight)
+      {
+        FramePtr cur_lm = load_frame(dir, &c.cam, 1, c.n_levels);
+        cur_lm->T_f_w_ = ref->T_f_w_;
+        SparseImgAlign lm(4, 0, 30, SparseImgAlign::LevenbergMarquardt, false, false);
+        lm.setRobustCostFunction(SparseImgAlign::MADScale, SparseImgAlign::HuberWeight);
+        const size_t n_lm = lm.run(ref, cur_lm);
+        std::vector<double> r2(cur_lm->T_f_w_.p, cur_lm->T_f_w_.p + 7);
+        r2.push_back((double)n_lm);
+        r2.push_back(lm.getChi2()); r2.push_back((double)lm.scale_); r2.push_back(lm.mu_); r2.push_back(lm.nu_); r2.push_back(lm.stop_ ? 1.0 : 0.0);
+        write_bin(out + "/sia_lm.bin", r2);
+      }
       // an empty reference frame returns 0 and leaves the pose alone
       FramePtr empty_ref = load_frame(dir, &c.cam, 0, c.n_levels);
       FramePtr cur2 = load_frame(dir, &c.cam, 1, c.n_levels);

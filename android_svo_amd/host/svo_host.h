@@ -281,16 +281,26 @@ class FrameTrackerGroup : public hip_bridge::FrameTrackerGroupT<HostTrackerPolic
 /// I/sparse_img_align.h:33-79
 class SparseImgAlign {
  public:
-  enum Method { GaussNewton, LevenbergMarquardt };
+  enum Method { GaussNewton, LevenbergMarquardt };                             // I/nlls_solver.h:46-48
+  enum ScaleEstimatorType { UnitScale, TDistScale, MADScale, NormalScale };
+  enum WeightFunctionType { UnitWeight, TDistWeight, TukeyWeight, HuberWeight };
   size_t n_iter_; double eps_; bool stop_ = false; size_t n_meas_ = 0;
+  Method method_;
+  double mu_ = 0.01f, nu_ = 2.0;
+  float scale_ = 0.0f;
   SparseImgAlign(int n_levels, int min_level, int n_iter, Method method, bool display, bool verbose)
-      : n_iter_(n_iter), eps_(0.000001), max_level_(n_levels), min_level_(min_level) {
-    (void)method; (void)display; (void)verbose;
+      : n_iter_(n_iter), eps_(0.000001), method_(method), max_level_(n_levels), min_level_(min_level) {
+    (void)display; (void)verbose;
     hip_bridge::check(svo_hip_ctx_create(&ctx_, 0, nullptr), nullptr, "ctx_create");
     ref_.reset(new hip_bridge::PyramidCache(ctx_, 1));
     cur_.reset(new hip_bridge::PyramidCache(ctx_, 1));
   }
   ~SparseImgAlign() { if (sia_) svo_hip_sia_destroy(sia_); ref_.reset(); cur_.reset(); svo_hip_ctx_destroy(ctx_); }
+
+  /// NLLSSolver::setRobustCostFunction (I/nlls_solver_impl.hpp:229-281): UnitScale switches the weights off
+  void setRobustCostFunction(ScaleEstimatorType scale_estimator, WeightFunctionType weight_function) {
+    scale_kind_ = (int)scale_estimator; weight_kind_ = (int)weight_function;
+  }
 
   size_t run(FramePtr ref_frame, FramePtr cur_frame) {
     stop_ = false; n_meas_ = 0; chi2_ = 1e10;
@@ -315,6 +325,10 @@ class SparseImgAlign {
     const svo_hip_camera cam = cur_frame->cam_->toC();
     svo_hip_sia_params prm{max_level_, min_level_, (int)n_iter_, eps_, 1};
     svo_hip_sia_result res;
+    hip_bridge::check(svo_hip_sia_set_option(sia_, SVO_HIP_SIA_OPT_METHOD, method_ == LevenbergMarquardt ? SVO_HIP_SIA_METHOD_LEVENBERG_MARQUARDT
+                                                                                                         : SVO_HIP_SIA_METHOD_GAUSS_NEWTON), ctx_, "set_option");
+    hip_bridge::check(svo_hip_sia_set_option(sia_, SVO_HIP_SIA_OPT_SCALE_ESTIMATOR, scale_kind_), ctx_, "set_option");
+    hip_bridge::check(svo_hip_sia_set_option(sia_, SVO_HIP_SIA_OPT_WEIGHT_FUNCTION, weight_kind_), ctx_, "set_option");
     hip_bridge::check(svo_hip_sia_set_frames(sia_, ref_->pyramid(), cur_->pyramid()), ctx_, "set_frames");
     hip_bridge::check(svo_hip_sia_upload_features(sia_, 0, n, px.data(), f.data(), pos.data(), hp.data()), ctx_, "upload_features");
     hip_bridge::check(svo_hip_sia_upload_poses(sia_, 0, &cam, ref_frame->T_f_w_.p, cur_frame->T_f_w_.p), ctx_, "upload_poses");
@@ -323,6 +337,8 @@ class SparseImgAlign {
     cur_frame->T_f_w_ = SE3(res.T_cur_w);                                     // :89
     std::memcpy(H_.data(), res.H, sizeof(res.H));
     chi2_ = res.chi2; stop_ = res.stop != 0; n_meas_ = (size_t)res.n_tracked * 16;
+    if (method_ == LevenbergMarquardt || scale_kind_ != SVO_HIP_SIA_SCALE_UNIT)
+      hip_bridge::check(svo_hip_sia_solver_state(sia_, 0, &scale_, &mu_, &nu_), ctx_, "solver_state");
     return (size_t)res.n_tracked;                                             // :91
   }
   std::array<double, 36> getFisherInformation() const {                       // :94-99
@@ -335,6 +351,7 @@ class SparseImgAlign {
 
  private:
   int max_level_, min_level_;
+  int scale_kind_ = SVO_HIP_SIA_SCALE_UNIT, weight_kind_ = SVO_HIP_SIA_WEIGHT_UNIT;
   svo_hip_ctx* ctx_ = nullptr;
   svo_hip_sia* sia_ = nullptr;
   int cap_ = 0;

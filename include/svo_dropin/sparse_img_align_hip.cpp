@@ -8,9 +8,11 @@
 //  * run() flattens ref_frame->fts_ (std::list walk, sparse_img_align.cpp:116-118) into SoA arrays in
 //    list order, uploads them with the two pyramids and the poses, runs, and reads back T_f_w_, n_meas_,
 //    H_ and chi2_.  Host pointers are never retained.
-//  * display_ (residual image window) and the Levenberg-Marquardt / robust-weight branches are not
-//    offloaded: no caller enables them (frame_handler_mono.cpp:186-187,331-332); requesting them
-//    logs a warning and runs plain Gauss-Newton.
+//  * method_ (GaussNewton / LevenbergMarquardt) and the robust cost set with setRobustCostFunction go down with the call
+//    (svo_hip_sia_set_option; android_svo_amd/csrc/svo_nlls.hip).  No caller of the reference enables either
+//    (frame_handler_mono.cpp:186-187,331-332), and Gauss-Newton without weights is the path with the fused kernel; the
+//    other branches run one launch per evaluation.  mu_, nu_ and scale_ are read back like H_ and chi2_.
+//  * display_ (residual image window) is not offloaded: a warning, then the run without it.
 //  * the virtual hooks computeResiduals/solve/update exist for the base class but are not called.
 #include <algorithm>
 #include <vector>
@@ -20,6 +22,7 @@
 #include <svo/feature.h>
 #include <svo/frame.h>
 #include <svo/point.h>
+#include <svo/robust_cost.h>
 #include <svo/sparse_img_align.h>
 
 #include "svo_hip_bridge.h"
@@ -94,7 +97,25 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   prm.max_level = max_level_; prm.min_level = min_level_; prm.n_iter = (int)n_iter_; prm.eps = eps_;
   prm.early_stop = 1;
   svo_hip_sia_result res;
-  int rc = svo_hip_sia_set_frames(dev.sia, dev.ref_pyr.pyramid(), dev.cur_pyr.pyramid());
+  if (display_) SVO_WARN_STREAM("SparseImgAlign: the residual image (display_) is not produced by the device path");
+  // NLLSSolver's other branches, as this object is configured (I/nlls_solver.h:46-48,105-111)
+  int scale_kind = SVO_HIP_SIA_SCALE_UNIT, weight_kind = SVO_HIP_SIA_WEIGHT_UNIT;
+  if (use_weights_) {
+    using namespace vk::robust_cost;
+    if (dynamic_cast<TDistributionScaleEstimator*>(scale_estimator_.get())) scale_kind = SVO_HIP_SIA_SCALE_TDIST;
+    else if (dynamic_cast<MADScaleEstimator*>(scale_estimator_.get())) scale_kind = SVO_HIP_SIA_SCALE_MAD;
+    else if (dynamic_cast<NormalDistributionScaleEstimator*>(scale_estimator_.get())) scale_kind = SVO_HIP_SIA_SCALE_NORMAL;
+    if (dynamic_cast<TDistributionWeightFunction*>(weight_function_.get())) weight_kind = SVO_HIP_SIA_WEIGHT_TDIST;
+    else if (dynamic_cast<TukeyWeightFunction*>(weight_function_.get())) weight_kind = SVO_HIP_SIA_WEIGHT_TUKEY;
+    else if (dynamic_cast<HuberWeightFunction*>(weight_function_.get())) weight_kind = SVO_HIP_SIA_WEIGHT_HUBER;
+    if (scale_kind == SVO_HIP_SIA_SCALE_UNIT)            // use_weights_ with an estimator of the caller's own
+      SVO_WARN_STREAM("SparseImgAlign: unknown scale estimator, running without weights");
+  }
+  int rc = svo_hip_sia_set_option(dev.sia, SVO_HIP_SIA_OPT_METHOD,
+                                  method_ == LevenbergMarquardt ? SVO_HIP_SIA_METHOD_LEVENBERG_MARQUARDT : SVO_HIP_SIA_METHOD_GAUSS_NEWTON);
+  if (rc == SVO_HIP_OK) rc = svo_hip_sia_set_option(dev.sia, SVO_HIP_SIA_OPT_SCALE_ESTIMATOR, scale_kind);
+  if (rc == SVO_HIP_OK) rc = svo_hip_sia_set_option(dev.sia, SVO_HIP_SIA_OPT_WEIGHT_FUNCTION, weight_kind);
+  if (rc == SVO_HIP_OK) rc = svo_hip_sia_set_frames(dev.sia, dev.ref_pyr.pyramid(), dev.cur_pyr.pyramid());
   if (rc == SVO_HIP_OK) rc = svo_hip_sia_upload_features(dev.sia, 0, n, px.data(), f.data(), pos.data(), has_point.data());
   if (rc == SVO_HIP_OK) rc = svo_hip_sia_upload_poses(dev.sia, 0, &cam, T_ref, T_cur);
   if (rc == SVO_HIP_OK) rc = svo_hip_sia_run(dev.sia, 1, &prm);
@@ -112,6 +133,11 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   chi2_ = res.chi2;
   stop_ = res.stop != 0;
   n_meas_ = (size_t)res.n_tracked * patch_area_;
+  if (method_ == LevenbergMarquardt || scale_kind != SVO_HIP_SIA_SCALE_UNIT) {
+    float scale = 0.0f;
+    double mu = mu_, nu = nu_;
+    if (svo_hip_sia_solver_state(dev.sia, 0, &scale, &mu, &nu) == SVO_HIP_OK) { scale_ = scale; mu_ = mu; nu_ = nu; }
+  }
   return (size_t)res.n_tracked;
 }
 

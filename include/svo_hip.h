@@ -222,6 +222,9 @@ int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
 #define SVO_HIP_SIA_OPT_EXTRA_LDS 3     /* fused kernel: waves with a third tile in LDS, -1 (automatic) .. 3 */
 #define SVO_HIP_SIA_OPT_OLD_TILES 4     /* fused kernel: tiles of the older wave of a SIMD, 0 (automatic) .. 6 */
 #define SVO_HIP_SIA_OPT_ARITH 5         /* fused kernel: SVO_HIP_SIA_ARITH_EXACT (default: the reference's arithmetic), _MOMENTS_F32 or _FAST (opt-in) */
+#define SVO_HIP_SIA_OPT_METHOD 6          /* NLLSSolver::method_ (I/nlls_solver.h:46): SVO_HIP_SIA_METHOD_GAUSS_NEWTON (default) or _LEVENBERG_MARQUARDT */
+#define SVO_HIP_SIA_OPT_SCALE_ESTIMATOR 7 /* setRobustCostFunction's first argument (:47): SVO_HIP_SIA_SCALE_UNIT (default: no weights), _TDIST, _MAD, _NORMAL */
+#define SVO_HIP_SIA_OPT_WEIGHT_FUNCTION 8 /* ... and its second (:48): SVO_HIP_SIA_WEIGHT_UNIT (default), _TDIST, _TUKEY, _HUBER */
 #define SVO_HIP_SIA_MODE_AUTO 0
 #define SVO_HIP_SIA_MODE_STREAM 1
 /* Arithmetic levels of the fused kernel.  At every level the image math is the reference's f32, pixel choice, projection,
@@ -245,7 +248,39 @@ int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
 #define SVO_HIP_SIA_ARITH_EXACT 0
 #define SVO_HIP_SIA_ARITH_FAST 1
 #define SVO_HIP_SIA_ARITH_MOMENTS_F32 2
+/* The other branches of vk::NLLSSolver<6,SE3> that SparseImgAlign inherits (I/nlls_solver.h:46-48; no caller in the
+ * reference enables them -- frame_handler_mono.cpp:186-187,331-332 construct with GaussNewton and set no robust cost).
+ * The values are the reference's enumerators.
+ *   METHOD _LEVENBERG_MARQUARDT: optimizeLevenbergMarquardt (I/nlls_solver_impl.hpp:102-227) as SparseImgAlign::run drives
+ *     it (mu_ = 0.1 at every level, S/sparse_img_align.cpp:74), with what the reference does around it: n_meas_ is not
+ *     cleared before a level's first evaluation (so chi2_ starts low on every level but the first), stop_ survives into the
+ *     next level, H_ is the DAMPED matrix of the last trial, params.early_stop is ignored and n_iter bounds the outer
+ *     iterations (up to 5 trials each).  result.iters counts evaluations; a trial costs one, not the reference's two: the
+ *     sums of the evaluation at an accepted pose are kept and are the next linearisation.
+ *   SCALE_ESTIMATOR / WEIGHT_FUNCTION: setRobustCostFunction (:229-281).  _SCALE_UNIT switches the weights off whatever
+ *     the weight function (as there).  The scale is estimated at a level's first pose when iter_ of the level before ended
+ *     at 0, i.e. normally once per run (S/sparse_img_align.cpp:281-283); the estimators are evaluated in f32 in the order
+ *     of the reference's errors vector (TDist and Normal sum sequentially; MAD selects the element nth_element leaves at
+ *     size/2; Normal reproduces std::accumulate's int seed), so scale_ is the reference's bit for bit.
+ * Both run over the streaming kernels (svo_hip_sia_last_run_mode 0) and make svo_hip_sia_run wait for the device once per
+ * pyramid level with Levenberg-Marquardt (the number of trials is data dependent).  The step-wise and sharded entry points
+ * refuse a solver that has either set (SVO_HIP_ERR_STATE).  chi2 is summed per patch in f32 and over the patches in f64,
+ * as everywhere in this library, where the reference adds every pixel into one f32: decisions taken on a chi2 difference
+ * of a few units in the last place of that f32 sum can differ. */
+#define SVO_HIP_SIA_METHOD_GAUSS_NEWTON 0
+#define SVO_HIP_SIA_METHOD_LEVENBERG_MARQUARDT 1
+#define SVO_HIP_SIA_SCALE_UNIT 0
+#define SVO_HIP_SIA_SCALE_TDIST 1
+#define SVO_HIP_SIA_SCALE_MAD 2
+#define SVO_HIP_SIA_SCALE_NORMAL 3
+#define SVO_HIP_SIA_WEIGHT_UNIT 0
+#define SVO_HIP_SIA_WEIGHT_TDIST 1
+#define SVO_HIP_SIA_WEIGHT_TUKEY 2
+#define SVO_HIP_SIA_WEIGHT_HUBER 3
 int svo_hip_sia_set_option(svo_hip_sia* sia, int option, int value);
+/* scale_, mu_ and nu_ of one slot as the last svo_hip_sia_run with Levenberg-Marquardt or a robust cost left them
+ * (blocks until the stream is idle; SVO_HIP_ERR_STATE when no such run has been made) */
+int svo_hip_sia_solver_state(svo_hip_sia* sia, int slot, float* scale, double* mu, double* nu);
 
 /* Which implementation the last svo_hip_sia_run used: 1 = the fused kernel (one workgroup per frame pair,
  * interpolated reference patches in LDS / L2-resident memory, whole coarse-to-fine loop in one launch; chosen

@@ -249,6 +249,39 @@ def gen_sia_ref():
     np.savez_compressed(os.path.join(OUT, "sia_ref.npz"), **out)
 
 
+# the other branches of NLLSSolver on the same frame pairs: (method, scale estimator, weight function), the reference's enums
+SIA_NLLS_COMBOS = [(1, 0, 0), (0, 1, 1), (0, 2, 2), (0, 2, 3), (0, 3, 1), (1, 1, 1), (1, 2, 3), (1, 3, 2), (1, 1, 2)]
+SIA_NLLS_CASES = ["c0_200", "c1_2000", "nulls_320", "border_320", "bigmotion_320", "iters5"]
+
+
+def nlls_key(name, combo):
+    return "%s_m%d_s%d_w%d" % ((name,) + tuple(combo))
+
+
+def gen_sia_nlls_ref():
+    """SparseImgAlign::run of the reference's compiled code with method_ = LevenbergMarquardt and / or a robust cost set
+    through its own setRobustCostFunction (oracle/ref/ref_objects.cpp: ref_sparse_img_align_run_ex)."""
+    out = {}
+    cases = {c[0]: c for c in SIA_REF_CASES}
+    for name in SIA_NLLS_CASES:
+        _, kw, max_level, min_level, n_iter = cases[name]
+        fp = make_sia_case(kw)
+        for combo in SIA_NLLS_COMBOS:
+            r = refpy.sparse_img_align_run(fp, max_level=max_level, min_level=min_level, n_iter=n_iter, method=combo[0],
+                                           scale_estimator=combo[1], weight_function=combo[2])
+            k = nlls_key(name, combo)
+            out[k + "_T"] = r["T_cur_w"]
+            out[k + "_n_tracked"] = np.array(r["n_tracked"])
+            out[k + "_H"] = r["H"]
+            out[k + "_chi2"] = np.array(r["chi2"])
+            out[k + "_stop"] = np.array(r["stop"])
+            out[k + "_iter"] = r["iter"]
+            out[k + "_n_meas"] = r["n_meas"]
+            out[k + "_scale_mu_nu"] = np.array([np.float64(r["scale"]), r["mu"], r["nu"]])
+            print("sia_nlls_ref", k, "tracked", r["n_tracked"], "iter", r["iter"][:5], "stop", r["stop"], "scale", r["scale"])
+    np.savez_compressed(os.path.join(OUT, "sia_nlls_ref.npz"), **out)
+
+
 def epi_case_inputs():
     """600 seeds on a 320x240 keyframe with four kinds of depth interval (see tests)."""
     from android_svo_amd import seedsynth
@@ -507,6 +540,10 @@ def main():
         assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
         gen_camera_ref()
         return
+    if "--nlls-only" in sys.argv:
+        assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
+        gen_sia_nlls_ref()
+        return
     if "--map-only" in sys.argv:
         assert refpy.available(), "build oracle/_ref first: make -C oracle ref"
         gen_reproject_map_ref()
@@ -517,7 +554,7 @@ def main():
         rng = np.random.default_rng(20240607)
         gen_se3(rng); gen_algebra(rng); gen_gn(rng); gen_align(rng); gen_matcher(rng); gen_vision(rng)
     if not any(a in sys.argv for a in ("--refine-only", "--shitomasi-only", "--reproject-only")):
-        gen_sia_ref(); gen_epi_ref(); gen_match_direct_ref()
+        gen_sia_ref(); gen_sia_nlls_ref(); gen_epi_ref(); gen_match_direct_ref()
     if "--shitomasi-only" not in sys.argv and "--reproject-only" not in sys.argv:
         gen_refine_ref()
     if "--reproject-only" not in sys.argv:

@@ -98,7 +98,9 @@ def f64(a):
 
 
 def sparse_img_align(fp, max_level=4, min_level=0, n_iter=30, eps=1e-6, early_stop=True,
-                     T_cur_w_init=None) -> SiaResult:
+                     T_cur_w_init=None, method=0, scale_estimator=0, weight_function=0) -> SiaResult:
+    """method 0 GaussNewton / 1 LevenbergMarquardt; scale_estimator 0 Unit (no weights) / 1 TDist / 2 MAD / 3 Normal;
+    weight_function 0 Unit / 1 TDist / 2 Tukey / 3 Huber.  The result carries `.scale` (scale_ after the run)."""
     L = lib()
     cam = camera(fp.cam, getattr(fp, "dist", None))
     prm = SiaParams(max_level, min_level, n_iter, eps, 1 if early_stop else 0)
@@ -108,9 +110,12 @@ def sparse_img_align(fp, max_level=4, min_level=0, n_iter=30, eps=1e-6, early_st
     hp = np.ascontiguousarray(fp.has_point, dtype=np.uint8)
     T_ref = f64(fp.T_ref_w)
     T_init = f64(fp.T_cur_w_init if T_cur_w_init is None else T_cur_w_init)
-    L.svo_orc_sparse_img_align(C.byref(cam), rp, cp, C.c_int(len(px)), _p(px, C.c_double),
-                               _p(f, C.c_double), _p(pos, C.c_double), _p(hp, C.c_uint8),
-                               _p(T_ref, C.c_double), _p(T_init, C.c_double), C.byref(prm), C.byref(out))
+    scale = C.c_float(0)
+    L.svo_orc_sparse_img_align_ex(C.byref(cam), rp, cp, C.c_int(len(px)), _p(px, C.c_double),
+                                  _p(f, C.c_double), _p(pos, C.c_double), _p(hp, C.c_uint8),
+                                  _p(T_ref, C.c_double), _p(T_init, C.c_double), C.byref(prm), C.c_int(method),
+                                  C.c_int(scale_estimator), C.c_int(weight_function), C.byref(out), C.byref(scale))
+    out.scale = np.float32(scale.value)
     return out
 
 

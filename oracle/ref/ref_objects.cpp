@@ -115,6 +115,19 @@ extern "C" {
 // Outputs: pose, n_meas_/16, H_, chi2_, iter_ and n_meas_ per level (after that level's optimize), and the
 // caches as they stand after the last level: ref_patch_cache_ [n][16] f32, jacobian_cache_ [n*16][6] f64
 // (column-major 6 x 16n), visible_fts_ [n].
+// method: 0 GaussNewton, 1 LevenbergMarquardt; scale_estimator / weight_function: the reference's enums
+// (nlls_solver.h:47-48), handed to ITS setRobustCostFunction (nlls_solver_impl.hpp:229-281, robust_cost.o).
+// scale_mu_out (optional): {scale_, mu_, nu_} as the run leaves them.
+int ref_sparse_img_align_run_ex(int width, int height, double fx, double fy, double cx, double cy, int n_levels,
+                             const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr, int n,
+                             const double* px, const double* fv, const double* pos, const uint8_t* has_point,
+                             const double* T_ref_w, const double* T_cur_w_init, int max_level, int min_level,
+                             int n_iter, int method, int scale_estimator, int weight_function,
+                             double* T_cur_w_out, size_t* n_tracked, double* H_out, double* chi2_out,
+                             int* stop_out, int* iter_per_level /*[8]*/, size_t* n_meas_per_level /*[8]*/,
+                             float* ref_patch_cache_out, double* jacobian_cache_out, uint8_t* visible_out,
+                             double* scale_mu_out /*[3]*/);
+
 int ref_sparse_img_align_run(int width, int height, double fx, double fy, double cx, double cy, int n_levels,
                              const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr, int n,
                              const double* px, const double* fv, const double* pos, const uint8_t* has_point,
@@ -122,6 +135,21 @@ int ref_sparse_img_align_run(int width, int height, double fx, double fy, double
                              int n_iter, double* T_cur_w_out, size_t* n_tracked, double* H_out, double* chi2_out,
                              int* stop_out, int* iter_per_level /*[8]*/, size_t* n_meas_per_level /*[8]*/,
                              float* ref_patch_cache_out, double* jacobian_cache_out, uint8_t* visible_out) {
+  return ref_sparse_img_align_run_ex(width, height, fx, fy, cx, cy, n_levels, ref_pyr, cur_pyr, n, px, fv, pos, has_point, T_ref_w,
+                                     T_cur_w_init, max_level, min_level, n_iter, 0, 0, 0, T_cur_w_out, n_tracked, H_out, chi2_out,
+                                     stop_out, iter_per_level, n_meas_per_level, ref_patch_cache_out, jacobian_cache_out,
+                                     visible_out, nullptr);
+}
+
+int ref_sparse_img_align_run_ex(int width, int height, double fx, double fy, double cx, double cy, int n_levels,
+                             const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr, int n,
+                             const double* px, const double* fv, const double* pos, const uint8_t* has_point,
+                             const double* T_ref_w, const double* T_cur_w_init, int max_level, int min_level,
+                             int n_iter, int method, int scale_estimator, int weight_function,
+                             double* T_cur_w_out, size_t* n_tracked, double* H_out, double* chi2_out,
+                             int* stop_out, int* iter_per_level /*[8]*/, size_t* n_meas_per_level /*[8]*/,
+                             float* ref_patch_cache_out, double* jacobian_cache_out, uint8_t* visible_out,
+                             double* scale_mu_out) {
   HarnessPinhole cam(width, height, fx, fy, cx, cy);
   HandFrame ref(&cam, ref_pyr, width, height, n_levels, T_ref_w);
   HandFrame cur(&cam, cur_pyr, width, height, n_levels, T_cur_w_init);
@@ -142,9 +170,14 @@ int ref_sparse_img_align_run(int width, int height, double fx, double fy, double
   // SparseImgAlign::SparseImgAlign(max_level, min_level, n_iter, GaussNewton, false, false) (:29-41)
   s->display_ = false; s->max_level_ = max_level; s->min_level_ = min_level;
   s->n_iter_ = n_iter; s->n_iter_init_ = s->n_iter_;
-  s->method_ = svo::SparseImgAlign::GaussNewton;
+  s->method_ = method == 1 ? svo::SparseImgAlign::LevenbergMarquardt : svo::SparseImgAlign::GaussNewton;
   s->verbose_ = false;
   s->eps_ = 0.000001;
+  // the zeroed scale_estimator_ / weight_function_ members are empty shared pointers; a caller of the reference sets a
+  // robust cost through the solver's own public member
+  if (scale_estimator != 0 || weight_function != 0)
+    s->setRobustCostFunction((svo::SparseImgAlign::ScaleEstimatorType)scale_estimator,
+                             (svo::SparseImgAlign::WeightFunctionType)weight_function);
 
   // SparseImgAlign::run (:51-92)
   size_t ret = 0;
@@ -173,6 +206,7 @@ int ref_sparse_img_align_run(int width, int height, double fx, double fy, double
   for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) H_out[6 * i + j] = s->H_(i, j);
   *chi2_out = s->chi2_;
   *stop_out = s->stop_ ? 1 : 0;
+  if (scale_mu_out) { scale_mu_out[0] = (double)s->scale_; scale_mu_out[1] = s->mu_; scale_mu_out[2] = s->nu_; }
   if (cache) {
     if (ref_patch_cache_out) std::memcpy(ref_patch_cache_out, cache, (size_t)n * 16 * sizeof(float));
     if (jacobian_cache_out) std::memcpy(jacobian_cache_out, s->jacobian_cache_.data(), (size_t)n * 16 * 6 * sizeof(double));
@@ -181,6 +215,8 @@ int ref_sparse_img_align_run(int width, int height, double fx, double fy, double
   // tear down by hand (no destructor of the hand-laid object runs)
   s->jacobian_cache_.resize(Eigen::NoChange, 0);
   s->visible_fts_.~vector();
+  s->scale_estimator_.reset();
+  s->weight_function_.reset();
   s->ref_frame_.reset();
   s->cur_frame_.reset();
   std::free(cache);

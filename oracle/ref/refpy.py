@@ -176,7 +176,9 @@ def _cam_args(cam):
     return (C.c_int(cam.width), C.c_int(cam.height), D(cam.fx), D(cam.fy), D(cam.cx), D(cam.cy))
 
 
-def sparse_img_align_run(fp, max_level=4, min_level=0, n_iter=30, T_cur_w_init=None):
+def sparse_img_align_run(fp, max_level=4, min_level=0, n_iter=30, T_cur_w_init=None, method=0, scale_estimator=0, weight_function=0):
+    """method 0 GaussNewton / 1 LevenbergMarquardt, scale_estimator / weight_function: the reference's enums
+    (nlls_solver.h:47-48), set through its own setRobustCostFunction."""
     rp, cp = orc.pyr_ptrs(fp.ref_pyr), orc.pyr_ptrs(fp.cur_pyr)
     px, f, pos = f64(fp.px), f64(fp.f), f64(fp.pos)
     n = len(px)
@@ -190,12 +192,14 @@ def sparse_img_align_run(fp, max_level=4, min_level=0, n_iter=30, T_cur_w_init=N
     cache = np.zeros((max(n, 1), 16), dtype=np.float32)
     jac = np.zeros((max(n, 1) * 16, 6))
     vis = np.zeros(max(n, 1), dtype=np.uint8)
-    lib().ref_sparse_img_align_run(*_cam_args(fp.cam), C.c_int(len(fp.ref_pyr)), rp, cp, C.c_int(n), _p(px, D), _p(f, D),
-                                   _p(pos, D), _p(hp, C.c_uint8), _p(T_ref, D), _p(T_init, D), C.c_int(max_level),
-                                   C.c_int(min_level), C.c_int(n_iter), _p(T_out, D), C.byref(nt), _p(H, D),
-                                   C.byref(chi2), C.byref(stop), _p(iters, C.c_int), _p(n_meas, C.c_size_t),
-                                   _p(cache, C.c_float), _p(jac, D), _p(vis, C.c_uint8))
-    return {"T_cur_w": T_out, "n_tracked": nt.value, "H": H, "chi2": chi2.value, "stop": stop.value, "iter": iters,
+    smn = np.zeros(3)
+    lib().ref_sparse_img_align_run_ex(*_cam_args(fp.cam), C.c_int(len(fp.ref_pyr)), rp, cp, C.c_int(n), _p(px, D), _p(f, D),
+                                      _p(pos, D), _p(hp, C.c_uint8), _p(T_ref, D), _p(T_init, D), C.c_int(max_level),
+                                      C.c_int(min_level), C.c_int(n_iter), C.c_int(method), C.c_int(scale_estimator),
+                                      C.c_int(weight_function), _p(T_out, D), C.byref(nt), _p(H, D),
+                                      C.byref(chi2), C.byref(stop), _p(iters, C.c_int), _p(n_meas, C.c_size_t),
+                                      _p(cache, C.c_float), _p(jac, D), _p(vis, C.c_uint8), _p(smn, D))
+    return {"scale": np.float32(smn[0]), "mu": smn[1], "nu": smn[2], "T_cur_w": T_out, "n_tracked": nt.value, "H": H, "chi2": chi2.value, "stop": stop.value, "iter": iters,
             "n_meas": n_meas, "ref_patch_cache": cache[:n], "jacobian_cache": jac[:n * 16], "visible": vis[:n]}
 
 

@@ -407,6 +407,14 @@ typedef struct {
   size_t n_meas;
   int stop;
   long n_pre, n_res;
+  /* the other branches of NLLSSolver (I/nlls_solver.h:46-48,96-111): method_, robust cost, LM damping */
+  int method;               /* 0 GaussNewton, 1 LevenbergMarquardt */
+  int use_weights;          /* setRobustCostFunction: true unless the scale estimator is UnitScale */
+  int scale_kind, weight_kind;
+  float scale;              /* scale_ (0.0 until the first estimate) */
+  size_t iter;              /* iter_: survives from one level's optimize() into the next one's weight-scale pass */
+  double mu, nu;
+  int evals;
 } sia_state;
 
 /* S/sparse_img_align.cpp:105-178 */
@@ -463,8 +471,78 @@ static void sia_precompute(sia_state* s) {
   s->have_ref_patch_cache = 1;
 }
 
-/* S/sparse_img_align.cpp:184-286 (use_weights_ == false: weight == 1) */
+/* ---- robust cost, S/robust_cost.cpp (all f32, evaluated in the order of the errors vector) */
+/* TDistributionScaleEstimator::compute (:38-66), dof 5, initial sigma 5 */
+static float scale_tdist(const float* e, size_t n) {
+  const float dof = 5.0f;
+  float initial_lamda = 1.0f / (5.0f * 5.0f);
+  int num = 0;
+  float lambda = initial_lamda;
+  do {
+    initial_lamda = lambda;
+    num = 0;
+    lambda = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+      if (isfinite(e[i])) {
+        ++num;
+        const float error2 = e[i] * e[i];
+        lambda += error2 * ((dof + 1.0f) / (dof + initial_lamda * error2));
+      }
+    }
+    lambda = (float)num / lambda;
+  } while ((double)fabsf(lambda - initial_lamda) > 1e-3);
+  return sqrtf(1.0f / lambda);
+}
+
+static int cmp_float_asc(const void* a, const void* b) {
+  const float x = *(const float*)a, y = *(const float*)b;
+  return (x > y) - (x < y);
+}
+
+/* MADScaleEstimator::compute (:70-75): 1.48 * the element nth_element leaves at floor(n/2) (I/math_utils.h:124-131) */
+static float scale_mad(float* e, size_t n) {
+  if (n == 0) return NAN;                                   /* (the reference reads past an empty vector here) */
+  qsort(e, n, sizeof(float), cmp_float_asc);
+  return 1.48f * e[n / 2];
+}
+
+/* NormalDistributionScaleEstimator::compute (:77-86): std::accumulate with an int seed truncates the running sum to
+ * int at every step, the mean is an integer quotient, and the value returned is sqrt of the SUM of squares */
+static float scale_normal(const float* e, size_t n) {
+  if (n == 0) return NAN;                                   /* (integer division by zero in the reference) */
+  int acc = 0;
+  for (size_t i = 0; i < n; ++i) acc = (int)((float)acc + e[i]);
+  const float mean = (float)((size_t)acc / n);
+  float var = 0.0f;
+  for (size_t i = 0; i < n; ++i) var += (e[i] - mean) * (e[i] - mean);
+  return sqrtf(var);
+}
+
+/* WeightFunction::value (:94-160): TDist dof 5, Tukey b 8.6851, Huber k 1.345 */
+static float robust_weight(int kind, float x) {
+  switch (kind) {
+    case 1: return (5.0f + 1.0f) / (5.0f + (x * x));
+    case 2: {
+      const float b_square = 8.6851f * 8.6851f;
+      const float x_square = x * x;
+      if (x_square <= b_square) { const float tmp = 1.0f - x_square / b_square; return tmp * tmp; }
+      return 0.0f;
+    }
+    case 3: {
+      const float t_abs = fabsf(x);
+      if (t_abs < 1.345f) return 1.0f;
+      return 1.345f / t_abs;
+    }
+    default: return 1.0f;
+  }
+}
+
+/* S/sparse_img_align.cpp:184-286 */
+static double sia_compute_residuals_w(sia_state* s, const double T_cur_from_ref[7], int linearize, int compute_weight_scale);
 static double sia_compute_residuals(sia_state* s, const double T_cur_from_ref[7], int linearize) {
+  return sia_compute_residuals_w(s, T_cur_from_ref, linearize, 0);
+}
+static double sia_compute_residuals_w(sia_state* s, const double T_cur_from_ref[7], int linearize, int compute_weight_scale) {
   const int L = s->level;
   const uint8_t* cur_img = s->cur_pyr[L];
   if (!s->have_ref_patch_cache) sia_precompute(s);
@@ -473,6 +551,9 @@ static double sia_compute_residuals(sia_state* s, const double T_cur_from_ref[7]
   const int border = 2 + 1;
   const float scale = 1.0f / (1 << L);
   float chi2 = 0.0f;
+  float* errors = NULL;
+  size_t n_err = 0;
+  if (compute_weight_scale) errors = (float*)malloc(sizeof(float) * 16 * (size_t)(s->n > 0 ? s->n : 1));
   for (int i = 0; i < s->n; ++i) {
     if (!s->visible[i]) continue;
     const double dxp = s->pos[3 * i] - s->ref_pos[0];
@@ -505,7 +586,9 @@ static double sia_compute_residuals(sia_state* s, const double T_cur_from_ref[7]
       for (int x = 0; x < 4; ++x, ++pix, ++p) {
         const float intensity_cur = w_tl * p[0] + w_tr * p[1] + w_bl * p[stride] + w_br * p[stride + 1];
         const float res = intensity_cur - cache[pix];
+        if (compute_weight_scale) errors[n_err++] = fabsf(res);             /* :256-257 */
         float weight = 1.0f;
+        if (s->use_weights) weight = robust_weight(s->weight_kind, res / s->scale);   /* :260-263 */
         chi2 += res * res * weight;
         s->n_meas++;
         if (linearize) {
@@ -518,6 +601,18 @@ static double sia_compute_residuals(sia_state* s, const double T_cur_from_ref[7]
         }
       }
     }
+  }
+  /* compute the weights on the first iteration (:281-283) */
+  if (compute_weight_scale) {
+    if (s->iter == 0) {
+      switch (s->scale_kind) {
+        case 1: s->scale = scale_tdist(errors, n_err); break;
+        case 2: s->scale = scale_mad(errors, n_err); break;
+        case 3: s->scale = scale_normal(errors, n_err); break;
+        default: s->scale = 1.0f; break;
+      }
+    }
+    free(errors);
   }
   /* float / size_t -> float division, then widened (:285) */
   return (double)(chi2 / (float)s->n_meas);
@@ -534,10 +629,13 @@ static double norm_max6(const double* v) {
  * early_stop == 0 ("fixed work"): the error-increase and |x|<=eps exits are
  * disabled so exactly n_iter evaluations run per level (a NaN solve still stops). */
 static int sia_optimize_gn(sia_state* s, double model[7], int n_iter, double eps, int early_stop) {
+  if (s->use_weights) sia_compute_residuals_w(s, model, 0, 1);          /* :28-29 */
   double old_model[7];
   memcpy(old_model, model, sizeof(old_model));
   int evals = 0;
-  for (int iter = 0; iter < n_iter; ++iter) {
+  int iter;
+  for (iter = 0; iter < n_iter; ++iter) {
+    s->iter = (size_t)iter;
     memset(s->H, 0, sizeof(s->H));
     memset(s->Jres, 0, sizeof(s->Jres));
     s->n_meas = 0;
@@ -558,6 +656,64 @@ static int sia_optimize_gn(sia_state* s, double model[7], int n_iter, double eps
     s->chi2 = new_chi2;
     if (early_stop && norm_max6(s->x) <= eps) break;
   }
+  s->iter = (size_t)iter;                                               /* iter_ as the loop leaves it */
+  return evals;
+}
+
+/* I/nlls_solver_impl.hpp:102-227 with S/sparse_img_align.cpp:291-308 plugged in (have_prior_ false, mu_ >= 0).
+ * As in the reference: n_meas_ is NOT cleared before the weight-scale pass and the first evaluation, so chi2_ of a
+ * level starts as that evaluation's f32 sum over (what the previous level left + this level's counts); H_ is damped in
+ * place and is what getInformationMatrix() returns afterwards; stop_ survives into the next level. */
+static int sia_optimize_lm(sia_state* s, double model[7], int n_iter, double eps) {
+  if (s->use_weights) sia_compute_residuals_w(s, model, 0, 1);          /* :105-106 */
+  s->chi2 = sia_compute_residuals(s, model, 1);                         /* :109 */
+  int evals = 1;
+  const int n_trials_max = 5;
+  size_t iter;
+  for (iter = 0; iter < (size_t)n_iter; ++iter) {
+    s->iter = iter;
+    int n_trials = 0;
+    double rho;
+    do {
+      double new_model[7];
+      double new_chi2 = -1;
+      memset(s->H, 0, sizeof(s->H));
+      memset(s->Jres, 0, sizeof(s->Jres));
+      s->n_meas = 0;
+      sia_compute_residuals(s, model, 1);
+      ++evals;
+      for (int k = 0; k < 6; ++k) s->H[7 * k] += s->H[7 * k] * s->mu;   /* H_ += (H_.diagonal()*mu_).asDiagonal() (:150) */
+      svo_orc_ldlt6_solve(s->H, s->Jres, s->x);
+      if (!isnan(s->x[0])) {
+        double mx[6], dT[7];
+        for (int k = 0; k < 6; ++k) mx[k] = -s->x[k];
+        svo_orc_se3_exp(mx, dT);
+        svo_orc_se3_mul(model, dT, new_model);
+        s->n_meas = 0;
+        new_chi2 = sia_compute_residuals(s, new_model, 0);
+        ++evals;
+        rho = s->chi2 - new_chi2;
+      } else {
+        rho = -1;
+      }
+      if (rho > 0) {
+        memcpy(model, new_model, sizeof(new_model));
+        s->chi2 = new_chi2;
+        s->stop = norm_max6(s->x) <= eps;
+        const double c = 1. - pow(2 * rho - 1, 3);
+        const double m = c < 2. / 3. ? c : 2. / 3.;
+        s->mu *= (1. / 3. > m ? 1. / 3. : m);                            /* max(1./3., min(1.-pow(2*rho_-1,3), 2./3.)) */
+        s->nu = 2.;
+      } else {
+        s->mu *= s->nu;
+        s->nu *= 2.;
+        ++n_trials;
+        if (n_trials >= n_trials_max) s->stop = 1;
+      }
+    } while (!(rho > 0 || s->stop));
+    if (s->stop) break;
+  }
+  s->iter = iter;
   return evals;
 }
 
@@ -567,6 +723,14 @@ int svo_orc_sparse_img_align(
     int n_feat, const double* px, const double* f, const double* pos, const uint8_t* has_point,
     const double T_ref_w[7], const double T_cur_w_init[7], const svo_orc_sia_params* prm,
     svo_orc_sia_result* out) {
+  return svo_orc_sparse_img_align_ex(cam, ref_pyr, cur_pyr, n_feat, px, f, pos, has_point, T_ref_w, T_cur_w_init, prm, 0, 0, 0, out, NULL);
+}
+
+int svo_orc_sparse_img_align_ex(
+    const svo_orc_camera* cam, const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr,
+    int n_feat, const double* px, const double* f, const double* pos, const uint8_t* has_point,
+    const double T_ref_w[7], const double T_cur_w_init[7], const svo_orc_sia_params* prm,
+    int method, int scale_estimator, int weight_function, svo_orc_sia_result* out, float* scale_out) {
   memset(out, 0, sizeof(*out));
   memcpy(out->T_cur_w, T_cur_w_init, 7 * sizeof(double));
   out->chi2 = 1e10;
@@ -579,6 +743,12 @@ int svo_orc_sparse_img_align(
   s.jac = (double*)calloc((size_t)n_feat * 96, sizeof(double));
   s.visible = (uint8_t*)calloc((size_t)n_feat, 1);
   s.chi2 = 1e10;                                      /* reset(), nlls_solver_impl.hpp:299-309 */
+  s.method = method;
+  s.scale_kind = scale_estimator; s.weight_kind = weight_function;
+  s.use_weights = scale_estimator != 0;               /* setRobustCostFunction (:234-262): UnitScale switches the weights off */
+  s.scale = 0.0f;
+  s.iter = 0;
+  s.nu = 2.0;                                         /* nu_init_, restored by reset() */
   double T_ref_inv[7], T_cur_from_ref[7];
   svo_orc_se3_inverse(T_ref_w, T_ref_inv);
   s.ref_pos[0] = T_ref_inv[0]; s.ref_pos[1] = T_ref_inv[1]; s.ref_pos[2] = T_ref_inv[2];
@@ -587,7 +757,9 @@ int svo_orc_sparse_img_align(
     s.level = L;
     memset(s.jac, 0, (size_t)n_feat * 96 * sizeof(double));    /* :76 */
     s.have_ref_patch_cache = 0;
-    int ev = sia_optimize_gn(&s, T_cur_from_ref, prm->n_iter, prm->eps, prm->early_stop);
+    s.mu = 0.1;                                                /* :74 */
+    int ev = method == 1 ? sia_optimize_lm(&s, T_cur_from_ref, prm->n_iter, prm->eps)
+                         : sia_optimize_gn(&s, T_cur_from_ref, prm->n_iter, prm->eps, prm->early_stop);
     if (L < SVO_ORACLE_MAX_LEVELS) out->iters[L] = ev;
   }
   svo_orc_se3_mul(T_cur_from_ref, T_ref_w, out->T_cur_w);      /* :89 */
@@ -598,6 +770,7 @@ int svo_orc_sparse_img_align(
   out->stop = s.stop;
   out->n_precompute_patches = s.n_pre;
   out->n_residual_patches = s.n_res;
+  if (scale_out) *scale_out = s.scale;
   free(s.ref_patch_cache); free(s.jac); free(s.visible);
   return 0;
 }

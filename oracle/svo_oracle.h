@@ -113,6 +113,18 @@ int svo_orc_sparse_img_align(
     const double* pos /*[n][3]*/, const uint8_t* has_point /*[n]*/,
     const double T_ref_w[7], const double T_cur_w_init[7],
     const svo_orc_sia_params* prm, svo_orc_sia_result* out);
+/* The same with the other branches of vk::NLLSSolver (I/nlls_solver.h:46-48): method 0 GaussNewton / 1
+ * LevenbergMarquardt (nlls_solver_impl.hpp:102-227; early_stop is ignored there), scale_estimator 0 Unit (no weights) /
+ * 1 TDist / 2 MAD / 3 Normal, weight_function 0 Unit / 1 TDist / 2 Tukey / 3 Huber (S/robust_cost.cpp).  With LM,
+ * `iters` counts computeResiduals calls (two per trial) and `H` is the damped matrix of the last trial.
+ * scale_out (optional): scale_ as the run leaves it. */
+int svo_orc_sparse_img_align_ex(
+    const svo_orc_camera* cam,
+    const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr,
+    int n_feat, const double* px, const double* f, const double* pos, const uint8_t* has_point,
+    const double T_ref_w[7], const double T_cur_w_init[7],
+    const svo_orc_sia_params* prm, int method, int scale_estimator, int weight_function,
+    svo_orc_sia_result* out, float* scale_out);
 
 /* Single residual/linearisation evaluation, for kernel-level parity tests:
  * runs precompute at `level` (fresh visibility) then one computeResiduals at

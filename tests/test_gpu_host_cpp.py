@@ -97,6 +97,13 @@ def test_cpp_host_layer_end_to_end(tmp_path, dist):
     assert rot < 1e-4 and trans < 1e-3
     assert int(sia[7]) == o.n_tracked
     np.testing.assert_allclose(sia[8:44], np.array(o.H) / (5e-4 * 255 * 255), rtol=1e-6, atol=1e-6)
+    # ... and with method_ = LevenbergMarquardt and setRobustCostFunction(MADScale, HuberWeight) on the C++ object
+    olm = orc.sparse_img_align(fp, method=1, scale_estimator=2, weight_function=3)
+    lm = np.fromfile(out / "sia_lm.bin")
+    rot, trans = synth.pose_error(lm[:7], np.array(olm.T_cur_w))
+    assert rot < 1e-8 and trans < 1e-8, (rot, trans)
+    assert int(lm[7]) == olm.n_tracked and abs(lm[8] - olm.chi2) <= 2.5e-7 * olm.chi2 and np.float32(lm[9]) == np.float32(olm.scale)
+    assert int(lm[12]) == olm.stop
 
     # ---- DepthFilter protocol: oracle replay of the reference's loop.  The seed list is [batch A..., batch B...]; every
     # frame walks it in list order: converged seeds fire the callback and leave, NaN seeds leave; on a keyframe every

@@ -1,0 +1,161 @@
+"""GPU parity of the NLLSSolver branches no caller of the reference enables (android_svo_amd/csrc/svo_nlls.hip):
+Levenberg-Marquardt and the robust cost, through svo_hip_sia_set_option + svo_hip_sia_run, against SparseImgAlign::run
+executed by the reference's own compiled code (tests/golden/sia_nlls_ref.npz) and against the oracle that fixture pins
+(tests/test_oracle_nlls.py)."""
+import numpy as np
+import pytest
+
+from android_svo_amd import hip, synth
+from oracle import gen_golden, orc
+
+pytestmark = pytest.mark.gpu
+
+CASES = {c[0]: c for c in gen_golden.SIA_REF_CASES}
+PAIRS = [(n, c) for n in gen_golden.SIA_NLLS_CASES for c in gen_golden.SIA_NLLS_COMBOS]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def _run(ctx, fps, max_level, min_level, n_iter, combo, early_stop=True):
+    cam = fps[0].cam
+    B = len(fps)
+    ref = hip.Pyramid(ctx, cam.width, cam.height, 5, B)
+    cur = hip.Pyramid(ctx, cam.width, cam.height, 5, B)
+    sia = hip.SparseImgAlign(ctx, B, max(max(len(fp.px) for fp in fps), 1))
+    sia.set_frames(ref, cur)
+    for i, fp in enumerate(fps):
+        ref.upload(i, fp.ref_pyr)
+        cur.upload(i, fp.cur_pyr)
+        sia.upload_pair(i, fp)
+    sia.set_method(combo[0])
+    sia.set_robust_cost_function(combo[1], combo[2])
+    sia.run(B, sia.params(max_level=max_level, min_level=min_level, n_iter=n_iter, eps=1e-6, early_stop=early_stop))
+    out = [(sia.download(i), sia.solver_state(i)) for i in range(B)]
+    mode = sia.last_run_mode()
+    for o in (sia, ref, cur):
+        o.destroy()
+    return out, mode
+
+
+@pytest.mark.parametrize("name,combo", PAIRS, ids=[gen_golden.nlls_key(n, c) for n, c in PAIRS])
+def test_against_the_reference_run(ctx, golden, name, combo):
+    g = golden("sia_nlls_ref.npz")
+    _, kw, max_level, min_level, n_iter = CASES[name]
+    fp = gen_golden.make_sia_case(kw)
+    out, mode = _run(ctx, [fp], max_level, min_level, n_iter, combo)
+    r, (scale, mu, nu) = out[0]
+    assert mode == 0                                            # the streaming kernels
+    k = gen_golden.nlls_key(name, combo)
+    rot, trans = synth.pose_error(np.array(r.T_cur_w), g[k + "_T"])
+    print(k, "rot", rot, "trans", trans, "scale", scale, g[k + "_scale_mu_nu"][0], "mu", mu, g[k + "_scale_mu_nu"][1], "iters", list(r.iters[:5]),
+          "chi2", r.chi2, float(g[k + "_chi2"]), "stop", r.stop, int(g[k + "_stop"]))
+    assert rot < 1e-4 and trans < 1e-3, (rot, trans)            # north_star tolerance
+    # chi2 of this path is the reference's one-f32 sum in the reference's order, so Levenberg-Marquardt's accept / reject
+    # decisions and the exits are the reference's: the poses agree to rounding level (observed: <= 1e-11 rad, 1.3e-9 in one
+    # large-motion case) and chi2_ is the reference's f32 bit for bit in 53 of the 54 runs, one unit in the last place off
+    # in that one
+    assert rot < 1e-8 and trans < 1e-8, (rot, trans)
+    assert abs(r.chi2 - float(g[k + "_chi2"])) <= 2.5e-7 * float(g[k + "_chi2"])
+    if rot < 1e-12:
+        assert r.chi2 == float(g[k + "_chi2"])                  # bit for bit
+    assert r.n_tracked == int(g[k + "_n_tracked"])
+    assert int(r.stop) == int(g[k + "_stop"])
+    H = np.array(r.H)
+    assert np.abs(H - g[k + "_H"]).max() <= 1e-9 * np.abs(g[k + "_H"]).max()     # for LM: the damped matrix of the last trial
+    if combo[1]:
+        assert np.float32(scale) == np.float32(g[k + "_scale_mu_nu"][0])      # scale_ bit for bit
+    if combo[0]:
+        assert abs(mu - g[k + "_scale_mu_nu"][1]) <= 1e-9 * g[k + "_scale_mu_nu"][1] and nu == g[k + "_scale_mu_nu"][2]
+
+
+def _cases(names):
+    return [gen_golden.make_sia_case(CASES[n][1]) for n in names]
+
+
+@pytest.mark.parametrize("combo", [(1, 0, 0), (1, 2, 3), (0, 1, 1)], ids=["lm", "lm_mad_huber", "gn_tdist"])
+def test_a_ragged_batch_equals_the_single_runs_and_the_oracle(ctx, combo):
+    """Five frame pairs of different sizes (one of them without features) in ONE call: every slot finishes on its own
+    trial count, and is bit for bit what it is when run alone."""
+    fps = _cases(["c0_200", "iters5", "empty", "c0_l2", "c0_200"])
+    fps[4] = synth.make_frame_pair(seed=4711, n_features=333)
+    fps[3] = synth.make_frame_pair(seed=4712, n_features=64)
+    batch, _ = _run(ctx, fps, 4, 0, 12, combo)
+    for i, fp in enumerate(fps):
+        alone, _ = _run(ctx, [fp], 4, 0, 12, combo)
+        r, st = batch[i]
+        a, st_a = alone[0]
+        assert np.array_equal(np.array(r.T_cur_w), np.array(a.T_cur_w)) and r.chi2 == a.chi2 and r.n_tracked == a.n_tracked
+        assert list(r.iters) == list(a.iters) and st == st_a
+        o = orc.sparse_img_align(fp, 4, 0, 12, method=combo[0], scale_estimator=combo[1], weight_function=combo[2])
+        rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
+        assert rot < 1e-9 and trans < 1e-9, (i, rot, trans)
+        assert r.n_tracked == o.n_tracked and int(r.stop) == o.stop
+        if len(fp.px):
+            assert r.chi2 == o.chi2
+            if combo[1]:
+                assert np.float32(st[0]) == np.float32(o.scale)
+        else:
+            assert r.n_tracked == 0 and np.array_equal(np.array(r.T_cur_w), np.asarray(fp.T_cur_w_init, dtype=np.float64))
+
+
+def test_fixed_work_gauss_newton_with_a_robust_cost(ctx):
+    """early_stop = 0 (exactly n_iter evaluations per level) with weights, against the oracle in the same mode"""
+    fp = synth.make_frame_pair(seed=99, n_features=500)
+    out, _ = _run(ctx, [fp], 4, 1, 6, (0, 2, 2), early_stop=False)
+    r, st = out[0]
+    o = orc.sparse_img_align(fp, 4, 1, 6, early_stop=False, scale_estimator=2, weight_function=2)
+    rot, trans = synth.pose_error(np.array(r.T_cur_w), np.array(o.T_cur_w))
+    assert rot < 1e-9 and trans < 1e-9, (rot, trans)
+    assert list(r.iters[1:5]) == [6, 6, 6, 6] and r.chi2 == o.chi2 and np.float32(st[0]) == np.float32(o.scale)
+
+
+def test_zero_iterations(ctx):
+    """n_iter = 0: Gauss-Newton evaluates nothing; Levenberg-Marquardt still makes the evaluation that sets chi2_ (:109)"""
+    fp = synth.make_frame_pair(seed=5, n_features=150)
+    for combo in [(1, 0, 0), (1, 1, 1), (0, 1, 1)]:
+        out, _ = _run(ctx, [fp], 3, 1, 0, combo)
+        r, _st = out[0]
+        o = orc.sparse_img_align(fp, 3, 1, 0, method=combo[0], scale_estimator=combo[1], weight_function=combo[2])
+        assert np.allclose(np.array(r.T_cur_w), np.array(o.T_cur_w), rtol=0, atol=1e-15)
+        assert r.chi2 == o.chi2 and r.n_tracked == o.n_tracked, (combo, r.chi2, o.chi2, r.n_tracked, o.n_tracked)
+
+
+def test_unit_scale_is_the_plain_solver_and_other_entry_points_refuse(ctx):
+    fp = synth.make_frame_pair(seed=31, n_features=300)
+    cam = fp.cam
+    ref = hip.Pyramid(ctx, cam.width, cam.height, 5, 1)
+    cur = hip.Pyramid(ctx, cam.width, cam.height, 5, 1)
+    sia = hip.SparseImgAlign(ctx, 1, 300)
+    sia.set_frames(ref, cur)
+    ref.upload(0, fp.ref_pyr); cur.upload(0, fp.cur_pyr); sia.upload_pair(0, fp)
+    prm = sia.params(n_iter=10)
+    sia.run(1, prm)
+    plain = sia.download(0)
+    assert sia.last_run_mode() == 1
+    sia.set_robust_cost_function(hip.SIA_SCALE_UNIT, hip.SIA_WEIGHT_TUKEY)       # UnitScale: use_weights_ stays false
+    sia.run(1, prm)
+    same = sia.download(0)
+    assert sia.last_run_mode() == 1 and np.array_equal(np.array(plain.T_cur_w), np.array(same.T_cur_w))
+    with pytest.raises(hip.SvoHipError):
+        sia.solver_state(0)                                                      # no such run yet
+    sia.set_method(hip.SIA_METHOD_LEVENBERG_MARQUARDT)
+    sia.begin(1, prm)
+    sia.level_begin(4)
+    with pytest.raises(hip.SvoHipError):
+        sia.accumulate()                                                         # the step-wise form is Gauss-Newton only
+    sia.finish()
+    with pytest.raises(hip.SvoHipError):
+        sia.set_option(hip.SIA_OPT_METHOD, 2)
+    sia.run(1, prm)
+    assert sia.last_run_mode() == 0 and sia.solver_state(0)[2] >= 2.0
+    sia.set_method(hip.SIA_METHOD_GAUSS_NEWTON)
+    sia.run(1, prm)
+    again = sia.download(0)
+    assert sia.last_run_mode() == 1 and np.array_equal(np.array(plain.T_cur_w), np.array(again.T_cur_w))
+    for o in (sia, ref, cur):
+        o.destroy()
