@@ -34,6 +34,7 @@ constexpr int RED = SVO_HIP_REDUCE_DOUBLES;
 constexpr int TILE = 64;
 constexpr int MAX_CHUNKS = 64;                // block rows per frame in the solver's partial buffer (svo_sia.hip)
 constexpr int N_TRIALS_MAX = 5;             // n_trials_max_ (I/nlls_solver.h:107)
+constexpr int BURST = 6;                    // evaluations launched between two looks at the frames' state
 constexpr int SEQ_PATCHES = 128;            // patches per LDS stage of a sequential f32 sum (8 KiB)
 
 // state of one frame beside FrameState
@@ -253,14 +254,18 @@ SVO_DEV float block_sequential(const float* __restrict__ vals, const uint8_t* __
     for (int k = threadIdx.x; k < m; k += blockDim.x) s_ok[k] = ok[base + k];
     __syncthreads();
     if (threadIdx.x == 0) {
+      // the next patch's 16 values are read from LDS while the chain of 16 dependent operations of this one runs
+      const float4* q = reinterpret_cast<const float4*>(s_stage);
+      float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
       for (int i = 0; i < m; ++i) {
+        const float4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
+        const int nx = i + 1 < m ? i + 1 : i;
+        n0 = q[4 * nx]; n1 = q[4 * nx + 1]; n2 = q[4 * nx + 2]; n3 = q[4 * nx + 3];
         if (!s_ok[i]) continue;
-        const float4* q = reinterpret_cast<const float4*>(s_stage + 16 * i);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 v = q[j];
-          op.step(v.x); op.step(v.y); op.step(v.z); op.step(v.w);
-        }
+        op.step(v0.x); op.step(v0.y); op.step(v0.z); op.step(v0.w);
+        op.step(v1.x); op.step(v1.y); op.step(v1.z); op.step(v1.w);
+        op.step(v2.x); op.step(v2.y); op.step(v2.z); op.step(v2.w);
+        op.step(v3.x); op.step(v3.y); op.step(v3.z); op.step(v3.w);
       }
     }
     __syncthreads();
@@ -568,6 +573,7 @@ int nlls_reserve(svo_hip_ctx* ctx, svo_nlls_ext** slot, int n_slots, int max_n) 
     (*slot)->ctx = ctx;
     void* h = nullptr;
     SVO_CHECK_HIP(ctx, hipHostMalloc(&h, sizeof(int), hipHostMallocMapped));
+    ++ctx->n_allocs;
     (*slot)->pending_host = (int*)h;
     void* d = nullptr;
     SVO_CHECK_HIP(ctx, hipHostGetDevicePointer(&d, h, 0));
@@ -576,26 +582,30 @@ int nlls_reserve(svo_hip_ctx* ctx, svo_nlls_ext** slot, int n_slots, int max_n) 
   svo_nlls_ext* e = *slot;
   if (e->cap_slots < n_slots) {
     SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (e->ext) (void)hipFree(e->ext);
+    if (e->ext) { (void)hipFree(e->ext); ++ctx->n_frees; }
     e->ext = nullptr; e->cap_slots = 0;
     void* p = nullptr;
     SVO_CHECK_HIP(ctx, hipMalloc(&p, sizeof(NllsExt) * (size_t)n_slots));
+    ++ctx->n_allocs;
     e->ext = (NllsExt*)p;
     e->cap_slots = n_slots;
   }
   const size_t patches = (size_t)n_slots * max_n;
   if (e->cap_patches < patches) {
     SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (e->errs) (void)hipFree(e->errs);
-    if (e->terms) (void)hipFree(e->terms);
-    if (e->err_ok) (void)hipFree(e->err_ok);
+    if (e->errs) { (void)hipFree(e->errs); ++ctx->n_frees; }
+    if (e->terms) { (void)hipFree(e->terms); ++ctx->n_frees; }
+    if (e->err_ok) { (void)hipFree(e->err_ok); ++ctx->n_frees; }
     e->errs = e->terms = nullptr; e->err_ok = nullptr; e->cap_patches = 0;
     void* p = nullptr;
     SVO_CHECK_HIP(ctx, hipMalloc(&p, patches * 16 * sizeof(float)));
+    ++ctx->n_allocs;
     e->errs = (float*)p;
     SVO_CHECK_HIP(ctx, hipMalloc(&p, patches * 16 * sizeof(float)));
+    ++ctx->n_allocs;
     e->terms = (float*)p;
     SVO_CHECK_HIP(ctx, hipMalloc(&p, patches));
+    ++ctx->n_allocs;
     e->err_ok = (uint8_t*)p;
     e->cap_patches = patches;
   }
@@ -656,26 +666,22 @@ int svo_nlls_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int
       SVO_CHECK_HIP(ctx, hipGetLastError());
       return SVO_HIP_OK;
     };
-    if (!lm) {
-      for (int it = 0; it < prm->n_iter; ++it)
+    // Gauss-Newton: at most n_iter evaluations.  Levenberg-Marquardt: one for chi2_, then one per trial, at most
+    // N_TRIALS_MAX per outer iteration.  How many a frame needs is data dependent (a handful, normally): they are launched
+    // in rounds of BURST and the host looks at the number of unfinished frames between rounds -- cheaper than launching the
+    // worst case (launches of finished frames return at once but still cost a few microseconds each).
+    const long budget = lm ? 1 + (long)N_TRIALS_MAX * prm->n_iter : (long)prm->n_iter;
+    long done = 0;
+    while (done < budget) {
+      const long m = BURST < budget - done ? BURST : budget - done;
+      for (long k = 0; k < m; ++k)
         if ((rc = evaluate_and_step()) != SVO_HIP_OK) return rc;
-    } else {
-      // one evaluation for chi2_, then one per trial: at most N_TRIALS_MAX per outer iteration.  How many are needed is
-      // data dependent: launched in rounds, the host looks at the number of unfinished frames between them.
-      const long budget = 1 + (long)N_TRIALS_MAX * prm->n_iter;
-      long done = 0;
-      int round = 1 + prm->n_iter;
-      while (done < budget) {
-        const long m = round < budget - done ? round : budget - done;
-        for (long k = 0; k < m; ++k)
-          if ((rc = evaluate_and_step()) != SVO_HIP_OK) return rc;
-        done += m;
-        hipLaunchKernelGGL(nlls_pending_kernel, dim3(1), dim3(256), 0, ctx->stream, v.st, n_slots, e->pending_dev);
-        SVO_CHECK_HIP(ctx, hipGetLastError());
-        SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (*(volatile int*)e->pending_host == 0) break;
-        round = prm->n_iter > 0 ? prm->n_iter : 1;
-      }
+      done += m;
+      if (done >= budget) break;
+      hipLaunchKernelGGL(nlls_pending_kernel, dim3(1), dim3(256), 0, ctx->stream, v.st, n_slots, e->pending_dev);
+      SVO_CHECK_HIP(ctx, hipGetLastError());
+      SVO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (*(volatile int*)e->pending_host == 0) break;
     }
   }
   if (*slot) (*slot)->ran = true;

@@ -1659,6 +1659,7 @@ struct svo_hip_sia {
   int opt_mode = 0, opt_waves = 0, opt_chunks = 0, opt_extra_lds = -1, opt_old_tiles = 0, opt_arith = SVO_HIP_SIA_ARITH_EXACT;
   // NLLSSolver's other branches (svo_nlls.hip): method_, setRobustCostFunction
   int opt_method = SVO_HIP_SIA_METHOD_GAUSS_NEWTON, opt_scale = SVO_HIP_SIA_SCALE_UNIT, opt_weight = SVO_HIP_SIA_WEIGHT_UNIT;
+  int opt_chi2 = SVO_HIP_SIA_CHI2_PER_PATCH;
   svo_nlls_ext* nlls = nullptr;
   // stepwise state
   svo_hip_sia_params prm{};
@@ -1840,7 +1841,10 @@ int launch_fused_shape(svo_hip_sia* s, int n_launch, int max_n, const svo_hip_si
 }
 
 // setRobustCostFunction switches use_weights_ on for every scale estimator but UnitScale (nlls_solver_impl.hpp:234-262)
-bool nlls_branches(const svo_hip_sia* s) { return s->opt_method != SVO_HIP_SIA_METHOD_GAUSS_NEWTON || s->opt_scale != SVO_HIP_SIA_SCALE_UNIT; }
+// (... and plain Gauss-Newton takes the same driver when chi2 is asked for in the reference's summation order)
+bool nlls_branches(const svo_hip_sia* s) {
+  return s->opt_method != SVO_HIP_SIA_METHOD_GAUSS_NEWTON || s->opt_scale != SVO_HIP_SIA_SCALE_UNIT || s->opt_chi2 != SVO_HIP_SIA_CHI2_PER_PATCH;
+}
 
 // The fused kernel handles frames of at most FUSED_MAX_TILES tiles that are not patch-sharded.
 bool fused_applies(const svo_hip_sia* s, int n_slots) {
@@ -2140,7 +2144,7 @@ static int launch_solve(svo_hip_sia* s, bool from_partials, const FrameState* st
 int svo_hip_sia_accumulate(svo_hip_sia* s) {
   if (!s) return SVO_HIP_ERR_INVALID;
   svo_hip_ctx* ctx = s->ctx;
-  if (nlls_branches(s)) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_accumulate", "Levenberg-Marquardt / robust weights run through svo_hip_sia_run only");
+  if (nlls_branches(s)) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_accumulate", "Levenberg-Marquardt / robust weights / reference-order chi2 run through svo_hip_sia_run only");
   if (!s->begun || s->level < 0) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_accumulate", "level_begin not called");
   int rc = launch_residual(s);
   if (rc != SVO_HIP_OK) return rc;
@@ -2172,7 +2176,7 @@ int svo_hip_sia_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm) 
   if (!s || !prm) return SVO_HIP_ERR_INVALID;
   if (s->shard_world != 1)     // (svo_hip_sia_run_sharded / the step-wise entry points are the sharded forms)
     return svo_fail(s->ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_run", "a patch shard is set on this solver: the whole solve needs the all-reduce of svo_hip_sia_run_sharded");
-  // Levenberg-Marquardt and / or a robust cost (I/nlls_solver.h:46-48): their own driver over the streaming kernels
+  // Levenberg-Marquardt, a robust cost (I/nlls_solver.h:46-48), chi2 in the reference's order: their own driver over the streaming kernels
   if (nlls_branches(s)) return svo_nlls_run(s, n_slots, prm, s->opt_method, s->opt_scale, s->opt_weight);
   if (n_slots > 0 && n_slots <= s->batch && fused_applies(s, n_slots)) return run_fused(s, n_slots, prm);
   s->last_mode = 0;
@@ -2274,7 +2278,7 @@ int svo_hip_sia_run_sharded(svo_hip_sia* s, svo_hip_comm* comm, int n_slots, con
   svo_hip_ctx* ctx = s->ctx;
   // the collective is enqueued on the communicator's stream, the kernels on the solver's: they must be the same one
   SVO_REQUIRE(ctx, svo_comm_ctx(comm) == s->ctx);
-  if (nlls_branches(s)) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_run_sharded", "Levenberg-Marquardt / robust weights run through svo_hip_sia_run only");
+  if (nlls_branches(s)) return svo_fail(ctx, SVO_HIP_ERR_STATE, "svo_hip_sia_run_sharded", "Levenberg-Marquardt / robust weights / reference-order chi2 run through svo_hip_sia_run only");
   int rank = 0, world = 1, kind = 0;
   svo_hip_comm_info(comm, &rank, &world, &kind);
   // the shard of this call only: whatever svo_hip_sia_set_shard left on the object is back in place afterwards, on the
@@ -2305,6 +2309,7 @@ int svo_hip_sia_set_option(svo_hip_sia* s, int option, int value) {
       break;
     case SVO_HIP_SIA_OPT_SCALE_ESTIMATOR: SVO_REQUIRE(ctx, value >= SVO_HIP_SIA_SCALE_UNIT && value <= SVO_HIP_SIA_SCALE_NORMAL); s->opt_scale = value; break;
     case SVO_HIP_SIA_OPT_WEIGHT_FUNCTION: SVO_REQUIRE(ctx, value >= SVO_HIP_SIA_WEIGHT_UNIT && value <= SVO_HIP_SIA_WEIGHT_HUBER); s->opt_weight = value; break;
+    case SVO_HIP_SIA_OPT_CHI2: SVO_REQUIRE(ctx, value == SVO_HIP_SIA_CHI2_PER_PATCH || value == SVO_HIP_SIA_CHI2_REFERENCE_ORDER); s->opt_chi2 = value; break;
     default: return svo_fail(ctx, SVO_HIP_ERR_INVALID, "svo_hip_sia_set_option", "unknown option");
   }
   return SVO_HIP_OK;

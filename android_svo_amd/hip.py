@@ -21,7 +21,8 @@ SEED_BEHIND, SEED_NOT_IN_FRAME, SEED_NO_MATCH, SEED_UPDATED, SEED_CONVERGED, SEE
 
 # svo_hip_sia_set_option (per solver object; the library itself reads no environment variable)
 SIA_OPT_MODE, SIA_OPT_WAVES, SIA_OPT_CHUNKS, SIA_OPT_EXTRA_LDS, SIA_OPT_OLD_TILES, SIA_OPT_ARITH = range(6)
-SIA_OPT_METHOD, SIA_OPT_SCALE_ESTIMATOR, SIA_OPT_WEIGHT_FUNCTION = 6, 7, 8
+SIA_OPT_METHOD, SIA_OPT_SCALE_ESTIMATOR, SIA_OPT_WEIGHT_FUNCTION, SIA_OPT_CHI2 = 6, 7, 8, 9
+SIA_CHI2_PER_PATCH, SIA_CHI2_REFERENCE_ORDER = 0, 1
 # vk::NLLSSolver's enumerators (I/nlls_solver.h:46-48)
 SIA_METHOD_GAUSS_NEWTON, SIA_METHOD_LEVENBERG_MARQUARDT = 0, 1
 SIA_SCALE_UNIT, SIA_SCALE_TDIST, SIA_SCALE_MAD, SIA_SCALE_NORMAL = range(4)

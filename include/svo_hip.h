@@ -225,6 +225,7 @@ int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
 #define SVO_HIP_SIA_OPT_METHOD 6          /* NLLSSolver::method_ (I/nlls_solver.h:46): SVO_HIP_SIA_METHOD_GAUSS_NEWTON (default) or _LEVENBERG_MARQUARDT */
 #define SVO_HIP_SIA_OPT_SCALE_ESTIMATOR 7 /* setRobustCostFunction's first argument (:47): SVO_HIP_SIA_SCALE_UNIT (default: no weights), _TDIST, _MAD, _NORMAL */
 #define SVO_HIP_SIA_OPT_WEIGHT_FUNCTION 8 /* ... and its second (:48): SVO_HIP_SIA_WEIGHT_UNIT (default), _TDIST, _TUKEY, _HUBER */
+#define SVO_HIP_SIA_OPT_CHI2 9            /* SVO_HIP_SIA_CHI2_PER_PATCH (default) or _REFERENCE_ORDER, see below */
 #define SVO_HIP_SIA_MODE_AUTO 0
 #define SVO_HIP_SIA_MODE_STREAM 1
 /* Arithmetic levels of the fused kernel.  At every level the image math is the reference's f32, pixel choice, projection,
@@ -262,11 +263,23 @@ int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
  *     at 0, i.e. normally once per run (S/sparse_img_align.cpp:281-283); the estimators are evaluated in f32 in the order
  *     of the reference's errors vector (TDist and Normal sum sequentially; MAD selects the element nth_element leaves at
  *     size/2; Normal reproduces std::accumulate's int seed), so scale_ is the reference's bit for bit.
- * Both run over the streaming kernels (svo_hip_sia_last_run_mode 0) and make svo_hip_sia_run wait for the device once per
- * pyramid level with Levenberg-Marquardt (the number of trials is data dependent).  The step-wise and sharded entry points
- * refuse a solver that has either set (SVO_HIP_ERR_STATE).  chi2 is summed per patch in f32 and over the patches in f64,
- * as everywhere in this library, where the reference adds every pixel into one f32: decisions taken on a chi2 difference
- * of a few units in the last place of that f32 sum can differ. */
+ * Both run over the streaming kernels (svo_hip_sia_last_run_mode 0), one launch pair per evaluation, and svo_hip_sia_run
+ * looks at the frames' state after every sixth evaluation of a level (the number of trials is data dependent): unlike the
+ * default path the call waits for the device.  The step-wise and sharded entry points
+ * refuse a solver that has either set (SVO_HIP_ERR_STATE).  chi2 is added up in the reference's order on these paths
+ * (SVO_HIP_SIA_OPT_CHI2 below): Levenberg-Marquardt accepts or rejects a trial on the sign of a chi2 difference that is
+ * often a few units in the last place. */
+/* CHI2: how the residuals' squares are added up.  The reference adds every pixel of every patch, in list order, into ONE
+ * f32 (float chi2 ... chi2 += res*res*weight, S/sparse_img_align.cpp:207,266) and decides on that sum whether an iteration
+ * increased the error (I/nlls_solver_impl.hpp:62).  _PER_PATCH (default; the fused kernel, the streaming and sharded paths,
+ * the tracking chain): f32 within a patch, f64 over the patches -- a better sum, and the only one that parallelises; when two
+ * successive values differ by a few units in the last place of the reference's f32 sum, the error-increase exit can fall
+ * one iteration earlier or later than in the reference (poses then differ by < 2e-5 rad / 5e-5 m on the scenes tested).
+ * _REFERENCE_ORDER: the squares go to memory and one lane adds them in the reference's order: chi2_ is the reference's bit
+ * for bit and every exit falls where the reference's does.  Costs ~7 us per evaluation per 200 patches on top of the
+ * streaming kernels (svo_hip_sia_last_run_mode 0); Levenberg-Marquardt and the robust costs always use it. */
+#define SVO_HIP_SIA_CHI2_PER_PATCH 0
+#define SVO_HIP_SIA_CHI2_REFERENCE_ORDER 1
 #define SVO_HIP_SIA_METHOD_GAUSS_NEWTON 0
 #define SVO_HIP_SIA_METHOD_LEVENBERG_MARQUARDT 1
 #define SVO_HIP_SIA_SCALE_UNIT 0
