@@ -25,6 +25,7 @@
 #include <new>
 
 #include "svo_internal.h"
+#include "svo_ordered_sum.h"
 
 using namespace svo_dev;
 
@@ -230,14 +231,10 @@ __global__ __launch_bounds__(256) void nlls_residual_robust_kernel(
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// ---- sequential f32 recurrences over the errors of a frame, in the order of the reference's vector (patches in list
+// ---- a sequential recurrence over the errors of a frame, in the order of the reference's vector (patches in list
 // order, those that were inside the image only; 16 pixels each).  The whole block stages SEQ_PATCHES patches in LDS,
-// thread 0 runs the recurrence over them.  Every thread returns the final value.
-struct SeqAdd {                                  // lambda += term (TDistributionScaleEstimator, :53-60), var += term (:83-85)
-  float acc = 0.0f;
-  SVO_DEV void step(float v) { acc += v; }
-  SVO_DEV float value() const { return acc; }
-};
+// thread 0 runs the recurrence over them.  Every thread returns the final value.  (The plain f32 sums -- chi2, TDist's
+// lambda, Normal's variance -- do not need one lane: svo_ordered_sum.h.)
 struct SeqIntAdd {                               // std::accumulate(begin, end, 0): the int seed truncates every partial sum (:80)
   int acc = 0;
   SVO_DEV void step(float v) { acc = (int)((float)acc + v); }
@@ -296,6 +293,7 @@ __global__ __launch_bounds__(256) void nlls_scale_kernel(const FrameConst* __res
   __shared__ unsigned s_hist[256];
   __shared__ unsigned s_sel[2];
   __shared__ int s_count;
+  __shared__ OsShared s_os;
   const int tid = threadIdx.x;
   if (tid == 0) s_count = 0;
   __syncthreads();
@@ -320,7 +318,7 @@ __global__ __launch_bounds__(256) void nlls_scale_kernel(const FrameConst* __res
         terms[k] = error2 * ((5.0f + 1.0f) / (5.0f + initial_lamda * error2));
       }
       __syncthreads();
-      const float sum = block_sequential<SeqAdd>(terms, ok, n, s_stage, s_ok, &s_out);
+      const float sum = os_block_sum(terms, ok, n * 16, s_os);      // lambda += ..., one f32, in order (svo_ordered_sum.h)
       lambda = (float)n_err / sum;
       if (!((double)fabsf(lambda - initial_lamda) > 1e-3)) break;  // block-uniform: every thread holds the same values
     }
@@ -369,7 +367,7 @@ __global__ __launch_bounds__(256) void nlls_scale_kernel(const FrameConst* __res
         terms[k] = (errs[k] - mean) * (errs[k] - mean);
       }
       __syncthreads();
-      result = sqrtf(block_sequential<SeqAdd>(terms, ok, n, s_stage, s_ok, &s_out));
+      result = sqrtf(os_block_sum(terms, ok, n * 16, s_os));
     }
   } else {
     result = 1.0f;                                                 // UnitScaleEstimator
@@ -512,16 +510,14 @@ __global__ __launch_bounds__(256) void nlls_solve_kernel(const FrameConst* __res
   const int tid = threadIdx.x;
   if (b >= n_slots || st[b].level_done) return;                    // block-uniform
   __shared__ double r[RED];
-  __shared__ __attribute__((aligned(16))) float s_stage[SEQ_PATCHES * 16];
-  __shared__ uint8_t s_ok[SEQ_PATCHES];
-  __shared__ float s_out;
+  __shared__ OsShared s_os;
   if (tid < RED) {
     double v = 0.0;
     const double* p = partial + (size_t)b * chunks * RED + tid;
     for (int c = 0; c < chunks; ++c) v += p[(size_t)c * RED];
     r[tid] = v;
   }
-  const float chi2 = block_sequential<SeqAdd>(terms_all + (size_t)b * max_n * 16, ok_all + (size_t)b * max_n, fc[b].n_feat, s_stage, s_ok, &s_out);
+  const float chi2 = os_block_sum(terms_all + (size_t)b * max_n * 16, ok_all + (size_t)b * max_n, fc[b].n_feat * 16, s_os);
   if (tid != 0) return;
   r[27] = (double)chi2;                                            // (the control steps divide (float)r[27] by (float)n_meas_, :285)
   if (method == SVO_HIP_SIA_METHOD_LEVENBERG_MARQUARDT) lm_control_step(st[b], ext[b], r, level, n_iter, eps);
@@ -703,4 +699,21 @@ int svo_nlls_scale(svo_hip_sia* s, int slot, float* scale, double* mu, double* n
 extern "C" int svo_hip_sia_solver_state(svo_hip_sia* sia, int slot, float* scale, double* mu, double* nu) {
   if (!sia) return SVO_HIP_ERR_INVALID;
   return svo_nlls_scale(sia, slot, scale, mu, nu);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void ordered_sum_kernel(const float* __restrict__ vals, int n, float* __restrict__ out) {
+  __shared__ OsShared s_os;
+  const float r = os_block_sum(vals, nullptr, n, s_os);
+  if (threadIdx.x == 0) *out = r;
+}
+}  // namespace
+
+extern "C" int svo_hip_ordered_sum_f32_dev(svo_hip_ctx* ctx, const float* vals_dev, size_t n, float* out_dev) {
+  if (!ctx) return SVO_HIP_ERR_INVALID;
+  SVO_REQUIRE(ctx, (vals_dev || !n) && out_dev && n <= (size_t)INT_MAX);
+  SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, vals_dev, (int)n, out_dev);
+  SVO_CHECK_HIP(ctx, hipGetLastError());
+  return SVO_HIP_OK;
 }

@@ -195,6 +195,19 @@ class DeviceArray:
             self.ptr = 0
 
 
+def ordered_sum_f32(ctx: Context, values: np.ndarray) -> np.float32:
+    """svo_hip_ordered_sum_f32_dev: the f32 sum of `values` in index order, rounded as a scalar loop rounds it"""
+    v = np.ascontiguousarray(values, dtype=np.float32).ravel()
+    d_v = DeviceArray(ctx, v) if len(v) else None
+    d_o = DeviceArray(ctx, shape=(1,), dtype=np.float32)
+    ctx.check(ctx.lib.svo_hip_ordered_sum_f32_dev(ctx.h, C.c_void_p(d_v.ptr if d_v else 0), C.c_size_t(len(v)), C.c_void_p(d_o.ptr)), "ordered_sum")
+    out = d_o.download()[0]
+    d_o.free()
+    if d_v:
+        d_v.free()
+    return out
+
+
 class Pyramid:
     """svo_hip_pyramid: a batch of image pyramids resident in HBM."""
 
