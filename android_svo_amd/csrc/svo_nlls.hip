@@ -276,8 +276,8 @@ SVO_DEV float block_sequential(const float* __restrict__ vals, const uint8_t* __
 
 // The end of the weight-scale call: n_meas_ has grown by its pixels (n_meas_++ at :267 runs in that call too, and nobody
 // clears n_meas_ before it), and scale_ = scale_estimator_->compute(errors) for the frames whose iter_ is 0 (:281-283).
-// grid = n_slots, block = 256.  errs / terms: [slot][max_n][16] f32.
-__global__ __launch_bounds__(256) void nlls_scale_kernel(const FrameConst* __restrict__ fc, FrameState* __restrict__ st,
+// grid = n_slots, block = OS_THREADS.  errs / terms: [slot][max_n][16] f32.
+__global__ __launch_bounds__(OS_THREADS) void nlls_scale_kernel(const FrameConst* __restrict__ fc, FrameState* __restrict__ st,
                                                          NllsExt* __restrict__ ext, const float* __restrict__ errs_all,
                                                          const uint8_t* __restrict__ ok_all, float* __restrict__ terms_all, int max_n,
                                                          int scale_kind) {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void nlls_scale_kernel(const FrameConst* __res
       unsigned prefix = 0, rank = (unsigned)(n_err / 2);
       for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        s_hist[tid] = 0;
+        if (tid < 256) s_hist[tid] = 0;
         __syncthreads();
         for (int k = tid; k < n * 16; k += blockDim.x) {
           if (!ok[k >> 4]) continue;
@@ -502,7 +502,7 @@ SVO_DEV void lm_control_step(FrameState& s, NllsExt& e, const double* r, int lev
 // One workgroup per frame: lanes 0..28 add the frame's block rows in block order; the block adds the frame's
 // res*res*weight into one f32 in the reference's order (float chi2 ... chi2 += res*res*weight, :207,266); thread 0 takes the
 // control step.
-__global__ __launch_bounds__(256) void nlls_solve_kernel(const FrameConst* __restrict__ fc, FrameState* __restrict__ st, NllsExt* __restrict__ ext,
+__global__ __launch_bounds__(OS_THREADS) void nlls_solve_kernel(const FrameConst* __restrict__ fc, FrameState* __restrict__ st, NllsExt* __restrict__ ext,
                                                          const double* __restrict__ partial, const float* __restrict__ terms_all,
                                                          const uint8_t* __restrict__ ok_all, int max_n, int chunks, int n_slots, int level,
                                                          int n_iter, double eps, int early_stop, int method) {
@@ -518,6 +518,7 @@ __global__ __launch_bounds__(256) void nlls_solve_kernel(const FrameConst* __res
     r[tid] = v;
   }
   const float chi2 = os_block_sum(terms_all + (size_t)b * max_n * 16, ok_all + (size_t)b * max_n, fc[b].n_feat * 16, s_os);
+  __syncthreads();
   if (tid != 0) return;
   r[27] = (double)chi2;                                            // (the control steps divide (float)r[27] by (float)n_meas_, :285)
   if (method == SVO_HIP_SIA_METHOD_LEVENBERG_MARQUARDT) lm_control_step(st[b], ext[b], r, level, n_iter, eps);
@@ -649,7 +650,7 @@ int svo_nlls_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int
     SVO_CHECK_HIP(ctx, hipGetLastError());
     if (weights) {                                          // computeResiduals(model, false, true) (:28-29 / :105-106)
       if ((rc = launch_robust<true>(v, e, weight_function, chunks, tpw)) != SVO_HIP_OK) return rc;
-      hipLaunchKernelGGL(nlls_scale_kernel, dim3(n_slots), dim3(256), 0, ctx->stream, v.fc, v.st, e->ext, e->errs, e->err_ok, e->terms,
+      hipLaunchKernelGGL(nlls_scale_kernel, dim3(n_slots), dim3(OS_THREADS), 0, ctx->stream, v.fc, v.st, e->ext, e->errs, e->err_ok, e->terms,
                          v.max_n, scale_estimator);
       SVO_CHECK_HIP(ctx, hipGetLastError());
     }
@@ -657,7 +658,7 @@ int svo_nlls_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int
       // (without a robust cost the weight function is Unit: the same kernel, every weight 1)
       int r2 = launch_robust<false>(v, e, weights ? weight_function : SVO_HIP_SIA_WEIGHT_UNIT, chunks, tpw);
       if (r2 != SVO_HIP_OK) return r2;
-      hipLaunchKernelGGL(nlls_solve_kernel, dim3(n_slots), dim3(256), 0, ctx->stream, v.fc, v.st, e->ext, v.partial, e->terms, e->err_ok, v.max_n,
+      hipLaunchKernelGGL(nlls_solve_kernel, dim3(n_slots), dim3(OS_THREADS), 0, ctx->stream, v.fc, v.st, e->ext, v.partial, e->terms, e->err_ok, v.max_n,
                          chunks, n_slots, level, prm->n_iter, prm->eps, prm->early_stop, method);
       SVO_CHECK_HIP(ctx, hipGetLastError());
       return SVO_HIP_OK;
@@ -702,7 +703,7 @@ extern "C" int svo_hip_sia_solver_state(svo_hip_sia* sia, int slot, float* scale
 }
 
 namespace {
-__global__ __launch_bounds__(256) void ordered_sum_kernel(const float* __restrict__ vals, int n, float* __restrict__ out) {
+__global__ __launch_bounds__(OS_THREADS) void ordered_sum_kernel(const float* __restrict__ vals, int n, float* __restrict__ out) {
   __shared__ OsShared s_os;
   const float r = os_block_sum(vals, nullptr, n, s_os);
   if (threadIdx.x == 0) *out = r;
@@ -713,7 +714,7 @@ extern "C" int svo_hip_ordered_sum_f32_dev(svo_hip_ctx* ctx, const float* vals_d
   if (!ctx) return SVO_HIP_ERR_INVALID;
   SVO_REQUIRE(ctx, (vals_dev || !n) && out_dev && n <= (size_t)INT_MAX);
   SVO_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, vals_dev, (int)n, out_dev);
+  hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(OS_THREADS), 0, ctx->stream, vals_dev, (int)n, out_dev);
   SVO_CHECK_HIP(ctx, hipGetLastError());
   return SVO_HIP_OK;
 }

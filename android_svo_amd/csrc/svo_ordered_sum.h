@@ -1,7 +1,7 @@
 // svo_ordered_sum.h -- the f32 sum of a sequence of non-negative values EXACTLY as a scalar loop rounds it
 //     float s = 0; for (k = 0; k < n; ++k) s += x[k];
 // (the reference's chi2 += res*res*weight, S/sparse_img_align.cpp:266, and the sums of its scale estimators,
-// S/robust_cost.cpp:53-60,83-85), computed by a 256-thread workgroup instead of one lane's chain of n dependent additions.
+// S/robust_cost.cpp:53-60,83-85), computed by a 1024-thread workgroup instead of one lane's chain of n dependent additions.
 //
 // Why a sequential f32 sum of non-negative terms parallelises after all.  While the running sum s stays inside one
 // binade [2^e, 2^(e+1)) its unit in the last place u = 2^(e-23) is fixed and s = m*u with an integer m in [2^23, 2^24).
@@ -23,17 +23,18 @@
 
 namespace svo_dev {
 
-constexpr int OS_THREADS = 256;
-constexpr int OS_PER_THREAD = 16;
+constexpr int OS_THREADS = 1024;               // the workgroup: 16 waves, four per SIMD (a lone wave issues one instruction every ~5 cycles)
+constexpr int OS_WAVES = OS_THREADS / 64;
+constexpr int OS_PER_THREAD = 4;
 constexpr int OS_WINDOW = OS_THREADS * OS_PER_THREAD;
-constexpr int OS_SERIAL_HEAD = 512;            // elements one lane adds before the scans start (the sum is still small there)
-constexpr int OS_SERIAL_MAX = 4096;            // sequences up to this length are added by one lane altogether (cheaper)
+constexpr int OS_SERIAL_HEAD = 128;            // elements one lane adds before the scans start (the sum is still small there)
+constexpr int OS_SERIAL_MAX = 3072;            // sequences up to this length are added by one lane altogether (cheaper)
 constexpr unsigned OS_LIMIT = 1u << 24;        // m stays below: the binade's end in units of u
 constexpr unsigned OS_SAT = 1u << 26;          // unit counts saturate here (anything >= OS_LIMIT only says "past the end")
 
 struct OsShared {
   float stage[OS_WINDOW];
-  unsigned wave_fn[OS_THREADS / 64][2];
+  unsigned wave_fn[OS_WAVES][2];
   unsigned m_before[OS_THREADS];
   int cross[2];
   int invalid;
@@ -56,6 +57,31 @@ SVO_DEV OsFn os_compose(const OsFn& f, const OsFn& g) {
   h.f0 = os_sat_add(f.f0 & ~OS_PAR, g0 & ~OS_PAR) | (g0 & OS_PAR);
   h.f1 = os_sat_add(f.f1 & ~OS_PAR, g1 & ~OS_PAR) | (g1 & OS_PAR);
   return h;
+}
+
+// A word from another lane by DPP; a lane without a source keeps `keep` (the identity of the scan).
+template <int CTRL, int ROW_MASK>
+SVO_DEV unsigned os_dpp(unsigned keep, unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)keep, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+SVO_DEV OsFn os_dpp(const OsFn& v) {
+  OsFn p;
+  p.f0 = os_dpp<CTRL, ROW_MASK>(0u, v.f0);          // identity: (0 units, parity kept)
+  p.f1 = os_dpp<CTRL, ROW_MASK>(OS_PAR, v.f1);
+  return p;
+}
+
+// inclusive scan of the composition over the lanes of a wave, in lane order: shifts inside the rows of 16 lanes, then the
+// last lane of a row to the rows above it (DPP: no trip through the LDS crossbar, a handful of cycles per step)
+SVO_DEV OsFn os_wave_scan(OsFn v) {
+  v = os_compose(os_dpp<0x111, 0xf>(v), v);          // row_shr:1
+  v = os_compose(os_dpp<0x112, 0xf>(v), v);          // row_shr:2
+  v = os_compose(os_dpp<0x114, 0xf>(v), v);          // row_shr:4
+  v = os_compose(os_dpp<0x118, 0xf>(v), v);          // row_shr:8
+  v = os_compose(os_dpp<0x142, 0xa>(v), v);          // row_bcast:15 into rows 1 and 3
+  v = os_compose(os_dpp<0x143, 0xc>(v), v);          // row_bcast:31 into rows 2 and 3
+  return v;
 }
 
 // s >= 0 finite: s = m * 2^ue, the unit of its binade (2^-149 for subnormals and for [2^-126, 2^-125))
@@ -97,22 +123,33 @@ SVO_DEV void os_decode(unsigned M, int ex, int ue, unsigned* q, unsigned* kind) 
   }
 }
 
-// The sum of vals[0 .. N) in index order, every thread of the 256-thread workgroup calling (all of them get the result).
+// The sum of vals[0 .. N) in index order, every thread of the OS_THREADS-thread workgroup calling (all of them get the result).
 // ok16 (optional): one flag per 16 values; a group whose flag is 0 is skipped (adds +0, which changes nothing).
 SVO_DEV float os_block_sum(const float* __restrict__ vals, const uint8_t* __restrict__ ok16, int N, OsShared& sh) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float inf = __int_as_float(0x7f800000);
   float S = 0.0f;
   unsigned phase = 0;
-  for (int base = 0; base < N; base += OS_WINDOW) {
+  // a window's values are asked for while the window before it is being added
+  auto fetch = [&](int base, float* x) {
     const int k0 = base + tid * OS_PER_THREAD;
-    const bool live = k0 < N && (!ok16 || ok16[k0 >> 4]);
+    const bool live = k0 < N && (!ok16 || ok16[k0 >> 4]);            // (a thread's OS_PER_THREAD elements lie inside one group of 16)
+#pragma unroll
+    for (int j = 0; j < OS_PER_THREAD; ++j) x[j] = (live && k0 + j < N) ? vals[k0 + j] : 0.0f;
+  };
+  float xn[OS_PER_THREAD];
+  fetch(0, xn);
+  for (int base = 0; base < N; base += OS_WINDOW) {
     unsigned M[OS_PER_THREAD];
     int ex[OS_PER_THREAD];
     bool bad = false;
+    float xc[OS_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < OS_PER_THREAD; ++j) xc[j] = xn[j];
+    if (base + OS_WINDOW < N) fetch(base + OS_WINDOW, xn);
 #pragma unroll
     for (int j = 0; j < OS_PER_THREAD; ++j) {
-      const float x = (live && k0 + j < N) ? vals[k0 + j] : 0.0f;
+      const float x = xc[j];
       bad = bad || x < 0.0f || !(x < inf);                                  // negative, infinite or NaN
       sh.stage[tid * OS_PER_THREAD + j] = x;
       os_split(x, &M[j], &ex[j]);
@@ -159,32 +196,30 @@ SVO_DEV float os_block_sum(const float* __restrict__ vals, const uint8_t* __rest
         i1 = os_sat_add(i1, d1); p1 = (p1 + d1) & 1u;
       }
       // inclusive scan over the wave, the waves' totals through LDS
-      OsFn incl = {i0 | (p0 << 31), i1 | (p1 << 31)};
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        OsFn p;
-        p.f0 = __shfl_up(incl.f0, off, 64); p.f1 = __shfl_up(incl.f1, off, 64);
-        if (lane >= off) incl = os_compose(p, incl);
-      }
+      const OsFn incl = os_wave_scan(OsFn{i0 | (p0 << 31), i1 | (p1 << 31)});
       if (lane == 63) { sh.wave_fn[wave][0] = incl.f0; sh.wave_fn[wave][1] = incl.f1; }
       int* cross = &sh.cross[phase & 1u];
       if (tid == 0) *cross = INT_MAX;
       __syncthreads();
-      OsFn before = {0u, OS_PAR}, total = {0u, OS_PAR};
-#pragma unroll
-      for (int w = 0; w < OS_THREADS / 64; ++w) {
-        const OsFn g = {sh.wave_fn[w][0], sh.wave_fn[w][1]};
-        if (w < wave) before = os_compose(before, g);
-        total = os_compose(total, g);
+      // every wave scans the waves' totals itself (lanes 0..OS_WAVES-1), takes what lies before it and the grand total
+      OsFn wt = {0u, OS_PAR};
+      if (lane < OS_WAVES) { wt.f0 = sh.wave_fn[lane][0]; wt.f1 = sh.wave_fn[lane][1]; }
+      wt = os_wave_scan(wt);                        // (lanes past OS_WAVES - 1 hold the identity: they compose to the grand total)
+      OsFn before = {0u, OS_PAR}, total;
+      total.f0 = (unsigned)__builtin_amdgcn_readlane((int)wt.f0, OS_WAVES - 1); total.f1 = (unsigned)__builtin_amdgcn_readlane((int)wt.f1, OS_WAVES - 1);
+      if (wave > 0) {                               // wave-uniform
+        before.f0 = (unsigned)__builtin_amdgcn_readlane((int)wt.f0, wave - 1);
+        before.f1 = (unsigned)__builtin_amdgcn_readlane((int)wt.f1, wave - 1);
       }
       {
-        OsFn p;
-        p.f0 = __shfl_up(incl.f0, 1, 64); p.f1 = __shfl_up(incl.f1, 1, 64);
-        if (lane > 0) before = os_compose(before, p);
+        // what the lanes below mine add: the inclusive scan one lane down (wave_shr:1; lane 0 keeps the identity)
+        const OsFn p = os_dpp<0x138, 0xf>(incl);
+        before = os_compose(before, p);
       }
       const unsigned p_start = m0 & 1u;
       const unsigned bf = p_start ? before.f1 : before.f0;
       unsigned m = os_sat_add(m0, bf & ~OS_PAR), par = bf >> 31;
+      const unsigned m_in = m;
       // walk my elements with the true running count: the first addition that leaves the binade
       int cross_j = -1;
       unsigned m_before = 0;
@@ -197,7 +232,9 @@ SVO_DEV float os_block_sum(const float* __restrict__ vals, const uint8_t* __rest
           else { m += d; par = (par + d) & 1u; }
         }
       }
-      if (cross_j >= 0) { sh.m_before[tid] = m_before; atomicMin(cross, tid * OS_PER_THREAD + cross_j); }
+      // (every thread behind the crossing one sees a count past the end too: only the one whose own incoming count is
+      // still inside the binade is the first -- one atomic per phase, not a thousand on one address)
+      if (cross_j >= 0 && m_in < OS_LIMIT) { sh.m_before[tid] = m_before; atomicMin(cross, tid * OS_PER_THREAD + cross_j); }
       __syncthreads();
       const int kx = *cross;
       if (kx == INT_MAX) {                        // the window ends inside this binade

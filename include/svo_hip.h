@@ -276,7 +276,7 @@ int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
  * successive values differ by a few units in the last place of the reference's f32 sum, the error-increase exit can fall
  * one iteration earlier or later than in the reference (poses then differ by < 2e-5 rad / 5e-5 m on the scenes tested).
  * _REFERENCE_ORDER: the squares go to memory and are added in the reference's order: chi2_ is the reference's bit
- * for bit and every exit falls where the reference's does.  Costs ~25 us per evaluation at 200 patches (one lane) and ~85 us
+ * for bit and every exit falls where the reference's does.  Costs ~25 us per evaluation at 200 patches (one lane) and ~60 us
  * at 2000 (a workgroup: svo_hip_ordered_sum_f32_dev below) on top of the streaming kernels (svo_hip_sia_last_run_mode 0);
  * Levenberg-Marquardt and the robust costs always use it. */
 #define SVO_HIP_SIA_CHI2_PER_PATCH 0
@@ -294,10 +294,10 @@ int svo_hip_sia_set_reduce_buffer(svo_hip_sia* sia, void* dev_ptr);
 int svo_hip_sia_set_option(svo_hip_sia* sia, int option, int value);
 /* The f32 sum of n values in index order, rounded exactly as `float s = 0; for (k...) s += x[k];` rounds it -- the form
  * of the reference's chi2 (S/sparse_img_align.cpp:207,266) and of its scale estimators' sums (S/robust_cost.cpp:53-60,83-85)
- * -- by one 256-thread workgroup instead of a chain of n dependent additions (android_svo_amd/csrc/svo_ordered_sum.h: inside
+ * -- by one 1024-thread workgroup instead of a chain of n dependent additions (android_svo_amd/csrc/svo_ordered_sum.h: inside
  * a binade a non-negative addition depends on its predecessors through the parity of the running sum only; sequences of up
- * to 4096 values, and any stretch with a negative, infinite or NaN value, are added by one lane).  1.6 ns per value for long
- * sequences against 7 ns for the one-lane chain (tools/ordered_sum_probe.py).  Enqueued on the context's stream.  What
+ * to 3072 values, and any stretch with a negative, infinite or NaN value, are added by one lane).  1.0 ns per value for long
+ * sequences, 62 us for 32 000 values, against 7-9 ns per value for the one-lane chain (tools/ordered_sum_probe.py).  Enqueued on the context's stream.  What
  * SVO_HIP_SIA_CHI2_REFERENCE_ORDER, Levenberg-Marquardt and the robust costs use. */
 int svo_hip_ordered_sum_f32_dev(svo_hip_ctx* ctx, const float* vals_dev, size_t n, float* out_dev);
 /* scale_, mu_ and nu_ of one slot as the last svo_hip_sia_run with Levenberg-Marquardt or a robust cost left them

@@ -4,7 +4,7 @@ sys.path.insert(0, '/root/repo')
 from android_svo_amd import hip
 ctx = hip.Context(0)
 rng = np.random.default_rng(1)
-for n in (3200, 8192, 32000, 131072, 1048576):
+for n in (1024, 1600, 2048, 3200, 4096, 8192, 32000, 131072, 1048576):
     x = (rng.normal(0, 6, n).astype(np.float32) ** 2).astype(np.float32)
     d_v = hip.DeviceArray(ctx, x); d_o = hip.DeviceArray(ctx, shape=(1,), dtype=np.float32)
     def run(k):
