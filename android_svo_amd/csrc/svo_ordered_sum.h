@@ -28,12 +28,12 @@ constexpr int OS_WAVES = OS_THREADS / 64;
 constexpr int OS_PER_THREAD = 4;
 constexpr int OS_WINDOW = OS_THREADS * OS_PER_THREAD;
 constexpr int OS_SERIAL_HEAD = 128;            // elements one lane adds before the scans start (the sum is still small there)
-constexpr int OS_SERIAL_MAX = 3072;            // sequences up to this length are added by one lane altogether (cheaper)
+constexpr int OS_SERIAL_MAX = 4096;            // sequences up to this length are added by one lane altogether (cheaper)
 constexpr unsigned OS_LIMIT = 1u << 24;        // m stays below: the binade's end in units of u
 constexpr unsigned OS_SAT = 1u << 26;          // unit counts saturate here (anything >= OS_LIMIT only says "past the end")
 
 struct OsShared {
-  float stage[OS_WINDOW];
+  __attribute__((aligned(16))) float stage[OS_WINDOW];
   unsigned wave_fn[OS_WAVES][2];
   unsigned m_before[OS_THREADS];
   int cross[2];
@@ -165,8 +165,22 @@ SVO_DEV float os_block_sum(const float* __restrict__ vals, const uint8_t* __rest
       const int left = N - base < OS_WINDOW ? N - base : OS_WINDOW;
       const int cnt = serial_all ? left : (left < OS_SERIAL_HEAD ? left : OS_SERIAL_HEAD);
       if (tid == 0) {
+        // 16 values per step, the next 16 on their way out of LDS while this step's chain of additions runs (a lone lane
+        // issues an instruction every ~5 cycles: the chain is as long as its instruction count)
         float a = S;
-        for (int k = 0; k < cnt; ++k) a += sh.stage[k];
+        const float4* q = reinterpret_cast<const float4*>(sh.stage);
+        const int n16 = cnt / 16;
+        float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+        for (int i = 0; i < n16; ++i) {
+          const float4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
+          const int nx = i + 1 < n16 ? i + 1 : i;
+          n0 = q[4 * nx]; n1 = q[4 * nx + 1]; n2 = q[4 * nx + 2]; n3 = q[4 * nx + 3];
+          a += v0.x; a += v0.y; a += v0.z; a += v0.w;
+          a += v1.x; a += v1.y; a += v1.z; a += v1.w;
+          a += v2.x; a += v2.y; a += v2.z; a += v2.w;
+          a += v3.x; a += v3.y; a += v3.z; a += v3.w;
+        }
+        for (int k = 16 * n16; k < cnt; ++k) a += sh.stage[k];
         sh.S = a;
       }
       __syncthreads();

@@ -296,8 +296,8 @@ int svo_hip_sia_set_option(svo_hip_sia* sia, int option, int value);
  * of the reference's chi2 (S/sparse_img_align.cpp:207,266) and of its scale estimators' sums (S/robust_cost.cpp:53-60,83-85)
  * -- by one 1024-thread workgroup instead of a chain of n dependent additions (android_svo_amd/csrc/svo_ordered_sum.h: inside
  * a binade a non-negative addition depends on its predecessors through the parity of the running sum only; sequences of up
- * to 3072 values, and any stretch with a negative, infinite or NaN value, are added by one lane).  1.0 ns per value for long
- * sequences, 62 us for 32 000 values, against 7-9 ns per value for the one-lane chain (tools/ordered_sum_probe.py).  Enqueued on the context's stream.  What
+ * to 4096 values, and any stretch with a negative, infinite or NaN value, are added by one lane).  1.0 ns per value for long
+ * sequences, 62 us for 32 000 values, against 5 ns per value for the one-lane chain (tools/ordered_sum_probe.py).  Enqueued on the context's stream.  What
  * SVO_HIP_SIA_CHI2_REFERENCE_ORDER, Levenberg-Marquardt and the robust costs use. */
 int svo_hip_ordered_sum_f32_dev(svo_hip_ctx* ctx, const float* vals_dev, size_t n, float* out_dev);
 /* scale_, mu_ and nu_ of one slot as the last svo_hip_sia_run with Levenberg-Marquardt or a robust cost left them
