@@ -234,3 +234,25 @@ def test_random_small_configs_fuzz(ctx):
                 if combo[1] and rot < 1e-12:
                     assert np.float32(scale) == np.float32(o.scale), (gi, combo, i, scale, o.scale)
     assert n_checked > 60 and n_degenerate > 5, (n_checked, n_degenerate)
+
+
+def test_full_size_batch_of_c1_frames(ctx):
+    """64 frame pairs of BASELINE config C1's size (2000 patches, 640x480, L4..L0) in one call through Levenberg-Marquardt
+    with MAD / Huber: four distinct scenes, sixteen replicas each.  Replicas must agree bit for bit (a slot's result does
+    not depend on its position or its neighbours), every scene with its oracle run, and the in-order chi2 sum takes the
+    workgroup path here (32 000 values per frame)."""
+    scenes = [synth.make_frame_pair(seed=500 + i, n_features=2000) for i in range(4)]
+    fps = [scenes[i % 4] for i in range(64)]
+    combo = (1, 2, 3)
+    out, mode = _run(ctx, fps, 4, 0, 30, combo)
+    assert mode == 0
+    for s in range(4):
+        o = orc.sparse_img_align(scenes[s], 4, 0, 30, method=1, scale_estimator=2, weight_function=3)
+        r0, st0 = out[s]
+        rot, trans = synth.pose_error(np.array(r0.T_cur_w), np.array(o.T_cur_w))
+        assert rot < 5e-8 and trans < 5e-8, (s, rot, trans)
+        assert r0.n_tracked == o.n_tracked and int(r0.stop) == o.stop and np.float32(st0[0]) == np.float32(o.scale)
+        assert abs(r0.chi2 - o.chi2) <= 2.5e-7 * o.chi2
+        for k in range(s + 4, 64, 4):
+            r, st = out[k]
+            assert np.array_equal(np.array(r.T_cur_w), np.array(r0.T_cur_w)) and r.chi2 == r0.chi2 and st == st0 and list(r.iters) == list(r0.iters), (s, k)
