@@ -213,6 +213,11 @@ SIA_REF_CASES = [
     ("bigmotion_320", dict(seed=902, width=320, height=240, n_features=300, border=6, t_mag=0.12, r_mag=0.04), 4, 0, 30),
     ("iters5", dict(seed=12347, n_features=600), 3, 1, 5),
     ("empty", dict(seed=12345, n_features=0), 4, 0, 30),
+    # BASELINE config C3's frame size, the shipping level range (Config::kltMaxLevel / kltMinLevel: L4..L2) at C1's size,
+    # a frame above the fused kernel's 2816 features (the streaming kernels)
+    ("hd_1280", dict(seed=12350, width=1280, height=720, n_features=2000), 4, 0, 30),
+    ("c1_l4_l2", dict(seed=12351, n_features=2000), 4, 2, 30),
+    ("big_3500", dict(seed=12352, n_features=3500), 4, 0, 30),
 ]
 
 

@@ -961,7 +961,7 @@ def test_fast_arithmetic_against_reference_run(ctx, golden, case):
     sia.set_option(hip.SIA_OPT_ARITH, hip.SIA_ARITH_FAST)
     prm = sia.params(max_level=max_level, min_level=min_level, n_iter=n_iter, eps=1e-6, early_stop=True)
     sia.run(1, prm)
-    assert sia.last_run_mode() == 1
+    assert sia.last_run_mode() == (1 if len(fp.px) <= 2816 else 0)       # (a frame above 2816 features: the streaming kernels, always EXACT)
     r = sia.download(0)
     rot, trans = synth.pose_error(np.array(r.T_cur_w), g[name + "_T"])
     assert rot < 1e-4 and trans < 1e-3, (rot, trans)            # north_star tolerance
