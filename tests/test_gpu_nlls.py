@@ -256,3 +256,39 @@ def test_full_size_batch_of_c1_frames(ctx):
         for k in range(s + 4, 64, 4):
             r, st = out[k]
             assert np.array_equal(np.array(r.T_cur_w), np.array(r0.T_cur_w)) and r.chi2 == r0.chi2 and st == st0 and list(r.iters) == list(r0.iters), (s, k)
+
+
+def test_one_solver_with_a_growing_number_of_slots(ctx):
+    """The branch state (per-slot records, the error / term buffers) is sized by the slots a call uses and grows with them:
+    a solver run with 2, then 6, then 3 slots gives every slot the same bits each time, and goes back to the fused kernel
+    when the options are taken off again."""
+    fps = [synth.make_frame_pair(seed=900 + i, n_features=n) for i, n in enumerate((300, 64, 555, 200, 17, 410))]
+    cam = fps[0].cam
+    ref = hip.Pyramid(ctx, cam.width, cam.height, 5, 6)
+    cur = hip.Pyramid(ctx, cam.width, cam.height, 5, 6)
+    sia = hip.SparseImgAlign(ctx, 6, 600)
+    sia.set_frames(ref, cur)
+    for i, fp in enumerate(fps):
+        ref.upload(i, fp.ref_pyr); cur.upload(i, fp.cur_pyr); sia.upload_pair(i, fp)
+    prm = sia.params(n_iter=10)
+    sia.run(6, prm)
+    plain = [np.array(sia.download(i).T_cur_w) for i in range(6)]
+    assert sia.last_run_mode() == 1
+    sia.set_method(hip.SIA_METHOD_LEVENBERG_MARQUARDT)
+    sia.set_robust_cost_function(hip.SIA_SCALE_TDIST, hip.SIA_WEIGHT_TUKEY)
+    seen = {}
+    for n_slots in (2, 6, 3):
+        sia.run(n_slots, prm)
+        assert sia.last_run_mode() == 0
+        for i in range(n_slots):
+            r, st = sia.download(i), sia.solver_state(i)
+            key = ([float(v).hex() for v in r.T_cur_w], r.chi2, list(r.iters), st)
+            assert seen.setdefault(i, key) == key, (n_slots, i)
+    sia.set_method(hip.SIA_METHOD_GAUSS_NEWTON)
+    sia.set_robust_cost_function(hip.SIA_SCALE_UNIT, hip.SIA_WEIGHT_UNIT)
+    sia.run(6, prm)
+    assert sia.last_run_mode() == 1
+    for i in range(6):
+        assert np.array_equal(np.array(sia.download(i).T_cur_w), plain[i])
+    for o in (sia, ref, cur):
+        o.destroy()
