@@ -114,12 +114,13 @@ def host_cpus():
 def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=16):
     """CPU baseline on the host cores, bounded sample.
 
-    Fixed-work workload (the default, BASELINE config C1's "30 GN iters"): the C oracle (`kind: port`) -- the
-    reference's solver cannot be made to do fixed work without editing it (its error-increase exit is unconditional).
-    Reference early-stop workload (--early-stop): the reference's OWN compiled SparseImgAlign (oracle/_ref, `kind:
-    reference`) when the prebuilt library travelled to this box, else the port.  In the fixed-work case the line
-    also carries a side-by-side early-stop timing of port and reference (`reference_check`), which shows how close
-    the port's speed is to the real thing.
+    Both workloads run the reference's OWN compiled code (oracle/_ref, `kind: reference`) when the prebuilt library
+    travelled to this box, else the C oracle (`kind: port`; the line then also carries `reference_check` = none).
+    Fixed work (the default, BASELINE config C1's "30 GN iters"): the reference's compiled computeResiduals / solve /
+    update, exactly 30 evaluations per level -- the loop around them is oracle/ref/ref_objects.cpp's, because the
+    reference's own loop cannot be made to do fixed work (its error-increase exit is unconditional); results equal
+    the port's bit for bit (tests/test_oracle_reference_objects.py).  Early stop (--early-stop): the reference's
+    whole optimize().
 
     Threads: one independent frame pair at a time per thread (the reference's run() is serial), once with as many
     threads as the process is granted CPUs and -- when the host shows more logical CPUs than that -- once with one thread
@@ -135,11 +136,13 @@ def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=16):
     except Exception:
         have_ref = False
     nproc, usable = host_cpus()
-    use_ref = bool(early_stop and have_ref)
+    use_ref = bool(have_ref)
 
     def one(fp):
-        if use_ref:
+        if use_ref and early_stop:
             refpy.sparse_img_align_run(fp, n_iter=n_iter)
+        elif use_ref:
+            refpy.sparse_img_align_fixed_work(fp, n_iter=n_iter)
         else:
             orc.sparse_img_align(fp, n_iter=n_iter, early_stop=early_stop)
 
@@ -170,19 +173,8 @@ def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=16):
            "sample": "%d frame pairs (640x480, %d patches, L4-L0, %s) on %d threads in %.1f s; 1 thread: %.2f frames/s" %
                      (best["frames"], len(fps[0].px), "early stop" if early_stop else "30 GN evaluations/level fixed work",
                       best["threads"], best["seconds"], 1.0 / single)}
-    if have_ref and not early_stop:
-        def timed(fn, reps=3):
-            fn()
-            t = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            return (time.perf_counter() - t) / reps * 1e3
-        out["reference_check"] = {
-            "what": "one frame pair, reference early-stop semantics, 1 thread: the reference's own compiled SparseImgAlign (oracle/_ref) beside the port",
-            "reference_ms": timed(lambda: refpy.sparse_img_align_run(fps[0], n_iter=n_iter)),
-            "port_ms": timed(lambda: orc.sparse_img_align(fps[0], n_iter=n_iter, early_stop=True))}
-        # the port is slower than the reference's own code: a ratio of `value` to the port is that much LARGER than one to the reference
-        out["port_vs_reference_speed"] = out["reference_check"]["reference_ms"] / out["reference_check"]["port_ms"]
+    if use_ref and not early_stop:
+        out["driver"] = "harness loop of 30 evaluations/level around the reference's compiled computeResiduals/solve/update"
     return out
 
 
@@ -191,7 +183,7 @@ def c0_leg(ctx, n_scenes=8, batch=1024):
     timed as SURVEY 8(d) 'CPU baseline timing' asks: both Gauss-Newton modes; ONE PINNED CORE, median of 20 runs after 3
     warm-ups (the reference's run() is serial); all granted cores, one independent pair per thread.  Early stop is the
     reference's OWN compiled SparseImgAlign (oracle/_ref, kind "reference") when the prebuilt library is on this box, else the
-    port; fixed work is the port (the reference's error-increase exit cannot be switched off).  Beside it the GPU's C0 figures:
+    port; fixed work is the reference's compiled computeResiduals / solve / update in a 30-evaluation loop (see cpu_baseline).  Beside it the GPU's C0 figures:
     one pair at a time (latency) and `batch` pairs per launch (the 4-wave shape: two pairs per CU)."""
     from oracle import orc
     orc.lib()
@@ -205,7 +197,7 @@ def c0_leg(ctx, n_scenes=8, batch=1024):
     fps = [synth.make_frame_pair(seed=777 + i, n_features=200) for i in range(n_scenes)]
     n_patches = len(fps[0].px)
     es = (lambda fp: refpy.sparse_img_align_run(fp, n_iter=30)) if have_ref else (lambda fp: orc.sparse_img_align(fp, n_iter=30, early_stop=True))
-    fw = lambda fp: orc.sparse_img_align(fp, n_iter=30, early_stop=False)
+    fw = (lambda fp: refpy.sparse_img_align_fixed_work(fp, n_iter=30)) if have_ref else (lambda fp: orc.sparse_img_align(fp, n_iter=30, early_stop=False))
 
     def pinned_median(fn):
         old = None
@@ -242,7 +234,7 @@ def c0_leg(ctx, n_scenes=8, batch=1024):
     es_fps, cores = all_cores(es, 40)
     fw_fps, _ = all_cores(fw, 8)
     cpu = {"es_ms_1core": es_ms, "fw_ms_1core": fw_ms, "es_fps": es_fps, "fw_fps": fw_fps, "cores": cores,
-           "kind_es": "reference" if have_ref else "port", "kind_fw": "port"}
+           "kind_es": "reference" if have_ref else "port", "kind_fw": "reference" if have_ref else "port"}
     # ---- the GPU on the same pairs
     cam = fps[0].cam
     ref = hip.Pyramid(ctx, cam.width, cam.height, 5, batch)

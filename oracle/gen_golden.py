@@ -250,6 +250,12 @@ def gen_sia_ref():
         out[name + "_cache64"] = r["ref_patch_cache"][:k]
         out[name + "_jac64"] = r["jacobian_cache"][:k * 16]
         out[name + "_cache_crc"] = np.array([crc(r["ref_patch_cache"]), crc(r["jacobian_cache"])], dtype=np.uint64)
+        # fixed work: exactly n_iter evaluations per level through the reference's compiled computeResiduals / solve / update
+        fw = refpy.sparse_img_align_fixed_work(fp, max_level=max_level, min_level=min_level, n_iter=n_iter)
+        out[name + "_fw_T"] = fw["T_cur_w"]
+        out[name + "_fw_H"] = fw["H"]
+        out[name + "_fw_chi2"] = np.array(fw["chi2"])
+        out[name + "_fw_n_tracked"] = np.array(fw["n_tracked"])
         print("sia_ref", name, "n", n, "tracked", r["n_tracked"], "iter", r["iter"][:5], "stop", r["stop"])
     np.savez_compressed(os.path.join(OUT, "sia_ref.npz"), **out)
 

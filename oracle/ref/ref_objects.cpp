@@ -128,6 +128,16 @@ int ref_sparse_img_align_run_ex(int width, int height, double fx, double fy, dou
                              float* ref_patch_cache_out, double* jacobian_cache_out, uint8_t* visible_out,
                              double* scale_mu_out /*[3]*/);
 
+// Fixed work (BASELINE config C1's "30 GN iters"): the reference's compiled computeResiduals / solve / update, exactly
+// n_iter evaluations per level.  Its own optimizeGaussNewton cannot do that (the error-increase exit is unconditional,
+// nlls_solver_impl.hpp:62), so the loop around the three members (:35-60 without the exits) is made here.
+static thread_local int g_fixed_work = 0;
+int ref_sparse_img_align_run_fixed_work(int width, int height, double fx, double fy, double cx, double cy, int n_levels,
+                             const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr, int n,
+                             const double* px, const double* fv, const double* pos, const uint8_t* has_point,
+                             const double* T_ref_w, const double* T_cur_w_init, int max_level, int min_level,
+                             int n_iter, double* T_cur_w_out, size_t* n_tracked, double* H_out, double* chi2_out);
+
 int ref_sparse_img_align_run(int width, int height, double fx, double fy, double cx, double cy, int n_levels,
                              const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr, int n,
                              const double* px, const double* fv, const double* pos, const uint8_t* has_point,
@@ -150,6 +160,7 @@ int ref_sparse_img_align_run_ex(int width, int height, double fx, double fy, dou
                              int* stop_out, int* iter_per_level /*[8]*/, size_t* n_meas_per_level /*[8]*/,
                              float* ref_patch_cache_out, double* jacobian_cache_out, uint8_t* visible_out,
                              double* scale_mu_out) {
+  const bool fixed_work = g_fixed_work != 0;
   HarnessPinhole cam(width, height, fx, fy, cx, cy);
   HandFrame ref(&cam, ref_pyr, width, height, n_levels, T_ref_w);
   HandFrame cur(&cam, cur_pyr, width, height, n_levels, T_cur_w_init);
@@ -195,7 +206,21 @@ int ref_sparse_img_align_run_ex(int width, int height, double fx, double fy, dou
       s->mu_ = 0.1;
       s->jacobian_cache_.setZero();
       s->have_ref_patch_cache_ = false;
-      s->optimize(T_cur_from_ref);
+      if (fixed_work) {
+        for (s->iter_ = 0; s->iter_ < s->n_iter_; ++s->iter_) {
+          s->H_.setZero();
+          s->Jres_.setZero();
+          s->n_meas_ = 0;
+          const double new_chi2 = s->computeResiduals(T_cur_from_ref, true, false);
+          if (!s->solve()) { s->stop_ = true; break; }
+          SE3 T_new;
+          s->update(T_cur_from_ref, T_new);
+          T_cur_from_ref = T_new;
+          s->chi2_ = new_chi2;
+        }
+      } else {
+        s->optimize(T_cur_from_ref);
+      }
       if (s->level_ < 8) { iter_per_level[s->level_] = (int)s->iter_; n_meas_per_level[s->level_] = s->n_meas_; }
     }
     cur_frame->T_f_w_ = T_cur_from_ref * ref_frame->T_f_w_;
@@ -222,6 +247,21 @@ int ref_sparse_img_align_run_ex(int width, int height, double fx, double fy, dou
   std::free(cache);
   std::free(storage);
   return 0;
+}
+
+int ref_sparse_img_align_run_fixed_work(int width, int height, double fx, double fy, double cx, double cy, int n_levels,
+                             const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr, int n,
+                             const double* px, const double* fv, const double* pos, const uint8_t* has_point,
+                             const double* T_ref_w, const double* T_cur_w_init, int max_level, int min_level,
+                             int n_iter, double* T_cur_w_out, size_t* n_tracked, double* H_out, double* chi2_out) {
+  int stop = 0, iters[8] = {0};
+  size_t n_meas[8] = {0};
+  g_fixed_work = 1;
+  const int rc = ref_sparse_img_align_run_ex(width, height, fx, fy, cx, cy, n_levels, ref_pyr, cur_pyr, n, px, fv, pos, has_point, T_ref_w,
+                                             T_cur_w_init, max_level, min_level, n_iter, 0, 0, 0, T_cur_w_out, n_tracked, H_out, chi2_out,
+                                             &stop, iters, n_meas, nullptr, nullptr, nullptr, nullptr);
+  g_fixed_work = 0;
+  return rc;
 }
 
 // Matcher::findEpipolarMatchDirect (matcher.cpp:207-355) on real frames.

@@ -203,6 +203,22 @@ def sparse_img_align_run(fp, max_level=4, min_level=0, n_iter=30, T_cur_w_init=N
             "n_meas": n_meas, "ref_patch_cache": cache[:n], "jacobian_cache": jac[:n * 16], "visible": vis[:n]}
 
 
+def sparse_img_align_fixed_work(fp, max_level=4, min_level=0, n_iter=30, T_cur_w_init=None):
+    """Exactly n_iter evaluations per level through the reference's compiled computeResiduals / solve / update (the loop
+    around them is the harness's: the reference's own has an unconditional error-increase exit)."""
+    rp, cp = orc.pyr_ptrs(fp.ref_pyr), orc.pyr_ptrs(fp.cur_pyr)
+    px, f, pos = f64(fp.px), f64(fp.f), f64(fp.pos)
+    hp = np.ascontiguousarray(fp.has_point, dtype=np.uint8)
+    T_ref = f64(fp.T_ref_w)
+    T_init = f64(fp.T_cur_w_init if T_cur_w_init is None else T_cur_w_init)
+    T_out, H = np.zeros(7), np.zeros(36)
+    nt, chi2 = C.c_size_t(0), D(0)
+    lib().ref_sparse_img_align_run_fixed_work(*_cam_args(fp.cam), C.c_int(len(fp.ref_pyr)), rp, cp, C.c_int(len(px)), _p(px, D), _p(f, D),
+                                              _p(pos, D), _p(hp, C.c_uint8), _p(T_ref, D), _p(T_init, D), C.c_int(max_level),
+                                              C.c_int(min_level), C.c_int(n_iter), _p(T_out, D), C.byref(nt), _p(H, D), C.byref(chi2))
+    return {"T_cur_w": T_out, "n_tracked": nt.value, "H": H, "chi2": chi2.value}
+
+
 def find_epipolar_match_direct(cam, ref_pyr, cur_pyr, T_ref_w, T_cur_w, px_ref, f_ref, level_ref, d_estimate, d_min,
                                d_max):
     rp, cp = orc.pyr_ptrs(ref_pyr), orc.pyr_ptrs(cur_pyr)

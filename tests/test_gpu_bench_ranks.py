@@ -89,7 +89,7 @@ def test_default_bench_line_fits_the_drivers_tail_and_carries_the_contract():
     r = d["roofline"]
     assert r["bound"] in ("valu", "hbm") and 0.0 < r["frac"] <= 1.0 and r["peak"] > 0 and r["traffic"] > 0 and "profile_refused" not in r
     c = d["cpu_baseline"]
-    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] in ("port", "reference") and 0.5 < c["port_vs_reference_speed"] < 1.5
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] in ("port", "reference") and (c["kind"] == "port" or "driver" in c)
     assert d["pose_err_vs_cpu_ref"]["max_rot_rad_over_scenes"] < 1e-4 and d["pose_err_vs_cpu_ref"]["n_tracked_equal_in_every_scene"]
     for lvl in ("moments_f32_arithmetic", "fast_arithmetic"):
         assert d[lvl]["value"] > 0 and 0.0 < d[lvl]["roofline"]["frac"] <= 1.0 and d[lvl]["pose_err_vs_cpu_ref"]["max_rot_rad_over_scenes"] < 1e-6

@@ -916,6 +916,29 @@ def test_sparse_img_align_against_reference_run(ctx, sia_mode, golden, case):
     _free(sia, ref, cur)
 
 
+@pytest.mark.parametrize("case", [c for c in _ref_cases() if c[1].get("n_features", 1)], ids=[c[0] for c in _ref_cases() if c[1].get("n_features", 1)])
+def test_fixed_work_mode_against_the_reference_members(ctx, sia_mode, golden, case):
+    """The bench's workload -- exactly n_iter evaluations per level -- against the reference's compiled computeResiduals /
+    solve / update driven for exactly that many evaluations (tests/golden/sia_ref.npz `_fw_*`): no data-dependent control
+    flow on either side, so the poses agree to summation-order noise amplified by the solve (large motion: 1e-8)."""
+    from oracle import gen_golden
+    name, kw, max_level, min_level, n_iter = case
+    g = golden("sia_ref.npz")
+    fp = gen_golden.make_sia_case(kw)
+    ref, cur, sia = _upload_pair(ctx, [fp], max_feat=len(fp.px))
+    sia.run(1, sia.params(max_level=max_level, min_level=min_level, n_iter=n_iter, eps=1e-6, early_stop=False))
+    r = sia.download(0)
+    assert all(r.iters[level] == n_iter for level in range(min_level, max_level + 1))
+    assert r.n_tracked == int(g[name + "_fw_n_tracked"])
+    rot, trans = synth.pose_error(np.array(r.T_cur_w), g[name + "_fw_T"])
+    bound = 1e-7 if _tight() else 5e-7                          # (the opt-in f32-moments level on a 102-patch frame: 2.7e-7 m)
+    assert rot < bound and trans < bound, (rot, trans)
+    H = np.array(r.H)
+    assert np.abs(H - g[name + "_fw_H"]).max() <= 1e-6 * np.abs(g[name + "_fw_H"]).max()
+    assert abs(r.chi2 - float(g[name + "_fw_chi2"])) <= 1e-4 * float(g[name + "_fw_chi2"])
+    _free(sia, ref, cur)
+
+
 @pytest.mark.parametrize("case", _ref_cases(), ids=[c[0] for c in _ref_cases()])
 def test_moments_f32_arithmetic_against_reference_run_and_exact_level(ctx, golden, case):
     """The opt-in SVO_HIP_SIA_ARITH_MOMENTS_F32 level (the reference's residuals and chi2, a patch's two gradient moments

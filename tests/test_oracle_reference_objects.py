@@ -57,6 +57,22 @@ def test_sparse_img_align_against_reference_run(golden, case):
         assert [crc(cache), crc(jac)] == [int(v) for v in g[name + "_cache_crc"]]
 
 
+@pytest.mark.parametrize("case", [c for c in gen_golden.SIA_REF_CASES if c[1].get("n_features", 1)], ids=[c[0] for c in gen_golden.SIA_REF_CASES if c[1].get("n_features", 1)])
+def test_fixed_work_mode_against_the_reference_members(golden, case):
+    """The oracle's fixed-work mode (early_stop off: exactly n_iter evaluations per level -- the throughput workload of the
+    bench) against the reference's compiled computeResiduals / solve / update driven for exactly n_iter evaluations per level
+    (ref_sparse_img_align_run_fixed_work: the reference's own loop has an unconditional error-increase exit): pose, H_ and
+    chi2_ bit for bit."""
+    name, kw, max_level, min_level, n_iter = case
+    g = golden("sia_ref.npz")
+    fp = gen_golden.make_sia_case(kw)
+    o = orc.sparse_img_align(fp, max_level=max_level, min_level=min_level, n_iter=n_iter, early_stop=False)
+    np.testing.assert_array_equal(np.array(o.T_cur_w), g[name + "_fw_T"])
+    np.testing.assert_array_equal(np.array(o.H), g[name + "_fw_H"])
+    assert o.chi2 == float(g[name + "_fw_chi2"]) and o.n_tracked == int(g[name + "_fw_n_tracked"])
+    assert all(o.iters[level] == n_iter for level in range(min_level, max_level + 1))
+
+
 def test_find_epipolar_match_direct_against_reference(golden):
     g = golden("epi_ref.npz")
     sc, d_est, d_min, d_max = gen_golden.epi_case_inputs()
