@@ -96,3 +96,22 @@ def test_every_prefix_of_a_tie_heavy_sequence(ctx):
     acc = np.add.accumulate(x, dtype=np.float32)
     for n in list(range(1, 300)) + list(range(4080, 4200)):
         assert same(hip.ordered_sum_f32(ctx, x[:n]), acc[n - 1]), n
+
+
+def test_random_sequences(ctx):
+    """300 sequences of random length and make: magnitudes spread over up to 40 binades, a share of exact zeros, mantissas cut
+    to a few bits (ties), occasional spikes."""
+    rng = np.random.default_rng(31337)
+    for k in range(300):
+        n = int(rng.choice([rng.integers(1, 600), rng.integers(600, 9000), rng.integers(9000, 70000)]))
+        x = np.exp2(rng.uniform(-rng.integers(1, 20), rng.integers(1, 20), n)) * rng.random(n)
+        if k % 3 == 0:
+            x = x * (rng.random(n) > rng.uniform(0.05, 0.6))
+        x = x.astype(np.float32)
+        if k % 4 == 1:                                              # few mantissa bits: additions that land exactly half way
+            bits = x.view(np.uint32) & np.uint32((0xFFFFFFFF << int(rng.integers(12, 22))) & 0xFFFFFFFF)
+            x = bits.view(np.float32)
+        if k % 5 == 2:
+            x[rng.integers(0, n, max(1, n // 500))] *= np.float32(2.0 ** rng.integers(8, 40))
+        got, want = hip.ordered_sum_f32(ctx, x), scalar_loop(x)
+        assert same(got, want), (k, n, got, want)
