@@ -292,3 +292,24 @@ def test_one_solver_with_a_growing_number_of_slots(ctx):
         assert np.array_equal(np.array(sia.download(i).T_cur_w), plain[i])
     for o in (sia, ref, cur):
         o.destroy()
+
+
+@pytest.mark.parametrize("combo", [(0, 2, 1), (1, 2, 3), (0, 1, 2), (1, 3, 1)], ids=["gn_mad_tdist", "lm_mad_huber", "gn_tdist_tukey", "lm_normal_tdist"])
+def test_identical_frames_a_zero_scale_and_nan_weights(ctx, combo):
+    """Reference and current image identical, the pose already exact: every residual is exactly 0, the MAD / Normal scale is
+    0, res / scale_ is 0 / 0 and the TDist / Huber weights NaN (Tukey's comparison turns a NaN into weight 0) -- in the
+    reference too.  The run must end like the oracle's (same stop flag and tracked count, a pose that is the oracle's or NaN
+    where the oracle's is NaN), not hang or fault: NaN terms take the in-order sum's one-lane path."""
+    fp = synth.make_frame_pair(seed=77, n_features=180)
+    fp.cur_pyr = [l.copy() for l in fp.ref_pyr]
+    fp.T_cur_w_init = np.array(fp.T_ref_w, dtype=np.float64)
+    out, _ = _run(ctx, [fp], 4, 1, 8, combo)
+    r, (scale, mu, nu) = out[0]
+    o = orc.sparse_img_align(fp, 4, 1, 8, method=combo[0], scale_estimator=combo[1], weight_function=combo[2])
+    assert int(r.stop) == o.stop and r.n_tracked == o.n_tracked, (r.stop, o.stop, r.n_tracked, o.n_tracked)
+    assert (np.float32(scale) == np.float32(o.scale)) or (np.isnan(scale) and np.isnan(o.scale))
+    got, want = np.array(r.T_cur_w), np.array(o.T_cur_w)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), (got, want)
+    if not np.isnan(want).any():
+        rot, trans = synth.pose_error(got, want)
+        assert rot < 1e-9 and trans < 1e-9, (rot, trans)
