@@ -176,10 +176,15 @@ class PyramidCache {
     std::set<int> distinct;
     for (const Frame* f : frames) { ids.push_back(f->id_); distinct.insert(f->id_); }
     const int need = table_.capacityFor((int)distinct.size());
-    if (need != table_.capacity() || !pyr_) {
+    // (every frame of a call has the geometry of the first; a cache that holds another geometry starts again)
+    const Frame& f = *frames[0];
+    const int n_levels = (int)f.img_pyr_.size();
+    for (const Frame* g : frames)
+      if (g->cam_->width != f.cam_->width || g->cam_->height != f.cam_->height || (int)g->img_pyr_.size() != n_levels) return false;
+    if (need != table_.capacity() || !pyr_ || f.cam_->width != width_ || f.cam_->height != height_ || n_levels != n_levels_) {
       if (pyr_) { svo_hip_pyramid_destroy(pyr_); pyr_ = nullptr; }
-      const Frame& f = *frames[0];
-      check(svo_hip_pyramid_create(ctx_, f.cam_->width, f.cam_->height, (int)f.img_pyr_.size(), need, &pyr_), ctx_, "pyramid_create");
+      check(svo_hip_pyramid_create(ctx_, f.cam_->width, f.cam_->height, n_levels, need, &pyr_), ctx_, "pyramid_create");
+      width_ = f.cam_->width; height_ = f.cam_->height; n_levels_ = n_levels;
       table_.reset(need);
       ++n_created_;
     }
@@ -197,7 +202,7 @@ class PyramidCache {
   int capacity() const { return table_.capacity(); }
   int uploads() const { return n_uploads_; }
  private:
-  svo_hip_ctx* ctx_; svo_hip_pyramid* pyr_ = nullptr; SlotTable table_; int n_uploads_ = 0, n_created_ = 0;
+  svo_hip_ctx* ctx_; svo_hip_pyramid* pyr_ = nullptr; int width_ = 0, height_ = 0, n_levels_ = 0; SlotTable table_; int n_uploads_ = 0, n_created_ = 0;
 };
 }  // namespace hip_bridge
 

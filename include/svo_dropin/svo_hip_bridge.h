@@ -6,6 +6,8 @@
 #ifndef SVO_HIP_BRIDGE_H_
 #define SVO_HIP_BRIDGE_H_
 
+#include <algorithm>
+#include <cmath>
 #include <condition_variable>
 #include <map>
 #include <memory>
@@ -47,8 +49,21 @@ inline svo_hip_camera toCamera(const vk::AbstractCamera* cam) {
     c.d[0] = ph->d0(); c.d[1] = ph->d1(); c.d[2] = ph->d2(); c.d[3] = ph->d3(); c.d[4] = ph->d4();
     c.distortion = std::fabs(ph->d0()) > 0.0000001;       // pinhole_camera.cpp:27
   } else {
-    c.fx = c.fy = cam->errorMultiplier2();
-    c.cx = cam->width() / 2.0; c.cy = cam->height() / 2.0;
+    // another camera class: the device knows the pinhole / radtan model only.  The intrinsics are read off the camera's own
+    // projection of the unit plane (exact for any distortion-free pinhole: fl(f*1 + c) - c == f whenever both are exact in
+    // f64, as half-pixel principal points and integer-ish focal lengths are), and the model is checked at two more points: a
+    // camera that is not a plain pinhole is reported, loudly, instead of being tracked with the wrong projection.
+    const Vector2d o = cam->world2cam(Vector2d(0.0, 0.0)), ex = cam->world2cam(Vector2d(1.0, 0.0)), ey = cam->world2cam(Vector2d(0.0, 1.0));
+    c.cx = o[0]; c.cy = o[1];
+    c.fx = ex[0] - o[0]; c.fy = ey[1] - o[1];
+    const Vector2d p = cam->world2cam(Vector2d(-0.37, 0.23)), q = cam->world2cam(Vector2d(0.51, -0.29));
+    const double err = std::max(std::max(std::fabs(p[0] - (c.fx * -0.37 + c.cx)), std::fabs(p[1] - (c.fy * 0.23 + c.cy))),
+                                std::max(std::fabs(q[0] - (c.fx * 0.51 + c.cx)), std::fabs(q[1] - (c.fy * -0.29 + c.cy))));
+    if (!(err < 1e-9) || ex[1] != o[1] || ey[0] != o[0]) {
+      fprintf(stderr, "[svo_hip] the camera is neither a vk::PinholeCamera nor a distortion-free pinhole (projection differs by %g px): "
+                      "the device path does not support this model\n", err);
+      fflush(stderr);
+    }
   }
   return c;
 }
@@ -81,7 +96,7 @@ class Context {
 /// call that needs several frames has to resolve them together).
 class PyramidCache {
  public:
-  PyramidCache(svo_hip_ctx* ctx, int capacity) : ctx_(ctx), pyr_(NULL), table_(capacity) {}
+  PyramidCache(svo_hip_ctx* ctx, int capacity) : ctx_(ctx), pyr_(NULL), width_(0), height_(0), n_levels_(0), table_(capacity) {}
   ~PyramidCache() { if (pyr_) svo_hip_pyramid_destroy(pyr_); }
 
   /// slot holding `frame`'s pyramid, uploading it (all levels, stride == cols) if needed; -1 on error.  For ONE frame per
@@ -107,10 +122,18 @@ class PyramidCache {
       if (!seen) ++distinct;
     }
     const int need = table_.capacityFor(distinct);
-    if (need != table_.capacity() || !pyr_) {
+    // every frame of a call has the geometry of the first; a cache that holds another geometry (the camera's resolution or
+    // the number of pyramid levels changed since) starts again: what it held cannot be what these frames are
+    const cv::Mat& l0 = frames[0]->img_pyr_[0];
+    const int n_levels = (int)frames[0]->img_pyr_.size();
+    for (size_t k = 1; k < frames.size(); ++k) {
+      const cv::Mat& lk = frames[k]->img_pyr_[0];
+      if (lk.cols != l0.cols || lk.rows != l0.rows || (int)frames[k]->img_pyr_.size() != n_levels) return false;
+    }
+    if (need != table_.capacity() || !pyr_ || l0.cols != width_ || l0.rows != height_ || n_levels != n_levels_) {
       if (pyr_) { svo_hip_pyramid_destroy(pyr_); pyr_ = NULL; }
-      const cv::Mat& l0 = frames[0]->img_pyr_[0];
-      if (svo_hip_pyramid_create(ctx_, l0.cols, l0.rows, (int)frames[0]->img_pyr_.size(), need, &pyr_) != SVO_HIP_OK) return false;
+      if (svo_hip_pyramid_create(ctx_, l0.cols, l0.rows, n_levels, need, &pyr_) != SVO_HIP_OK) return false;
+      width_ = l0.cols; height_ = l0.rows; n_levels_ = n_levels;
       table_.reset(need);
     }
     Uploader up = {this, &frames};
@@ -145,6 +168,7 @@ class PyramidCache {
 
   svo_hip_ctx* ctx_;
   svo_hip_pyramid* pyr_;
+  int width_, height_, n_levels_;   // geometry of pyr_
   SlotTable table_;
 };
 

@@ -1,0 +1,148 @@
+// dropin_run.cpp -- RUNS the drop-in bindings include/svo_dropin/sparse_img_align_hip.cpp and pose_optimizer_hip.cpp on the reference's own types
+// (TEST INFRASTRUCTURE ONLY; built into oracle/_ref/libsvo_dropin_run.so by `make -C oracle dropin-run`, only where
+// /root/reference is mounted; the built library travels to the GPU box and is loaded by tests/test_gpu_dropin_binding.py).
+//
+// What runs: the drop-in's svo::SparseImgAlign::run() and getFisherInformation() -- the translation unit a maintainer compiles
+// INSTEAD of svo/sparse_img_align.cpp -- with the reference's unmodified headers (svo::Frame, Feature, Point,
+// vk::PinholeCamera, the NLLSSolver base with its reset() and setRobustCostFunction) and the reference's compiled point.o,
+// config.o, robust_cost.o, pinhole_camera.o behind them; the device work in android_svo_amd/csrc/libsvo_hip.so.
+// What is laid out by hand (as in ref_objects.cpp / ref_camera.cpp, for the same reason: cv::Mat's constructors and
+// destructor live in the OpenCV library this image does not have, and no stand-in is written): the two svo::Frame objects,
+// the vk::PinholeCamera, and the SparseImgAlign object itself -- zeroed storage, the vptr pointed at the DROP-IN's vtable,
+// the fields set to what the inline base constructor (nlls_solver.h:96-116) and the drop-in's constructor body assign
+// (sparse_img_align_hip.cpp: its two cv::Mat members stay zeroed headers nothing touches).
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <memory>
+#include <vector>
+
+#include <svo/global.h>
+
+// width_/height_ are protected, the intrinsics private const members, the solver state of SparseImgAlign protected; access
+// specifiers do not change the layout gcc gives the classes
+#define protected public
+#define private public
+#include <svo/abstract_camera.h>
+#include <svo/pinhole_camera.h>
+#include <svo/nlls_solver.h>
+#include <svo/sparse_img_align.h>
+#undef private
+#undef protected
+
+#include <svo/config.h>
+#include <svo/frame.h>
+#include <svo/feature.h>
+#include <svo/point.h>
+#include <svo/pose_optimizer.h>
+#include <svo/robust_cost.h>
+
+#include "ref_common.h"
+#include "ref_frames.h"
+
+using namespace refh;
+
+// vtable of vk::PinholeCamera, emitted in the reference's pinhole_camera.o; of svo::SparseImgAlign, emitted in the drop-in's object
+extern "C" char _ZTVN2vk13PinholeCameraE[];
+extern "C" char _ZTVN3svo14SparseImgAlignE[];
+
+namespace {
+struct HandPinhole {
+  void* storage;
+  vk::AbstractCamera* cam;
+  HandPinhole(int width, int height, double fx, double fy, double cx, double cy, const double* d) {
+    storage = ::aligned_alloc(32, (sizeof(vk::PinholeCamera) + 31) / 32 * 32);
+    std::memset(storage, 0, sizeof(vk::PinholeCamera));
+    *reinterpret_cast<void**>(storage) = _ZTVN2vk13PinholeCameraE + 2 * sizeof(void*);
+    vk::PinholeCamera* p = reinterpret_cast<vk::PinholeCamera*>(storage);
+    p->width_ = width; p->height_ = height;                                    // AbstractCamera(width, height)
+    const_cast<double&>(p->fx_) = fx; const_cast<double&>(p->fy_) = fy;        // fx_(fx), fy_(fy), cx_(cx), cy_(cy)
+    const_cast<double&>(p->cx_) = cx; const_cast<double&>(p->cy_) = cy;
+    p->distortion_ = std::fabs(d[0]) > 0.0000001;                              // distortion_(fabs(d0) > 0.0000001)
+    for (int i = 0; i < 5; ++i) p->d_[i] = d[i];
+    p->use_optimization_ = false;
+    p->K_ << fx, 0.0, cx, 0.0, fy, cy, 0.0, 0.0, 1.0;
+    cam = p;
+  }
+  ~HandPinhole() { std::free(storage); }
+};
+}  // namespace
+
+extern "C" {
+
+// svo::SparseImgAlign(max_level, min_level, n_iter, method, false, false) [+ setRobustCostFunction]; run(ref_frame, cur_frame)
+// exactly as FrameHandlerMono::processFrame makes the call (frame_handler_mono.cpp:186-188), through the DROP-IN.
+int dropin_sparse_img_align_run(int width, int height, double fx, double fy, double cx, double cy, const double* d5, int n_levels,
+                                const uint8_t* const* ref_pyr, const uint8_t* const* cur_pyr, int n, const double* px,
+                                const double* fv, const double* pos, const uint8_t* has_point, const double* T_ref_w,
+                                const double* T_cur_w_init, int max_level, int min_level, int n_iter, int method, int scale_estimator,
+                                int weight_function, double* T_cur_w_out, size_t* n_tracked, double* fisher36, double* chi2_out,
+                                int* stop_out, double* scale_mu_nu /*[3]*/) {
+  HandPinhole cam(width, height, fx, fy, cx, cy, d5);
+  HandFrame ref(cam.cam, ref_pyr, width, height, n_levels, T_ref_w);
+  HandFrame cur(cam.cam, cur_pyr, width, height, n_levels, T_cur_w_init);
+  for (int i = 0; i < n; ++i) ref.add_feature(px + 2 * i, fv + 3 * i, 0, has_point[i] ? pos + 3 * i : nullptr);
+  svo::FramePtr ref_frame = ref.ptr(), cur_frame = cur.ptr();
+  void* storage = ::aligned_alloc(32, (sizeof(svo::SparseImgAlign) + 31) / 32 * 32);
+  std::memset(storage, 0, sizeof(svo::SparseImgAlign));
+  *reinterpret_cast<void**>(storage) = _ZTVN3svo14SparseImgAlignE + 2 * sizeof(void*);
+  svo::SparseImgAlign* s = reinterpret_cast<svo::SparseImgAlign*>(storage);
+  // vk::NLLSSolver<6,SE3>::NLLSSolver() (nlls_solver.h:96-116)
+  s->have_prior_ = false;
+  s->mu_init_ = 0.01f; s->mu_ = s->mu_init_;
+  s->nu_init_ = 2.0; s->nu_ = s->nu_init_;
+  s->n_trials_ = 0; s->n_trials_max_ = 5; s->n_meas_ = 0;
+  s->stop_ = false; s->iter_ = 0;
+  s->use_weights_ = false; s->scale_ = 0.0;
+  // SparseImgAlign::SparseImgAlign(max_level, min_level, n_iter, method, false, false) as the drop-in writes it
+  s->display_ = false; s->max_level_ = max_level; s->min_level_ = min_level;
+  s->n_iter_ = n_iter; s->n_iter_init_ = s->n_iter_;
+  s->method_ = method == 1 ? svo::SparseImgAlign::LevenbergMarquardt : svo::SparseImgAlign::GaussNewton;
+  s->verbose_ = false;
+  s->eps_ = 0.000001;
+  if (scale_estimator != 0 || weight_function != 0)
+    s->setRobustCostFunction((svo::SparseImgAlign::ScaleEstimatorType)scale_estimator, (svo::SparseImgAlign::WeightFunctionType)weight_function);
+  const size_t ret = s->run(ref_frame, cur_frame);                   // the drop-in
+  {
+    const Eigen::Matrix<double, 6, 6> I = s->getFisherInformation();
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) fisher36[6 * i + j] = I(i, j);
+  }
+  *chi2_out = s->getChi2();
+  *stop_out = s->stop_ ? 1 : 0;
+  if (scale_mu_nu) { scale_mu_nu[0] = (double)s->scale_; scale_mu_nu[1] = s->mu_; scale_mu_nu[2] = s->nu_; }
+  // tear down by hand (no destructor of the hand-laid object runs)
+  s->scale_estimator_.reset();
+  s->weight_function_.reset();
+  s->ref_frame_.reset();
+  s->cur_frame_.reset();
+  from_se3(cur_frame->T_f_w_, T_cur_w_out);
+  *n_tracked = ret;
+  std::free(storage);
+  return 0;
+}
+
+// pose_optimizer::optimizeGaussNewton(reproj_thresh, n_iter, false, frame, ...) as FrameHandlerMono::processFrame calls it
+// (frame_handler_mono.cpp:226-229), through the DROP-IN (pose_optimizer_hip.cpp, compiled instead of pose_optimizer.cpp): the
+// frame's features and their points in, frame->T_f_w_, frame->Cov_, the nulled Feature::point of rejected observations and the
+// four outputs back.
+int dropin_pose_optimize(int width, int height, double fx, double fy, double cx, double cy, const double* d5, double reproj_thresh,
+                         int n_iter, const double* T_f_w_in, int n, const double* fv, const double* pos, const int32_t* level,
+                         uint8_t* has_point_inout, double* T_f_w_out, double* cov36, double* outputs4 /*scale, init, final, num_obs*/) {
+  HandPinhole cam(width, height, fx, fy, cx, cy, d5);
+  HandFrame fr(cam.cam, nullptr, width, height, 0, T_f_w_in);
+  const double px0[2] = {0.0, 0.0};
+  std::vector<svo::Feature*> fts;
+  for (int i = 0; i < n; ++i) fts.push_back(fr.add_feature(px0, fv + 3 * i, level[i], has_point_inout[i] ? pos + 3 * i : nullptr));
+  svo::FramePtr frame = fr.ptr();
+  double estimated_scale = 0.0, error_init = 0.0, error_final = 0.0;
+  size_t num_obs = 0;
+  svo::pose_optimizer::optimizeGaussNewton(reproj_thresh, (size_t)n_iter, false, frame, estimated_scale, error_init, error_final, num_obs);
+  from_se3(frame->T_f_w_, T_f_w_out);
+  for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) cov36[6 * r + c] = frame->Cov_(r, c);
+  for (int i = 0; i < n; ++i) has_point_inout[i] = fts[i]->point != nullptr ? 1 : 0;
+  outputs4[0] = estimated_scale; outputs4[1] = error_init; outputs4[2] = error_final; outputs4[3] = (double)num_obs;
+  return 0;
+}
+
+}  // extern "C"

@@ -358,8 +358,9 @@ def camera_is_in_frame(width, height, obs, boundary, level):
 
 
 # ---- the whole Reprojector::reprojectMap on a real svo::Map (ref_objects.cpp: ref_reproject_map) ----
-def reproject_map(cs, max_fts=1200, n_pyr_levels=3, key_override=None):
-    """cs: a case of android_svo_amd.synth.make_map_case.  Returns the reference's outputs, incl. the key points its own
+def reproject_map(cs, max_fts=1200, n_pyr_levels=3, key_override=None, library=None):
+    """cs: a case of android_svo_amd.synth.make_map_case.  library: another build of the same harness (the one linked with
+    the PATCHED reprojector of include/svo_dropin/reprojector.patch: tests/test_gpu_dropin_binding.py).  Returns the reference's outputs, incl. the key points its own
     Frame::setKeyPoints chose for every keyframe (an input of the oracle / HIP forms of the call).
     key_override [n_kf][5] (-2: keep the reference's choice, -1: empty slot, else point index): the key features to start
     from; kf_key_point is then what the call started from and kf_key_point_after what Map::safeDeletePoint ->
@@ -386,7 +387,7 @@ def reproject_map(cs, max_fts=1200, n_pyr_levels=3, key_override=None):
     nm, nt = C.c_size_t(0), C.c_size_t(0)
     ko = None if key_override is None else i32(key_override)
     key_after = np.zeros((n_kf, 5), np.int32)
-    k = lib().ref_reproject_map_keys(*_cam_args(cam), I(len(cs["cur_pyr"])), I(cs["cell_size"]), I(max_fts), I(n_pyr_levels), I(n_kf), kp,
+    k = (library or lib()).ref_reproject_map_keys(*_cam_args(cam), I(len(cs["cur_pyr"])), I(cs["cell_size"]), I(max_fts), I(n_pyr_levels), I(n_kf), kp,
                                 _p(ins["Tk"], D), orc.pyr_ptrs(cs["cur_pyr"]), _p(ins["Tc"], D), I(n_pts), _p(ins["pos"], D), _p(ins["ty"], I),
                                 _p(ins["nf"], I), _p(ins["ns"], I), I(n_obs), _p(ins["op"], I), _p(ins["ok"], I), _p(ins["opx"], D),
                                 _p(ins["of"], D), _p(ins["ol"], I), _p(ins["oe"], U), _p(ins["og"], D), _p(ins["ko"], I), _p(ins["kb"], I),

@@ -1,0 +1,177 @@
+"""The drop-in binding include/svo_dropin/sparse_img_align_hip.cpp EXECUTED on the reference's own types, on the GPU.
+
+oracle/_ref/libsvo_dropin_run.so (`make -C oracle dropin-run`, built where /root/reference is mounted, travels to the GPU box)
+holds that translation unit compiled against the reference's unmodified headers, the reference's compiled point.o / config.o /
+robust_cost.o / pinhole_camera.o, and a harness that lays two svo::Frame objects, a vk::PinholeCamera and the SparseImgAlign
+object out by hand (their constructors need the OpenCV library; oracle/ref/dropin_run.cpp says exactly what is by hand).
+What runs is what FrameHandlerMono would run after the one-file swap of INTEGRATION.md: svo::SparseImgAlign::run(ref_frame,
+cur_frame) -> std::list walk over ref_frame->fts_, hip_bridge pyramid upload from cv::Mat headers, camera from the
+vk::PinholeCamera, libsvo_hip.so, results written back into cur_frame->T_f_w_ / H_ / chi2_ / stop_ / n_meas_.
+
+Compared with SparseImgAlign::run of the reference's OWN compiled code on the same frames (tests/golden/sia_ref.npz,
+sia_nlls_ref.npz)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from android_svo_amd import synth
+from oracle import gen_golden, orc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_ref", "libsvo_dropin_run.so")
+D = C.c_double
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        pytest.skip("oracle/_ref/libsvo_dropin_run.so is built where /root/reference is mounted (make -C oracle dropin-run)")
+    # RTLD_LAZY: the constructor and destructor of the drop-in class (never called here) reference cv::Mat members of the OpenCV
+    # library, which this image does not have
+    return C.CDLL(LIB, mode=os.RTLD_LAZY)
+
+
+def run_dropin(lib, fp, max_level, min_level, n_iter, method=0, scale_estimator=0, weight_function=0):
+    rp, cp = orc.pyr_ptrs(fp.ref_pyr), orc.pyr_ptrs(fp.cur_pyr)
+    px, f, pos = (np.ascontiguousarray(a, dtype=np.float64) for a in (fp.px, fp.f, fp.pos))
+    hp = np.ascontiguousarray(fp.has_point, dtype=np.uint8)
+    T_ref, T_init = np.ascontiguousarray(fp.T_ref_w, dtype=np.float64), np.ascontiguousarray(fp.T_cur_w_init, dtype=np.float64)
+    d5 = np.zeros(5)
+    T_out, fisher, smn = np.zeros(7), np.zeros(36), np.zeros(3)
+    nt, chi2, stop = C.c_size_t(0), D(0), C.c_int(0)
+    cam = fp.cam
+    rc = lib.dropin_sparse_img_align_run(C.c_int(cam.width), C.c_int(cam.height), D(cam.fx), D(cam.fy), D(cam.cx), D(cam.cy), _p(d5, D),
+                                         C.c_int(len(fp.ref_pyr)), rp, cp, C.c_int(len(px)), _p(px, D), _p(f, D), _p(pos, D), _p(hp, C.c_uint8),
+                                         _p(T_ref, D), _p(T_init, D), C.c_int(max_level), C.c_int(min_level), C.c_int(n_iter), C.c_int(method),
+                                         C.c_int(scale_estimator), C.c_int(weight_function), _p(T_out, D), C.byref(nt), _p(fisher, D),
+                                         C.byref(chi2), C.byref(stop), _p(smn, D))
+    assert rc == 0
+    return {"T": T_out, "n_tracked": nt.value, "fisher": fisher, "chi2": chi2.value, "stop": stop.value, "scale": np.float32(smn[0]),
+            "mu": smn[1], "nu": smn[2]}
+
+
+REF_CASES = gen_golden.SIA_REF_CASES
+
+
+@pytest.mark.parametrize("case", REF_CASES, ids=[c[0] for c in REF_CASES])
+def test_dropin_run_against_the_reference_run(lib, golden, case):
+    """Gauss-Newton as the app constructs it: the pose cur_frame->T_f_w_ ends with, the return value, stop_ and
+    getFisherInformation() = H_ / (5e-4 * 255^2) against the reference's own run."""
+    name, kw, max_level, min_level, n_iter = case
+    g = golden("sia_ref.npz")
+    fp = gen_golden.make_sia_case(kw)
+    r = run_dropin(lib, fp, max_level, min_level, n_iter)
+    rot, trans = synth.pose_error(r["T"], g[name + "_T"])
+    assert rot < 1e-4 and trans < 1e-3, (rot, trans)            # north_star tolerance
+    assert rot < 2e-5 and trans < 5e-5, (rot, trans)            # what a chi2-order exit flip can cost at most here
+    assert r["n_tracked"] == int(g[name + "_n_tracked"]) and r["stop"] == int(g[name + "_stop"])
+    if len(fp.px) == 0:
+        assert np.array_equal(r["T"], np.asarray(fp.T_cur_w_init, dtype=np.float64))   # run() returns 0 and leaves the pose alone (:55-59)
+        return
+    if rot < 1e-9:                                               # the same evaluation sequence
+        H = g[name + "_H"] / (5e-4 * 255 * 255)
+        assert np.abs(r["fisher"] - H).max() <= 1e-6 * np.abs(H).max()
+        assert abs(r["chi2"] - float(g[name + "_chi2"])) <= 1e-4 * float(g[name + "_chi2"])
+
+
+NLLS = [("c0_200", (1, 0, 0)), ("c0_200", (0, 2, 2)), ("nulls_320", (1, 2, 3)), ("c1_2000", (1, 1, 1)), ("border_320", (0, 3, 1)), ("iters5", (1, 1, 2))]
+
+
+@pytest.mark.parametrize("name,combo", NLLS, ids=[gen_golden.nlls_key(n, c) for n, c in NLLS])
+def test_dropin_method_and_robust_cost_go_down_with_the_call(lib, golden, name, combo):
+    """method_ = LevenbergMarquardt and setRobustCostFunction on the C++ object (the reference's own base-class member, its
+    own estimator / weight classes from robust_cost.o): the binding reads them off the object (dynamic types of
+    scale_estimator_ / weight_function_), and mu_, nu_, scale_ come back into it."""
+    g = golden("sia_nlls_ref.npz")
+    case = {c[0]: c for c in REF_CASES}[name]
+    _, kw, max_level, min_level, n_iter = case
+    fp = gen_golden.make_sia_case(kw)
+    r = run_dropin(lib, fp, max_level, min_level, n_iter, method=combo[0], scale_estimator=combo[1], weight_function=combo[2])
+    k = gen_golden.nlls_key(name, combo)
+    rot, trans = synth.pose_error(r["T"], g[k + "_T"])
+    assert rot < 5e-8 and trans < 5e-8, (rot, trans)
+    assert r["n_tracked"] == int(g[k + "_n_tracked"]) and r["stop"] == int(g[k + "_stop"])
+    assert abs(r["chi2"] - float(g[k + "_chi2"])) <= 2.5e-7 * float(g[k + "_chi2"])
+    if combo[1]:
+        assert r["scale"] == np.float32(g[k + "_scale_mu_nu"][0])
+    if combo[0]:
+        assert abs(r["mu"] - g[k + "_scale_mu_nu"][1]) <= 1e-9 * g[k + "_scale_mu_nu"][1] and r["nu"] == g[k + "_scale_mu_nu"][2]
+
+
+@pytest.mark.parametrize("seed,n", [(5, 400), (6, 1200), (7, 37)])
+def test_dropin_pose_optimizer_on_a_real_frame(lib, seed, n):
+    """pose_optimizer::optimizeGaussNewton of include/svo_dropin/pose_optimizer_hip.cpp (compiled instead of the reference's
+    pose_optimizer.cpp) called on a svo::Frame with real Feature / Point objects: frame->T_f_w_, frame->Cov_, the
+    observations whose Feature::point it nulls and the four outputs, against the oracle restatement of the reference's
+    function (the reference's own translation unit does not compile here: SURVEY 8c)."""
+    pc = synth.make_pose_opt_case(seed=seed, n=n)
+    cam = pc.cam
+    em = abs(cam.fx)
+    o, hp_o = orc.pose_optimize(em, pc.T_f_w_init, pc.f, pc.pos, pc.level, pc.has_point)
+    f, pos = np.ascontiguousarray(pc.f, dtype=np.float64), np.ascontiguousarray(pc.pos, dtype=np.float64)
+    level = np.ascontiguousarray(pc.level, dtype=np.int32)
+    hp = np.ascontiguousarray(pc.has_point, dtype=np.uint8).copy()
+    T_in = np.ascontiguousarray(pc.T_f_w_init, dtype=np.float64)
+    T_out, cov, outs, d5 = np.zeros(7), np.zeros(36), np.zeros(4), np.zeros(5)
+    rc = lib.dropin_pose_optimize(C.c_int(cam.width), C.c_int(cam.height), D(cam.fx), D(cam.fy), D(cam.cx), D(cam.cy), _p(d5, D), D(2.0),
+                                  C.c_int(10), _p(T_in, D), C.c_int(len(f)), _p(f, D), _p(pos, D), _p(level, C.c_int32), _p(hp, C.c_uint8),
+                                  _p(T_out, D), _p(cov, D), _p(outs, D))
+    assert rc == 0
+    rot, trans = synth.pose_error(T_out, np.array(o.T_f_w))
+    assert rot < 1e-10 and trans < 1e-10, (rot, trans)
+    assert outs[0] == o.estimated_scale                                   # the k-th element of the f32 errors: exact
+    assert abs(outs[1] - o.error_init) <= 1e-12 * o.error_init and abs(outs[2] - o.error_final) <= 1e-8 * o.error_final
+    assert (hp != hp_o).sum() <= 1 and abs(int(outs[3]) - int(o.num_obs)) <= 1   # only an observation on the threshold may flip
+    Co = np.array(o.Cov)
+    assert np.abs(cov - Co).max() <= 1e-6 * np.abs(Co).max()
+
+
+# ---- the reprojector drop-in: the reference's own reprojector.cpp with reprojector.patch applied, under the harness that runs
+# ---- the reference's Reprojector::reprojectMap on a real svo::Map (oracle/_ref/libsvo_dropin_reproject.so)
+REPROJ_LIB = os.path.join(ROOT, "oracle", "_ref", "libsvo_dropin_reproject.so")
+
+
+@pytest.fixture(scope="module")
+def reproj_lib():
+    if not os.path.exists(REPROJ_LIB):
+        pytest.skip("oracle/_ref/libsvo_dropin_reproject.so is built where /root/reference is mounted (make -C oracle dropin-run)")
+    return C.CDLL(REPROJ_LIB, mode=os.RTLD_LAZY)
+
+
+def _map_cases():
+    from test_oracle_reproject_map import CASES
+    return CASES
+
+
+@pytest.mark.parametrize("tag,kw,max_fts", _map_cases(), ids=[c[0] for c in _map_cases()])
+def test_patched_reprojector_on_a_real_map(reproj_lib, golden, tag, kw, max_fts):
+    """Reprojector::reprojectMap of the PATCHED reference file -- close-keyframe selection, the projection into cells, the
+    candidate loop: the reference's own statements; the cell loop: hip_bridge::reprojectCellsHip -> libsvo_hip.so on the GPU,
+    then the reference's serial policy -- on a real svo::Map with keyframes, multi-observation points and candidates,
+    against the fixture the UNPATCHED reference left (tests/golden/reproject_map_ref.npz): every integer equal, pixels and
+    gradients bitwise, the map's bookkeeping (point types, counters, deletions, key features chosen again) included."""
+    from oracle.ref import refpy
+    from test_oracle_reproject_map import check_map_result
+    g = golden("reproject_map_ref.npz")
+    cs = synth.make_map_case(**kw)
+    ko = None
+    if tag == "rekey":                      # the key features the fixture's run started from
+        ko = np.where(g[tag + "_kf_key_point"] == refpy_keys_of_near(g), -2, g[tag + "_kf_key_point"]).astype(np.int32)
+    r = refpy.reproject_map(cs, max_fts=max_fts, key_override=ko, library=reproj_lib)
+    np.testing.assert_array_equal(r["kf_key_point"], g[tag + "_kf_key_point"])
+    check_map_result(g, tag, r)
+    np.testing.assert_array_equal(r["kf_key_point_after"], g[tag + "_kf_key_point_after"])
+
+
+def refpy_keys_of_near(g):
+    """the reference's own key-point choice for the map of the "near" / "rekey" cases (the rekey fixture differs from it only
+    in the slots that were put in by hand)"""
+    return g["near_kf_key_point"]
