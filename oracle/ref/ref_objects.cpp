@@ -48,6 +48,9 @@
 
 #include "ref_common.h"
 #include "ref_frames.h"
+#ifdef REF_RUN_TRACKER_BINDING
+#include "frame_tracker_hip.h"      // include/svo_dropin: the binding under test (tests/test_gpu_dropin_binding.py)
+#endif
 
 using namespace refh;
 
@@ -57,6 +60,18 @@ extern "C" char _ZTVN3svo14SparseImgAlignE[];
 // (HandFrame: ref_frames.h)
 
 static bool pt_obs_nonempty(const svo::Point* p) { return !p->obs_.empty(); }
+
+#ifdef REF_RUN_TRACKER_BINDING
+// what the last ref_reproject_map_keys call of this build (the frame-tracker binding in place of the Reprojector) left
+static int g_tracker_ok = 0, g_tracker_pose_optimised = 0;
+static double g_tracker_pose[7] = {0}, g_tracker_sfba[4] = {0};
+extern "C" int dropin_tracker_last(double* pose7, double* sfba4, int* pose_optimised) {
+  for (int i = 0; i < 7; ++i) pose7[i] = g_tracker_pose[i];
+  for (int i = 0; i < 4; ++i) sfba4[i] = g_tracker_sfba[i];
+  *pose_optimised = g_tracker_pose_optimised;
+  return g_tracker_ok;
+}
+#endif
 
 extern "C" {
 
@@ -498,11 +513,32 @@ int ref_reproject_map_keys(int width, int height, double fx, double fy, double c
   for (int k = 0; k < n_kf; ++k) map->addKeyframe(kfs[k]->ptr());
   for (int c = 0; c < n_candidates; ++c)                               // (newCandidatePoint would reset the type: push the pair as it does)
     map->point_candidates_.candidates_.push_back(svo::MapPointCandidates::PointCandidate(pts[cand_point[c]], obs[cand_obs[c]]));
-  svo::Reprojector* rp = new svo::Reprojector(&cam, *map);
   std::vector<std::pair<svo::FramePtr, std::size_t> > overlap;
+#ifdef REF_RUN_TRACKER_BINDING
+  // The SAME scene through the frame-tracker binding (include/svo_dropin/frame_tracker_hip.h: processFrame's alignment,
+  // reprojection and pose refinement as one device call) instead of the reference's Reprojector: a last frame without features
+  // at the pose the fixture was recorded at (SparseImgAlign::run returns at once, :55-59), then track().  The binding flattens
+  // this svo::Map, runs the chain on the GPU and applies the outcome to these objects with the reference's own functions.
+  svo::Reprojector* rp = nullptr;
+  {
+    HandFrame last(&cam, cur_pyr, width, height, n_levels, T_cur_w);
+    svo::hip_bridge::FrameTracker tracker(&cam, n_kf > 0 ? n_kf : 1);
+    svo::hip_bridge::FrameTracker::Outcome oc;
+    std::memset(&oc, 0, sizeof(oc));
+    g_tracker_ok = tracker.ok() && tracker.track(last.ptr(), frame, *map, overlap, oc) ? 1 : 0;
+    *n_matches = oc.repr_n_matches;
+    *n_trials = oc.repr_n_trials;
+    g_tracker_pose_optimised = oc.pose_optimised ? 1 : 0;
+    g_tracker_sfba[0] = (double)oc.sfba_n_edges_final; g_tracker_sfba[1] = oc.sfba_thresh; g_tracker_sfba[2] = oc.sfba_error_init;
+    g_tracker_sfba[3] = oc.sfba_error_final;
+    from_se3(frame->T_f_w_, g_tracker_pose);
+  }
+#else
+  svo::Reprojector* rp = new svo::Reprojector(&cam, *map);
   rp->reprojectMap(frame, overlap);
   *n_matches = rp->n_matches_;
   *n_trials = rp->n_trials_;
+#endif
   *n_overlap = (int)overlap.size();
   for (size_t i = 0; i < overlap.size(); ++i) {
     overlap_kf[i] = -1;

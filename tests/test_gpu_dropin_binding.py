@@ -175,3 +175,52 @@ def refpy_keys_of_near(g):
     """the reference's own key-point choice for the map of the "near" / "rekey" cases (the rekey fixture differs from it only
     in the slots that were put in by hand)"""
     return g["near_kf_key_point"]
+
+
+# ---- the frame-tracker binding (frame_tracker_hip.h): the same map harness compiled with -DREF_RUN_TRACKER_BINDING
+TRACKER_LIB = os.path.join(ROOT, "oracle", "_ref", "libsvo_dropin_tracker.so")
+
+
+@pytest.fixture(scope="module")
+def tracker_lib():
+    if not os.path.exists(TRACKER_LIB):
+        pytest.skip("oracle/_ref/libsvo_dropin_tracker.so is built where /root/reference is mounted (make -C oracle dropin-run)")
+    return C.CDLL(TRACKER_LIB, mode=os.RTLD_LAZY)
+
+
+@pytest.mark.parametrize("tag,kw,max_fts", _map_cases(), ids=[c[0] for c in _map_cases()])
+def test_frame_tracker_binding_on_a_real_map(tracker_lib, golden, tag, kw, max_fts):
+    """svo::hip_bridge::FrameTracker::track(last, fresh, map, overlap, outcome) -- what replaces lines 175-229 of
+    FrameHandlerMono::processFrame (INTEGRATION.md) -- on a real svo::Map: the binding flattens the reference's keyframes,
+    points, observations and candidates, the chain runs on the GPU, and the outcome is applied to the reference's objects with
+    the reference's own functions (Frame::addFeature, Map::safeDeletePoint -> Frame::removeKeyPoint, deleteCandidatePoint).
+    The reprojection stage against what the reference's Reprojector::reprojectMap leaves on the same scene (every integer,
+    pixels and gradients bit for bit; the observations the pose refinement then drops are the ones the oracle drops), the
+    refined pose against the oracle's refinement of the fixture's features."""
+    from oracle.ref import refpy
+    from test_oracle_reproject_map import check_map_result
+    g = golden("reproject_map_ref.npz")
+    cs = synth.make_map_case(**kw)
+    ko = None
+    if tag == "rekey":
+        ko = np.where(g[tag + "_kf_key_point"] == refpy_keys_of_near(g), -2, g[tag + "_kf_key_point"]).astype(np.int32)
+    r = refpy.reproject_map(cs, max_fts=max_fts, key_override=ko, library=tracker_lib)
+    pose, sfba, opt = np.zeros(7), np.zeros(4), C.c_int(0)
+    assert tracker_lib.dropin_tracker_last(_p(pose, D), _p(sfba, D), C.byref(opt)) == 1, "the binding reported a failure"
+    np.testing.assert_array_equal(r["kf_key_point"], g[tag + "_kf_key_point"])
+    n_feat = len(g[tag + "_feat_point"])
+    enough = n_feat >= 40                                           # Config::qualityMinFts() (config.cpp:83): below it processFrame stops before the refinement
+    assert bool(opt.value) == enough
+    if enough:
+        po, hp = orc.pose_optimize(abs(cs["cam"].fx), cs["T_cur_w"], orc.cam2world(cs["cam"], g[tag + "_feat_px"]),
+                                   cs["pt_pos"][g[tag + "_feat_point"]], g[tag + "_feat_level"], np.ones(n_feat, np.uint8))
+        dropped = r["feat_point"] < 0                               # Feature::point nulled by the refinement's outlier test
+        np.testing.assert_array_equal(dropped, ~hp.astype(bool))
+        r = dict(r, feat_point=np.where(dropped, g[tag + "_feat_point"], r["feat_point"]))
+        rot, trans = synth.pose_error(pose, np.array(po.T_f_w))
+        assert rot < 1e-9 and trans < 1e-9, (rot, trans)
+        assert int(sfba[0]) == int(po.num_obs)
+    else:
+        np.testing.assert_array_equal(pose, np.asarray(cs["T_cur_w"], dtype=np.float64))
+    check_map_result(g, tag, r)
+    np.testing.assert_array_equal(r["kf_key_point_after"], g[tag + "_kf_key_point_after"])
