@@ -218,11 +218,18 @@ SIA_REF_CASES = [
     ("hd_1280", dict(seed=12350, width=1280, height=720, n_features=2000), 4, 0, 30),
     ("c1_l4_l2", dict(seed=12351, n_features=2000), 4, 2, 30),
     ("big_3500", dict(seed=12352, n_features=3500), 4, 0, 30),
+    # a vk::PinholeCamera with radtan distortion: the reference's compiled world2cam (pinhole_camera.cpp:79-106) inside computeResiduals
+    ("radtan_600", dict(seed=77, n_features=600, dist=(-0.05, 0.01, 1e-3, -5e-4, 2e-3)), 4, 0, 30),
 ]
 
 
 def make_sia_case(kw):
     kw = dict(kw)
+    dist = kw.pop("dist", None)
+    if dist is not None:
+        fp = synth.make_frame_pair(**kw)
+        fp.dist = list(dist)
+        return fp
     if kw.get("n_features", 1) == 0:
         kw["n_features"] = 8
         fp = synth.make_frame_pair(**kw)

@@ -43,31 +43,11 @@
 
 using namespace refh;
 
-// vtable of vk::PinholeCamera, emitted in the reference's pinhole_camera.o; of svo::SparseImgAlign, emitted in the drop-in's object
-extern "C" char _ZTVN2vk13PinholeCameraE[];
+// vtable of svo::SparseImgAlign, emitted in the drop-in's object
 extern "C" char _ZTVN3svo14SparseImgAlignE[];
 
-namespace {
-struct HandPinhole {
-  void* storage;
-  vk::AbstractCamera* cam;
-  HandPinhole(int width, int height, double fx, double fy, double cx, double cy, const double* d) {
-    storage = ::aligned_alloc(32, (sizeof(vk::PinholeCamera) + 31) / 32 * 32);
-    std::memset(storage, 0, sizeof(vk::PinholeCamera));
-    *reinterpret_cast<void**>(storage) = _ZTVN2vk13PinholeCameraE + 2 * sizeof(void*);
-    vk::PinholeCamera* p = reinterpret_cast<vk::PinholeCamera*>(storage);
-    p->width_ = width; p->height_ = height;                                    // AbstractCamera(width, height)
-    const_cast<double&>(p->fx_) = fx; const_cast<double&>(p->fy_) = fy;        // fx_(fx), fy_(fy), cx_(cx), cy_(cy)
-    const_cast<double&>(p->cx_) = cx; const_cast<double&>(p->cy_) = cy;
-    p->distortion_ = std::fabs(d[0]) > 0.0000001;                              // distortion_(fabs(d0) > 0.0000001)
-    for (int i = 0; i < 5; ++i) p->d_[i] = d[i];
-    p->use_optimization_ = false;
-    p->K_ << fx, 0.0, cx, 0.0, fy, cy, 0.0, 0.0, 1.0;
-    cam = p;
-  }
-  ~HandPinhole() { std::free(storage); }
-};
-}  // namespace
+#include "ref_pinhole_hand.h"
+using refh::HandPinhole;
 
 extern "C" {
 

@@ -25,30 +25,20 @@
 #undef private
 #undef protected
 
-// vtable of vk::PinholeCamera, emitted in the reference's pinhole_camera.o
-extern "C" char _ZTVN2vk13PinholeCameraE[];
 
-namespace {
-struct HandPinhole {
-  void* storage;
-  vk::AbstractCamera* cam;
-  HandPinhole(int width, int height, double fx, double fy, double cx, double cy, const double* d) {
-    storage = ::aligned_alloc(32, (sizeof(vk::PinholeCamera) + 31) / 32 * 32);
-    std::memset(storage, 0, sizeof(vk::PinholeCamera));
-    *reinterpret_cast<void**>(storage) = _ZTVN2vk13PinholeCameraE + 2 * sizeof(void*);
-    vk::PinholeCamera* p = reinterpret_cast<vk::PinholeCamera*>(storage);
-    p->width_ = width; p->height_ = height;                                    // AbstractCamera(width, height)
-    const_cast<double&>(p->fx_) = fx; const_cast<double&>(p->fy_) = fy;        // fx_(fx), fy_(fy), cx_(cx), cy_(cy)
-    const_cast<double&>(p->cx_) = cx; const_cast<double&>(p->cy_) = cy;
-    p->distortion_ = std::fabs(d[0]) > 0.0000001;                              // distortion_(fabs(d0) > 0.0000001)
-    for (int i = 0; i < 5; ++i) p->d_[i] = d[i];
-    p->use_optimization_ = false;
-    p->K_ << fx, 0.0, cx, 0.0, fy, cy, 0.0, 0.0, 1.0;
-    cam = p;                                                                   // used through the abstract interface
-  }
-  ~HandPinhole() { std::free(storage); }
-};
-}  // namespace
+#include "ref_pinhole_hand.h"
+using refh::HandPinhole;
+
+// for the translation units that see vk::PinholeCamera with its access specifiers closed (ref_objects.cpp): a hand-laid
+// camera behind the abstract interface (ref_common.h declares the two)
+namespace refh {
+vk::AbstractCamera* make_hand_pinhole(int width, int height, double fx, double fy, double cx, double cy, const double* d5, void** handle) {
+  HandPinhole* h = new HandPinhole(width, height, fx, fy, cx, cy, d5);
+  *handle = h;
+  return h->cam;
+}
+void free_hand_pinhole(void* handle) { delete static_cast<HandPinhole*>(handle); }
+}  // namespace refh
 
 extern "C" {
 

@@ -70,6 +70,10 @@ class HarnessPinhole : public vk::AbstractCamera {
   double errorMultiplier() const override { return std::fabs(4.0 * fx_ * fy_); }
 };
 
+// a vk::PinholeCamera (with its radtan coefficients) laid out by hand, behind the abstract interface (ref_camera.cpp)
+vk::AbstractCamera* make_hand_pinhole(int width, int height, double fx, double fy, double cx, double cy, const double* d5, void** handle);
+void free_hand_pinhole(void* handle);
+
 inline SE3 to_se3(const double* T) { return SE3(T[0], T[1], T[2], T[3], T[4], T[5], T[6]); }
 inline void from_se3(const SE3& s, double* T) {
   T[0] = s.get_translation().x; T[1] = s.get_translation().y; T[2] = s.get_translation().z;

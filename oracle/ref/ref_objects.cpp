@@ -61,6 +61,11 @@ extern "C" char _ZTVN3svo14SparseImgAlignE[];
 
 static bool pt_obs_nonempty(const svo::Point* p) { return !p->obs_.empty(); }
 
+// radtan coefficients of the camera of the next ref_sparse_img_align_run* calls of this thread (all zero: the distortion-free
+// HarnessPinhole the fixtures were recorded with; otherwise a hand-laid vk::PinholeCamera: the reference's compiled world2cam)
+static thread_local double g_dist[5] = {0, 0, 0, 0, 0};
+extern "C" void ref_set_distortion(const double* d5) { for (int i = 0; i < 5; ++i) g_dist[i] = d5 ? d5[i] : 0.0; }
+
 #ifdef REF_RUN_TRACKER_BINDING
 // what the last ref_reproject_map_keys call of this build (the frame-tracker binding in place of the Reprojector) left
 static int g_tracker_ok = 0, g_tracker_pose_optimised = 0;
@@ -125,9 +130,14 @@ int ref_sparse_img_align_run_ex(int width, int height, double fx, double fy, dou
                              float* ref_patch_cache_out, double* jacobian_cache_out, uint8_t* visible_out,
                              double* scale_mu_out) {
   const bool fixed_work = g_fixed_work != 0;
-  HarnessPinhole cam(width, height, fx, fy, cx, cy);
-  HandFrame ref(&cam, ref_pyr, width, height, n_levels, T_ref_w);
-  HandFrame cur(&cam, cur_pyr, width, height, n_levels, T_cur_w_init);
+  HarnessPinhole plain(width, height, fx, fy, cx, cy);
+  void* hand = nullptr;
+  bool radtan = false;
+  for (int i = 0; i < 5; ++i) radtan = radtan || g_dist[i] != 0.0;
+  vk::AbstractCamera* camp = radtan ? make_hand_pinhole(width, height, fx, fy, cx, cy, g_dist, &hand) : &plain;
+  struct HandGuard { void* h; ~HandGuard() { if (h) free_hand_pinhole(h); } } guard = {hand};
+  HandFrame ref(camp, ref_pyr, width, height, n_levels, T_ref_w);
+  HandFrame cur(camp, cur_pyr, width, height, n_levels, T_cur_w_init);
   for (int i = 0; i < n; ++i) ref.add_feature(px + 2 * i, fv + 3 * i, 0, has_point[i] ? pos + 3 * i : nullptr);
   svo::FramePtr ref_frame = ref.ptr(), cur_frame = cur.ptr();
 

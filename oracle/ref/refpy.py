@@ -176,6 +176,14 @@ def _cam_args(cam):
     return (C.c_int(cam.width), C.c_int(cam.height), D(cam.fx), D(cam.fy), D(cam.cx), D(cam.cy))
 
 
+def _set_distortion(fp):
+    """radtan coefficients (fp.dist) of the camera of the next SparseImgAlign harness call: the reference's compiled
+    vk::PinholeCamera::world2cam on a hand-laid camera object; None / all zero: the distortion-free harness camera"""
+    d = getattr(fp, "dist", None) if fp is not None else None
+    d5 = f64(d if d is not None else np.zeros(5))
+    lib().ref_set_distortion(_p(d5, D))
+
+
 def sparse_img_align_run(fp, max_level=4, min_level=0, n_iter=30, T_cur_w_init=None, method=0, scale_estimator=0, weight_function=0):
     """method 0 GaussNewton / 1 LevenbergMarquardt, scale_estimator / weight_function: the reference's enums
     (nlls_solver.h:47-48), set through its own setRobustCostFunction."""
@@ -193,12 +201,14 @@ def sparse_img_align_run(fp, max_level=4, min_level=0, n_iter=30, T_cur_w_init=N
     jac = np.zeros((max(n, 1) * 16, 6))
     vis = np.zeros(max(n, 1), dtype=np.uint8)
     smn = np.zeros(3)
+    _set_distortion(fp)
     lib().ref_sparse_img_align_run_ex(*_cam_args(fp.cam), C.c_int(len(fp.ref_pyr)), rp, cp, C.c_int(n), _p(px, D), _p(f, D),
                                       _p(pos, D), _p(hp, C.c_uint8), _p(T_ref, D), _p(T_init, D), C.c_int(max_level),
                                       C.c_int(min_level), C.c_int(n_iter), C.c_int(method), C.c_int(scale_estimator),
                                       C.c_int(weight_function), _p(T_out, D), C.byref(nt), _p(H, D),
                                       C.byref(chi2), C.byref(stop), _p(iters, C.c_int), _p(n_meas, C.c_size_t),
                                       _p(cache, C.c_float), _p(jac, D), _p(vis, C.c_uint8), _p(smn, D))
+    _set_distortion(None)
     return {"scale": np.float32(smn[0]), "mu": smn[1], "nu": smn[2], "T_cur_w": T_out, "n_tracked": nt.value, "H": H, "chi2": chi2.value, "stop": stop.value, "iter": iters,
             "n_meas": n_meas, "ref_patch_cache": cache[:n], "jacobian_cache": jac[:n * 16], "visible": vis[:n]}
 
@@ -213,9 +223,11 @@ def sparse_img_align_fixed_work(fp, max_level=4, min_level=0, n_iter=30, T_cur_w
     T_init = f64(fp.T_cur_w_init if T_cur_w_init is None else T_cur_w_init)
     T_out, H = np.zeros(7), np.zeros(36)
     nt, chi2 = C.c_size_t(0), D(0)
+    _set_distortion(fp)
     lib().ref_sparse_img_align_run_fixed_work(*_cam_args(fp.cam), C.c_int(len(fp.ref_pyr)), rp, cp, C.c_int(len(px)), _p(px, D), _p(f, D),
                                               _p(pos, D), _p(hp, C.c_uint8), _p(T_ref, D), _p(T_init, D), C.c_int(max_level),
                                               C.c_int(min_level), C.c_int(n_iter), _p(T_out, D), C.byref(nt), _p(H, D), C.byref(chi2))
+    _set_distortion(None)
     return {"T_cur_w": T_out, "n_tracked": nt.value, "H": H, "chi2": chi2.value}
 
 

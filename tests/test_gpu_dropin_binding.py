@@ -44,7 +44,7 @@ def run_dropin(lib, fp, max_level, min_level, n_iter, method=0, scale_estimator=
     px, f, pos = (np.ascontiguousarray(a, dtype=np.float64) for a in (fp.px, fp.f, fp.pos))
     hp = np.ascontiguousarray(fp.has_point, dtype=np.uint8)
     T_ref, T_init = np.ascontiguousarray(fp.T_ref_w, dtype=np.float64), np.ascontiguousarray(fp.T_cur_w_init, dtype=np.float64)
-    d5 = np.zeros(5)
+    d5 = np.ascontiguousarray(getattr(fp, "dist", None) if getattr(fp, "dist", None) is not None else np.zeros(5), dtype=np.float64)   # a radtan vk::PinholeCamera
     T_out, fisher, smn = np.zeros(7), np.zeros(36), np.zeros(3)
     nt, chi2, stop = C.c_size_t(0), D(0), C.c_int(0)
     cam = fp.cam
