@@ -58,10 +58,29 @@ int dropin_sparse_img_align_run(int width, int height, double fx, double fy, dou
                                 const double* fv, const double* pos, const uint8_t* has_point, const double* T_ref_w,
                                 const double* T_cur_w_init, int max_level, int min_level, int n_iter, int method, int scale_estimator,
                                 int weight_function, double* T_cur_w_out, size_t* n_tracked, double* fisher36, double* chi2_out,
-                                int* stop_out, double* scale_mu_nu /*[3]*/) {
+                                int* stop_out, double* scale_mu_nu /*[3]*/, int row_pad) {
   HandPinhole cam(width, height, fx, fy, cx, cy, d5);
-  HandFrame ref(cam.cam, ref_pyr, width, height, n_levels, T_ref_w);
-  HandFrame cur(cam.cam, cur_pyr, width, height, n_levels, T_cur_w_init);
+  // row_pad > 0: the frames' cv::Mat levels are NOT continuous (step = cols + row_pad, the padding filled with noise): the
+  // bridge has to compact them before the upload
+  std::vector<std::vector<uint8_t> > padded;
+  std::vector<const uint8_t*> ref_p(n_levels), cur_p(n_levels);
+  for (int l = 0; l < n_levels; ++l) { ref_p[l] = ref_pyr[l]; cur_p[l] = cur_pyr[l]; }
+  if (row_pad > 0) {
+    for (int which = 0; which < 2; ++which)
+      for (int l = 0; l < n_levels; ++l) {
+        const int w = width >> l, h = height >> l, st = w + row_pad;
+        padded.push_back(std::vector<uint8_t>((size_t)st * h));
+        std::vector<uint8_t>& b = padded.back();
+        const uint8_t* src = which ? cur_pyr[l] : ref_pyr[l];
+        for (int y = 0; y < h; ++y) {
+          std::memcpy(&b[(size_t)y * st], src + (size_t)y * w, w);
+          for (int x = w; x < st; ++x) b[(size_t)y * st + x] = (uint8_t)(37 * x + 11 * y + 101 * l);
+        }
+        (which ? cur_p : ref_p)[l] = b.data();
+      }
+  }
+  HandFrame ref(cam.cam, ref_p.data(), width, height, n_levels, T_ref_w, row_pad);
+  HandFrame cur(cam.cam, cur_p.data(), width, height, n_levels, T_cur_w_init, row_pad);
   for (int i = 0; i < n; ++i) ref.add_feature(px + 2 * i, fv + 3 * i, 0, has_point[i] ? pos + 3 * i : nullptr);
   svo::FramePtr ref_frame = ref.ptr(), cur_frame = cur.ptr();
   void* storage = ::aligned_alloc(32, (sizeof(svo::SparseImgAlign) + 31) / 32 * 32);

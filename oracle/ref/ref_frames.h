@@ -18,7 +18,8 @@ struct HandFrame {
   svo::Frame* f = nullptr;
   std::vector<svo::Point*> points;
 
-  HandFrame(vk::AbstractCamera* cam, const uint8_t* const* pyr, int width, int height, int n_levels, const double* T_f_w) {
+  /// row_pad: extra bytes at the end of every row of the caller's level buffers (a cv::Mat that is not continuous)
+  HandFrame(vk::AbstractCamera* cam, const uint8_t* const* pyr, int width, int height, int n_levels, const double* T_f_w, int row_pad = 0) {
     storage = ::aligned_alloc(32, (sizeof(svo::Frame) + 31) / 32 * 32);
     std::memset(storage, 0, sizeof(svo::Frame));
     f = reinterpret_cast<svo::Frame*>(storage);
@@ -33,7 +34,7 @@ struct HandFrame {
     mats = ::aligned_alloc(32, (sizeof(cv::Mat) * n_levels + 31) / 32 * 32);
     cv::Mat* m = reinterpret_cast<cv::Mat*>(mats);
     for (int l = 0; l < n_levels; ++l)
-      fill_mat_header(&m[l], const_cast<uint8_t*>(pyr[l]), height >> l, width >> l, (size_t)(width >> l), CV_8UC1);
+      fill_mat_header(&m[l], const_cast<uint8_t*>(pyr[l]), height >> l, width >> l, (size_t)((width >> l) + row_pad), CV_8UC1);
     cv::Mat* rep[3] = {m, m + n_levels, m + n_levels};
     std::memcpy(static_cast<void*>(&f->img_pyr_), rep, sizeof(rep));
   }

@@ -39,7 +39,7 @@ def lib():
     return C.CDLL(LIB, mode=os.RTLD_LAZY)
 
 
-def run_dropin(lib, fp, max_level, min_level, n_iter, method=0, scale_estimator=0, weight_function=0):
+def run_dropin(lib, fp, max_level, min_level, n_iter, method=0, scale_estimator=0, weight_function=0, row_pad=0):
     rp, cp = orc.pyr_ptrs(fp.ref_pyr), orc.pyr_ptrs(fp.cur_pyr)
     px, f, pos = (np.ascontiguousarray(a, dtype=np.float64) for a in (fp.px, fp.f, fp.pos))
     hp = np.ascontiguousarray(fp.has_point, dtype=np.uint8)
@@ -52,7 +52,7 @@ def run_dropin(lib, fp, max_level, min_level, n_iter, method=0, scale_estimator=
                                          C.c_int(len(fp.ref_pyr)), rp, cp, C.c_int(len(px)), _p(px, D), _p(f, D), _p(pos, D), _p(hp, C.c_uint8),
                                          _p(T_ref, D), _p(T_init, D), C.c_int(max_level), C.c_int(min_level), C.c_int(n_iter), C.c_int(method),
                                          C.c_int(scale_estimator), C.c_int(weight_function), _p(T_out, D), C.byref(nt), _p(fisher, D),
-                                         C.byref(chi2), C.byref(stop), _p(smn, D))
+                                         C.byref(chi2), C.byref(stop), _p(smn, D), C.c_int(row_pad))
     assert rc == 0
     return {"T": T_out, "n_tracked": nt.value, "fisher": fisher, "chi2": chi2.value, "stop": stop.value, "scale": np.float32(smn[0]),
             "mu": smn[1], "nu": smn[2]}
@@ -80,6 +80,15 @@ def test_dropin_run_against_the_reference_run(lib, golden, case):
         H = g[name + "_H"] / (5e-4 * 255 * 255)
         assert np.abs(r["fisher"] - H).max() <= 1e-6 * np.abs(H).max()
         assert abs(r["chi2"] - float(g[name + "_chi2"])) <= 1e-4 * float(g[name + "_chi2"])
+
+
+def test_dropin_run_with_padded_image_rows(lib):
+    """cv::Mat levels that are not continuous (step = cols + 13, noise in the padding): the bridge compacts them before the
+    upload; the run is bit for bit the run on continuous images."""
+    fp = gen_golden.make_sia_case(dict(seed=12345, n_features=200))
+    a = run_dropin(lib, fp, 4, 0, 30)
+    b = run_dropin(lib, fp, 4, 0, 30, row_pad=13)
+    assert np.array_equal(a["T"], b["T"]) and a["chi2"] == b["chi2"] and a["n_tracked"] == b["n_tracked"] == 200
 
 
 NLLS = [("c0_200", (1, 0, 0)), ("c0_200", (0, 2, 2)), ("nulls_320", (1, 2, 3)), ("c1_2000", (1, 1, 1)), ("border_320", (0, 3, 1)), ("iters5", (1, 1, 2))]
