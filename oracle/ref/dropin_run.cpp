@@ -1,4 +1,5 @@
-// dropin_run.cpp -- RUNS the drop-in bindings include/svo_dropin/sparse_img_align_hip.cpp and pose_optimizer_hip.cpp on the reference's own types
+// dropin_run.cpp -- RUNS the drop-in bindings include/svo_dropin/sparse_img_align_hip.cpp, pose_optimizer_hip.cpp and
+// feature_alignment_hip.h on the reference's own types
 // (TEST INFRASTRUCTURE ONLY; built into oracle/_ref/libsvo_dropin_run.so by `make -C oracle dropin-run`, only where
 // /root/reference is mounted; the built library travels to the GPU box and is loaded by tests/test_gpu_dropin_binding.py).
 //
@@ -40,6 +41,7 @@
 
 #include "ref_common.h"
 #include "ref_frames.h"
+#include "feature_alignment_hip.h"   // include/svo_dropin: the batched align2D wrapper (header-only)
 
 using namespace refh;
 
@@ -142,6 +144,24 @@ int dropin_pose_optimize(int width, int height, double fx, double fy, double cx,
   for (int i = 0; i < n; ++i) has_point_inout[i] = fts[i]->point != nullptr ? 1 : 0;
   outputs4[0] = estimated_scale; outputs4[1] = error_init; outputs4[2] = error_final; outputs4[3] = (double)num_obs;
   return 0;
+}
+
+// feature_alignment::align2D_batch of include/svo_dropin/feature_alignment_hip.h on a real svo::Frame: n 10x10 reference
+// patches against pyramid level `level` of the frame's image, px in / out in level coordinates, convergence flags out.
+int dropin_align2d_batch(int width, int height, const uint8_t* img, int n, const uint8_t* ref_patch_with_border, int n_iter,
+                         double* px_inout, uint8_t* converged) {
+  const double d0[5] = {0, 0, 0, 0, 0}, T0[7] = {0, 0, 0, 0, 0, 0, 1};
+  HandPinhole cam(width, height, 100.0, 100.0, width / 2.0, height / 2.0, d0);
+  const uint8_t* levels[1] = {img};
+  HandFrame fr(cam.cam, levels, width, height, 1, T0);
+  static thread_local svo::hip_bridge::Context ctx(0);
+  static thread_local svo::hip_bridge::PyramidCache pyr(ctx.get(), 1);
+  std::vector<uint8_t> pwb(ref_patch_with_border, ref_patch_with_border + (size_t)n * 100);
+  std::vector<Eigen::Vector2d> px((size_t)n);
+  for (int i = 0; i < n; ++i) px[i] = Eigen::Vector2d(px_inout[2 * i], px_inout[2 * i + 1]);
+  const std::vector<bool> ok = svo::feature_alignment::align2D_batch(ctx, pyr, *fr.f, 0, pwb, n_iter, px);
+  for (int i = 0; i < n; ++i) { px_inout[2 * i] = px[i][0]; px_inout[2 * i + 1] = px[i][1]; converged[i] = ok[i] ? 1 : 0; }
+  return ctx.ok() ? 0 : -1;
 }
 
 }  // extern "C"

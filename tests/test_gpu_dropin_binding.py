@@ -91,6 +91,27 @@ def test_dropin_run_with_padded_image_rows(lib):
     assert np.array_equal(a["T"], b["T"]) and a["chi2"] == b["chi2"] and a["n_tracked"] == b["n_tracked"] == 200
 
 
+def test_dropin_align2d_batch_against_the_reference_fixture(lib, golden):
+    """feature_alignment::align2D_batch (feature_alignment_hip.h) on a real svo::Frame against feature_alignment::align2D of
+    the reference's own compiled code, patch by patch (tests/golden/align.npz): the flags equal, the pixels bit for bit."""
+    g = golden("align.npz")
+    cur = np.ascontiguousarray(g["cur"], dtype=np.uint8)
+    h, w = cur.shape
+    for budget in np.unique(g["n_iter"]):
+        sel = np.where(g["n_iter"] == budget)[0]
+        same_interior = np.array([np.array_equal(g["pwb"][i].reshape(10, 10)[1:9, 1:9].reshape(64), g["patch"][i]) for i in sel])
+        sel = sel[same_interior]                      # (the wrapper takes the bordered patch only: its interior is the 8x8 patch)
+        pwb = np.ascontiguousarray(g["pwb"][sel], dtype=np.uint8)
+        px = np.ascontiguousarray(g["px_in"][sel], dtype=np.float64).copy()
+        conv = np.zeros(len(sel), np.uint8)
+        assert lib.dropin_align2d_batch(C.c_int(w), C.c_int(h), _p(cur, C.c_uint8), C.c_int(len(sel)), _p(pwb, C.c_uint8), C.c_int(int(budget)),
+                                        _p(px, D), _p(conv, C.c_uint8)) == 0
+        np.testing.assert_array_equal(conv.astype(bool), g["ok"][sel].astype(bool))
+        want = g["px_out"][sel]
+        both_nan = np.isnan(px) & np.isnan(want)
+        assert ((px.view(np.uint64) == want.view(np.uint64)) | both_nan).all()
+
+
 NLLS = [("c0_200", (1, 0, 0)), ("c0_200", (0, 2, 2)), ("nulls_320", (1, 2, 3)), ("c1_2000", (1, 1, 1)), ("border_320", (0, 3, 1)), ("iters5", (1, 1, 2))]
 
 
