@@ -11,11 +11,51 @@
 #include <condition_variable>
 
 #include <svo/depth_filter.h>
+#include <svo/feature.h>
+#include <svo/feature_detection.h>
+#include <svo/frame.h>
+#include <svo/point.h>
 
 #include "depth_filter_batch.h"
 #include "svo_hip_bridge.h"
 
 namespace svo {
+
+namespace hip_bridge {
+/// Host policy of hip_bridge::DeviceSeedMirror on the reference's data model: how a Seed's feature, its keyframe, the frames'
+/// pyramids and poses are read, and what happens on the host when a seed converges (depth_filter.cpp:302-331).  What
+/// DepthFilterHip::updateSeeds hands to the mirror; tests/test_gpu_dropin_binding.py runs the mirror with it on real Seed /
+/// Feature / Frame objects.
+struct DepthFilterRefHost {
+  hip_bridge::PyramidCache* kf_pyr;
+  hip_bridge::PyramidCache* cur_pyr;
+  feature_detection::AbstractDetector* detector;
+  DepthFilter::callback_t* seed_converged_cb;
+
+  Frame* keyframeOf(const Seed& s) const { return s.ftr->frame; }
+  void feature(const Seed& s, double px[2], double f[3], int* level) const {
+    px[0] = s.ftr->px[0]; px[1] = s.ftr->px[1];
+    f[0] = s.ftr->f[0]; f[1] = s.ftr->f[1]; f[2] = s.ftr->f[2];
+    *level = s.ftr->level;
+  }
+  void pose7(const Frame& fr, double T[7]) const { hip_bridge::toPose7(fr.T_f_w_, T); }
+  bool keyframeSlots(const std::vector<Frame*>& kfs, std::vector<int>& slots) {
+    std::vector<const Frame*> c(kfs.begin(), kfs.end());
+    return kf_pyr->acquire(c, slots);
+  }
+  int currentSlot(Frame& fr) { return cur_pyr->slotOf(fr); }
+  svo_hip_pyramid* keyframePyramids() const { return kf_pyr->pyramid(); }
+  svo_hip_pyramid* currentPyramids() const { return cur_pyr->pyramid(); }
+  svo_hip_camera camera(const Frame& fr) const { return hip_bridge::toCamera(fr.cam_); }
+  bool isKeyframe(const Frame& fr) const { return fr.isKeyframe(); }
+  void setGridOccupancy(const double px_cur[2]) { detector->setGridOccpuancy(Vector2d(px_cur[0], px_cur[1])); }   // depth_filter.cpp:302-306
+  void converged(Seed& s, const double xyz[3]) {                                                                 // :310-331
+    Point* point = new Point(Vector3d(xyz[0], xyz[1], xyz[2]), s.ftr);
+    s.ftr->point = point;
+    (*seed_converged_cb)(point, s.sigma2);
+  }
+};
+}  // namespace hip_bridge
 
 class DepthFilterHip : public DepthFilter {
  public:

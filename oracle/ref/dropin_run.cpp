@@ -13,8 +13,10 @@
 // the fields set to what the inline base constructor (nlls_solver.h:96-116) and the drop-in's constructor body assign
 // (sparse_img_align_hip.cpp: its two cv::Mat members stay zeroed headers nothing touches).
 #include <cmath>
+#include <condition_variable>   // (I/depth_filter.h:148 relies on a transitive include of libc++; depth_filter_hip.h includes it first too)
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <list>
 #include <memory>
 #include <vector>
@@ -33,6 +35,7 @@
 #undef protected
 
 #include <svo/config.h>
+#include <svo/depth_filter.h>
 #include <svo/frame.h>
 #include <svo/feature.h>
 #include <svo/point.h>
@@ -42,6 +45,7 @@
 #include "ref_common.h"
 #include "ref_frames.h"
 #include "feature_alignment_hip.h"   // include/svo_dropin: the batched align2D wrapper (header-only)
+#include "depth_filter_hip.h"        // ... the depth filter binding's host policy + the device seed mirror it drives
 
 using namespace refh;
 
@@ -162,6 +166,86 @@ int dropin_align2d_batch(int width, int height, const uint8_t* img, int n, const
   const std::vector<bool> ok = svo::feature_alignment::align2D_batch(ctx, pyr, *fr.f, 0, pwb, n_iter, px);
   for (int i = 0; i < n; ++i) { px_inout[2 * i] = px[i][0]; px_inout[2 * i + 1] = px[i][1]; converged[i] = ok[i] ? 1 : 0; }
   return ctx.ok() ? 0 : -1;
+}
+
+// The depth filter binding's work on real Seed / Feature / Frame objects: hip_bridge::DeviceSeedMirror<std::list<Seed>> driven
+// with hip_bridge::DepthFilterRefHost (depth_filter_hip.h) -- what DepthFilterHip::updateSeeds does under its mutex -- for a
+// keyframe with n_seeds seeds over n_frames frames.  (DepthFilterHip itself cannot be instantiated here: its base class lives in
+// depth_filter.cpp, which needs the NDK's <android/log.h>; Seed's constructor too, so the seeds are laid out by hand with the
+// values depth_filter.cpp:36-45 assigns.)
+// Outputs: the seeds still in the list (id, a, b, mu, sigma2) in list order, the convergence callbacks in firing order
+// (seed id, point xyz, sigma2).
+int dropin_depth_filter_frames(int width, int height, double fx, double fy, double cx, double cy, const double* d5, int n_levels,
+                               const uint8_t* const* kf_pyr, const double* T_kf_w, int n_frames, const uint8_t* const* const* cur_pyr,
+                               const double* T_cur_w, int n_seeds, const double* seed_px, const double* seed_f, const int32_t* seed_level,
+                               double depth_mean, double depth_min, int n_pyr_levels, double* rows_out /*[n_seeds][5]*/, int* n_rows,
+                               double* conv_out /*[n_seeds][5]*/, int* n_conv) {
+  svo::Config::nPyrLevels() = (size_t)n_pyr_levels;
+  HandPinhole cam(width, height, fx, fy, cx, cy, d5);
+  HandFrame kf(cam.cam, kf_pyr, width, height, n_levels, T_kf_w);
+  kf.f->is_keyframe_ = true;
+  std::list<svo::Seed> seeds;
+  std::vector<svo::Feature*> fts;
+  for (int i = 0; i < n_seeds; ++i) {
+    svo::Feature* ftr = new svo::Feature(kf.f, Eigen::Vector2d(seed_px[2 * i], seed_px[2 * i + 1]),
+                                         Eigen::Vector3d(seed_f[3 * i], seed_f[3 * i + 1], seed_f[3 * i + 2]), seed_level[i]);
+    fts.push_back(ftr);
+    alignas(svo::Seed) unsigned char raw[sizeof(svo::Seed)];
+    std::memset(raw, 0, sizeof(raw));
+    svo::Seed& s0 = *reinterpret_cast<svo::Seed*>(raw);         // Seed::Seed(ftr, depth_mean, depth_min), depth_filter.cpp:36-45
+    s0.batch_id = 0; s0.id = i; s0.ftr = ftr;
+    const float dmean = (float)depth_mean, dmin = (float)depth_min;      // (the constructor's parameters are floats)
+    s0.a = 10; s0.b = 10;
+    s0.mu = 1.0 / dmean;
+    s0.z_range = 1.0 / dmin;
+    s0.sigma2 = s0.z_range * s0.z_range / 36;
+    seeds.push_back(s0);
+  }
+  struct Fired { int id; double xyz[3]; double sigma2; };
+  std::vector<Fired> fired;
+  std::vector<svo::Point*> made;
+  svo::DepthFilter::callback_t cb = [&](svo::Point* pt, double sigma2) {
+    Fired fd;
+    fd.id = -1;
+    for (int i = 0; i < n_seeds; ++i) if (fts[i]->point == pt) fd.id = i;
+    fd.xyz[0] = pt->pos_[0]; fd.xyz[1] = pt->pos_[1]; fd.xyz[2] = pt->pos_[2];
+    fd.sigma2 = sigma2;
+    fired.push_back(fd);
+    made.push_back(pt);
+  };
+  int rc = 0;
+  {
+    svo::hip_bridge::Context ctx(0);
+    svo::hip_bridge::PyramidCache kf_cache(ctx.get(), 8), cur_cache(ctx.get(), 2);
+    svo::hip_bridge::DeviceSeedMirror<std::list<svo::Seed> > mirror;
+    svo::hip_bridge::DepthFilterRefHost host;
+    host.kf_pyr = &kf_cache; host.cur_pyr = &cur_cache; host.detector = nullptr; host.seed_converged_cb = &cb;
+    svo_hip_df_params prm;
+    prm.n_pyr_levels = n_pyr_levels; prm.align_max_iter = 10; prm.max_epi_search_steps = 1000;
+    prm.seed_convergence_sigma2_thresh = svo::DepthFilter::Options().seed_convergence_sigma2_thresh;   // (I/depth_filter.h:78-87: 100)
+    const volatile bool halt = false;
+    if (!ctx.ok()) rc = -1;
+    for (int k = 0; k < n_frames && rc == 0; ++k) {
+      HandFrame cur(cam.cam, cur_pyr[k], width, height, n_levels, T_cur_w + 7 * k);
+      const svo::hip_bridge::SeedBatchStats st = mirror.update(host, ctx.get(), seeds, *cur.f, prm, /*Seed::batch_counter*/ 1, /*max_n_kfs*/ 3, halt);
+      if (st.n_device_errors) rc = -2;
+    }
+    if (rc == 0 && !mirror.syncToHost()) rc = -3;
+    mirror.clear();
+  }
+  *n_rows = 0;
+  for (const svo::Seed& s1 : seeds) {
+    double* r = rows_out + 5 * (*n_rows)++;
+    r[0] = s1.id; r[1] = s1.a; r[2] = s1.b; r[3] = s1.mu; r[4] = s1.sigma2;
+  }
+  *n_conv = (int)fired.size();
+  for (size_t i = 0; i < fired.size(); ++i) {
+    double* r = conv_out + 5 * i;
+    r[0] = fired[i].id; r[1] = fired[i].xyz[0]; r[2] = fired[i].xyz[1]; r[3] = fired[i].xyz[2]; r[4] = fired[i].sigma2;
+  }
+  for (svo::Point* p2 : made) delete p2;
+  for (svo::Feature* f2 : fts) delete f2;
+  return rc;
 }
 
 }  // extern "C"

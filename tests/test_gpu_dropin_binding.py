@@ -254,3 +254,73 @@ def test_frame_tracker_binding_on_a_real_map(tracker_lib, golden, tag, kw, max_f
         np.testing.assert_array_equal(pose, np.asarray(cs["T_cur_w"], dtype=np.float64))
     check_map_result(g, tag, r)
     np.testing.assert_array_equal(r["kf_key_point_after"], g[tag + "_kf_key_point_after"])
+
+
+def test_depth_filter_mirror_on_real_seeds(lib):
+    """hip_bridge::DeviceSeedMirror<std::list<svo::Seed>> driven with hip_bridge::DepthFilterRefHost -- the work of
+    DepthFilterHip::updateSeeds -- on the reference's own Seed / Feature / Frame / vk::PinholeCamera objects: 2500 seeds of one
+    keyframe over five frames.  Against the oracle's replay of the reference's loop (depth_filter.cpp:237-341): the convergence
+    callbacks fire for the same seeds in the same order with the same points, the seeds left in the list are the same ones in
+    the same order with the same state."""
+    from android_svo_amd import seedsynth
+    rng = np.random.default_rng(11)
+    cam = synth.Camera.default()
+    scene = synth.PlaneScene(seed=4, depth=2.0, tilt=(0.08, 0.05))
+    n_frames = 6
+    T0 = synth.se3_from_twist([0.02, -0.01, 0.0], [0.01, 0.005, -0.01])
+    direction = np.array([1.0, 0.3, 0.1]) / np.linalg.norm([1.0, 0.3, 0.1])
+    poses = [T0] + [synth.se3_mul(synth.se3_from_twist(direction * 0.035 * k, rng.uniform(-0.004, 0.004, 3)), T0) for k in range(1, n_frames)]
+    pyrs = [synth.build_pyramid(scene.render(cam, T)) for T in poses]
+    n_seeds = 2500
+    spx = np.floor(np.stack([rng.uniform(40, cam.width - 40, n_seeds), rng.uniform(40, cam.height - 40, n_seeds)], axis=1))
+    slevel = rng.choice([0, 0, 1, 2], n_seeds).astype(np.int32)
+    spx -= spx % (1 << slevel)[:, None]
+    sf = np.ascontiguousarray(synth.cam2world(cam, spx), dtype=np.float64)
+    X = scene.intersect(cam, poses[0], spx[:, 0], spx[:, 1])
+    zbar = float(np.median(np.linalg.norm(X - synth.se3_inv(poses[0])[:3], axis=1)))
+    depth_mean, depth_min = 1.1 * zbar, 0.5 * zbar
+
+    # ---- the oracle's replay of the list walk
+    a, b, mu, zr, s2 = seedsynth.seed_ctor(depth_mean, depth_min, n_seeds)
+    alive = np.ones(n_seeds, dtype=bool)
+    conv_expected = []
+    for k in range(1, n_frames):
+        idx = np.where(alive)[0]
+        aa, bb, mm, ss = (v[idx].copy() for v in (a, b, mu, s2))
+        res = orc.update_seeds(cam, pyrs[0], pyrs[k], poses[0], poses[k], spx[idx], sf[idx], slevel[idx], aa, bb, mm, zr[idx].copy(), ss)
+        a[idx], b[idx], mu[idx], s2[idx] = aa, bb, mm, ss
+        for j in np.where(res["status"] == 4)[0]:
+            conv_expected.append((int(idx[j]), res["xyz_world"][j], float(ss[j])))
+        alive[idx[(res["status"] == 4) | (res["status"] == 5)]] = False
+
+    # ---- the mirror on the reference's objects
+    kp = orc.pyr_ptrs(pyrs[0])
+    cps = (C.POINTER(C.POINTER(C.c_uint8)) * (n_frames - 1))()
+    keep = []
+    for k in range(1, n_frames):
+        pp = orc.pyr_ptrs(pyrs[k])
+        keep.append(pp)
+        cps[k - 1] = C.cast(pp, C.POINTER(C.POINTER(C.c_uint8)))
+    T_kf = np.ascontiguousarray(poses[0], dtype=np.float64)
+    T_cur = np.ascontiguousarray(np.stack(poses[1:]), dtype=np.float64)
+    px = np.ascontiguousarray(spx, dtype=np.float64)
+    rows, conv = np.zeros((n_seeds, 5)), np.zeros((n_seeds, 5))
+    n_rows, n_conv = C.c_int(0), C.c_int(0)
+    d5 = np.zeros(5)
+    rc = lib.dropin_depth_filter_frames(C.c_int(cam.width), C.c_int(cam.height), D(cam.fx), D(cam.fy), D(cam.cx), D(cam.cy), _p(d5, D), C.c_int(5),
+                                        kp, _p(T_kf, D), C.c_int(n_frames - 1), cps, _p(T_cur, D), C.c_int(n_seeds), _p(px, D), _p(sf, D),
+                                        _p(slevel, C.c_int32), D(depth_mean), D(depth_min), C.c_int(3), _p(rows, D), C.byref(n_rows),
+                                        _p(conv, D), C.byref(n_conv))
+    assert rc == 0
+    rows, conv = rows[:n_rows.value], conv[:n_conv.value]
+    assert 0.2 * n_seeds < len(conv_expected)                      # the sequence really converges a good part of the seeds
+    np.testing.assert_array_equal(conv[:, 0].astype(int), np.array([c[0] for c in conv_expected]))      # same seeds, same order
+    np.testing.assert_allclose(conv[:, 1:4], np.stack([c[1] for c in conv_expected]), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(conv[:, 4], np.array([c[2] for c in conv_expected]), rtol=1e-6)
+    np.testing.assert_array_equal(rows[:, 0].astype(int), np.where(alive)[0])
+    # the state of the seeds left: the oracle's f32 values bit for bit in (nearly) every seed
+    exact = (rows[:, 3] == mu[alive].astype(np.float64)) & (rows[:, 2] == b[alive].astype(np.float64)) & (rows[:, 4] == s2[alive].astype(np.float64)) & \
+        (rows[:, 1] == a[alive].astype(np.float64))
+    assert exact.mean() >= 0.999, exact.mean()
+    np.testing.assert_allclose(rows[:, 3], mu[alive], rtol=1e-5)
+    np.testing.assert_allclose(rows[:, 4], s2[alive], rtol=1e-5)
