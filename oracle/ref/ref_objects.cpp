@@ -19,6 +19,7 @@
 // vptr is pointed at the class's own vtable, cv::Mat headers get their public fields filled (as in
 // MatView), and the dozen driver statements of run() (:51-92) are performed here through the object's
 // own members.  Every arithmetic statement that produces a compared number is reference code.
+#include <algorithm>
 #include <cstdlib>
 #include <list>
 #include <memory>
@@ -70,6 +71,9 @@ extern "C" void ref_set_distortion(const double* d5) { for (int i = 0; i < 5; ++
 // what the last ref_reproject_map_keys call of this build (the frame-tracker binding in place of the Reprojector) left
 static int g_tracker_ok = 0, g_tracker_pose_optimised = 0;
 static double g_tracker_pose[7] = {0}, g_tracker_sfba[4] = {0};
+static int g_struct_n = 0;
+static double g_struct_max_diff = -1.0, g_struct_moved = 0.0;
+extern "C" int dropin_tracker_structure(double* max_diff, double* moved) { *max_diff = g_struct_max_diff; *moved = g_struct_moved; return g_struct_n; }
 extern "C" int dropin_tracker_last(double* pose7, double* sfba4, int* pose_optimised) {
   for (int i = 0; i < 7; ++i) pose7[i] = g_tracker_pose[i];
   for (int i = 0; i < 4; ++i) sfba4[i] = g_tracker_sfba[i];
@@ -542,6 +546,29 @@ int ref_reproject_map_keys(int width, int height, double fx, double fy, double c
     g_tracker_sfba[0] = (double)oc.sfba_n_edges_final; g_tracker_sfba[1] = oc.sfba_thresh; g_tracker_sfba[2] = oc.sfba_error_init;
     g_tracker_sfba[3] = oc.sfba_error_final;
     from_se3(frame->T_f_w_, g_tracker_pose);
+    // FrameHandlerBase::optimizeStructure (frame_handler_base.cpp:190-210) through the binding -- the frame's points refined on
+    // the device, positions written back into Point::pos_ -- against the reference's compiled Point::optimize (point.o) run on
+    // the very same objects from the very same start
+    std::vector<svo::Point*> fpts;
+    for (svo::Feature* ftr : frame->fts_)
+      if (ftr->point != nullptr && std::find(fpts.begin(), fpts.end(), ftr->point) == fpts.end()) fpts.push_back(ftr->point);
+    std::vector<Eigen::Vector3d> start;
+    for (svo::Point* pt : fpts) start.push_back(pt->pos_);
+    g_struct_n = (int)fpts.size();
+    g_struct_max_diff = -1.0;
+    if (g_tracker_ok && !fpts.empty() && tracker.optimiseStructure(frame, *map, fpts.size(), 5)) {
+      std::vector<Eigen::Vector3d> dev;
+      for (svo::Point* pt : fpts) dev.push_back(pt->pos_);
+      g_struct_max_diff = 0.0;
+      g_struct_moved = 0.0;
+      for (size_t i = 0; i < fpts.size(); ++i) {
+        fpts[i]->pos_ = start[i];
+        fpts[i]->optimize(5);                                        // the reference's own
+        g_struct_max_diff = std::max(g_struct_max_diff, (fpts[i]->pos_ - dev[i]).cwiseAbs().maxCoeff());
+        g_struct_moved = std::max(g_struct_moved, (fpts[i]->pos_ - start[i]).cwiseAbs().maxCoeff());
+        fpts[i]->pos_ = start[i];                                    // (the outputs below are those of the tracking call)
+      }
+    }
   }
 #else
   svo::Reprojector* rp = new svo::Reprojector(&cam, *map);

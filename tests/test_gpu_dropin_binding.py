@@ -254,6 +254,11 @@ def test_frame_tracker_binding_on_a_real_map(tracker_lib, golden, tag, kw, max_f
         np.testing.assert_array_equal(pose, np.asarray(cs["T_cur_w"], dtype=np.float64))
     check_map_result(g, tag, r)
     np.testing.assert_array_equal(r["kf_key_point_after"], g[tag + "_kf_key_point_after"])
+    # FrameHandlerBase::optimizeStructure through the binding (FrameTracker::optimiseStructure: the frame's points refined on
+    # the device) against the reference's compiled Point::optimize on the same objects from the same start: bit for bit
+    diff, moved = D(0), D(0)
+    n_pts = tracker_lib.dropin_tracker_structure(C.byref(diff), C.byref(moved))
+    assert n_pts >= 30 and diff.value == 0.0 and moved.value > 1e-6, (n_pts, diff.value, moved.value)
 
 
 def test_depth_filter_mirror_on_real_seeds(lib):
