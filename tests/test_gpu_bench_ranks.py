@@ -71,8 +71,9 @@ def test_bench_c4_gpus_2_started_plainly():
 def test_default_bench_line_fits_the_drivers_tail_and_carries_the_contract():
     """`python bench.py` as the driver runs it (N = 1, every secondary section on): ONE JSON line of at most 6 KiB (round 3's 14 kB
     line lost its first half in the driver's tail), with the contract keys, `roofline` and `cpu_baseline` objects, the per-stage
-    bounds of the depth filter and the drop-in entry's timing.  (The one GPU test whose process maps oracle/_ref/libsvo_ref.so:
-    bench.py's `cpu_baseline` / `c0` legs time the reference's own compiled SparseImgAlign where the prebuilt library is present.)"""
+    bounds of the depth filter and the drop-in entry's timing.  (One of the two places where a process on the GPU box maps reference object code: bench.py's `cpu_baseline` / `c0` legs
+    time the reference's own compiled SparseImgAlign where the prebuilt oracle/_ref/libsvo_ref.so is present; the other is
+    tests/test_gpu_dropin_binding.py, which RUNS the drop-in bindings against the reference's own types.)"""
     d_line = None
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True,
