@@ -71,6 +71,8 @@ extern "C" void ref_set_distortion(const double* d5) { for (int i = 0; i < 5; ++
 // what the last ref_reproject_map_keys call of this build (the frame-tracker binding in place of the Reprojector) left
 static int g_tracker_ok = 0, g_tracker_pose_optimised = 0;
 static double g_tracker_pose[7] = {0}, g_tracker_sfba[4] = {0};
+static double g_second[8] = {0};      // second frame: ok, SparseImgAlign's tracked count, last-frame features with a point, matches, |pose change|, refined
+extern "C" void dropin_tracker_second(double* out8) { for (int i = 0; i < 8; ++i) out8[i] = g_second[i]; }
 static int g_struct_n = 0;
 static double g_struct_max_diff = -1.0, g_struct_moved = 0.0;
 extern "C" int dropin_tracker_structure(double* max_diff, double* moved) { *max_diff = g_struct_max_diff; *moved = g_struct_moved; return g_struct_n; }
@@ -534,9 +536,10 @@ int ref_reproject_map_keys(int width, int height, double fx, double fy, double c
   // at the pose the fixture was recorded at (SparseImgAlign::run returns at once, :55-59), then track().  The binding flattens
   // this svo::Map, runs the chain on the GPU and applies the outcome to these objects with the reference's own functions.
   svo::Reprojector* rp = nullptr;
+  svo::hip_bridge::FrameTracker* tracker_p = new svo::hip_bridge::FrameTracker(&cam, n_kf > 0 ? n_kf : 1);
   {
     HandFrame last(&cam, cur_pyr, width, height, n_levels, T_cur_w);
-    svo::hip_bridge::FrameTracker tracker(&cam, n_kf > 0 ? n_kf : 1);
+    svo::hip_bridge::FrameTracker& tracker = *tracker_p;
     svo::hip_bridge::FrameTracker::Outcome oc;
     std::memset(&oc, 0, sizeof(oc));
     g_tracker_ok = tracker.ok() && tracker.track(last.ptr(), frame, *map, overlap, oc) ? 1 : 0;
@@ -612,6 +615,47 @@ int ref_reproject_map_keys(int width, int height, double fx, double fy, double c
     feat_grad[2 * nf] = ftr->grad[0]; feat_grad[2 * nf + 1] = ftr->grad[1];
     ++nf;
   }
+#ifdef REF_RUN_TRACKER_BINDING
+  // A SECOND frame through the same tracker object, with the frame just tracked as the last frame: its features and their
+  // points are the alignment's reference now (the hand-over inside the binding).  The image is the same and the pose starts
+  // where the last frame's ended, so the alignment must use every last-frame feature that has a point and leave the pose
+  // where it is; the reprojection runs again on the map as the first call left it.
+  // (The image differs from the last one in the lowest bit of every 13th pixel: with the very same image every residual is
+  // exactly 0, the update is exactly 0 and SE3::exp returns the NaN translation the reference's own exp returns for a zero
+  // rotation -- SURVEY 8a-11, reproduced by the device -- which is not what this check is after.)
+  {
+    double T_last[7];
+    from_se3(frame->T_f_w_, T_last);
+    std::vector<std::vector<uint8_t> > second_img((size_t)n_levels);
+    std::vector<const uint8_t*> second_pyr((size_t)n_levels);
+    for (int l = 0; l < n_levels; ++l) {
+      const size_t npx = (size_t)(width >> l) * (size_t)(height >> l);
+      second_img[l].assign(cur_pyr[l], cur_pyr[l] + npx);
+      for (size_t i = (size_t)l; i < npx; i += 13) second_img[l][i] ^= 1;
+      second_pyr[l] = second_img[l].data();
+    }
+    HandFrame second(&cam, second_pyr.data(), width, height, n_levels, T_last);
+    svo::FramePtr f2 = second.ptr();
+    std::vector<std::pair<svo::FramePtr, std::size_t> > ov2;
+    svo::hip_bridge::FrameTracker::Outcome o2;
+    std::memset(&o2, 0, sizeof(o2));
+    size_t with_point = 0;
+    for (svo::Feature* ftr : frame->fts_) with_point += ftr->point != nullptr ? 1 : 0;
+    g_second[0] = tracker_p->track(frame, f2, *map, ov2, o2) ? 1.0 : 0.0;
+    g_second[1] = (double)o2.img_align_n_tracked;
+    g_second[2] = (double)with_point;
+    g_second[3] = (double)o2.repr_n_matches;
+    double T2[7];
+    from_se3(f2->T_f_w_, T2);
+    double dmax = 0.0;
+    for (int i = 0; i < 7; ++i) dmax = std::max(dmax, std::fabs(T2[i] - T_last[i]));
+    g_second[4] = dmax;
+    g_second[5] = o2.pose_optimised ? 1.0 : 0.0;
+    g_second[6] = (double)o2.repr_n_trials;
+    g_second[7] = (double)ov2.size();
+  }
+  delete tracker_p;
+#endif
   // tear down.  Candidate points and their features belong to the map (MapPointCandidates::reset / its trash delete them);
   // deleted map points sit in the map's trash; the other points are ours; keyframe features die with their HandFrame.
   delete rp;

@@ -259,6 +259,14 @@ def test_frame_tracker_binding_on_a_real_map(tracker_lib, golden, tag, kw, max_f
     diff, moved = D(0), D(0)
     n_pts = tracker_lib.dropin_tracker_structure(C.byref(diff), C.byref(moved))
     assert n_pts >= 30 and diff.value == 0.0 and moved.value > 1e-6, (n_pts, diff.value, moved.value)
+    # a second frame through the same tracker object, the frame just tracked being the last frame now (its features and points
+    # are the alignment's reference: the hand-over inside the binding); the same view (lowest bit of every 13th pixel flipped),
+    # the pose starting where the last ended
+    sec = np.zeros(8)
+    tracker_lib.dropin_tracker_second(_p(sec, D))
+    assert sec[0] == 1.0 and sec[3] >= 0.8 * n_feat and sec[6] >= sec[3] and sec[7] >= 1, sec
+    assert 0 < sec[1] <= sec[2] and sec[1] >= 0.9 * sec[2], sec      # SparseImgAlign used (nearly) every last-frame feature that has a point
+    assert sec[4] < 5e-2, sec                                        # the same view: the pose stays within what the refinement of the new matches moves it (1.6e-2 with 41 matches)
 
 
 def test_depth_filter_mirror_on_real_seeds(lib):
