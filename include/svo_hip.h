@@ -194,7 +194,9 @@ int svo_hip_sia_run_sharded(svo_hip_sia* sia, svo_hip_comm* comm, int n_slots, c
 int svo_hip_sia_set_sharded_graph(svo_hip_sia* sia, int enable);
 
 /* run(): the whole coarse-to-fine solve for slots [0, n_slots), enqueued on the stream with no
- * host round trip.  Poses restart from the uploaded initial poses on every call. */
+ * host round trip (the default, Gauss-Newton; with SVO_HIP_SIA_OPT_METHOD / _SCALE_ESTIMATOR / _CHI2 set the call looks
+ * at the frames' state between rounds of evaluations and so waits for the device: see those options).  Poses restart
+ * from the uploaded initial poses on every call. */
 int svo_hip_sia_run(svo_hip_sia* sia, int n_slots, const svo_hip_sia_params* prm);
 /* blocks until the stream is idle, then copies the result of one slot */
 int svo_hip_sia_download(svo_hip_sia* sia, int slot, svo_hip_sia_result* out);
