@@ -1,3 +1,5 @@
+"""Time svo_hip_ordered_sum_f32_dev (android_svo_amd/csrc/svo_ordered_sum.h: the in-order f32 sum by a workgroup) for a range of
+lengths, 50 launches each, and check the result against the scalar loop.  GPU box: python tools/ordered_sum_probe.py"""
 import sys, time, ctypes as C
 import numpy as np
 sys.path.insert(0, '/root/repo')

@@ -1,3 +1,6 @@
+"""6000 random non-negative f32 sequences (lengths 1 .. 120 000; magnitudes over up to 60 binades, zeros, mantissas cut to a few
+bits, spikes) through svo_hip_ordered_sum_f32_dev against numpy's left-to-right f32 accumulate; prints the number of mismatches.
+GPU box: python tools/ordered_sum_stress.py [seed]"""
 import sys, numpy as np
 sys.path.insert(0, '/root/repo')
 from android_svo_amd import hip
