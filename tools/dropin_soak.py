@@ -2,7 +2,8 @@
 switch frame size, camera model, padded / continuous images and solver branch from call to call; every repeat of a configuration
 must be bit-equal and the process must not grow.  python tools/dropin_soak.py"""
 import sys, os, ctypes as C, numpy as np, psutil, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import test_gpu_dropin_binding as T
 from oracle import gen_golden
 lib = C.CDLL(T.LIB, mode=os.RTLD_LAZY)

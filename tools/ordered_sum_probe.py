@@ -2,7 +2,7 @@
 lengths, 50 launches each, and check the result against the scalar loop.  GPU box: python tools/ordered_sum_probe.py"""
 import sys, time, ctypes as C
 import numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from android_svo_amd import hip
 ctx = hip.Context(0)
 rng = np.random.default_rng(1)

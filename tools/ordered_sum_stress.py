@@ -2,7 +2,7 @@
 bits, spikes) through svo_hip_ordered_sum_f32_dev against numpy's left-to-right f32 accumulate; prints the number of mismatches.
 GPU box: python tools/ordered_sum_stress.py [seed]"""
 import sys, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from android_svo_amd import hip
 ctx = hip.Context(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
