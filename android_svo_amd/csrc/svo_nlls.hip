@@ -548,7 +548,7 @@ struct svo_nlls_ext {
   int* pending_dev = nullptr;
   int cap_slots = 0;
   size_t cap_patches = 0;
-  bool ran = false;
+  int ran_slots = 0;               // frames of the last completed run (what svo_hip_sia_solver_state may read)
 };
 
 void svo_nlls_free(svo_nlls_ext* e) {
@@ -568,12 +568,18 @@ int nlls_reserve(svo_hip_ctx* ctx, svo_nlls_ext** slot, int n_slots, int max_n) 
     *slot = new (std::nothrow) svo_nlls_ext();
     if (!*slot) return SVO_HIP_ERR_NOMEM;
     (*slot)->ctx = ctx;
+  }
+  if (!(*slot)->pending_dev) {                               // (both pointers or neither: a failure half way leaves neither)
     void* h = nullptr;
     SVO_CHECK_HIP(ctx, hipHostMalloc(&h, sizeof(int), hipHostMallocMapped));
+    void* d = nullptr;
+    const hipError_t err = hipHostGetDevicePointer(&d, h, 0);
+    if (err != hipSuccess || !d) {
+      (void)hipHostFree(h);
+      SVO_CHECK_HIP(ctx, err != hipSuccess ? err : hipErrorInvalidValue);
+    }
     ++ctx->n_allocs;
     (*slot)->pending_host = (int*)h;
-    void* d = nullptr;
-    SVO_CHECK_HIP(ctx, hipHostGetDevicePointer(&d, h, 0));
     (*slot)->pending_dev = (int*)d;
   }
   svo_nlls_ext* e = *slot;
@@ -627,6 +633,7 @@ int svo_nlls_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int
   const bool weights = scale_estimator != SVO_HIP_SIA_SCALE_UNIT;
   const bool lm = method == SVO_HIP_SIA_METHOD_LEVENBERG_MARQUARDT;
   svo_nlls_ext** slot = svo_sia_nlls_slot(s);
+  if (*slot) (*slot)->ran_slots = 0;
   svo_sia_view v;
   svo_hip_ctx* ctx = nullptr;
   int chunks = 1, tpw = 1;
@@ -681,13 +688,14 @@ int svo_nlls_run(svo_hip_sia* s, int n_slots, const svo_hip_sia_params* prm, int
       if (*(volatile int*)e->pending_host == 0) break;
     }
   }
-  if (*slot) (*slot)->ran = true;
-  return svo_hip_sia_finish(s);
+  rc = svo_hip_sia_finish(s);
+  if (*slot) (*slot)->ran_slots = rc == SVO_HIP_OK ? n_slots : 0;
+  return rc;
 }
 
 int svo_nlls_scale(svo_hip_sia* s, int slot, float* scale, double* mu, double* nu) {
   svo_nlls_ext** p = svo_sia_nlls_slot(s);
-  if (!p || !*p || !(*p)->ran || slot < 0 || slot >= (*p)->cap_slots) return SVO_HIP_ERR_STATE;
+  if (!p || !*p || slot < 0 || slot >= (*p)->ran_slots) return SVO_HIP_ERR_STATE;
   NllsExt h;
   int rc = svo_hip_memcpy_d2h((*p)->ctx, &h, (*p)->ext + slot, sizeof(h));      // (waits for the context's stream)
   if (rc != SVO_HIP_OK) return rc;

@@ -303,7 +303,7 @@ int svo_hip_sia_set_option(svo_hip_sia* sia, int option, int value);
  * SVO_HIP_SIA_CHI2_REFERENCE_ORDER, Levenberg-Marquardt and the robust costs use. */
 int svo_hip_ordered_sum_f32_dev(svo_hip_ctx* ctx, const float* vals_dev, size_t n, float* out_dev);
 /* scale_, mu_ and nu_ of one slot as the last svo_hip_sia_run with Levenberg-Marquardt or a robust cost left them
- * (blocks until the stream is idle; SVO_HIP_ERR_STATE when no such run has been made) */
+ * (blocks until the stream is idle; SVO_HIP_ERR_STATE when no such run has been made or `slot` was not one of its frames) */
 int svo_hip_sia_solver_state(svo_hip_sia* sia, int slot, float* scale, double* mu, double* nu);
 
 /* Which implementation the last svo_hip_sia_run used: 1 = the fused kernel (one workgroup per frame pair,

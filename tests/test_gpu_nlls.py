@@ -284,6 +284,8 @@ def test_one_solver_with_a_growing_number_of_slots(ctx):
             r, st = sia.download(i), sia.solver_state(i)
             key = ([float(v).hex() for v in r.T_cur_w], r.chi2, list(r.iters), st)
             assert seen.setdefault(i, key) == key, (n_slots, i)
+        with pytest.raises(hip.SvoHipError):                 # not a frame of that run (its record may be an older run's)
+            sia.solver_state(n_slots)
     sia.set_method(hip.SIA_METHOD_GAUSS_NEWTON)
     sia.set_robust_cost_function(hip.SIA_SCALE_UNIT, hip.SIA_WEIGHT_UNIT)
     sia.run(6, prm)
