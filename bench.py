@@ -174,7 +174,7 @@ def cpu_baseline(fps, n_iter=30, early_stop=False, frames_per_thread=16):
                      (best["frames"], len(fps[0].px), "early stop" if early_stop else "30 GN evaluations/level fixed work",
                       best["threads"], best["seconds"], 1.0 / single)}
     if use_ref and not early_stop:
-        out["driver"] = "harness loop of 30 evaluations/level around the reference's compiled computeResiduals/solve/update"
+        out["driver"] = "harness loop around the reference's compiled computeResiduals/solve/update"   # (30 per level: profiles/BENCH_KEYS.md)
     return out
 
 
